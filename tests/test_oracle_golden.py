@@ -1,0 +1,173 @@
+"""Pins oracle/ref_cpu.py against vectors produced by the real reference (tools/gen_golden.py). CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu as O
+
+torch.set_num_threads(8)
+TOL = 2e-6   # oracle and reference run the same ATen CPU kernels; observed agreement is ~1e-7
+
+
+def stats(t):
+    t = t.detach().double()
+    return torch.tensor([t.sum().item(), t.norm().item(), t.abs().max().item()], dtype=torch.float64)
+
+
+def check_stats(solver, expect, what="grad", rtol=2e-4, skip=()):
+    bad = []
+    for k, m in solver.model.items():
+        for n, p in m.named_parameters():
+            key = f"{k}/{n}"
+            e = expect[key]
+            t = p.grad if what == "grad" else p
+            if e is None:
+                assert t is None, key
+                continue
+            if key in skip:
+                continue
+            s = stats(t)
+            scale = max(float(e[1]), 1e-12)       # compare sum / norm / absmax relative to the tensor's norm
+            if not torch.all((s - e).abs() <= rtol * scale + 1e-9):
+                bad.append((key, s.tolist(), e.tolist()))
+    assert not bad, bad[:5]
+
+
+def test_seed0_init_is_bit_identical(golden_sd):
+    torch.manual_seed(0)
+    nets = O.build_networks()
+    for k in O.NET_NAMES:
+        sd = nets[k].state_dict()
+        assert list(sd.keys()) == list(golden_sd[k].keys())
+        for n, t in sd.items():
+            assert torch.equal(t, golden_sd[k][n]), (k, n)
+
+
+def test_case_A_standard_training(golden_cases, golden_sd):
+    A = golden_cases["A_standard"]
+    s = O.OracleSolver(state_dicts=golden_sd)
+    s.reset_all_optimizers()
+    std = s.standard_training(A["clean"], A["label"], A["noisy"])
+    (std[0] + std[1] + std[2] + std[3]).backward()
+    got = torch.tensor([float(v) for v in std], dtype=torch.float64)
+    assert torch.allclose(got, A["losses"], atol=TOL, rtol=0)
+    assert torch.allclose(s.z_i, A["z_i"], atol=TOL) and torch.allclose(s.z_s, A["z_s"], atol=TOL)
+    check_stats(s, A["grad_stats"])
+    for key, g in A["grads"].items():
+        k, n = key.split("/")
+        mine = dict(s.model[k].named_parameters())[n].grad
+        assert torch.allclose(mine, g, atol=1e-6 + 1e-4 * g.abs().max().item()), key
+    for key, b in A["buffers_after"].items():
+        k, n = key.split("/")
+        mine = dict(s.model[k].named_buffers())[n]
+        assert torch.allclose(mine.double(), b.double(), atol=1e-6), key
+
+
+def test_case_B_masking(golden_cases, golden_sd):
+    A, B = golden_cases["A_standard"], golden_cases["B_masking"]
+    s = O.OracleSolver(state_dicts=golden_sd)
+    O.set_grad(s.model["segmentation_decoder"], False)
+    O.set_grad(s.model["image_decoder"], False)
+    for name, fn, z, dec, lab, loss_type in [
+        ("channel_mse", O.mask_latent_code_channel_wise, A["z_i"], "image_decoder", A["clean"], "mse"),
+        ("spatial_mse", O.mask_latent_code_spatial_wise, A["z_i"], "image_decoder", A["clean"], "mse"),
+        ("channel_ce", O.mask_latent_code_channel_wise, A["z_s"], "segmentation_decoder", A["label"], "ce"),
+        ("spatial_ce", O.mask_latent_code_spatial_wise, A["z_s"], "segmentation_decoder", A["label"], "ce"),
+    ]:
+        for pct in (0.5, 0.2):
+            masked, mask = fn(z, s.model[dec], lab, num_classes=4, percentile=pct, random=False, loss_type=loss_type,
+                              if_detach=True, if_soft=False)
+            e = B[f"{name}_p{pct}"]
+            assert torch.equal(mask, e["mask"]), (name, pct)          # selection is integer-exact
+            assert torch.equal(masked, e["masked"]), (name, pct)
+            L = mask.numel() // mask.shape[0]
+            assert int((mask.reshape(mask.shape[0], -1) == 0).sum(1).unique().item()) == int(L * pct)
+        torch.manual_seed(77)
+        masked, mask = fn(z, s.model[dec], lab, num_classes=4, percentile=0.3, random=False, loss_type=loss_type,
+                          if_detach=True, if_soft=True)
+        e = B[f"{name}_soft_seed77"]
+        assert torch.equal(mask, e["mask"]) and torch.equal(masked, e["masked"]), name
+        soft = mask[mask != 1]
+        assert soft.numel() > 0 and float(soft.max()) < 0.5 and float(soft.min()) >= 0
+    for key, b in B["buffers_after"].items():
+        k, n = key.split("/")
+        assert torch.allclose(dict(s.model[k].named_buffers())[n].double(), b.double(), atol=1e-6), key
+
+
+def _overrides(rec, cfgs):
+    """Turn the draws recorded from the reference into the oracle's override dicts."""
+    ovs, draws, noises, keeps = [], list(rec["rand_draws"]), list(rec["soft_noises"]), list(rec["dropout_keeps"])
+    for cfg, code_shape in zip(cfgs, (rec["z_i"].shape, rec["z_s"].shape)):
+        ov = {}
+        if cfg["mask_type"] == "dropout":
+            ov["keep"] = keeps.pop(0)
+        else:
+            L = code_shape[1] if cfg["mask_type"] == "channel" else code_shape[2] * code_shape[3]
+            if cfg["random_threshold"]:
+                ov["k"] = int(L * (draws.pop(0) * cfg["max_threshold"]))
+            if cfg["if_soft"]:
+                ov["soft_noise"] = noises.pop(0)
+        ovs.append(ov)
+    return ovs
+
+
+@pytest.mark.parametrize("case", ["C_step_channel_spatial", "D_step_dropout", "E_step_soft_random"])
+def test_full_cooperative_step(golden_cases, golden_sd, case):
+    C = golden_cases[case]
+    s = O.OracleSolver(state_dicts=golden_sd)
+    ov_img, ov_seg = _overrides(C, (C["img_cfg"], C["seg_cfg"]))
+    losses = s.cooperative_step(C["clean"], C["label"], C["noisy"], C["img_cfg"], C["seg_cfg"],
+                                image_override=ov_img, seg_override=ov_seg)
+    assert torch.allclose(torch.tensor(losses, dtype=torch.float64), C["losses"], atol=5e-6, rtol=0), (losses, C["losses"])
+    assert torch.equal(s.last_masks["image"], C["masks"][0])
+    assert torch.equal(s.last_masks["seg"], C["masks"][1])
+    check_stats(s, C["grad_stats"])
+    for key, g in C["grads"].items():
+        k, n = key.split("/")
+        mine = dict(s.model[k].named_parameters())[n].grad
+        assert torch.allclose(mine, g, atol=1e-6 + 2e-4 * g.abs().max().item()), key
+    for key, b in C["buffers_after"].items():
+        k, n = key.split("/")
+        assert torch.allclose(dict(s.model[k].named_buffers())[n].double(), b.double(), atol=2e-6), key
+    # post-Adam weights: Adam's first step is sign-like (lr*g/|g|), so a conv bias that feeds a training-mode BN
+    # (true gradient 0, observed gradient = rounding noise) moves by +-lr in a noise-decided direction.
+    # Compare every parameter with atol 2*lr + tiny.
+    for key, p in C["params_after"].items():
+        k, n = key.split("/")
+        mine = dict(s.model[k].named_parameters())[n]
+        assert torch.allclose(mine, p, atol=2.1e-4), key
+
+
+def test_case_F_predict(golden_cases, golden_sd):
+    F_ = golden_cases["F_predict"]
+    s = O.OracleSolver(state_dicts=golden_sd)
+    with torch.no_grad():
+        for i in range(3):
+            c_, l_, n_ = O.synthetic_batch(2, 64, 64, seed=10 + i, structured=True)
+            s.standard_training(c_, l_, n_)
+    p1, p2 = s.predict(F_["vol"], n_iter=1), s.predict(F_["vol"], n_iter=2)
+    assert torch.allclose(p1, F_["logits_n1"], atol=1e-5) and torch.allclose(p2, F_["logits_n2"], atol=1e-5)
+    for p, key in ((p1, "argmax_n1"), (p2, "argmax_n2")):
+        top2 = p.topk(2, dim=1)[0]
+        safe = (top2[:, 0] - top2[:, 1]) > 1e-3
+        assert torch.equal(p.max(1)[1].to(torch.uint8)[safe], F_[key][safe])      # integer label maps bit-exact
+    assert torch.allclose(s.predict(F_["vol"], n_iter=3), p2)                     # refinement re-feeds FTN logits
+
+
+def test_case_G_bs16_256_checksum(golden_cases, golden_sd):
+    G = golden_cases["G_bs16_256_fwd"]
+    s = O.OracleSolver(state_dicts=golden_sd)
+    c, l, n = O.synthetic_batch(16, 256, 256, seed=0)
+    with torch.no_grad():
+        st = s.standard_training(c, l, n)
+    assert torch.allclose(torch.tensor([float(v) for v in st], dtype=torch.float64), G["losses"], atol=5e-6)
+    assert torch.allclose(stats(s.z_i), G["z_i_stats"], rtol=1e-5) and torch.allclose(stats(s.z_s), G["z_s_stats"], rtol=1e-5)
+
+
+def test_dice_and_hist():
+    a = np.array([[0, 1, 1], [2, 2, 0]])
+    b = np.array([[0, 1, 0], [2, 1, 0]])
+    assert O.dice(a == 1, b == 1) == pytest.approx(2 * 1 / (2 + 2))
+    assert np.isnan(O.dice(a == 3, b == 3))
+    h = O.confusion_hist(a, b, 3)
+    assert h.sum() == 6 and h[1, 1] == 1 and h[1, 0] == 1 and h[2, 1] == 1
