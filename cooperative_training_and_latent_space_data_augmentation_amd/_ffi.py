@@ -1,0 +1,133 @@
+"""ctypes binding of libctl_hip.so (include/ctl_hip.h).  There is NO fallback: if the HIP library is missing or a call
+fails, the product path raises -- it never routes through PyTorch ops or the CPU oracle."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libctl_hip.so")
+
+# enums of ctl_hip.h
+IN_PLAIN, IN_UP2, IN_ZINS2 = 0, 1, 2
+ACT_NONE, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2
+EPI_BIAS, EPI_ACCUM, EPI_RES, EPI_STATS = 1, 2, 4, 8
+RED_BLOCKS = 512
+(OP_CONV, OP_WGRAD, OP_WGRAD_REDUCE, OP_PACK, OP_BN_FINALIZE, OP_BN_EVAL, OP_BN_ACT, OP_BWD_REDUCE, OP_BN_BWD_FINALIZE,
+ OP_BWD_APPLY, OP_CHAN_SUM_FINALIZE, OP_SUMPOOL2, OP_SIGMOID_BWD, OP_ZERO) = range(1, 15)
+OP_MAX_T = 12
+
+CONV_DTYPE = np.dtype([
+    ("n", "<i4"), ("hin", "<i4"), ("win", "<i4"), ("cin", "<i4"), ("hout", "<i4"), ("wout", "<i4"), ("cout", "<i4"),
+    ("ks", "<i4"), ("stride", "<i4"), ("pad", "<i4"), ("in_mode", "<i4"), ("pro_affine", "<i4"), ("pro_slope", "<f4"),
+    ("epi_flags", "<i4"), ("epi_act", "<i4"), ("epi_slope", "<f4"), ("out_h", "<i4"), ("out_w", "<i4"),
+    ("out_sy", "<i4"), ("out_sx", "<i4"), ("nsub", "<i4"), ("out_sub", "<i4")])
+OP_DTYPE = np.dtype([("kind", "<i4"), ("i", "<i4", (27,)), ("f", "<f4", (4,)), ("slot", "<i4", (OP_MAX_T,)),
+                     ("off", "<i8", (OP_MAX_T,)), ("l", "<i8", (4,))], align=True)
+
+
+class CtlError(RuntimeError):
+    pass
+
+
+class _Lib:
+    def __init__(self):
+        self._lib = None
+
+    def load(self):
+        if self._lib is not None:
+            return self._lib
+        if not os.path.exists(LIB_PATH):
+            raise CtlError(f"HIP extension not built: {LIB_PATH} is missing. Run `python -c 'import __graft_entry__ as g; "
+                           "g.build()'` (or `make -C <package>/csrc`). There is no fallback path.")
+        lib = C.CDLL(LIB_PATH)
+        lib.ctl_last_error.restype = C.c_char_p
+        lib.ctl_version.restype = C.c_int
+        for name in ("ctl_conv_wpack_floats", "ctl_conv_stats_floats", "ctl_wgrad_partial_floats",
+                     "ctl_wgrad_bias_partial_floats", "ctl_latent_score_ws_floats", "ctl_sizeof_op", "ctl_sizeof_conv"):
+            getattr(lib, name).restype = C.c_size_t
+        p, i32, i64, f32, u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64
+        sig = {
+            "ctl_conv_wpack_floats": [i32, i32, i32],
+            "ctl_conv_stats_floats": [p], "ctl_conv_stats_blocks": [p],
+            "ctl_wgrad_splits": [p], "ctl_wgrad_partial_floats": [p], "ctl_wgrad_bias_partial_floats": [p],
+            "ctl_pack_weights": [p, p, i32, i32, i32, i64, i64, i64, i64, i32, p],
+            "ctl_conv_forward": [p] * 12,
+            "ctl_conv_wgrad": [p] * 8,
+            "ctl_wgrad_reduce": [p, p, p, p, i64, i64, i64, i64, p, i32, p],
+            "ctl_bn_finalize": [p, i32, i32, i64, p, p, f32, f32, i32, p, p, p, p, p, p, p, p],
+            "ctl_bn_eval_coeffs": [i32, p, p, p, p, f32, p, p, p],
+            "ctl_bn_act": [p, p, p, f32, p, i64, i32, p],
+            "ctl_bwd_reduce": [i32, p, p, p, p, p, f32, i64, i32, p, p],
+            "ctl_bn_bwd_finalize": [p, i32, i64, p, p, p, p, p, p, i32, p],
+            "ctl_bwd_apply": [i32, p, p, p, p, p, f32, p, i64, i32, p, p, p],
+            "ctl_chan_sum_finalize": [p, i32, p, i32, p],
+            "ctl_sumpool2": [p, p, i32, i32, i32, i32, i32, p],
+            "ctl_sigmoid_bwd": [p, p, p, i64, p],
+            "ctl_softmax_t_fwd": [p, f32, p, i64, i32, p],
+            "ctl_softmax_t_bwd": [p, p, f32, p, i64, i32, p],
+            "ctl_onehot": [p, p, i64, i32, p],
+            "ctl_ce2d_fwd": [p, p, i64, i32, p, p, p],
+            "ctl_ce2d_bwd": [p, p, p, i64, i32, p, p],
+            "ctl_mse_fwd": [p, p, i64, f32, p, p, p],
+            "ctl_mse_bwd": [p, p, p, i64, f32, p, p],
+            "ctl_argmax_c": [p, p, i64, i32, p],
+            "ctl_latent_score_ws_floats": [i32, i32, i32, i32],
+            "ctl_latent_score": [i32, p, p, p, i32, i32, i32, p],
+            "ctl_latent_mask_apply": [i32, p, p, p, i32, p, p, p, i32, i32, i32, p],
+            "ctl_dropout2d": [p, p, u64, f32, p, p, i32, i32, i32, p],
+            "ctl_uniform": [p, i64, u64, p],
+            "ctl_adam": [p, p, p, p, i64, f32, f32, f32, f32, i32, f32, p],
+            "ctl_plan_run": [p, i32, p, i32, p],
+        }
+        for name, args in sig.items():
+            getattr(lib, name).argtypes = args
+        if lib.ctl_sizeof_op() != OP_DTYPE.itemsize or lib.ctl_sizeof_conv() != CONV_DTYPE.itemsize:
+            raise CtlError(f"ABI mismatch: sizeof(ctl_op)={lib.ctl_sizeof_op()} vs {OP_DTYPE.itemsize}, "
+                           f"sizeof(ctl_conv)={lib.ctl_sizeof_conv()} vs {CONV_DTYPE.itemsize}")
+        self._lib = lib
+        return lib
+
+    def __getattr__(self, name):
+        return getattr(self.load(), name)
+
+
+lib = _Lib()
+
+# every symbol include/ctl_hip.h declares (checked by tests/test_cabi.py without a GPU)
+EXPORTED = ["ctl_version", "ctl_last_error", "ctl_conv_wpack_floats", "ctl_conv_stats_floats", "ctl_conv_stats_blocks",
+            "ctl_pack_weights", "ctl_conv_forward", "ctl_wgrad_splits", "ctl_wgrad_partial_floats",
+            "ctl_wgrad_bias_partial_floats", "ctl_conv_wgrad", "ctl_wgrad_reduce", "ctl_bn_finalize", "ctl_bn_eval_coeffs",
+            "ctl_bn_act", "ctl_bwd_reduce", "ctl_bn_bwd_finalize", "ctl_bwd_apply", "ctl_chan_sum_finalize", "ctl_sumpool2",
+            "ctl_sigmoid_bwd", "ctl_softmax_t_fwd", "ctl_softmax_t_bwd", "ctl_onehot", "ctl_ce2d_fwd", "ctl_ce2d_bwd",
+            "ctl_mse_fwd", "ctl_mse_bwd", "ctl_argmax_c", "ctl_latent_score_ws_floats", "ctl_latent_score",
+            "ctl_latent_mask_apply", "ctl_dropout2d", "ctl_uniform", "ctl_adam", "ctl_plan_run", "ctl_sizeof_op",
+            "ctl_sizeof_conv"]
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib.ctl_last_error()
+        raise CtlError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")
+
+
+def conv_desc(**kw) -> np.ndarray:
+    """Build a ctl_conv record (numpy scalar array of CONV_DTYPE) with defaults for the plain, non-scattered case."""
+    d = np.zeros((), dtype=CONV_DTYPE)
+    d["pad"] = 1 if kw.get("ks", 3) == 3 else 0
+    d["stride"] = 1
+    d["nsub"] = 1
+    d["out_sy"] = d["out_sx"] = 1
+    for k, v in kw.items():
+        d[k] = v
+    if "out_h" not in kw:
+        d["out_h"] = d["hout"]
+    if "out_w" not in kw:
+        d["out_w"] = d["wout"]
+    return d
+
+
+def desc_ptr(d: np.ndarray) -> int:
+    return d.ctypes.data

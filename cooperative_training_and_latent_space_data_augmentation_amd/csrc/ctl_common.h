@@ -1,0 +1,53 @@
+// Internal helpers shared by the libctl_hip.so translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "ctl_hip.h"
+
+void ctl_set_error(const char* fmt, ...);
+
+#define CTL_FAIL(code, ...)            \
+    do {                               \
+        ctl_set_error(__VA_ARGS__);    \
+        return (code);                 \
+    } while (0)
+
+#define CTL_REQUIRE(cond, ...)                        \
+    do {                                              \
+        if (!(cond)) CTL_FAIL(CTL_EINVAL, __VA_ARGS__); \
+    } while (0)
+
+// every launcher ends with this: catches bad launch configurations without synchronising
+#define CTL_LAUNCH_CHECK(name)                                                         \
+    do {                                                                               \
+        hipError_t e__ = hipGetLastError();                                            \
+        if (e__ != hipSuccess) CTL_FAIL(CTL_ELAUNCH, "%s: %s", name, hipGetErrorString(e__)); \
+    } while (0)
+
+__host__ __device__ static inline int ctl_cdiv(int a, int b) { return (a + b - 1) / b; }
+__host__ __device__ static inline int64_t ctl_cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float ctl_leaky(float v, float slope) { return v > 0.f ? v : v * slope; }
+// derivative factor chosen from the sign of the activation *output* (== sign of its input for slope >= 0)
+__device__ __forceinline__ float ctl_leaky_grad(float out, float slope) { return out > 0.f ? 1.f : slope; }
+
+// XCD-aware bijective remap of a 1-D block index: blocks b and b+8 share an XCD (observed round-robin), so give
+// every XCD a contiguous chunk of the tile list -> neighbouring tiles (shared halos) meet in one L2.
+__device__ __forceinline__ int ctl_xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7, x = bid & 7;
+    const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    return base + (bid >> 3);
+}
+
+// conv descriptors shared between ctl_conv.hip and ctl_plan.cpp
+struct ctl_conv_cfg {
+    int mt, tw, nt;      // M-tiles per wave, tile width in pixels, cout tiles (of 16) per block
+    int th;              // tile height
+    int tiles_h, tiles_w;
+    int g;               // cin chunks of 16
+    int cot;             // cout tiles of 16 (total)
+};
+int ctl_conv_pick_cfg(const ctl_conv* d, ctl_conv_cfg* c);

@@ -1,0 +1,637 @@
+// Implicit-GEMM convolution family for gfx950 (MI355X): fp32 NHWC, MFMA f32 16x16x4, LDS-staged input tiles.
+//
+// GEMM view (computed transposed so that every lane ends up with 4 consecutive output channels of ONE pixel and the
+// epilogue is a single coalesced 16-byte store per lane):
+//     D^T[co][pixel] += W^T[co][k] * X^T[k][pixel],   k = (tap, ci)
+//   MFMA A operand = weights  : lane l -> A[row co = l&15][k-slot l>>4]
+//   MFMA B operand = input    : lane l -> B[k-slot l>>4][col pixel = l&15]
+//   D                          : lane l holds co = 4*(l>>4)+r (r=0..3) of pixel l&15
+// The order of k inside a 16-channel chunk is free as long as A and B agree, so one ds_read_b128 per lane
+// (4 consecutive channels of "its" pixel, quarter l>>4 of the chunk) feeds FOUR MFMAs: MFMA j uses component j, i.e.
+// k-slot q of MFMA j is channel 16*g + 4*q + j.  Weights are pre-packed in exactly that fragment order
+// (ctl_pack_weights), so the A operand is one coalesced 16-byte global load per lane, served from L2.
+//
+// LDS input tile: [row][col][16 channels] floats for the current 16-channel chunk; 16 consecutive output pixels of a
+// row read 1 KiB contiguous -> conflict-free ds_read_b128.  For stride 2 the columns are de-interleaved (even | odd)
+// so the same holds.  BatchNorm-apply + LeakyReLU of the producer layer is applied once per element while staging.
+#include "ctl_common.h"
+
+template <int KS, int S, int MT, int TW>
+struct Geom {
+    static constexpr int MTILES = 4 * MT;            // 16-pixel M-tiles per 256-thread block
+    static constexpr int TH = MTILES * 16 / TW;      // output tile height
+    static constexpr int TP = TH * TW;               // output pixels per tile
+    static constexpr int IH = (TH - 1) * S + KS;     // input tile (virtual coordinates)
+    static constexpr int IW = (TW - 1) * S + KS;
+    static constexpr int IWH = (IW + 1) / 2;
+    static constexpr int IWP = (S == 2) ? 2 * IWH : IW;
+    static constexpr int XT_FLOATS = IH * IWP * 16;
+    static constexpr int PAD = (KS == 3) ? 1 : 0;
+    __device__ static __forceinline__ int ldscol(int c) { return (S == 2) ? ((c & 1) * IWH + (c >> 1)) : c; }
+};
+
+// Stage the 16-channel chunk g of the (virtual) input tile into LDS, applying the fused BN+LeakyReLU prologue.
+template <int KS, int S, int MODE, int MT, int TW>
+__device__ __forceinline__ void stage_x(float* __restrict__ xt, const float* __restrict__ x, const ctl_conv& d, int n,
+                                        int vh0, int vw0, int g, const float* __restrict__ pro_scale,
+                                        const float* __restrict__ pro_shift) {
+    using G = Geom<KS, S, MT, TW>;
+    const int tid = threadIdx.x;
+    const int cq = tid & 3;
+    const int cb = g * 16 + cq * 4;
+    const int hv = (MODE == CTL_IN_PLAIN) ? d.hin : 2 * d.hin;
+    const int wv = (MODE == CTL_IN_PLAIN) ? d.win : 2 * d.win;
+    const bool chan_ok = cb < d.cin;
+    const bool pro = d.pro_affine != 0;
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (pro && chan_ok) {
+        if (d.cin >= 4) {
+            sc = *reinterpret_cast<const f32x4*>(pro_scale + cb);
+            sh = *reinterpret_cast<const f32x4*>(pro_shift + cb);
+        } else {
+            sc.x = pro_scale[0];
+            sh.x = pro_shift[0];
+        }
+    }
+    const float slope = d.pro_slope;
+    for (int u = tid; u < G::IH * G::IW * 4; u += 256) {
+        const int pix = u >> 2;
+        const int r = pix / G::IW;
+        const int c = pix - r * G::IW;
+        const int vh = vh0 + r, vw = vw0 + c;
+        bool ok = chan_ok && vh >= 0 && vh < hv && vw >= 0 && vw < wv;
+        if (MODE == CTL_IN_ZINS2) ok = ok && ((vh & 1) == 0) && ((vw & 1) == 0);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (ok) {
+            const int sh_ = (MODE == CTL_IN_PLAIN) ? vh : (vh >> 1);
+            const int sw_ = (MODE == CTL_IN_PLAIN) ? vw : (vw >> 1);
+            const int64_t base = (((int64_t)n * d.hin + sh_) * d.win + sw_) * d.cin + cb;
+            if (d.cin >= 4) {
+                v = *reinterpret_cast<const f32x4*>(x + base);
+                if (pro) {
+                    v.x = ctl_leaky(v.x * sc.x + sh.x, slope);
+                    v.y = ctl_leaky(v.y * sc.y + sh.y, slope);
+                    v.z = ctl_leaky(v.z * sc.z + sh.z, slope);
+                    v.w = ctl_leaky(v.w * sc.w + sh.w, slope);
+                }
+            } else {  // cin == 1
+                v.x = x[base];
+                if (pro) v.x = ctl_leaky(v.x * sc.x + sh.x, slope);
+            }
+        }
+        *reinterpret_cast<f32x4*>(xt + (r * G::IWP + G::ldscol(c)) * 16 + cq * 4) = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ forward-type kernel
+template <int KS, int S, int MODE, int MT, int TW, int NT>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ctl_conv d, const float* __restrict__ x,
+                                                          const float* __restrict__ wpack,
+                                                          const float* __restrict__ bias,
+                                                          const float* __restrict__ pro_scale,
+                                                          const float* __restrict__ pro_shift,
+                                                          const float* __restrict__ res,
+                                                          const float* __restrict__ res_scale,
+                                                          const float* __restrict__ res_shift, float* __restrict__ y,
+                                                          float* __restrict__ stats_partial, int tiles_h, int tiles_w,
+                                                          int G_chunks, int64_t wpack_sub_stride) {
+    using G = Geom<KS, S, MT, TW>;
+    constexpr int TAPS = KS * KS;
+    constexpr int RED_FLOATS = 4 * NT * 16 * 2;
+    __shared__ __attribute__((aligned(16))) float xt[(G::XT_FLOATS > RED_FLOATS) ? G::XT_FLOATS : RED_FLOATS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p = lane & 15, q = lane >> 4;
+
+    int bid = ctl_xcd_remap(blockIdx.x, gridDim.x);
+    const int twi = bid % tiles_w;
+    bid /= tiles_w;
+    const int thi = bid % tiles_h;
+    const int n = bid / tiles_h;
+    const int ho0 = thi * G::TH, wo0 = twi * TW;
+    const int z = blockIdx.z;
+    const int cot0 = blockIdx.y * NT;
+    const float* wp = wpack + (int64_t)z * wpack_sub_stride;
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int g = 0; g < G_chunks; ++g) {
+        if (g > 0) __syncthreads();
+        stage_x<KS, S, MODE, MT, TW>(xt, x, d, n, ho0 * S - G::PAD, wo0 * S - G::PAD, g, pro_scale, pro_shift);
+        __syncthreads();
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int kh = tap / KS, kw = tap % KS;
+            f32x4 wf[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                wf[t] = *reinterpret_cast<const f32x4*>(
+                    wp + ((((int64_t)(cot0 + t) * TAPS + tap) * G_chunks + g) * 64 + lane) * 4);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int mt = wave * MT + m;
+                const int tr = mt / (TW / 16), tc = (mt % (TW / 16)) * 16;
+                const int r = tr * S + kh;
+                const int c = (tc + p) * S + kw;
+                const f32x4 xf = *reinterpret_cast<const f32x4*>(xt + (r * G::IWP + G::ldscol(c)) * 16 + q * 4);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t].x, xf.x, acc[m][t], 0, 0, 0);
+                    acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t].y, xf.y, acc[m][t], 0, 0, 0);
+                    acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t].z, xf.z, acc[m][t], 0, 0, 0);
+                    acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t].w, xf.w, acc[m][t], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---------------- epilogue: lane (p,q) holds channels co0..co0+3 of pixel p of each M-tile
+    const int flags = d.epi_flags;
+    const int oy0 = (z >> 1) * d.out_sub, ox0 = (z & 1) * d.out_sub;
+    f32x4 ssum[NT], ssq[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) ssum[t] = ssq[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int co0 = (cot0 + t) * 16 + q * 4;
+        if (co0 >= d.cout) continue;
+        f32x4 b = {0.f, 0.f, 0.f, 0.f}, rs = {0.f, 0.f, 0.f, 0.f}, rh = {0.f, 0.f, 0.f, 0.f};
+        if (d.cout >= 4) {
+            if (flags & CTL_EPI_BIAS) b = *reinterpret_cast<const f32x4*>(bias + co0);
+            if (flags & CTL_EPI_RES) {
+                rs = *reinterpret_cast<const f32x4*>(res_scale + co0);
+                rh = *reinterpret_cast<const f32x4*>(res_shift + co0);
+            }
+        } else {
+            if (flags & CTL_EPI_BIAS) b.x = bias[0];
+            if (flags & CTL_EPI_RES) { rs.x = res_scale[0]; rh.x = res_shift[0]; }
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int mt = wave * MT + m;
+            const int ho = ho0 + mt / (TW / 16), wo = wo0 + (mt % (TW / 16)) * 16 + p;
+            if (ho >= d.hout || wo >= d.wout) continue;
+            f32x4 v = acc[m][t];
+            v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+            const int64_t opix = ((int64_t)n * d.out_h + (ho * d.out_sy + oy0)) * d.out_w + (wo * d.out_sx + ox0);
+            float* yp = y + opix * d.cout + co0;
+            if (d.cout >= 4) {
+                if (flags & CTL_EPI_RES) {
+                    const f32x4 rv = *reinterpret_cast<const f32x4*>(res + opix * d.cout + co0);
+                    v.x += rv.x * rs.x + rh.x; v.y += rv.y * rs.y + rh.y;
+                    v.z += rv.z * rs.z + rh.z; v.w += rv.w * rs.w + rh.w;
+                }
+                if (flags & CTL_EPI_STATS) {
+                    ssum[t].x += v.x; ssum[t].y += v.y; ssum[t].z += v.z; ssum[t].w += v.w;
+                    ssq[t].x += v.x * v.x; ssq[t].y += v.y * v.y; ssq[t].z += v.z * v.z; ssq[t].w += v.w * v.w;
+                }
+                if (d.epi_act == CTL_ACT_LEAKY) {
+                    v.x = ctl_leaky(v.x, d.epi_slope); v.y = ctl_leaky(v.y, d.epi_slope);
+                    v.z = ctl_leaky(v.z, d.epi_slope); v.w = ctl_leaky(v.w, d.epi_slope);
+                } else if (d.epi_act == CTL_ACT_SIGMOID) {
+                    v.x = 1.f / (1.f + __expf(-v.x)); v.y = 1.f / (1.f + __expf(-v.y));
+                    v.z = 1.f / (1.f + __expf(-v.z)); v.w = 1.f / (1.f + __expf(-v.w));
+                }
+                if (flags & CTL_EPI_ACCUM) {
+                    const f32x4 o = *reinterpret_cast<const f32x4*>(yp);
+                    v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                }
+                *reinterpret_cast<f32x4*>(yp) = v;
+            } else {  // cout == 1: only q == 0, component x is real
+                float s = v.x;
+                if (flags & CTL_EPI_RES) s += res[opix] * rs.x + rh.x;
+                if (flags & CTL_EPI_STATS) { ssum[t].x += s; ssq[t].x += s * s; }
+                if (d.epi_act == CTL_ACT_LEAKY) s = ctl_leaky(s, d.epi_slope);
+                else if (d.epi_act == CTL_ACT_SIGMOID) s = 1.f / (1.f + expf(-s));
+                if (flags & CTL_EPI_ACCUM) s += yp[0];
+                yp[0] = s;
+            }
+        }
+    }
+
+    if (flags & CTL_EPI_STATS) {  // per-channel sum / sum of squares of this tile -> stats_partial[block][2][cout]
+        __syncthreads();          // xt is reused as the cross-wave reduction buffer
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            float a[8] = {ssum[t].x, ssum[t].y, ssum[t].z, ssum[t].w, ssq[t].x, ssq[t].y, ssq[t].z, ssq[t].w};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float v = a[i];
+                v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+                a[i] = v;
+            }
+            if (p == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    xt[((wave * NT + t) * 16 + q * 4 + r) * 2 + 0] = a[r];
+                    xt[((wave * NT + t) * 16 + q * 4 + r) * 2 + 1] = a[4 + r];
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < NT * 16 * 2) {
+            const int stat = tid / (NT * 16), cl = tid % (NT * 16);
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) v += xt[((w * NT * 16) + cl) * 2 + stat];
+            const int co = cot0 * 16 + cl;
+            if (co < d.cout) stats_partial[((int64_t)blockIdx.x * 2 + stat) * d.cout + co] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradient
+// dW[tap][ci][co] = sum_pixels x_virtual[pixel*S + tap - pad][ci] * dy[pixel][co]:  D[ci][co] += A[ci][k=pixel] B[pixel][co]
+//   A: lane l -> x[pixel 4s + (l>>4) shifted by tap][ci = l&15]   (ds_read_b32, 256 B contiguous per wave)
+//   B: lane l -> dy[pixel 4s + (l>>4)][co = l&15]
+//   D: lane l holds dW[ci = 4*(l>>4)+r][co = l&15]
+// Each block owns one 16-channel cin chunk (blockIdx.y) and NTW cout tiles (blockIdx.z), walks tiles
+// blockIdx.x, +gridDim.x, ... and keeps all KS*KS*NTW accumulator tiles in registers; its four waves split the
+// tile's pixels and are summed through LDS at the end.  Partial results per split are reduced by wgrad_reduce_kernel
+// (deterministic: no float atomics).
+template <int KS, int S, int MODE, int MT, int TW, int NTW>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const ctl_conv d, const float* __restrict__ x,
+                                                          const float* __restrict__ pro_scale,
+                                                          const float* __restrict__ pro_shift,
+                                                          const float* __restrict__ dy, float* __restrict__ w_partial,
+                                                          float* __restrict__ b_partial, int tiles_h, int tiles_w,
+                                                          int ntiles, int cin_p, int cout_p) {
+    using G = Geom<KS, S, MT, TW>;
+    constexpr int TAPS = KS * KS;
+    constexpr int DYT_FLOATS = NTW * G::TP * 16;
+    constexpr int RED_FLOATS = 4 * NTW * 256;
+    constexpr int LDS_FLOATS = (G::XT_FLOATS + DYT_FLOATS > RED_FLOATS) ? (G::XT_FLOATS + DYT_FLOATS) : RED_FLOATS;
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+    float* xt = lds;
+    float* dyt = lds + G::XT_FLOATS;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p = lane & 15, q = lane >> 4;
+    const int g = blockIdx.y;
+    const int cot0 = blockIdx.z * NTW;
+
+    f32x4 acc[TAPS][NTW];
+#pragma unroll
+    for (int a = 0; a < TAPS; ++a)
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) acc[a][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) bsum[t] = 0.f;
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int b = tile;
+        const int twi = b % tiles_w;
+        b /= tiles_w;
+        const int thi = b % tiles_h;
+        const int n = b / tiles_h;
+        const int ho0 = thi * G::TH, wo0 = twi * TW;
+        __syncthreads();
+        stage_x<KS, S, MODE, MT, TW>(xt, x, d, n, ho0 * S - G::PAD, wo0 * S - G::PAD, g, pro_scale, pro_shift);
+        for (int u = tid; u < G::TP * NTW * 4; u += 256) {
+            const int pix = u / (NTW * 4);
+            const int q4 = u - pix * (NTW * 4);
+            const int t = q4 >> 2, cq = q4 & 3;
+            const int ho = ho0 + pix / TW, wo = wo0 + pix % TW;
+            const int co = (cot0 + t) * 16 + cq * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ho < d.hout && wo < d.wout && co < d.cout) {
+                const int64_t base = (((int64_t)n * d.hout + ho) * d.wout + wo) * d.cout + co;
+                if (d.cout >= 4) v = *reinterpret_cast<const f32x4*>(dy + base);
+                else v.x = dy[base];
+            }
+            *reinterpret_cast<f32x4*>(dyt + (t * G::TP + pix) * 16 + cq * 4) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int mt = wave * MT + m;
+            const int tr = mt / (TW / 16), tc = (mt % (TW / 16)) * 16;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int pc = tc + 4 * s + q;  // this lane's k-slot pixel column inside the tile
+                float bf[NTW];
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) {
+                    bf[t] = dyt[(t * G::TP + tr * TW + pc) * 16 + p];
+                    bsum[t] += bf[t];
+                }
+#pragma unroll
+                for (int tap = 0; tap < TAPS; ++tap) {
+                    const int kh = tap / KS, kw = tap % KS;
+                    const float af = xt[((tr * S + kh) * G::IWP + G::ldscol(pc * S + kw)) * 16 + p];
+#pragma unroll
+                    for (int t = 0; t < NTW; ++t)
+                        acc[tap][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf[t], acc[tap][t], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---------------- sum the four waves through LDS, tap by tap, and write this split's partial
+    float* red = lds;
+    const int64_t split_base = (int64_t)blockIdx.x * TAPS * cin_p * cout_p;
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap) {
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            red[((wave * NTW + t) * 4 + 0) * 64 + lane] = acc[tap][t].x;
+            red[((wave * NTW + t) * 4 + 1) * 64 + lane] = acc[tap][t].y;
+            red[((wave * NTW + t) * 4 + 2) * 64 + lane] = acc[tap][t].z;
+            red[((wave * NTW + t) * 4 + 3) * 64 + lane] = acc[tap][t].w;
+        }
+        __syncthreads();
+        for (int e = tid; e < NTW * 256; e += 256) {
+            const int t = e >> 8, r = (e >> 6) & 3, l = e & 63;
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) v += red[((w * NTW + t) * 4 + r) * 64 + l];
+            const int ci = g * 16 + (l >> 4) * 4 + r;
+            const int co = (cot0 + t) * 16 + (l & 15);
+            if (co < cout_p) w_partial[split_base + ((int64_t)tap * cin_p + ci) * cout_p + co] = v;
+        }
+    }
+    if (g == 0 && b_partial != nullptr) {  // bias gradient: column sums of dy
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            float v = bsum[t];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (q == 0) red[(wave * NTW + t) * 16 + p] = v;
+        }
+        __syncthreads();
+        if (tid < NTW * 16) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) v += red[w * NTW * 16 + tid];
+            const int co = cot0 * 16 + tid;
+            if (co < cout_p) b_partial[(int64_t)blockIdx.x * cout_p + co] = v;
+        }
+    }
+}
+
+__global__ void wgrad_reduce_kernel(const float* __restrict__ w_partial, const float* __restrict__ b_partial,
+                                    int splits, int taps, int ks, int cin, int cout, int cin_p, int cout_p,
+                                    float* __restrict__ dw, int64_t s_co, int64_t s_ci, int64_t s_kh, int64_t s_kw,
+                                    float* __restrict__ dbias, int accumulate) {
+    const int64_t total = (int64_t)taps * cin * cout;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < total) {
+        const int co = idx % cout;
+        const int ci = (idx / cout) % cin;
+        const int tap = idx / ((int64_t)cout * cin);
+        const int64_t stride = (int64_t)taps * cin_p * cout_p;
+        const float* src = w_partial + ((int64_t)tap * cin_p + ci) * cout_p + co;
+        float v = 0.f;
+        for (int s = 0; s < splits; ++s) v += src[s * stride];
+        float* dst = dw + co * s_co + ci * s_ci + (tap / ks) * s_kh + (tap % ks) * s_kw;
+        *dst = accumulate ? (*dst + v) : v;
+    } else if (dbias != nullptr && idx < total + cout) {
+        const int co = idx - total;
+        float v = 0.f;
+        for (int s = 0; s < splits; ++s) v += b_partial[(int64_t)s * cout_p + co];
+        dbias[co] = accumulate ? (dbias[co] + v) : v;
+    }
+}
+
+__global__ void pack_weights_kernel(const float* __restrict__ src, float* __restrict__ dst, int cout, int cin, int ks,
+                                    int g_chunks, int64_t total, int64_t s_co, int64_t s_ci, int64_t s_kh,
+                                    int64_t s_kw, int flip) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int j = idx & 3, lane = (idx >> 2) & 63;
+    int64_t rest = idx >> 8;
+    const int g = rest % g_chunks;
+    rest /= g_chunks;
+    const int taps = ks * ks;
+    const int tap = rest % taps;
+    const int cot = rest / taps;
+    const int co = cot * 16 + (lane & 15);
+    const int ci = g * 16 + (lane >> 4) * 4 + j;
+    int kh = tap / ks, kw = tap % ks;
+    if (flip) { kh = ks - 1 - kh; kw = ks - 1 - kw; }
+    float v = 0.f;
+    if (co < cout && ci < cin) v = src[co * s_co + ci * s_ci + kh * s_kh + kw * s_kw];
+    dst[idx] = v;
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+extern "C" size_t ctl_conv_wpack_floats(int32_t cin, int32_t cout, int32_t ks) {
+    return (size_t)ctl_cdiv(cout, 16) * ks * ks * ctl_cdiv(cin, 16) * 256;
+}
+
+static bool conv_combo_ok(const ctl_conv* d) {
+    const int k = d->ks, s = d->stride, m = d->in_mode, pd = d->pad;
+    if (k == 3 && s == 1 && pd == 1) return true;
+    if (k == 3 && s == 2 && pd == 1 && m == CTL_IN_PLAIN) return true;
+    if (k == 1 && s == 1 && pd == 0 && m != CTL_IN_ZINS2) return true;
+    if (k == 2 && s == 2 && pd == 0 && m == CTL_IN_PLAIN) return true;
+    return false;
+}
+
+int ctl_conv_pick_cfg(const ctl_conv* d, ctl_conv_cfg* c) {
+    CTL_REQUIRE(conv_combo_ok(d), "conv: unsupported ks/stride/pad/in_mode %d/%d/%d/%d", d->ks, d->stride, d->pad,
+                d->in_mode);
+    CTL_REQUIRE(d->cin == 1 || d->cin % 4 == 0, "conv: cin must be 1 or a multiple of 4 (got %d)", d->cin);
+    CTL_REQUIRE(d->cout == 1 || d->cout % 4 == 0, "conv: cout must be 1 or a multiple of 4 (got %d)", d->cout);
+    CTL_REQUIRE(d->cin < 16 ? (d->cin == 1 || d->cin == 4 || d->cin == 8 || d->cin == 12) : d->cin % 16 == 0,
+                "conv: cin >= 16 must be a multiple of 16 (got %d)", d->cin);
+    CTL_REQUIRE(d->nsub == 1 || d->nsub == 4, "conv: nsub must be 1 or 4");
+    c->cot = ctl_cdiv(d->cout, 16);
+    c->g = ctl_cdiv(d->cin, 16);
+    c->nt = (c->cot % 4 == 0) ? 4 : (c->cot % 2 == 0) ? 2 : 1;
+    const int64_t pix_per_img = (int64_t)d->hout * d->wout;
+    auto blocks = [&](int mt, int tw) {
+        const int th = 4 * mt * 16 / tw;
+        return (int64_t)d->n * ctl_cdiv(d->hout, th) * ctl_cdiv(d->wout, tw) * (c->cot / c->nt) * d->nsub;
+    };
+    (void)pix_per_img;
+    int mt, tw;
+    if (d->stride == 2) {
+        if (blocks(2, 16) >= 384) { mt = 2; tw = 16; } else { mt = 1; tw = 16; }
+    } else if (d->wout >= 32 && blocks(4, 32) >= 512) {
+        mt = 4; tw = 32;
+    } else if (blocks(2, 16) >= 384) {
+        mt = 2; tw = 16;
+    } else {
+        mt = 1; tw = 16;
+    }
+    c->mt = mt; c->tw = tw; c->th = 4 * mt * 16 / tw;
+    c->tiles_h = ctl_cdiv(d->hout, c->th);
+    c->tiles_w = ctl_cdiv(d->wout, c->tw);
+    return CTL_OK;
+}
+
+extern "C" int ctl_conv_stats_blocks(const ctl_conv* d) {
+    ctl_conv_cfg c;
+    if (ctl_conv_pick_cfg(d, &c) != CTL_OK) return -1;
+    return d->n * c.tiles_h * c.tiles_w;
+}
+extern "C" size_t ctl_conv_stats_floats(const ctl_conv* d) {
+    const int b = ctl_conv_stats_blocks(d);
+    return b < 0 ? 0 : (size_t)b * 2 * d->cout;
+}
+
+extern "C" int ctl_pack_weights(const float* src, float* dst, int32_t cout, int32_t cin, int32_t ks, int64_t s_co,
+                                int64_t s_ci, int64_t s_kh, int64_t s_kw, int32_t flip, ctl_stream stream) {
+    CTL_REQUIRE(src && dst && cout > 0 && cin > 0 && ks >= 1 && ks <= 3, "pack_weights: bad arguments");
+    const int64_t total = (int64_t)ctl_conv_wpack_floats(cin, cout, ks);
+    pack_weights_kernel<<<dim3((unsigned)ctl_cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream>>>(
+        src, dst, cout, cin, ks, ctl_cdiv(cin, 16), total, s_co, s_ci, s_kh, s_kw, flip);
+    CTL_LAUNCH_CHECK("pack_weights");
+    return CTL_OK;
+}
+
+#define CONV_ARGS *d, x, wpack, bias, pro_scale, pro_shift, res, res_scale, res_shift, y, stats_partial, c.tiles_h, \
+                  c.tiles_w, c.g, sub_stride
+#define LAUNCH_CONV(KS, S, MODE, MT, TW, NT)                                                           \
+    conv_igemm_kernel<KS, S, MODE, MT, TW, NT><<<grid, dim3(256), 0, (hipStream_t)stream>>>(CONV_ARGS)
+#define DISPATCH_NT(KS, S, MODE, MT, TW)                     \
+    do {                                                     \
+        if (c.nt == 4) LAUNCH_CONV(KS, S, MODE, MT, TW, 4);  \
+        else if (c.nt == 2) LAUNCH_CONV(KS, S, MODE, MT, TW, 2); \
+        else LAUNCH_CONV(KS, S, MODE, MT, TW, 1);            \
+    } while (0)
+#define DISPATCH_TILE(KS, S, MODE)                                   \
+    do {                                                             \
+        if (c.mt == 4 && c.tw == 32) DISPATCH_NT(KS, S, MODE, 4, 32); \
+        else if (c.mt == 2) DISPATCH_NT(KS, S, MODE, 2, 16);         \
+        else DISPATCH_NT(KS, S, MODE, 1, 16);                        \
+    } while (0)
+#define DISPATCH_TILE_S2(KS, S, MODE)                        \
+    do {                                                     \
+        if (c.mt == 2) DISPATCH_NT(KS, S, MODE, 2, 16);      \
+        else DISPATCH_NT(KS, S, MODE, 1, 16);                \
+    } while (0)
+
+extern "C" int ctl_conv_forward(const ctl_conv* d, const float* x, const float* wpack, const float* bias,
+                                const float* pro_scale, const float* pro_shift, const float* res,
+                                const float* res_scale, const float* res_shift, float* y, float* stats_partial,
+                                ctl_stream stream) {
+    CTL_REQUIRE(d && x && wpack && y, "conv_forward: null argument");
+    ctl_conv_cfg c;
+    int rc = ctl_conv_pick_cfg(d, &c);
+    if (rc != CTL_OK) return rc;
+    CTL_REQUIRE(!(d->epi_flags & CTL_EPI_BIAS) || bias, "conv_forward: CTL_EPI_BIAS without bias");
+    CTL_REQUIRE(!(d->epi_flags & CTL_EPI_RES) || (res && res_scale && res_shift), "conv_forward: CTL_EPI_RES without res");
+    CTL_REQUIRE(!(d->epi_flags & CTL_EPI_STATS) || (stats_partial && d->nsub == 1), "conv_forward: bad CTL_EPI_STATS use");
+    CTL_REQUIRE(!d->pro_affine || (pro_scale && pro_shift), "conv_forward: prologue without scale/shift");
+    CTL_REQUIRE(d->n > 0 && d->hout > 0 && d->wout > 0, "conv_forward: empty problem");
+    const int64_t sub_stride = (int64_t)ctl_conv_wpack_floats(d->cin, d->cout, d->ks);
+    const dim3 grid((unsigned)(d->n * c.tiles_h * c.tiles_w), (unsigned)(c.cot / c.nt), (unsigned)d->nsub);
+    const int k = d->ks, s = d->stride, m = d->in_mode;
+    if (k == 3 && s == 1 && m == CTL_IN_PLAIN) DISPATCH_TILE(3, 1, CTL_IN_PLAIN);
+    else if (k == 3 && s == 1 && m == CTL_IN_UP2) DISPATCH_TILE(3, 1, CTL_IN_UP2);
+    else if (k == 3 && s == 1 && m == CTL_IN_ZINS2) DISPATCH_TILE(3, 1, CTL_IN_ZINS2);
+    else if (k == 3 && s == 2) DISPATCH_TILE_S2(3, 2, CTL_IN_PLAIN);
+    else if (k == 1 && m == CTL_IN_PLAIN) DISPATCH_TILE(1, 1, CTL_IN_PLAIN);
+    else if (k == 1 && m == CTL_IN_UP2) DISPATCH_TILE(1, 1, CTL_IN_UP2);
+    else if (k == 2 && s == 2) DISPATCH_TILE_S2(2, 2, CTL_IN_PLAIN);
+    else CTL_FAIL(CTL_EUNSUPPORTED, "conv_forward: no kernel for this combination");
+    CTL_LAUNCH_CHECK("conv_forward");
+    return CTL_OK;
+}
+
+// ---- wgrad host side
+struct wgrad_cfg { ctl_conv_cfg c; int ntw, splits, ntiles, cin_p, cout_p; };
+
+static int wgrad_pick(const ctl_conv* d, wgrad_cfg* w) {
+    CTL_REQUIRE(d->nsub == 1, "wgrad: nsub must be 1");
+    CTL_REQUIRE(d->in_mode != CTL_IN_ZINS2, "wgrad: zero-insert input is not a forward mode");
+    int rc = ctl_conv_pick_cfg(d, &w->c);
+    if (rc != CTL_OK) return rc;
+    // the wgrad kernel reuses the forward tile shapes; cap LDS by keeping (4,32) only for stride 1
+    w->ntw = (w->c.cot >= 2 && w->c.cot % 2 == 0) ? 2 : 1;
+    w->ntiles = d->n * w->c.tiles_h * w->c.tiles_w;
+    w->cin_p = w->c.g * 16;
+    w->cout_p = w->c.cot * 16;
+    const int par = w->c.g * (w->c.cot / w->ntw);
+    int splits = ctl_cdiv(1024, par);
+    if (splits > w->ntiles) splits = w->ntiles;
+    if (splits < 1) splits = 1;
+    w->splits = splits;
+    return CTL_OK;
+}
+
+extern "C" int ctl_wgrad_splits(const ctl_conv* d) {
+    wgrad_cfg w;
+    return wgrad_pick(d, &w) == CTL_OK ? w.splits : -1;
+}
+extern "C" size_t ctl_wgrad_partial_floats(const ctl_conv* d) {
+    wgrad_cfg w;
+    if (wgrad_pick(d, &w) != CTL_OK) return 0;
+    return (size_t)w.splits * d->ks * d->ks * w.cin_p * w.cout_p;
+}
+extern "C" size_t ctl_wgrad_bias_partial_floats(const ctl_conv* d) {
+    wgrad_cfg w;
+    if (wgrad_pick(d, &w) != CTL_OK) return 0;
+    return (size_t)w.splits * w.cout_p;
+}
+
+#define WGRAD_ARGS *d, x, pro_scale, pro_shift, dy, w_partial, b_partial, w.c.tiles_h, w.c.tiles_w, w.ntiles, w.cin_p, w.cout_p
+#define LAUNCH_WG(KS, S, MODE, MT, TW, NTW)                                                              \
+    conv_wgrad_kernel<KS, S, MODE, MT, TW, NTW><<<grid, dim3(256), 0, (hipStream_t)stream>>>(WGRAD_ARGS)
+#define WG_NT(KS, S, MODE, MT, TW)                       \
+    do {                                                 \
+        if (w.ntw == 2) LAUNCH_WG(KS, S, MODE, MT, TW, 2); \
+        else LAUNCH_WG(KS, S, MODE, MT, TW, 1);          \
+    } while (0)
+#define WG_TILE(KS, S, MODE)                                      \
+    do {                                                          \
+        if (w.c.mt == 4 && w.c.tw == 32) WG_NT(KS, S, MODE, 4, 32); \
+        else if (w.c.mt == 2) WG_NT(KS, S, MODE, 2, 16);          \
+        else WG_NT(KS, S, MODE, 1, 16);                           \
+    } while (0)
+#define WG_TILE_S2(KS, S, MODE)                         \
+    do {                                                \
+        if (w.c.mt == 2) WG_NT(KS, S, MODE, 2, 16);     \
+        else WG_NT(KS, S, MODE, 1, 16);                 \
+    } while (0)
+
+extern "C" int ctl_conv_wgrad(const ctl_conv* d, const float* x, const float* pro_scale, const float* pro_shift,
+                              const float* dy, float* w_partial, float* b_partial, ctl_stream stream) {
+    CTL_REQUIRE(d && x && dy && w_partial, "conv_wgrad: null argument");
+    CTL_REQUIRE(!d->pro_affine || (pro_scale && pro_shift), "conv_wgrad: prologue without scale/shift");
+    wgrad_cfg w;
+    int rc = wgrad_pick(d, &w);
+    if (rc != CTL_OK) return rc;
+    const dim3 grid((unsigned)w.splits, (unsigned)w.c.g, (unsigned)(w.c.cot / w.ntw));
+    const int k = d->ks, s = d->stride, m = d->in_mode;
+    if (k == 3 && s == 1 && m == CTL_IN_PLAIN) WG_TILE(3, 1, CTL_IN_PLAIN);
+    else if (k == 3 && s == 1 && m == CTL_IN_UP2) WG_TILE(3, 1, CTL_IN_UP2);
+    else if (k == 3 && s == 2) WG_TILE_S2(3, 2, CTL_IN_PLAIN);
+    else if (k == 1 && m == CTL_IN_PLAIN) WG_TILE(1, 1, CTL_IN_PLAIN);
+    else if (k == 1 && m == CTL_IN_UP2) WG_TILE(1, 1, CTL_IN_UP2);
+    else if (k == 2 && s == 2) WG_TILE_S2(2, 2, CTL_IN_PLAIN);
+    else CTL_FAIL(CTL_EUNSUPPORTED, "conv_wgrad: no kernel for this combination");
+    CTL_LAUNCH_CHECK("conv_wgrad");
+    return CTL_OK;
+}
+
+extern "C" int ctl_wgrad_reduce(const ctl_conv* d, const float* w_partial, const float* b_partial, float* dw,
+                                int64_t s_co, int64_t s_ci, int64_t s_kh, int64_t s_kw, float* dbias,
+                                int32_t accumulate, ctl_stream stream) {
+    CTL_REQUIRE(d && w_partial && dw, "wgrad_reduce: null argument");
+    CTL_REQUIRE(!dbias || b_partial, "wgrad_reduce: dbias without b_partial");
+    wgrad_cfg w;
+    int rc = wgrad_pick(d, &w);
+    if (rc != CTL_OK) return rc;
+    const int taps = d->ks * d->ks;
+    const int64_t total = (int64_t)taps * d->cin * d->cout + (dbias ? d->cout : 0);
+    wgrad_reduce_kernel<<<dim3((unsigned)ctl_cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream>>>(
+        w_partial, b_partial, w.splits, taps, d->ks, d->cin, d->cout, w.cin_p, w.cout_p, dw, s_co, s_ci, s_kh, s_kw,
+        dbias, accumulate);
+    CTL_LAUNCH_CHECK("wgrad_reduce");
+    return CTL_OK;
+}

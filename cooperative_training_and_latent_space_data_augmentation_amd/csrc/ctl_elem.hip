@@ -1,0 +1,545 @@
+// HBM-bound kernels of the hot path: BatchNorm finalize/apply/backward, residual/activation backward, nearest-upsample
+// backward, STN input builders, fused losses, argmax and the flat multi-tensor Adam.  All fp32 NHWC; 16 bytes per lane
+// wherever the channel count allows, wavefront(64)-shuffle + LDS block reductions, two-stage deterministic sums
+// (per-block partials in fp32, finalisation in fp64) instead of float atomics.
+#include "ctl_common.h"
+
+#define EB 256               // threads per block for the streaming kernels
+#define MAX_STREAM_BLOCKS 2048
+
+static inline unsigned stream_blocks(int64_t work_items) {
+    int64_t b = ctl_cdiv64(work_items, EB);
+    if (b > MAX_STREAM_BLOCKS) b = MAX_STREAM_BLOCKS;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+__device__ __forceinline__ double block_sum_double(double v, double* sm) {
+    // 256 threads: wave shuffle then LDS
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) sm[w] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0) {
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) r += sm[i];
+    }
+    return r;  // valid on thread 0
+}
+
+// ------------------------------------------------------------------------------------------------ BatchNorm forward
+__global__ __launch_bounds__(EB) void bn_finalize_kernel(const float* __restrict__ partial, int blocks, int c,
+                                                          double count, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float eps, float momentum,
+                                                          int update_running, float* __restrict__ running_mean,
+                                                          float* __restrict__ running_var,
+                                                          int64_t* __restrict__ nbt, float* __restrict__ scale,
+                                                          float* __restrict__ shift, float* __restrict__ save_mean,
+                                                          float* __restrict__ save_invstd) {
+    __shared__ double sm[8];
+    const int ch = blockIdx.x;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = threadIdx.x; b < blocks; b += EB) {
+        s1 += (double)partial[((int64_t)b * 2 + 0) * c + ch];
+        s2 += (double)partial[((int64_t)b * 2 + 1) * c + ch];
+    }
+    s1 = block_sum_double(s1, sm);
+    __syncthreads();
+    s2 = block_sum_double(s2, sm + 4);
+    if (threadIdx.x == 0) {
+        const double mean = s1 / count;
+        double var = s2 / count - mean * mean;   // biased variance, as F.batch_norm normalises with
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float g = gamma[ch], b = beta[ch];
+        const float sc = g * invstd;
+        scale[ch] = sc;
+        shift[ch] = b - (float)mean * sc;
+        if (save_mean) save_mean[ch] = (float)mean;
+        if (save_invstd) save_invstd[ch] = invstd;
+        if (update_running) {   // nn.BatchNorm2d: momentum 0.1, running_var uses the unbiased estimate
+            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+            running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * (float)mean;
+            running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * (float)unbiased;
+            if (ch == 0 && nbt) nbt[0] += 1;
+        }
+    }
+}
+
+__global__ void bn_eval_kernel(int c, const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                               float* scale, float* shift) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch < c) {
+        const float sc = gamma[ch] / sqrtf(rv[ch] + eps);
+        scale[ch] = sc;
+        shift[ch] = beta[ch] - rm[ch] * sc;
+    }
+}
+
+__global__ __launch_bounds__(EB) void bn_act_kernel(const f32x4* __restrict__ x, const f32x4* __restrict__ scale,
+                                                     const f32x4* __restrict__ shift, float slope,
+                                                     f32x4* __restrict__ y, int64_t quads, int cq) {
+    const int64_t stride = (int64_t)gridDim.x * EB;
+    for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < quads; i += stride) {
+        const int q = (int)(i % cq);
+        const f32x4 sc = scale[q], sh = shift[q];
+        f32x4 v = x[i];
+        v.x = ctl_leaky(v.x * sc.x + sh.x, slope); v.y = ctl_leaky(v.y * sc.y + sh.y, slope);
+        v.z = ctl_leaky(v.z * sc.z + sh.z, slope); v.w = ctl_leaky(v.w * sc.w + sh.w, slope);
+        y[i] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward reductions
+// grid = CTL_RED_BLOCKS x 256; the global stride (131072) is a multiple of every C/4 in use, so a thread always sees
+// the same channel quad and accumulates it in registers.
+template <int MODE>
+__global__ __launch_bounds__(EB) void bwd_reduce_kernel(const f32x4* __restrict__ dy, const f32x4* __restrict__ act_src,
+                                                         const f32x4* __restrict__ bn_src,
+                                                         const f32x4* __restrict__ scale,
+                                                         const f32x4* __restrict__ shift, float slope, int64_t quads,
+                                                         int cq, float* __restrict__ partial) {
+    __shared__ f32x4 sm[2][EB];
+    const int64_t gtid = (int64_t)blockIdx.x * EB + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * EB;
+    const int q = (int)(gtid % cq);
+    f32x4 sc = {1, 1, 1, 1}, sh = {0, 0, 0, 0};
+    if (MODE == 1) { sc = scale[q]; sh = shift[q]; }
+    f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
+    for (int64_t i = gtid; i < quads; i += stride) {
+        f32x4 g = dy[i];
+        if (MODE == 0) {
+            const f32x4 o = act_src[i];
+            g.x *= ctl_leaky_grad(o.x, slope); g.y *= ctl_leaky_grad(o.y, slope);
+            g.z *= ctl_leaky_grad(o.z, slope); g.w *= ctl_leaky_grad(o.w, slope);
+        }
+        if (MODE == 2) {
+            s1.x += g.x; s1.y += g.y; s1.z += g.z; s1.w += g.w;
+        } else {
+            const f32x4 u = bn_src[i];
+            if (MODE == 1) {
+                g.x *= ctl_leaky_grad(u.x * sc.x + sh.x, slope); g.y *= ctl_leaky_grad(u.y * sc.y + sh.y, slope);
+                g.z *= ctl_leaky_grad(u.z * sc.z + sh.z, slope); g.w *= ctl_leaky_grad(u.w * sc.w + sh.w, slope);
+            }
+            s1.x += g.x; s1.y += g.y; s1.z += g.z; s1.w += g.w;
+            s2.x += g.x * u.x; s2.y += g.y * u.y; s2.z += g.z * u.z; s2.w += g.w * u.w;
+        }
+    }
+    sm[0][threadIdx.x] = s1;
+    sm[1][threadIdx.x] = s2;
+    __syncthreads();
+    const int c = cq * 4;
+    for (int t = threadIdx.x; t < 2 * c; t += EB) {   // one (stat, channel) per thread
+        const int stat = t / c, ch = t % c;
+        const int qq = ch >> 2, comp = ch & 3;
+        float v = 0.f;
+        // threads with (tid % cq) == qq hold this quad (EB % cq == 0 for every cq in use)
+        for (int k = qq; k < EB; k += cq) v += sm[stat][k][comp];
+        partial[((int64_t)blockIdx.x * 2 + stat) * c + ch] = v;
+    }
+}
+
+__global__ __launch_bounds__(EB) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int blocks, int c,
+                                                              double count, const float* __restrict__ gamma,
+                                                              const float* __restrict__ save_mean,
+                                                              const float* __restrict__ save_invstd,
+                                                              float* __restrict__ coef, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, int accumulate) {
+    __shared__ double sm[8];
+    const int ch = blockIdx.x;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = threadIdx.x; b < blocks; b += EB) {
+        s1 += (double)partial[((int64_t)b * 2 + 0) * c + ch];
+        s2 += (double)partial[((int64_t)b * 2 + 1) * c + ch];
+    }
+    s1 = block_sum_double(s1, sm);
+    __syncthreads();
+    s2 = block_sum_double(s2, sm + 4);
+    if (threadIdx.x == 0) {
+        const double mu = save_mean[ch], is = save_invstd[ch], g = gamma[ch];
+        const double sum_g = s1;
+        const double sum_gxhat = is * (s2 - mu * s1);
+        const double m1 = sum_g / count, m2 = sum_gxhat / count;
+        // dx = gamma*is*(g - m1 - xhat*m2),  xhat = (x-mu)*is   ==>  dx = A*g + B*x + C
+        const double A = g * is;
+        const double B = -g * is * is * m2;
+        const double C = -g * is * m1 + g * is * is * m2 * mu;
+        coef[ch] = (float)A;
+        coef[c + ch] = (float)B;
+        coef[2 * c + ch] = (float)C;
+        if (dgamma) dgamma[ch] = accumulate ? dgamma[ch] + (float)sum_gxhat : (float)sum_gxhat;
+        if (dbeta) dbeta[ch] = accumulate ? dbeta[ch] + (float)sum_g : (float)sum_g;
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(EB) void bwd_apply_kernel(const f32x4* __restrict__ dy, const f32x4* __restrict__ act_src,
+                                                        const f32x4* __restrict__ bn_src,
+                                                        const f32x4* __restrict__ scale,
+                                                        const f32x4* __restrict__ shift, float slope,
+                                                        const f32x4* __restrict__ coef, int64_t quads, int cq,
+                                                        f32x4* __restrict__ ds, f32x4* __restrict__ dx) {
+    const int64_t stride = (int64_t)gridDim.x * EB;
+    for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < quads; i += stride) {
+        const int q = (int)(i % cq);
+        f32x4 g = dy[i];
+        const f32x4 u = bn_src[i];
+        if (MODE == 0) {
+            const f32x4 o = act_src[i];
+            g.x *= ctl_leaky_grad(o.x, slope); g.y *= ctl_leaky_grad(o.y, slope);
+            g.z *= ctl_leaky_grad(o.z, slope); g.w *= ctl_leaky_grad(o.w, slope);
+            if (ds) ds[i] = g;
+        } else {
+            const f32x4 sc = scale[q], sh = shift[q];
+            g.x *= ctl_leaky_grad(u.x * sc.x + sh.x, slope); g.y *= ctl_leaky_grad(u.y * sc.y + sh.y, slope);
+            g.z *= ctl_leaky_grad(u.z * sc.z + sh.z, slope); g.w *= ctl_leaky_grad(u.w * sc.w + sh.w, slope);
+        }
+        const f32x4 A = coef[q], B = coef[cq + q], C = coef[2 * cq + q];
+        f32x4 r;
+        r.x = A.x * g.x + B.x * u.x + C.x; r.y = A.y * g.y + B.y * u.y + C.y;
+        r.z = A.z * g.z + B.z * u.z + C.z; r.w = A.w * g.w + B.w * u.w + C.w;
+        dx[i] = r;
+    }
+}
+
+__global__ __launch_bounds__(EB) void chan_sum_finalize_kernel(const float* __restrict__ partial, int blocks, int c,
+                                                                float* __restrict__ out, int accumulate) {
+    __shared__ double sm[8];
+    const int ch = blockIdx.x;
+    double s1 = 0.0;
+    for (int b = threadIdx.x; b < blocks; b += EB) s1 += (double)partial[((int64_t)b * 2) * c + ch];
+    s1 = block_sum_double(s1, sm);
+    if (threadIdx.x == 0) out[ch] = accumulate ? out[ch] + (float)s1 : (float)s1;
+}
+
+__global__ __launch_bounds__(EB) void sumpool2_kernel(const f32x4* __restrict__ dup, f32x4* __restrict__ dx, int n, int h,
+                                                       int w, int cq, int accumulate) {
+    const int64_t quads = (int64_t)n * h * w * cq;
+    const int64_t stride = (int64_t)gridDim.x * EB;
+    for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < quads; i += stride) {
+        const int q = (int)(i % cq);
+        int64_t r = i / cq;
+        const int x = (int)(r % w);
+        r /= w;
+        const int y = (int)(r % h);
+        const int64_t b = r / h;
+        const int64_t row0 = ((b * 2 * h + 2 * y) * 2 * w + 2 * x) * cq + q;
+        const int64_t row1 = row0 + (int64_t)2 * w * cq;
+        const f32x4 a0 = dup[row0], a1 = dup[row0 + cq], a2 = dup[row1], a3 = dup[row1 + cq];
+        f32x4 v;
+        v.x = (a0.x + a1.x) + (a2.x + a3.x); v.y = (a0.y + a1.y) + (a2.y + a3.y);
+        v.z = (a0.z + a1.z) + (a2.z + a3.z); v.w = (a0.w + a1.w) + (a2.w + a3.w);
+        if (accumulate) { const f32x4 o = dx[i]; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+        dx[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(EB) void sigmoid_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                          float* __restrict__ dx, int64_t count) {
+    const int64_t stride = (int64_t)gridDim.x * EB;
+    for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < count; i += stride) {
+        const float s = y[i];
+        dx[i] = dy[i] * s * (1.f - s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ STN input builders
+#define MAXC 16
+__global__ __launch_bounds__(EB) void softmax_t_fwd_kernel(const float* __restrict__ x, float inv_t, float* __restrict__ p,
+                                                            int64_t pixels, int c) {
+    const int64_t stride = (int64_t)gridDim.x * EB;
+    for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < pixels; i += stride) {
+        float v[MAXC];
+        float m = -INFINITY;
+        for (int k = 0; k < c; ++k) { v[k] = x[i * c + k] * inv_t; m = fmaxf(m, v[k]); }
+        float s = 0.f;
+        for (int k = 0; k < c; ++k) { v[k] = expf(v[k] - m); s += v[k]; }
+        const float r = 1.f / s;
+        for (int k = 0; k < c; ++k) p[i * c + k] = v[k] * r;
+    }
+}
+__global__ __launch_bounds__(EB) void softmax_t_bwd_kernel(const float* __restrict__ p, const float* __restrict__ dp,
+                                                            float inv_t, float* __restrict__ dx, int64_t pixels, int c) {
+    const int64_t stride = (int64_t)gridDim.x * EB;
+    for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < pixels; i += stride) {
+        float dot = 0.f;
+        for (int k = 0; k < c; ++k) dot += p[i * c + k] * dp[i * c + k];
+        for (int k = 0; k < c; ++k) dx[i * c + k] = p[i * c + k] * (dp[i * c + k] - dot) * inv_t;
+    }
+}
+__global__ __launch_bounds__(EB) void onehot_kernel(const int64_t* __restrict__ label, float* __restrict__ y,
+                                                     int64_t pixels, int c) {
+    const int64_t stride = (int64_t)gridDim.x * EB;
+    for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < pixels; i += stride) {
+        const int l = (int)label[i];
+        for (int k = 0; k < c; ++k) y[i * c + k] = (k == l) ? 1.f : 0.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ losses
+__global__ __launch_bounds__(EB) void ce2d_partial_kernel(const float* __restrict__ logit,
+                                                           const int64_t* __restrict__ label, int64_t pixels, int c,
+                                                           double* __restrict__ partial) {
+    __shared__ double sm[8];
+    const int64_t stride = (int64_t)gridDim.x * EB;
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < pixels; i += stride) {
+        float v[MAXC];
+        float m = -INFINITY;
+        for (int k = 0; k < c; ++k) { v[k] = logit[i * c + k]; m = fmaxf(m, v[k]); }
+        float s = 0.f;
+        for (int k = 0; k < c; ++k) s += expf(v[k] - m);
+        const int l = (int)label[i];
+        float xl = 0.f;
+        for (int k = 0; k < c; ++k) xl = (k == l) ? v[k] : xl;
+        acc += (double)(-(xl - m - logf(s)));
+    }
+    acc = block_sum_double(acc, sm);
+    if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+}
+__global__ __launch_bounds__(EB) void scalar_finalize_kernel(const double* __restrict__ partial, int blocks, double mul,
+                                                              float* __restrict__ out) {
+    __shared__ double sm[8];
+    double s = 0.0;
+    for (int b = threadIdx.x; b < blocks; b += EB) s += partial[b];
+    s = block_sum_double(s, sm);
+    if (threadIdx.x == 0) out[0] = (float)(s * mul);
+}
+__global__ __launch_bounds__(EB) void ce2d_bwd_kernel(const float* __restrict__ logit, const int64_t* __restrict__ label,
+                                                       const float* __restrict__ gout, int64_t pixels, int c,
+                                                       float* __restrict__ dlogit) {
+    const float gs = gout[0] / (float)pixels;
+    const int64_t stride = (int64_t)gridDim.x * EB;
+    for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < pixels; i += stride) {
+        float v[MAXC];
+        float m = -INFINITY;
+        for (int k = 0; k < c; ++k) { v[k] = logit[i * c + k]; m = fmaxf(m, v[k]); }
+        float s = 0.f;
+        for (int k = 0; k < c; ++k) { v[k] = expf(v[k] - m); s += v[k]; }
+        const float r = 1.f / s;
+        const int l = (int)label[i];
+        for (int k = 0; k < c; ++k) dlogit[i * c + k] = gs * (v[k] * r - ((k == l) ? 1.f : 0.f));
+    }
+}
+__global__ __launch_bounds__(EB) void mse_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                          int64_t count, double* __restrict__ partial) {
+    __shared__ double sm[8];
+    const int64_t stride = (int64_t)gridDim.x * EB;
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < count; i += stride) {
+        const float d = a[i] - b[i];
+        acc += (double)(d * d);
+    }
+    acc = block_sum_double(acc, sm);
+    if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+}
+__global__ __launch_bounds__(EB) void mse_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                      const float* __restrict__ gout, int64_t count, float scale,
+                                                      float* __restrict__ da) {
+    const float gs = gout[0] * 2.f * scale / (float)count;
+    const int64_t stride = (int64_t)gridDim.x * EB;
+    for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < count; i += stride) da[i] = gs * (a[i] - b[i]);
+}
+__global__ __launch_bounds__(EB) void argmax_kernel(const float* __restrict__ logit, uint8_t* __restrict__ out,
+                                                     int64_t pixels, int c) {
+    const int64_t stride = (int64_t)gridDim.x * EB;
+    for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < pixels; i += stride) {
+        float best = logit[i * c];
+        int bi = 0;
+        for (int k = 1; k < c; ++k) {
+            const float v = logit[i * c + k];
+            if (v > best) { best = v; bi = k; }
+        }
+        out[i] = (uint8_t)bi;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ Adam
+__global__ __launch_bounds__(EB) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, int64_t count, float lr, float b1, float b2,
+                                                   float eps, float bc1, float bc2_sqrt, float gscale) {
+    // torch.optim.Adam (no amsgrad, no weight decay): denom = sqrt(v)/sqrt(bc2) + eps; p -= lr/bc1 * m/denom
+    const int64_t stride = (int64_t)gridDim.x * EB;
+    const float step_size = lr / bc1;
+    for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < count; i += stride) {
+        const float gi = g[i] * gscale;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = p[i] - step_size * (mi / denom);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ launchers
+#define S_ (hipStream_t) stream
+
+extern "C" int ctl_bn_finalize(const float* partial, int32_t blocks, int32_t c, int64_t count, const float* gamma,
+                               const float* beta, float eps, float momentum, int32_t update_running,
+                               float* running_mean, float* running_var, int64_t* nbt, float* scale, float* shift,
+                               float* save_mean, float* save_invstd, ctl_stream stream) {
+    CTL_REQUIRE(partial && gamma && beta && scale && shift && blocks > 0 && c > 0 && count > 0, "bn_finalize: bad arguments");
+    CTL_REQUIRE(!update_running || (running_mean && running_var), "bn_finalize: update_running without buffers");
+    bn_finalize_kernel<<<dim3(c), dim3(EB), 0, S_>>>(partial, blocks, c, (double)count, gamma, beta, eps, momentum,
+                                                      update_running, running_mean, running_var, nbt, scale, shift,
+                                                      save_mean, save_invstd);
+    CTL_LAUNCH_CHECK("bn_finalize");
+    return CTL_OK;
+}
+extern "C" int ctl_bn_eval_coeffs(int32_t c, const float* gamma, const float* beta, const float* rm, const float* rv,
+                                  float eps, float* scale, float* shift, ctl_stream stream) {
+    CTL_REQUIRE(c > 0 && gamma && beta && rm && rv && scale && shift, "bn_eval_coeffs: bad arguments");
+    bn_eval_kernel<<<dim3(ctl_cdiv(c, 64)), dim3(64), 0, S_>>>(c, gamma, beta, rm, rv, eps, scale, shift);
+    CTL_LAUNCH_CHECK("bn_eval_coeffs");
+    return CTL_OK;
+}
+extern "C" int ctl_bn_act(const float* x, const float* scale, const float* shift, float slope, float* y, int64_t pixels,
+                          int32_t c, ctl_stream stream) {
+    CTL_REQUIRE(x && y && scale && shift && c % 4 == 0 && pixels > 0, "bn_act: bad arguments (c must be a multiple of 4)");
+    const int64_t quads = pixels * (c / 4);
+    bn_act_kernel<<<dim3(stream_blocks(quads)), dim3(EB), 0, S_>>>((const f32x4*)x, (const f32x4*)scale,
+                                                                   (const f32x4*)shift, slope, (f32x4*)y, quads, c / 4);
+    CTL_LAUNCH_CHECK("bn_act");
+    return CTL_OK;
+}
+static bool red_c_ok(int c) { return c >= 4 && c % 4 == 0 && (EB % (c / 4)) == 0; }
+
+extern "C" int ctl_bwd_reduce(int32_t mode, const float* dy, const float* act_src, const float* bn_src,
+                              const float* scale, const float* shift, float slope, int64_t pixels, int32_t c,
+                              float* partial, ctl_stream stream) {
+    CTL_REQUIRE(dy && partial && pixels > 0 && red_c_ok(c), "bwd_reduce: bad arguments (c=%d)", c);
+    const int64_t quads = pixels * (c / 4);
+    const dim3 grid(CTL_RED_BLOCKS), blk(EB);
+    if (mode == 0) {
+        CTL_REQUIRE(act_src && bn_src, "bwd_reduce mode 0 needs act_src and bn_src");
+        bwd_reduce_kernel<0><<<grid, blk, 0, S_>>>((const f32x4*)dy, (const f32x4*)act_src, (const f32x4*)bn_src, nullptr,
+                                                  nullptr, slope, quads, c / 4, partial);
+    } else if (mode == 1) {
+        CTL_REQUIRE(bn_src && scale && shift, "bwd_reduce mode 1 needs bn_src, scale, shift");
+        bwd_reduce_kernel<1><<<grid, blk, 0, S_>>>((const f32x4*)dy, nullptr, (const f32x4*)bn_src, (const f32x4*)scale,
+                                                  (const f32x4*)shift, slope, quads, c / 4, partial);
+    } else if (mode == 2) {
+        bwd_reduce_kernel<2><<<grid, blk, 0, S_>>>((const f32x4*)dy, nullptr, nullptr, nullptr, nullptr, slope, quads,
+                                                  c / 4, partial);
+    } else {
+        CTL_FAIL(CTL_EINVAL, "bwd_reduce: mode %d", mode);
+    }
+    CTL_LAUNCH_CHECK("bwd_reduce");
+    return CTL_OK;
+}
+extern "C" int ctl_bn_bwd_finalize(const float* partial, int32_t c, int64_t count, const float* gamma,
+                                   const float* save_mean, const float* save_invstd, float* coef, float* dgamma,
+                                   float* dbeta, int32_t accumulate, ctl_stream stream) {
+    CTL_REQUIRE(partial && gamma && save_mean && save_invstd && coef && c > 0 && count > 0, "bn_bwd_finalize: bad arguments");
+    bn_bwd_finalize_kernel<<<dim3(c), dim3(EB), 0, S_>>>(partial, CTL_RED_BLOCKS, c, (double)count, gamma, save_mean,
+                                                          save_invstd, coef, dgamma, dbeta, accumulate);
+    CTL_LAUNCH_CHECK("bn_bwd_finalize");
+    return CTL_OK;
+}
+extern "C" int ctl_bwd_apply(int32_t mode, const float* dy, const float* act_src, const float* bn_src,
+                             const float* scale, const float* shift, float slope, const float* coef, int64_t pixels,
+                             int32_t c, float* ds, float* dx, ctl_stream stream) {
+    CTL_REQUIRE(dy && bn_src && coef && dx && pixels > 0 && c % 4 == 0, "bwd_apply: bad arguments");
+    const int64_t quads = pixels * (c / 4);
+    const dim3 grid(stream_blocks(quads)), blk(EB);
+    if (mode == 0) {
+        CTL_REQUIRE(act_src, "bwd_apply mode 0 needs act_src");
+        bwd_apply_kernel<0><<<grid, blk, 0, S_>>>((const f32x4*)dy, (const f32x4*)act_src, (const f32x4*)bn_src, nullptr,
+                                                 nullptr, slope, (const f32x4*)coef, quads, c / 4, (f32x4*)ds, (f32x4*)dx);
+    } else if (mode == 1) {
+        CTL_REQUIRE(scale && shift, "bwd_apply mode 1 needs scale and shift");
+        bwd_apply_kernel<1><<<grid, blk, 0, S_>>>((const f32x4*)dy, nullptr, (const f32x4*)bn_src, (const f32x4*)scale,
+                                                 (const f32x4*)shift, slope, (const f32x4*)coef, quads, c / 4, nullptr,
+                                                 (f32x4*)dx);
+    } else {
+        CTL_FAIL(CTL_EINVAL, "bwd_apply: mode %d", mode);
+    }
+    CTL_LAUNCH_CHECK("bwd_apply");
+    return CTL_OK;
+}
+extern "C" int ctl_chan_sum_finalize(const float* partial, int32_t c, float* out, int32_t accumulate, ctl_stream stream) {
+    CTL_REQUIRE(partial && out && c > 0, "chan_sum_finalize: bad arguments");
+    chan_sum_finalize_kernel<<<dim3(c), dim3(EB), 0, S_>>>(partial, CTL_RED_BLOCKS, c, out, accumulate);
+    CTL_LAUNCH_CHECK("chan_sum_finalize");
+    return CTL_OK;
+}
+extern "C" int ctl_sumpool2(const float* dup, float* dx, int32_t n, int32_t h, int32_t w, int32_t c, int32_t accumulate,
+                            ctl_stream stream) {
+    CTL_REQUIRE(dup && dx && n > 0 && h > 0 && w > 0 && c % 4 == 0, "sumpool2: bad arguments");
+    const int64_t quads = (int64_t)n * h * w * (c / 4);
+    sumpool2_kernel<<<dim3(stream_blocks(quads)), dim3(EB), 0, S_>>>((const f32x4*)dup, (f32x4*)dx, n, h, w, c / 4, accumulate);
+    CTL_LAUNCH_CHECK("sumpool2");
+    return CTL_OK;
+}
+extern "C" int ctl_sigmoid_bwd(const float* dy, const float* y, float* dx, int64_t count, ctl_stream stream) {
+    CTL_REQUIRE(dy && y && dx && count > 0, "sigmoid_bwd: bad arguments");
+    sigmoid_bwd_kernel<<<dim3(stream_blocks(count)), dim3(EB), 0, S_>>>(dy, y, dx, count);
+    CTL_LAUNCH_CHECK("sigmoid_bwd");
+    return CTL_OK;
+}
+extern "C" int ctl_softmax_t_fwd(const float* x, float inv_t, float* p, int64_t pixels, int32_t c, ctl_stream stream) {
+    CTL_REQUIRE(x && p && pixels > 0 && c > 0 && c <= MAXC, "softmax_t_fwd: bad arguments");
+    softmax_t_fwd_kernel<<<dim3(stream_blocks(pixels)), dim3(EB), 0, S_>>>(x, inv_t, p, pixels, c);
+    CTL_LAUNCH_CHECK("softmax_t_fwd");
+    return CTL_OK;
+}
+extern "C" int ctl_softmax_t_bwd(const float* p, const float* dp, float inv_t, float* dx, int64_t pixels, int32_t c,
+                                 ctl_stream stream) {
+    CTL_REQUIRE(p && dp && dx && pixels > 0 && c > 0 && c <= MAXC, "softmax_t_bwd: bad arguments");
+    softmax_t_bwd_kernel<<<dim3(stream_blocks(pixels)), dim3(EB), 0, S_>>>(p, dp, inv_t, dx, pixels, c);
+    CTL_LAUNCH_CHECK("softmax_t_bwd");
+    return CTL_OK;
+}
+extern "C" int ctl_onehot(const int64_t* label, float* y, int64_t pixels, int32_t c, ctl_stream stream) {
+    CTL_REQUIRE(label && y && pixels > 0 && c > 0, "onehot: bad arguments");
+    onehot_kernel<<<dim3(stream_blocks(pixels)), dim3(EB), 0, S_>>>(label, y, pixels, c);
+    CTL_LAUNCH_CHECK("onehot");
+    return CTL_OK;
+}
+extern "C" int ctl_ce2d_fwd(const float* logit, const int64_t* label, int64_t pixels, int32_t c, double* partial,
+                            float* loss, ctl_stream stream) {
+    CTL_REQUIRE(logit && label && partial && loss && pixels > 0 && c > 0 && c <= MAXC, "ce2d_fwd: bad arguments");
+    ce2d_partial_kernel<<<dim3(CTL_RED_BLOCKS), dim3(EB), 0, S_>>>(logit, label, pixels, c, partial);
+    scalar_finalize_kernel<<<dim3(1), dim3(EB), 0, S_>>>(partial, CTL_RED_BLOCKS, 1.0 / (double)pixels, loss);
+    CTL_LAUNCH_CHECK("ce2d_fwd");
+    return CTL_OK;
+}
+extern "C" int ctl_ce2d_bwd(const float* logit, const int64_t* label, const float* gout, int64_t pixels, int32_t c,
+                            float* dlogit, ctl_stream stream) {
+    CTL_REQUIRE(logit && label && gout && dlogit && pixels > 0 && c > 0 && c <= MAXC, "ce2d_bwd: bad arguments");
+    ce2d_bwd_kernel<<<dim3(stream_blocks(pixels)), dim3(EB), 0, S_>>>(logit, label, gout, pixels, c, dlogit);
+    CTL_LAUNCH_CHECK("ce2d_bwd");
+    return CTL_OK;
+}
+extern "C" int ctl_mse_fwd(const float* a, const float* b, int64_t count, float scale, double* partial, float* loss,
+                           ctl_stream stream) {
+    CTL_REQUIRE(a && b && partial && loss && count > 0, "mse_fwd: bad arguments");
+    mse_partial_kernel<<<dim3(CTL_RED_BLOCKS), dim3(EB), 0, S_>>>(a, b, count, partial);
+    scalar_finalize_kernel<<<dim3(1), dim3(EB), 0, S_>>>(partial, CTL_RED_BLOCKS, (double)scale / (double)count, loss);
+    CTL_LAUNCH_CHECK("mse_fwd");
+    return CTL_OK;
+}
+extern "C" int ctl_mse_bwd(const float* a, const float* b, const float* gout, int64_t count, float scale, float* da,
+                           ctl_stream stream) {
+    CTL_REQUIRE(a && b && gout && da && count > 0, "mse_bwd: bad arguments");
+    mse_bwd_kernel<<<dim3(stream_blocks(count)), dim3(EB), 0, S_>>>(a, b, gout, count, scale, da);
+    CTL_LAUNCH_CHECK("mse_bwd");
+    return CTL_OK;
+}
+extern "C" int ctl_argmax_c(const float* logit, uint8_t* out, int64_t pixels, int32_t c, ctl_stream stream) {
+    CTL_REQUIRE(logit && out && pixels > 0 && c > 0 && c < 256, "argmax_c: bad arguments");
+    argmax_kernel<<<dim3(stream_blocks(pixels)), dim3(EB), 0, S_>>>(logit, out, pixels, c);
+    CTL_LAUNCH_CHECK("argmax_c");
+    return CTL_OK;
+}
+extern "C" int ctl_adam(float* p, const float* g, float* m, float* v, int64_t count, float lr, float beta1, float beta2,
+                        float eps, int32_t step, float grad_scale, ctl_stream stream) {
+    CTL_REQUIRE(p && g && m && v && count > 0 && step >= 1, "adam: bad arguments");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    adam_kernel<<<dim3(stream_blocks(count)), dim3(EB), 0, S_>>>(p, g, m, v, count, lr, beta1, beta2, eps, (float)bc1,
+                                                                 (float)sqrt(bc2), grad_scale);
+    CTL_LAUNCH_CHECK("adam");
+    return CTL_OK;
+}

@@ -1,0 +1,229 @@
+// Latent-space hard-example generator, device side (reference: medseg/models/model_util.py:224-249 channel-wise,
+// 285-312 spatial-wise; F.dropout2d branch of model.py:333).
+//
+//   score  : signed mean of dL/dz over H*W (channel mode) or over C (spatial mode)        -- pass 1 over grad
+//   select : entry i is masked  <=>  score_i > sort(score, desc)[k]  <=>  #{j : score_j >= score_i} <= k
+//            (strict '>' of the reference, exact under ties; no sort: each block ranks only the entries it applies)
+//   apply  : masked = code * mask (mask broadcast over H*W or over C)                     -- pass 1 over code, 1 write
+//
+// HBM traffic = read grad + read code + write masked = 3*N*C*H*W*4 bytes (+ the tiny score/mask vectors): the kernels
+// are pure streams, 16 B per lane, coalesced NHWC.  At the configured size (16x128x16x16 = 2 MiB per tensor) everything
+// sits in L2/Infinity Cache and the pair is launch-latency bound; bench.py sweeps sizes to show the HBM-bound regime.
+#include "ctl_common.h"
+
+#define MB 256
+#define SCORE_SPLIT_PIX 64      // pixels per block in the channel-mode score pass
+
+// ---- channel mode, pass 1: partial[n][split][c] = sum over the split's pixels of grad[n][pix][c]
+__global__ __launch_bounds__(MB) void score_channel_partial_kernel(const f32x4* __restrict__ grad,
+                                                                    float* __restrict__ partial, int hw, int cq,
+                                                                    int splits) {
+    __shared__ f32x4 sm[MB];
+    const int n = blockIdx.y, sp = blockIdx.x;
+    const int q = threadIdx.x % cq;              // MB % cq == 0 (checked on the host)
+    const int prow = threadIdx.x / cq;           // pixel lane inside the block
+    const int ppb = MB / cq;                     // pixels in flight per iteration
+    const int p0 = sp * SCORE_SPLIT_PIX;
+    const int p1 = min(hw, p0 + SCORE_SPLIT_PIX);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int pix = p0 + prow; pix < p1; pix += ppb) {
+        const f32x4 v = grad[((int64_t)n * hw + pix) * cq + q];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < cq) {
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+        for (int k = threadIdx.x; k < MB; k += cq) { const f32x4 v = sm[k]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+        reinterpret_cast<f32x4*>(partial)[((int64_t)n * splits + sp) * cq + threadIdx.x] = t;
+    }
+}
+__global__ void score_channel_finalize_kernel(const float* __restrict__ partial, float* __restrict__ score, int c,
+                                              int splits, float inv_count) {
+    const int n = blockIdx.y;
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    float s = 0.f;
+    for (int sp = 0; sp < splits; ++sp) s += partial[((int64_t)n * splits + sp) * c + ch];
+    score[(int64_t)n * c + ch] = s * inv_count;
+}
+
+// ---- spatial mode: score[n][pix] = mean over c; a group of cq lanes (cq | 64) owns one pixel
+__global__ __launch_bounds__(MB) void score_spatial_kernel(const f32x4* __restrict__ grad, float* __restrict__ score,
+                                                            int64_t pixels, int cq, float inv_count) {
+    const int ppb = MB / cq;
+    const int q = threadIdx.x % cq, prow = threadIdx.x / cq;
+    const int64_t stride = (int64_t)gridDim.x * ppb;
+    const int64_t npad = ctl_cdiv64(pixels, stride) * stride;      // keep whole waves converged for the shuffles
+    for (int64_t pix = (int64_t)blockIdx.x * ppb + prow; pix < npad; pix += stride) {
+        float s = 0.f;
+        if (pix < pixels) {
+            const f32x4 v = grad[pix * cq + q];
+            s = (v.x + v.y) + (v.z + v.w);
+        }
+        for (int o = cq >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (q == 0 && pix < pixels) score[pix] = s * inv_count;
+    }
+}
+
+// ---- select + apply
+// grid (slabs, n).  LDS holds the image's whole score row (L <= 8192 floats).
+template <int MODE>
+__global__ __launch_bounds__(MB) void mask_apply_kernel(const f32x4* __restrict__ code, const float* __restrict__ score,
+                                                         const float* __restrict__ soft_noise, int k_host,
+                                                         const int* __restrict__ k_dev, f32x4* __restrict__ masked,
+                                                         float* __restrict__ mask_out, int hw, int cq, int slab_pix) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int c = cq * 4;
+    const int L = (MODE == 0) ? c : hw;
+    float* srow = sm;            // [L] scores
+    float* mval = sm + L;        // [c] (channel) or [slab_pix] (spatial) mask values
+    const int n = blockIdx.y;
+    const int k = k_dev ? k_dev[0] : k_host;
+    const int p0 = blockIdx.x * slab_pix;
+    const int p1 = min(hw, p0 + slab_pix);
+    for (int i = threadIdx.x; i < L; i += MB) srow[i] = score[(int64_t)n * L + i];
+    __syncthreads();
+    const int first = (MODE == 0) ? 0 : p0;
+    const int count = (MODE == 0) ? c : (p1 - p0);
+    for (int e = threadIdx.x; e < count; e += MB) {
+        const int i = first + e;
+        const float si = srow[i];
+        int ge = 0;
+        for (int j = 0; j < L; ++j) ge += (srow[j] >= si) ? 1 : 0;
+        float mv = 1.f;
+        if (ge <= k) mv = soft_noise ? 0.5f * soft_noise[(int64_t)n * L + i] : 0.f;
+        mval[e] = mv;
+        if (MODE == 1 || blockIdx.x == 0) mask_out[(int64_t)n * L + i] = mv;
+    }
+    __syncthreads();
+    const int64_t base = ((int64_t)n * hw + p0) * cq;
+    const int quads = (p1 - p0) * cq;
+    for (int e = threadIdx.x; e < quads; e += MB) {
+        f32x4 v = code[base + e];
+        if (MODE == 0) {
+            const f32x4 m = reinterpret_cast<const f32x4*>(mval)[e % cq];
+            v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
+        } else {
+            const float m = mval[e / cq];
+            v.x *= m; v.y *= m; v.z *= m; v.w *= m;
+        }
+        masked[base + e] = v;
+    }
+}
+
+// ---- dropout2d and uniform noise from a counter hash (splitmix64): stateless, graph-replay safe given a seed buffer
+__device__ __forceinline__ float hash_uniform(uint64_t seed, uint64_t idx) {
+    uint64_t z = seed + (idx + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (float)(z >> 40) * (1.0f / 16777216.0f);   // 24 random bits -> [0,1)
+}
+__global__ __launch_bounds__(MB) void dropout2d_kernel(const f32x4* __restrict__ z, const float* __restrict__ keep,
+                                                        uint64_t seed, float p, f32x4* __restrict__ out,
+                                                        float* __restrict__ keep_out, int hw, int cq, int slab_pix) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];     // [c] multipliers
+    const int c = cq * 4, n = blockIdx.y;
+    const float inv = 1.f / (1.f - p);
+    for (int ch = threadIdx.x; ch < c; ch += MB) {
+        float kp = keep ? keep[(int64_t)n * c + ch] : (hash_uniform(seed, (uint64_t)n * c + ch) >= p ? 1.f : 0.f);
+        if (keep_out && blockIdx.x == 0) keep_out[(int64_t)n * c + ch] = kp;
+        sm[ch] = kp * inv;
+    }
+    __syncthreads();
+    const int p0 = blockIdx.x * slab_pix, p1 = min(hw, p0 + slab_pix);
+    const int64_t base = ((int64_t)n * hw + p0) * cq;
+    const int quads = (p1 - p0) * cq;
+    for (int e = threadIdx.x; e < quads; e += MB) {
+        f32x4 v = z[base + e];
+        const f32x4 m = reinterpret_cast<const f32x4*>(sm)[e % cq];
+        v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
+        out[base + e] = v;
+    }
+}
+__global__ __launch_bounds__(MB) void uniform_kernel(float* __restrict__ out, int64_t count, uint64_t seed) {
+    const int64_t stride = (int64_t)gridDim.x * MB;
+    for (int64_t i = (int64_t)blockIdx.x * MB + threadIdx.x; i < count; i += stride) out[i] = hash_uniform(seed, (uint64_t)i);
+}
+
+// ------------------------------------------------------------------------------------------------ launchers
+static bool cq_ok(int c) { return c >= 4 && c % 4 == 0 && (c / 4) <= 64 && (64 % (c / 4)) == 0; }
+static int slab_pixels(int n, int hw, int c) {
+    // ~16 KiB of code per block, but at least ~1024 blocks when the problem is large enough
+    int sp = (16 * 1024) / (c * 4);
+    if (sp < 1) sp = 1;
+    while (sp > 1 && (int64_t)n * ctl_cdiv(hw, sp) < 512) sp >>= 1;
+    return sp;
+}
+
+extern "C" size_t ctl_latent_score_ws_floats(int32_t mode, int32_t n, int32_t hw, int32_t c) {
+    return mode == 0 ? (size_t)n * ctl_cdiv(hw, SCORE_SPLIT_PIX) * c : 0;
+}
+
+extern "C" int ctl_latent_score(int32_t mode, const float* grad, float* score, float* scratch, int32_t n, int32_t hw,
+                                int32_t c, ctl_stream stream) {
+    CTL_REQUIRE(grad && score && n > 0 && hw > 0 && cq_ok(c), "latent_score: bad arguments (c=%d)", c);
+    hipStream_t s = (hipStream_t)stream;
+    const int cq = c / 4;
+    if (mode == 0) {
+        CTL_REQUIRE(scratch, "latent_score: channel mode needs scratch");
+        const int splits = ctl_cdiv(hw, SCORE_SPLIT_PIX);
+        score_channel_partial_kernel<<<dim3(splits, n), dim3(MB), 0, s>>>((const f32x4*)grad, scratch, hw, cq, splits);
+        score_channel_finalize_kernel<<<dim3(ctl_cdiv(c, 64), n), dim3(64), 0, s>>>(scratch, score, c, splits, 1.f / (float)hw);
+    } else if (mode == 1) {
+        const int64_t pixels = (int64_t)n * hw;
+        const int ppb = MB / cq;
+        int64_t blocks = ctl_cdiv64(pixels, ppb);
+        if (blocks > 2048) blocks = 2048;
+        score_spatial_kernel<<<dim3((unsigned)blocks), dim3(MB), 0, s>>>((const f32x4*)grad, score, pixels, cq, 1.f / (float)c);
+    } else {
+        CTL_FAIL(CTL_EINVAL, "latent_score: mode %d", mode);
+    }
+    CTL_LAUNCH_CHECK("latent_score");
+    return CTL_OK;
+}
+
+extern "C" int ctl_latent_mask_apply(int32_t mode, const float* code, const float* score, const float* soft_noise,
+                                     int32_t k_host, const int32_t* k_dev, float* masked, float* mask_out, int32_t n,
+                                     int32_t hw, int32_t c, ctl_stream stream) {
+    CTL_REQUIRE(code && score && masked && mask_out && n > 0 && hw > 0 && cq_ok(c), "latent_mask_apply: bad arguments");
+    const int L = mode == 0 ? c : hw;
+    CTL_REQUIRE(L <= 8192, "latent_mask_apply: row length %d > 8192", L);
+    CTL_REQUIRE(k_dev || (k_host >= 0 && k_host < L), "latent_mask_apply: k=%d out of range [0,%d)", k_host, L);
+    hipStream_t s = (hipStream_t)stream;
+    const int sp = slab_pixels(n, hw, c);
+    const dim3 grid(ctl_cdiv(hw, sp), n);
+    if (mode == 0) {
+        const size_t lds = (size_t)(L + c) * sizeof(float);
+        mask_apply_kernel<0><<<grid, dim3(MB), lds, s>>>((const f32x4*)code, score, soft_noise, k_host, k_dev,
+                                                        (f32x4*)masked, mask_out, hw, c / 4, sp);
+    } else if (mode == 1) {
+        const size_t lds = (size_t)(L + sp) * sizeof(float);
+        mask_apply_kernel<1><<<grid, dim3(MB), lds, s>>>((const f32x4*)code, score, soft_noise, k_host, k_dev,
+                                                        (f32x4*)masked, mask_out, hw, c / 4, sp);
+    } else {
+        CTL_FAIL(CTL_EINVAL, "latent_mask_apply: mode %d", mode);
+    }
+    CTL_LAUNCH_CHECK("latent_mask_apply");
+    return CTL_OK;
+}
+
+extern "C" int ctl_dropout2d(const float* z, const float* keep, uint64_t seed, float p, float* out, float* keep_out,
+                             int32_t n, int32_t hw, int32_t c, ctl_stream stream) {
+    CTL_REQUIRE(z && out && n > 0 && hw > 0 && cq_ok(c) && p >= 0.f && p < 1.f, "dropout2d: bad arguments");
+    const int sp = slab_pixels(n, hw, c);
+    dropout2d_kernel<<<dim3(ctl_cdiv(hw, sp), n), dim3(MB), (size_t)c * sizeof(float), (hipStream_t)stream>>>(
+        (const f32x4*)z, keep, seed, p, (f32x4*)out, keep_out, hw, c / 4, sp);
+    CTL_LAUNCH_CHECK("dropout2d");
+    return CTL_OK;
+}
+
+extern "C" int ctl_uniform(float* out, int64_t count, uint64_t seed, ctl_stream stream) {
+    CTL_REQUIRE(out && count > 0, "uniform: bad arguments");
+    int64_t blocks = ctl_cdiv64(count, MB);
+    if (blocks > 2048) blocks = 2048;
+    uniform_kernel<<<dim3((unsigned)blocks), dim3(MB), 0, (hipStream_t)stream>>>(out, count, seed);
+    CTL_LAUNCH_CHECK("uniform");
+    return CTL_OK;
+}

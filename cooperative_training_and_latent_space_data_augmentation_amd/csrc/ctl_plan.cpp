@@ -1,0 +1,119 @@
+// Plan executor: runs an array of ctl_op on one HIP stream (one C call per network pass), plus the library's
+// version / error plumbing.  No allocation, no synchronisation: safe under hipStreamBeginCapture.
+//
+// Tensor slots per op kind (index into op.slot/op.off):
+//   CONV              0 x  1 wpack  2 bias  3 pro_scale  4 pro_shift  5 res  6 res_scale  7 res_shift  8 y  9 stats_partial
+//   WGRAD             0 x  1 pro_scale  2 pro_shift  3 dy  4 w_partial  5 b_partial
+//   WGRAD_REDUCE      0 w_partial  1 b_partial  2 dw  3 dbias            i[23]=accumulate  l[0..3]=s_co,s_ci,s_kh,s_kw
+//   PACK              0 src  1 dst                                       i[0..3]=cout,cin,ks,flip  l[0..3]=strides
+//   BN_FINALIZE       0 partial 1 gamma 2 beta 3 running_mean 4 running_var 5 nbt 6 scale 7 shift 8 save_mean 9 save_invstd
+//                                                                        i[0..2]=blocks,c,update_running l[0]=count f[0]=eps f[1]=momentum
+//   BN_EVAL           0 gamma 1 beta 2 running_mean 3 running_var 4 scale 5 shift      i[0]=c f[0]=eps
+//   BN_ACT            0 x 1 scale 2 shift 3 y                            i[0]=c l[0]=pixels f[0]=slope
+//   BWD_REDUCE        0 dy 1 act_src 2 bn_src 3 scale 4 shift 5 partial  i[0]=mode i[1]=c l[0]=pixels f[0]=slope
+//   BN_BWD_FINALIZE   0 partial 1 gamma 2 save_mean 3 save_invstd 4 coef 5 dgamma 6 dbeta   i[0]=c i[1]=accumulate l[0]=count
+//   BWD_APPLY         0 dy 1 act_src 2 bn_src 3 scale 4 shift 5 coef 6 ds 7 dx   i[0]=mode i[1]=c l[0]=pixels f[0]=slope
+//   CHAN_SUM_FINALIZE 0 partial 1 out                                    i[0]=c i[1]=accumulate
+//   SUMPOOL2          0 dup 1 dx                                         i[0..4]=n,h,w,c,accumulate
+//   SIGMOID_BWD       0 dy 1 y 2 dx                                      l[0]=count
+//   ZERO              0 ptr                                              l[0]=bytes
+#include <stdarg.h>
+#include <string.h>
+
+#include "ctl_common.h"
+
+static thread_local char g_err[512] = "";
+
+void ctl_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" int ctl_version(void) { return 1; }
+extern "C" const char* ctl_last_error(void) { return g_err; }
+extern "C" size_t ctl_sizeof_op(void) { return sizeof(ctl_op); }
+extern "C" size_t ctl_sizeof_conv(void) { return sizeof(ctl_conv); }
+
+static_assert(sizeof(ctl_conv) == 22 * 4, "ctl_conv must be 22 32-bit words (it is embedded in ctl_op.i)");
+
+extern "C" int ctl_plan_run(const ctl_op* ops, int32_t n_ops, void* const* bases, int32_t n_bases, ctl_stream stream) {
+    CTL_REQUIRE(ops && bases && n_ops >= 0, "plan_run: null arguments");
+    for (int32_t k = 0; k < n_ops; ++k) {
+        const ctl_op& op = ops[k];
+        void* t[CTL_OP_MAX_T];
+        for (int a = 0; a < CTL_OP_MAX_T; ++a) {
+            const int s = op.slot[a];
+            if (s < 0) { t[a] = nullptr; continue; }
+            CTL_REQUIRE(s < n_bases && bases[s], "plan_run: op %d arg %d uses empty slot %d", k, a, s);
+            t[a] = (char*)bases[s] + op.off[a];
+        }
+#define F(a) ((float*)t[a])
+#define CF(a) ((const float*)t[a])
+        int rc = CTL_OK;
+        ctl_conv d;
+        switch (op.kind) {
+            case CTL_OP_CONV:
+                memcpy(&d, op.i, sizeof(d));
+                rc = ctl_conv_forward(&d, CF(0), CF(1), CF(2), CF(3), CF(4), CF(5), CF(6), CF(7), F(8), F(9), stream);
+                break;
+            case CTL_OP_WGRAD:
+                memcpy(&d, op.i, sizeof(d));
+                rc = ctl_conv_wgrad(&d, CF(0), CF(1), CF(2), CF(3), F(4), F(5), stream);
+                break;
+            case CTL_OP_WGRAD_REDUCE:
+                memcpy(&d, op.i, sizeof(d));
+                rc = ctl_wgrad_reduce(&d, CF(0), CF(1), F(2), op.l[0], op.l[1], op.l[2], op.l[3], F(3), op.i[23], stream);
+                break;
+            case CTL_OP_PACK:
+                rc = ctl_pack_weights(CF(0), F(1), op.i[0], op.i[1], op.i[2], op.l[0], op.l[1], op.l[2], op.l[3], op.i[3], stream);
+                break;
+            case CTL_OP_BN_FINALIZE:
+                rc = ctl_bn_finalize(CF(0), op.i[0], op.i[1], op.l[0], CF(1), CF(2), op.f[0], op.f[1], op.i[2], F(3), F(4),
+                                     (int64_t*)t[5], F(6), F(7), F(8), F(9), stream);
+                break;
+            case CTL_OP_BN_EVAL:
+                rc = ctl_bn_eval_coeffs(op.i[0], CF(0), CF(1), CF(2), CF(3), op.f[0], F(4), F(5), stream);
+                break;
+            case CTL_OP_BN_ACT:
+                rc = ctl_bn_act(CF(0), CF(1), CF(2), op.f[0], F(3), op.l[0], op.i[0], stream);
+                break;
+            case CTL_OP_BWD_REDUCE:
+                rc = ctl_bwd_reduce(op.i[0], CF(0), CF(1), CF(2), CF(3), CF(4), op.f[0], op.l[0], op.i[1], F(5), stream);
+                break;
+            case CTL_OP_BN_BWD_FINALIZE:
+                rc = ctl_bn_bwd_finalize(CF(0), op.i[0], op.l[0], CF(1), CF(2), CF(3), F(4), F(5), F(6), op.i[1], stream);
+                break;
+            case CTL_OP_BWD_APPLY:
+                rc = ctl_bwd_apply(op.i[0], CF(0), CF(1), CF(2), CF(3), CF(4), op.f[0], CF(5), op.l[0], op.i[1], F(6), F(7), stream);
+                break;
+            case CTL_OP_CHAN_SUM_FINALIZE:
+                rc = ctl_chan_sum_finalize(CF(0), op.i[0], F(1), op.i[1], stream);
+                break;
+            case CTL_OP_SUMPOOL2:
+                rc = ctl_sumpool2(CF(0), F(1), op.i[0], op.i[1], op.i[2], op.i[3], op.i[4], stream);
+                break;
+            case CTL_OP_SIGMOID_BWD:
+                rc = ctl_sigmoid_bwd(CF(0), CF(1), F(2), op.l[0], stream);
+                break;
+            case CTL_OP_ZERO: {
+                CTL_REQUIRE(t[0] && op.l[0] > 0, "plan_run: op %d ZERO needs a pointer and a size", k);
+                hipError_t e = hipMemsetAsync(t[0], 0, (size_t)op.l[0], (hipStream_t)stream);
+                if (e != hipSuccess) CTL_FAIL(CTL_ELAUNCH, "plan_run: memset: %s", hipGetErrorString(e));
+                break;
+            }
+            default:
+                CTL_FAIL(CTL_EINVAL, "plan_run: op %d has unknown kind %d", k, op.kind);
+        }
+#undef F
+#undef CF
+        if (rc != CTL_OK) {
+            char msg[400];
+            snprintf(msg, sizeof(msg), "%s", g_err);
+            ctl_set_error("plan_run: op %d (kind %d) failed: %s", k, op.kind, msg);
+            return rc;
+        }
+    }
+    return CTL_OK;
+}

@@ -1,0 +1,224 @@
+"""Thin tensor-level wrappers over the C-ABI (one call = one kernel enqueue on torch's current stream).
+
+PyTorch is used here only for device memory and the stream handle.  4-D activations are logical NCHW tensors in
+``torch.channels_last`` memory format, i.e. NHWC in HBM, which is what every kernel expects.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _ffi
+from ._ffi import lib, check
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def require_gpu(*ts: torch.Tensor) -> None:
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _ffi.CtlError("the HIP path needs device tensors (got a CPU tensor); there is no CPU fallback")
+
+
+def as_nhwc(x: torch.Tensor) -> torch.Tensor:
+    """Logical NCHW tensor whose memory is NHWC (no copy if it already is)."""
+    if x.dim() != 4:
+        raise ValueError("expected a 4-D NCHW tensor")
+    return x.float().contiguous(memory_format=torch.channels_last)
+
+
+def empty_nhwc(n: int, c: int, h: int, w: int, device) -> torch.Tensor:
+    return torch.empty((n, c, h, w), dtype=torch.float32, device=device, memory_format=torch.channels_last)
+
+
+# ---------------------------------------------------------------------------------------------- conv (unit-level API)
+def pack_weights(src: torch.Tensor, cout: int, cin: int, ks: int, strides, flip: bool, src_offset: int = 0) -> torch.Tensor:
+    require_gpu(src)
+    n = lib.ctl_conv_wpack_floats(cin, cout, ks)
+    dst = torch.empty(n, dtype=torch.float32, device=src.device)
+    check(lib.ctl_pack_weights(src.data_ptr() + 4 * src_offset, dst.data_ptr(), cout, cin, ks, *[int(s) for s in strides],
+                               int(flip), stream_ptr()), "ctl_pack_weights")
+    return dst
+
+
+def pack_oihw_fwd(w: torch.Tensor) -> torch.Tensor:
+    co, ci, ks, _ = w.shape
+    return pack_weights(w.contiguous(), co, ci, ks, (ci * ks * ks, ks * ks, ks, 1), False)
+
+
+def pack_oihw_dgrad(w: torch.Tensor) -> torch.Tensor:
+    co, ci, ks, _ = w.shape
+    return pack_weights(w.contiguous(), ci, co, ks, (ks * ks, ci * ks * ks, ks, 1), True)
+
+
+def conv_forward(d: np.ndarray, x, wpack, bias=None, pro_scale=None, pro_shift=None, res=None, res_scale=None,
+                 res_shift=None, y=None, want_stats=False):
+    """Run one conv problem described by the ctl_conv record `d`.  Returns (y, stats_partial or None)."""
+    require_gpu(x, wpack)
+    n, cout, oh, ow = int(d["n"]), int(d["cout"]), int(d["out_h"]), int(d["out_w"])
+    if y is None:
+        y = empty_nhwc(n, cout, oh, ow, x.device)
+    stats = None
+    if want_stats:
+        stats = torch.empty(lib.ctl_conv_stats_floats(_ffi.desc_ptr(d)), dtype=torch.float32, device=x.device)
+    check(lib.ctl_conv_forward(_ffi.desc_ptr(d), ptr(x), ptr(wpack), ptr(bias), ptr(pro_scale), ptr(pro_shift), ptr(res),
+                               ptr(res_scale), ptr(res_shift), ptr(y), ptr(stats), stream_ptr()), "ctl_conv_forward")
+    return y, stats
+
+
+def conv_wgrad(d: np.ndarray, x, dy, dw: torch.Tensor, strides, dbias: Optional[torch.Tensor] = None, pro_scale=None,
+               pro_shift=None, accumulate=False):
+    require_gpu(x, dy, dw)
+    dp = _ffi.desc_ptr(d)
+    wpart = torch.empty(lib.ctl_wgrad_partial_floats(dp), dtype=torch.float32, device=x.device)
+    bpart = torch.empty(lib.ctl_wgrad_bias_partial_floats(dp), dtype=torch.float32, device=x.device) if dbias is not None else None
+    check(lib.ctl_conv_wgrad(dp, ptr(x), ptr(pro_scale), ptr(pro_shift), ptr(dy), ptr(wpart), ptr(bpart), stream_ptr()),
+          "ctl_conv_wgrad")
+    check(lib.ctl_wgrad_reduce(dp, ptr(wpart), ptr(bpart), ptr(dw), *[int(s) for s in strides], ptr(dbias), int(accumulate),
+                               stream_ptr()), "ctl_wgrad_reduce")
+    return dw, dbias
+
+
+# ---------------------------------------------------------------------------------------------- BN pieces
+def bn_finalize(partial, c, count, gamma, beta, eps=1e-5, momentum=0.1, running_mean=None, running_var=None, nbt=None):
+    dev = partial.device
+    scale, shift, mean, invstd = (torch.empty(c, dtype=torch.float32, device=dev) for _ in range(4))
+    blocks = partial.numel() // (2 * c)
+    check(lib.ctl_bn_finalize(ptr(partial), blocks, c, count, ptr(gamma), ptr(beta), eps, momentum,
+                              int(running_mean is not None), ptr(running_mean), ptr(running_var), ptr(nbt), ptr(scale),
+                              ptr(shift), ptr(mean), ptr(invstd), stream_ptr()), "ctl_bn_finalize")
+    return scale, shift, mean, invstd
+
+
+def bn_act(x, scale, shift, slope):
+    y = torch.empty_like(x)
+    n, c, h, w = x.shape
+    check(lib.ctl_bn_act(ptr(x), ptr(scale), ptr(shift), slope, ptr(y), n * h * w, c, stream_ptr()), "ctl_bn_act")
+    return y
+
+
+# ---------------------------------------------------------------------------------------------- STN input / losses
+def softmax_t_fwd(x: torch.Tensor, temperature: float = 2.0) -> torch.Tensor:
+    require_gpu(x)
+    n, c, h, w = x.shape
+    p = torch.empty_like(x)
+    check(lib.ctl_softmax_t_fwd(ptr(x), 1.0 / temperature, ptr(p), n * h * w, c, stream_ptr()), "ctl_softmax_t_fwd")
+    return p
+
+
+def softmax_t_bwd(p, dp, temperature: float = 2.0):
+    n, c, h, w = p.shape
+    dx = torch.empty_like(p)
+    check(lib.ctl_softmax_t_bwd(ptr(p), ptr(dp), 1.0 / temperature, ptr(dx), n * h * w, c, stream_ptr()), "ctl_softmax_t_bwd")
+    return dx
+
+
+def onehot(label: torch.Tensor, c: int) -> torch.Tensor:
+    require_gpu(label)
+    label = label.long().contiguous()
+    n, h, w = label.shape
+    y = empty_nhwc(n, c, h, w, label.device)
+    check(lib.ctl_onehot(ptr(label), ptr(y), n * h * w, c, stream_ptr()), "ctl_onehot")
+    return y
+
+
+def ce2d_fwd(logit, label):
+    n, c, h, w = logit.shape
+    partial = torch.empty(_ffi.RED_BLOCKS, dtype=torch.float64, device=logit.device)
+    loss = torch.empty((), dtype=torch.float32, device=logit.device)
+    check(lib.ctl_ce2d_fwd(ptr(logit), ptr(label), n * h * w, c, ptr(partial), ptr(loss), stream_ptr()), "ctl_ce2d_fwd")
+    return loss
+
+
+def ce2d_bwd(logit, label, gout):
+    n, c, h, w = logit.shape
+    d = torch.empty_like(logit)
+    check(lib.ctl_ce2d_bwd(ptr(logit), ptr(label), ptr(gout), n * h * w, c, ptr(d), stream_ptr()), "ctl_ce2d_bwd")
+    return d
+
+
+def mse_fwd(a, b, scale):
+    partial = torch.empty(_ffi.RED_BLOCKS, dtype=torch.float64, device=a.device)
+    loss = torch.empty((), dtype=torch.float32, device=a.device)
+    check(lib.ctl_mse_fwd(ptr(a), ptr(b), a.numel(), scale, ptr(partial), ptr(loss), stream_ptr()), "ctl_mse_fwd")
+    return loss
+
+
+def mse_bwd(a, b, gout, scale):
+    d = torch.empty_like(a)
+    check(lib.ctl_mse_bwd(ptr(a), ptr(b), ptr(gout), a.numel(), scale, ptr(d), stream_ptr()), "ctl_mse_bwd")
+    return d
+
+
+def argmax_c(logit: torch.Tensor) -> torch.Tensor:
+    require_gpu(logit)
+    logit = as_nhwc(logit)
+    n, c, h, w = logit.shape
+    out = torch.empty((n, h, w), dtype=torch.uint8, device=logit.device)
+    check(lib.ctl_argmax_c(ptr(logit), ptr(out), n * h * w, c, stream_ptr()), "ctl_argmax_c")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------- latent masking
+def latent_score(grad: torch.Tensor, mode: int) -> torch.Tensor:
+    """mode 0: [N,C] signed mean over H*W; mode 1: [N,H*W] signed mean over C (model_util.py:224-225 / 285-286)."""
+    require_gpu(grad)
+    grad = as_nhwc(grad)
+    n, c, h, w = grad.shape
+    L = c if mode == 0 else h * w
+    score = torch.empty((n, L), dtype=torch.float32, device=grad.device)
+    ws = lib.ctl_latent_score_ws_floats(mode, n, h * w, c)
+    scratch = torch.empty(max(ws, 1), dtype=torch.float32, device=grad.device)
+    check(lib.ctl_latent_score(mode, ptr(grad), ptr(score), ptr(scratch), n, h * w, c, stream_ptr()), "ctl_latent_score")
+    return score
+
+
+def latent_mask_apply(code: torch.Tensor, score: torch.Tensor, mode: int, k, soft_noise: Optional[torch.Tensor] = None):
+    """Returns (masked code [N,C,H,W], mask [N,C,1,1] or [N,1,H,W]).  `k` is an int or a 1-element int32 device tensor."""
+    require_gpu(code, score)
+    code = as_nhwc(code)
+    n, c, h, w = code.shape
+    masked = torch.empty_like(code)
+    L = c if mode == 0 else h * w
+    mask = torch.empty((n, L), dtype=torch.float32, device=code.device)
+    k_dev = k if isinstance(k, torch.Tensor) else None
+    k_host = 0 if k_dev is not None else int(k)
+    if soft_noise is not None:
+        soft_noise = soft_noise.reshape(n, L).float().contiguous()
+    check(lib.ctl_latent_mask_apply(mode, ptr(code), ptr(score), ptr(soft_noise), k_host, ptr(k_dev), ptr(masked), ptr(mask),
+                                    n, h * w, c, stream_ptr()), "ctl_latent_mask_apply")
+    return masked, (mask.view(n, c, 1, 1) if mode == 0 else mask.view(n, 1, h, w))
+
+
+def dropout2d(z: torch.Tensor, p: float, keep: Optional[torch.Tensor] = None, seed: int = 0):
+    """Returns (out, keep[N,C]).  keep=None draws the Bernoulli pattern on device from `seed`."""
+    require_gpu(z)
+    z = as_nhwc(z)
+    n, c, h, w = z.shape
+    out = torch.empty_like(z)
+    keep_out = torch.empty((n, c), dtype=torch.float32, device=z.device)
+    if keep is not None:
+        keep = keep.reshape(n, c).float().contiguous()
+    check(lib.ctl_dropout2d(ptr(z), ptr(keep), seed & (2 ** 64 - 1), p, ptr(out), ptr(keep_out), n, h * w, c, stream_ptr()),
+          "ctl_dropout2d")
+    return out, keep_out
+
+
+def uniform(shape, device, seed: int) -> torch.Tensor:
+    out = torch.empty(shape, dtype=torch.float32, device=device)
+    check(lib.ctl_uniform(ptr(out), out.numel(), seed & (2 ** 64 - 1), stream_ptr()), "ctl_uniform")
+    return out
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
+    require_gpu(p, g, m, v)
+    check(lib.ctl_adam(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, step, grad_scale, stream_ptr()),
+          "ctl_adam")

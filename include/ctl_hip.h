@@ -1,0 +1,200 @@
+/*
+ * ctl_hip.h -- C-ABI of libctl_hip.so: the MI355X (gfx950) kernels behind the cooperative-training hot path.
+ *
+ * The reference (cherise215/Cooperative_Training_and_Latent_Space_Data_Augmentation) is pure PyTorch-eager and has
+ * no FFI of its own; every entry point below replaces the ATen ops that the cited reference lines dispatch.
+ * "model.py" = medseg/models/advanced_triplet_recon_segmentation_model.py,
+ * "encdec.py" = medseg/models/ebm/encoder_decoder.py, "util.py" = medseg/models/model_util.py.
+ *
+ * Conventions
+ *   - all tensors are fp32 NHWC ("channels_last") in device memory owned by the caller; labels are int64 NHW
+ *   - every call only enqueues work on `stream`; no allocation, no host sync, no retained pointers
+ *   - return 0 on success, negative ctl_status on error; ctl_last_error() gives a thread-local message
+ *   - scratch / partial-sum buffers are sized by the *_ws_* helpers and passed in by the caller
+ */
+#ifndef CTL_HIP_H
+#define CTL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* ctl_stream;            /* hipStream_t */
+
+enum ctl_status { CTL_OK = 0, CTL_EINVAL = -1, CTL_EUNSUPPORTED = -2, CTL_ELAUNCH = -3 };
+
+int         ctl_version(void);
+const char* ctl_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------ convolution
+ * One implicit-GEMM kernel family (MFMA f32 16x16x4, LDS-staged NHWC input tiles) serves
+ *   nn.Conv2d 3x3 s1/s2 p1 and 1x1          encdec.py:40-55, 323-335, 371-376, 390-391, 439-440, 469-474
+ *   nn.ConvTranspose2d k2 s2                 encdec.py:302            (4 scattered 1x1 problems, `nsub` = 4)
+ *   nn.UpsamplingNearest2d folded into the consumer conv's input indexing   encdec.py:294-296 (in_mode 1)
+ *   every dgrad (conv over dy with transposed/flipped weights; stride-2 dgrad via zero-insertion, in_mode 2)
+ * with BatchNorm-apply + LeakyReLU fused into the input staging ("prologue") and bias / residual / activation /
+ * BatchNorm statistics fused into the epilogue.
+ */
+enum { CTL_IN_PLAIN = 0, CTL_IN_UP2 = 1, CTL_IN_ZINS2 = 2 };
+enum { CTL_ACT_NONE = 0, CTL_ACT_LEAKY = 1, CTL_ACT_SIGMOID = 2 };
+enum { CTL_EPI_BIAS = 1, CTL_EPI_ACCUM = 2, CTL_EPI_RES = 4, CTL_EPI_STATS = 8 };
+
+typedef struct ctl_conv {
+    int32_t n, hin, win, cin;        /* stored input tensor [n,hin,win,cin]                                   */
+    int32_t hout, wout, cout;        /* output pixel grid of this problem and its channel count               */
+    int32_t ks, stride, pad;         /* 3/1|2/1, 1/1/0, 2/2/0                                                  */
+    int32_t in_mode;                 /* CTL_IN_*: virtual input = stored | nearest-up x2 | zero-insert x2     */
+    int32_t pro_affine;              /* 1: x <- leaky(x*pro_scale[c]+pro_shift[c], pro_slope) while staging   */
+    float   pro_slope;
+    int32_t epi_flags;               /* CTL_EPI_*                                                             */
+    int32_t epi_act;                 /* CTL_ACT_* applied after bias/residual                                  */
+    float   epi_slope;
+    int32_t out_h, out_w;            /* output tensor [n,out_h,out_w,cout]; pixel (ho,wo) of sub-problem z     */
+    int32_t out_sy, out_sx;          /*   lands at (ho*out_sy + z/2*out_sub, wo*out_sx + z%2*out_sub)          */
+    int32_t nsub, out_sub;           /* nsub = 1 (plain) or 4 (ConvTranspose k2s2: out_sy=out_sx=2,out_sub=1)  */
+} ctl_conv;
+
+/* number of floats of the packed weight buffer for one sub-problem, and of the statistics partial buffer */
+size_t ctl_conv_wpack_floats(int32_t cin, int32_t cout, int32_t ks);
+size_t ctl_conv_stats_floats(const ctl_conv* d);     /* [blocks][2][cout] */
+int    ctl_conv_stats_blocks(const ctl_conv* d);
+
+/* Pack weights into MFMA-fragment order.  Element (co,ci,kh,kw) of the *effective* conv is read from
+ * src[co*s_co + ci*s_ci + kh'*s_kh + kw'*s_kw] with (kh',kw') = flip ? (ks-1-kh, ks-1-kw) : (kh,kw).  Covers OIHW
+ * forward weights, their dgrad transposes and both ConvTranspose2d uses. */
+int ctl_pack_weights(const float* src, float* dst, int32_t cout, int32_t cin, int32_t ks,
+                     int64_t s_co, int64_t s_ci, int64_t s_kh, int64_t s_kw, int32_t flip, ctl_stream stream);
+
+/* y = epi( conv(pro(x)) ).  res/res_scale/res_shift: CTL_EPI_RES adds res*res_scale[c]+res_shift[c] (the
+ * BatchNorm'ed main branch of res_convdown / res_up_family, encdec.py:64,344).  stats_partial: CTL_EPI_STATS. */
+int ctl_conv_forward(const ctl_conv* d, const float* x, const float* wpack, const float* bias,
+                     const float* pro_scale, const float* pro_shift,
+                     const float* res, const float* res_scale, const float* res_shift,
+                     float* y, float* stats_partial, ctl_stream stream);
+
+/* Weight gradient of the conv described by d (x [n,hin,win,cin] -> dy [n,hout,wout,cout], nsub must be 1):
+ * partial[split][tap][cin16][cout16] (+ bias partial[split][cout16]); then ctl_wgrad_reduce sums the splits and
+ * (accumulate ? += : =) into a gradient tensor with the same generic strides as ctl_pack_weights. */
+int    ctl_wgrad_splits(const ctl_conv* d);
+size_t ctl_wgrad_partial_floats(const ctl_conv* d);          /* weights part  */
+size_t ctl_wgrad_bias_partial_floats(const ctl_conv* d);     /* bias part     */
+int ctl_conv_wgrad(const ctl_conv* d, const float* x, const float* pro_scale, const float* pro_shift,
+                   const float* dy, float* w_partial, float* b_partial, ctl_stream stream);
+int ctl_wgrad_reduce(const ctl_conv* d, const float* w_partial, const float* b_partial,
+                     float* dw, int64_t s_co, int64_t s_ci, int64_t s_kh, int64_t s_kw,
+                     float* dbias, int32_t accumulate, ctl_stream stream);
+
+/* ------------------------------------------------------------------------------------------------ BatchNorm2d
+ * encdec.py: every `norm(out_ch)`; three modes of SURVEY 8a row 4 (util.py:414-451).
+ * finalize: partial [blocks][2][c] (sum, sum of squares over `count` pixels) -> scale=gamma*invstd,
+ * shift=beta-mean*scale, save_mean, save_invstd; if update_running: running stats (momentum, unbiased var) and
+ * num_batches_tracked (int64) are updated in place. */
+int ctl_bn_finalize(const float* partial, int32_t blocks, int32_t c, int64_t count, const float* gamma,
+                    const float* beta, float eps, float momentum, int32_t update_running, float* running_mean,
+                    float* running_var, int64_t* num_batches_tracked, float* scale, float* shift, float* save_mean,
+                    float* save_invstd, ctl_stream stream);
+/* eval mode: scale = gamma/sqrt(running_var+eps), shift = beta - running_mean*scale */
+int ctl_bn_eval_coeffs(int32_t c, const float* gamma, const float* beta, const float* running_mean,
+                       const float* running_var, float eps, float* scale, float* shift, ctl_stream stream);
+/* y = leaky(x*scale[c]+shift[c], slope)  (slope 0 = ReLU, slope 1 = identity) */
+int ctl_bn_act(const float* x, const float* scale, const float* shift, float slope, float* y, int64_t pixels,
+               int32_t c, ctl_stream stream);
+
+/* backward helpers; `partial` buffers are [CTL_RED_BLOCKS][2][c] floats */
+#define CTL_RED_BLOCKS 512
+/* mode 0 (residual tail, encdec.py:64,344): g = dout * leaky'(out);        sums: sum g, sum g*v
+ * mode 1 (BN->act tail):                    g = da * leaky'(u*scale+shift); sums: sum g, sum g*u
+ * mode 2 (plain):                           g = da;                         sums: sum g, (unused)          */
+int ctl_bwd_reduce(int32_t mode, const float* dy, const float* act_src, const float* bn_src, const float* scale,
+                   const float* shift, float slope, int64_t pixels, int32_t c, float* partial, ctl_stream stream);
+/* partial -> coefficients A,B,C with dx = A*g + B*bn_src + C (training-mode BN backward), and, if dgamma/dbeta
+ * are non-NULL, dgamma += sum g*xhat, dbeta += sum g (accumulate ? += : =). */
+int ctl_bn_bwd_finalize(const float* partial, int32_t c, int64_t count, const float* gamma, const float* save_mean,
+                        const float* save_invstd, float* coef, float* dgamma, float* dbeta, int32_t accumulate,
+                        ctl_stream stream);
+/* mode 0: ds = dout*leaky'(out) (written if ds != NULL), dv = A*ds + B*v + C;  mode 1: du = A*g + B*u + C */
+int ctl_bwd_apply(int32_t mode, const float* dy, const float* act_src, const float* bn_src, const float* scale,
+                  const float* shift, float slope, const float* coef, int64_t pixels, int32_t c, float* ds,
+                  float* dx, ctl_stream stream);
+/* partial[blocks][2][c] -> out[c] (+)= sum over blocks of row 0 (bias gradient of ConvTranspose2d) */
+int ctl_chan_sum_finalize(const float* partial, int32_t c, float* out, int32_t accumulate, ctl_stream stream);
+/* nearest-upsample backward: dx[n,h,w,c] = sum of the 2x2 block of dup[n,2h,2w,c]; accumulate ? += : = */
+int ctl_sumpool2(const float* dup, float* dx, int32_t n, int32_t h, int32_t w, int32_t c, int32_t accumulate,
+                 ctl_stream stream);
+/* dlogit = dy * y * (1-y)  (nn.Sigmoid of image_decoder, model.py:100) */
+int ctl_sigmoid_bwd(const float* dy, const float* y, float* dx, int64_t count, ctl_stream stream);
+
+/* ------------------------------------------------------------------------------------------------ STN input, losses
+ * construct_input (medseg/common_utils/basic_operations.py:110-158): softmax(x/T, dim=C) or one-hot(label) */
+int ctl_softmax_t_fwd(const float* x, float inv_t, float* p, int64_t pixels, int32_t c, ctl_stream stream);
+int ctl_softmax_t_bwd(const float* p, const float* dp, float inv_t, float* dx, int64_t pixels, int32_t c,
+                      ctl_stream stream);
+int ctl_onehot(const int64_t* label, float* y, int64_t pixels, int32_t c, ctl_stream stream);
+/* cross_entropy_2D (medseg/models/custom_loss.py:706-740, util.py:104-115): loss = mean_pixels -log_softmax[label].
+ * fwd writes loss[0]; partial is [CTL_RED_BLOCKS] doubles.  bwd: dlogit = gout[0] * (softmax - onehot) / pixels */
+int ctl_ce2d_fwd(const float* logit, const int64_t* label, int64_t pixels, int32_t c, double* partial, float* loss,
+                 ctl_stream stream);
+int ctl_ce2d_bwd(const float* logit, const int64_t* label, const float* gout, int64_t pixels, int32_t c,
+                 float* dlogit, ctl_stream stream);
+/* loss = scale * mean((a-b)^2) (model.py:445-447: scale 0.5; util.py:216: scale 1); bwd: da = gout*2*scale*(a-b)/count */
+int ctl_mse_fwd(const float* a, const float* b, int64_t count, float scale, double* partial, float* loss,
+                ctl_stream stream);
+int ctl_mse_bwd(const float* a, const float* b, const float* gout, int64_t count, float scale, float* da,
+                ctl_stream stream);
+/* pred.max(1)[1] (model.py:657): first maximal channel, uint8 out */
+int ctl_argmax_c(const float* logit, uint8_t* out, int64_t pixels, int32_t c, ctl_stream stream);
+
+/* ------------------------------------------------------------------------------------------------ latent masking
+ * util.py:224-249 (channel) / 285-312 (spatial).  mode 0: score[n,c] = mean_hw grad; mode 1: score[n,hw] = mean_c grad.
+ * `scratch` holds ctl_latent_score_ws_floats() floats (deterministic two-stage sum, no float atomics).
+ * ctl_latent_mask_apply: entry i of row n is masked iff
+ * #{j : score[n,j] >= score[n,i]} <= k  (== "score > sort(desc)[k]", strict, util.py:231-244);
+ * mask value = soft_noise ? 0.5*soft_noise[n,i] : 0; kept = 1.  k is read from k_dev[0] if k_dev != NULL (graph replay)
+ * else from k_host.  masked = code * mask (broadcast), mask_out [n,L]. */
+size_t ctl_latent_score_ws_floats(int32_t mode, int32_t n, int32_t hw, int32_t c);
+int ctl_latent_score(int32_t mode, const float* grad, float* score, float* scratch, int32_t n, int32_t hw, int32_t c,
+                     ctl_stream stream);
+int ctl_latent_mask_apply(int32_t mode, const float* code, const float* score, const float* soft_noise,
+                          int32_t k_host, const int32_t* k_dev, float* masked, float* mask_out, int32_t n, int32_t hw,
+                          int32_t c, ctl_stream stream);
+/* F.dropout2d(z,p) (model.py:333): out = z * keep[n,c] / (1-p).  keep != NULL: injected {0,1} floats; else drawn on
+ * device from a counter hash of (seed, n*c index) and written to keep_out. */
+int ctl_dropout2d(const float* z, const float* keep, uint64_t seed, float p, float* out, float* keep_out, int32_t n,
+                  int32_t hw, int32_t c, ctl_stream stream);
+/* 0.5*U[0,1) style uniform fill from the same counter hash (soft-mask noise, util.py:239) */
+int ctl_uniform(float* out, int64_t count, uint64_t seed, ctl_stream stream);
+
+/* ------------------------------------------------------------------------------------------------ optimizer
+ * torch.optim.Adam defaults (model.py:774-785), one flat buffer: p,g,m,v [count].  step = 1-based step index.
+ * grad_scale folds the 1/world_size of the data-parallel all-reduce. */
+int ctl_adam(float* p, const float* g, float* m, float* v, int64_t count, float lr, float beta1, float beta2,
+             float eps, int32_t step, float grad_scale, ctl_stream stream);
+
+/* ------------------------------------------------------------------------------------------------ plans
+ * A plan is an array of ctl_op executed in order on one stream: one C call per network pass (the Python host builds
+ * it once per (network, shape, mode)).  Tensor arguments are (slot, byte offset) pairs resolved against `bases`. */
+enum ctl_op_kind {
+    CTL_OP_CONV = 1, CTL_OP_WGRAD = 2, CTL_OP_WGRAD_REDUCE = 3, CTL_OP_PACK = 4, CTL_OP_BN_FINALIZE = 5,
+    CTL_OP_BN_EVAL = 6, CTL_OP_BN_ACT = 7, CTL_OP_BWD_REDUCE = 8, CTL_OP_BN_BWD_FINALIZE = 9, CTL_OP_BWD_APPLY = 10,
+    CTL_OP_CHAN_SUM_FINALIZE = 11, CTL_OP_SUMPOOL2 = 12, CTL_OP_SIGMOID_BWD = 13, CTL_OP_ZERO = 14
+};
+#define CTL_OP_MAX_T 12
+typedef struct ctl_op {
+    int32_t kind;
+    int32_t i[27];                    /* CONV/WGRAD/WGRAD_REDUCE: i[0..21] = ctl_conv as int32 words, i[23] = accumulate; others: see ctl_plan.cpp */
+    float   f[4];
+    int32_t slot[CTL_OP_MAX_T];       /* -1 = NULL */
+    int64_t off[CTL_OP_MAX_T];
+    int64_t l[4];                     /* 64-bit scalars (strides, counts) */
+} ctl_op;
+int ctl_plan_run(const ctl_op* ops, int32_t n_ops, void* const* bases, int32_t n_bases, ctl_stream stream);
+size_t ctl_sizeof_op(void);
+size_t ctl_sizeof_conv(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

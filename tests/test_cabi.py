@@ -1,0 +1,55 @@
+"""CPU-side checks of the C-ABI boundary: the library loads, exports every symbol include/ctl_hip.h declares, the
+struct layouts match the ctypes/numpy mirrors, and argument validation fails loudly (no compute without a GPU)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from cooperative_training_and_latent_space_data_augmentation_amd import _ffi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_reports_version():
+    assert _ffi.lib.ctl_version() == 1
+
+
+def test_every_declared_symbol_is_exported():
+    header = open(os.path.join(ROOT, "include", "ctl_hip.h")).read()
+    declared = set(re.findall(r"\b(ctl_[a-z0-9_]+)\s*\(", header))
+    declared -= {"ctl_stream"}
+    raw = ctypes.CDLL(_ffi.LIB_PATH)
+    missing = [s for s in sorted(declared) if not hasattr(raw, s)]
+    assert not missing, missing
+    assert declared == set(_ffi.EXPORTED), declared ^ set(_ffi.EXPORTED)
+
+
+def test_struct_layouts_match():
+    assert _ffi.lib.ctl_sizeof_op() == _ffi.OP_DTYPE.itemsize == 304
+    assert _ffi.lib.ctl_sizeof_conv() == _ffi.CONV_DTYPE.itemsize == 88
+
+
+def test_invalid_arguments_fail_loudly():
+    d = _ffi.conv_desc(n=1, hin=8, win=8, cin=16, hout=8, wout=8, cout=16, ks=3)
+    rc = _ffi.lib.ctl_conv_forward(_ffi.desc_ptr(d), None, None, None, None, None, None, None, None, None, None, None)
+    assert rc == -1 and b"null" in _ffi.lib.ctl_last_error()
+    with pytest.raises(_ffi.CtlError):
+        _ffi.check(rc, "ctl_conv_forward")
+    bad = _ffi.conv_desc(n=1, hin=8, win=8, cin=24, hout=8, wout=8, cout=16, ks=3)   # cin >= 16 must be a multiple of 16
+    assert _ffi.lib.ctl_conv_stats_blocks(_ffi.desc_ptr(bad)) == -1
+    bad2 = _ffi.conv_desc(n=1, hin=8, win=8, cin=16, hout=8, wout=8, cout=16, ks=3, stride=2, in_mode=_ffi.IN_UP2)
+    assert _ffi.lib.ctl_conv_stats_blocks(_ffi.desc_ptr(bad2)) == -1
+
+
+def test_host_side_sizing_helpers():
+    assert _ffi.lib.ctl_conv_wpack_floats(16, 16, 3) == 9 * 256
+    assert _ffi.lib.ctl_conv_wpack_floats(4, 16, 3) == 9 * 256          # cin padded to one 16-chunk
+    assert _ffi.lib.ctl_conv_wpack_floats(128, 64, 1) == 4 * 8 * 256
+    d = _ffi.conv_desc(n=16, hin=256, win=256, cin=16, hout=256, wout=256, cout=16, ks=3)
+    assert _ffi.lib.ctl_conv_stats_blocks(_ffi.desc_ptr(d)) == 16 * 32 * 8  # 8x32 tiles
+    assert _ffi.lib.ctl_conv_stats_floats(_ffi.desc_ptr(d)) == 16 * 32 * 8 * 2 * 16
+    assert _ffi.lib.ctl_wgrad_splits(_ffi.desc_ptr(d)) == 1024
+    assert _ffi.lib.ctl_wgrad_partial_floats(_ffi.desc_ptr(d)) == 1024 * 9 * 16 * 16
+    assert _ffi.lib.ctl_latent_score_ws_floats(0, 16, 256, 128) == 16 * 4 * 128
