@@ -1,0 +1,110 @@
+"""torch.autograd bridge: one Function per *network pass* (not per layer) plus the fused loss / STN-input ops, so the
+reference's `loss.backward()` call pattern works unchanged while every FLOP runs in the HIP kernels."""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from ._ffi import CtlError
+
+
+def _nhwc(t: torch.Tensor) -> torch.Tensor:
+    return t.float().contiguous(memory_format=torch.channels_last)
+
+
+class _NetFn(torch.autograd.Function):
+    """A whole encoder / decoder pass.  Inputs: the activation `x` and the network's flat parameter buffer."""
+
+    @staticmethod
+    def forward(ctx, net, mode, affine, x, flat):
+        outs, act, plan = net.run_forward(x, mode)
+        ctx.net, ctx.mode, ctx.affine, ctx.act, ctx.plan = net, mode, affine, act, plan
+        ctx.save_for_backward(x, *outs)
+        ctx.set_materialize_grads(False)
+        return outs
+
+    @staticmethod
+    def backward(ctx, *douts):
+        if ctx.mode == "C":
+            raise CtlError("backward through an eval-mode (running-statistics) pass is not part of the hot path")
+        saved = ctx.saved_tensors
+        x, outs = saved[0], saved[1:]
+        need_dx, need_w = ctx.needs_input_grad[3], ctx.needs_input_grad[4]
+        if all(d is None for d in douts) or not (need_dx or need_w):
+            return None, None, None, None, None
+        douts = tuple(None if d is None else _nhwc(d) for d in douts)
+        dx, gflat = ctx.net.run_backward(x, ctx.act, outs, ctx.plan, ctx.mode, douts, need_dx, need_w, ctx.affine)
+        return None, None, None, dx, gflat
+
+
+def net_apply(net, x: torch.Tensor):
+    """Run `net` on `x` (logical NCHW) in its current BatchNorm mode; returns a tuple of outputs."""
+    ops.require_gpu(x)
+    x = _nhwc(x)
+    mode = net.bn_mode()
+    track_params = torch.is_grad_enabled() and mode != "C" and net.wants_param_grad()
+    flat = net._flat if track_params else net._flat.detach()
+    return _NetFn.apply(net, mode, mode == "A", x, flat)
+
+
+class _CrossEntropy2D(torch.autograd.Function):
+    """cross_entropy_2D with an integer label map (custom_loss.py:706-740 / model_util.py:104-115)."""
+
+    @staticmethod
+    def forward(ctx, logit, label):
+        logit = _nhwc(logit)
+        label = label.long().contiguous()
+        ctx.save_for_backward(logit, label)
+        return ops.ce2d_fwd(logit, label)
+
+    @staticmethod
+    def backward(ctx, g):
+        logit, label = ctx.saved_tensors
+        return ops.ce2d_bwd(logit, label, g.float().contiguous()), None
+
+
+class _ScaledMSE(torch.autograd.Function):
+    """scale * mean((a-b)^2)"""
+
+    @staticmethod
+    def forward(ctx, a, b, scale):
+        a, b = _nhwc(a), _nhwc(b)
+        ctx.save_for_backward(a, b)
+        ctx.scale = scale
+        return ops.mse_fwd(a, b, scale)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        return ops.mse_bwd(a, b, g.float().contiguous(), ctx.scale), None, None
+
+
+class _SoftmaxT(torch.autograd.Function):
+    """softmax(x / T, dim=C) (construct_input, basic_operations.py:129-131)."""
+
+    @staticmethod
+    def forward(ctx, x, temperature):
+        p = ops.softmax_t_fwd(_nhwc(x), temperature)
+        ctx.save_for_backward(p)
+        ctx.t = temperature
+        return p
+
+    @staticmethod
+    def backward(ctx, dp):
+        p, = ctx.saved_tensors
+        return ops.softmax_t_bwd(p, _nhwc(dp), ctx.t), None
+
+
+def cross_entropy_2D(logit, label):
+    ops.require_gpu(logit, label)
+    return _CrossEntropy2D.apply(logit, label)
+
+
+def scaled_mse(a, b, scale=1.0):
+    ops.require_gpu(a, b)
+    return _ScaledMSE.apply(a, b, float(scale))
+
+
+def softmax_t(x, temperature=2.0):
+    ops.require_gpu(x)
+    return _SoftmaxT.apply(x, float(temperature))

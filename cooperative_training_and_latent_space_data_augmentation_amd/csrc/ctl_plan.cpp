@@ -17,6 +17,7 @@
 //   SUMPOOL2          0 dup 1 dx                                         i[0..4]=n,h,w,c,accumulate
 //   SIGMOID_BWD       0 dy 1 y 2 dx                                      l[0]=count
 //   ZERO              0 ptr                                              l[0]=bytes
+//   COPY              0 src 1 dst                                        l[0]=bytes
 #include <stdarg.h>
 #include <string.h>
 
@@ -101,6 +102,12 @@ extern "C" int ctl_plan_run(const ctl_op* ops, int32_t n_ops, void* const* bases
                 CTL_REQUIRE(t[0] && op.l[0] > 0, "plan_run: op %d ZERO needs a pointer and a size", k);
                 hipError_t e = hipMemsetAsync(t[0], 0, (size_t)op.l[0], (hipStream_t)stream);
                 if (e != hipSuccess) CTL_FAIL(CTL_ELAUNCH, "plan_run: memset: %s", hipGetErrorString(e));
+                break;
+            }
+            case CTL_OP_COPY: {
+                CTL_REQUIRE(t[0] && t[1] && op.l[0] > 0, "plan_run: op %d COPY needs two pointers and a size", k);
+                hipError_t e = hipMemcpyAsync(t[1], t[0], (size_t)op.l[0], hipMemcpyDeviceToDevice, (hipStream_t)stream);
+                if (e != hipSuccess) CTL_FAIL(CTL_ELAUNCH, "plan_run: memcpy: %s", hipGetErrorString(e));
                 break;
             }
             default:

@@ -1,0 +1,830 @@
+"""FTN/STN networks of the reference, re-designed for MI355X: each network pass is ONE C call (`ctl_plan_run`) over a
+pre-compiled list of kernel launches ("plan") working on NHWC fp32 tensors.
+
+Mirrors (names + state_dict keys, so upstream `.pth` files load unchanged):
+    MyEncoder            medseg/models/ebm/encoder_decoder.py:351-415
+    MyDecoder            medseg/models/ebm/encoder_decoder.py:418-453
+    Dual_Branch_Encoder  medseg/models/ebm/encoder_decoder.py:456-503
+    res_convdown / res_up_family blocks: :19-68 / :285-348
+
+HBM data layout
+    parameters   one flat fp32 buffer per network (`_flat`), every tensor 256-B aligned; the named nn.Parameters are
+                 OIHW views into it (checkpoint-compatible); gradients likewise (`_flat.grad`); Adam runs on the flat
+                 buffer in one launch.
+    weights      re-packed once per optimizer step into MFMA-fragment order (forward + dgrad variants), `_wp`.
+    activations  NHWC; raw (pre-BatchNorm) conv outputs are what is stored.  BatchNorm-apply + LeakyReLU is never
+                 materialised on the main path: the consumer conv applies it while staging its input tile, the
+                 residual tail is fused into the 1x1 `conv_input` epilogue, nearest-upsampling is pure indexing.
+
+BatchNorm modes (SURVEY 8a row 4 / model_util.py:414-451): "A" train+track, "B" train without running-stat update and
+without gamma/beta gradients, "C" eval (running statistics).
+"""
+from __future__ import annotations
+
+import ctypes
+from collections import namedtuple
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _ffi, init as _init
+from ._ffi import lib, check, OP_DTYPE
+
+(S_X, S_P, S_B, S_NBT, S_WP, S_ACT, S_SCR, S_OUT0, S_OUT1, S_DOUT0, S_DOUT1, S_GRAD, S_DX, S_BSCR) = range(14)
+N_SLOTS = 14
+SLOPE = 0.2
+EPS = 1e-5
+MOMENTUM = 0.1
+ALIGN_F = 64            # floats (256 B)
+
+T = namedtuple("T", "ref n h w c")     # tensor descriptor: ref = (slot, byte offset), NHWC dims
+
+
+def _rup(x: int, a: int) -> int:
+    return (x + a - 1) // a * a
+
+
+class _Holder(nn.Module):
+    """Plain container (stands in for nn.Sequential / the block classes; it owns no compute)."""
+
+
+class _ConvP(nn.Module):
+    def __init__(self, cin, cout, ks, transposed=False):
+        super().__init__()
+        self.cin, self.cout, self.ks, self.transposed = cin, cout, ks, transposed
+        shape = (cin, cout, ks, ks) if transposed else (cout, cin, ks, ks)
+        self.weight = nn.Parameter(torch.zeros(shape))
+        self.bias = nn.Parameter(torch.zeros(cout))
+
+
+class _BNP(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.c = c
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+        self.register_buffer("running_mean", torch.zeros(c))
+        self.register_buffer("running_var", torch.ones(c))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+
+class ConvInfo:
+    __slots__ = ("key", "cin", "cout", "ks", "transposed", "w_off", "b_off", "wp_fwd", "wp_dgrad", "wp_sub")
+
+
+class BNInfo:
+    __slots__ = ("key", "c", "g_off", "b_off", "rm_off", "rv_off", "nbt_idx")
+
+
+class Arena:
+    def __init__(self, slot):
+        self.slot, self.size = slot, 0
+
+    def alloc(self, nbytes: int):
+        off = self.size
+        self.size += _rup(max(int(nbytes), 4), 256)
+        return (self.slot, off)
+
+    def tensor(self, n, h, w, c) -> T:
+        return T(self.alloc(4 * n * h * w * c), n, h, w, c)
+
+
+class Plan:
+    __slots__ = ("ops", "n_ops", "act_bytes", "scr_bytes", "bscr_bytes", "rec", "out_shapes")
+
+
+class PlanBuilder:
+    def __init__(self, net: "CtlNet"):
+        self.net = net
+        self.ops: List[np.ndarray] = []
+        self.act = Arena(S_ACT)
+        self.bscr = Arena(S_BSCR)
+        self.scr_bytes = 0
+
+    # -- low level
+    def op(self, kind: int) -> np.ndarray:
+        r = np.zeros((), dtype=OP_DTYPE)
+        r["kind"] = kind
+        r["slot"][:] = -1
+        self.ops.append(r)
+        return r
+
+    @staticmethod
+    def set_t(op, idx, ref):
+        if ref is not None:
+            op["slot"][idx] = ref[0]
+            op["off"][idx] = ref[1]
+
+    def scr(self, *nbytes):
+        """Transient scratch (valid until the next op that asks for scratch)."""
+        refs, off = [], 0
+        for nb in nbytes:
+            refs.append((S_SCR, off))
+            off += _rup(int(nb), 256)
+        self.scr_bytes = max(self.scr_bytes, off)
+        return refs
+
+    @staticmethod
+    def P(off_floats):
+        return (S_P, 4 * off_floats)
+
+    @staticmethod
+    def G(off_floats):
+        return (S_GRAD, 4 * off_floats)
+
+    # -- conv family
+    def _conv_desc(self, x: T, cout, ks, stride, in_mode, hout, wout, pro, flags, act, slope, nsub=1):
+        d = _ffi.conv_desc(n=x.n, hin=x.h, win=x.w, cin=x.c, hout=hout, wout=wout, cout=cout, ks=ks, stride=stride,
+                           pad=1 if ks == 3 else 0, in_mode=in_mode, pro_affine=1 if pro else 0,
+                           pro_slope=pro[2] if pro else 0.0, epi_flags=flags, epi_act=act, epi_slope=slope)
+        if nsub == 4:
+            d["out_h"], d["out_w"], d["out_sy"], d["out_sx"], d["nsub"], d["out_sub"] = 2 * hout, 2 * wout, 2, 2, 4, 1
+        return d
+
+    def conv(self, x: T, wp_ref, cout, ks, *, stride=1, in_mode=0, pro=None, bias_ref=None, stats=False, act=0,
+             slope=0.0, res=None, accum=False, out: Optional[T] = None, arena: Optional[Arena] = None, nsub=1,
+             hout=None, wout=None):
+        """Emit one CTL_OP_CONV.  pro = (scale_ref, shift_ref, slope); res = (T v, scale_ref, shift_ref).
+        Returns (T y, stats_ref or None, stats_blocks)."""
+        if hout is None:
+            if in_mode == _ffi.IN_UP2:
+                hout, wout = 2 * x.h, 2 * x.w
+            elif stride == 2:
+                hout, wout = ((x.h + 1) // 2, (x.w + 1) // 2) if ks == 3 else (x.h // 2, x.w // 2)
+            else:
+                hout, wout = x.h, x.w
+        flags = (_ffi.EPI_BIAS if bias_ref is not None else 0) | (_ffi.EPI_STATS if stats else 0) | \
+                (_ffi.EPI_RES if res is not None else 0) | (_ffi.EPI_ACCUM if accum else 0)
+        d = self._conv_desc(x, cout, ks, stride, in_mode, hout, wout, pro, flags, act, slope, nsub)
+        oh, ow = (2 * hout, 2 * wout) if nsub == 4 else (hout, wout)
+        if out is None:
+            out = (arena or self.act).tensor(x.n, oh, ow, cout)
+        assert (out.n, out.h, out.w, out.c) == (x.n, oh, ow, cout), (out, x.n, oh, ow, cout)
+        op = self.op(_ffi.OP_CONV)
+        op["i"][:22] = np.frombuffer(d.tobytes(), dtype="<i4")
+        stats_ref, blocks = None, 0
+        if stats:
+            blocks = lib.ctl_conv_stats_blocks(_ffi.desc_ptr(d))
+            if blocks <= 0:
+                raise _ffi.CtlError("conv plan: " + lib.ctl_last_error().decode())
+            stats_ref, = self.scr(4 * blocks * 2 * cout)
+        for idx, ref in enumerate([x.ref, wp_ref, bias_ref, pro[0] if pro else None, pro[1] if pro else None,
+                                   res[0].ref if res else None, res[1] if res else None, res[2] if res else None,
+                                   out.ref, stats_ref]):
+            self.set_t(op, idx, ref)
+        return out, stats_ref, blocks
+
+    def wgrad(self, x: T, dy: T, ks, *, stride=1, in_mode=0, pro=None, dw_ref, strides, dbias_ref=None, accumulate=False):
+        """CTL_OP_WGRAD + CTL_OP_WGRAD_REDUCE for the conv x -> dy."""
+        d = self._conv_desc(x, dy.c, ks, stride, in_mode, dy.h, dy.w, pro, 0, 0, 0.0)
+        dp = _ffi.desc_ptr(d)
+        wb, bb = 4 * lib.ctl_wgrad_partial_floats(dp), 4 * lib.ctl_wgrad_bias_partial_floats(dp)
+        if wb == 0:
+            raise _ffi.CtlError("wgrad plan: " + lib.ctl_last_error().decode())
+        wref, bref = self.scr(wb, bb)
+        words = np.frombuffer(d.tobytes(), dtype="<i4")
+        op = self.op(_ffi.OP_WGRAD)
+        op["i"][:22] = words
+        for idx, ref in enumerate([x.ref, pro[0] if pro else None, pro[1] if pro else None, dy.ref, wref,
+                                   bref if dbias_ref is not None else None]):
+            self.set_t(op, idx, ref)
+        op2 = self.op(_ffi.OP_WGRAD_REDUCE)
+        op2["i"][:22] = words
+        op2["i"][23] = 1 if accumulate else 0
+        op2["l"][:] = strides
+        for idx, ref in enumerate([wref, bref if dbias_ref is not None else None, dw_ref, dbias_ref]):
+            self.set_t(op2, idx, ref)
+
+    # -- BatchNorm
+    def bn_forward(self, bn: BNInfo, stats_ref, blocks, count, mode: str):
+        """Returns dict(scale, shift, mean, invstd) of refs living in the ACT arena."""
+        c = bn.c
+        co = {k: self.act.alloc(4 * c) for k in ("scale", "shift", "mean", "invstd")}
+        if mode == "C":
+            op = self.op(_ffi.OP_BN_EVAL)
+            op["i"][0] = c
+            op["f"][0] = EPS
+            for idx, ref in enumerate([self.P(bn.g_off), self.P(bn.b_off), (S_B, 4 * bn.rm_off), (S_B, 4 * bn.rv_off),
+                                       co["scale"], co["shift"]]):
+                self.set_t(op, idx, ref)
+            return co
+        op = self.op(_ffi.OP_BN_FINALIZE)
+        op["i"][0], op["i"][1], op["i"][2] = blocks, c, 1 if mode == "A" else 0
+        op["l"][0] = count
+        op["f"][0], op["f"][1] = EPS, MOMENTUM
+        for idx, ref in enumerate([stats_ref, self.P(bn.g_off), self.P(bn.b_off), (S_B, 4 * bn.rm_off),
+                                   (S_B, 4 * bn.rv_off), (S_NBT, 8 * bn.nbt_idx), co["scale"], co["shift"], co["mean"],
+                                   co["invstd"]]):
+            self.set_t(op, idx, ref)
+        return co
+
+    def bn_act(self, x: T, co, slope, out: T):
+        op = self.op(_ffi.OP_BN_ACT)
+        op["i"][0] = x.c
+        op["l"][0] = x.n * x.h * x.w
+        op["f"][0] = slope
+        for idx, ref in enumerate([x.ref, co["scale"], co["shift"], out.ref]):
+            self.set_t(op, idx, ref)
+
+    def bn_backward(self, mode_kind: int, dy: T, act_src: Optional[T], bn_src: T, bn: BNInfo, co, slope, *, ds: Optional[T],
+                    dx: T, affine_grad: bool):
+        """reduce -> finalize -> apply.  mode_kind 0 = residual tail, 1 = BN->activation tail."""
+        c, pixels = bn_src.c, bn_src.n * bn_src.h * bn_src.w
+        part, = self.scr(4 * _ffi.RED_BLOCKS * 2 * c)
+        coef = self.bscr.alloc(4 * 3 * c)
+        op = self.op(_ffi.OP_BWD_REDUCE)
+        op["i"][0], op["i"][1] = mode_kind, c
+        op["l"][0] = pixels
+        op["f"][0] = slope
+        for idx, ref in enumerate([dy.ref, act_src.ref if act_src else None, bn_src.ref, co["scale"], co["shift"], part]):
+            self.set_t(op, idx, ref)
+        op = self.op(_ffi.OP_BN_BWD_FINALIZE)
+        op["i"][0], op["i"][1] = c, 0
+        op["l"][0] = pixels
+        for idx, ref in enumerate([part, self.P(bn.g_off), co["mean"], co["invstd"], coef,
+                                   self.G(bn.g_off) if affine_grad else None, self.G(bn.b_off) if affine_grad else None]):
+            self.set_t(op, idx, ref)
+        op = self.op(_ffi.OP_BWD_APPLY)
+        op["i"][0], op["i"][1] = mode_kind, c
+        op["l"][0] = pixels
+        op["f"][0] = slope
+        for idx, ref in enumerate([dy.ref, act_src.ref if act_src else None, bn_src.ref, co["scale"], co["shift"], coef,
+                                   ds.ref if ds else None, dx.ref]):
+            self.set_t(op, idx, ref)
+
+    def chan_sum(self, dy: T, out_ref):
+        c = dy.c
+        part, = self.scr(4 * _ffi.RED_BLOCKS * 2 * c)
+        op = self.op(_ffi.OP_BWD_REDUCE)
+        op["i"][0], op["i"][1] = 2, c
+        op["l"][0] = dy.n * dy.h * dy.w
+        self.set_t(op, 0, dy.ref)
+        self.set_t(op, 5, part)
+        op = self.op(_ffi.OP_CHAN_SUM_FINALIZE)
+        op["i"][0], op["i"][1] = c, 0
+        self.set_t(op, 0, part)
+        self.set_t(op, 1, out_ref)
+
+    def sumpool2(self, dup: T, dx: T, accumulate=False):
+        op = self.op(_ffi.OP_SUMPOOL2)
+        op["i"][:5] = [dx.n, dx.h, dx.w, dx.c, 1 if accumulate else 0]
+        self.set_t(op, 0, dup.ref)
+        self.set_t(op, 1, dx.ref)
+
+    def sigmoid_bwd(self, dy: T, y: T, dx: T):
+        op = self.op(_ffi.OP_SIGMOID_BWD)
+        op["l"][0] = y.n * y.h * y.w * y.c
+        for idx, ref in enumerate([dy.ref, y.ref, dx.ref]):
+            self.set_t(op, idx, ref)
+
+    def zero(self, ref, nbytes):
+        op = self.op(_ffi.OP_ZERO)
+        op["l"][0] = nbytes
+        self.set_t(op, 0, ref)
+
+    def copy(self, src_ref, dst_ref, nbytes):
+        op = self.op(_ffi.OP_COPY)
+        op["l"][0] = nbytes
+        self.set_t(op, 0, src_ref)
+        self.set_t(op, 1, dst_ref)
+
+    def finish(self, rec=None, out_shapes=None) -> Plan:
+        p = Plan()
+        p.ops = np.stack(self.ops) if self.ops else np.zeros(0, dtype=OP_DTYPE)
+        p.ops = np.ascontiguousarray(p.ops)
+        p.n_ops = len(self.ops)
+        p.act_bytes, p.scr_bytes, p.bscr_bytes = self.act.size, self.scr_bytes, self.bscr.size
+        p.rec, p.out_shapes = rec, out_shapes
+        return p
+
+
+# ================================================================================================ network base class
+class CtlNet(nn.Module):
+    """Flat-storage network whose compute is a compiled plan of HIP kernel launches."""
+
+    def __init__(self, spec, cin: int, device):
+        super().__init__()
+        self._spec = spec
+        self.cin = cin
+        self._bn_track = True              # False inside `disable_tracking_bn_stats` (mode B)
+        self._convs: Dict[str, ConvInfo] = {}
+        self._bns: Dict[str, BNInfo] = {}
+        self._plans: Dict[tuple, Plan] = {}
+        self._packed_ok = False
+        self._scr: Optional[torch.Tensor] = None
+        self._build_tree()
+        self._finalize_storage(torch.device(device))
+
+    # ---------------------------------------------------------------- construction / storage
+    def _build_tree(self):
+        for key, kind, a in self._spec:
+            parts = key.split(".")
+            m = self
+            for p in parts[:-1]:
+                if p not in m._modules:
+                    m.add_module(p, _Holder())
+                m = m._modules[p]
+            if kind == "bn":
+                leaf = _BNP(a[0])
+            else:
+                leaf = _ConvP(a[0], a[1], a[2], transposed=(kind == "convT"))
+            m.add_module(parts[-1], leaf)
+
+    def _finalize_storage(self, device: torch.device):
+        old_p = {n: p.detach().to("cpu") for n, p in self.named_parameters()}
+        old_b = {n: b.detach().to("cpu") for n, b in self.named_buffers()}
+        poff, off = {}, 0
+        for n, p in self.named_parameters():
+            poff[n] = off
+            off += _rup(p.numel(), ALIGN_F)
+        self._poff, self._pcount = poff, off
+        flat = torch.zeros(off, dtype=torch.float32, device=device)
+        grad = torch.zeros(off, dtype=torch.float32, device=device)
+        for n, p in self.named_parameters():
+            v = flat[poff[n]:poff[n] + p.numel()].view(p.shape)
+            v.copy_(old_p[n])
+            p.data = v
+            p.grad = grad[poff[n]:poff[n] + p.numel()].view(p.shape)
+        self._flat_data = flat
+        self._flat = flat.detach().requires_grad_(True)      # the autograd leaf (shares storage)
+        self._flat.grad = grad
+        boff, off, nbt_names = {}, 0, []
+        for n, b in self.named_buffers():
+            if b.dtype == torch.long:
+                nbt_names.append(n)
+            else:
+                boff[n] = off
+                off += _rup(b.numel(), ALIGN_F)
+        self._bflat = torch.zeros(max(off, 1), dtype=torch.float32, device=device)
+        self._nbt = torch.zeros(max(len(nbt_names), 1), dtype=torch.long, device=device)
+        mods = dict(self.named_modules())
+        for n in list(boff) + nbt_names:
+            mname, bname = n.rsplit(".", 1)
+            if n in boff:
+                v = self._bflat[boff[n]:boff[n] + old_b[n].numel()].view(old_b[n].shape)
+            else:
+                v = self._nbt[nbt_names.index(n)]
+            v.copy_(old_b[n])
+            mods[mname]._buffers[bname] = v
+        self._boff, self._nbt_names = boff, nbt_names
+        # op-level descriptors + packed-weight layout
+        wp = 0
+        for key, kind, a in self._spec:
+            if kind == "bn":
+                bi = BNInfo()
+                bi.key, bi.c = key, a[0]
+                bi.g_off, bi.b_off = poff[key + ".weight"], poff[key + ".bias"]
+                bi.rm_off, bi.rv_off = boff[key + ".running_mean"], boff[key + ".running_var"]
+                bi.nbt_idx = nbt_names.index(key + ".num_batches_tracked")
+                self._bns[key] = bi
+            else:
+                ci = ConvInfo()
+                ci.key, ci.cin, ci.cout, ci.ks, ci.transposed = key, a[0], a[1], a[2], kind == "convT"
+                ci.w_off, ci.b_off = poff[key + ".weight"], poff[key + ".bias"]
+                if ci.transposed:     # forward = 4 scattered 1x1 problems, dgrad = 2x2 stride-2 conv
+                    ci.wp_sub = lib.ctl_conv_wpack_floats(ci.cin, ci.cout, 1)
+                    ci.wp_fwd, wp = wp, wp + 4 * ci.wp_sub
+                    ci.wp_dgrad, wp = wp, wp + lib.ctl_conv_wpack_floats(ci.cout, ci.cin, 2)
+                else:
+                    ci.wp_sub = 0
+                    ci.wp_fwd, wp = wp, wp + lib.ctl_conv_wpack_floats(ci.cin, ci.cout, ci.ks)
+                    ci.wp_dgrad, wp = wp, wp + lib.ctl_conv_wpack_floats(ci.cout, ci.cin, ci.ks)
+                self._convs[key] = ci
+        self._wp = torch.zeros(max(wp, 1), dtype=torch.float32, device=device)
+        self._pack_plan = self._build_pack_plan()
+        self._packed_ok = False
+        self._plans.clear()
+        self._scr = None
+
+    def _apply(self, fn, recurse=True):
+        probe = fn(torch.zeros(1, dtype=torch.float32, device=self._flat_data.device))
+        if probe.dtype != torch.float32:
+            raise _ffi.CtlError("CtlNet holds fp32 master weights; dtype conversion is not supported")
+        if probe.device != self._flat_data.device:
+            self._finalize_storage(probe.device)
+        return self
+
+    @property
+    def device(self):
+        return self._flat_data.device
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        r = super().load_state_dict(state_dict, strict=strict, **kw)
+        self._packed_ok = False
+        return r
+
+    def zero_grad(self, set_to_none: bool = False):
+        """Gradients are views of one flat buffer that is never re-allocated: zero it in place.  (upstream calls
+        `decoder_function.zero_grad()` inside the masking functions, model_util.py:251-254)"""
+        self._flat.grad.zero_()
+
+    def weights_changed(self):
+        """Call after modifying parameters in place by other means than the engine's optimizer / load_state_dict."""
+        self._packed_ok = False
+
+    def wants_param_grad(self) -> bool:
+        return any(p.requires_grad for p in self.parameters())
+
+    # ---------------------------------------------------------------- weight packing
+    def _build_pack_plan(self) -> Plan:
+        pb = PlanBuilder(self)
+
+        def pack(src_off_f, dst_off_f, cout, cin, ks, strides, flip):
+            op = pb.op(_ffi.OP_PACK)
+            op["i"][:4] = [cout, cin, ks, 1 if flip else 0]
+            op["l"][:] = strides
+            pb.set_t(op, 0, (S_P, 4 * src_off_f))
+            pb.set_t(op, 1, (S_WP, 4 * dst_off_f))
+
+        for ci in self._convs.values():
+            k2 = ci.ks * ci.ks
+            if ci.transposed:      # weight [Cin][Cout][2][2]
+                for z in range(4):
+                    pack(ci.w_off + z, ci.wp_fwd + z * ci.wp_sub, ci.cout, ci.cin, 1, (4, ci.cout * 4, 0, 0), False)
+                pack(ci.w_off, ci.wp_dgrad, ci.cin, ci.cout, 2, (ci.cout * 4, 4, 2, 1), False)
+            else:                  # weight [Cout][Cin][ks][ks]
+                pack(ci.w_off, ci.wp_fwd, ci.cout, ci.cin, ci.ks, (ci.cin * k2, k2, ci.ks, 1), False)
+                pack(ci.w_off, ci.wp_dgrad, ci.cin, ci.cout, ci.ks, (k2, ci.cin * k2, ci.ks, 1), True)
+        return pb.finish()
+
+    def ensure_packed(self):
+        if not self._packed_ok:
+            self._run(self._pack_plan, {S_P: self._flat_data, S_WP: self._wp})
+            self._packed_ok = True
+
+    # ---------------------------------------------------------------- plan execution
+    def _run(self, plan: Plan, tensors: Dict[int, torch.Tensor]):
+        if not self._flat_data.is_cuda:
+            raise _ffi.CtlError("the HIP engine needs the network on a GPU device; there is no CPU fallback")
+        if plan.scr_bytes:
+            if self._scr is None or self._scr.numel() < plan.scr_bytes:
+                self._scr = torch.empty(plan.scr_bytes, dtype=torch.uint8, device=self.device)
+            tensors = dict(tensors)
+            tensors[S_SCR] = self._scr
+        bases = (ctypes.c_void_p * N_SLOTS)()
+        for s, t in tensors.items():
+            bases[s] = t.data_ptr()
+        check(lib.ctl_plan_run(plan.ops.ctypes.data, plan.n_ops, bases, N_SLOTS, torch.cuda.current_stream().cuda_stream),
+              f"{type(self).__name__} plan")
+
+    def bn_mode(self) -> str:
+        if not self.training:
+            return "C"
+        return "A" if self._bn_track else "B"
+
+    def _wp_ref(self, off_f):
+        return (S_WP, 4 * off_f)
+
+    # ---------------------------------------------------------------- shared block emitters
+    def _emit_block_fwd(self, pb: PlanBuilder, prefix: str, pre: str, xin: T, xin_pro, mode: str) -> Tuple[T, dict]:
+        """res_convdown (pre='down') / res_up_family (pre='nn' | 'convT'):  out = LReLU(conv1x1(x') + BN(conv(LReLU(BN(conv(x'))))))"""
+        C, B = self._convs, self._bns
+        train = mode != "C"
+        rec = {"prefix": prefix, "pre": pre, "xin": xin, "xin_pro": xin_pro}
+        if pre == "down":
+            ci = C[prefix + ".down"]
+            src, _, _ = pb.conv(xin, self._wp_ref(ci.wp_fwd), ci.cout, 3, stride=2, pro=xin_pro, bias_ref=pb.P(ci.b_off))
+            src_mode = _ffi.IN_PLAIN
+        elif pre == "convT":
+            ci = C[prefix + ".up"]
+            src, _, _ = pb.conv(xin, self._wp_ref(ci.wp_fwd), ci.cout, 1, bias_ref=pb.P(ci.b_off), nsub=4)
+            src_mode = _ffi.IN_PLAIN
+        else:
+            src, src_mode = xin, _ffi.IN_UP2
+        c0, c3, c1 = C[prefix + ".conv.0"], C[prefix + ".conv.3"], C[prefix + ".conv_input"]
+        u, st, blk = pb.conv(src, self._wp_ref(c0.wp_fwd), c0.cout, 3, in_mode=src_mode, bias_ref=pb.P(c0.b_off), stats=train)
+        co1 = pb.bn_forward(B[prefix + ".conv.1"], st, blk, u.n * u.h * u.w, mode)
+        v, st, blk = pb.conv(u, self._wp_ref(c3.wp_fwd), c3.cout, 3, pro=(co1["scale"], co1["shift"], SLOPE),
+                             bias_ref=pb.P(c3.b_off), stats=train)
+        co2 = pb.bn_forward(B[prefix + ".conv.4"], st, blk, v.n * v.h * v.w, mode)
+        out, _, _ = pb.conv(src, self._wp_ref(c1.wp_fwd), c1.cout, 1, in_mode=src_mode, bias_ref=pb.P(c1.b_off),
+                            res=(v, co2["scale"], co2["shift"]), act=_ffi.ACT_LEAKY, slope=SLOPE)
+        rec.update(src=src, src_mode=src_mode, u=u, v=v, out=out, co1=co1, co2=co2)
+        return out, rec
+
+    def _emit_block_bwd(self, pb: PlanBuilder, rec: dict, d_out: T, d_in: Optional[T], need_w: bool, affine: bool) -> T:
+        """Backward of one residual block.  Returns the gradient w.r.t. the block input `xin` (post-activation tensor
+        the block consumed; if rec['xin_pro'] is set it is the gradient w.r.t. the *activated* virtual tensor)."""
+        C, B = self._convs, self._bns
+        prefix, pre = rec["prefix"], rec["pre"]
+        src, src_mode, u, v, out, xin = rec["src"], rec["src_mode"], rec["u"], rec["v"], rec["out"], rec["xin"]
+        c0, c3, c1 = C[prefix + ".conv.0"], C[prefix + ".conv.3"], C[prefix + ".conv_input"]
+        A = pb.bscr
+        # residual tail: dS (to conv_input) and dV (to conv.3)
+        ds, dv = A.tensor(out.n, out.h, out.w, out.c), A.tensor(out.n, out.h, out.w, out.c)
+        pb.bn_backward(0, d_out, out, v, B[prefix + ".conv.4"], rec["co2"], SLOPE, ds=ds, dx=dv, affine_grad=need_w and affine)
+        pro1 = (rec["co1"]["scale"], rec["co1"]["shift"], SLOPE)
+        k9 = 9
+        if need_w:
+            pb.wgrad(u, dv, 3, pro=pro1, dw_ref=pb.G(c3.w_off), strides=(c3.cin * k9, k9, 3, 1), dbias_ref=pb.G(c3.b_off))
+        da, _, _ = pb.conv(dv, self._wp_ref(c3.wp_dgrad), c3.cin, 3, arena=A)
+        # BN1 -> LeakyReLU tail (in place: dU overwrites dA)
+        pb.bn_backward(1, da, None, u, B[prefix + ".conv.1"], rec["co1"], SLOPE, ds=None, dx=da, affine_grad=need_w and affine)
+        du = da
+        if need_w:
+            pb.wgrad(src, du, 3, in_mode=src_mode, dw_ref=pb.G(c0.w_off), strides=(c0.cin * k9, k9, 3, 1), dbias_ref=pb.G(c0.b_off))
+            pb.wgrad(src, ds, 1, in_mode=src_mode, dw_ref=pb.G(c1.w_off), strides=(c1.cin, 1, 1, 1), dbias_ref=pb.G(c1.b_off))
+        # gradient w.r.t. x' (full resolution of this block)
+        if pre == "down" or pre == "convT":
+            dsrc_shape = (src.n, src.h, src.w, src.c)
+        else:
+            dsrc_shape = (src.n, 2 * src.h, 2 * src.w, src.c)
+        dsrc = A.tensor(*dsrc_shape)
+        pb.conv(du, self._wp_ref(c0.wp_dgrad), c0.cin, 3, out=dsrc)
+        pb.conv(ds, self._wp_ref(c1.wp_dgrad), c1.cin, 1, out=dsrc, accum=True)
+        if d_in is None:
+            d_in = A.tensor(xin.n, xin.h, xin.w, xin.c)
+        if pre == "nn":
+            pb.sumpool2(dsrc, d_in)
+        elif pre == "convT":
+            ci = C[prefix + ".up"]
+            if need_w:
+                pb.chan_sum(dsrc, pb.G(ci.b_off))
+                # role swap: "input" = dsrc (full res), "output gradient" = xin  ->  Wt[ci][co][a][b]
+                pb.wgrad(dsrc, xin, 2, stride=2, dw_ref=pb.G(ci.w_off), strides=(ci.cout * 4, 4, 2, 1))
+            pb.conv(dsrc, self._wp_ref(ci.wp_dgrad), ci.cin, 2, stride=2, out=d_in)
+        else:  # down: stride-2 conv
+            ci = C[prefix + ".down"]
+            if need_w:
+                pb.wgrad(xin, dsrc, 3, stride=2, pro=rec["xin_pro"], dw_ref=pb.G(ci.w_off), strides=(ci.cin * k9, k9, 3, 1),
+                         dbias_ref=pb.G(ci.b_off))
+            pb.conv(dsrc, self._wp_ref(ci.wp_dgrad), ci.cin, 3, in_mode=_ffi.IN_ZINS2, out=d_in, hout=xin.h, wout=xin.w)
+        return d_in
+
+    def _emit_conv_bn_pair_bwd(self, pb, conv_key, bn_key, x: T, x_pro, u: T, co, slope, d_act: T, d_x: Optional[T], need_w, affine,
+                               need_dx=True) -> Optional[T]:
+        """Backward of  a = act(BN(conv3x3/1x1(x)))  given d_act (gradient w.r.t. a).  Returns gradient w.r.t. x
+        (w.r.t. the activated virtual tensor if x_pro is set)."""
+        ci, bn = self._convs[conv_key], self._bns[bn_key]
+        A = pb.bscr
+        du = A.tensor(u.n, u.h, u.w, u.c)
+        pb.bn_backward(1, d_act, None, u, bn, co, slope, ds=None, dx=du, affine_grad=need_w and affine)
+        k2 = ci.ks * ci.ks
+        if need_w:
+            pb.wgrad(x, du, ci.ks, pro=x_pro, dw_ref=pb.G(ci.w_off), strides=(ci.cin * k2, k2, ci.ks, 1), dbias_ref=pb.G(ci.b_off))
+        if not need_dx:
+            return None
+        if d_x is None:
+            d_x = A.tensor(x.n, x.h, x.w, x.c)
+        pb.conv(du, self._wp_ref(ci.wp_dgrad), ci.cin, ci.ks, out=d_x)
+        return d_x
+
+    # ---------------------------------------------------------------- public compute entry points
+    def _alloc_out(self, shape):
+        n, h, w, c = shape
+        return torch.empty((n, c, h, w), dtype=torch.float32, device=self.device, memory_format=torch.channels_last)
+
+    def run_forward(self, x: torch.Tensor, mode: str):
+        """Returns (outputs tuple, act workspace tensor, plan).  x: logical NCHW, NHWC memory."""
+        n, c, h, w = x.shape
+        if c != self.cin:
+            raise ValueError(f"{type(self).__name__}: expected {self.cin} input channels, got {c}")
+        key = ("f", n, h, w, mode)
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = self._plans[key] = self._compile_forward(n, h, w, mode)
+        self.ensure_packed()
+        act = torch.empty(max(plan.act_bytes, 256), dtype=torch.uint8, device=self.device)
+        outs = [self._alloc_out(s) for s in plan.out_shapes]
+        tensors = {S_X: x, S_P: self._flat_data, S_B: self._bflat, S_NBT: self._nbt, S_WP: self._wp, S_ACT: act, S_OUT0: outs[0]}
+        if len(outs) > 1:
+            tensors[S_OUT1] = outs[1]
+        self._run(plan, tensors)
+        return tuple(outs), act, plan
+
+    def run_backward(self, x, act, outs, fwd_plan: Plan, mode: str, douts, need_dx: bool, need_w: bool, affine: bool):
+        """Returns (dx or None, flat parameter gradient or None)."""
+        n, c, h, w = x.shape
+        mask = tuple(d is not None for d in douts)
+        key = ("b", n, h, w, mode, mask, need_dx, need_w, affine)
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = self._plans[key] = self._compile_backward(fwd_plan, mode, mask, need_dx, need_w, affine)
+        bscr = torch.empty(max(plan.bscr_bytes, 256), dtype=torch.uint8, device=self.device)
+        self._dbg_last = (plan, bscr)          # lets tests inspect intermediate gradients
+        tensors = {S_X: x, S_P: self._flat_data, S_WP: self._wp, S_ACT: act, S_BSCR: bscr, S_OUT0: outs[0]}
+        if len(outs) > 1:
+            tensors[S_OUT1] = outs[1]
+        for slot, d in zip((S_DOUT0, S_DOUT1), douts):
+            if d is not None:
+                tensors[slot] = d
+        dx = gflat = None
+        if need_dx:
+            dx = self._alloc_out((n, h, w, c))
+            tensors[S_DX] = dx
+        if need_w:
+            gflat = torch.empty(self._pcount, dtype=torch.float32, device=self.device)
+            tensors[S_GRAD] = gflat
+        self._run(plan, tensors)
+        return dx, gflat
+
+
+# ================================================================================================ encoders
+class MyEncoder(CtlNet):
+    """MyEncoder(feature_reduce=4, norm=BatchNorm2d, act=ReLU): ladder 16-32-64-128-128, spatial /16."""
+
+    def __init__(self, input_channel: int, feature_reduce: int = 4, device="cuda", _spec=None, _prefix=""):
+        self._px = _prefix
+        self.chan = [64 // feature_reduce, 128 // feature_reduce, 256 // feature_reduce, 512 // feature_reduce,
+                     512 // feature_reduce]
+        super().__init__(_spec if _spec is not None else _init.encoder_spec("", input_channel, feature_reduce),
+                         input_channel, device)
+
+    # -- plan pieces shared with the dual encoder
+    def _emit_encoder_fwd(self, pb: PlanBuilder, x: T, mode: str, z_out: T):
+        C, B, px = self._convs, self._bns, self._px
+        train = mode != "C"
+        c0, c3 = C[px + "inc.0"], C[px + "inc.3"]
+        u0, st, blk = pb.conv(x, self._wp_ref(c0.wp_fwd), c0.cout, 3, bias_ref=pb.P(c0.b_off), stats=train)
+        co0 = pb.bn_forward(B[px + "inc.1"], st, blk, u0.n * u0.h * u0.w, mode)
+        v0, st, blk = pb.conv(u0, self._wp_ref(c3.wp_fwd), c3.cout, 3, pro=(co0["scale"], co0["shift"], SLOPE),
+                              bias_ref=pb.P(c3.b_off), stats=train)
+        co1 = pb.bn_forward(B[px + "inc.4"], st, blk, v0.n * v0.h * v0.w, mode)
+        rec = {"x": x, "u0": u0, "v0": v0, "co0": co0, "co1": co1, "blocks": []}
+        cur, cur_pro = v0, (co1["scale"], co1["shift"], SLOPE)      # x1 = LReLU(BN(v0)) stays virtual
+        for i in range(1, 5):
+            cur, brec = self._emit_block_fwd(pb, f"{px}down{i}", "down", cur, cur_pro, mode)
+            cur_pro = None
+            rec["blocks"].append(brec)
+        cf = C[px + "final_conv.0"]
+        uf, st, blk = pb.conv(cur, self._wp_ref(cf.wp_fwd), cf.cout, 1, bias_ref=pb.P(cf.b_off), stats=train)
+        cof = pb.bn_forward(B[px + "final_conv.1"], st, blk, uf.n * uf.h * uf.w, mode)
+        pb.bn_act(uf, cof, 0.0, z_out)                               # act = ReLU
+        rec.update(uf=uf, cof=cof, z=z_out, x4=cur)
+        return rec
+
+    def _emit_encoder_bwd(self, pb: PlanBuilder, rec, dz: T, need_dx: bool, need_w: bool, affine: bool):
+        px = self._px
+        d = self._emit_conv_bn_pair_bwd(pb, px + "final_conv.0", px + "final_conv.1", rec["x4"], None, rec["uf"], rec["cof"], 0.0,
+                                        dz, None, need_w, affine)
+        for brec in reversed(rec["blocks"]):
+            d = self._emit_block_bwd(pb, brec, d, None, need_w, affine)
+        # d = gradient w.r.t. x1 = LReLU(BN(v0))
+        pro0 = (rec["co0"]["scale"], rec["co0"]["shift"], SLOPE)
+        d = self._emit_conv_bn_pair_bwd(pb, px + "inc.3", px + "inc.4", rec["u0"], pro0, rec["v0"], rec["co1"], SLOPE, d, None,
+                                        need_w, affine)
+        dx = T((S_DX, 0), *rec["x"][1:]) if need_dx else None
+        self._emit_conv_bn_pair_bwd(pb, px + "inc.0", px + "inc.1", rec["x"], None, rec["u0"], rec["co0"], SLOPE, d, dx,
+                                    need_w, affine, need_dx=need_dx)
+
+    def _zdims(self, n, h, w):
+        for _ in range(4):
+            h, w = (h + 1) // 2, (w + 1) // 2
+        return (n, h, w, self.chan[4])
+
+    def _compile_forward(self, n, h, w, mode) -> Plan:
+        pb = PlanBuilder(self)
+        zs = self._zdims(n, h, w)
+        rec = self._emit_encoder_fwd(pb, T((S_X, 0), n, h, w, self.cin), mode, T((S_OUT0, 0), *zs))
+        return pb.finish(rec, [zs])
+
+    def _compile_backward(self, fwd: Plan, mode, mask, need_dx, need_w, affine) -> Plan:
+        pb = PlanBuilder(self)
+        if need_w:
+            pb.zero((S_GRAD, 0), 4 * self._pcount)
+        z = fwd.rec["z"]
+        self._emit_encoder_bwd(pb, fwd.rec, T((S_DOUT0, 0), *z[1:]), need_dx, need_w, affine)
+        return pb.finish()
+
+    def forward(self, x):
+        from .autograd import net_apply
+        return net_apply(self, x)[0]
+
+
+class Dual_Branch_Encoder(MyEncoder):
+    """FTN encoder: z_i = general_encoder(x), z_s = code_decoupler(z_i)."""
+
+    def __init__(self, input_channel: int, z_level_1_channel: int = 128, z_level_2_channel: int = 128, feature_reduce: int = 4,
+                 device="cuda"):
+        assert z_level_1_channel == z_level_2_channel == 512 // feature_reduce
+        super().__init__(input_channel, feature_reduce, device,
+                         _spec=_init.dual_encoder_spec(input_channel, z_level_1_channel, feature_reduce),
+                         _prefix="general_encoder.")
+
+    def _compile_forward(self, n, h, w, mode) -> Plan:
+        pb = PlanBuilder(self)
+        C, B = self._convs, self._bns
+        train = mode != "C"
+        zs = self._zdims(n, h, w)
+        z_i, z_s = T((S_OUT0, 0), *zs), T((S_OUT1, 0), *zs)
+        rec = self._emit_encoder_fwd(pb, T((S_X, 0), n, h, w, self.cin), mode, z_i)
+        d0, d3 = C["code_decoupler.0"], C["code_decoupler.3"]
+        ud, st, blk = pb.conv(z_i, self._wp_ref(d0.wp_fwd), d0.cout, 3, bias_ref=pb.P(d0.b_off), stats=train)
+        cod0 = pb.bn_forward(B["code_decoupler.1"], st, blk, ud.n * ud.h * ud.w, mode)
+        vd, st, blk = pb.conv(ud, self._wp_ref(d3.wp_fwd), d3.cout, 3, pro=(cod0["scale"], cod0["shift"], SLOPE),
+                              bias_ref=pb.P(d3.b_off), stats=train)
+        cod1 = pb.bn_forward(B["code_decoupler.4"], st, blk, vd.n * vd.h * vd.w, mode)
+        pb.bn_act(vd, cod1, 0.0, z_s)                                # nn.ReLU at the end of code_decoupler
+        rec.update(ud=ud, vd=vd, cod0=cod0, cod1=cod1, z_s=z_s)
+        return pb.finish(rec, [zs, zs])
+
+    def _compile_backward(self, fwd: Plan, mode, mask, need_dx, need_w, affine) -> Plan:
+        pb = PlanBuilder(self)
+        rec = fwd.rec
+        if need_w:
+            pb.zero((S_GRAD, 0), 4 * self._pcount)
+        z_i = rec["z"]
+        dzi_in = T((S_DOUT0, 0), *z_i[1:]) if mask[0] else None
+        if mask[1]:
+            dzs = T((S_DOUT1, 0), *z_i[1:])
+            pro = (rec["cod0"]["scale"], rec["cod0"]["shift"], SLOPE)
+            d = self._emit_conv_bn_pair_bwd(pb, "code_decoupler.3", "code_decoupler.4", rec["ud"], pro, rec["vd"], rec["cod1"], 0.0,
+                                            dzs, None, need_w, affine)
+            # conv d.0 consumes z_i: its dgrad is added to the gradient arriving at z_i directly
+            ci, bn = self._convs["code_decoupler.0"], self._bns["code_decoupler.1"]
+            du = pb.bscr.tensor(*rec["ud"][1:])
+            pb.bn_backward(1, d, None, rec["ud"], bn, rec["cod0"], SLOPE, ds=None, dx=du, affine_grad=need_w and affine)
+            if need_w:
+                pb.wgrad(z_i, du, 3, dw_ref=pb.G(ci.w_off), strides=(ci.cin * 9, 9, 3, 1), dbias_ref=pb.G(ci.b_off))
+            dzi = pb.bscr.tensor(*z_i[1:])
+            if dzi_in is not None:      # dz_i = (gradient arriving at z_i directly) + dgrad of code_decoupler.0
+                pb.copy(dzi_in.ref, dzi.ref, 4 * z_i.n * z_i.h * z_i.w * z_i.c)
+            pb.conv(du, self._wp_ref(ci.wp_dgrad), ci.cin, 3, out=dzi, accum=dzi_in is not None)
+        else:
+            dzi = dzi_in
+        if dzi is None:
+            raise _ffi.CtlError("Dual_Branch_Encoder backward called without any output gradient")
+        self._emit_encoder_bwd(pb, rec, dzi, need_dx, need_w, affine)
+        return pb.finish()
+
+    def forward(self, x):
+        from .autograd import net_apply
+        return net_apply(self, x)
+
+    def filter_code(self, z):
+        raise NotImplementedError("filter_code(z) alone is off the training hot path (SURVEY 8f rank 4)")
+
+
+# ================================================================================================ decoder
+class MyDecoder(CtlNet):
+    """MyDecoder(up_type in {'NN','Conv2'}, norm=BatchNorm2d, last_act in {None, Sigmoid})."""
+
+    def __init__(self, input_channel: int, output_channel: int, feature_reduce: int = 4, up_type: str = "NN",
+                 last_act: Optional[str] = None, device="cuda"):
+        if up_type not in ("NN", "Conv2"):
+            raise NotImplementedError(f"up_type {up_type!r} (the reference's FCN_16_standard uses 'NN' and 'Conv2')")
+        self.up_type, self.out_ch = up_type, output_channel
+        self.sigmoid = last_act in ("sigmoid", "Sigmoid") or isinstance(last_act, nn.Sigmoid)
+        super().__init__(_init.decoder_spec(input_channel, output_channel, up_type, feature_reduce), input_channel, device)
+
+    def _compile_forward(self, n, h, w, mode) -> Plan:
+        pb = PlanBuilder(self)
+        cur = T((S_X, 0), n, h, w, self.cin)
+        rec = {"x": cur, "blocks": []}
+        pre = "nn" if self.up_type == "NN" else "convT"
+        for i in range(1, 5):
+            cur, brec = self._emit_block_fwd(pb, f"up{i}", pre, cur, None, mode)
+            rec["blocks"].append(brec)
+        cf = self._convs["final_conv"]
+        out = T((S_OUT0, 0), cur.n, cur.h, cur.w, cf.cout)
+        pb.conv(cur, self._wp_ref(cf.wp_fwd), cf.cout, 1, bias_ref=pb.P(cf.b_off), act=_ffi.ACT_SIGMOID if self.sigmoid else 0,
+                out=out)
+        rec.update(x4=cur, out=out)
+        return pb.finish(rec, [(out.n, out.h, out.w, out.c)])
+
+    def _compile_backward(self, fwd: Plan, mode, mask, need_dx, need_w, affine) -> Plan:
+        pb = PlanBuilder(self)
+        rec = fwd.rec
+        if need_w:
+            pb.zero((S_GRAD, 0), 4 * self._pcount)
+        out, x4, cf = rec["out"], rec["x4"], self._convs["final_conv"]
+        dout = T((S_DOUT0, 0), *out[1:])
+        if self.sigmoid:
+            dl = pb.bscr.tensor(*out[1:])
+            pb.sigmoid_bwd(dout, out, dl)
+            dout = dl
+        if need_w:
+            pb.wgrad(x4, dout, 1, dw_ref=pb.G(cf.w_off), strides=(cf.cin, 1, 1, 1), dbias_ref=pb.G(cf.b_off))
+        d, _, _ = pb.conv(dout, self._wp_ref(cf.wp_dgrad), cf.cin, 1, arena=pb.bscr)
+        blocks = rec["blocks"]
+        dbg = {"d_out4": d}
+        for i in range(3, -1, -1):
+            d_in = T((S_DX, 0), *rec["x"][1:]) if (i == 0 and need_dx) else None
+            d = self._emit_block_bwd(pb, blocks[i], d, d_in, need_w, affine)
+            dbg[f"d_out{i}"] = d
+        return pb.finish(dbg)
+
+    def forward(self, x):
+        from .autograd import net_apply
+        return net_apply(self, x)[0]
+
+
+def build_networks(image_ch: int = 1, num_classes: int = 4, reduce_factor: int = 4, device="cuda",
+                   state_dicts: Optional[dict] = None) -> Dict[str, CtlNet]:
+    """`get_network('FCN_16_standard')` (model.py:76-149).  Without `state_dicts` the weights are drawn exactly like the
+    reference does for the current torch seed (see init.py)."""
+    z = 512 // reduce_factor
+    sds = state_dicts if state_dicts is not None else _init.reference_init_state_dicts(image_ch, num_classes, reduce_factor)
+    nets = {
+        "image_encoder": Dual_Branch_Encoder(image_ch, z, z, reduce_factor, device=device),
+        "segmentation_decoder": MyDecoder(z, num_classes, reduce_factor, "NN", None, device=device),
+        "shape_encoder": MyEncoder(num_classes, reduce_factor, device=device),
+        "shape_decoder": MyDecoder(z, num_classes, reduce_factor, "NN", None, device=device),
+        "image_decoder": MyDecoder(z, image_ch, reduce_factor, "Conv2", "sigmoid", device=device),
+    }
+    for k, net in nets.items():
+        if k in sds and sds[k] is not None:
+            net.load_state_dict(sds[k])
+    return nets

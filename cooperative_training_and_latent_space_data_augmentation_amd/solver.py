@@ -1,0 +1,410 @@
+"""`AdvancedTripletReconSegmentationModel` -- drop-in for the reference solver
+(medseg/models/advanced_triplet_recon_segmentation_model.py:24-813) on the MI355X engine.
+
+Same constructor, method names, argument meaning and return values as upstream, so
+`medseg/train_adv_supervised_segmentation_triplet.py` can import this class instead.  The five
+networks live in `self.model` (dict name -> nn.Module, reference state_dict keys); compute goes through compiled HIP
+plans (nets.py), losses / STN inputs through fused HIP ops (autograd.py), the optimizer is one flat Adam launch per
+network (optim.py).  Optional keyword-only `override` dicts inject the reference's random draws for parity tests.
+"""
+from __future__ import annotations
+
+import gc
+import itertools
+import os
+import random
+from os.path import join
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .autograd import cross_entropy_2D, scaled_mse, softmax_t
+from .metrics import runningScore
+from .model_util import (_disable_tracking_bn_stats, _draw_seed, mask_latent_code_channel_wise,
+                         mask_latent_code_spatial_wise, set_grad)
+from .nets import build_networks
+from .optim import FlatAdam
+
+_DEFAULT_IMG_CFG = {"loss_name": "mse", "mask_type": "random", "max_threshold": 0.5, "random_threshold": True, "if_soft": True}
+_DEFAULT_SEG_CFG = {"loss_name": "ce", "mask_type": "random", "max_threshold": 0.5, "random_threshold": True, "if_soft": True}
+
+
+def basic_loss_fn(pred, target, loss_type="cross entropy"):
+    """custom_loss.py:8-19 -- the solver only ever asks for 'cross entropy'."""
+    if loss_type != "cross entropy":
+        raise NotImplementedError(loss_type)
+    return cross_entropy_2D(pred, target)
+
+
+class AdvancedTripletReconSegmentationModel(nn.Module):
+    def __init__(self, network_type="FCN_16_standard", image_ch=1, learning_rate=1e-4, encoder_dropout=None,
+                 decoder_dropout=None, num_classes=4, n_iter=1, checkpoint_dir=None, use_gpu=True, debug=False):
+        super().__init__()
+        if network_type not in ("FCN_16_standard", "FCN_16_standard_w_o_filter", "FCN_16_standard_share_code"):
+            raise NotImplementedError(network_type)
+        if encoder_dropout is not None or decoder_dropout is not None:
+            raise NotImplementedError("encoder/decoder Dropout2d is unused by the reference configs (dropout=None)")
+        if not use_gpu:
+            raise RuntimeError("this engine runs on MI355X only (use_gpu=True); the CPU path is the oracle under oracle/")
+        self.network_type, self.image_ch, self.checkpoint_dir = network_type, image_ch, checkpoint_dir
+        self.num_classes, self.learning_rate, self.n_iter = num_classes, learning_rate, n_iter
+        self.encoder_dropout, self.decoder_dropout = encoder_dropout, decoder_dropout
+        self.use_gpu, self.debug = use_gpu, debug
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        self.model = self.get_network(checkpoint_dir=checkpoint_dir)
+        self.optimizers = None
+        self.reset_all_optimizers()
+        self.latent_code = {"image": None, "segmentation": None, "shape": None}
+        self.running_metric = self.set_running_metric()
+        self.cur_eval_images = self.cur_eval_predicts = self.cur_eval_gts = None
+        self.cur_time_predicts = {}
+        self.loss = 0.0
+        self.z_i = self.z_s = None
+        self.last_masks = {}
+        self.grad_scale = 1.0          # set to 1/world_size by the data-parallel wrapper
+        self.training = True
+
+    # ------------------------------------------------------------------ construction / checkpoints
+    def get_network(self, checkpoint_dir=None):
+        """model.py:76-149: fresh weights follow the reference's init for the current torch seed; with a checkpoint
+        directory, `<name>.pth` state dicts are loaded (model.py:114-131,157-173)."""
+        model = build_networks(self.image_ch, self.num_classes, 4, device=self.device)
+        if checkpoint_dir:
+            for name, net in model.items():
+                self.init_model(net, resume_path=join(checkpoint_dir, name + ".pth"))
+        return model
+
+    def init_model(self, model, resume_path=None):
+        if resume_path:
+            assert os.path.exists(resume_path), "path: {} must exist".format(resume_path)
+            sd = torch.load(resume_path, map_location="cpu")
+            if isinstance(sd, dict) and "model_state" in sd:
+                sd = sd["model_state"]
+            model.load_state_dict(sd)
+        return model
+
+    def parameters(self):
+        return itertools.chain(*[m.parameters() for m in self.model.values()])
+
+    def named_parameters(self):
+        return itertools.chain(*[m.named_parameters() for m in self.model.values()])
+
+    def save_model(self, save_dir, epoch_iter, model_prefix=None, save_optimizers=False):
+        """model.py:666-678: <save_dir>/<epoch>/checkpoints/<name>.pth (+ <name>_optim.pth)."""
+        epoch_path = join(save_dir, str(epoch_iter), "checkpoints")
+        os.makedirs(epoch_path, exist_ok=True)
+        for name, net in self.model.items():
+            torch.save({k: v.detach().cpu().clone() for k, v in net.state_dict().items()}, join(epoch_path, f"{name}.pth"))
+        if save_optimizers:
+            for name, opt in self.optimizers.items():
+                torch.save(opt.state_dict(), join(epoch_path, f"{name}_optim.pth"))
+
+    def save_snapshots(self, save_dir, epoch, model_prefix="interrupted"):
+        """model.py:680-701."""
+        epoch_path = join(save_dir, "interrupted", "checkpoints")
+        os.makedirs(epoch_path, exist_ok=True)
+        save_path = join(epoch_path, self.network_type + ".pkl")
+        state = {"network_type": self.network_type, "epoch": epoch,
+                 "model_state": {k: {n: v.detach().cpu().clone() for n, v in m.state_dict().items()} for k, m in self.model.items()},
+                 "optimizer_state": {k: o.state_dict() for k, o in self.optimizers.items()}}
+        torch.save(state, save_path)
+        return save_path
+
+    def load_snapshots(self, file_path):
+        """model.py:703-738."""
+        if not file_path or not os.path.exists(file_path):
+            print(f"warning: {file_path} does not exists")
+            return 0
+        ckpt = torch.load(file_path, map_location="cpu")
+        for k, net in self.model.items():
+            net.load_state_dict(ckpt["model_state"][k])
+        for k, opt in self.optimizers.items():
+            opt.load_state_dict(ckpt["optimizer_state"][k])
+        return ckpt["epoch"]
+
+    # ------------------------------------------------------------------ mode switches / optimizers (model.py:740-795)
+    def train(self, if_testing=False):
+        self.training = True          # upstream never clears this inside train(); eval() clears it first
+        for net in self.model.values():
+            if not if_testing:
+                net.train()
+                set_grad(net, True)
+            else:
+                net.eval()
+        return self
+
+    def eval(self):
+        self.training = False
+        self.train(if_testing=True)
+        return self
+
+    def set_optimizers(self):
+        self.optimizers = {name: FlatAdam(net, lr=self.learning_rate) for name, net in self.model.items()}
+
+    def reset_all_optimizers(self):
+        if self.optimizers is None:
+            self.set_optimizers()
+        for o in self.optimizers.values():
+            o.zero_grad()
+
+    def zero_grad(self):
+        self.reset_all_optimizers()
+
+    def get_optimizer(self, model_name=None):
+        return self.optimizers if model_name is None else self.optimizers[model_name]
+
+    def optimize_all_params(self):
+        for o in self.optimizers.values():
+            o.step(grad_scale=self.grad_scale)
+
+    def optimize_params(self, model_name):
+        self.optimizers[model_name].step(grad_scale=self.grad_scale)
+
+    def reset_optimizer(self, model_name):
+        self.optimizers[model_name].zero_grad()
+
+    def set_running_metric(self):
+        return runningScore(n_classes=self.num_classes)
+
+    def get_modules(self):
+        return self.model.values()
+
+    # ------------------------------------------------------------------ network plumbing (model.py:182-287)
+    def _enc(self, x, disable_track_bn_stats=False):
+        enc = self.model["image_encoder"]
+        if disable_track_bn_stats:
+            with _disable_tracking_bn_stats(enc):
+                z_i, z_s = enc(x)
+        else:
+            z_i, z_s = enc(x)
+        if "share_code" in self.network_type:
+            z_i = z_s
+        elif "w_o_filter" in self.network_type:
+            z_s = z_i
+        return z_i, z_s
+
+    @staticmethod
+    def _call(net, x, disable_track_bn_stats=False):
+        if disable_track_bn_stats:
+            with _disable_tracking_bn_stats(net):
+                return net(x)
+        return net(x)
+
+    def encode_image(self, input, disable_track_bn_stats=False):
+        z_i, z_s = self._enc(input, disable_track_bn_stats)
+        self.latent_code["image"], self.latent_code["segmentation"] = z_i, z_s
+        return z_i, z_s
+
+    def decode_image(self, latent_code, disable_track_bn_stats=False):
+        return self._call(self.model["image_decoder"], latent_code, disable_track_bn_stats)
+
+    def encode_shape(self, segmentation, is_label_map=False, disable_track_bn_stats=False, temperature=2):
+        """construct_input (basic_operations.py:110-158): one-hot(label) or softmax(logit / T)."""
+        if is_label_map:
+            inp = ops.onehot(segmentation, self.num_classes)
+        else:
+            inp = softmax_t(segmentation, temperature)
+        code = self._call(self.model["shape_encoder"], inp, disable_track_bn_stats)
+        self.latent_code["shape"] = code
+        return code
+
+    def decode_shape(self, latent_code, disable_track_bn_stats=False):
+        return self._call(self.model["shape_decoder"], latent_code, disable_track_bn_stats)
+
+    def recon_shape(self, segmentation_logit, is_label_map=False, disable_track_bn_stats=False):
+        return self.decode_shape(self.encode_shape(segmentation_logit, is_label_map, disable_track_bn_stats), disable_track_bn_stats)
+
+    def recon_image(self, image, disable_track_bn_stats=False):
+        z_i, _ = self.encode_image(image, disable_track_bn_stats)
+        return self.decode_image(z_i, disable_track_bn_stats)
+
+    def run(self, input):
+        zi, zs = self.encode_image(input)
+        init_predict = self.model["segmentation_decoder"](zs)
+        return self.decode_image(zi), init_predict, self.recon_shape(init_predict)
+
+    def forward(self, input):
+        return self.fast_predict(input)[1]
+
+    def fast_predict(self, input, disable_track_bn_stats=False):
+        """model.py:561-601 -> ((z_i, z_s), y_0)."""
+        if not self.training:
+            with torch.no_grad():
+                z_i, z_s = self._enc(input)
+                y_0 = self.model["segmentation_decoder"](z_s)
+        else:
+            z_i, z_s = self._enc(input, disable_track_bn_stats)
+            y_0 = self._call(self.model["segmentation_decoder"], z_s, disable_track_bn_stats)
+        return (z_i, z_s), y_0
+
+    def decoder_inference(self, decoder, latent_code, eval=False, disable_track_bn_stats=False):
+        """model.py:396-412."""
+        state = decoder.training
+        if eval:
+            decoder.eval()
+            with torch.no_grad():
+                logit = decoder(latent_code)
+        else:
+            logit = self._call(decoder, latent_code, disable_track_bn_stats)
+        decoder.train(mode=state)
+        return logit
+
+    # ------------------------------------------------------------------ losses of one step (model.py:414-467, 525-559)
+    def standard_training(self, clean_image_l, label_l, perturbed_image, separate_training=False, compute_gt_recon=True,
+                          update_latent=True, disable_track_bn_stats=False):
+        zero = torch.zeros((), device=clean_image_l.device)
+        (z_i, z_s), y_0 = self.fast_predict(perturbed_image, disable_track_bn_stats=disable_track_bn_stats)
+        if update_latent:
+            self.z_i, self.z_s = z_i, z_s
+        standard_supervised_loss = basic_loss_fn(y_0, label_l.detach(), "cross entropy")
+        image_recon = self.decode_image(z_i)                           # always BN mode A, as upstream (model.py:444)
+        image_recon_loss = scaled_mse(image_recon, clean_image_l, 0.5)
+        if compute_gt_recon:
+            gt_recon = self.recon_shape(label_l.detach(), is_label_map=True)
+            gt_shape_recon_loss = basic_loss_fn(gt_recon, label_l, "cross entropy")
+        else:
+            gt_shape_recon_loss = zero
+        y_0_new = y_0.detach() if separate_training else y_0
+        p_recon = self.recon_shape(y_0_new, is_label_map=False, disable_track_bn_stats=disable_track_bn_stats)
+        pred_shape_recon_loss = basic_loss_fn(p_recon, label_l, "cross entropy")
+        return standard_supervised_loss, image_recon_loss, gt_shape_recon_loss, pred_shape_recon_loss
+
+    def hard_example_training(self, perturbed_image, clean_image_l, perturbed_seg, label_l, separate_training=False, use_gpu=True):
+        dev = clean_image_l.device
+        zero = torch.zeros((), device=dev)
+        seg_loss = recon_loss = shape_loss = perturbed_p_recon_loss = zero
+        if perturbed_image is not None:
+            seg_loss, recon_loss, _, shape_loss = self.standard_training(
+                clean_image_l=clean_image_l, label_l=label_l, perturbed_image=perturbed_image.detach(), compute_gt_recon=False,
+                separate_training=separate_training, update_latent=False, disable_track_bn_stats=True)
+        if perturbed_seg is not None:
+            if separate_training:
+                perturbed_seg = perturbed_seg.detach()
+            perturbed_p_recon = self.recon_shape(perturbed_seg, is_label_map=False, disable_track_bn_stats=True)
+            perturbed_p_recon_loss = basic_loss_fn(perturbed_p_recon, label_l, "cross entropy")
+        return seg_loss, recon_loss, shape_loss, perturbed_p_recon_loss
+
+    # ------------------------------------------------------------------ latent-space hard examples (model.py:300-350, 469-523)
+    def perturb_latent_code(self, latent_code, decoder_function, label_y=None, perturb_type="random", threshold=0.5,
+                            if_soft=False, random_threshold=False, loss_type="mse", if_detach=False, *, override=None):
+        assert perturb_type in ["random", "dropout", "spatial", "channel"], "invalid method name"
+        ov = override or {}
+        perturb_type = ov.get("scheme", perturb_type)
+        if perturb_type == "random":
+            cands = ["dropout", "spatial", "channel"]
+            random.shuffle(cands)
+            perturb_type = cands[0]
+        self.last_scheme = perturb_type
+        if perturb_type == "dropout":
+            masked, keep = ops.dropout2d(latent_code.detach(), threshold, keep=ov.get("keep"), seed=_draw_seed())
+            mask = keep.view(keep.shape[0], keep.shape[1], 1, 1)      # the keep pattern (upstream's `mask` compares floats)
+            if not if_detach and latent_code.requires_grad:
+                masked = latent_code * (mask / (1.0 - threshold))
+        else:
+            assert loss_type in ["mse", "ce", "corr"], "not implemented loss"
+            fn = mask_latent_code_spatial_wise if perturb_type == "spatial" else mask_latent_code_channel_wise
+            masked, mask = fn(latent_code, num_classes=self.num_classes, decoder_function=decoder_function, label=label_y,
+                              percentile=threshold, random=random_threshold, loss_type=loss_type, if_detach=if_detach,
+                              if_soft=if_soft, k=ov.get("k"), soft_noise=ov.get("soft_noise"))
+        if if_detach:
+            masked = masked.detach()
+        return masked, mask
+
+    def hard_example_generation(self, clean_image_l, label_l, gen_corrupted_seg=True, gen_corrupted_image=True,
+                                corrupted_image_DA_config=None, corrupted_seg_DA_config=None, *, image_override=None,
+                                seg_override=None):
+        img_cfg = corrupted_image_DA_config or _DEFAULT_IMG_CFG
+        seg_cfg = corrupted_seg_DA_config or _DEFAULT_SEG_CFG
+        d_seg, d_img = self.model["segmentation_decoder"], self.model["image_decoder"]
+        set_grad(d_seg, requires_grad=False)
+        set_grad(d_img, requires_grad=False)
+        perturbed_image_0 = perturbed_y_0 = None
+        try:
+            if gen_corrupted_image:
+                self.reset_all_optimizers()
+                z, m = self.perturb_latent_code(self.z_i, d_img, label_y=clean_image_l, perturb_type=img_cfg["mask_type"],
+                                                loss_type=img_cfg["loss_name"], threshold=img_cfg["max_threshold"],
+                                                random_threshold=img_cfg["random_threshold"], if_detach=True,
+                                                if_soft=img_cfg["if_soft"], override=image_override)
+                self.last_masks["image"] = m
+                perturbed_image_0 = self.decoder_inference(d_img, z, eval=False, disable_track_bn_stats=True)
+            if gen_corrupted_seg:
+                self.reset_all_optimizers()
+                z, m = self.perturb_latent_code(self.z_s, d_seg, label_y=label_l, perturb_type=seg_cfg["mask_type"],
+                                                loss_type=seg_cfg["loss_name"], threshold=seg_cfg["max_threshold"],
+                                                random_threshold=seg_cfg["random_threshold"], if_detach=True,
+                                                if_soft=seg_cfg["if_soft"], override=seg_override)
+                self.last_masks["seg"] = m
+                perturbed_y_0 = self.decoder_inference(d_seg, z, eval=False, disable_track_bn_stats=True)
+        finally:
+            set_grad(d_seg, requires_grad=True)
+            set_grad(d_img, requires_grad=True)
+        return perturbed_image_0, perturbed_y_0
+
+    # ------------------------------------------------------------------ inference (model.py:375-394, 608-664)
+    def slow_refinement(self, pred_logit, n_steps=1, auto_stop=False, save_internal_predicts=False):
+        """Every pass re-feeds the ORIGINAL FTN logits (model.py:629), so all passes give the same tensor: run one."""
+        n_steps = self.n_iter if n_steps is None else n_steps
+        s_t = pred_logit
+        if n_steps >= 1:
+            s_t = self.recon_shape(pred_logit.detach())
+        return s_t, {0: [pred_logit]}
+
+    def predict(self, input, softmax=False, n_iter=None):
+        self.eval()
+        n_iter = self.n_iter if n_iter is None else n_iter
+        with torch.no_grad():
+            _, pred = self.fast_predict(input)
+            if n_iter >= 2:
+                pred, _ = self.slow_refinement(pred, n_steps=n_iter)
+        if softmax:
+            pred = softmax_t(pred, 1.0)
+        return pred
+
+    def evaluate(self, input, targets_npy, n_iter=None):
+        """model.py:643-664: argmax on device (uint8), confusion matrix on host."""
+        n_iter = self.n_iter if n_iter is None else n_iter
+        self.train(if_testing=True)
+        pred = self.predict(input, n_iter=n_iter)
+        pred_npy = ops.argmax_c(pred).cpu().numpy()
+        self.running_metric.update(label_trues=targets_npy, label_preds=pred_npy)
+        self.cur_eval_images = input.detach().cpu().numpy()[:, 0, :, :]
+        self.cur_eval_predicts, self.cur_eval_gts = pred_npy, targets_npy
+        return pred
+
+    def get_recon_diff(self, input):
+        self.eval()
+        with torch.no_grad():
+            (z_i, _), first = self.fast_predict(input)
+            refined = self.recon_shape(first, is_label_map=False)
+            recon = self.decode_image(z_i)
+        return torch.abs(input - recon), torch.abs(refined - first), first, refined, recon
+
+    # ------------------------------------------------------------------ one full iteration (train...py:171-237)
+    def cooperative_step(self, clean_image_l, label_l, image_l, img_cfg=None, seg_cfg=None, latent_DA=True, separate_training=False,
+                         image_override=None, seg_override=None, do_optim=True, grad_hook=None):
+        """The loop body of `train_network`, without its ten `.item()` syncs / `empty_cache()` stalls.  Returns the
+        8 loss tensors (device scalars): standard (seg, image, gt_shape, shape) + hard (seg, image, shape, perturbed)."""
+        self.train()
+        self.reset_all_optimizers()
+        std = self.standard_training(clean_image_l, label_l, perturbed_image=image_l, separate_training=separate_training)
+        loss = std[0] + std[1] + std[3] + std[2]
+        zero = torch.zeros((), device=clean_image_l.device)
+        hard = (zero, zero, zero, zero)
+        if latent_DA:
+            xh, yh = self.hard_example_generation(clean_image_l.detach(), label_l.detach(), gen_corrupted_seg=seg_cfg is not None,
+                                                  gen_corrupted_image=img_cfg is not None, corrupted_image_DA_config=img_cfg,
+                                                  corrupted_seg_DA_config=seg_cfg, image_override=image_override,
+                                                  seg_override=seg_override)
+            hard = self.hard_example_training(perturbed_image=xh, perturbed_seg=yh, clean_image_l=clean_image_l, label_l=label_l,
+                                              separate_training=separate_training)
+            loss = loss + (hard[0] + hard[1] + hard[2] + hard[3])
+        self.reset_all_optimizers()
+        loss.backward()
+        if grad_hook is not None:
+            grad_hook(self)          # data-parallel gradient all-reduce goes here
+        if do_optim:
+            self.optimize_all_params()
+        return tuple(std) + tuple(hard)

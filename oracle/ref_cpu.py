@@ -192,15 +192,17 @@ def set_grad(module: nn.Module, requires_grad: bool) -> None:
         p.requires_grad = requires_grad
 
 
-def one_hot(label: torch.Tensor, num_classes: int) -> torch.Tensor:
-    """model_util.py:168-177 and basic_operations.py:135-140: int64 [N,H,W] -> float [N,C,H,W]."""
-    return F.one_hot(label.long(), num_classes).permute(0, 3, 1, 2).to(torch.float32)
+def one_hot(label: torch.Tensor, num_classes: int, dtype=torch.float32) -> torch.Tensor:
+    """model_util.py:168-177 and basic_operations.py:135-140: int64 [N,H,W] -> float [N,C,H,W].
+    (`dtype` exists only so that the whole oracle can also be run in fp64 as an accuracy yardstick.)"""
+    return F.one_hot(label.long(), num_classes).permute(0, 3, 1, 2).to(dtype)
 
 
-def stn_input(seg: torch.Tensor, num_classes: int, is_label_map: bool, temperature: float = 2.0) -> torch.Tensor:
+def stn_input(seg: torch.Tensor, num_classes: int, is_label_map: bool, temperature: float = 2.0,
+              dtype=torch.float32) -> torch.Tensor:
     """`construct_input` as called by `encode_shape` (basic_operations.py:110-158; model.py:233-246)."""
     if is_label_map:
-        return one_hot(seg, num_classes)
+        return one_hot(seg, num_classes, dtype)
     return torch.softmax(seg / temperature, dim=1)
 
 
@@ -248,11 +250,16 @@ def _run(net: nn.Module, x, no_track: bool):
 
 
 # --------------------------------------------------------------------------- latent masking
+def _as_float(t: torch.Tensor) -> torch.Tensor:
+    """`makeVariable(type='float')` (model_util.py:603-618) casts to fp32; fp64 inputs are kept for the fp64 yardstick."""
+    return t if t.dtype == torch.float64 else t.float()
+
+
 def saliency_grad(code: torch.Tensor, decoder: Callable, label: torch.Tensor, num_classes: int,
                   loss_type: str) -> torch.Tensor:
     """dL/dz of model_util.py:202-223 (same lines 263-283 for the spatial variant)."""
-    code = code.detach().float().requires_grad_(True)
-    gt = one_hot(label, num_classes) if label.dim() < code.dim() else label
+    code = _as_float(code.detach()).requires_grad_(True)
+    gt = one_hot(label, num_classes, code.dtype) if label.dim() < code.dim() else label
     out = decoder(code)
     if loss_type == "mse":
         loss = torch.mean((out - gt) ** 2)
@@ -281,7 +288,7 @@ def mask_latent_code_channel_wise(latent_code, decoder_function, label, num_clas
                                   return_aux: bool = False):
     """model_util.py:180-255.  `k` / `soft_noise` override the numpy / torch draws of lines 228-230, 239."""
     n, c = latent_code.shape[:2]
-    code = latent_code.detach().float()
+    code = _as_float(latent_code.detach())
     grad = saliency_grad(code, decoder_function, label, num_classes, loss_type)
     score = grad.view(n, c, -1).mean(dim=2)                                   # signed mean, not |grad|: :224-225
     if k is None:
@@ -306,7 +313,7 @@ def mask_latent_code_spatial_wise(latent_code, decoder_function, label, num_clas
                                   return_aux: bool = False):
     """model_util.py:258-318: mean over channels, ranks the H*W positions, mask [N,1,H,W]."""
     n, c, h, w = latent_code.shape
-    code = latent_code.detach().float()
+    code = _as_float(latent_code.detach())
     grad = saliency_grad(code, decoder_function, label, num_classes, loss_type)
     score = grad.mean(dim=1).reshape(n, h * w)
     if k is None:
@@ -331,8 +338,8 @@ def dropout2d_with_keep(z: torch.Tensor, p: float, keep: Optional[torch.Tensor])
     definition: 1 where masked == input else 0 (model.py:334-336)."""
     n, c = z.shape[:2]
     if keep is None:
-        keep = (torch.rand(n, c) >= p).to(z.dtype)
-    out = z * (keep.view(n, c, 1, 1) / (1.0 - p))
+        keep = (torch.rand(n, c) >= p)
+    out = z * (keep.to(z.dtype).view(n, c, 1, 1) / (1.0 - p))
     mask = torch.where(out == z, torch.ones_like(out), torch.zeros_like(out))
     return out, mask
 
@@ -354,7 +361,16 @@ class OracleSolver:
         self.optimizers = {k: torch.optim.Adam(m.parameters(), lr=learning_rate) for k, m in self.model.items()}
         self.z_i = self.z_s = None
         self.last_masks = {}
+        self.dtype = torch.float32
         self.train()
+
+    def double(self):
+        """fp64 copy of the whole path: the accuracy yardstick for fp32 results (reference's and HIP's alike)."""
+        for m in self.model.values():
+            m.double()
+        self.optimizers = {k: torch.optim.Adam(m.parameters(), lr=self.learning_rate) for k, m in self.model.items()}
+        self.dtype = torch.float64
+        return self
 
     # -- mode switches (model.py:740-752); `self.training` stays True upstream, grad suppression in
     #    predict comes from its own no_grad (model.py:382)
@@ -384,7 +400,7 @@ class OracleSolver:
 
     def recon_shape(self, seg, is_label_map=False, no_track=False):
         """model.py:262-269 -> 233-260."""
-        inp = stn_input(seg, self.num_classes, is_label_map)
+        inp = stn_input(seg, self.num_classes, is_label_map, dtype=self.dtype)
         code = _run(self.model["shape_encoder"], inp, no_track)
         return _run(self.model["shape_decoder"], code, no_track)
 

@@ -1,0 +1,309 @@
+"""Engine-level parity on MI355X: whole networks and whole cooperative steps (HIP plans through the C-ABI) against the
+CPU oracle on the same seeded inputs, and against the golden vectors recorded from the real reference.
+Tolerances: forward tensors / losses 1e-4 abs (north_star), gradients 5e-4 of the tensor's max."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ref_cpu as O  # noqa: E402
+from cooperative_training_and_latent_space_data_augmentation_amd import nets, ops  # noqa: E402
+from cooperative_training_and_latent_space_data_augmentation_amd.model_util import _disable_tracking_bn_stats  # noqa: E402
+from cooperative_training_and_latent_space_data_augmentation_amd.solver import AdvancedTripletReconSegmentationModel  # noqa: E402
+
+DEV = "cuda"
+torch.set_num_threads(8)
+
+
+def dev(x):
+    x = x.to(DEV)
+    return x.contiguous(memory_format=torch.channels_last) if x.dim() == 4 else x.contiguous()
+
+
+def close(a, b, atol=1e-4, rel=0.0, what=""):
+    a, b = a.detach().cpu().float(), b.detach().cpu().float()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    tol = atol + rel * float(b.abs().max())
+    err = float((a - b).abs().max())
+    assert err <= tol, f"{what}: max err {err:.3e} > tol {tol:.3e} (max|ref| {float(b.abs().max()):.3e})"
+
+
+def is_dead_bias(name):
+    """Bias of a conv that feeds a training-mode BatchNorm: its true gradient is exactly 0, every implementation
+    (the reference included) returns rounding noise there."""
+    return name.endswith(("conv.0.bias", "conv.3.bias", "inc.0.bias", "inc.3.bias", "final_conv.0.bias",
+                          "code_decoupler.0.bias", "code_decoupler.3.bias"))
+
+
+def grads_close_robust(a, b, what):
+    """Gradient parity in the presence of LeakyReLU-derivative ties: a pre-activation within fp32 rounding of 0 takes
+    slope 1 in one implementation and 0.2 in the other (verified with tools/debug_sign_ties.py), which perturbs the
+    gradient downstream of that single element.  So: small relative L2 error overall and tight agreement in the bulk."""
+    a, b = a.detach().cpu().float().flatten(), b.detach().cpu().float().flatten()
+    scale = max(float(b.abs().max()), 1e-12)
+    l2 = float((a - b).norm()) / max(float(b.norm()), 1e-12)
+    q90 = float(torch.quantile((a - b).abs()[:1_000_000], 0.9))
+    assert l2 <= 3e-2, f"{what}: relative L2 error {l2:.3e}"
+    assert q90 <= 2e-3 * scale + 2e-6, f"{what}: 90th-percentile abs error {q90:.3e} (max|ref| {scale:.3e})"
+
+
+def min_preactivation(onet, x):
+    """Smallest |input| of any (Leaky)ReLU in the oracle network for input x (tie detector)."""
+    vals, hooks = [], []
+    for m in onet.modules():
+        if isinstance(m, (torch.nn.LeakyReLU, torch.nn.ReLU)):
+            hooks.append(m.register_forward_hook(lambda mod, a, o: vals.append(float(a[0].detach().abs().min()))))
+    if hasattr(onet, "inc") or hasattr(onet, "general_encoder"):
+        enc = onet.general_encoder if hasattr(onet, "general_encoder") else onet
+        hooks.append(enc.inc.register_forward_hook(lambda mod, a, o: vals.append(float(o.detach().abs().min()))))
+    with torch.no_grad():
+        onet(x)
+    for h in hooks:
+        h.remove()
+    return min(vals)
+
+
+def make_pair(name, golden_sd):
+    onet = O.build_networks(init=False)[name]
+    onet.load_state_dict(golden_sd[name])
+    hnet = nets.build_networks(device=DEV, state_dicts={name: golden_sd[name]})[name]
+    return onet, hnet
+
+
+NET_INPUT = {"image_encoder": (1, 64, 48), "shape_encoder": (4, 48, 64), "segmentation_decoder": (128, 4, 3),
+             "shape_decoder": (128, 3, 4), "image_decoder": (128, 4, 4)}
+
+
+@pytest.mark.parametrize("mode", ["A", "B"])
+@pytest.mark.parametrize("name", list(NET_INPUT))
+def test_network_forward_backward_vs_oracle(name, mode, golden_sd):
+    onet, hnet = make_pair(name, golden_sd)
+    onet.train()
+    hnet.train()
+    c, h, w = NET_INPUT[name]
+    for seed in range(64):                 # first input without an activation tie (see grads_close_robust)
+        g = torch.Generator().manual_seed(seed)
+        x = torch.rand(3, c, h, w, generator=g)
+        if "decoder" in name:
+            x = torch.relu(torch.randn(3, c, h, w, generator=g))
+        buf = {k: v.clone() for k, v in onet.state_dict().items()}
+        ok = min_preactivation(onet, x) > 4e-6
+        onet.load_state_dict(buf)          # the probe moved the running statistics
+        if ok:
+            break
+    else:
+        pytest.skip("no tie-free input found")
+    xo = x.clone().requires_grad_(True)
+    xh = dev(x).requires_grad_(True)
+    if mode == "B":
+        with O.bn_no_track(onet):
+            yo = onet(xo)
+        with _disable_tracking_bn_stats(hnet):
+            yh = hnet(xh)
+    else:
+        yo, yh = onet(xo), hnet(xh)
+    yo = yo if isinstance(yo, tuple) else (yo,)
+    yh = yh if isinstance(yh, tuple) else (yh,)
+    douts = []
+    for a, b in zip(yh, yo):
+        close(a, b, what=f"{name} output")
+        douts.append(torch.randn(b.shape, generator=g))
+    torch.autograd.backward(yo, douts)
+    torch.autograd.backward(yh, [dev(d) for d in douts])
+    close(xh.grad, xo.grad, atol=1e-6, rel=5e-4, what=f"{name} dx")
+    hp = dict(hnet.named_parameters())
+    for n, p in onet.named_parameters():
+        if mode == "B" and p.grad is None:             # gamma/beta are frozen in mode B
+            assert float(hp[n].grad.abs().max()) == 0.0, n
+            continue
+        if is_dead_bias(n):
+            wn = float(dict(onet.named_parameters())[n[:-4] + "weight"].grad.norm())
+            assert float(hp[n].grad.abs().max()) <= 1e-3 * wn + 1e-4, n
+            continue
+        close(hp[n].grad, p.grad, atol=2e-6, rel=5e-4, what=f"{name} grad {n}")
+    hb = dict(hnet.named_buffers())
+    for n, b in onet.named_buffers():
+        close(hb[n].double(), b.double(), atol=1e-5, rel=1e-5, what=f"{name} buffer {n}")
+    if mode == "B":
+        assert int(hb[[k for k in hb if k.endswith("num_batches_tracked")][0]]) == 0
+
+
+@pytest.mark.parametrize("name", list(NET_INPUT))
+def test_network_eval_mode_vs_oracle(name, golden_sd):
+    onet, hnet = make_pair(name, golden_sd)
+    c, h, w = NET_INPUT[name]
+    g = torch.Generator().manual_seed(7)
+    x = torch.rand(2, c, h, w, generator=g)
+    with torch.no_grad():
+        for _ in range(2):                     # move the running statistics first
+            onet(x * 1.5)
+            hnet(dev(x * 1.5))
+        onet.eval()
+        hnet.eval()
+        yo, yh = onet(x), hnet(dev(x))
+    for a, b in zip(yh if isinstance(yh, tuple) else (yh,), yo if isinstance(yo, tuple) else (yo,)):
+        close(a, b, what=f"{name} eval output")
+
+
+def _solver(golden_sd):
+    s = AdvancedTripletReconSegmentationModel(use_gpu=True)
+    for k, m in s.model.items():
+        m.load_state_dict(golden_sd[k])
+    return s
+
+
+def _overrides(rec, cfgs):
+    ovs, draws, noises, keeps = [], list(rec["rand_draws"]), list(rec["soft_noises"]), list(rec["dropout_keeps"])
+    for cfg, shp in zip(cfgs, (rec["z_i"].shape, rec["z_s"].shape)):
+        ov = {}
+        if cfg["mask_type"] == "dropout":
+            ov["keep"] = keeps.pop(0).to(DEV)
+        else:
+            L = shp[1] if cfg["mask_type"] == "channel" else shp[2] * shp[3]
+            if cfg["random_threshold"]:
+                ov["k"] = int(L * (draws.pop(0) * cfg["max_threshold"]))
+            if cfg["if_soft"]:
+                ov["soft_noise"] = noises.pop(0).to(DEV)
+        ovs.append(ov)
+    return ovs
+
+
+def test_standard_training_vs_golden(golden_cases, golden_sd):
+    A = golden_cases["A_standard"]
+    s = _solver(golden_sd)
+    s.train()
+    s.reset_all_optimizers()
+    std = s.standard_training(dev(A["clean"]), dev(A["label"]), dev(A["noisy"]))
+    (std[0] + std[1] + std[2] + std[3]).backward()
+    got = torch.stack([v.detach() for v in std]).cpu().double()
+    assert torch.allclose(got, A["losses"], atol=1e-4, rtol=0), (got, A["losses"])
+    close(s.z_i, A["z_i"], what="z_i")
+    close(s.z_s, A["z_s"], what="z_s")
+    for key, gref in A["grads"].items():
+        k, n = key.split("/")
+        if not is_dead_bias(n):
+            grads_close_robust(dict(s.model[k].named_parameters())[n].grad, gref, key)
+    for key, b in A["buffers_after"].items():
+        k, n = key.split("/")
+        close(dict(s.model[k].named_buffers())[n].double(), b.double(), atol=1e-5, rel=1e-5, what=key)
+
+
+def _to64(ov):
+    return {k: ((v.cpu().double() if v.is_floating_point() else v.cpu()) if torch.is_tensor(v) else v) for k, v in ov.items()}
+
+
+@pytest.mark.parametrize("case", ["C_step_channel_spatial", "D_step_dropout", "E_step_soft_random"])
+def test_full_cooperative_step_vs_golden(golden_cases, golden_sd, case):
+    """One whole iteration (standard + generation + hard + backward + Adam) against the reference's recorded run.
+    Forward quantities (8 losses, masks, BN buffers) are compared strictly.  Gradients of this network are
+    ill-conditioned in fp32 (LeakyReLU-derivative ties: the REFERENCE's fp32 gradients are themselves 0.3-1 % away
+    from an fp64 run of the same step), so the yardstick is the fp64 oracle: the HIP error must stay within a small
+    factor of the reference's own fp32 error."""
+    C = golden_cases[case]
+    s = _solver(golden_sd)
+    ov_img, ov_seg = _overrides(C, (C["img_cfg"], C["seg_cfg"]))
+    losses = s.cooperative_step(dev(C["clean"]), dev(C["label"]), dev(C["noisy"]), C["img_cfg"], C["seg_cfg"],
+                                image_override=ov_img, seg_override=ov_seg)
+    got = torch.stack([v.detach().float() for v in losses]).cpu().double()
+    assert torch.allclose(got, C["losses"], atol=1e-4, rtol=0), (got, C["losses"])
+    if C["img_cfg"]["mask_type"] != "dropout":
+        assert torch.equal(s.last_masks["image"].cpu(), C["masks"][0])       # integer-exact selection
+        assert torch.equal(s.last_masks["seg"].cpu(), C["masks"][1])
+    o64 = O.OracleSolver(state_dicts=golden_sd).double()
+    l64 = o64.cooperative_step(C["clean"].double(), C["label"], C["noisy"].double(), C["img_cfg"], C["seg_cfg"],
+                               image_override=_to64(ov_img), seg_override=_to64(ov_seg), do_optim=False)
+    assert float((got - torch.tensor(l64, dtype=torch.float64)).abs().max()) < 1e-4
+    rel = lambda a, b: float((a - b).norm() / b.norm().clamp_min(1e-30))
+    e_hip, e_ref = {}, {}
+    for key, gref in C["grads"].items():
+        k, n = key.split("/")
+        if is_dead_bias(n):
+            continue
+        g64 = dict(o64.model[k].named_parameters())[n].grad
+        e_hip[key] = rel(dict(s.model[k].named_parameters())[n].grad.detach().cpu().double(), g64)
+        e_ref[key] = rel(gref.double(), g64)
+    noise = max(e_ref.values())                        # fp32 noise level of this step, measured on the reference itself
+    for key in e_hip:
+        assert e_hip[key] <= max(5 * noise, 1e-2), f"{key}: HIP-vs-fp64 {e_hip[key]:.2e}, reference-vs-fp64 {e_ref[key]:.2e}"
+    bad = []
+    for k, m in s.model.items():                       # every parameter: gradient norm within 5 % of the fp64 norm
+        for n, p in m.named_parameters():
+            if is_dead_bias(n):
+                continue
+            n64 = float(dict(o64.model[k].named_parameters())[n].grad.norm())
+            nh = float(p.grad.detach().double().norm())
+            if abs(nh - n64) > 5e-2 * n64 + 1e-7:
+                bad.append((k, n, nh, n64))
+    assert not bad, bad[:4]
+    for key, b in C["buffers_after"].items():
+        k, n = key.split("/")
+        close(dict(s.model[k].named_buffers())[n].double(), b.double(), atol=2e-5, rel=1e-5, what=key)
+    for key, p in C["params_after"].items():          # Adam's first step is +-lr (see tests/test_oracle_golden.py)
+        k, n = key.split("/")
+        close(dict(s.model[k].named_parameters())[n], p, atol=2.1e-4, what=key)
+
+
+def test_predict_vs_golden(golden_cases, golden_sd):
+    F_ = golden_cases["F_predict"]
+    s = _solver(golden_sd)
+    s.train()
+    with torch.no_grad():
+        for i in range(3):
+            c_, l_, n_ = O.synthetic_batch(2, 64, 64, seed=10 + i, structured=True)
+            s.standard_training(dev(c_), dev(l_), dev(n_))
+    for key, b in F_["buffers_after"].items():
+        k, n = key.split("/")
+        close(dict(s.model[k].named_buffers())[n].double(), b.double(), atol=2e-5, rel=1e-5, what=key)
+    p1 = s.predict(dev(F_["vol"]), n_iter=1)
+    p2 = s.predict(dev(F_["vol"]), n_iter=2)
+    close(p1, F_["logits_n1"], atol=1e-4, rel=2e-5, what="logits n_iter=1")      # |logit| up to ~7: 1e-4 abs + 2e-5 rel
+    close(p2, F_["logits_n2"], atol=1e-4, rel=2e-5, what="logits n_iter=2")
+    for p, key in ((p1, "argmax_n1"), (p2, "argmax_n2")):
+        ref_logits = F_["logits_n1" if key.endswith("1") else "logits_n2"]
+        top2 = ref_logits.topk(2, dim=1)[0]
+        safe = (top2[:, 0] - top2[:, 1]) > 1e-3
+        lab = ops.argmax_c(p).cpu()
+        assert torch.equal(lab[safe], F_[key][safe])            # integer label maps bit-exact away from near-ties
+        for cls in range(1, 4):
+            d_h, d_r = O.dice(lab.numpy() == cls, F_["vlab"].numpy() == cls), O.dice(F_[key].numpy() == cls, F_["vlab"].numpy() == cls)
+            assert (np.isnan(d_h) and np.isnan(d_r)) or abs(d_h - d_r) < 1e-4
+    s.running_metric.reset()
+    s.evaluate(dev(F_["vol"]), F_["vlab"].numpy(), n_iter=2)
+    ref_hist = sum(O.confusion_hist(F_["vlab"][i].numpy(), ops.argmax_c(p2).cpu()[i].numpy().astype(np.int64), 4) for i in range(3))
+    assert np.array_equal(s.running_metric.confusion_matrix, ref_hist)
+
+
+def test_bs16_256_forward_checksum_vs_golden(golden_cases, golden_sd):
+    """BASELINE-sized input (16 x 256 x 256): the four standard-training losses and the latent codes' checksums."""
+    G = golden_cases["G_bs16_256_fwd"]
+    s = _solver(golden_sd)
+    c, l, n = O.synthetic_batch(16, 256, 256, seed=0)
+    s.train()
+    with torch.no_grad():
+        st = s.standard_training(dev(c), dev(l), dev(n))
+    got = torch.stack([v.detach().float() for v in st]).cpu().double()
+    assert torch.allclose(got, G["losses"], atol=1e-4), (got, G["losses"])
+    for z, key in ((s.z_i, "z_i_stats"), (s.z_s, "z_s_stats")):
+        zz = z.detach().double().cpu()
+        stt = torch.tensor([zz.sum().item(), zz.norm().item(), zz.abs().max().item()], dtype=torch.float64)
+        assert torch.allclose(stt, G[key], rtol=2e-4), (stt, G[key])
+
+
+def test_full_size_step_properties(golden_sd):
+    """At the metric's size (bs16, 256x256) run one full step and check size-independent properties: finite losses,
+    exactly k masked entries per image, masked code == code * mask, BN running stats moved, weights changed by <= lr."""
+    s = _solver(golden_sd)
+    c, l, n = O.synthetic_batch(16, 256, 256, seed=3)
+    img_cfg = {"loss_name": "mse", "mask_type": "channel", "max_threshold": 0.5, "random_threshold": False, "if_soft": False}
+    seg_cfg = {"loss_name": "ce", "mask_type": "spatial", "max_threshold": 0.5, "random_threshold": False, "if_soft": False}
+    before = s.model["shape_decoder"]._flat_data.clone()
+    losses = s.cooperative_step(dev(c), dev(l), dev(n), img_cfg, seg_cfg)
+    vals = torch.stack([v.detach().float() for v in losses]).cpu()
+    assert torch.isfinite(vals).all() and (vals >= 0).all()
+    mi, ms = s.last_masks["image"].cpu(), s.last_masks["seg"].cpu()
+    assert mi.shape == (16, 128, 1, 1) and ms.shape == (16, 1, 16, 16)
+    assert ((mi == 0).flatten(1).sum(1) == 64).all() and ((ms == 0).flatten(1).sum(1) == 128).all()
+    delta = (s.model["shape_decoder"]._flat_data - before).abs().max().item()
+    assert 0 < delta <= 1.001e-4           # |Adam's first step| <= lr (+ fp32 rounding of the weight)
+    assert int(s.model["image_encoder"]._nbt[0]) == 1 and int(s.model["image_decoder"]._nbt[0]) == 3
