@@ -1,0 +1,152 @@
+#!/usr/bin/env python3
+"""Headline benchmark: cooperative-training slices/s on synthetic 256x256 batches (BASELINE.json configs[1]):
+batch 16 per GPU, full cooperative step = standard_training + hard_example_generation (dropout masks on both latent
+codes) + hard_example_training + backward + 5x Adam, fp32, one process per GPU.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.  `roofline` is measured live: HIP events bracket every launch of the dominant kernel
+(inside the timed region, on the launch stream).  `cpu_baseline` times the CPU oracle (oracle/ref_cpu.py, a port of the
+reference's PyTorch-CPU path) on one step of the same workload on the host cores (N=1 only)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+DROP_IMG = {"loss_name": "mse", "mask_type": "dropout", "max_threshold": 0.5, "random_threshold": True, "if_soft": True}
+DROP_SEG = {"loss_name": "ce", "mask_type": "dropout", "max_threshold": 0.5, "random_threshold": True, "if_soft": True}
+PEAK_MFMA_F32_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+PEAK_HBM_GBS = 8000.0
+# dominant kernel of this workload per profiles/ (rocprofv3 --kernel-trace --stats): the 3x3 stride-1 implicit-GEMM conv
+# at 8x32 tiles / 16 output channels, i.e. every 16->16 (and 1|4->16, 16->4) conv and dgrad at 256x256
+DOMINANT = "conv_igemm<ks3,s1,in0,mt4,tw32,nt1>"
+
+
+def synthetic(n, h, w, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    clean = torch.rand(n, 1, h, w, generator=g)
+    label = torch.randint(0, 4, (n, h, w), generator=g)
+    noisy = torch.clamp(clean + 0.05 * torch.randn(n, 1, h, w, generator=g), 0, 1)
+    return clean.to(device), label.to(device), noisy.to(device), (clean, label, noisy)
+
+
+def cpu_baseline(host_batch, threads):
+    from oracle import ref_cpu as O                      # the checker, timed as the reported CPU baseline
+    from cooperative_training_and_latent_space_data_augmentation_amd.init import reference_init_state_dicts
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    s = O.OracleSolver(state_dicts=reference_init_state_dicts())
+    nb = min(8, host_batch[0].shape[0])                  # bounded sample: half a batch keeps this leg at ~10-30 s
+    clean, label, noisy = (t[:nb] for t in host_batch)
+    t0 = time.perf_counter()
+    s.cooperative_step(clean, label, noisy, DROP_IMG, DROP_SEG)
+    dt = time.perf_counter() - t0
+    return {"value": clean.shape[0] / dt, "unit": "slices/s", "cores": threads, "kind": "port",
+            "sample": f"1 full cooperative step (bs{clean.shape[0]} = half a GPU batch, 256x256, dropout masks) of oracle/ref_cpu.py, "
+                      f"{threads} torch threads, no warm-up, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--prof-filter", default=DOMINANT)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback of the product path)")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    from cooperative_training_and_latent_space_data_augmentation_amd import _ffi
+    from cooperative_training_and_latent_space_data_augmentation_amd.solver import AdvancedTripletReconSegmentationModel
+    from cooperative_training_and_latent_space_data_augmentation_amd.dist import DataParallel
+
+    torch.manual_seed(0)                                 # identical initial weights on every rank
+    solver = AdvancedTripletReconSegmentationModel(network_type="FCN_16_standard", image_ch=1, num_classes=4,
+                                                   learning_rate=1e-4, use_gpu=True)
+    dp = DataParallel(solver) if world > 1 else None
+    clean, label, noisy, host_batch = synthetic(args.batch, args.size, args.size, 1000 + rank, device)
+    hook = dp.sync_gradients if dp else None
+
+    def step():
+        return solver.cooperative_step(clean, label, noisy, DROP_IMG, DROP_SEG, grad_hook=hook)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    if rank == 0:
+        _ffi.prof_start(args.prof_filter)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses = step()
+    fence()
+    dt = time.perf_counter() - t0
+    prof = _ffi.prof_stop() if rank == 0 else {}
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss_vals = [float(v) for v in losses]
+    assert all(v == v and abs(v) < 1e6 for v in loss_vals), loss_vals
+
+    if rank == 0:
+        out = {
+            "metric": "cooperative-training slices/sec (256x256, bs16 per GPU)", "value": world * args.batch * args.steps / dt,
+            "unit": "slices/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"ACDC-shaped synthetic {args.size}x{args.size}x1, batch {args.batch}/GPU, full cooperative step "
+                                   "(FTN+STN standard + dropout latent masks + hard-example training + backward + 5x Adam), "
+                                   "reference-init weights", "global_batch": world * args.batch,
+                       "parallelism": f"dp{world}" if world > 1 else "single GPU"},
+            "final_losses": loss_vals,
+        }
+        if prof:
+            kid, rec = max(prof.items(), key=lambda kv: kv[1]["ms"])
+            secs = rec["ms"] * 1e-3
+            tf, gbs = rec["flops"] / secs / 1e12, rec["bytes"] / secs / 1e9
+            f_mfma, f_hbm = tf / PEAK_MFMA_F32_TFLOPS, gbs / PEAK_HBM_GBS
+            bound = "mfma" if f_mfma >= f_hbm else "hbm"
+            out["roofline"] = {"bound": bound, "achieved": tf if bound == "mfma" else gbs,
+                               "peak": PEAK_MFMA_F32_TFLOPS if bound == "mfma" else PEAK_HBM_GBS,
+                               "unit": "TFLOP/s" if bound == "mfma" else "GB/s", "frac": max(f_mfma, f_hbm), "traffic": None,
+                               "kernel": kid, "launches": int(rec["launches"]), "avg_us": 1e3 * rec["ms"] / rec["launches"],
+                               "algorithmic_gflop_per_launch": rec["flops"] / rec["launches"] / 1e9,
+                               "algorithmic_mb_per_launch": rec["bytes"] / rec["launches"] / 1e6,
+                               "hbm_gbs": gbs, "hbm_frac": f_hbm, "share_of_step_time": secs / dt}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(host_batch, args.cpu_threads or min(32, os.cpu_count()))
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -81,6 +81,7 @@ class _Lib:
             "ctl_uniform": [p, i64, u64, p],
             "ctl_adam": [p, p, p, p, i64, f32, f32, f32, f32, i32, f32, p],
             "ctl_plan_run": [p, i32, p, i32, p],
+            "ctl_prof_start": [C.c_char_p], "ctl_prof_stop": [p, C.c_size_t],
         }
         for name, args in sig.items():
             getattr(lib, name).argtypes = args
@@ -104,7 +105,22 @@ EXPORTED = ["ctl_version", "ctl_last_error", "ctl_conv_wpack_floats", "ctl_conv_
             "ctl_sigmoid_bwd", "ctl_softmax_t_fwd", "ctl_softmax_t_bwd", "ctl_onehot", "ctl_ce2d_fwd", "ctl_ce2d_bwd",
             "ctl_mse_fwd", "ctl_mse_bwd", "ctl_argmax_c", "ctl_latent_score_ws_floats", "ctl_latent_score",
             "ctl_latent_mask_apply", "ctl_dropout2d", "ctl_uniform", "ctl_adam", "ctl_plan_run", "ctl_sizeof_op",
-            "ctl_sizeof_conv"]
+            "ctl_sizeof_conv", "ctl_prof_start", "ctl_prof_stop"]
+
+
+def prof_start(kernel_filter: str = "") -> None:
+    check(lib.ctl_prof_start(kernel_filter.encode()), "ctl_prof_start")
+
+
+def prof_stop() -> dict:
+    """{kernel id: dict(launches, ms, flops, bytes)} for the launches bracketed since prof_start."""
+    buf = C.create_string_buffer(1 << 16)
+    check(lib.ctl_prof_stop(buf, len(buf)), "ctl_prof_stop")
+    out = {}
+    for line in buf.value.decode().splitlines():
+        parts = line.split()
+        out[parts[0]] = {k: float(v) for k, v in (kv.split("=") for kv in parts[1:])}
+    return out
 
 
 def check(rc: int, what: str = "") -> None:

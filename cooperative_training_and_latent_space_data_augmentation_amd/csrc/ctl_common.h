@@ -51,3 +51,7 @@ struct ctl_conv_cfg {
     int cot;             // cout tiles of 16 (total)
 };
 int ctl_conv_pick_cfg(const ctl_conv* d, ctl_conv_cfg* c);
+
+// in-process profiling (ctl_plan.cpp): returns a token >= 0 if this launch is being timed
+int ctl_prof_begin(const char* kind, const ctl_conv* d, const ctl_conv_cfg* c, int nt, hipStream_t stream);
+void ctl_prof_end(int token, hipStream_t stream);

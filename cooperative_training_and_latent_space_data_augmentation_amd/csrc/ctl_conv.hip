@@ -98,7 +98,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ctl_conv d, const
     using G = Geom<KS, S, MT, TW>;
     constexpr int TAPS = KS * KS;
     constexpr int RED_FLOATS = 4 * NT * 16 * 2;
-    __shared__ __attribute__((aligned(16))) float xt[(G::XT_FLOATS > RED_FLOATS) ? G::XT_FLOATS : RED_FLOATS];
+    // Cout >= 32 (NT >= 2): the block's weight chunk [tap][nt][64 lanes][4] goes through LDS once per 16-channel chunk and
+    // is shared by the four waves (4x less L2 traffic, no per-wave L2 latency); Cout = 16: 36 fragments stay in VGPRs.
+    constexpr bool WLDS = NT >= 2;
+    constexpr int WT_FLOATS = WLDS ? TAPS * NT * 256 : 0;
+    constexpr int XT_ALLOC = (G::XT_FLOATS > RED_FLOATS) ? G::XT_FLOATS : RED_FLOATS;
+    __shared__ __attribute__((aligned(16))) float xt[XT_ALLOC + WT_FLOATS];
+    float* wt = xt + XT_ALLOC;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -124,15 +130,27 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ctl_conv d, const
     for (int g = 0; g < G_chunks; ++g) {
         if (g > 0) __syncthreads();
         stage_x<KS, S, MODE, MT, TW>(xt, x, d, n, ho0 * S - G::PAD, wo0 * S - G::PAD, g, pro_scale, pro_shift);
+        if (WLDS) {
+            for (int u = tid; u < TAPS * NT * 64; u += 256) {
+                const int tt = u >> 6, l = u & 63;           // tt = tap * NT + t
+                const int tap = tt / NT, t = tt - tap * NT;
+                *reinterpret_cast<f32x4*>(wt + (tt * 64 + l) * 4) = *reinterpret_cast<const f32x4*>(
+                    wp + ((((int64_t)(cot0 + t) * TAPS + tap) * G_chunks + g) * 64 + l) * 4);
+            }
+        }
         __syncthreads();
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
             const int kh = tap / KS, kw = tap % KS;
             f32x4 wf[NT];
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
-                wf[t] = *reinterpret_cast<const f32x4*>(
-                    wp + ((((int64_t)(cot0 + t) * TAPS + tap) * G_chunks + g) * 64 + lane) * 4);
+            for (int t = 0; t < NT; ++t) {
+                if (WLDS)
+                    wf[t] = *reinterpret_cast<const f32x4*>(wt + ((tap * NT + t) * 64 + lane) * 4);
+                else
+                    wf[t] = *reinterpret_cast<const f32x4*>(
+                        wp + ((((int64_t)(cot0 + t) * TAPS + tap) * G_chunks + g) * 64 + lane) * 4);
+            }
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 const int mt = wave * MT + m;
@@ -381,27 +399,41 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ctl_conv d, const
     }
 }
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ w_partial, const float* __restrict__ b_partial,
-                                    int splits, int taps, int ks, int cin, int cout, int cin_p, int cout_p,
-                                    float* __restrict__ dw, int64_t s_co, int64_t s_ci, int64_t s_kh, int64_t s_kw,
-                                    float* __restrict__ dbias, int accumulate) {
+// Sums the per-split partials: a block owns 32 consecutive weight elements (contiguous in the partial layout) and
+// spreads the splits over 8 thread groups; deterministic (fixed order), no atomics.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ w_partial,
+                                                            const float* __restrict__ b_partial, int splits, int taps,
+                                                            int ks, int cin, int cout, int cin_p, int cout_p,
+                                                            float* __restrict__ dw, int64_t s_co, int64_t s_ci,
+                                                            int64_t s_kh, int64_t s_kw, float* __restrict__ dbias,
+                                                            int accumulate) {
+    __shared__ float sm[8][32];
+    const int e = threadIdx.x & 31, sl = threadIdx.x >> 5;
     const int64_t total = (int64_t)taps * cin * cout;
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < total) {
-        const int co = idx % cout;
-        const int ci = (idx / cout) % cin;
-        const int tap = idx / ((int64_t)cout * cin);
+    const int64_t idx = (int64_t)blockIdx.x * 32 + e;
+    const bool is_w = idx < total;
+    const bool is_b = !is_w && dbias != nullptr && idx < total + cout;
+    float v = 0.f;
+    int co = 0, ci = 0, tap = 0;
+    if (is_w) {
+        co = idx % cout;
+        ci = (idx / cout) % cin;
+        tap = idx / ((int64_t)cout * cin);
         const int64_t stride = (int64_t)taps * cin_p * cout_p;
         const float* src = w_partial + ((int64_t)tap * cin_p + ci) * cout_p + co;
-        float v = 0.f;
-        for (int s = 0; s < splits; ++s) v += src[s * stride];
-        float* dst = dw + co * s_co + ci * s_ci + (tap / ks) * s_kh + (tap % ks) * s_kw;
-        *dst = accumulate ? (*dst + v) : v;
-    } else if (dbias != nullptr && idx < total + cout) {
-        const int co = idx - total;
-        float v = 0.f;
-        for (int s = 0; s < splits; ++s) v += b_partial[(int64_t)s * cout_p + co];
-        dbias[co] = accumulate ? (dbias[co] + v) : v;
+        for (int s = sl; s < splits; s += 8) v += src[s * stride];
+    } else if (is_b) {
+        co = idx - total;
+        for (int s = sl; s < splits; s += 8) v += b_partial[(int64_t)s * cout_p + co];
+    }
+    sm[sl][e] = v;
+    __syncthreads();
+    if (sl == 0 && (is_w || is_b)) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += sm[k][e];
+        float* dst = is_w ? dw + co * s_co + ci * s_ci + (tap / ks) * s_kh + (tap % ks) * s_kw : dbias + co;
+        *dst = accumulate ? (*dst + t) : t;
     }
 }
 
@@ -467,6 +499,8 @@ int ctl_conv_pick_cfg(const ctl_conv* d, ctl_conv_cfg* c) {
     } else {
         mt = 1; tw = 16;
     }
+    if (d->stride == 2 && c->nt == 4) c->nt = 2;            // stride-2 input tiles are 4x larger: keep LDS < 64 KiB
+    if (c->nt == 4 && blocks(mt, tw) < 384) c->nt = 2;      // small problems: halve the cout tile to fill the 256 CUs
     c->mt = mt; c->tw = tw; c->th = 4 * mt * 16 / tw;
     c->tiles_h = ctl_cdiv(d->hout, c->th);
     c->tiles_w = ctl_cdiv(d->wout, c->tw);
@@ -509,10 +543,15 @@ extern "C" int ctl_pack_weights(const float* src, float* dst, int32_t cout, int3
         else if (c.mt == 2) DISPATCH_NT(KS, S, MODE, 2, 16);         \
         else DISPATCH_NT(KS, S, MODE, 1, 16);                        \
     } while (0)
+#define DISPATCH_NT_S2(KS, S, MODE, MT, TW)                  \
+    do {                                                     \
+        if (c.nt == 2) LAUNCH_CONV(KS, S, MODE, MT, TW, 2);  \
+        else LAUNCH_CONV(KS, S, MODE, MT, TW, 1);            \
+    } while (0)
 #define DISPATCH_TILE_S2(KS, S, MODE)                        \
     do {                                                     \
-        if (c.mt == 2) DISPATCH_NT(KS, S, MODE, 2, 16);      \
-        else DISPATCH_NT(KS, S, MODE, 1, 16);                \
+        if (c.mt == 2) DISPATCH_NT_S2(KS, S, MODE, 2, 16);   \
+        else DISPATCH_NT_S2(KS, S, MODE, 1, 16);             \
     } while (0)
 
 extern "C" int ctl_conv_forward(const ctl_conv* d, const float* x, const float* wpack, const float* bias,
@@ -531,6 +570,7 @@ extern "C" int ctl_conv_forward(const ctl_conv* d, const float* x, const float* 
     const int64_t sub_stride = (int64_t)ctl_conv_wpack_floats(d->cin, d->cout, d->ks);
     const dim3 grid((unsigned)(d->n * c.tiles_h * c.tiles_w), (unsigned)(c.cot / c.nt), (unsigned)d->nsub);
     const int k = d->ks, s = d->stride, m = d->in_mode;
+    const int ptok = ctl_prof_begin("conv_igemm", d, &c, c.nt, (hipStream_t)stream);
     if (k == 3 && s == 1 && m == CTL_IN_PLAIN) DISPATCH_TILE(3, 1, CTL_IN_PLAIN);
     else if (k == 3 && s == 1 && m == CTL_IN_UP2) DISPATCH_TILE(3, 1, CTL_IN_UP2);
     else if (k == 3 && s == 1 && m == CTL_IN_ZINS2) DISPATCH_TILE(3, 1, CTL_IN_ZINS2);
@@ -539,6 +579,7 @@ extern "C" int ctl_conv_forward(const ctl_conv* d, const float* x, const float* 
     else if (k == 1 && m == CTL_IN_UP2) DISPATCH_TILE(1, 1, CTL_IN_UP2);
     else if (k == 2 && s == 2) DISPATCH_TILE_S2(2, 2, CTL_IN_PLAIN);
     else CTL_FAIL(CTL_EUNSUPPORTED, "conv_forward: no kernel for this combination");
+    ctl_prof_end(ptok, (hipStream_t)stream);
     CTL_LAUNCH_CHECK("conv_forward");
     return CTL_OK;
 }
@@ -557,7 +598,8 @@ static int wgrad_pick(const ctl_conv* d, wgrad_cfg* w) {
     w->cin_p = w->c.g * 16;
     w->cout_p = w->c.cot * 16;
     const int par = w->c.g * (w->c.cot / w->ntw);
-    int splits = ctl_cdiv(1024, par);
+    int splits = ctl_cdiv(768, par);           // ~3 blocks per CU in total; every block then walks >= a few tiles
+    if (splits > 256) splits = 256;
     if (splits > w->ntiles) splits = w->ntiles;
     if (splits < 1) splits = 1;
     w->splits = splits;
@@ -608,6 +650,7 @@ extern "C" int ctl_conv_wgrad(const ctl_conv* d, const float* x, const float* pr
     if (rc != CTL_OK) return rc;
     const dim3 grid((unsigned)w.splits, (unsigned)w.c.g, (unsigned)(w.c.cot / w.ntw));
     const int k = d->ks, s = d->stride, m = d->in_mode;
+    const int ptok = ctl_prof_begin("conv_wgrad", d, &w.c, w.ntw, (hipStream_t)stream);
     if (k == 3 && s == 1 && m == CTL_IN_PLAIN) WG_TILE(3, 1, CTL_IN_PLAIN);
     else if (k == 3 && s == 1 && m == CTL_IN_UP2) WG_TILE(3, 1, CTL_IN_UP2);
     else if (k == 3 && s == 2) WG_TILE_S2(3, 2, CTL_IN_PLAIN);
@@ -615,6 +658,7 @@ extern "C" int ctl_conv_wgrad(const ctl_conv* d, const float* x, const float* pr
     else if (k == 1 && m == CTL_IN_UP2) WG_TILE(1, 1, CTL_IN_UP2);
     else if (k == 2 && s == 2) WG_TILE_S2(2, 2, CTL_IN_PLAIN);
     else CTL_FAIL(CTL_EUNSUPPORTED, "conv_wgrad: no kernel for this combination");
+    ctl_prof_end(ptok, (hipStream_t)stream);
     CTL_LAUNCH_CHECK("conv_wgrad");
     return CTL_OK;
 }
@@ -629,7 +673,7 @@ extern "C" int ctl_wgrad_reduce(const ctl_conv* d, const float* w_partial, const
     if (rc != CTL_OK) return rc;
     const int taps = d->ks * d->ks;
     const int64_t total = (int64_t)taps * d->cin * d->cout + (dbias ? d->cout : 0);
-    wgrad_reduce_kernel<<<dim3((unsigned)ctl_cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream>>>(
+    wgrad_reduce_kernel<<<dim3((unsigned)ctl_cdiv64(total, 32)), dim3(256), 0, (hipStream_t)stream>>>(
         w_partial, b_partial, w.splits, taps, d->ks, d->cin, d->cout, w.cin_p, w.cout_p, dw, s_co, s_ci, s_kh, s_kw,
         dbias, accumulate);
     CTL_LAUNCH_CHECK("wgrad_reduce");

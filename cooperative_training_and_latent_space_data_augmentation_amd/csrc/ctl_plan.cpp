@@ -32,6 +32,73 @@ void ctl_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+// ------------------------------------------------------------------------------------------------ profiling
+#include <map>
+#include <string>
+#include <vector>
+namespace {
+struct ProfRec { std::string id; hipEvent_t a, b; double flops, bytes; };
+bool g_prof_on = false;
+std::string g_prof_filter;
+std::vector<ProfRec> g_prof;
+}  // namespace
+
+int ctl_prof_begin(const char* kind, const ctl_conv* d, const ctl_conv_cfg* c, int nt, hipStream_t stream) {
+    if (!g_prof_on) return -1;
+    char id[128];
+    snprintf(id, sizeof(id), "%s<ks%d,s%d,in%d,mt%d,tw%d,nt%d>", kind, d->ks, d->stride, d->in_mode, c->mt, c->tw, nt);
+    if (!g_prof_filter.empty() && std::string(id).find(g_prof_filter) == std::string::npos) return -1;
+    ProfRec r;
+    r.id = id;
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return -1;
+    const double pix = (double)d->n * d->hout * d->wout * d->nsub;
+    r.flops = 2.0 * pix * d->cout * d->cin * d->ks * d->ks;
+    const double in_b = 4.0 * d->n * d->hin * d->win * d->cin, out_b = 4.0 * pix * d->cout;
+    r.bytes = in_b + out_b;
+    if (d->epi_flags & CTL_EPI_RES) r.bytes += out_b;
+    if (d->epi_flags & CTL_EPI_ACCUM) r.bytes += out_b;
+    hipEventRecord(r.a, stream);
+    g_prof.push_back(r);
+    return (int)g_prof.size() - 1;
+}
+void ctl_prof_end(int token, hipStream_t stream) {
+    if (token >= 0 && token < (int)g_prof.size()) hipEventRecord(g_prof[token].b, stream);
+}
+extern "C" int ctl_prof_start(const char* filter) {
+    for (auto& r : g_prof) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+    g_prof.clear();
+    g_prof_filter = filter ? filter : "";
+    g_prof_on = true;
+    return CTL_OK;
+}
+extern "C" int ctl_prof_stop(char* out, size_t cap) {
+    g_prof_on = false;
+    struct Agg { long n = 0; double ms = 0, flops = 0, bytes = 0; };
+    std::map<std::string, Agg> agg;
+    for (auto& r : g_prof) {
+        float ms = 0.f;
+        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            Agg& a = agg[r.id];
+            a.n++; a.ms += ms; a.flops += r.flops; a.bytes += r.bytes;
+        }
+        hipEventDestroy(r.a);
+        hipEventDestroy(r.b);
+    }
+    g_prof.clear();
+    std::string text;
+    for (auto& kv : agg) {
+        char line[320];
+        snprintf(line, sizeof(line), "%s launches=%ld ms=%.6f flops=%.6e bytes=%.6e\n", kv.first.c_str(), kv.second.n,
+                 kv.second.ms, kv.second.flops, kv.second.bytes);
+        text += line;
+    }
+    if (out && cap) {
+        CTL_REQUIRE(text.size() + 1 <= cap, "prof_stop: output buffer too small (%zu needed)", text.size() + 1);
+        memcpy(out, text.c_str(), text.size() + 1);
+    }
+    return CTL_OK;
+}
+
 extern "C" int ctl_version(void) { return 1; }
 extern "C" const char* ctl_last_error(void) { return g_err; }
 extern "C" size_t ctl_sizeof_op(void) { return sizeof(ctl_op); }

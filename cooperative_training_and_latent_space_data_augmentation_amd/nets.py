@@ -415,6 +415,14 @@ class CtlNet(nn.Module):
         self._packed_ok = False
         return r
 
+    def bind_grad_buffer(self, buf: torch.Tensor):
+        """Re-home this network's flat gradient inside a caller-owned bucket (one all-reduce for all five networks)."""
+        assert buf.numel() == self._pcount and buf.dtype == torch.float32 and buf.device == self._flat_data.device
+        buf.copy_(self._flat.grad)
+        self._flat.grad = buf
+        for n, p in self.named_parameters():
+            p.grad = buf[self._poff[n]:self._poff[n] + p.numel()].view(p.shape)
+
     def zero_grad(self, set_to_none: bool = False):
         """Gradients are views of one flat buffer that is never re-allocated: zero it in place.  (upstream calls
         `decoder_function.zero_grad()` inside the masking functions, model_util.py:251-254)"""

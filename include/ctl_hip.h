@@ -191,6 +191,16 @@ typedef struct ctl_op {
     int64_t l[4];                     /* 64-bit scalars (strides, counts) */
 } ctl_op;
 int ctl_plan_run(const ctl_op* ops, int32_t n_ops, void* const* bases, int32_t n_bases, ctl_stream stream);
+
+/* ------------------------------------------------------------------------------------------------ in-process profiling
+ * Brackets every conv-family launch whose kernel id contains `filter` ("" = all) with hipEvents recorded on the launch
+ * stream, and sums the ALGORITHMIC work of those launches: flops = 2*pixels*cout*cin*ks*ks (real channels), bytes =
+ * input + output (+ residual / accumulate reads) tensors once each.  Kernel ids look like
+ * "conv_igemm<ks3,s1,in0,mt4,tw32,nt1>" / "conv_wgrad<...>" (the template instantiation rocprofv3 reports).
+ * ctl_prof_stop synchronises the recorded events and writes one text line per kernel id:
+ *   "<id> launches=<n> ms=<total> flops=<sum> bytes=<sum>\n".  Not for use under graph capture. */
+int ctl_prof_start(const char* filter);
+int ctl_prof_stop(char* out, size_t cap);
 size_t ctl_sizeof_op(void);
 size_t ctl_sizeof_conv(void);
 
