@@ -598,8 +598,8 @@ static int wgrad_pick(const ctl_conv* d, wgrad_cfg* w) {
     w->cin_p = w->c.g * 16;
     w->cout_p = w->c.cot * 16;
     const int par = w->c.g * (w->c.cot / w->ntw);
-    int splits = ctl_cdiv(768, par);           // ~3 blocks per CU in total; every block then walks >= a few tiles
-    if (splits > 256) splits = 256;
+    int splits = ctl_cdiv(1024, par);          // ~4 blocks per CU in total; every block then walks >= a few tiles
+    if (splits > 512) splits = 512;
     if (splits > w->ntiles) splits = w->ntiles;
     if (splits < 1) splits = 1;
     w->splits = splits;
