@@ -42,6 +42,29 @@ __device__ __forceinline__ int ctl_xcd_remap(int bid, int nblk) {
     return base + (bid >> 3);
 }
 
+// Co-resident workgroups of a persistent kernel run the same phase sequence (load | MFMA | epilogue) and, started together,
+// stay in lockstep: all fight for the matrix pipe, then all leave it idle (measured: kernel time = MFMA time + memory time).
+// Giving the waves that share a SIMD different static priorities (keyed by the hardware wave slot) breaks the symmetry:
+// the highest-priority wave finishes its MFMA phase first and moves on while the others compute.
+__device__ __forceinline__ void ctl_stagger_priority() {
+    const unsigned hw = __builtin_amdgcn_s_getreg((4) | (0 << 6) | ((4 - 1) << 11));   // HW_REG_HW_ID[3:0] = wave slot
+    switch (hw & 3u) {
+        case 0: __builtin_amdgcn_s_setprio(0); break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(3); break;
+    }
+}
+
+// Workgroup barriers for the pipelined loops.  __syncthreads() is a workgroup-scope FENCE + barrier: hipcc puts
+// s_waitcnt vmcnt(0) in front of it, which drains every in-flight global load AND store of the wave (seen in the ISA; it made
+// prefetch and epilogue stores strictly serial with the MFMA phase).  The loops only need LDS ordering:
+//   ctl_barrier_lds_reads_done : all waves finished READING an LDS image (their ds_reads were consumed by MFMAs, i.e.
+//                                already waited for) -> bare s_barrier
+//   ctl_barrier_lds_writes_done: ds_writes of this wave have landed (lgkmcnt(0)) and everybody arrived
+__device__ __forceinline__ void ctl_barrier_lds_reads_done() { asm volatile("s_barrier" ::: "memory"); }
+__device__ __forceinline__ void ctl_barrier_lds_writes_done() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // conv descriptors shared between ctl_conv.hip and ctl_plan.cpp
 struct ctl_conv_cfg {
     int mt, tw, nt;      // M-tiles per wave, tile width in pixels, cout tiles (of 16) per block
@@ -50,7 +73,7 @@ struct ctl_conv_cfg {
     int g;               // cin chunks of 16
     int cot;             // cout tiles of 16 (total)
 };
-int ctl_conv_pick_cfg(const ctl_conv* d, ctl_conv_cfg* c);
+int ctl_conv_pick_cfg(const ctl_conv* d, ctl_conv_cfg* c, int for_wgrad);
 
 // in-process profiling (ctl_plan.cpp): returns a token >= 0 if this launch is being timed
 int ctl_prof_begin(const char* kind, const ctl_conv* d, const ctl_conv_cfg* c, int nt, hipStream_t stream);

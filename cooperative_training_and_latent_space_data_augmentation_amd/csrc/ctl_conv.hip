@@ -14,6 +14,8 @@
 // LDS input tile: [row][col][16 channels] floats for the current 16-channel chunk; 16 consecutive output pixels of a
 // row read 1 KiB contiguous -> conflict-free ds_read_b128.  For stride 2 the columns are de-interleaved (even | odd)
 // so the same holds.  BatchNorm-apply + LeakyReLU of the producer layer is applied once per element while staging.
+#include <stdlib.h>
+
 #include "ctl_common.h"
 
 template <int KS, int S, int MT, int TW>
@@ -30,61 +32,149 @@ struct Geom {
     __device__ static __forceinline__ int ldscol(int c) { return (S == 2) ? ((c & 1) * IWH + (c >> 1)) : c; }
 };
 
-// Stage the 16-channel chunk g of the (virtual) input tile into LDS, applying the fused BN+LeakyReLU prologue.
-template <int KS, int S, int MODE, int MT, int TW>
-__device__ __forceinline__ void stage_x(float* __restrict__ xt, const float* __restrict__ x, const ctl_conv& d, int n,
-                                        int vh0, int vw0, int g, const float* __restrict__ pro_scale,
-                                        const float* __restrict__ pro_shift) {
-    using G = Geom<KS, S, MT, TW>;
-    const int tid = threadIdx.x;
-    const int cq = tid & 3;
-    const int cb = g * 16 + cq * 4;
-    const int hv = (MODE == CTL_IN_PLAIN) ? d.hin : 2 * d.hin;
-    const int wv = (MODE == CTL_IN_PLAIN) ? d.win : 2 * d.win;
-    const bool chan_ok = cb < d.cin;
-    const bool pro = d.pro_affine != 0;
-    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-    if (pro && chan_ok) {
-        if (d.cin >= 4) {
-            sc = *reinterpret_cast<const f32x4*>(pro_scale + cb);
-            sh = *reinterpret_cast<const f32x4*>(pro_shift + cb);
-        } else {
-            sc.x = pro_scale[0];
-            sh.x = pro_shift[0];
-        }
-    }
-    const float slope = d.pro_slope;
-    for (int u = tid; u < G::IH * G::IW * 4; u += 256) {
-        const int pix = u >> 2;
-        const int r = pix / G::IW;
-        const int c = pix - r * G::IW;
-        const int vh = vh0 + r, vw = vw0 + c;
-        bool ok = chan_ok && vh >= 0 && vh < hv && vw >= 0 && vw < wv;
-        if (MODE == CTL_IN_ZINS2) ok = ok && ((vh & 1) == 0) && ((vw & 1) == 0);
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (ok) {
-            const int sh_ = (MODE == CTL_IN_PLAIN) ? vh : (vh >> 1);
-            const int sw_ = (MODE == CTL_IN_PLAIN) ? vw : (vw >> 1);
-            const int64_t base = (((int64_t)n * d.hin + sh_) * d.win + sw_) * d.cin + cb;
-            if (d.cin >= 4) {
-                v = *reinterpret_cast<const f32x4*>(x + base);
-                if (pro) {
-                    v.x = ctl_leaky(v.x * sc.x + sh.x, slope);
-                    v.y = ctl_leaky(v.y * sc.y + sh.y, slope);
-                    v.z = ctl_leaky(v.z * sc.z + sh.z, slope);
-                    v.w = ctl_leaky(v.w * sc.w + sh.w, slope);
-                }
-            } else {  // cin == 1
-                v.x = x[base];
-                if (pro) v.x = ctl_leaky(v.x * sc.x + sh.x, slope);
-            }
-        }
-        *reinterpret_cast<f32x4*>(xt + (r * G::IWP + G::ldscol(c)) * 16 + cq * 4) = v;
-    }
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// Byte offset that is out of range for every tensor (all are < 2 GiB, checked on the host): a buffer load from it returns 0
+// and a buffer store to it is dropped by the hardware bounds check -> zero padding / ragged edges cost no branch and no select.
+#define CTL_OOB ((int)0x80000000)
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ctl_rsrc(const void* p, int64_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 ctl_bload4(__amdgpu_buffer_rsrc_t r, int voff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0));
+}
+__device__ __forceinline__ float ctl_bload1(__amdgpu_buffer_rsrc_t r, int voff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, 0, 0));
+}
+__device__ __forceinline__ void ctl_bstore4(__amdgpu_buffer_rsrc_t r, int voff, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, 0, 0);
+}
+__device__ __forceinline__ void ctl_bstore1(__amdgpu_buffer_rsrc_t r, int voff, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), r, voff, 0, 0);
 }
 
+// Staging of one 16-channel chunk of the (virtual) input tile into LDS, with the BN+LeakyReLU prologue.  Everything that
+// depends only on the thread (tile-relative coordinates, source byte offset, LDS offset) is computed ONCE (init); per tile a
+// unit costs two adds + two unsigned compares (bounds) + one select for the buffer offset.  LOAD issues all buffer loads of
+// the tile back to back (nothing consumes them), STORE (after the MFMA phase) applies the prologue and writes LDS.
+template <int KS, int S, int MODE, int MT, int TW>
+struct XStage {
+    using G = Geom<KS, S, MT, TW>;
+    static constexpr int UNITS = G::IH * G::IW * 4;
+    static constexpr int NU = (UNITS + 255) / 256;
+    int rel[NU];        // byte offset of the unit relative to the tile's source origin
+    int rc[NU];         // r | c << 16 (tile-relative virtual coordinates); 0x7fff7fff for the units past the tile
+    int lds[NU];        // LDS float offset, -1 for the units past the tile
+    f32x4 v[NU];
+    unsigned vmask;     // bit i: unit i of the tile held in v[] lies inside the image (gets the prologue)
+
+    __device__ __forceinline__ void init(const ctl_conv& d) {
+        const int tid = threadIdx.x, cq = tid & 3;
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            const int u = tid + i * 256;
+            const int pix = u >> 2;
+            const int r = pix / G::IW;
+            const int c = pix - r * G::IW;
+            const bool in = u < UNITS;
+            // source = virtual for plain inputs; for x2 nearest / zero-insert inputs the tile origin is even, so
+            // (origin - PAD + r) >> 1 = origin/2 + ((r - PAD) >> 1)
+            const int rr = (MODE == CTL_IN_PLAIN) ? r : ((r - G::PAD) >> 1);
+            const int cc = (MODE == CTL_IN_PLAIN) ? c : ((c - G::PAD) >> 1);
+            rel[i] = ((rr * d.win + cc) * d.cin + cq * 4) * 4;
+            rc[i] = in ? (r | (c << 16)) : 0x7fff7fff;
+            lds[i] = in ? ((r * G::IWP + G::ldscol(c)) * 16 + cq * 4) : -1;
+        }
+        vmask = 0;
+    }
+
+    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rx, const ctl_conv& d, int n, int ho0, int wo0, int g) {
+        const int vh0 = ho0 * S - G::PAD, vw0 = wo0 * S - G::PAD;
+        const unsigned hv = (MODE == CTL_IN_PLAIN) ? d.hin : 2 * d.hin;
+        const unsigned wv = (MODE == CTL_IN_PLAIN) ? d.win : 2 * d.win;
+        const int oh = (MODE == CTL_IN_PLAIN) ? vh0 : (ho0 >> 1);
+        const int ow = (MODE == CTL_IN_PLAIN) ? vw0 : (wo0 >> 1);
+        const int tb = (((n * d.hin + oh) * d.win + ow) * d.cin + g * 16) * 4;      // uniform; may be negative at the border
+        const bool chan_ok = g * 16 + (threadIdx.x & 3) * 4 < d.cin;
+        unsigned m = 0;
+        int vo[NU];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            const int vh = vh0 + (rc[i] & 0xffff), vw = vw0 + (rc[i] >> 16);
+            bool ok = chan_ok && (unsigned)vh < hv && (unsigned)vw < wv;
+            if (MODE == CTL_IN_ZINS2) ok = ok && (((vh | vw) & 1) == 0);
+            vo[i] = ok ? (tb + rel[i]) : CTL_OOB;
+            m |= ok ? (1u << i) : 0u;
+        }
+        vmask = m;
+        if (d.cin >= 4) {
+#pragma unroll
+            for (int i = 0; i < NU; ++i) v[i] = ctl_bload4(rx, vo[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NU; ++i) v[i] = f32x4{ctl_bload1(rx, vo[i]), 0.f, 0.f, 0.f};
+        }
+    }
+
+    __device__ __forceinline__ void store(float* __restrict__ xt, const ctl_conv& d, int g,
+                                          const float* __restrict__ pro_scale, const float* __restrict__ pro_shift) {
+        const int cb = g * 16 + (threadIdx.x & 3) * 4;
+        const bool pro = d.pro_affine != 0;
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+        if (pro && cb < d.cin) {
+            if (d.cin >= 4) {
+                sc = *reinterpret_cast<const f32x4*>(pro_scale + cb);
+                sh = *reinterpret_cast<const f32x4*>(pro_shift + cb);
+            } else {
+                sc.x = pro_scale[0];
+                sh.x = pro_shift[0];
+            }
+        }
+        const float slope = d.pro_slope;
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            f32x4 t = v[i];
+            if (pro && ((vmask >> i) & 1u)) {          // padding / channel-pad lanes hold hardware zeros: no prologue
+                t.x = ctl_leaky(t.x * sc.x + sh.x, slope);
+                if (d.cin >= 4) {
+                    t.y = ctl_leaky(t.y * sc.y + sh.y, slope);
+                    t.z = ctl_leaky(t.z * sc.z + sh.z, slope);
+                    t.w = ctl_leaky(t.w * sc.w + sh.w, slope);
+                }
+            }
+            if (lds[i] >= 0) *reinterpret_cast<f32x4*>(xt + lds[i]) = t;
+        }
+    }
+};
+
+// Tile walker of a persistent block: tile index bid0, bid0+nblk, ... decoded incrementally (no per-tile divisions).
+struct TileWalk {
+    int n, th, tw;            // current tile coordinates
+    int dn, dth, dtw;         // decomposition of the stride nblk
+    int tiles_h, tiles_w;
+    __device__ __forceinline__ void init(int bid0, int nblk, int tiles_h_, int tiles_w_) {
+        tiles_h = tiles_h_; tiles_w = tiles_w_;
+        tw = bid0 % tiles_w; int b = bid0 / tiles_w; th = b % tiles_h; n = b / tiles_h;
+        dtw = nblk % tiles_w; b = nblk / tiles_w; dth = b % tiles_h; dn = b / tiles_h;
+    }
+    __device__ __forceinline__ void next() {
+        tw += dtw;
+        if (tw >= tiles_w) { tw -= tiles_w; ++th; }
+        th += dth;
+        if (th >= tiles_h) { th -= tiles_h; ++n; }
+        n += dn;
+    }
+};
+
 // ------------------------------------------------------------------------------------------------ forward-type kernel
-template <int KS, int S, int MODE, int MT, int TW, int NT>
+// Persistent, software-pipelined: a block walks tiles bid, bid+grid, ... and for every (tile, 16-channel chunk) step
+//   1. issues the NEXT step's buffer loads (input tile + weight chunk) into registers        -- HBM/L2 latency in flight
+//   2. runs the MFMA loop of the CURRENT step out of LDS
+//   3. bare s_barrier; ds_write the prefetched registers; lgkmcnt(0) + s_barrier               -- no vmcnt drain
+//   4. (last chunk of a tile) epilogue: bias / residual / activation, buffer stores that are never waited for in the loop;
+//      BatchNorm statistics stay in registers until the block is done.
+// Weight chunks [tap][nt][64 lanes][4] go through LDS (shared by the four waves; staged once when Cin <= 16).
+template <int KS, int S, int MODE, int MT, int TW, int NT, int EPI>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ctl_conv d, const float* __restrict__ x,
                                                           const float* __restrict__ wpack,
                                                           const float* __restrict__ bias,
@@ -94,63 +184,105 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ctl_conv d, const
                                                           const float* __restrict__ res_scale,
                                                           const float* __restrict__ res_shift, float* __restrict__ y,
                                                           float* __restrict__ stats_partial, int tiles_h, int tiles_w,
-                                                          int G_chunks, int64_t wpack_sub_stride) {
+                                                          int G_chunks, int64_t wpack_sub_stride, int ntiles, int dbg) {
     using G = Geom<KS, S, MT, TW>;
     constexpr int TAPS = KS * KS;
     constexpr int RED_FLOATS = 4 * NT * 16 * 2;
-    // Cout >= 32 (NT >= 2): the block's weight chunk [tap][nt][64 lanes][4] goes through LDS once per 16-channel chunk and
-    // is shared by the four waves (4x less L2 traffic, no per-wave L2 latency); Cout = 16: 36 fragments stay in VGPRs.
-    constexpr bool WLDS = NT >= 2;
-    constexpr int WT_FLOATS = WLDS ? TAPS * NT * 256 : 0;
+    constexpr int WT_FLOATS = TAPS * NT * 256;
     constexpr int XT_ALLOC = (G::XT_FLOATS > RED_FLOATS) ? G::XT_FLOATS : RED_FLOATS;
     __shared__ __attribute__((aligned(16))) float xt[XT_ALLOC + WT_FLOATS];
     float* wt = xt + XT_ALLOC;
+    constexpr int WU = TAPS * NT * 64, NW = (WU + 255) / 256;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int p = lane & 15, q = lane >> 4;
-
-    int bid = ctl_xcd_remap(blockIdx.x, gridDim.x);
-    const int twi = bid % tiles_w;
-    bid /= tiles_w;
-    const int thi = bid % tiles_h;
-    const int n = bid / tiles_h;
-    const int ho0 = thi * G::TH, wo0 = twi * TW;
+    const int nblk = gridDim.x;
+    const int bid0 = ctl_xcd_remap(blockIdx.x, nblk);
     const int z = blockIdx.z;
     const int cot0 = blockIdx.y * NT;
     const float* wp = wpack + (int64_t)z * wpack_sub_stride;
+    const int my_tiles = (bid0 < ntiles) ? (ntiles - bid0 + nblk - 1) / nblk : 0;
+    const int total_it = my_tiles * G_chunks;
+    const int flags = d.epi_flags;
+    const int oy0 = (z >> 1) * d.out_sub, ox0 = (z & 1) * d.out_sub;
+    const __amdgpu_buffer_rsrc_t rx = ctl_rsrc(x, (int64_t)d.n * d.hin * d.win * d.cin * 4);
+    const int64_t ybytes = (int64_t)d.n * d.out_h * d.out_w * d.cout * 4;
+    const __amdgpu_buffer_rsrc_t ry = ctl_rsrc(y, ybytes);
+    const __amdgpu_buffer_rsrc_t rres = ctl_rsrc(EPI ? (const void*)res : (const void*)y, ybytes);
+
+    f32x4 ssum[NT], ssq[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) ssum[t] = ssq[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // per-thread constants of the epilogue: byte offset of this lane's 4 channels of M-tile m relative to the tile's output origin
+    int yrel[MT], wcol[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int mt = wave * MT + m;
+        const int tr = mt / (TW / 16), tc = (mt % (TW / 16)) * 16;
+        wcol[m] = tc + p;
+        yrel[m] = ((tr * d.out_sy * d.out_w + (tc + p) * d.out_sx) * d.cout + q * 4) * 4;
+    }
+
+    XStage<KS, S, MODE, MT, TW> xs;
+    xs.init(d);
+    f32x4 wv[NW];
+    auto wload = [&](int g) {
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int u = tid + i * 256;
+            const int tt = u >> 6, l = u & 63;           // tt = tap * NT + t
+            const int tap = tt / NT, t = tt - tap * NT;
+            if (u < WU)
+                wv[i] = *reinterpret_cast<const f32x4*>(
+                    wp + ((((int64_t)(cot0 + t) * TAPS + tap) * G_chunks + g) * 64 + l) * 4);
+        }
+    };
+    auto wstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int u = tid + i * 256;
+            if (u < WU) *reinterpret_cast<f32x4*>(wt + u * 4) = wv[i];
+        }
+    };
+
+    TileWalk cur, nxt;
+    cur.init(bid0, nblk, tiles_h, tiles_w);
+    nxt = cur;
+    if (total_it > 0) {
+        xs.load(rx, d, cur.n, cur.th * G::TH, cur.tw * TW, 0);
+        wload(0);
+        xs.store(xt, d, 0, pro_scale, pro_shift);
+        wstore();
+    }
+    __syncthreads();
 
     f32x4 acc[MT][NT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    for (int g = 0; g < G_chunks; ++g) {
-        if (g > 0) __syncthreads();
-        stage_x<KS, S, MODE, MT, TW>(xt, x, d, n, ho0 * S - G::PAD, wo0 * S - G::PAD, g, pro_scale, pro_shift);
-        if (WLDS) {
-            for (int u = tid; u < TAPS * NT * 64; u += 256) {
-                const int tt = u >> 6, l = u & 63;           // tt = tap * NT + t
-                const int tap = tt / NT, t = tt - tap * NT;
-                *reinterpret_cast<f32x4*>(wt + (tt * 64 + l) * 4) = *reinterpret_cast<const f32x4*>(
-                    wp + ((((int64_t)(cot0 + t) * TAPS + tap) * G_chunks + g) * 64 + l) * 4);
-            }
+    for (int it = 0, g = 0; it < total_it; ++it) {
+        const int n = cur.n, ho0 = cur.th * G::TH, wo0 = cur.tw * TW;
+        const bool has_next = it + 1 < total_it;
+        const int g2 = (g + 1 == G_chunks) ? 0 : g + 1;
+        const bool new_w = has_next && G_chunks > 1;
+        if (g2 == 0) nxt.next();
+        if (has_next && !(dbg & 2)) {
+            xs.load(rx, d, nxt.n, nxt.th * G::TH, nxt.tw * TW, g2);
+            if (new_w) wload(g2);
         }
-        __syncthreads();
+        if (g == 0) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (!(dbg & 1))
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
             const int kh = tap / KS, kw = tap % KS;
             f32x4 wf[NT];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                if (WLDS)
-                    wf[t] = *reinterpret_cast<const f32x4*>(wt + ((tap * NT + t) * 64 + lane) * 4);
-                else
-                    wf[t] = *reinterpret_cast<const f32x4*>(
-                        wp + ((((int64_t)(cot0 + t) * TAPS + tap) * G_chunks + g) * 64 + lane) * 4);
-            }
+            for (int t = 0; t < NT; ++t) wf[t] = *reinterpret_cast<const f32x4*>(wt + ((tap * NT + t) * 64 + lane) * 4);
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 const int mt = wave * MT + m;
@@ -167,75 +299,95 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ctl_conv d, const
                 }
             }
         }
+
+        ctl_barrier_lds_reads_done();    // every wave is done reading this step's LDS images
+        if (has_next && !(dbg & 2)) {    // refill LDS from the prefetched registers
+            xs.store(xt, d, g2, pro_scale, pro_shift);
+            if (new_w) wstore();
+        }
+        ctl_barrier_lds_writes_done();
+
+        if (g == G_chunks - 1 && !(dbg & 4)) {
+            // ---------------- epilogue: lane (p,q) holds channels co0..co0+3 of pixel p of each M-tile.  Buffer stores with
+            // hardware bounds checks: ragged pixels / padded channels get CTL_OOB and are dropped; nothing here is waited for.
+            const int ybase = (((n * d.out_h + ho0 * d.out_sy + oy0) * d.out_w + wo0 * d.out_sx + ox0) * d.cout + cot0 * 16) * 4;
+            bool pv[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int tr = (wave * MT + m) / (TW / 16);
+                pv[m] = (ho0 + tr < d.hout) && (wo0 + wcol[m] < d.wout);
+            }
+            f32x4 rv[EPI ? MT : 1][EPI ? NT : 1], ov[EPI ? MT : 1][EPI ? NT : 1];
+            if (EPI) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const bool cok = (cot0 + t) * 16 + q * 4 < d.cout;
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        const int vo = (pv[m] && cok) ? (ybase + yrel[m] + t * 64) : CTL_OOB;
+                        rv[m][t] = ov[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if (d.cout >= 4) {
+                            if (flags & CTL_EPI_RES) rv[m][t] = ctl_bload4(rres, vo);
+                            if (flags & CTL_EPI_ACCUM) ov[m][t] = ctl_bload4(ry, vo);
+                        } else {
+                            if (flags & CTL_EPI_RES) rv[m][t].x = ctl_bload1(rres, vo);
+                            if (flags & CTL_EPI_ACCUM) ov[m][t].x = ctl_bload1(ry, vo);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int co0 = (cot0 + t) * 16 + q * 4;
+                const bool cok = co0 < d.cout;
+                const int cc = cok ? co0 : 0;
+                f32x4 b = {0.f, 0.f, 0.f, 0.f}, rs = {0.f, 0.f, 0.f, 0.f}, rh = {0.f, 0.f, 0.f, 0.f};
+                if (d.cout >= 4) {
+                    if (flags & CTL_EPI_BIAS) b = *reinterpret_cast<const f32x4*>(bias + cc);
+                    if (EPI && (flags & CTL_EPI_RES)) {
+                        rs = *reinterpret_cast<const f32x4*>(res_scale + cc);
+                        rh = *reinterpret_cast<const f32x4*>(res_shift + cc);
+                    }
+                } else {
+                    if (flags & CTL_EPI_BIAS) b.x = bias[0];
+                    if (EPI && (flags & CTL_EPI_RES)) { rs.x = res_scale[0]; rh.x = res_shift[0]; }
+                }
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    f32x4 v = acc[m][t];
+                    v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+                    if (EPI) {
+                        const f32x4 r_ = rv[m][t];
+                        v.x += r_.x * rs.x + rh.x; v.y += r_.y * rs.y + rh.y;
+                        v.z += r_.z * rs.z + rh.z; v.w += r_.w * rs.w + rh.w;
+                    }
+                    if ((flags & CTL_EPI_STATS) && pv[m]) {
+                        ssum[t].x += v.x; ssum[t].y += v.y; ssum[t].z += v.z; ssum[t].w += v.w;
+                        ssq[t].x += v.x * v.x; ssq[t].y += v.y * v.y; ssq[t].z += v.z * v.z; ssq[t].w += v.w * v.w;
+                    }
+                    if (d.epi_act == CTL_ACT_LEAKY) {
+                        v.x = ctl_leaky(v.x, d.epi_slope); v.y = ctl_leaky(v.y, d.epi_slope);
+                        v.z = ctl_leaky(v.z, d.epi_slope); v.w = ctl_leaky(v.w, d.epi_slope);
+                    } else if (d.epi_act == CTL_ACT_SIGMOID) {
+                        v.x = 1.f / (1.f + expf(-v.x)); v.y = 1.f / (1.f + expf(-v.y));
+                        v.z = 1.f / (1.f + expf(-v.z)); v.w = 1.f / (1.f + expf(-v.w));
+                    }
+                    if (EPI) {
+                        const f32x4 o = ov[m][t];
+                        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                    }
+                    const int vo = (pv[m] && cok) ? (ybase + yrel[m] + t * 64) : CTL_OOB;
+                    if (d.cout >= 4) ctl_bstore4(ry, vo, v);
+                    else ctl_bstore1(ry, vo, v.x);       // cout == 1: only q == 0 passes `cok`, component x is the channel
+                }
+            }
+        }
+        if (g2 == 0) cur = nxt;
+        g = g2;
     }
 
-    // ---------------- epilogue: lane (p,q) holds channels co0..co0+3 of pixel p of each M-tile
-    const int flags = d.epi_flags;
-    const int oy0 = (z >> 1) * d.out_sub, ox0 = (z & 1) * d.out_sub;
-    f32x4 ssum[NT], ssq[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) ssum[t] = ssq[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int co0 = (cot0 + t) * 16 + q * 4;
-        if (co0 >= d.cout) continue;
-        f32x4 b = {0.f, 0.f, 0.f, 0.f}, rs = {0.f, 0.f, 0.f, 0.f}, rh = {0.f, 0.f, 0.f, 0.f};
-        if (d.cout >= 4) {
-            if (flags & CTL_EPI_BIAS) b = *reinterpret_cast<const f32x4*>(bias + co0);
-            if (flags & CTL_EPI_RES) {
-                rs = *reinterpret_cast<const f32x4*>(res_scale + co0);
-                rh = *reinterpret_cast<const f32x4*>(res_shift + co0);
-            }
-        } else {
-            if (flags & CTL_EPI_BIAS) b.x = bias[0];
-            if (flags & CTL_EPI_RES) { rs.x = res_scale[0]; rh.x = res_shift[0]; }
-        }
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const int mt = wave * MT + m;
-            const int ho = ho0 + mt / (TW / 16), wo = wo0 + (mt % (TW / 16)) * 16 + p;
-            if (ho >= d.hout || wo >= d.wout) continue;
-            f32x4 v = acc[m][t];
-            v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
-            const int64_t opix = ((int64_t)n * d.out_h + (ho * d.out_sy + oy0)) * d.out_w + (wo * d.out_sx + ox0);
-            float* yp = y + opix * d.cout + co0;
-            if (d.cout >= 4) {
-                if (flags & CTL_EPI_RES) {
-                    const f32x4 rv = *reinterpret_cast<const f32x4*>(res + opix * d.cout + co0);
-                    v.x += rv.x * rs.x + rh.x; v.y += rv.y * rs.y + rh.y;
-                    v.z += rv.z * rs.z + rh.z; v.w += rv.w * rs.w + rh.w;
-                }
-                if (flags & CTL_EPI_STATS) {
-                    ssum[t].x += v.x; ssum[t].y += v.y; ssum[t].z += v.z; ssum[t].w += v.w;
-                    ssq[t].x += v.x * v.x; ssq[t].y += v.y * v.y; ssq[t].z += v.z * v.z; ssq[t].w += v.w * v.w;
-                }
-                if (d.epi_act == CTL_ACT_LEAKY) {
-                    v.x = ctl_leaky(v.x, d.epi_slope); v.y = ctl_leaky(v.y, d.epi_slope);
-                    v.z = ctl_leaky(v.z, d.epi_slope); v.w = ctl_leaky(v.w, d.epi_slope);
-                } else if (d.epi_act == CTL_ACT_SIGMOID) {
-                    v.x = 1.f / (1.f + __expf(-v.x)); v.y = 1.f / (1.f + __expf(-v.y));
-                    v.z = 1.f / (1.f + __expf(-v.z)); v.w = 1.f / (1.f + __expf(-v.w));
-                }
-                if (flags & CTL_EPI_ACCUM) {
-                    const f32x4 o = *reinterpret_cast<const f32x4*>(yp);
-                    v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
-                }
-                *reinterpret_cast<f32x4*>(yp) = v;
-            } else {  // cout == 1: only q == 0, component x is real
-                float s = v.x;
-                if (flags & CTL_EPI_RES) s += res[opix] * rs.x + rh.x;
-                if (flags & CTL_EPI_STATS) { ssum[t].x += s; ssq[t].x += s * s; }
-                if (d.epi_act == CTL_ACT_LEAKY) s = ctl_leaky(s, d.epi_slope);
-                else if (d.epi_act == CTL_ACT_SIGMOID) s = 1.f / (1.f + expf(-s));
-                if (flags & CTL_EPI_ACCUM) s += yp[0];
-                yp[0] = s;
-            }
-        }
-    }
-
-    if (flags & CTL_EPI_STATS) {  // per-channel sum / sum of squares of this tile -> stats_partial[block][2][cout]
-        __syncthreads();          // xt is reused as the cross-wave reduction buffer
+    __syncthreads();
+    if (flags & CTL_EPI_STATS) {  // per-channel sum / sum of squares of this block's tiles -> stats_partial[block][2][cout]
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             float a[8] = {ssum[t].x, ssum[t].y, ssum[t].z, ssum[t].w, ssq[t].x, ssq[t].y, ssq[t].z, ssq[t].w};
@@ -306,30 +458,56 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ctl_conv d, const
 #pragma unroll
     for (int t = 0; t < NTW; ++t) bsum[t] = 0.f;
 
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        int b = tile;
-        const int twi = b % tiles_w;
-        b /= tiles_w;
-        const int thi = b % tiles_h;
-        const int n = b / tiles_h;
-        const int ho0 = thi * G::TH, wo0 = twi * TW;
-        __syncthreads();
-        stage_x<KS, S, MODE, MT, TW>(xt, x, d, n, ho0 * S - G::PAD, wo0 * S - G::PAD, g, pro_scale, pro_shift);
-        for (int u = tid; u < G::TP * NTW * 4; u += 256) {
-            const int pix = u / (NTW * 4);
-            const int q4 = u - pix * (NTW * 4);
-            const int t = q4 >> 2, cq = q4 & 3;
-            const int ho = ho0 + pix / TW, wo = wo0 + pix % TW;
-            const int co = (cot0 + t) * 16 + cq * 4;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ho < d.hout && wo < d.wout && co < d.cout) {
-                const int64_t base = (((int64_t)n * d.hout + ho) * d.wout + wo) * d.cout + co;
-                if (d.cout >= 4) v = *reinterpret_cast<const f32x4*>(dy + base);
-                else v.x = dy[base];
-            }
-            *reinterpret_cast<f32x4*>(dyt + (t * G::TP + pix) * 16 + cq * 4) = v;
+    constexpr int DU = G::TP * NTW * 4, ND = DU / 256;       // TP is a multiple of 64 -> exact
+    const __amdgpu_buffer_rsrc_t rx = ctl_rsrc(x, (int64_t)d.n * d.hin * d.win * d.cin * 4);
+    const __amdgpu_buffer_rsrc_t rdy = ctl_rsrc(dy, (int64_t)d.n * d.hout * d.wout * d.cout * 4);
+    XStage<KS, S, MODE, MT, TW> xs;
+    xs.init(d);
+    // dy tile: per-thread constants (pixel row/col inside the tile, byte offset relative to the tile origin, LDS offset)
+    f32x4 dv[ND];
+    int drel[ND], drc[ND], dlds[ND];
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+        const int u = tid + i * 256;
+        const int pix = u / (NTW * 4);
+        const int q4 = u - pix * (NTW * 4);
+        const int t = q4 >> 2, cq = q4 & 3;
+        const int pr = pix / TW, pc = pix % TW;
+        const int co = (cot0 + t) * 16 + cq * 4;
+        drc[i] = (co < d.cout) ? (pr | (pc << 16)) : 0x7fff7fff;
+        drel[i] = ((pr * d.wout + pc) * d.cout + co) * 4;
+        dlds[i] = (t * G::TP + pix) * 16 + cq * 4;
+    }
+    auto dyload = [&](int n, int ho0, int wo0) {
+        const int tb = ((n * d.hout + ho0) * d.wout + wo0) * d.cout * 4;
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const bool ok = (unsigned)(ho0 + (drc[i] & 0xffff)) < (unsigned)d.hout && (unsigned)(wo0 + (drc[i] >> 16)) < (unsigned)d.wout;
+            const int vo = ok ? (tb + drel[i]) : CTL_OOB;
+            if (d.cout >= 4) dv[i] = ctl_bload4(rdy, vo);
+            else dv[i] = f32x4{ctl_bload1(rdy, vo), 0.f, 0.f, 0.f};
         }
-        __syncthreads();
+    };
+    auto dystore = [&]() {
+#pragma unroll
+        for (int i = 0; i < ND; ++i) *reinterpret_cast<f32x4*>(dyt + dlds[i]) = dv[i];
+    };
+    TileWalk cur;
+    cur.init(blockIdx.x, gridDim.x, tiles_h, tiles_w);
+    if ((int)blockIdx.x < ntiles) {
+        xs.load(rx, d, cur.n, cur.th * G::TH, cur.tw * TW, g);
+        dyload(cur.n, cur.th * G::TH, cur.tw * TW);
+        xs.store(xt, d, g, pro_scale, pro_shift);
+        dystore();
+    }
+    __syncthreads();
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const bool has_next = tile + (int)gridDim.x < ntiles;
+        if (has_next) {                   // next tile's loads fly while this tile's MFMAs run
+            cur.next();
+            xs.load(rx, d, cur.n, cur.th * G::TH, cur.tw * TW, g);
+            dyload(cur.n, cur.th * G::TH, cur.tw * TW);
+        }
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const int mt = wave * MT + m;
@@ -353,7 +531,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ctl_conv d, const
                 }
             }
         }
+        ctl_barrier_lds_reads_done();
+        if (has_next) {
+            xs.store(xt, d, g, pro_scale, pro_shift);
+            dystore();
+        }
+        ctl_barrier_lds_writes_done();
     }
+    __syncthreads();
 
     // ---------------- sum the four waves through LDS, tap by tap, and write this split's partial
     float* red = lds;
@@ -472,7 +657,7 @@ static bool conv_combo_ok(const ctl_conv* d) {
     return false;
 }
 
-int ctl_conv_pick_cfg(const ctl_conv* d, ctl_conv_cfg* c) {
+int ctl_conv_pick_cfg(const ctl_conv* d, ctl_conv_cfg* c, int for_wgrad) {
     CTL_REQUIRE(conv_combo_ok(d), "conv: unsupported ks/stride/pad/in_mode %d/%d/%d/%d", d->ks, d->stride, d->pad,
                 d->in_mode);
     CTL_REQUIRE(d->cin == 1 || d->cin % 4 == 0, "conv: cin must be 1 or a multiple of 4 (got %d)", d->cin);
@@ -482,15 +667,19 @@ int ctl_conv_pick_cfg(const ctl_conv* d, ctl_conv_cfg* c) {
     CTL_REQUIRE(d->nsub == 1 || d->nsub == 4, "conv: nsub must be 1 or 4");
     c->cot = ctl_cdiv(d->cout, 16);
     c->g = ctl_cdiv(d->cin, 16);
-    c->nt = (c->cot % 4 == 0) ? 4 : (c->cot % 2 == 0) ? 2 : 1;
-    const int64_t pix_per_img = (int64_t)d->hout * d->wout;
+    // Measured on MI355X (tools/bench_conv.py, bs16 layers): 32 output channels per block (NT=2, weights through LDS)
+    // beats 64 everywhere (occupancy); 8x32 tiles win while they still give >= 512 blocks, then 8x16, then 4x16.
+    c->nt = (c->cot % 2 == 0) ? 2 : 1;
     auto blocks = [&](int mt, int tw) {
         const int th = 4 * mt * 16 / tw;
         return (int64_t)d->n * ctl_cdiv(d->hout, th) * ctl_cdiv(d->wout, tw) * (c->cot / c->nt) * d->nsub;
     };
-    (void)pix_per_img;
     int mt, tw;
-    if (d->stride == 2) {
+    if (for_wgrad) {
+        // the wgrad kernel keeps KS*KS*NTW accumulator tiles in registers: 8x16 tiles measured best on every layer
+        if (d->hout >= 8) { mt = 2; tw = 16; }
+        else { mt = 1; tw = 16; }
+    } else if (d->stride == 2) {
         if (blocks(2, 16) >= 384) { mt = 2; tw = 16; } else { mt = 1; tw = 16; }
     } else if (d->wout >= 32 && blocks(4, 32) >= 512) {
         mt = 4; tw = 32;
@@ -499,18 +688,42 @@ int ctl_conv_pick_cfg(const ctl_conv* d, ctl_conv_cfg* c) {
     } else {
         mt = 1; tw = 16;
     }
+    {   // tuning hook (tools/bench_conv.py): CTL_FORCE_CFG="mt,tw,nt" overrides the heuristic when the combination is valid
+        const char* f = getenv("CTL_FORCE_CFG");
+        int fm, ft, fn;
+        if (f && sscanf(f, "%d,%d,%d", &fm, &ft, &fn) == 3) {
+            const bool tile_ok = (fm == 4 && ft == 32 && d->stride == 1) || (fm == 2 && ft == 16) || (fm == 1 && ft == 16);
+            if (tile_ok) { mt = fm; tw = ft; }
+            if ((fn == 1 || fn == 2 || fn == 4) && c->cot % fn == 0) c->nt = fn;
+        }
+    }
     if (d->stride == 2 && c->nt == 4) c->nt = 2;            // stride-2 input tiles are 4x larger: keep LDS < 64 KiB
-    if (c->nt == 4 && blocks(mt, tw) < 384) c->nt = 2;      // small problems: halve the cout tile to fill the 256 CUs
     c->mt = mt; c->tw = tw; c->th = 4 * mt * 16 / tw;
     c->tiles_h = ctl_cdiv(d->hout, c->th);
     c->tiles_w = ctl_cdiv(d->wout, c->tw);
     return CTL_OK;
 }
 
+// persistent grid: ~CTL_PERSIST blocks per CU in total (default 4; the blocks of one launch share the chip with
+// nothing else), never more than there are tiles
+static int conv_grid_x(const ctl_conv* d, const ctl_conv_cfg* c) {
+    static int per_cu = -1;
+    if (per_cu < 0) {
+        const char* e = getenv("CTL_PERSIST");
+        per_cu = e ? atoi(e) : 4;
+        if (per_cu < 1) per_cu = 1;
+    }
+    const int ntiles = d->n * c->tiles_h * c->tiles_w;
+    const int other = (c->cot / c->nt) * d->nsub;
+    int cap = ctl_cdiv(256 * per_cu, other);
+    if (cap < 1) cap = 1;
+    return ntiles < cap ? ntiles : cap;
+}
+
 extern "C" int ctl_conv_stats_blocks(const ctl_conv* d) {
     ctl_conv_cfg c;
-    if (ctl_conv_pick_cfg(d, &c) != CTL_OK) return -1;
-    return d->n * c.tiles_h * c.tiles_w;
+    if (ctl_conv_pick_cfg(d, &c, 0) != CTL_OK) return -1;
+    return conv_grid_x(d, &c);
 }
 extern "C" size_t ctl_conv_stats_floats(const ctl_conv* d) {
     const int b = ctl_conv_stats_blocks(d);
@@ -528,9 +741,12 @@ extern "C" int ctl_pack_weights(const float* src, float* dst, int32_t cout, int3
 }
 
 #define CONV_ARGS *d, x, wpack, bias, pro_scale, pro_shift, res, res_scale, res_shift, y, stats_partial, c.tiles_h, \
-                  c.tiles_w, c.g, sub_stride
-#define LAUNCH_CONV(KS, S, MODE, MT, TW, NT)                                                           \
-    conv_igemm_kernel<KS, S, MODE, MT, TW, NT><<<grid, dim3(256), 0, (hipStream_t)stream>>>(CONV_ARGS)
+                  c.tiles_w, c.g, sub_stride, ntiles, dbg
+#define LAUNCH_CONV(KS, S, MODE, MT, TW, NT)                                                                     \
+    do {                                                                                                         \
+        if (epi) conv_igemm_kernel<KS, S, MODE, MT, TW, NT, 1><<<grid, dim3(256), 0, (hipStream_t)stream>>>(CONV_ARGS); \
+        else conv_igemm_kernel<KS, S, MODE, MT, TW, NT, 0><<<grid, dim3(256), 0, (hipStream_t)stream>>>(CONV_ARGS);     \
+    } while (0)
 #define DISPATCH_NT(KS, S, MODE, MT, TW)                     \
     do {                                                     \
         if (c.nt == 4) LAUNCH_CONV(KS, S, MODE, MT, TW, 4);  \
@@ -560,15 +776,22 @@ extern "C" int ctl_conv_forward(const ctl_conv* d, const float* x, const float* 
                                 ctl_stream stream) {
     CTL_REQUIRE(d && x && wpack && y, "conv_forward: null argument");
     ctl_conv_cfg c;
-    int rc = ctl_conv_pick_cfg(d, &c);
+    int rc = ctl_conv_pick_cfg(d, &c, 0);
     if (rc != CTL_OK) return rc;
     CTL_REQUIRE(!(d->epi_flags & CTL_EPI_BIAS) || bias, "conv_forward: CTL_EPI_BIAS without bias");
     CTL_REQUIRE(!(d->epi_flags & CTL_EPI_RES) || (res && res_scale && res_shift), "conv_forward: CTL_EPI_RES without res");
     CTL_REQUIRE(!(d->epi_flags & CTL_EPI_STATS) || (stats_partial && d->nsub == 1), "conv_forward: bad CTL_EPI_STATS use");
     CTL_REQUIRE(!d->pro_affine || (pro_scale && pro_shift), "conv_forward: prologue without scale/shift");
     CTL_REQUIRE(d->n > 0 && d->hout > 0 && d->wout > 0, "conv_forward: empty problem");
+    CTL_REQUIRE((int64_t)d->n * d->hin * d->win * d->cin * 4 < (1ll << 31) &&
+                (int64_t)d->n * d->out_h * d->out_w * d->cout * 4 < (1ll << 31),
+                "conv_forward: tensors must stay below 2 GiB (32-bit buffer offsets)");
     const int64_t sub_stride = (int64_t)ctl_conv_wpack_floats(d->cin, d->cout, d->ks);
-    const dim3 grid((unsigned)(d->n * c.tiles_h * c.tiles_w), (unsigned)(c.cot / c.nt), (unsigned)d->nsub);
+    const int ntiles = d->n * c.tiles_h * c.tiles_w;
+    const bool epi = (d->epi_flags & (CTL_EPI_RES | CTL_EPI_ACCUM)) != 0;
+    static int dbg = -1;                       // CTL_DBG ablation mask (tools/bench_conv.py): 1 no MFMA, 2 no prefetch, 4 no epilogue
+    if (dbg < 0) { const char* e = getenv("CTL_DBG"); dbg = e ? atoi(e) : 0; }
+    const dim3 grid((unsigned)conv_grid_x(d, &c), (unsigned)(c.cot / c.nt), (unsigned)d->nsub);
     const int k = d->ks, s = d->stride, m = d->in_mode;
     const int ptok = ctl_prof_begin("conv_igemm", d, &c, c.nt, (hipStream_t)stream);
     if (k == 3 && s == 1 && m == CTL_IN_PLAIN) DISPATCH_TILE(3, 1, CTL_IN_PLAIN);
@@ -590,7 +813,7 @@ struct wgrad_cfg { ctl_conv_cfg c; int ntw, splits, ntiles, cin_p, cout_p; };
 static int wgrad_pick(const ctl_conv* d, wgrad_cfg* w) {
     CTL_REQUIRE(d->nsub == 1, "wgrad: nsub must be 1");
     CTL_REQUIRE(d->in_mode != CTL_IN_ZINS2, "wgrad: zero-insert input is not a forward mode");
-    int rc = ctl_conv_pick_cfg(d, &w->c);
+    int rc = ctl_conv_pick_cfg(d, &w->c, 1);
     if (rc != CTL_OK) return rc;
     // the wgrad kernel reuses the forward tile shapes; cap LDS by keeping (4,32) only for stride 1
     w->ntw = (w->c.cot >= 2 && w->c.cot % 2 == 0) ? 2 : 1;
@@ -645,6 +868,9 @@ extern "C" int ctl_conv_wgrad(const ctl_conv* d, const float* x, const float* pr
                               const float* dy, float* w_partial, float* b_partial, ctl_stream stream) {
     CTL_REQUIRE(d && x && dy && w_partial, "conv_wgrad: null argument");
     CTL_REQUIRE(!d->pro_affine || (pro_scale && pro_shift), "conv_wgrad: prologue without scale/shift");
+    CTL_REQUIRE((int64_t)d->n * d->hin * d->win * d->cin * 4 < (1ll << 31) &&
+                (int64_t)d->n * d->hout * d->wout * d->cout * 4 < (1ll << 31),
+                "conv_wgrad: tensors must stay below 2 GiB (32-bit buffer offsets)");
     wgrad_cfg w;
     int rc = wgrad_pick(d, &w);
     if (rc != CTL_OK) return rc;

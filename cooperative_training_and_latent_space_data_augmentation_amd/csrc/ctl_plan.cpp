@@ -57,15 +57,15 @@ int ctl_prof_begin(const char* kind, const ctl_conv* d, const ctl_conv_cfg* c, i
     r.bytes = in_b + out_b;
     if (d->epi_flags & CTL_EPI_RES) r.bytes += out_b;
     if (d->epi_flags & CTL_EPI_ACCUM) r.bytes += out_b;
-    hipEventRecord(r.a, stream);
+    (void)hipEventRecord(r.a, stream);
     g_prof.push_back(r);
     return (int)g_prof.size() - 1;
 }
 void ctl_prof_end(int token, hipStream_t stream) {
-    if (token >= 0 && token < (int)g_prof.size()) hipEventRecord(g_prof[token].b, stream);
+    if (token >= 0 && token < (int)g_prof.size()) (void)hipEventRecord(g_prof[token].b, stream);
 }
 extern "C" int ctl_prof_start(const char* filter) {
-    for (auto& r : g_prof) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+    for (auto& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     g_prof.clear();
     g_prof_filter = filter ? filter : "";
     g_prof_on = true;
@@ -81,8 +81,8 @@ extern "C" int ctl_prof_stop(char* out, size_t cap) {
             Agg& a = agg[r.id];
             a.n++; a.ms += ms; a.flops += r.flops; a.bytes += r.bytes;
         }
-        hipEventDestroy(r.a);
-        hipEventDestroy(r.b);
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
     }
     g_prof.clear();
     std::string text;
