@@ -16,7 +16,7 @@ ACT_NONE, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2
 EPI_BIAS, EPI_ACCUM, EPI_RES, EPI_STATS = 1, 2, 4, 8
 RED_BLOCKS = 512
 (OP_CONV, OP_WGRAD, OP_WGRAD_REDUCE, OP_PACK, OP_BN_FINALIZE, OP_BN_EVAL, OP_BN_ACT, OP_BWD_REDUCE, OP_BN_BWD_FINALIZE,
- OP_BWD_APPLY, OP_CHAN_SUM_FINALIZE, OP_SUMPOOL2, OP_SIGMOID_BWD, OP_ZERO, OP_COPY) = range(1, 16)
+ OP_BWD_APPLY, OP_CHAN_SUM_FINALIZE, OP_SUMPOOL2, OP_SIGMOID_BWD, OP_ZERO, OP_COPY, OP_PACK_BATCH, OP_WGRAD_REDUCE_BATCH) = range(1, 18)
 OP_MAX_T = 12
 
 CONV_DTYPE = np.dtype([
@@ -82,6 +82,7 @@ class _Lib:
             "ctl_adam": [p, p, p, p, i64, f32, f32, f32, f32, i32, f32, p],
             "ctl_plan_run": [p, i32, p, i32, p],
             "ctl_prof_start": [C.c_char_p], "ctl_prof_stop": [p, C.c_size_t],
+            "ctl_pack_weights_batched": [p, p, p, i32, i64, p], "ctl_wgrad_reduce_batched": [p, p, p, i32, i64, p],
         }
         for name, args in sig.items():
             getattr(lib, name).argtypes = args
@@ -105,7 +106,8 @@ EXPORTED = ["ctl_version", "ctl_last_error", "ctl_conv_wpack_floats", "ctl_conv_
             "ctl_sigmoid_bwd", "ctl_softmax_t_fwd", "ctl_softmax_t_bwd", "ctl_onehot", "ctl_ce2d_fwd", "ctl_ce2d_bwd",
             "ctl_mse_fwd", "ctl_mse_bwd", "ctl_argmax_c", "ctl_latent_score_ws_floats", "ctl_latent_score",
             "ctl_latent_mask_apply", "ctl_dropout2d", "ctl_uniform", "ctl_adam", "ctl_plan_run", "ctl_sizeof_op",
-            "ctl_sizeof_conv", "ctl_prof_start", "ctl_prof_stop"]
+            "ctl_sizeof_conv", "ctl_prof_start", "ctl_prof_stop", "ctl_pack_weights_batched",
+            "ctl_wgrad_reduce_batched"]
 
 
 def prof_start(kernel_filter: str = "") -> None:

@@ -643,7 +643,92 @@ __global__ void pack_weights_kernel(const float* __restrict__ src, float* __rest
     dst[idx] = v;
 }
 
+// ---- table-driven batched forms: blockIdx.y selects the record
+__global__ void pack_weights_batched_kernel(const float* __restrict__ params, float* __restrict__ wpack,
+                                            const int64_t* __restrict__ table) {
+    const int64_t* r = table + (int64_t)blockIdx.y * 12;
+    const int64_t total = r[10];
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const float* src = params + r[0];
+    float* dst = wpack + r[1];
+    const int cout = (int)r[2], cin = (int)r[3], ks = (int)r[4], flip = (int)r[5];
+    const int g_chunks = (cin + 15) / 16;
+    const int j = idx & 3, lane = (idx >> 2) & 63;
+    int64_t rest = idx >> 8;
+    const int g = rest % g_chunks;
+    rest /= g_chunks;
+    const int taps = ks * ks;
+    const int tap = rest % taps;
+    const int cot = rest / taps;
+    const int co = cot * 16 + (lane & 15);
+    const int ci = g * 16 + (lane >> 4) * 4 + j;
+    int kh = tap / ks, kw = tap % ks;
+    if (flip) { kh = ks - 1 - kh; kw = ks - 1 - kw; }
+    float v = 0.f;
+    if (co < cout && ci < cin) v = src[co * r[6] + ci * r[7] + kh * r[8] + kw * r[9]];
+    dst[idx] = v;
+}
+
+// Block shape adapts to the record: many splits of a small weight tensor -> 8 elements x 32 split lanes; few splits of a
+// large one -> 64 elements x 4 split lanes (256-byte coalesced rows).  Splits are summed in a fixed order (deterministic).
+__global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(const float* __restrict__ scratch, float* __restrict__ grad,
+                                                                    const int64_t* __restrict__ table) {
+    __shared__ float sm[32][65];
+    const int64_t* r = table + (int64_t)blockIdx.y * 16;
+    const int splits = (int)r[4], taps = (int)(r[5] & 0xff), ks = (int)(r[5] >> 8), cin = (int)r[6], cout = (int)r[7];
+    const int cin_p = (int)r[8], cout_p = (int)r[9];
+    const int64_t total = (int64_t)taps * cin * cout;
+    const bool has_b = r[1] >= 0 && r[3] >= 0;
+    const bool wide = splits <= 64;
+    const int EW = wide ? 64 : 8, SLN = wide ? 4 : 32;
+    if ((int64_t)blockIdx.x * EW >= total + (has_b ? cout : 0)) return;
+    const int e = wide ? (threadIdx.x & 63) : (threadIdx.x & 7), sl = wide ? (threadIdx.x >> 6) : (threadIdx.x >> 3);
+    const int64_t idx = (int64_t)blockIdx.x * EW + e;
+    const bool is_w = idx < total, is_b = !is_w && has_b && idx < total + cout;
+    float v = 0.f;
+    int co = 0, ci = 0, tap = 0;
+    if (is_w) {
+        co = idx % cout;
+        ci = (idx / cout) % cin;
+        tap = idx / ((int64_t)cout * cin);
+        const int64_t stride = (int64_t)taps * cin_p * cout_p;
+        const float* src = scratch + r[0] + ((int64_t)tap * cin_p + ci) * cout_p + co;
+        for (int s = sl; s < splits; s += SLN) v += src[s * stride];
+    } else if (is_b) {
+        co = idx - total;
+        const float* src = scratch + r[1] + co;
+        for (int s = sl; s < splits; s += SLN) v += src[(int64_t)s * cout_p];
+    }
+    sm[sl][e] = v;
+    __syncthreads();
+    if (sl == 0 && (is_w || is_b)) {
+        float t = 0.f;
+        for (int k = 0; k < SLN; ++k) t += sm[k][e];
+        float* dst = is_w ? grad + r[2] + co * r[10] + ci * r[11] + (tap / ks) * r[12] + (tap % ks) * r[13] : grad + r[3] + co;
+        *dst = r[14] ? (*dst + t) : t;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ host side
+extern "C" int ctl_pack_weights_batched(const float* params, float* wpack, const int64_t* table, int32_t n_rec,
+                                        int64_t max_total, ctl_stream stream) {
+    CTL_REQUIRE(params && wpack && table && n_rec > 0 && max_total > 0, "pack_weights_batched: bad arguments");
+    pack_weights_batched_kernel<<<dim3((unsigned)ctl_cdiv64(max_total, 256), (unsigned)n_rec), dim3(256), 0, (hipStream_t)stream>>>(
+        params, wpack, table);
+    CTL_LAUNCH_CHECK("pack_weights_batched");
+    return CTL_OK;
+}
+extern "C" int ctl_wgrad_reduce_batched(const float* scratch, float* grad, const int64_t* table, int32_t n_rec,
+                                        int64_t max_elems, ctl_stream stream) {
+    CTL_REQUIRE(scratch && grad && table && n_rec > 0 && max_elems > 0, "wgrad_reduce_batched: bad arguments");
+    // `max_elems` is the largest per-record block count (elements / 64 for <= 64 splits, / 8 otherwise), see nets.py
+    wgrad_reduce_batched_kernel<<<dim3((unsigned)max_elems, (unsigned)n_rec), dim3(256), 0, (hipStream_t)stream>>>(
+        scratch, grad, table);
+    CTL_LAUNCH_CHECK("wgrad_reduce_batched");
+    return CTL_OK;
+}
+
 extern "C" size_t ctl_conv_wpack_floats(int32_t cin, int32_t cout, int32_t ks) {
     return (size_t)ctl_cdiv(cout, 16) * ks * ks * ctl_cdiv(cin, 16) * 256;
 }

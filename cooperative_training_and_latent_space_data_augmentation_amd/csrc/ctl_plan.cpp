@@ -18,6 +18,8 @@
 //   SIGMOID_BWD       0 dy 1 y 2 dx                                      l[0]=count
 //   ZERO              0 ptr                                              l[0]=bytes
 //   COPY              0 src 1 dst                                        l[0]=bytes
+//   PACK_BATCH        0 params 1 wpack 2 table                           i[0]=n_rec l[0]=max_total
+//   WGRAD_REDUCE_BATCH 0 scratch 1 grad 2 table                          i[0]=n_rec l[0]=max_elems
 #include <stdarg.h>
 #include <string.h>
 
@@ -171,6 +173,12 @@ extern "C" int ctl_plan_run(const ctl_op* ops, int32_t n_ops, void* const* bases
                 if (e != hipSuccess) CTL_FAIL(CTL_ELAUNCH, "plan_run: memset: %s", hipGetErrorString(e));
                 break;
             }
+            case CTL_OP_PACK_BATCH:
+                rc = ctl_pack_weights_batched(CF(0), F(1), (const int64_t*)t[2], op.i[0], op.l[0], stream);
+                break;
+            case CTL_OP_WGRAD_REDUCE_BATCH:
+                rc = ctl_wgrad_reduce_batched(CF(0), F(1), (const int64_t*)t[2], op.i[0], op.l[0], stream);
+                break;
             case CTL_OP_COPY: {
                 CTL_REQUIRE(t[0] && t[1] && op.l[0] > 0, "plan_run: op %d COPY needs two pointers and a size", k);
                 hipError_t e = hipMemcpyAsync(t[1], t[0], (size_t)op.l[0], hipMemcpyDeviceToDevice, (hipStream_t)stream);

@@ -32,8 +32,8 @@ import torch.nn as nn
 from . import _ffi, init as _init
 from ._ffi import lib, check, OP_DTYPE
 
-(S_X, S_P, S_B, S_NBT, S_WP, S_ACT, S_SCR, S_OUT0, S_OUT1, S_DOUT0, S_DOUT1, S_GRAD, S_DX, S_BSCR) = range(14)
-N_SLOTS = 14
+(S_X, S_P, S_B, S_NBT, S_WP, S_ACT, S_SCR, S_OUT0, S_OUT1, S_DOUT0, S_DOUT1, S_GRAD, S_DX, S_BSCR, S_TAB) = range(15)
+N_SLOTS = 15
 SLOPE = 0.2
 EPS = 1e-5
 MOMENTUM = 0.1
@@ -92,7 +92,7 @@ class Arena:
 
 
 class Plan:
-    __slots__ = ("ops", "n_ops", "act_bytes", "scr_bytes", "bscr_bytes", "rec", "out_shapes")
+    __slots__ = ("ops", "n_ops", "act_bytes", "scr_bytes", "bscr_bytes", "rec", "out_shapes", "table_np", "table_dev")
 
 
 class PlanBuilder:
@@ -102,6 +102,8 @@ class PlanBuilder:
         self.act = Arena(S_ACT)
         self.bscr = Arena(S_BSCR)
         self.scr_bytes = 0
+        self.reduce_recs: List[list] = []     # batched wgrad reduction records (one launch at the end of the plan)
+        self.table: Optional[np.ndarray] = None
 
     # -- low level
     def op(self, kind: int) -> np.ndarray:
@@ -183,19 +185,33 @@ class PlanBuilder:
         wb, bb = 4 * lib.ctl_wgrad_partial_floats(dp), 4 * lib.ctl_wgrad_bias_partial_floats(dp)
         if wb == 0:
             raise _ffi.CtlError("wgrad plan: " + lib.ctl_last_error().decode())
-        wref, bref = self.scr(wb, bb)
+        # every layer keeps its own partial buffers (backward arena): all reductions run as ONE table-driven launch at the end
+        wref = self.bscr.alloc(wb)
+        bref = self.bscr.alloc(bb) if dbias_ref is not None else None
         words = np.frombuffer(d.tobytes(), dtype="<i4")
         op = self.op(_ffi.OP_WGRAD)
         op["i"][:22] = words
-        for idx, ref in enumerate([x.ref, pro[0] if pro else None, pro[1] if pro else None, dy.ref, wref,
-                                   bref if dbias_ref is not None else None]):
+        for idx, ref in enumerate([x.ref, pro[0] if pro else None, pro[1] if pro else None, dy.ref, wref, bref]):
             self.set_t(op, idx, ref)
-        op2 = self.op(_ffi.OP_WGRAD_REDUCE)
-        op2["i"][:22] = words
-        op2["i"][23] = 1 if accumulate else 0
-        op2["l"][:] = strides
-        for idx, ref in enumerate([wref, bref if dbias_ref is not None else None, dw_ref, dbias_ref]):
-            self.set_t(op2, idx, ref)
+        assert dw_ref[0] == S_GRAD and (dbias_ref is None or dbias_ref[0] == S_GRAD)
+        splits = lib.ctl_wgrad_splits(dp)
+        cin_p, cout_p = _rup(x.c, 16), _rup(dy.c, 16)
+        self.reduce_recs.append([wref[1] // 4, bref[1] // 4 if bref else -1, dw_ref[1] // 4, dbias_ref[1] // 4 if dbias_ref else -1,
+                                 splits, (ks * ks) | (ks << 8), x.c, dy.c, cin_p, cout_p, *[int(v) for v in strides],
+                                 1 if accumulate else 0, 0])
+
+    def flush_wgrad_reductions(self):
+        if not self.reduce_recs:
+            return
+        assert self.table is None
+        self.table = np.asarray(self.reduce_recs, dtype=np.int64)
+        op = self.op(_ffi.OP_WGRAD_REDUCE_BATCH)
+        op["i"][0] = len(self.reduce_recs)
+        op["l"][0] = max(-(-((r[5] & 0xff) * r[6] * r[7] + r[7]) // (64 if r[4] <= 64 else 8)) for r in self.reduce_recs)
+        self.set_t(op, 0, (S_BSCR, 0))
+        self.set_t(op, 1, (S_GRAD, 0))
+        self.set_t(op, 2, (S_TAB, 0))
+        self.reduce_recs = []
 
     # -- BatchNorm
     def bn_forward(self, bn: BNInfo, stats_ref, blocks, count, mode: str):
@@ -291,7 +307,9 @@ class PlanBuilder:
         self.set_t(op, 1, dst_ref)
 
     def finish(self, rec=None, out_shapes=None) -> Plan:
+        self.flush_wgrad_reductions()
         p = Plan()
+        p.table_np, p.table_dev = self.table, None
         p.ops = np.stack(self.ops) if self.ops else np.zeros(0, dtype=OP_DTYPE)
         p.ops = np.ascontiguousarray(p.ops)
         p.n_ops = len(self.ops)
@@ -438,13 +456,11 @@ class CtlNet(nn.Module):
     # ---------------------------------------------------------------- weight packing
     def _build_pack_plan(self) -> Plan:
         pb = PlanBuilder(self)
+        recs = []
 
         def pack(src_off_f, dst_off_f, cout, cin, ks, strides, flip):
-            op = pb.op(_ffi.OP_PACK)
-            op["i"][:4] = [cout, cin, ks, 1 if flip else 0]
-            op["l"][:] = strides
-            pb.set_t(op, 0, (S_P, 4 * src_off_f))
-            pb.set_t(op, 1, (S_WP, 4 * dst_off_f))
+            total = lib.ctl_conv_wpack_floats(cin, cout, ks)
+            recs.append([src_off_f, dst_off_f, cout, cin, ks, 1 if flip else 0, *strides, total, 0])
 
         for ci in self._convs.values():
             k2 = ci.ks * ci.ks
@@ -455,6 +471,13 @@ class CtlNet(nn.Module):
             else:                  # weight [Cout][Cin][ks][ks]
                 pack(ci.w_off, ci.wp_fwd, ci.cout, ci.cin, ci.ks, (ci.cin * k2, k2, ci.ks, 1), False)
                 pack(ci.w_off, ci.wp_dgrad, ci.cin, ci.cout, ci.ks, (k2, ci.cin * k2, ci.ks, 1), True)
+        pb.table = np.asarray(recs, dtype=np.int64)
+        op = pb.op(_ffi.OP_PACK_BATCH)                 # ONE launch re-packs every conv of the network
+        op["i"][0] = len(recs)
+        op["l"][0] = max(r[10] for r in recs)
+        pb.set_t(op, 0, (S_P, 0))
+        pb.set_t(op, 1, (S_WP, 0))
+        pb.set_t(op, 2, (S_TAB, 0))
         return pb.finish()
 
     def ensure_packed(self):
@@ -471,6 +494,11 @@ class CtlNet(nn.Module):
                 self._scr = torch.empty(plan.scr_bytes, dtype=torch.uint8, device=self.device)
             tensors = dict(tensors)
             tensors[S_SCR] = self._scr
+        if plan.table_np is not None:
+            if plan.table_dev is None or plan.table_dev.device != self.device:
+                plan.table_dev = torch.from_numpy(plan.table_np).to(self.device)
+            tensors = dict(tensors)
+            tensors[S_TAB] = plan.table_dev
         bases = (ctypes.c_void_p * N_SLOTS)()
         for s, t in tensors.items():
             bases[s] = t.data_ptr()

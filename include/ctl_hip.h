@@ -87,6 +87,16 @@ int ctl_wgrad_reduce(const ctl_conv* d, const float* w_partial, const float* b_p
                      float* dw, int64_t s_co, int64_t s_ci, int64_t s_kh, int64_t s_kw,
                      float* dbias, int32_t accumulate, ctl_stream stream);
 
+/* Batched forms (one launch for a whole network): `table` is a device array of int64 records.
+ * pack record   (12 words): src_off, dst_off (floats into params / wpack), cout, cin, ks, flip, s_co, s_ci, s_kh, s_kw, total, 0
+ * reduce record (16 words): w_off, b_off (floats into scratch; b_off < 0: none), dw_off, db_off (floats into grad; db_off < 0:
+ *                           none), splits, taps|ks<<8, cin, cout, cin_p, cout_p, s_co, s_ci, s_kh, s_kw, accumulate, 0;
+ *                           max_blocks = max over records of ceil((elements + cout) / (splits <= 64 ? 64 : 8)) */
+int ctl_pack_weights_batched(const float* params, float* wpack, const int64_t* table, int32_t n_rec, int64_t max_total,
+                             ctl_stream stream);
+int ctl_wgrad_reduce_batched(const float* scratch, float* grad, const int64_t* table, int32_t n_rec, int64_t max_blocks,
+                             ctl_stream stream);
+
 /* ------------------------------------------------------------------------------------------------ BatchNorm2d
  * encdec.py: every `norm(out_ch)`; three modes of SURVEY 8a row 4 (util.py:414-451).
  * finalize: partial [blocks][2][c] (sum, sum of squares over `count` pixels) -> scale=gamma*invstd,
@@ -179,7 +189,8 @@ int ctl_adam(float* p, const float* g, float* m, float* v, int64_t count, float 
 enum ctl_op_kind {
     CTL_OP_CONV = 1, CTL_OP_WGRAD = 2, CTL_OP_WGRAD_REDUCE = 3, CTL_OP_PACK = 4, CTL_OP_BN_FINALIZE = 5,
     CTL_OP_BN_EVAL = 6, CTL_OP_BN_ACT = 7, CTL_OP_BWD_REDUCE = 8, CTL_OP_BN_BWD_FINALIZE = 9, CTL_OP_BWD_APPLY = 10,
-    CTL_OP_CHAN_SUM_FINALIZE = 11, CTL_OP_SUMPOOL2 = 12, CTL_OP_SIGMOID_BWD = 13, CTL_OP_ZERO = 14, CTL_OP_COPY = 15
+    CTL_OP_CHAN_SUM_FINALIZE = 11, CTL_OP_SUMPOOL2 = 12, CTL_OP_SIGMOID_BWD = 13, CTL_OP_ZERO = 14, CTL_OP_COPY = 15, CTL_OP_PACK_BATCH = 16,
+    CTL_OP_WGRAD_REDUCE_BATCH = 17
 };
 #define CTL_OP_MAX_T 12
 typedef struct ctl_op {
