@@ -37,6 +37,31 @@ def synthetic(n, h, w, seed, device):
     return clean.to(device), label.to(device), noisy.to(device), (clean, label, noisy)
 
 
+def latent_mask_roofline(device):
+    """The north-star's named kernel: score + rank-select + apply, channel mode.  Algorithmic bytes = 3*N*C*h*w*4 (+ vectors).
+    Configured size (16x128x16x16, 2 MiB/tensor: cache-resident, launch-latency bound) and a 128 MiB/tensor problem (HBM-bound)."""
+    from cooperative_training_and_latent_space_data_augmentation_amd import ops
+    out = {}
+    for tag, (n, c, h, w) in (("configured_16x128x16x16", (16, 128, 16, 16)), ("hbm_regime_64x128x64x64", (64, 128, 64, 64))):
+        grad = torch.randn(n, c, h, w, device=device).contiguous(memory_format=torch.channels_last)
+        code = torch.rand(n, c, h, w, device=device).contiguous(memory_format=torch.channels_last)
+        for _ in range(3):
+            ops.latent_mask_apply(code, ops.latent_score(grad, 0), 0, c // 3)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # kernels run on torch's current stream
+        iters = 20
+        e0.record()
+        for _ in range(iters):
+            ops.latent_mask_apply(code, ops.latent_score(grad, 0), 0, c // 3)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / iters
+        nbytes = 12 * n * c * h * w + 12 * n * c
+        out[tag] = {"bound": "hbm", "achieved": nbytes / us / 1e3, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": nbytes / us / 1e3 / PEAK_HBM_GBS, "us_per_call": us, "algorithmic_mb": nbytes / 1e6}
+    return out
+
+
 def cpu_baseline(host_batch, threads):
     from oracle import ref_cpu as O                      # the checker, timed as the reported CPU baseline
     from cooperative_training_and_latent_space_data_augmentation_amd.init import reference_init_state_dicts
@@ -141,6 +166,13 @@ def main():
                                "algorithmic_gflop_per_launch": rec["flops"] / rec["launches"] / 1e9,
                                "algorithmic_mb_per_launch": rec["bytes"] / rec["launches"] / 1e6,
                                "hbm_gbs": gbs, "hbm_frac": f_hbm, "share_of_step_time": secs / dt}
+        tfile = os.path.join(ROOT, "profiles", "dominant_kernel_traffic.json")      # committed rocprofv3 --pmc measurement
+        if "roofline" in out and os.path.exists(tfile):
+            t = json.load(open(tfile))
+            if t.get("kernel") == out["roofline"]["kernel"]:
+                out["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
+        if world == 1:
+            out["roofline_latent_mask"] = latent_mask_roofline(device)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(host_batch, args.cpu_threads or min(32, os.cpu_count()))
         print(json.dumps(out), flush=True)

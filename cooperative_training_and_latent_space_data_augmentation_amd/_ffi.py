@@ -46,7 +46,8 @@ class _Lib:
         lib.ctl_last_error.restype = C.c_char_p
         lib.ctl_version.restype = C.c_int
         for name in ("ctl_conv_wpack_floats", "ctl_conv_stats_floats", "ctl_wgrad_partial_floats",
-                     "ctl_wgrad_bias_partial_floats", "ctl_latent_score_ws_floats", "ctl_sizeof_op", "ctl_sizeof_conv"):
+                     "ctl_wgrad_bias_partial_floats", "ctl_latent_score_ws_floats", "ctl_latent_mask_apply_ws_floats",
+                     "ctl_sizeof_op", "ctl_sizeof_conv"):
             getattr(lib, name).restype = C.c_size_t
         p, i32, i64, f32, u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64
         sig = {
@@ -76,7 +77,8 @@ class _Lib:
             "ctl_argmax_c": [p, p, i64, i32, p],
             "ctl_latent_score_ws_floats": [i32, i32, i32, i32],
             "ctl_latent_score": [i32, p, p, p, i32, i32, i32, p],
-            "ctl_latent_mask_apply": [i32, p, p, p, i32, p, p, p, i32, i32, i32, p],
+            "ctl_latent_mask_apply": [i32, p, p, p, i32, p, p, p, p, i32, i32, i32, p],
+            "ctl_latent_mask_apply_ws_floats": [i32, i32, i32, i32],
             "ctl_dropout2d": [p, p, u64, f32, p, p, i32, i32, i32, p],
             "ctl_uniform": [p, i64, u64, p],
             "ctl_adam": [p, p, p, p, i64, f32, f32, f32, f32, i32, f32, p],
@@ -105,7 +107,7 @@ EXPORTED = ["ctl_version", "ctl_last_error", "ctl_conv_wpack_floats", "ctl_conv_
             "ctl_bn_act", "ctl_bwd_reduce", "ctl_bn_bwd_finalize", "ctl_bwd_apply", "ctl_chan_sum_finalize", "ctl_sumpool2",
             "ctl_sigmoid_bwd", "ctl_softmax_t_fwd", "ctl_softmax_t_bwd", "ctl_onehot", "ctl_ce2d_fwd", "ctl_ce2d_bwd",
             "ctl_mse_fwd", "ctl_mse_bwd", "ctl_argmax_c", "ctl_latent_score_ws_floats", "ctl_latent_score",
-            "ctl_latent_mask_apply", "ctl_dropout2d", "ctl_uniform", "ctl_adam", "ctl_plan_run", "ctl_sizeof_op",
+            "ctl_latent_mask_apply", "ctl_latent_mask_apply_ws_floats", "ctl_dropout2d", "ctl_uniform", "ctl_adam", "ctl_plan_run", "ctl_sizeof_op",
             "ctl_sizeof_conv", "ctl_prof_start", "ctl_prof_stop", "ctl_pack_weights_batched",
             "ctl_wgrad_reduce_batched"]
 

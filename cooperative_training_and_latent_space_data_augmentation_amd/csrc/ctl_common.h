@@ -55,6 +55,13 @@ __device__ __forceinline__ void ctl_stagger_priority() {
         default: __builtin_amdgcn_s_setprio(3); break;
     }
 }
+// Explicit start stagger: waves sharing a SIMD start `slot * units` x 64 cycles apart (experiment hook, units = 0: off).
+__device__ __forceinline__ void ctl_stagger_sleep(int units) {
+    if (units <= 0) return;
+    const unsigned hw = __builtin_amdgcn_s_getreg((4) | (0 << 6) | ((4 - 1) << 11));
+    const int n = (int)(hw & 3u) * units;
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(16);      // 16 x 64 = 1024 cycles per iteration
+}
 
 // Workgroup barriers for the pipelined loops.  __syncthreads() is a workgroup-scope FENCE + barrier: hipcc puts
 // s_waitcnt vmcnt(0) in front of it, which drains every in-flight global load AND store of the wave (seen in the ISA; it made

@@ -175,7 +175,7 @@ struct TileWalk {
 //      BatchNorm statistics stay in registers until the block is done.
 // Weight chunks [tap][nt][64 lanes][4] go through LDS (shared by the four waves; staged once when Cin <= 16).
 template <int KS, int S, int MODE, int MT, int TW, int NT, int EPI>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ctl_conv d, const float* __restrict__ x,
+__global__ __launch_bounds__(256, (MT * NT >= 8) ? 2 : ((MT * NT >= 4) ? 3 : 4)) void conv_igemm_kernel(const ctl_conv d, const float* __restrict__ x,
                                                           const float* __restrict__ wpack,
                                                           const float* __restrict__ bias,
                                                           const float* __restrict__ pro_scale,
@@ -251,6 +251,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ctl_conv d, const
     TileWalk cur, nxt;
     cur.init(bid0, nblk, tiles_h, tiles_w);
     nxt = cur;
+    ctl_stagger_sleep(dbg >> 8);
     if (total_it > 0) {
         xs.load(rx, d, cur.n, cur.th * G::TH, cur.tw * TW, 0);
         wload(0);

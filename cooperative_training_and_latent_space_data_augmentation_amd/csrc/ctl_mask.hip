@@ -12,19 +12,21 @@
 #include "ctl_common.h"
 
 #define MB 256
-#define SCORE_SPLIT_PIX 64      // pixels per block in the channel-mode score pass
+// pixels per block in the channel-mode score pass: 64 keeps the tiny configured problem (hw = 256) spread over 64 blocks;
+// large problems use 512-pixel slabs (more bytes in flight per block, 8x fewer partial rows)
+static inline int score_split_pix(int hw) { return hw >= 4096 ? 512 : 64; }
 
 // ---- channel mode, pass 1: partial[n][split][c] = sum over the split's pixels of grad[n][pix][c]
 __global__ __launch_bounds__(MB) void score_channel_partial_kernel(const f32x4* __restrict__ grad,
                                                                     float* __restrict__ partial, int hw, int cq,
-                                                                    int splits) {
+                                                                    int splits, int split_pix) {
     __shared__ f32x4 sm[MB];
     const int n = blockIdx.y, sp = blockIdx.x;
     const int q = threadIdx.x % cq;              // MB % cq == 0 (checked on the host)
     const int prow = threadIdx.x / cq;           // pixel lane inside the block
     const int ppb = MB / cq;                     // pixels in flight per iteration
-    const int p0 = sp * SCORE_SPLIT_PIX;
-    const int p1 = min(hw, p0 + SCORE_SPLIT_PIX);
+    const int p0 = sp * split_pix;
+    const int p1 = min(hw, p0 + split_pix);
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     for (int pix = p0 + prow; pix < p1; pix += ppb) {
         const f32x4 v = grad[((int64_t)n * hw + pix) * cq + q];
@@ -112,6 +114,64 @@ __global__ __launch_bounds__(MB) void mask_apply_kernel(const f32x4* __restrict_
     }
 }
 
+// ---- long rows (L > 1024): threshold = sort(score, descending)[k] by a bitonic sort in LDS, one block per image; the apply
+// pass is then a pure stream (mask = score > thr), exactly the reference's formulation (model_util.py:231-244).
+__global__ __launch_bounds__(MB) void latent_threshold_kernel(const float* __restrict__ score, int L, int Lp2, int k_host,
+                                                               const int* __restrict__ k_dev, float* __restrict__ thr) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int n = blockIdx.x;
+    const int k = k_dev ? k_dev[0] : k_host;
+    for (int i = threadIdx.x; i < Lp2; i += MB) sm[i] = (i < L) ? score[(int64_t)n * L + i] : -INFINITY;
+    __syncthreads();
+    for (int size = 2; size <= Lp2; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int i = threadIdx.x; i < (Lp2 >> 1); i += MB) {
+                const int lo = 2 * i - (i & (stride - 1));         // index with bit `stride` cleared
+                const int hi = lo + stride;
+                const bool desc = ((lo & size) == 0);               // overall order: descending
+                const float a = sm[lo], b = sm[hi];
+                if ((a < b) == desc) { sm[lo] = b; sm[hi] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    if (threadIdx.x == 0) thr[n] = sm[k];
+}
+
+template <int MODE>
+__global__ __launch_bounds__(MB) void mask_apply_thr_kernel(const f32x4* __restrict__ code, const float* __restrict__ score,
+                                                             const float* __restrict__ soft_noise,
+                                                             const float* __restrict__ thr, f32x4* __restrict__ masked,
+                                                             float* __restrict__ mask_out, int hw, int cq, int slab_pix) {
+    extern __shared__ __attribute__((aligned(16))) float mval[];    // [c] (channel) or [slab_pix] (spatial)
+    const int c = cq * 4, n = blockIdx.y;
+    const int L = (MODE == 0) ? c : hw;
+    const float t = thr[n];
+    const int p0 = blockIdx.x * slab_pix, p1 = min(hw, p0 + slab_pix);
+    const int first = (MODE == 0) ? 0 : p0, count = (MODE == 0) ? c : (p1 - p0);
+    for (int e = threadIdx.x; e < count; e += MB) {
+        const int i = first + e;
+        float mv = 1.f;
+        if (score[(int64_t)n * L + i] > t) mv = soft_noise ? 0.5f * soft_noise[(int64_t)n * L + i] : 0.f;
+        mval[e] = mv;
+        if (MODE == 1 || blockIdx.x == 0) mask_out[(int64_t)n * L + i] = mv;
+    }
+    __syncthreads();
+    const int64_t base = ((int64_t)n * hw + p0) * cq;
+    const int quads = (p1 - p0) * cq;
+    for (int e = threadIdx.x; e < quads; e += MB) {
+        f32x4 v = code[base + e];
+        if (MODE == 0) {
+            const f32x4 m = reinterpret_cast<const f32x4*>(mval)[e % cq];
+            v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
+        } else {
+            const float m = mval[e / cq];
+            v.x *= m; v.y *= m; v.z *= m; v.w *= m;
+        }
+        masked[base + e] = v;
+    }
+}
+
 // ---- dropout2d and uniform noise from a counter hash (splitmix64): stateless, graph-replay safe given a seed buffer
 __device__ __forceinline__ float hash_uniform(uint64_t seed, uint64_t idx) {
     uint64_t z = seed + (idx + 1) * 0x9E3779B97F4A7C15ull;
@@ -158,7 +218,7 @@ static int slab_pixels(int n, int hw, int c) {
 }
 
 extern "C" size_t ctl_latent_score_ws_floats(int32_t mode, int32_t n, int32_t hw, int32_t c) {
-    return mode == 0 ? (size_t)n * ctl_cdiv(hw, SCORE_SPLIT_PIX) * c : 0;
+    return mode == 0 ? (size_t)n * ctl_cdiv(hw, score_split_pix(hw)) * c : 0;
 }
 
 extern "C" int ctl_latent_score(int32_t mode, const float* grad, float* score, float* scratch, int32_t n, int32_t hw,
@@ -168,8 +228,9 @@ extern "C" int ctl_latent_score(int32_t mode, const float* grad, float* score, f
     const int cq = c / 4;
     if (mode == 0) {
         CTL_REQUIRE(scratch, "latent_score: channel mode needs scratch");
-        const int splits = ctl_cdiv(hw, SCORE_SPLIT_PIX);
-        score_channel_partial_kernel<<<dim3(splits, n), dim3(MB), 0, s>>>((const f32x4*)grad, scratch, hw, cq, splits);
+        const int sp_pix = score_split_pix(hw);
+        const int splits = ctl_cdiv(hw, sp_pix);
+        score_channel_partial_kernel<<<dim3(splits, n), dim3(MB), 0, s>>>((const f32x4*)grad, scratch, hw, cq, splits, sp_pix);
         score_channel_finalize_kernel<<<dim3(ctl_cdiv(c, 64), n), dim3(64), 0, s>>>(scratch, score, c, splits, 1.f / (float)hw);
     } else if (mode == 1) {
         const int64_t pixels = (int64_t)n * hw;
@@ -184,9 +245,13 @@ extern "C" int ctl_latent_score(int32_t mode, const float* grad, float* score, f
     return CTL_OK;
 }
 
+extern "C" size_t ctl_latent_mask_apply_ws_floats(int32_t mode, int32_t n, int32_t hw, int32_t c) {
+    return ((mode == 0 ? c : hw) > 1024) ? (size_t)n : 0;
+}
+
 extern "C" int ctl_latent_mask_apply(int32_t mode, const float* code, const float* score, const float* soft_noise,
-                                     int32_t k_host, const int32_t* k_dev, float* masked, float* mask_out, int32_t n,
-                                     int32_t hw, int32_t c, ctl_stream stream) {
+                                     int32_t k_host, const int32_t* k_dev, float* masked, float* mask_out, float* scratch,
+                                     int32_t n, int32_t hw, int32_t c, ctl_stream stream) {
     CTL_REQUIRE(code && score && masked && mask_out && n > 0 && hw > 0 && cq_ok(c), "latent_mask_apply: bad arguments");
     const int L = mode == 0 ? c : hw;
     CTL_REQUIRE(L <= 8192, "latent_mask_apply: row length %d > 8192", L);
@@ -194,6 +259,18 @@ extern "C" int ctl_latent_mask_apply(int32_t mode, const float* code, const floa
     hipStream_t s = (hipStream_t)stream;
     const int sp = slab_pixels(n, hw, c);
     const dim3 grid(ctl_cdiv(hw, sp), n);
+    if (L > 1024) {
+        // long rows: per-image threshold by bitonic sort (caller-provided scratch holds the n thresholds), then a streaming apply
+        CTL_REQUIRE(mode == 1, "latent_mask_apply: channel rows longer than 1024 are not supported");
+        CTL_REQUIRE(scratch, "latent_mask_apply: rows longer than 1024 need ctl_latent_mask_apply_ws_floats() floats of scratch");
+        int lp2 = 1;
+        while (lp2 < L) lp2 <<= 1;
+        latent_threshold_kernel<<<dim3(n), dim3(MB), (size_t)lp2 * sizeof(float), s>>>(score, L, lp2, k_host, k_dev, scratch);
+        mask_apply_thr_kernel<1><<<grid, dim3(MB), (size_t)sp * sizeof(float), s>>>((const f32x4*)code, score, soft_noise, scratch,
+                                                                                   (f32x4*)masked, mask_out, hw, c / 4, sp);
+        CTL_LAUNCH_CHECK("latent_mask_apply(thr)");
+        return CTL_OK;
+    }
     if (mode == 0) {
         const size_t lds = (size_t)(L + c) * sizeof(float);
         mask_apply_kernel<0><<<grid, dim3(MB), lds, s>>>((const f32x4*)code, score, soft_noise, k_host, k_dev,

@@ -21,6 +21,7 @@
 //   PACK_BATCH        0 params 1 wpack 2 table                           i[0]=n_rec l[0]=max_total
 //   WGRAD_REDUCE_BATCH 0 scratch 1 grad 2 table                          i[0]=n_rec l[0]=max_elems
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "ctl_common.h"
@@ -108,10 +109,49 @@ extern "C" size_t ctl_sizeof_conv(void) { return sizeof(ctl_conv); }
 
 static_assert(sizeof(ctl_conv) == 22 * 4, "ctl_conv must be 22 32-bit words (it is embedded in ctl_op.i)");
 
-extern "C" int ctl_plan_run(const ctl_op* ops, int32_t n_ops, void* const* bases, int32_t n_bases, ctl_stream stream) {
+// Side lane: ops with i[26] == 1 (weight gradients and their batched reduction: off the critical dgrad chain) run on a
+// library-owned second stream so that their launches fill the ramp-up / tail bubbles of the main chain.  Fork = event
+// recorded on the main stream right before the side op (it then sees everything the main stream produced so far);
+// join = the main stream waits for the side stream once, at the end of the plan.  Opt-in: CTL_SIDE_STREAM=1.
+namespace {
+hipStream_t g_side = nullptr;
+std::vector<hipEvent_t> g_fork_events;
+hipEvent_t g_join_event = nullptr;
+int g_side_enabled = -1;
+}  // namespace
+
+static hipEvent_t fork_event(size_t k) {
+    while (g_fork_events.size() <= k) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+        g_fork_events.push_back(e);
+    }
+    return g_fork_events[k];
+}
+
+extern "C" int ctl_plan_run(const ctl_op* ops, int32_t n_ops, void* const* bases, int32_t n_bases, ctl_stream stream_) {
     CTL_REQUIRE(ops && bases && n_ops >= 0, "plan_run: null arguments");
+    if (g_side_enabled < 0) {
+        const char* e = getenv("CTL_SIDE_STREAM");
+        g_side_enabled = (e && atoi(e) == 1) ? 1 : 0;      // measured neutral on MI355X (the chain has no fillable bubbles): off by default
+    }
+    size_t forks = 0;
+    bool side_used = false;
     for (int32_t k = 0; k < n_ops; ++k) {
         const ctl_op& op = ops[k];
+        ctl_stream stream = stream_;
+        if (g_side_enabled && op.i[26] == 1) {
+            if (!g_side) {
+                CTL_REQUIRE(hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking) == hipSuccess &&
+                            hipEventCreateWithFlags(&g_join_event, hipEventDisableTiming) == hipSuccess,
+                            "plan_run: cannot create the side stream");
+            }
+            hipEvent_t ev = fork_event(forks++);
+            CTL_REQUIRE(ev && hipEventRecord(ev, (hipStream_t)stream_) == hipSuccess &&
+                        hipStreamWaitEvent(g_side, ev, 0) == hipSuccess, "plan_run: fork failed");
+            stream = (ctl_stream)g_side;
+            side_used = true;
+        }
         void* t[CTL_OP_MAX_T];
         for (int a = 0; a < CTL_OP_MAX_T; ++a) {
             const int s = op.slot[a];
@@ -196,6 +236,10 @@ extern "C" int ctl_plan_run(const ctl_op* ops, int32_t n_ops, void* const* bases
             ctl_set_error("plan_run: op %d (kind %d) failed: %s", k, op.kind, msg);
             return rc;
         }
+    }
+    if (side_used) {
+        CTL_REQUIRE(hipEventRecord(g_join_event, g_side) == hipSuccess &&
+                    hipStreamWaitEvent((hipStream_t)stream_, g_join_event, 0) == hipSuccess, "plan_run: join failed");
     }
     return CTL_OK;
 }

@@ -191,6 +191,7 @@ class PlanBuilder:
         words = np.frombuffer(d.tobytes(), dtype="<i4")
         op = self.op(_ffi.OP_WGRAD)
         op["i"][:22] = words
+        op["i"][26] = 1                    # side lane: off the critical dgrad chain (see ctl_plan.cpp)
         for idx, ref in enumerate([x.ref, pro[0] if pro else None, pro[1] if pro else None, dy.ref, wref, bref]):
             self.set_t(op, idx, ref)
         assert dw_ref[0] == S_GRAD and (dbias_ref is None or dbias_ref[0] == S_GRAD)
@@ -206,6 +207,7 @@ class PlanBuilder:
         assert self.table is None
         self.table = np.asarray(self.reduce_recs, dtype=np.int64)
         op = self.op(_ffi.OP_WGRAD_REDUCE_BATCH)
+        op["i"][26] = 1
         op["i"][0] = len(self.reduce_recs)
         op["l"][0] = max(-(-((r[5] & 0xff) * r[6] * r[7] + r[7]) // (64 if r[4] <= 64 else 8)) for r in self.reduce_recs)
         self.set_t(op, 0, (S_BSCR, 0))

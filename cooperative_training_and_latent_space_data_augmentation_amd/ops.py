@@ -193,8 +193,10 @@ def latent_mask_apply(code: torch.Tensor, score: torch.Tensor, mode: int, k, sof
     k_host = 0 if k_dev is not None else int(k)
     if soft_noise is not None:
         soft_noise = soft_noise.reshape(n, L).float().contiguous()
+    ws = lib.ctl_latent_mask_apply_ws_floats(mode, n, h * w, c)
+    scratch = torch.empty(ws, dtype=torch.float32, device=code.device) if ws else None
     check(lib.ctl_latent_mask_apply(mode, ptr(code), ptr(score), ptr(soft_noise), k_host, ptr(k_dev), ptr(masked), ptr(mask),
-                                    n, h * w, c, stream_ptr()), "ctl_latent_mask_apply")
+                                    ptr(scratch), n, h * w, c, stream_ptr()), "ctl_latent_mask_apply")
     return masked, (mask.view(n, c, 1, 1) if mode == 0 else mask.view(n, 1, h, w))
 
 

@@ -163,13 +163,15 @@ int ctl_argmax_c(const float* logit, uint8_t* out, int64_t pixels, int32_t c, ct
  * ctl_latent_mask_apply: entry i of row n is masked iff
  * #{j : score[n,j] >= score[n,i]} <= k  (== "score > sort(desc)[k]", strict, util.py:231-244);
  * mask value = soft_noise ? 0.5*soft_noise[n,i] : 0; kept = 1.  k is read from k_dev[0] if k_dev != NULL (graph replay)
- * else from k_host.  masked = code * mask (broadcast), mask_out [n,L]. */
+ * else from k_host.  masked = code * mask (broadcast), mask_out [n,L].  Rows up to 1024 entries are ranked inside the apply
+ * kernel; longer rows (spatial mode on large latents) take the threshold from a per-image bitonic sort (scratch). */
 size_t ctl_latent_score_ws_floats(int32_t mode, int32_t n, int32_t hw, int32_t c);
 int ctl_latent_score(int32_t mode, const float* grad, float* score, float* scratch, int32_t n, int32_t hw, int32_t c,
                      ctl_stream stream);
+size_t ctl_latent_mask_apply_ws_floats(int32_t mode, int32_t n, int32_t hw, int32_t c);   /* 0 unless the row is > 1024 long */
 int ctl_latent_mask_apply(int32_t mode, const float* code, const float* score, const float* soft_noise,
-                          int32_t k_host, const int32_t* k_dev, float* masked, float* mask_out, int32_t n, int32_t hw,
-                          int32_t c, ctl_stream stream);
+                          int32_t k_host, const int32_t* k_dev, float* masked, float* mask_out, float* scratch, int32_t n,
+                          int32_t hw, int32_t c, ctl_stream stream);
 /* F.dropout2d(z,p) (model.py:333): out = z * keep[n,c] / (1-p).  keep != NULL: injected {0,1} floats; else drawn on
  * device from a counter hash of (seed, n*c index) and written to keep_out. */
 int ctl_dropout2d(const float* z, const float* keep, uint64_t seed, float p, float* out, float* keep_out, int32_t n,
@@ -195,7 +197,8 @@ enum ctl_op_kind {
 #define CTL_OP_MAX_T 12
 typedef struct ctl_op {
     int32_t kind;
-    int32_t i[27];                    /* CONV/WGRAD/WGRAD_REDUCE: i[0..21] = ctl_conv as int32 words, i[23] = accumulate; others: see ctl_plan.cpp */
+    int32_t i[27];                    /* CONV/WGRAD/WGRAD_REDUCE: i[0..21] = ctl_conv as int32 words, i[23] = accumulate; others: see
+                                         ctl_plan.cpp; i[26] = lane (0 main stream, 1 side stream: weight-gradient work) */
     float   f[4];
     int32_t slot[CTL_OP_MAX_T];       /* -1 = NULL */
     int64_t off[CTL_OP_MAX_T];

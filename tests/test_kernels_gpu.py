@@ -317,7 +317,7 @@ def test_adam_matches_torch():
         assert float((pd.cpu() - ref.detach()).abs().max()) < 2e-7
 
 
-@pytest.mark.parametrize("n,c,h,w", [(16, 128, 16, 16), (2, 128, 4, 4), (3, 64, 6, 5), (4, 256, 32, 32)])
+@pytest.mark.parametrize("n,c,h,w", [(16, 128, 16, 16), (2, 128, 4, 4), (3, 64, 6, 5), (4, 256, 32, 32), (3, 32, 48, 40)])
 def test_latent_mask_kernels(n, c, h, w):
     g = torch.Generator().manual_seed(c + h)
     grad = torch.randn(n, c, h, w, generator=g)
