@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--prof-filter", default=DOMINANT)
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even for a world of 1")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -104,9 +105,12 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     import torch.distributed as dist
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=device)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
 
     from cooperative_training_and_latent_space_data_augmentation_amd import _ffi
     from cooperative_training_and_latent_space_data_augmentation_amd.solver import AdvancedTripletReconSegmentationModel
@@ -115,7 +119,7 @@ def main():
     torch.manual_seed(0)                                 # identical initial weights on every rank
     solver = AdvancedTripletReconSegmentationModel(network_type="FCN_16_standard", image_ch=1, num_classes=4,
                                                    learning_rate=1e-4, use_gpu=True)
-    dp = DataParallel(solver) if world > 1 else None
+    dp = DataParallel(solver) if use_dist else None
     clean, label, noisy, host_batch = synthetic(args.batch, args.size, args.size, 1000 + rank, device)
     hook = dp.sync_gradients if dp else None
 
@@ -124,7 +128,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -139,7 +143,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     prof = _ffi.prof_stop() if rank == 0 else {}
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -180,7 +184,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(host_batch, args.cpu_threads or min(32, os.cpu_count()))
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
