@@ -194,6 +194,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 8) ? 2 : ((MT * NT >= 4) ? 3 : 4))
     float* wt = xt + XT_ALLOC;
     constexpr int WU = TAPS * NT * 64, NW = (WU + 255) / 256;
 
+    if (dbg & 8) return;                       // ablation: pure launch + dispatch cost
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -259,6 +260,11 @@ __global__ __launch_bounds__(256, (MT * NT >= 8) ? 2 : ((MT * NT >= 4) ? 3 : 4))
         wstore();
     }
     __syncthreads();
+    if (dbg & 16) return;                      // ablation: + init + first-tile staging
+    if (dbg & 32) {                            // ablation: + the loop skeleton (barriers, tile walk), no stats epilogue
+        for (int it = 0; it < total_it; ++it) { ctl_barrier_lds_reads_done(); ctl_barrier_lds_writes_done(); }
+        return;
+    }
 
     f32x4 acc[MT][NT];
     for (int it = 0, g = 0; it < total_it; ++it) {
@@ -290,7 +296,9 @@ __global__ __launch_bounds__(256, (MT * NT >= 8) ? 2 : ((MT * NT >= 4) ? 3 : 4))
                 const int tr = mt / (TW / 16), tc = (mt % (TW / 16)) * 16;
                 const int r = tr * S + kh;
                 const int c = (tc + p) * S + kw;
-                const f32x4 xf = *reinterpret_cast<const f32x4*>(xt + (r * G::IWP + G::ldscol(c)) * 16 + q * 4);
+                f32x4 xf;
+                if ((dbg & 64) && m > 0) xf = wf[0];      // ablation: no LDS read for M-tiles 1.. (wrong results, timing only)
+                else xf = *reinterpret_cast<const f32x4*>(xt + (r * G::IWP + G::ldscol(c)) * 16 + q * 4);
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t].x, xf.x, acc[m][t], 0, 0, 0);
@@ -301,12 +309,12 @@ __global__ __launch_bounds__(256, (MT * NT >= 8) ? 2 : ((MT * NT >= 4) ? 3 : 4))
             }
         }
 
-        ctl_barrier_lds_reads_done();    // every wave is done reading this step's LDS images
+        if (!(dbg & 128)) ctl_barrier_lds_reads_done();    // every wave is done reading this step's LDS images
         if (has_next && !(dbg & 2)) {    // refill LDS from the prefetched registers
             xs.store(xt, d, g2, pro_scale, pro_shift);
             if (new_w) wstore();
         }
-        ctl_barrier_lds_writes_done();
+        if (!(dbg & 128)) ctl_barrier_lds_writes_done();
 
         if (g == G_chunks - 1 && !(dbg & 4)) {
             // ---------------- epilogue: lane (p,q) holds channels co0..co0+3 of pixel p of each M-tile.  Buffer stores with

@@ -1,0 +1,6 @@
+for dbg in 8 16 32 7 0; do echo -n "dbg=$dbg : "; CTL_DBG=$dbg python tools/bench_conv.py child fwd 2>/dev/null | python -c "
+import sys,json
+for l in sys.stdin:
+    if l.startswith('RESULT '):
+        d=json.loads(l[7:]); print({k:d[k][0] for k in ('c16-16@256','c64-64@64','c128-128@32','c128-128@16','1x1 16-16@256')})
+"; done

@@ -1,0 +1,6 @@
+for z in "" 1; do for dbg in 0 6; do echo -n "zero=$z dbg=$dbg: "; CTL_ZERO_DATA=$z CTL_DBG=$dbg python tools/bench_conv.py child fwd 2>/dev/null | python -c "
+import sys,json
+for l in sys.stdin:
+    if l.startswith('RESULT '):
+        d=json.loads(l[7:]); print({k:d[k][0] for k in ('c16-16@256','c32-32@128','c64-64@64','c128-128@32','c128-128@16')})
+"; done; done

@@ -21,6 +21,8 @@ def child(kind):
         ho = (hv + 1) // 2 if stride == 2 else hv
         x = torch.randn(n, cin, h, h, device="cuda").contiguous(memory_format=torch.channels_last)
         w = torch.randn(cout, cin, ks, ks, device="cuda") * 0.1
+        if os.environ.get("CTL_ZERO_DATA"):      # power/DVFS probe: all-zero operands
+            x.zero_(); w.zero_()
         d = _ffi.conv_desc(n=n, hin=h, win=h, cin=cin, hout=ho, wout=ho, cout=cout, ks=ks, stride=stride, in_mode=mode,
                            epi_flags=_ffi.EPI_BIAS | (_ffi.EPI_STATS if kind == "fwd" else 0))
         b = torch.zeros(cout, device="cuda")
