@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libctl_hip.so")
+LIB_PATH = os.environ.get("CTL_HIP_LIB") or os.path.join(_HERE, "csrc", "libctl_hip.so")   # override: A/B builds of the kernels
 
 # enums of ctl_hip.h
 IN_PLAIN, IN_UP2, IN_ZINS2 = 0, 1, 2

@@ -16,6 +16,8 @@
 // so the same holds.  BatchNorm-apply + LeakyReLU of the producer layer is applied once per element while staging.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "ctl_common.h"
 
 template <int KS, int S, int MT, int TW>
@@ -27,7 +29,8 @@ struct Geom {
     static constexpr int IW = (TW - 1) * S + KS;
     static constexpr int IWH = (IW + 1) / 2;
     static constexpr int IWP = (S == 2) ? 2 * IWH : IW;
-    static constexpr int XT_FLOATS = IH * IWP * 16;
+    static constexpr int XT_IMAGE = IH * IWP * 16;
+    static constexpr int XT_FLOATS = XT_IMAGE + 4;   // + one 16-byte dump slot for the staging units past the tile
     static constexpr int PAD = (KS == 3) ? 1 : 0;
     __device__ static __forceinline__ int ldscol(int c) { return (S == 2) ? ((c & 1) * IWH + (c >> 1)) : c; }
 };
@@ -52,6 +55,18 @@ __device__ __forceinline__ void ctl_bstore4(__amdgpu_buffer_rsrc_t r, int voff, 
 __device__ __forceinline__ void ctl_bstore1(__amdgpu_buffer_rsrc_t r, int voff, float v) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), r, voff, 0, 0);
 }
+// Load with a wave-uniform byte offset in an SGPR: per-thread offsets stay loop-invariant VGPRs, the tile origin costs no VALU.
+// LOADS ONLY.  A buffer_store_dwordx4 with an SGPR soffset followed directly by a VALU write of its data VGPRs stores
+// garbage in the late-read lanes on gfx950 (measured: lanes 12-15 of every 16, second dword), and the compiler inserts the
+// required wait state only when soffset is NOT a register -> stores always carry the full offset in the VGPR.
+__device__ __forceinline__ f32x4 ctl_bload4s(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+// LeakyReLU for 0 <= slope <= 1 (checked on the host) as max(v, v*slope): two VALU ops, no compare+select
+__device__ __forceinline__ f32x4 ctl_leaky01(f32x4 v, float slope) {
+    const f32x4 m = v * slope;
+    return f32x4{fmaxf(v.x, m.x), fmaxf(v.y, m.y), fmaxf(v.z, m.z), fmaxf(v.w, m.w)};
+}
 
 // Staging of one 16-channel chunk of the (virtual) input tile into LDS, with the BN+LeakyReLU prologue.  Everything that
 // depends only on the thread (tile-relative coordinates, source byte offset, LDS offset) is computed ONCE (init); per tile a
@@ -62,11 +77,13 @@ struct XStage {
     using G = Geom<KS, S, MT, TW>;
     static constexpr int UNITS = G::IH * G::IW * 4;
     static constexpr int NU = (UNITS + 255) / 256;
+    static constexpr int PADH = (G::PAD + 1) >> 1;   // source-space padding of the x2 modes
     int rel[NU];        // byte offset of the unit relative to the tile's source origin
     int rc[NU];         // r | c << 16 (tile-relative virtual coordinates); 0x7fff7fff for the units past the tile
-    int lds[NU];        // LDS float offset, -1 for the units past the tile
+    int lds[NU];        // LDS float offset; the units past the tile write a dump slot behind the image
     f32x4 v[NU];
     unsigned vmask;     // bit i: unit i of the tile held in v[] lies inside the image (gets the prologue)
+    bool all_in;        // wave-uniform: every unit of the tile held in v[] is inside the image and the channel range
 
     __device__ __forceinline__ void init(const ctl_conv& d) {
         const int tid = threadIdx.x, cq = tid & 3;
@@ -78,23 +95,39 @@ struct XStage {
             const int c = pix - r * G::IW;
             const bool in = u < UNITS;
             // source = virtual for plain inputs; for x2 nearest / zero-insert inputs the tile origin is even, so
-            // (origin - PAD + r) >> 1 = origin/2 + ((r - PAD) >> 1)
-            const int rr = (MODE == CTL_IN_PLAIN) ? r : ((r - G::PAD) >> 1);
-            const int cc = (MODE == CTL_IN_PLAIN) ? c : ((c - G::PAD) >> 1);
-            rel[i] = ((rr * d.win + cc) * d.cin + cq * 4) * 4;
+            // (origin - PAD + r) >> 1 = origin/2 + ((r - PAD) >> 1); the source origin is moved up/left by PADH so that
+            // the per-thread offsets are never negative (they are unsigned voffsets next to a scalar tile offset)
+            const int rr = (MODE == CTL_IN_PLAIN) ? r : (((r - G::PAD) >> 1) + PADH);
+            const int cc = (MODE == CTL_IN_PLAIN) ? c : (((c - G::PAD) >> 1) + PADH);
+            rel[i] = in ? ((rr * d.win + cc) * d.cin + cq * 4) * 4 : CTL_OOB;
             rc[i] = in ? (r | (c << 16)) : 0x7fff7fff;
-            lds[i] = in ? ((r * G::IWP + G::ldscol(c)) * 16 + cq * 4) : -1;
+            lds[i] = in ? ((r * G::IWP + G::ldscol(c)) * 16 + cq * 4) : G::XT_IMAGE;
         }
         vmask = 0;
+        all_in = false;
     }
 
     __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rx, const ctl_conv& d, int n, int ho0, int wo0, int g) {
         const int vh0 = ho0 * S - G::PAD, vw0 = wo0 * S - G::PAD;
         const unsigned hv = (MODE == CTL_IN_PLAIN) ? d.hin : 2 * d.hin;
         const unsigned wv = (MODE == CTL_IN_PLAIN) ? d.win : 2 * d.win;
-        const int oh = (MODE == CTL_IN_PLAIN) ? vh0 : (ho0 >> 1);
-        const int ow = (MODE == CTL_IN_PLAIN) ? vw0 : (wo0 >> 1);
+        const int oh = (MODE == CTL_IN_PLAIN) ? vh0 : ((ho0 >> 1) - PADH);
+        const int ow = (MODE == CTL_IN_PLAIN) ? vw0 : ((wo0 >> 1) - PADH);
         const int tb = (((n * d.hin + oh) * d.win + ow) * d.cin + g * 16) * 4;      // uniform; may be negative at the border
+        // interior tile (most of them): every unit is in range -> the tile origin goes into the scalar offset of the buffer
+        // loads and the per-thread offsets are the loop-invariant rel[]: no VALU at all (fp32 MFMA shares the VALU issue
+        // port on this part, so every VALU instruction in the loop is time taken from the matrix work)
+#ifdef CTL_NO_INTERIOR
+        all_in = false;
+#else
+        all_in = MODE != CTL_IN_ZINS2 && vh0 >= 0 && vw0 >= 0 && vh0 + G::IH <= (int)hv && vw0 + G::IW <= (int)wv &&
+                 g * 16 + 16 <= d.cin;
+#endif
+        if (all_in) {
+#pragma unroll
+            for (int i = 0; i < NU; ++i) v[i] = ctl_bload4s(rx, rel[i], tb);
+            return;
+        }
         const bool chan_ok = g * 16 + (threadIdx.x & 3) * 4 < d.cin;
         unsigned m = 0;
         int vo[NU];
@@ -118,10 +151,14 @@ struct XStage {
 
     __device__ __forceinline__ void store(float* __restrict__ xt, const ctl_conv& d, int g,
                                           const float* __restrict__ pro_scale, const float* __restrict__ pro_shift) {
+        if (!d.pro_affine) {      // out-of-range units were loaded as hardware zeros: nothing to compute
+#pragma unroll
+            for (int i = 0; i < NU; ++i) *reinterpret_cast<f32x4*>(xt + lds[i]) = v[i];
+            return;
+        }
         const int cb = g * 16 + (threadIdx.x & 3) * 4;
-        const bool pro = d.pro_affine != 0;
         f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-        if (pro && cb < d.cin) {
+        if (cb < d.cin) {
             if (d.cin >= 4) {
                 sc = *reinterpret_cast<const f32x4*>(pro_scale + cb);
                 sh = *reinterpret_cast<const f32x4*>(pro_shift + cb);
@@ -131,18 +168,17 @@ struct XStage {
             }
         }
         const float slope = d.pro_slope;
+        if (all_in) {
+#pragma unroll
+            for (int i = 0; i < NU; ++i) *reinterpret_cast<f32x4*>(xt + lds[i]) = ctl_leaky01(v[i] * sc + sh, slope);
+            return;
+        }
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < NU; ++i) {
-            f32x4 t = v[i];
-            if (pro && ((vmask >> i) & 1u)) {          // padding / channel-pad lanes hold hardware zeros: no prologue
-                t.x = ctl_leaky(t.x * sc.x + sh.x, slope);
-                if (d.cin >= 4) {
-                    t.y = ctl_leaky(t.y * sc.y + sh.y, slope);
-                    t.z = ctl_leaky(t.z * sc.z + sh.z, slope);
-                    t.w = ctl_leaky(t.w * sc.w + sh.w, slope);
-                }
-            }
-            if (lds[i] >= 0) *reinterpret_cast<f32x4*>(xt + lds[i]) = t;
+            const f32x4 t = ctl_leaky01(v[i] * sc + sh, slope);
+            // padding / channel-pad lanes hold hardware zeros and must stay zero; units past the tile go to the dump slot
+            *reinterpret_cast<f32x4*>(xt + lds[i]) = ((vmask >> i) & 1u) ? t : zero;
         }
     }
 };
@@ -174,8 +210,45 @@ struct TileWalk {
 //   4. (last chunk of a tile) epilogue: bias / residual / activation, buffer stores that are never waited for in the loop;
 //      BatchNorm statistics stay in registers until the block is done.
 // Weight chunks [tap][nt][64 lanes][4] go through LDS (shared by the four waves; staged once when Cin <= 16).
+// Phase timers of the forward kernel (variant builds only: tools/build_variant.sh tm "-DCTL_TIMING"; read with
+// ctl_debug_timing).  Sums s_memtime deltas over every wave: [0] prefetch issue, [1] MFMA loop, [2] barrier after the
+// reads, [3] staging (vmcnt wait + prologue + ds_write), [4] barrier after the writes, [5] epilogue, [6] steps, [7] setup.
+#ifdef CTL_TIMING
+#define CTL_TM_WAVES 65536
+__device__ unsigned long long ctl_tm[CTL_TM_WAVES][10];      // one slot per wave: no atomics, the host sums
+#define TM_DECL unsigned long long tm_prev = __builtin_amdgcn_s_memtime(), tm_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; \
+                const unsigned long long tm_t0 = tm_prev, tm_r0 = __builtin_amdgcn_s_memrealtime();
+#define TM(i) { const unsigned long long tm_now = __builtin_amdgcn_s_memtime(); tm_acc[i] += tm_now - tm_prev; tm_prev = tm_now; }
+#define TM_COUNT(i) { tm_acc[i] += 1; }
+#define TM_FLUSH { const unsigned w_ = ((blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 4 + (threadIdx.x >> 6)) % CTL_TM_WAVES; \
+                   tm_acc[8] = __builtin_amdgcn_s_memtime() - tm_t0; tm_acc[9] = __builtin_amdgcn_s_memrealtime() - tm_r0; \
+                   if ((threadIdx.x & 63) == 0) { _Pragma("unroll") for (int i_ = 0; i_ < 10; ++i_) ctl_tm[w_][i_] += tm_acc[i_]; } }
+extern "C" int ctl_debug_timing(unsigned long long* out8) {
+    static unsigned long long host[CTL_TM_WAVES][10];       // out8 holds 10 values: [8] s_memtime span, [9] s_memrealtime span (100 MHz)
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(ctl_tm), sizeof(host)) != hipSuccess) return -1;
+    for (int i = 0; i < 12; ++i) out8[i] = 0;       // [10] max span over waves, [11] number of waves that ran
+    for (int w = 0; w < CTL_TM_WAVES; ++w) {
+        for (int i = 0; i < 10; ++i) out8[i] += host[w][i];
+        if (host[w][8] > out8[10]) out8[10] = host[w][8];
+        if (host[w][8]) out8[11] += 1;
+    }
+    for (int w = 0; w < CTL_TM_WAVES; ++w) for (int i = 0; i < 10; ++i) host[w][i] = 0;
+    return hipMemcpyToSymbol(HIP_SYMBOL(ctl_tm), host, sizeof(host)) == hipSuccess ? 0 : -1;
+}
+#else
+#define TM_DECL
+#define TM(i)
+#define TM_COUNT(i)
+#define TM_FLUSH
+#endif
+#ifndef CTL_LB_MID
+#define CTL_LB_MID 3
+#endif
+#ifndef CTL_LB_SMALL
+#define CTL_LB_SMALL 4
+#endif
 template <int KS, int S, int MODE, int MT, int TW, int NT, int EPI>
-__global__ __launch_bounds__(256, (MT * NT >= 8) ? 2 : ((MT * NT >= 4) ? 3 : 4)) void conv_igemm_kernel(const ctl_conv d, const float* __restrict__ x,
+__global__ __launch_bounds__(256, (MT * NT >= 8) ? 2 : ((MT * NT >= 4) ? CTL_LB_MID : CTL_LB_SMALL)) void conv_igemm_kernel(const ctl_conv d, const float* __restrict__ x,
                                                           const float* __restrict__ wpack,
                                                           const float* __restrict__ bias,
                                                           const float* __restrict__ pro_scale,
@@ -184,7 +257,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 8) ? 2 : ((MT * NT >= 4) ? 3 : 4))
                                                           const float* __restrict__ res_scale,
                                                           const float* __restrict__ res_shift, float* __restrict__ y,
                                                           float* __restrict__ stats_partial, int tiles_h, int tiles_w,
-                                                          int G_chunks, int64_t wpack_sub_stride, int ntiles, int dbg) {
+                                                          int G_chunks, int64_t wpack_sub_stride, int ntiles) {
     using G = Geom<KS, S, MT, TW>;
     constexpr int TAPS = KS * KS;
     constexpr int RED_FLOATS = 4 * NT * 16 * 2;
@@ -194,7 +267,6 @@ __global__ __launch_bounds__(256, (MT * NT >= 8) ? 2 : ((MT * NT >= 4) ? 3 : 4))
     float* wt = xt + XT_ALLOC;
     constexpr int WU = TAPS * NT * 64, NW = (WU + 255) / 256;
 
-    if (dbg & 8) return;                       // ablation: pure launch + dispatch cost
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -217,29 +289,47 @@ __global__ __launch_bounds__(256, (MT * NT >= 8) ? 2 : ((MT * NT >= 4) ? 3 : 4))
 #pragma unroll
     for (int t = 0; t < NT; ++t) ssum[t] = ssq[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // M-tile m of this wave: tile row tr = wave*(MT/TWT) + m/TWT, first column tc = (m % TWT) * 16
+    constexpr int TWT = TW / 16;
+    static_assert(MT % TWT == 0, "a wave's M-tiles must cover whole tile rows");
+    const int wrow = wave * (MT / TWT);
     // per-thread constants of the epilogue: byte offset of this lane's 4 channels of M-tile m relative to the tile's output origin
-    int yrel[MT], wcol[MT];
+    int yrel[MT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        const int mt = wave * MT + m;
-        const int tr = mt / (TW / 16), tc = (mt % (TW / 16)) * 16;
-        wcol[m] = tc + p;
-        yrel[m] = ((tr * d.out_sy * d.out_w + (tc + p) * d.out_sx) * d.cout + q * 4) * 4;
+    for (int m = 0; m < MT; ++m)
+        yrel[m] = (((wrow + m / TWT) * d.out_sy * d.out_w + ((m % TWT) * 16 + p) * d.out_sx) * d.cout + q * 4) * 4;
+    // bias of this lane's 4 output channels: the accumulators start from it (no add in the epilogue)
+    f32x4 bias4[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int co0 = (cot0 + t) * 16 + q * 4;
+        f32x4 b = {0.f, 0.f, 0.f, 0.f};
+        if (flags & CTL_EPI_BIAS) {
+            if (d.cout >= 4) b = *reinterpret_cast<const f32x4*>(bias + (co0 < d.cout ? co0 : 0));
+            else b.x = bias[0];
+        }
+        bias4[t] = b;
     }
+    // LDS operand addresses: one per-thread base; (M-tile, tap) offsets are compile-time immediates of the ds_read
+    const float* xrd = xt + ((wrow * S) * G::IWP + p) * 16 + q * 4;
+    const float* wrd = wt + lane * 4;
 
     XStage<KS, S, MODE, MT, TW> xs;
     xs.init(d);
+    // weight chunk g: [tap][t][64 lanes][4] floats; per-thread byte offsets are loop-invariant, the chunk goes in the scalar offset
+    const __amdgpu_buffer_rsrc_t rw = ctl_rsrc(wp, (int64_t)ctl_cdiv(d.cout, 16) * TAPS * G_chunks * 1024);
     f32x4 wv[NW];
+    int wrel[NW];
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        const int u = tid + i * 256;
+        const int tt = u >> 6, l = u & 63;           // tt = tap * NT + t
+        const int tap = tt / NT, t = tt - tap * NT;
+        wrel[i] = (u < WU) ? ((((cot0 + t) * TAPS + tap) * G_chunks) * 64 + l) * 16 : CTL_OOB;
+    }
     auto wload = [&](int g) {
 #pragma unroll
-        for (int i = 0; i < NW; ++i) {
-            const int u = tid + i * 256;
-            const int tt = u >> 6, l = u & 63;           // tt = tap * NT + t
-            const int tap = tt / NT, t = tt - tap * NT;
-            if (u < WU)
-                wv[i] = *reinterpret_cast<const f32x4*>(
-                    wp + ((((int64_t)(cot0 + t) * TAPS + tap) * G_chunks + g) * 64 + l) * 4);
-        }
+        for (int i = 0; i < NW; ++i) wv[i] = ctl_bload4s(rw, wrel[i], g * 1024);
     };
     auto wstore = [&]() {
 #pragma unroll
@@ -252,7 +342,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 8) ? 2 : ((MT * NT >= 4) ? 3 : 4))
     TileWalk cur, nxt;
     cur.init(bid0, nblk, tiles_h, tiles_w);
     nxt = cur;
-    ctl_stagger_sleep(dbg >> 8);
+    TM_DECL
     if (total_it > 0) {
         xs.load(rx, d, cur.n, cur.th * G::TH, cur.tw * TW, 0);
         wload(0);
@@ -260,140 +350,155 @@ __global__ __launch_bounds__(256, (MT * NT >= 8) ? 2 : ((MT * NT >= 4) ? 3 : 4))
         wstore();
     }
     __syncthreads();
-    if (dbg & 16) return;                      // ablation: + init + first-tile staging
-    if (dbg & 32) {                            // ablation: + the loop skeleton (barriers, tile walk), no stats epilogue
-        for (int it = 0; it < total_it; ++it) { ctl_barrier_lds_reads_done(); ctl_barrier_lds_writes_done(); }
-        return;
-    }
 
+    TM(7)
     f32x4 acc[MT][NT];
     for (int it = 0, g = 0; it < total_it; ++it) {
+        TM_COUNT(6)
         const int n = cur.n, ho0 = cur.th * G::TH, wo0 = cur.tw * TW;
         const bool has_next = it + 1 < total_it;
         const int g2 = (g + 1 == G_chunks) ? 0 : g + 1;
         const bool new_w = has_next && G_chunks > 1;
         if (g2 == 0) nxt.next();
-        if (has_next && !(dbg & 2)) {
+        if (has_next) {
             xs.load(rx, d, nxt.n, nxt.th * G::TH, nxt.tw * TW, g2);
             if (new_w) wload(g2);
         }
+        TM(0)
         if (g == 0) {
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
-                for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int t = 0; t < NT; ++t) acc[m][t] = bias4[t];
         }
-        if (!(dbg & 1))
+        {   // operands of tap+1 are read from LDS while the MFMAs of tap run (explicit double buffer; the sched_barriers keep
+            // the scheduler from sinking the read-ahead back down to its uses)
+            f32x4 wf[2][NT], xf[2][MT];
+            auto lds_operands = [&](int tap, int b) {
+                const int kh = tap / KS, kw = tap % KS;
+                const int kcol = (S == 2) ? ((kw & 1) * G::IWH + (kw >> 1)) : kw;
 #pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap) {
-            const int kh = tap / KS, kw = tap % KS;
-            f32x4 wf[NT];
+                for (int t = 0; t < NT; ++t) wf[b][t] = *reinterpret_cast<const f32x4*>(wrd + (tap * NT + t) * 256);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) wf[t] = *reinterpret_cast<const f32x4*>(wt + ((tap * NT + t) * 64 + lane) * 4);
+                for (int m = 0; m < MT; ++m)
+                    xf[b][m] = *reinterpret_cast<const f32x4*>(xrd + (((m / TWT) * S + kh) * G::IWP + (m % TWT) * 16 + kcol) * 16);
+            };
+            lds_operands(0, 0);
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const int mt = wave * MT + m;
-                const int tr = mt / (TW / 16), tc = (mt % (TW / 16)) * 16;
-                const int r = tr * S + kh;
-                const int c = (tc + p) * S + kw;
-                f32x4 xf;
-                if ((dbg & 64) && m > 0) xf = wf[0];      // ablation: no LDS read for M-tiles 1.. (wrong results, timing only)
-                else xf = *reinterpret_cast<const f32x4*>(xt + (r * G::IWP + G::ldscol(c)) * 16 + q * 4);
+            for (int tap = 0; tap < TAPS; ++tap) {
+                const int b = tap & 1;
+                if (tap + 1 < TAPS) lds_operands(tap + 1, b ^ 1);
+#ifndef CTL_NO_SCHED_BARRIER
+                __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t].x, xf.x, acc[m][t], 0, 0, 0);
-                    acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t].y, xf.y, acc[m][t], 0, 0, 0);
-                    acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t].z, xf.z, acc[m][t], 0, 0, 0);
-                    acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t].w, xf.w, acc[m][t], 0, 0, 0);
+                for (int m = 0; m < MT; ++m) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[b][t].x, xf[b][m].x, acc[m][t], 0, 0, 0);
+                        acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[b][t].y, xf[b][m].y, acc[m][t], 0, 0, 0);
+                        acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[b][t].z, xf[b][m].z, acc[m][t], 0, 0, 0);
+                        acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[b][t].w, xf[b][m].w, acc[m][t], 0, 0, 0);
+                    }
                 }
+#ifndef CTL_NO_SCHED_BARRIER
+                __builtin_amdgcn_sched_barrier(0);
+#endif
             }
         }
 
-        if (!(dbg & 128)) ctl_barrier_lds_reads_done();    // every wave is done reading this step's LDS images
-        if (has_next && !(dbg & 2)) {    // refill LDS from the prefetched registers
+        TM(1)
+        ctl_barrier_lds_reads_done();    // every wave is done reading this step's LDS images
+        TM(2)
+        if (has_next) {    // refill LDS from the prefetched registers
             xs.store(xt, d, g2, pro_scale, pro_shift);
             if (new_w) wstore();
         }
-        if (!(dbg & 128)) ctl_barrier_lds_writes_done();
+        TM(3)
+        ctl_barrier_lds_writes_done();
+        TM(4)
 
-        if (g == G_chunks - 1 && !(dbg & 4)) {
+        if (g == G_chunks - 1) {
             // ---------------- epilogue: lane (p,q) holds channels co0..co0+3 of pixel p of each M-tile.  Buffer stores with
-            // hardware bounds checks: ragged pixels / padded channels get CTL_OOB and are dropped; nothing here is waited for.
+            // hardware bounds checks; nothing here is waited for in the loop.  Whole tiles with whole channel tiles (FULL) put
+            // the tile origin into the scalar offset and skip every mask; ragged ones redirect dropped lanes to CTL_OOB.
             const int ybase = (((n * d.out_h + ho0 * d.out_sy + oy0) * d.out_w + wo0 * d.out_sx + ox0) * d.cout + cot0 * 16) * 4;
-            bool pv[MT];
+#ifdef CTL_NO_FULL_EPI
+            const bool full = false;
+#else
+            const bool full = ho0 + G::TH <= d.hout && wo0 + TW <= d.wout && (cot0 + NT) * 16 <= d.cout;
+#endif
+            auto epilogue = [&](auto full_tag) {
+                constexpr bool FULL = decltype(full_tag)::value;
+                bool pv[MT];
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const int tr = (wave * MT + m) / (TW / 16);
-                pv[m] = (ho0 + tr < d.hout) && (wo0 + wcol[m] < d.wout);
-            }
-            f32x4 rv[EPI ? MT : 1][EPI ? NT : 1], ov[EPI ? MT : 1][EPI ? NT : 1];
-            if (EPI) {
+                for (int m = 0; m < MT; ++m)
+                    pv[m] = FULL || ((ho0 + wrow + m / TWT < d.hout) && (wo0 + (m % TWT) * 16 + p < d.wout));
+                f32x4 rv[EPI ? MT : 1][EPI ? NT : 1], ov[EPI ? MT : 1][EPI ? NT : 1];
+                if (EPI) {
 #pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const bool cok = (cot0 + t) * 16 + q * 4 < d.cout;
+                    for (int t = 0; t < NT; ++t) {
+                        const bool cok = FULL || (cot0 + t) * 16 + q * 4 < d.cout;
 #pragma unroll
-                    for (int m = 0; m < MT; ++m) {
-                        const int vo = (pv[m] && cok) ? (ybase + yrel[m] + t * 64) : CTL_OOB;
-                        rv[m][t] = ov[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                        if (d.cout >= 4) {
-                            if (flags & CTL_EPI_RES) rv[m][t] = ctl_bload4(rres, vo);
-                            if (flags & CTL_EPI_ACCUM) ov[m][t] = ctl_bload4(ry, vo);
-                        } else {
-                            if (flags & CTL_EPI_RES) rv[m][t].x = ctl_bload1(rres, vo);
-                            if (flags & CTL_EPI_ACCUM) ov[m][t].x = ctl_bload1(ry, vo);
+                        for (int m = 0; m < MT; ++m) {
+                            const int vo = FULL ? (yrel[m] + t * 64) : ((pv[m] && cok) ? (ybase + yrel[m] + t * 64) : CTL_OOB);
+                            const int so = FULL ? ybase : 0;
+                            rv[m][t] = ov[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                            if (d.cout >= 4) {
+                                if (flags & CTL_EPI_RES) rv[m][t] = ctl_bload4s(rres, vo, so);
+                                if (flags & CTL_EPI_ACCUM) ov[m][t] = ctl_bload4s(ry, vo, so);
+                            } else {
+                                if (flags & CTL_EPI_RES) rv[m][t].x = ctl_bload1(rres, vo);
+                                if (flags & CTL_EPI_ACCUM) ov[m][t].x = ctl_bload1(ry, vo);
+                            }
                         }
                     }
                 }
-            }
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int co0 = (cot0 + t) * 16 + q * 4;
-                const bool cok = co0 < d.cout;
-                const int cc = cok ? co0 : 0;
-                f32x4 b = {0.f, 0.f, 0.f, 0.f}, rs = {0.f, 0.f, 0.f, 0.f}, rh = {0.f, 0.f, 0.f, 0.f};
-                if (d.cout >= 4) {
-                    if (flags & CTL_EPI_BIAS) b = *reinterpret_cast<const f32x4*>(bias + cc);
+                for (int t = 0; t < NT; ++t) {
+                    const int co0 = (cot0 + t) * 16 + q * 4;
+                    const bool cok = FULL || co0 < d.cout;
+                    const int cc = cok ? co0 : 0;
+                    f32x4 rs = {0.f, 0.f, 0.f, 0.f}, rh = {0.f, 0.f, 0.f, 0.f};
                     if (EPI && (flags & CTL_EPI_RES)) {
-                        rs = *reinterpret_cast<const f32x4*>(res_scale + cc);
-                        rh = *reinterpret_cast<const f32x4*>(res_shift + cc);
+                        if (d.cout >= 4) {
+                            rs = *reinterpret_cast<const f32x4*>(res_scale + cc);
+                            rh = *reinterpret_cast<const f32x4*>(res_shift + cc);
+                        } else { rs.x = res_scale[0]; rh.x = res_shift[0]; }
                     }
-                } else {
-                    if (flags & CTL_EPI_BIAS) b.x = bias[0];
-                    if (EPI && (flags & CTL_EPI_RES)) { rs.x = res_scale[0]; rh.x = res_shift[0]; }
-                }
 #pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    f32x4 v = acc[m][t];
-                    v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
-                    if (EPI) {
-                        const f32x4 r_ = rv[m][t];
-                        v.x += r_.x * rs.x + rh.x; v.y += r_.y * rs.y + rh.y;
-                        v.z += r_.z * rs.z + rh.z; v.w += r_.w * rs.w + rh.w;
+                    for (int m = 0; m < MT; ++m) {
+                        f32x4 v = acc[m][t];
+                        if (EPI) v += rv[m][t] * rs + rh;
+                        if (flags & CTL_EPI_STATS) {
+                            if (FULL) { ssum[t] += v; ssq[t] += v * v; }
+                            else if (pv[m]) { ssum[t] += v; ssq[t] += v * v; }
+                        }
+                        if (d.epi_act == CTL_ACT_LEAKY) {
+                            v = ctl_leaky01(v, d.epi_slope);
+                        } else if (d.epi_act == CTL_ACT_SIGMOID) {
+                            v.x = 1.f / (1.f + expf(-v.x)); v.y = 1.f / (1.f + expf(-v.y));
+                            v.z = 1.f / (1.f + expf(-v.z)); v.w = 1.f / (1.f + expf(-v.w));
+                        }
+                        if (EPI) v += ov[m][t];
+                        if (FULL) {
+                            ctl_bstore4(ry, ybase + yrel[m] + t * 64, v);     // no SGPR soffset on stores, see ctl_bload4s
+                        } else {
+                            const int vo = (pv[m] && cok) ? (ybase + yrel[m] + t * 64) : CTL_OOB;
+                            if (d.cout >= 4) ctl_bstore4(ry, vo, v);
+                            else ctl_bstore1(ry, vo, v.x);       // cout == 1: only q == 0 passes `cok`, component x is the channel
+                        }
                     }
-                    if ((flags & CTL_EPI_STATS) && pv[m]) {
-                        ssum[t].x += v.x; ssum[t].y += v.y; ssum[t].z += v.z; ssum[t].w += v.w;
-                        ssq[t].x += v.x * v.x; ssq[t].y += v.y * v.y; ssq[t].z += v.z * v.z; ssq[t].w += v.w * v.w;
-                    }
-                    if (d.epi_act == CTL_ACT_LEAKY) {
-                        v.x = ctl_leaky(v.x, d.epi_slope); v.y = ctl_leaky(v.y, d.epi_slope);
-                        v.z = ctl_leaky(v.z, d.epi_slope); v.w = ctl_leaky(v.w, d.epi_slope);
-                    } else if (d.epi_act == CTL_ACT_SIGMOID) {
-                        v.x = 1.f / (1.f + expf(-v.x)); v.y = 1.f / (1.f + expf(-v.y));
-                        v.z = 1.f / (1.f + expf(-v.z)); v.w = 1.f / (1.f + expf(-v.w));
-                    }
-                    if (EPI) {
-                        const f32x4 o = ov[m][t];
-                        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
-                    }
-                    const int vo = (pv[m] && cok) ? (ybase + yrel[m] + t * 64) : CTL_OOB;
-                    if (d.cout >= 4) ctl_bstore4(ry, vo, v);
-                    else ctl_bstore1(ry, vo, v.x);       // cout == 1: only q == 0 passes `cok`, component x is the channel
                 }
-            }
+            };
+            if (full) epilogue(std::true_type{});
+            else epilogue(std::false_type{});
         }
+        TM(5)
         if (g2 == 0) cur = nxt;
         g = g2;
     }
+    TM_FLUSH
 
     __syncthreads();
     if (flags & CTL_EPI_STATS) {  // per-channel sum / sum of squares of this block's tiles -> stats_partial[block][2][cout]
@@ -788,40 +893,31 @@ int ctl_conv_pick_cfg(const ctl_conv* d, ctl_conv_cfg* c, int for_wgrad) {
         if (f && sscanf(f, "%d,%d,%d", &fm, &ft, &fn) == 3) {
             const bool tile_ok = (fm == 4 && ft == 32 && d->stride == 1) || (fm == 2 && ft == 16) || (fm == 1 && ft == 16);
             if (tile_ok) { mt = fm; tw = ft; }
-            if ((fn == 1 || fn == 2 || fn == 4) && c->cot % fn == 0) c->nt = fn;
+            if ((fn == 1 || fn == 2) && c->cot % fn == 0) c->nt = fn;
         }
     }
-    if (d->stride == 2 && c->nt == 4) c->nt = 2;            // stride-2 input tiles are 4x larger: keep LDS < 64 KiB
     c->mt = mt; c->tw = tw; c->th = 4 * mt * 16 / tw;
     c->tiles_h = ctl_cdiv(d->hout, c->th);
     c->tiles_w = ctl_cdiv(d->wout, c->tw);
     return CTL_OK;
 }
 
-// persistent grid: ~CTL_PERSIST blocks per CU in total (default 4; the blocks of one launch share the chip with
-// nothing else), never more than there are tiles
-static int conv_grid_x(const ctl_conv* d, const ctl_conv_cfg* c) {
+// Persistent grid.  A launch owns the chip, so the grid is what is RESIDENT at once (256 CUs x the kernel's occupancy, at most
+// CTL_PERSIST = 4 blocks per CU): a larger grid runs in rounds, pays the block setup again and ends in a thin tail.  The
+// tiles are then dealt evenly: with r = ceil(tiles / capacity) tiles per block the grid shrinks to ceil(tiles / r).
+static int conv_grid_x(int ntiles, int other, int occ) {
     static int per_cu = -1;
     if (per_cu < 0) {
         const char* e = getenv("CTL_PERSIST");
         per_cu = e ? atoi(e) : 4;
         if (per_cu < 1) per_cu = 1;
     }
-    const int ntiles = d->n * c->tiles_h * c->tiles_w;
-    const int other = (c->cot / c->nt) * d->nsub;
-    int cap = ctl_cdiv(256 * per_cu, other);
+    const int resident = occ < per_cu ? occ : per_cu;
+    int cap = (256 * resident) / other;
     if (cap < 1) cap = 1;
-    return ntiles < cap ? ntiles : cap;
-}
-
-extern "C" int ctl_conv_stats_blocks(const ctl_conv* d) {
-    ctl_conv_cfg c;
-    if (ctl_conv_pick_cfg(d, &c, 0) != CTL_OK) return -1;
-    return conv_grid_x(d, &c);
-}
-extern "C" size_t ctl_conv_stats_floats(const ctl_conv* d) {
-    const int b = ctl_conv_stats_blocks(d);
-    return b < 0 ? 0 : (size_t)b * 2 * d->cout;
+    if (ntiles <= cap) return ntiles;
+    const int rounds = ctl_cdiv(ntiles, cap);
+    return ctl_cdiv(ntiles, rounds);
 }
 
 extern "C" int ctl_pack_weights(const float* src, float* dst, int32_t cout, int32_t cin, int32_t ks, int64_t s_co,
@@ -834,69 +930,99 @@ extern "C" int ctl_pack_weights(const float* src, float* dst, int32_t cout, int3
     return CTL_OK;
 }
 
-#define CONV_ARGS *d, x, wpack, bias, pro_scale, pro_shift, res, res_scale, res_shift, y, stats_partial, c.tiles_h, \
-                  c.tiles_w, c.g, sub_stride, ntiles, dbg
-#define LAUNCH_CONV(KS, S, MODE, MT, TW, NT)                                                                     \
-    do {                                                                                                         \
-        if (epi) conv_igemm_kernel<KS, S, MODE, MT, TW, NT, 1><<<grid, dim3(256), 0, (hipStream_t)stream>>>(CONV_ARGS); \
-        else conv_igemm_kernel<KS, S, MODE, MT, TW, NT, 0><<<grid, dim3(256), 0, (hipStream_t)stream>>>(CONV_ARGS);     \
-    } while (0)
-#define DISPATCH_NT(KS, S, MODE, MT, TW)                     \
-    do {                                                     \
-        if (c.nt == 4) LAUNCH_CONV(KS, S, MODE, MT, TW, 4);  \
-        else if (c.nt == 2) LAUNCH_CONV(KS, S, MODE, MT, TW, 2); \
-        else LAUNCH_CONV(KS, S, MODE, MT, TW, 1);            \
-    } while (0)
-#define DISPATCH_TILE(KS, S, MODE)                                   \
-    do {                                                             \
-        if (c.mt == 4 && c.tw == 32) DISPATCH_NT(KS, S, MODE, 4, 32); \
-        else if (c.mt == 2) DISPATCH_NT(KS, S, MODE, 2, 16);         \
-        else DISPATCH_NT(KS, S, MODE, 1, 16);                        \
-    } while (0)
-#define DISPATCH_NT_S2(KS, S, MODE, MT, TW)                  \
-    do {                                                     \
-        if (c.nt == 2) LAUNCH_CONV(KS, S, MODE, MT, TW, 2);  \
-        else LAUNCH_CONV(KS, S, MODE, MT, TW, 1);            \
-    } while (0)
-#define DISPATCH_TILE_S2(KS, S, MODE)                        \
-    do {                                                     \
-        if (c.mt == 2) DISPATCH_NT_S2(KS, S, MODE, 2, 16);   \
-        else DISPATCH_NT_S2(KS, S, MODE, 1, 16);             \
-    } while (0)
+struct conv_call {
+    const ctl_conv* d; ctl_conv_cfg c;
+    const float *x, *wpack, *bias, *pro_scale, *pro_shift, *res, *res_scale, *res_shift;
+    float *y, *stats_partial;
+    hipStream_t stream;
+    bool query;      // only report the grid (ctl_conv_stats_blocks), launch nothing
+    int grid_x;
+};
+
+template <int KS, int S, int MODE, int MT, int TW, int NT, int EPI>
+static void conv_go(conv_call& a) {
+    static int occ = 0;          // resident blocks per CU of this instantiation (asked once)
+    if (!occ) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_igemm_kernel<KS, S, MODE, MT, TW, NT, EPI>, 256, 0) != hipSuccess || n < 1) {
+            (void)hipGetLastError();
+            n = 2;
+        }
+        occ = n;
+    }
+    const ctl_conv* d = a.d;
+    const int ntiles = d->n * a.c.tiles_h * a.c.tiles_w;
+    a.grid_x = conv_grid_x(ntiles, (a.c.cot / NT) * d->nsub, occ);
+    if (a.query) return;
+    const dim3 grid((unsigned)a.grid_x, (unsigned)(a.c.cot / NT), (unsigned)d->nsub);
+    conv_igemm_kernel<KS, S, MODE, MT, TW, NT, EPI><<<grid, dim3(256), 0, a.stream>>>(
+        *d, a.x, a.wpack, a.bias, a.pro_scale, a.pro_shift, a.res, a.res_scale, a.res_shift, a.y, a.stats_partial, a.c.tiles_h,
+        a.c.tiles_w, a.c.g, (int64_t)ctl_conv_wpack_floats(d->cin, d->cout, d->ks), ntiles);
+}
+template <int KS, int S, int MODE, int MT, int TW>
+static void conv_go_nt(conv_call& a) {
+    const bool epi = (a.d->epi_flags & (CTL_EPI_RES | CTL_EPI_ACCUM)) != 0;
+    if (a.c.nt == 2) { if (epi) conv_go<KS, S, MODE, MT, TW, 2, 1>(a); else conv_go<KS, S, MODE, MT, TW, 2, 0>(a); }
+    else { if (epi) conv_go<KS, S, MODE, MT, TW, 1, 1>(a); else conv_go<KS, S, MODE, MT, TW, 1, 0>(a); }
+}
+template <int KS, int S, int MODE>
+static void conv_go_tile(conv_call& a) {
+    if (S == 1 && a.c.mt == 4 && a.c.tw == 32) conv_go_nt<KS, S, MODE, (S == 1 ? 4 : 2), (S == 1 ? 32 : 16)>(a);
+    else if (a.c.mt == 2) conv_go_nt<KS, S, MODE, 2, 16>(a);
+    else conv_go_nt<KS, S, MODE, 1, 16>(a);
+}
+static int conv_dispatch(conv_call& a) {
+    const int k = a.d->ks, s = a.d->stride, m = a.d->in_mode;
+    if (k == 3 && s == 1 && m == CTL_IN_PLAIN) conv_go_tile<3, 1, CTL_IN_PLAIN>(a);
+    else if (k == 3 && s == 1 && m == CTL_IN_UP2) conv_go_tile<3, 1, CTL_IN_UP2>(a);
+    else if (k == 3 && s == 1 && m == CTL_IN_ZINS2) conv_go_tile<3, 1, CTL_IN_ZINS2>(a);
+    else if (k == 3 && s == 2) conv_go_tile<3, 2, CTL_IN_PLAIN>(a);
+    else if (k == 1 && m == CTL_IN_PLAIN) conv_go_tile<1, 1, CTL_IN_PLAIN>(a);
+    else if (k == 1 && m == CTL_IN_UP2) conv_go_tile<1, 1, CTL_IN_UP2>(a);
+    else if (k == 2 && s == 2) conv_go_tile<2, 2, CTL_IN_PLAIN>(a);
+    else CTL_FAIL(CTL_EUNSUPPORTED, "conv_forward: no kernel for this combination");
+    return CTL_OK;
+}
+
+extern "C" int ctl_conv_stats_blocks(const ctl_conv* d) {
+    conv_call a = {};
+    a.d = d;
+    if (ctl_conv_pick_cfg(d, &a.c, 0) != CTL_OK) return -1;
+    a.query = true;
+    if (conv_dispatch(a) != CTL_OK) return -1;
+    return a.grid_x;
+}
+extern "C" size_t ctl_conv_stats_floats(const ctl_conv* d) {
+    const int b = ctl_conv_stats_blocks(d);
+    return b < 0 ? 0 : (size_t)b * 2 * d->cout;
+}
 
 extern "C" int ctl_conv_forward(const ctl_conv* d, const float* x, const float* wpack, const float* bias,
                                 const float* pro_scale, const float* pro_shift, const float* res,
                                 const float* res_scale, const float* res_shift, float* y, float* stats_partial,
                                 ctl_stream stream) {
     CTL_REQUIRE(d && x && wpack && y, "conv_forward: null argument");
-    ctl_conv_cfg c;
-    int rc = ctl_conv_pick_cfg(d, &c, 0);
+    conv_call a = {};
+    a.d = d;
+    int rc = ctl_conv_pick_cfg(d, &a.c, 0);
     if (rc != CTL_OK) return rc;
     CTL_REQUIRE(!(d->epi_flags & CTL_EPI_BIAS) || bias, "conv_forward: CTL_EPI_BIAS without bias");
     CTL_REQUIRE(!(d->epi_flags & CTL_EPI_RES) || (res && res_scale && res_shift), "conv_forward: CTL_EPI_RES without res");
     CTL_REQUIRE(!(d->epi_flags & CTL_EPI_STATS) || (stats_partial && d->nsub == 1), "conv_forward: bad CTL_EPI_STATS use");
     CTL_REQUIRE(!d->pro_affine || (pro_scale && pro_shift), "conv_forward: prologue without scale/shift");
+    CTL_REQUIRE(!d->pro_affine || (d->pro_slope >= 0.f && d->pro_slope <= 1.f), "conv_forward: prologue slope must be in [0, 1]");
+    CTL_REQUIRE(d->epi_act != CTL_ACT_LEAKY || (d->epi_slope >= 0.f && d->epi_slope <= 1.f), "conv_forward: LeakyReLU slope must be in [0, 1]");
     CTL_REQUIRE(d->n > 0 && d->hout > 0 && d->wout > 0, "conv_forward: empty problem");
     CTL_REQUIRE((int64_t)d->n * d->hin * d->win * d->cin * 4 < (1ll << 31) &&
                 (int64_t)d->n * d->out_h * d->out_w * d->cout * 4 < (1ll << 31),
                 "conv_forward: tensors must stay below 2 GiB (32-bit buffer offsets)");
-    const int64_t sub_stride = (int64_t)ctl_conv_wpack_floats(d->cin, d->cout, d->ks);
-    const int ntiles = d->n * c.tiles_h * c.tiles_w;
-    const bool epi = (d->epi_flags & (CTL_EPI_RES | CTL_EPI_ACCUM)) != 0;
-    static int dbg = -1;                       // CTL_DBG ablation mask (tools/bench_conv.py): 1 no MFMA, 2 no prefetch, 4 no epilogue
-    if (dbg < 0) { const char* e = getenv("CTL_DBG"); dbg = e ? atoi(e) : 0; }
-    const dim3 grid((unsigned)conv_grid_x(d, &c), (unsigned)(c.cot / c.nt), (unsigned)d->nsub);
-    const int k = d->ks, s = d->stride, m = d->in_mode;
-    const int ptok = ctl_prof_begin("conv_igemm", d, &c, c.nt, (hipStream_t)stream);
-    if (k == 3 && s == 1 && m == CTL_IN_PLAIN) DISPATCH_TILE(3, 1, CTL_IN_PLAIN);
-    else if (k == 3 && s == 1 && m == CTL_IN_UP2) DISPATCH_TILE(3, 1, CTL_IN_UP2);
-    else if (k == 3 && s == 1 && m == CTL_IN_ZINS2) DISPATCH_TILE(3, 1, CTL_IN_ZINS2);
-    else if (k == 3 && s == 2) DISPATCH_TILE_S2(3, 2, CTL_IN_PLAIN);
-    else if (k == 1 && m == CTL_IN_PLAIN) DISPATCH_TILE(1, 1, CTL_IN_PLAIN);
-    else if (k == 1 && m == CTL_IN_UP2) DISPATCH_TILE(1, 1, CTL_IN_UP2);
-    else if (k == 2 && s == 2) DISPATCH_TILE_S2(2, 2, CTL_IN_PLAIN);
-    else CTL_FAIL(CTL_EUNSUPPORTED, "conv_forward: no kernel for this combination");
-    ctl_prof_end(ptok, (hipStream_t)stream);
+    a.x = x; a.wpack = wpack; a.bias = bias; a.pro_scale = pro_scale; a.pro_shift = pro_shift; a.res = res;
+    a.res_scale = res_scale; a.res_shift = res_shift; a.y = y; a.stats_partial = stats_partial;
+    a.stream = (hipStream_t)stream;
+    const int ptok = ctl_prof_begin("conv_igemm", d, &a.c, a.c.nt, a.stream);
+    rc = conv_dispatch(a);
+    if (rc != CTL_OK) return rc;
+    ctl_prof_end(ptok, a.stream);
     CTL_LAUNCH_CHECK("conv_forward");
     return CTL_OK;
 }

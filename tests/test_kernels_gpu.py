@@ -36,6 +36,8 @@ CONV_CASES = [
     (2, 16, 16, 32, 32), (16, 16, 16, 64, 64), (4, 16, 16, 128, 128), (2, 32, 64, 16, 16), (2, 128, 128, 8, 8),
     (2, 64, 32, 24, 20), (2, 1, 16, 32, 32), (2, 4, 16, 20, 12), (2, 16, 4, 32, 32), (3, 16, 1, 16, 16), (1, 32, 32, 6, 6),
     (2, 128, 64, 3, 3),
+    # interior tiles (scalar-offset fast path) with several 16-channel chunks, ragged right/bottom edges
+    (2, 32, 32, 48, 48), (1, 64, 48, 40, 72), (2, 128, 32, 36, 52), (3, 48, 16, 70, 70),
 ]
 
 
@@ -65,7 +67,7 @@ def test_conv3x3_s1_forward_bias_prologue_stats(n, cin, cout, h, w):
 
 
 @pytest.mark.parametrize("n,c,cout,h,w", [(2, 16, 16, 32, 32), (2, 32, 32, 17, 23), (4, 64, 64, 16, 16), (2, 128, 128, 6, 6),
-                                           (16, 16, 16, 128, 128)])
+                                           (16, 16, 16, 128, 128), (2, 32, 64, 80, 72), (2, 64, 32, 50, 90)])
 def test_conv3x3_s2_forward_and_zero_insert_dgrad(n, c, cout, h, w):
     g = torch.Generator().manual_seed(c + h)
     x = torch.randn(n, c, h, w, generator=g, requires_grad=True)
@@ -83,7 +85,8 @@ def test_conv3x3_s2_forward_and_zero_insert_dgrad(n, c, cout, h, w):
     close(dx, x.grad, what="conv3x3 s2 dgrad (zero-insert)")
 
 
-@pytest.mark.parametrize("n,cin,cout,h,w", [(2, 16, 16, 16, 16), (2, 128, 64, 4, 4), (3, 32, 16, 24, 24), (16, 16, 16, 64, 64)])
+@pytest.mark.parametrize("n,cin,cout,h,w", [(2, 16, 16, 16, 16), (2, 128, 64, 4, 4), (3, 32, 16, 24, 24), (16, 16, 16, 64, 64),
+                                              (2, 64, 32, 40, 36), (1, 32, 32, 21, 50)])
 def test_conv3x3_on_nearest_upsampled_input_and_dgrad(n, cin, cout, h, w):
     g = torch.Generator().manual_seed(cin + h)
     x = torch.randn(n, cin, h, w, generator=g, requires_grad=True)
@@ -103,7 +106,8 @@ def test_conv3x3_on_nearest_upsampled_input_and_dgrad(n, cin, cout, h, w):
 
 
 @pytest.mark.parametrize("n,cin,cout,h,w,up", [(2, 16, 32, 32, 32, 0), (2, 128, 128, 4, 4, 0), (2, 64, 32, 8, 8, 1),
-                                                (2, 16, 4, 64, 64, 0), (2, 16, 1, 32, 32, 0), (16, 16, 16, 64, 64, 1)])
+                                                (2, 16, 4, 64, 64, 0), (2, 16, 1, 32, 32, 0), (16, 16, 16, 64, 64, 1),
+                                                (2, 64, 32, 48, 80, 0), (2, 32, 32, 24, 40, 1)])
 def test_conv1x1_residual_epilogue(n, cin, cout, h, w, up):
     g = torch.Generator().manual_seed(cin + cout + h)
     x = torch.randn(n, cin, h, w, generator=g)
@@ -130,7 +134,7 @@ def test_conv1x1_residual_epilogue(n, cin, cout, h, w, up):
     close(y3, F.conv2d(xi, wt) + v, what="conv1x1 accumulate")
 
 
-@pytest.mark.parametrize("n,c,h,w", [(2, 16, 16, 16), (2, 128, 4, 4), (3, 32, 9, 7), (16, 16, 64, 64)])
+@pytest.mark.parametrize("n,c,h,w", [(2, 16, 16, 16), (2, 128, 4, 4), (3, 32, 9, 7), (16, 16, 64, 64), (2, 32, 40, 56)])
 def test_conv_transpose2x2_forward_dgrad_wgrad(n, c, h, w):
     g = torch.Generator().manual_seed(c + h)
     x = torch.randn(n, c, h, w, generator=g, requires_grad=True)
@@ -172,6 +176,8 @@ WGRAD_CASES = [
     (2, 1, 16, 32, 32, 3, 1, 0), (2, 4, 16, 20, 12, 3, 1, 0), (2, 64, 64, 17, 23, 3, 2, 0), (4, 16, 16, 64, 64, 3, 2, 0),
     (2, 64, 32, 8, 8, 3, 1, 1), (2, 16, 32, 32, 32, 1, 1, 0), (2, 128, 64, 4, 4, 1, 1, 1), (2, 16, 4, 64, 64, 1, 1, 0),
     (2, 16, 1, 32, 32, 1, 1, 0), (4, 16, 16, 128, 128, 3, 1, 0),
+    # interior tiles of the staging fast path, several chunks
+    (2, 32, 32, 48, 40, 3, 1, 0), (2, 64, 32, 20, 28, 3, 1, 1), (2, 32, 48, 50, 70, 3, 2, 0), (2, 32, 32, 24, 40, 1, 1, 1),
 ]
 
 

@@ -1,6 +1,7 @@
 """GPU tuning helper: time single conv layers of the bs16 workload under forced tile configurations.
    python tools/bench_conv.py            (each layer x each valid "mt,tw,nt")"""
 import os, sys, subprocess, json
+import ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 LAYERS = [  # name, cin, cout, h(in), ks, stride, in_mode
     ("c16-16@256", 16, 16, 256, 3, 1, 0), ("c32-32@128", 32, 32, 128, 3, 1, 0), ("c16-32@128", 16, 32, 128, 3, 1, 0),
@@ -44,12 +45,20 @@ def child(kind):
         except Exception as e:
             res[name] = None; continue
         torch.cuda.synchronize()
+        tm = (C.c_ulonglong * 12)()
+        has_tm = kind == "fwd" and hasattr(lib, "ctl_debug_timing")      # -DCTL_TIMING variant build (tools/build_variant.sh)
+        if has_tm: lib.ctl_debug_timing(tm)                               # reset
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(20): run()
         e1.record(); torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / 20
         res[name] = (round(us, 1), round(flops / us / 1e6, 1))
+        if has_tm:
+            lib.ctl_debug_timing(tm)
+            steps = max(tm[6], 1)          # (tile, chunk) steps summed over waves
+            names = ["issue", "mfma", "bar_rd", "stage", "bar_wr", "epi"]
+            res[name] = res[name] + ({k: round(tm[i] / steps) for i, k in enumerate(names)}, {"setup/step": round(tm[7] / steps, 1), "steps/launch": steps // 20, "memtime_MHz": round(100.0 * tm[8] / max(tm[9], 1), 1), "span_mean_us": round(tm[9] / max(tm[11], 1) / 20 / 100.0, 1), "span_max_us": round(tm[10] / 20 / (100.0 * tm[8] / max(tm[9], 1)), 1)})
     print("RESULT " + json.dumps(res))
 
 if __name__ == "__main__":
