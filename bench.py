@@ -135,6 +135,11 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    phase_tm = None
+    if rank == 0 and os.environ.get("CTL_HIP_LIB") and hasattr(_ffi.lib, "ctl_debug_timing"):
+        import ctypes                                     # -DCTL_TIMING variant build: per-phase cycle counters of the conv kernel
+        phase_tm = (ctypes.c_ulonglong * 12)()
+        _ffi.lib.ctl_debug_timing(phase_tm)               # reset
     if rank == 0:
         _ffi.prof_start(args.prof_filter)
     t0 = time.perf_counter()
@@ -143,6 +148,12 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     prof = _ffi.prof_stop() if rank == 0 else {}
+    if phase_tm is not None:
+        _ffi.lib.ctl_debug_timing(phase_tm)
+        steps = max(phase_tm[6], 1)
+        names = ["issue", "mfma", "bar_rd", "stage", "bar_wr", "epi"]
+        print("conv phase cycles per (tile, chunk) step per wave:", {k: round(phase_tm[i] / steps) for i, k in enumerate(names)},
+              "setup/step", round(phase_tm[7] / steps), "MHz", round(100.0 * phase_tm[8] / max(phase_tm[9], 1)), file=sys.stderr)
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

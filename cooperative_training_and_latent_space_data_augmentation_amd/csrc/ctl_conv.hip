@@ -271,12 +271,19 @@ __global__ __launch_bounds__(256, (MT * NT >= 8) ? 2 : ((MT * NT >= 4) ? CTL_LB_
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int p = lane & 15, q = lane >> 4;
-    const int nblk = gridDim.x;
-    const int bid0 = ctl_xcd_remap(blockIdx.x, nblk);
+    // Tile ownership.  Blocks b, b+8, ... share an XCD (and its L2) and the dispatcher spreads blocks breadth-first: the
+    // first 256 land on distinct CUs (tools/micro/dispatch_probe.hip).  So the tile list is cut into one contiguous range
+    // per XCD (neighbouring tiles share halos in one L2) and the j-th block of an XCD walks tiles j, j+nb, ... of that
+    // range: the blocks that get one tile more are the first of each XCD, i.e. sit on different CUs.
+    const int P = gridDim.x < 8 ? (int)gridDim.x : 8;
+    const int xcd = blockIdx.x % P, jblk = blockIdx.x / P;
+    const int nb = ((int)gridDim.x - xcd + P - 1) / P;                 // blocks of this XCD
+    const int t_lo = (int)(((int64_t)ntiles * xcd) / P), t_hi = (int)(((int64_t)ntiles * (xcd + 1)) / P);
+    const int bid0 = t_lo + jblk;
     const int z = blockIdx.z;
     const int cot0 = blockIdx.y * NT;
     const float* wp = wpack + (int64_t)z * wpack_sub_stride;
-    const int my_tiles = (bid0 < ntiles) ? (ntiles - bid0 + nblk - 1) / nblk : 0;
+    const int my_tiles = (bid0 < t_hi) ? (t_hi - bid0 + nb - 1) / nb : 0;
     const int total_it = my_tiles * G_chunks;
     const int flags = d.epi_flags;
     const int oy0 = (z >> 1) * d.out_sub, ox0 = (z & 1) * d.out_sub;
@@ -340,7 +347,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 8) ? 2 : ((MT * NT >= 4) ? CTL_LB_
     };
 
     TileWalk cur, nxt;
-    cur.init(bid0, nblk, tiles_h, tiles_w);
+    cur.init(bid0, nb, tiles_h, tiles_w);
     nxt = cur;
     TM_DECL
     if (total_it > 0) {
@@ -498,6 +505,9 @@ __global__ __launch_bounds__(256, (MT * NT >= 8) ? 2 : ((MT * NT >= 4) ? CTL_LB_
         if (g2 == 0) cur = nxt;
         g = g2;
     }
+#ifdef CTL_TIMING_DOMINANT_ONLY
+    if (KS == 3 && S == 1 && MODE == 0 && MT == 4 && TW == 32 && NT == 1 && EPI == 0)
+#endif
     TM_FLUSH
 
     __syncthreads();
@@ -902,9 +912,10 @@ int ctl_conv_pick_cfg(const ctl_conv* d, ctl_conv_cfg* c, int for_wgrad) {
     return CTL_OK;
 }
 
-// Persistent grid.  A launch owns the chip, so the grid is what is RESIDENT at once (256 CUs x the kernel's occupancy, at most
-// CTL_PERSIST = 4 blocks per CU): a larger grid runs in rounds, pays the block setup again and ends in a thin tail.  The
-// tiles are then dealt evenly: with r = ceil(tiles / capacity) tiles per block the grid shrinks to ceil(tiles / r).
+// Persistent grid: what is RESIDENT at once (256 CUs x the kernel's occupancy, at most CTL_PERSIST = 4 blocks per CU) -- a
+// larger grid runs in rounds, pays the block setup again and ends in a thin tail; a smaller one leaves CUs with fewer blocks
+// than others (the dispatcher spreads blocks evenly over the CUs, tools/micro/dispatch_probe.hip).  With gridDim.y/z > 1 the
+// x extent is kept a multiple of 8 so that blockIdx.x % 8 stays the XCD of a block.
 static int conv_grid_x(int ntiles, int other, int occ) {
     static int per_cu = -1;
     if (per_cu < 0) {
@@ -914,10 +925,9 @@ static int conv_grid_x(int ntiles, int other, int occ) {
     }
     const int resident = occ < per_cu ? occ : per_cu;
     int cap = (256 * resident) / other;
+    if (other > 1 && cap >= 8) cap -= cap % 8;
     if (cap < 1) cap = 1;
-    if (ntiles <= cap) return ntiles;
-    const int rounds = ctl_cdiv(ntiles, cap);
-    return ctl_cdiv(ntiles, rounds);
+    return ntiles < cap ? ntiles : cap;
 }
 
 extern "C" int ctl_pack_weights(const float* src, float* dst, int32_t cout, int32_t cin, int32_t ks, int64_t s_co,

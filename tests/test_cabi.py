@@ -48,8 +48,10 @@ def test_host_side_sizing_helpers():
     assert _ffi.lib.ctl_conv_wpack_floats(4, 16, 3) == 9 * 256          # cin padded to one 16-chunk
     assert _ffi.lib.ctl_conv_wpack_floats(128, 64, 1) == 4 * 8 * 256
     d = _ffi.conv_desc(n=16, hin=256, win=256, cin=16, hout=256, wout=256, cout=16, ks=3)
-    assert _ffi.lib.ctl_conv_stats_blocks(_ffi.desc_ptr(d)) == 1024       # persistent grid: 4 blocks per CU
-    assert _ffi.lib.ctl_conv_stats_floats(_ffi.desc_ptr(d)) == 1024 * 2 * 16
+    # persistent grid = 256 CUs x resident blocks per CU of the chosen kernel (asked from the runtime; 2 assumed without a GPU)
+    blocks = _ffi.lib.ctl_conv_stats_blocks(_ffi.desc_ptr(d))
+    assert blocks in (512, 768, 1024)
+    assert _ffi.lib.ctl_conv_stats_floats(_ffi.desc_ptr(d)) == blocks * 2 * 16
     assert _ffi.lib.ctl_wgrad_splits(_ffi.desc_ptr(d)) == 512
     assert _ffi.lib.ctl_wgrad_partial_floats(_ffi.desc_ptr(d)) == 512 * 9 * 16 * 16
     assert _ffi.lib.ctl_latent_score_ws_floats(0, 16, 256, 128) == 16 * 4 * 128
