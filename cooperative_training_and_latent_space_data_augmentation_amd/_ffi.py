@@ -23,7 +23,7 @@ CONV_DTYPE = np.dtype([
     ("n", "<i4"), ("hin", "<i4"), ("win", "<i4"), ("cin", "<i4"), ("hout", "<i4"), ("wout", "<i4"), ("cout", "<i4"),
     ("ks", "<i4"), ("stride", "<i4"), ("pad", "<i4"), ("in_mode", "<i4"), ("pro_affine", "<i4"), ("pro_slope", "<f4"),
     ("epi_flags", "<i4"), ("epi_act", "<i4"), ("epi_slope", "<f4"), ("out_h", "<i4"), ("out_w", "<i4"),
-    ("out_sy", "<i4"), ("out_sx", "<i4"), ("nsub", "<i4"), ("out_sub", "<i4")])
+    ("out_sy", "<i4"), ("out_sx", "<i4"), ("nsub", "<i4"), ("out_sub", "<i4"), ("groups", "<i4")])
 OP_DTYPE = np.dtype([("kind", "<i4"), ("i", "<i4", (27,)), ("f", "<f4", (4,)), ("slot", "<i4", (OP_MAX_T,)),
                      ("off", "<i8", (OP_MAX_T,)), ("l", "<i8", (4,))], align=True)
 
@@ -58,12 +58,12 @@ class _Lib:
             "ctl_conv_forward": [p] * 12,
             "ctl_conv_wgrad": [p] * 8,
             "ctl_wgrad_reduce": [p, p, p, p, i64, i64, i64, i64, p, i32, p],
-            "ctl_bn_finalize": [p, i32, i32, i64, p, p, f32, f32, i32, p, p, p, p, p, p, p, p],
-            "ctl_bn_eval_coeffs": [i32, p, p, p, p, f32, p, p, p],
-            "ctl_bn_act": [p, p, p, f32, p, i64, i32, p],
-            "ctl_bwd_reduce": [i32, p, p, p, p, p, f32, i64, i32, p, p],
-            "ctl_bn_bwd_finalize": [p, i32, i64, p, p, p, p, p, p, i32, p],
-            "ctl_bwd_apply": [i32, p, p, p, p, p, f32, p, i64, i32, p, p, p],
+            "ctl_bn_finalize": [p, i32, i32, i64, p, p, f32, f32, i32, p, p, p, p, p, p, p, i32, p],
+            "ctl_bn_eval_coeffs": [i32, p, p, p, p, f32, p, p, i32, p],
+            "ctl_bn_act": [p, p, p, f32, p, i64, i32, i32, p],
+            "ctl_bwd_reduce": [i32, p, p, p, p, p, f32, i64, i32, p, i32, p],
+            "ctl_bn_bwd_finalize": [p, i32, i64, p, p, p, p, p, p, i32, i32, p],
+            "ctl_bwd_apply": [i32, p, p, p, p, p, f32, p, i64, i32, p, p, i32, p],
             "ctl_chan_sum_finalize": [p, i32, p, i32, p],
             "ctl_sumpool2": [p, p, i32, i32, i32, i32, i32, p],
             "ctl_sigmoid_bwd": [p, p, p, i64, p],
@@ -139,6 +139,7 @@ def conv_desc(**kw) -> np.ndarray:
     d["pad"] = 1 if kw.get("ks", 3) == 3 else 0
     d["stride"] = 1
     d["nsub"] = 1
+    d["groups"] = 1
     d["out_sy"] = d["out_sx"] = 1
     for k, v in kw.items():
         d[k] = v

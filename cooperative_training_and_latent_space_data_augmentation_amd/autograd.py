@@ -16,8 +16,8 @@ class _NetFn(torch.autograd.Function):
     """A whole encoder / decoder pass.  Inputs: the activation `x` and the network's flat parameter buffer."""
 
     @staticmethod
-    def forward(ctx, net, mode, affine, x, flat):
-        outs, act, plan = net.run_forward(x, mode)
+    def forward(ctx, net, mode, affine, groups, x, flat):
+        outs, act, plan = net.run_forward(x, mode, groups)
         ctx.net, ctx.mode, ctx.affine, ctx.act, ctx.plan = net, mode, affine, act, plan
         ctx.save_for_backward(x, *outs)
         ctx.set_materialize_grads(False)
@@ -29,22 +29,23 @@ class _NetFn(torch.autograd.Function):
             raise CtlError("backward through an eval-mode (running-statistics) pass is not part of the hot path")
         saved = ctx.saved_tensors
         x, outs = saved[0], saved[1:]
-        need_dx, need_w = ctx.needs_input_grad[3], ctx.needs_input_grad[4]
+        need_dx, need_w = ctx.needs_input_grad[4], ctx.needs_input_grad[5]
         if all(d is None for d in douts) or not (need_dx or need_w):
-            return None, None, None, None, None
+            return None, None, None, None, None, None
         douts = tuple(None if d is None else _nhwc(d) for d in douts)
         dx, gflat = ctx.net.run_backward(x, ctx.act, outs, ctx.plan, ctx.mode, douts, need_dx, need_w, ctx.affine)
-        return None, None, None, dx, gflat
+        return None, None, None, None, dx, gflat
 
 
-def net_apply(net, x: torch.Tensor):
-    """Run `net` on `x` (logical NCHW) in its current BatchNorm mode; returns a tuple of outputs."""
+def net_apply(net, x: torch.Tensor, groups: int = 1):
+    """Run `net` on `x` (logical NCHW) in its current BatchNorm mode; returns a tuple of outputs.  groups > 1: `x` stacks that
+    many independent batches along n and BatchNorm handles each as its own call (one launch chain instead of `groups`)."""
     ops.require_gpu(x)
     x = _nhwc(x)
     mode = net.bn_mode()
     track_params = torch.is_grad_enabled() and mode != "C" and net.wants_param_grad()
     flat = net._flat if track_params else net._flat.detach()
-    return _NetFn.apply(net, mode, mode == "A", x, flat)
+    return _NetFn.apply(net, mode, mode == "A", groups, x, flat)
 
 
 class _CrossEntropy2D(torch.autograd.Function):

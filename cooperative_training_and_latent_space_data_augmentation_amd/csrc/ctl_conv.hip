@@ -149,8 +149,9 @@ struct XStage {
         }
     }
 
+    // `goff` = BatchNorm group of the tile held in v[] times cin (row of the [groups][cin] prologue coefficients)
     __device__ __forceinline__ void store(float* __restrict__ xt, const ctl_conv& d, int g,
-                                          const float* __restrict__ pro_scale, const float* __restrict__ pro_shift) {
+                                          const float* __restrict__ pro_scale, const float* __restrict__ pro_shift, int goff) {
         if (!d.pro_affine) {      // out-of-range units were loaded as hardware zeros: nothing to compute
 #pragma unroll
             for (int i = 0; i < NU; ++i) *reinterpret_cast<f32x4*>(xt + lds[i]) = v[i];
@@ -160,11 +161,11 @@ struct XStage {
         f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
         if (cb < d.cin) {
             if (d.cin >= 4) {
-                sc = *reinterpret_cast<const f32x4*>(pro_scale + cb);
-                sh = *reinterpret_cast<const f32x4*>(pro_shift + cb);
+                sc = *reinterpret_cast<const f32x4*>(pro_scale + goff + cb);
+                sh = *reinterpret_cast<const f32x4*>(pro_shift + goff + cb);
             } else {
-                sc.x = pro_scale[0];
-                sh.x = pro_shift[0];
+                sc.x = pro_scale[goff];
+                sh.x = pro_shift[goff];
             }
         }
         const float slope = d.pro_slope;
@@ -262,9 +263,10 @@ __global__ __launch_bounds__(256, (MT * NT >= 8) ? 2 : ((MT * NT >= 4) ? CTL_LB_
     constexpr int TAPS = KS * KS;
     constexpr int RED_FLOATS = 4 * NT * 16 * 2;
     constexpr int WT_FLOATS = TAPS * NT * 256;
-    constexpr int XT_ALLOC = (G::XT_FLOATS > RED_FLOATS) ? G::XT_FLOATS : RED_FLOATS;
-    __shared__ __attribute__((aligned(16))) float xt[XT_ALLOC + WT_FLOATS];
+    constexpr int XT_ALLOC = G::XT_FLOATS;
+    __shared__ __attribute__((aligned(16))) float xt[XT_ALLOC + WT_FLOATS + RED_FLOATS];
     float* wt = xt + XT_ALLOC;
+    float* sred = wt + WT_FLOATS;        // statistics reduction scratch (a flush can happen while xt holds the next tile)
     constexpr int WU = TAPS * NT * 64, NW = (WU + 255) / 256;
 
     const int tid = threadIdx.x;
@@ -286,6 +288,8 @@ __global__ __launch_bounds__(256, (MT * NT >= 8) ? 2 : ((MT * NT >= 4) ? CTL_LB_
     const int my_tiles = (bid0 < t_hi) ? (t_hi - bid0 + nb - 1) / nb : 0;
     const int total_it = my_tiles * G_chunks;
     const int flags = d.epi_flags;
+    const int ngroups = d.groups > 1 ? d.groups : 1;
+    const int group_n = d.n / ngroups;                               // images per BatchNorm group
     const int oy0 = (z >> 1) * d.out_sub, ox0 = (z & 1) * d.out_sub;
     const __amdgpu_buffer_rsrc_t rx = ctl_rsrc(x, (int64_t)d.n * d.hin * d.win * d.cin * 4);
     const int64_t ybytes = (int64_t)d.n * d.out_h * d.out_w * d.cout * 4;
@@ -353,10 +357,49 @@ __global__ __launch_bounds__(256, (MT * NT >= 8) ? 2 : ((MT * NT >= 4) ? CTL_LB_
     if (total_it > 0) {
         xs.load(rx, d, cur.n, cur.th * G::TH, cur.tw * TW, 0);
         wload(0);
-        xs.store(xt, d, 0, pro_scale, pro_shift);
+        xs.store(xt, d, 0, pro_scale, pro_shift, (cur.n / group_n) * d.cin);
         wstore();
     }
     __syncthreads();
+
+    // Statistics of one BatchNorm group: block-level sum through LDS -> stats_partial[group][block][2][cout].  Called when the
+    // walk enters the next group (tiles are visited in increasing order) and once at the end; every wave takes part.
+    auto flush_stats = [&](int grp) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            float a[8] = {ssum[t].x, ssum[t].y, ssum[t].z, ssum[t].w, ssq[t].x, ssq[t].y, ssq[t].z, ssq[t].w};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float v = a[i];
+                v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+                a[i] = v;
+            }
+            if (p == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    sred[((wave * NT + t) * 16 + q * 4 + r) * 2 + 0] = a[r];
+                    sred[((wave * NT + t) * 16 + q * 4 + r) * 2 + 1] = a[4 + r];
+                }
+            }
+            ssum[t] = ssq[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        __syncthreads();
+        if (tid < NT * 16 * 2) {
+            const int stat = tid / (NT * 16), cl = tid % (NT * 16);
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) v += sred[((w * NT * 16) + cl) * 2 + stat];
+            const int co = cot0 * 16 + cl;
+            if (co < d.cout) stats_partial[(((int64_t)grp * gridDim.x + blockIdx.x) * 2 + stat) * d.cout + co] = v;
+        }
+        __syncthreads();
+    };
+    int cur_grp = (my_tiles > 0) ? cur.n / group_n : 0;
+    if ((flags & CTL_EPI_STATS) && ngroups > 1 && tid < NT * 16 * 2) {      // groups this block never visits contribute zeros
+        const int stat = tid / (NT * 16), co = cot0 * 16 + tid % (NT * 16);
+        if (co < d.cout)
+            for (int gi = 0; gi < ngroups; ++gi) stats_partial[(((int64_t)gi * gridDim.x + blockIdx.x) * 2 + stat) * d.cout + co] = 0.f;
+    }
 
     TM(7)
     f32x4 acc[MT][NT];
@@ -418,7 +461,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 8) ? 2 : ((MT * NT >= 4) ? CTL_LB_
         ctl_barrier_lds_reads_done();    // every wave is done reading this step's LDS images
         TM(2)
         if (has_next) {    // refill LDS from the prefetched registers
-            xs.store(xt, d, g2, pro_scale, pro_shift);
+            xs.store(xt, d, g2, pro_scale, pro_shift, (nxt.n / group_n) * d.cin);   // v[] holds chunk g2 of tile nxt (== cur unless g2 == 0)
             if (new_w) wstore();
         }
         TM(3)
@@ -429,6 +472,11 @@ __global__ __launch_bounds__(256, (MT * NT >= 8) ? 2 : ((MT * NT >= 4) ? CTL_LB_
             // ---------------- epilogue: lane (p,q) holds channels co0..co0+3 of pixel p of each M-tile.  Buffer stores with
             // hardware bounds checks; nothing here is waited for in the loop.  Whole tiles with whole channel tiles (FULL) put
             // the tile origin into the scalar offset and skip every mask; ragged ones redirect dropped lanes to CTL_OOB.
+            const int grp = n / group_n;
+            if ((flags & CTL_EPI_STATS) && grp != cur_grp) {
+                flush_stats(cur_grp);
+                cur_grp = grp;
+            }
             const int ybase = (((n * d.out_h + ho0 * d.out_sy + oy0) * d.out_w + wo0 * d.out_sx + ox0) * d.cout + cot0 * 16) * 4;
 #ifdef CTL_NO_FULL_EPI
             const bool full = false;
@@ -469,9 +517,9 @@ __global__ __launch_bounds__(256, (MT * NT >= 8) ? 2 : ((MT * NT >= 4) ? CTL_LB_
                     f32x4 rs = {0.f, 0.f, 0.f, 0.f}, rh = {0.f, 0.f, 0.f, 0.f};
                     if (EPI && (flags & CTL_EPI_RES)) {
                         if (d.cout >= 4) {
-                            rs = *reinterpret_cast<const f32x4*>(res_scale + cc);
-                            rh = *reinterpret_cast<const f32x4*>(res_shift + cc);
-                        } else { rs.x = res_scale[0]; rh.x = res_shift[0]; }
+                            rs = *reinterpret_cast<const f32x4*>(res_scale + grp * d.cout + cc);
+                            rh = *reinterpret_cast<const f32x4*>(res_shift + grp * d.cout + cc);
+                        } else { rs.x = res_scale[grp]; rh.x = res_shift[grp]; }
                     }
 #pragma unroll
                     for (int m = 0; m < MT; ++m) {
@@ -510,35 +558,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 8) ? 2 : ((MT * NT >= 4) ? CTL_LB_
 #endif
     TM_FLUSH
 
-    __syncthreads();
-    if (flags & CTL_EPI_STATS) {  // per-channel sum / sum of squares of this block's tiles -> stats_partial[block][2][cout]
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            float a[8] = {ssum[t].x, ssum[t].y, ssum[t].z, ssum[t].w, ssq[t].x, ssq[t].y, ssq[t].z, ssq[t].w};
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                float v = a[i];
-                v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
-                a[i] = v;
-            }
-            if (p == 0) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    xt[((wave * NT + t) * 16 + q * 4 + r) * 2 + 0] = a[r];
-                    xt[((wave * NT + t) * 16 + q * 4 + r) * 2 + 1] = a[4 + r];
-                }
-            }
-        }
-        __syncthreads();
-        if (tid < NT * 16 * 2) {
-            const int stat = tid / (NT * 16), cl = tid % (NT * 16);
-            float v = 0.f;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) v += xt[((w * NT * 16) + cl) * 2 + stat];
-            const int co = cot0 * 16 + cl;
-            if (co < d.cout) stats_partial[((int64_t)blockIdx.x * 2 + stat) * d.cout + co] = v;
-        }
-    }
+    if (flags & CTL_EPI_STATS) flush_stats(cur_grp);
 }
 
 // ------------------------------------------------------------------------------------------------ weight gradient
@@ -572,6 +592,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ctl_conv d, const
     const int p = lane & 15, q = lane >> 4;
     const int g = blockIdx.y;
     const int cot0 = blockIdx.z * NTW;
+    const int group_n = d.n / (d.groups > 1 ? d.groups : 1);        // images per BatchNorm group (prologue coefficients)
 
     f32x4 acc[TAPS][NTW];
 #pragma unroll
@@ -621,7 +642,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ctl_conv d, const
     if ((int)blockIdx.x < ntiles) {
         xs.load(rx, d, cur.n, cur.th * G::TH, cur.tw * TW, g);
         dyload(cur.n, cur.th * G::TH, cur.tw * TW);
-        xs.store(xt, d, g, pro_scale, pro_shift);
+        xs.store(xt, d, g, pro_scale, pro_shift, (cur.n / group_n) * d.cin);
         dystore();
     }
     __syncthreads();
@@ -657,7 +678,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ctl_conv d, const
         }
         ctl_barrier_lds_reads_done();
         if (has_next) {
-            xs.store(xt, d, g, pro_scale, pro_shift);
+            xs.store(xt, d, g, pro_scale, pro_shift, (cur.n / group_n) * d.cin);
             dystore();
         }
         ctl_barrier_lds_writes_done();
@@ -1004,7 +1025,7 @@ extern "C" int ctl_conv_stats_blocks(const ctl_conv* d) {
 }
 extern "C" size_t ctl_conv_stats_floats(const ctl_conv* d) {
     const int b = ctl_conv_stats_blocks(d);
-    return b < 0 ? 0 : (size_t)b * 2 * d->cout;
+    return b < 0 ? 0 : (size_t)(d->groups > 1 ? d->groups : 1) * b * 2 * d->cout;
 }
 
 extern "C" int ctl_conv_forward(const ctl_conv* d, const float* x, const float* wpack, const float* bias,
@@ -1023,6 +1044,7 @@ extern "C" int ctl_conv_forward(const ctl_conv* d, const float* x, const float* 
     CTL_REQUIRE(!d->pro_affine || (d->pro_slope >= 0.f && d->pro_slope <= 1.f), "conv_forward: prologue slope must be in [0, 1]");
     CTL_REQUIRE(d->epi_act != CTL_ACT_LEAKY || (d->epi_slope >= 0.f && d->epi_slope <= 1.f), "conv_forward: LeakyReLU slope must be in [0, 1]");
     CTL_REQUIRE(d->n > 0 && d->hout > 0 && d->wout > 0, "conv_forward: empty problem");
+    CTL_REQUIRE(d->groups >= 0 && (d->groups <= 1 || d->n % d->groups == 0), "conv_forward: n=%d is not divisible into %d groups", d->n, d->groups);
     CTL_REQUIRE((int64_t)d->n * d->hin * d->win * d->cin * 4 < (1ll << 31) &&
                 (int64_t)d->n * d->out_h * d->out_w * d->cout * 4 < (1ll << 31),
                 "conv_forward: tensors must stay below 2 GiB (32-bit buffer offsets)");

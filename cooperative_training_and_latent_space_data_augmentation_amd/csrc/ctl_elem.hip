@@ -35,53 +35,58 @@ __global__ __launch_bounds__(EB) void bn_finalize_kernel(const float* __restrict
                                                           float* __restrict__ running_var,
                                                           int64_t* __restrict__ nbt, float* __restrict__ scale,
                                                           float* __restrict__ shift, float* __restrict__ save_mean,
-                                                          float* __restrict__ save_invstd) {
+                                                          float* __restrict__ save_invstd, int groups) {
     __shared__ double sm[8];
     const int ch = blockIdx.x;
-    double s1 = 0.0, s2 = 0.0;
-    for (int b = threadIdx.x; b < blocks; b += EB) {
-        s1 += (double)partial[((int64_t)b * 2 + 0) * c + ch];
-        s2 += (double)partial[((int64_t)b * 2 + 1) * c + ch];
-    }
-    s1 = block_sum_double(s1, sm);
-    __syncthreads();
-    s2 = block_sum_double(s2, sm + 4);
-    if (threadIdx.x == 0) {
-        const double mean = s1 / count;
-        double var = s2 / count - mean * mean;   // biased variance, as F.batch_norm normalises with
-        if (var < 0.0) var = 0.0;
-        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-        const float g = gamma[ch], b = beta[ch];
-        const float sc = g * invstd;
-        scale[ch] = sc;
-        shift[ch] = b - (float)mean * sc;
-        if (save_mean) save_mean[ch] = (float)mean;
-        if (save_invstd) save_invstd[ch] = invstd;
-        if (update_running) {   // nn.BatchNorm2d: momentum 0.1, running_var uses the unbiased estimate
-            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-            running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * (float)mean;
-            running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * (float)unbiased;
-            if (ch == 0 && nbt) nbt[0] += 1;
+    // groups = independent passes batched along n: one set of coefficients each; the running statistics see them in order,
+    // exactly as consecutive forward calls would
+    for (int g = 0; g < groups; ++g) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int b = threadIdx.x; b < blocks; b += EB) {
+            s1 += (double)partial[(((int64_t)g * blocks + b) * 2 + 0) * c + ch];
+            s2 += (double)partial[(((int64_t)g * blocks + b) * 2 + 1) * c + ch];
+        }
+        s1 = block_sum_double(s1, sm);
+        __syncthreads();
+        s2 = block_sum_double(s2, sm + 4);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const double mean = s1 / count;
+            double var = s2 / count - mean * mean;   // biased variance, as F.batch_norm normalises with
+            if (var < 0.0) var = 0.0;
+            const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+            const float gm = gamma[ch], bt = beta[ch];
+            const float sc = gm * invstd;
+            scale[g * c + ch] = sc;
+            shift[g * c + ch] = bt - (float)mean * sc;
+            if (save_mean) save_mean[g * c + ch] = (float)mean;
+            if (save_invstd) save_invstd[g * c + ch] = invstd;
+            if (update_running) {   // nn.BatchNorm2d: momentum 0.1, running_var uses the unbiased estimate
+                const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+                running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * (float)mean;
+                running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * (float)unbiased;
+                if (ch == 0 && nbt) nbt[0] += 1;
+            }
         }
     }
 }
 
 __global__ void bn_eval_kernel(int c, const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
-                               float* scale, float* shift) {
+                               float* scale, float* shift, int groups) {
     const int ch = blockIdx.x * blockDim.x + threadIdx.x;
     if (ch < c) {
         const float sc = gamma[ch] / sqrtf(rv[ch] + eps);
-        scale[ch] = sc;
-        shift[ch] = beta[ch] - rm[ch] * sc;
+        const float sh = beta[ch] - rm[ch] * sc;
+        for (int g = 0; g < groups; ++g) { scale[g * c + ch] = sc; shift[g * c + ch] = sh; }
     }
 }
 
 __global__ __launch_bounds__(EB) void bn_act_kernel(const f32x4* __restrict__ x, const f32x4* __restrict__ scale,
                                                      const f32x4* __restrict__ shift, float slope,
-                                                     f32x4* __restrict__ y, int64_t quads, int cq) {
+                                                     f32x4* __restrict__ y, int64_t quads, int cq, int64_t group_quads) {
     const int64_t stride = (int64_t)gridDim.x * EB;
     for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < quads; i += stride) {
-        const int q = (int)(i % cq);
+        const int q = (int)(i % cq) + (int)(i / group_quads) * cq;
         const f32x4 sc = scale[q], sh = shift[q];
         f32x4 v = x[i];
         v.x = ctl_leaky(v.x * sc.x + sh.x, slope); v.y = ctl_leaky(v.y * sc.y + sh.y, slope);
@@ -99,12 +104,17 @@ __global__ __launch_bounds__(EB) void bwd_reduce_kernel(const f32x4* __restrict_
                                                          const f32x4* __restrict__ scale,
                                                          const f32x4* __restrict__ shift, float slope, int64_t quads,
                                                          int cq, float* __restrict__ partial) {
+    // blockIdx.y = BatchNorm group: `quads` is the size of one group, its data start at blockIdx.y * quads
     __shared__ f32x4 sm[2][EB];
     const int64_t gtid = (int64_t)blockIdx.x * EB + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * EB;
     const int q = (int)(gtid % cq);
+    const int64_t gbase = (int64_t)blockIdx.y * quads;
+    dy += gbase;
+    if (MODE == 0) act_src += gbase;
+    if (MODE != 2) bn_src += gbase;
     f32x4 sc = {1, 1, 1, 1}, sh = {0, 0, 0, 0};
-    if (MODE == 1) { sc = scale[q]; sh = shift[q]; }
+    if (MODE == 1) { sc = scale[blockIdx.y * cq + q]; sh = shift[blockIdx.y * cq + q]; }
     f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
     for (int64_t i = gtid; i < quads; i += stride) {
         f32x4 g = dy[i];
@@ -135,7 +145,7 @@ __global__ __launch_bounds__(EB) void bwd_reduce_kernel(const f32x4* __restrict_
         float v = 0.f;
         // threads with (tid % cq) == qq hold this quad (EB % cq == 0 for every cq in use)
         for (int k = qq; k < EB; k += cq) v += sm[stat][k][comp];
-        partial[((int64_t)blockIdx.x * 2 + stat) * c + ch] = v;
+        partial[(((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 + stat) * c + ch] = v;
     }
 }
 
@@ -144,31 +154,35 @@ __global__ __launch_bounds__(EB) void bn_bwd_finalize_kernel(const float* __rest
                                                               const float* __restrict__ save_mean,
                                                               const float* __restrict__ save_invstd,
                                                               float* __restrict__ coef, float* __restrict__ dgamma,
-                                                              float* __restrict__ dbeta, int accumulate) {
+                                                              float* __restrict__ dbeta, int accumulate, int groups) {
     __shared__ double sm[8];
     const int ch = blockIdx.x;
-    double s1 = 0.0, s2 = 0.0;
-    for (int b = threadIdx.x; b < blocks; b += EB) {
-        s1 += (double)partial[((int64_t)b * 2 + 0) * c + ch];
-        s2 += (double)partial[((int64_t)b * 2 + 1) * c + ch];
-    }
-    s1 = block_sum_double(s1, sm);
-    __syncthreads();
-    s2 = block_sum_double(s2, sm + 4);
-    if (threadIdx.x == 0) {
-        const double mu = save_mean[ch], is = save_invstd[ch], g = gamma[ch];
-        const double sum_g = s1;
-        const double sum_gxhat = is * (s2 - mu * s1);
-        const double m1 = sum_g / count, m2 = sum_gxhat / count;
-        // dx = gamma*is*(g - m1 - xhat*m2),  xhat = (x-mu)*is   ==>  dx = A*g + B*x + C
-        const double A = g * is;
-        const double B = -g * is * is * m2;
-        const double C = -g * is * m1 + g * is * is * m2 * mu;
-        coef[ch] = (float)A;
-        coef[c + ch] = (float)B;
-        coef[2 * c + ch] = (float)C;
-        if (dgamma) dgamma[ch] = accumulate ? dgamma[ch] + (float)sum_gxhat : (float)sum_gxhat;
-        if (dbeta) dbeta[ch] = accumulate ? dbeta[ch] + (float)sum_g : (float)sum_g;
+    for (int gi = 0; gi < groups; ++gi) {       // coef[group][3][c]; dgamma/dbeta sum the groups in order
+        double s1 = 0.0, s2 = 0.0;
+        for (int b = threadIdx.x; b < blocks; b += EB) {
+            s1 += (double)partial[(((int64_t)gi * blocks + b) * 2 + 0) * c + ch];
+            s2 += (double)partial[(((int64_t)gi * blocks + b) * 2 + 1) * c + ch];
+        }
+        s1 = block_sum_double(s1, sm);
+        __syncthreads();
+        s2 = block_sum_double(s2, sm + 4);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const double mu = save_mean[gi * c + ch], is = save_invstd[gi * c + ch], g = gamma[ch];
+            const double sum_g = s1;
+            const double sum_gxhat = is * (s2 - mu * s1);
+            const double m1 = sum_g / count, m2 = sum_gxhat / count;
+            // dx = gamma*is*(g - m1 - xhat*m2),  xhat = (x-mu)*is   ==>  dx = A*g + B*x + C
+            const double A = g * is;
+            const double B = -g * is * is * m2;
+            const double C = -g * is * m1 + g * is * is * m2 * mu;
+            coef[(gi * 3 + 0) * c + ch] = (float)A;
+            coef[(gi * 3 + 1) * c + ch] = (float)B;
+            coef[(gi * 3 + 2) * c + ch] = (float)C;
+            const bool acc = accumulate || gi > 0;
+            if (dgamma) dgamma[ch] = acc ? dgamma[ch] + (float)sum_gxhat : (float)sum_gxhat;
+            if (dbeta) dbeta[ch] = acc ? dbeta[ch] + (float)sum_g : (float)sum_g;
+        }
     }
 }
 
@@ -178,10 +192,11 @@ __global__ __launch_bounds__(EB) void bwd_apply_kernel(const f32x4* __restrict__
                                                         const f32x4* __restrict__ scale,
                                                         const f32x4* __restrict__ shift, float slope,
                                                         const f32x4* __restrict__ coef, int64_t quads, int cq,
-                                                        f32x4* __restrict__ ds, f32x4* __restrict__ dx) {
+                                                        f32x4* __restrict__ ds, f32x4* __restrict__ dx, int64_t group_quads) {
     const int64_t stride = (int64_t)gridDim.x * EB;
     for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < quads; i += stride) {
         const int q = (int)(i % cq);
+        const int gi = (int)(i / group_quads);
         f32x4 g = dy[i];
         const f32x4 u = bn_src[i];
         if (MODE == 0) {
@@ -190,11 +205,11 @@ __global__ __launch_bounds__(EB) void bwd_apply_kernel(const f32x4* __restrict__
             g.z *= ctl_leaky_grad(o.z, slope); g.w *= ctl_leaky_grad(o.w, slope);
             if (ds) ds[i] = g;
         } else {
-            const f32x4 sc = scale[q], sh = shift[q];
+            const f32x4 sc = scale[gi * cq + q], sh = shift[gi * cq + q];
             g.x *= ctl_leaky_grad(u.x * sc.x + sh.x, slope); g.y *= ctl_leaky_grad(u.y * sc.y + sh.y, slope);
             g.z *= ctl_leaky_grad(u.z * sc.z + sh.z, slope); g.w *= ctl_leaky_grad(u.w * sc.w + sh.w, slope);
         }
-        const f32x4 A = coef[q], B = coef[cq + q], C = coef[2 * cq + q];
+        const f32x4 A = coef[(gi * 3 + 0) * cq + q], B = coef[(gi * 3 + 1) * cq + q], C = coef[(gi * 3 + 2) * cq + q];
         f32x4 r;
         r.x = A.x * g.x + B.x * u.x + C.x; r.y = A.y * g.y + B.y * u.y + C.y;
         r.z = A.z * g.z + B.z * u.z + C.z; r.w = A.w * g.w + B.w * u.w + C.w;
@@ -378,28 +393,29 @@ __global__ __launch_bounds__(EB) void adam_kernel(float* __restrict__ p, const f
 extern "C" int ctl_bn_finalize(const float* partial, int32_t blocks, int32_t c, int64_t count, const float* gamma,
                                const float* beta, float eps, float momentum, int32_t update_running,
                                float* running_mean, float* running_var, int64_t* nbt, float* scale, float* shift,
-                               float* save_mean, float* save_invstd, ctl_stream stream) {
-    CTL_REQUIRE(partial && gamma && beta && scale && shift && blocks > 0 && c > 0 && count > 0, "bn_finalize: bad arguments");
+                               float* save_mean, float* save_invstd, int32_t groups, ctl_stream stream) {
+    CTL_REQUIRE(partial && gamma && beta && scale && shift && blocks > 0 && c > 0 && count > 0 && groups >= 1, "bn_finalize: bad arguments");
     CTL_REQUIRE(!update_running || (running_mean && running_var), "bn_finalize: update_running without buffers");
     bn_finalize_kernel<<<dim3(c), dim3(EB), 0, S_>>>(partial, blocks, c, (double)count, gamma, beta, eps, momentum,
                                                       update_running, running_mean, running_var, nbt, scale, shift,
-                                                      save_mean, save_invstd);
+                                                      save_mean, save_invstd, groups);
     CTL_LAUNCH_CHECK("bn_finalize");
     return CTL_OK;
 }
 extern "C" int ctl_bn_eval_coeffs(int32_t c, const float* gamma, const float* beta, const float* rm, const float* rv,
-                                  float eps, float* scale, float* shift, ctl_stream stream) {
-    CTL_REQUIRE(c > 0 && gamma && beta && rm && rv && scale && shift, "bn_eval_coeffs: bad arguments");
-    bn_eval_kernel<<<dim3(ctl_cdiv(c, 64)), dim3(64), 0, S_>>>(c, gamma, beta, rm, rv, eps, scale, shift);
+                                  float eps, float* scale, float* shift, int32_t groups, ctl_stream stream) {
+    CTL_REQUIRE(c > 0 && gamma && beta && rm && rv && scale && shift && groups >= 1, "bn_eval_coeffs: bad arguments");
+    bn_eval_kernel<<<dim3(ctl_cdiv(c, 64)), dim3(64), 0, S_>>>(c, gamma, beta, rm, rv, eps, scale, shift, groups);
     CTL_LAUNCH_CHECK("bn_eval_coeffs");
     return CTL_OK;
 }
 extern "C" int ctl_bn_act(const float* x, const float* scale, const float* shift, float slope, float* y, int64_t pixels,
-                          int32_t c, ctl_stream stream) {
-    CTL_REQUIRE(x && y && scale && shift && c % 4 == 0 && pixels > 0, "bn_act: bad arguments (c must be a multiple of 4)");
+                          int32_t c, int32_t groups, ctl_stream stream) {
+    CTL_REQUIRE(x && y && scale && shift && c % 4 == 0 && pixels > 0 && groups >= 1 && pixels % groups == 0,
+                "bn_act: bad arguments (c must be a multiple of 4, pixels of groups)");
     const int64_t quads = pixels * (c / 4);
     bn_act_kernel<<<dim3(stream_blocks(quads)), dim3(EB), 0, S_>>>((const f32x4*)x, (const f32x4*)scale,
-                                                                   (const f32x4*)shift, slope, (f32x4*)y, quads, c / 4);
+                                                                   (const f32x4*)shift, slope, (f32x4*)y, quads, c / 4, quads / groups);
     CTL_LAUNCH_CHECK("bn_act");
     return CTL_OK;
 }
@@ -407,10 +423,10 @@ static bool red_c_ok(int c) { return c >= 4 && c % 4 == 0 && (EB % (c / 4)) == 0
 
 extern "C" int ctl_bwd_reduce(int32_t mode, const float* dy, const float* act_src, const float* bn_src,
                               const float* scale, const float* shift, float slope, int64_t pixels, int32_t c,
-                              float* partial, ctl_stream stream) {
-    CTL_REQUIRE(dy && partial && pixels > 0 && red_c_ok(c), "bwd_reduce: bad arguments (c=%d)", c);
-    const int64_t quads = pixels * (c / 4);
-    const dim3 grid(CTL_RED_BLOCKS), blk(EB);
+                              float* partial, int32_t groups, ctl_stream stream) {
+    CTL_REQUIRE(dy && partial && pixels > 0 && red_c_ok(c) && groups >= 1 && pixels % groups == 0, "bwd_reduce: bad arguments (c=%d)", c);
+    const int64_t quads = (pixels / groups) * (c / 4);           // per group
+    const dim3 grid(CTL_RED_BLOCKS, (unsigned)groups), blk(EB);
     if (mode == 0) {
         CTL_REQUIRE(act_src && bn_src, "bwd_reduce mode 0 needs act_src and bn_src");
         bwd_reduce_kernel<0><<<grid, blk, 0, S_>>>((const f32x4*)dy, (const f32x4*)act_src, (const f32x4*)bn_src, nullptr,
@@ -420,6 +436,7 @@ extern "C" int ctl_bwd_reduce(int32_t mode, const float* dy, const float* act_sr
         bwd_reduce_kernel<1><<<grid, blk, 0, S_>>>((const f32x4*)dy, nullptr, (const f32x4*)bn_src, (const f32x4*)scale,
                                                   (const f32x4*)shift, slope, quads, c / 4, partial);
     } else if (mode == 2) {
+        CTL_REQUIRE(groups == 1, "bwd_reduce mode 2 sums everything: groups must be 1");
         bwd_reduce_kernel<2><<<grid, blk, 0, S_>>>((const f32x4*)dy, nullptr, nullptr, nullptr, nullptr, slope, quads,
                                                   c / 4, partial);
     } else {
@@ -430,28 +447,28 @@ extern "C" int ctl_bwd_reduce(int32_t mode, const float* dy, const float* act_sr
 }
 extern "C" int ctl_bn_bwd_finalize(const float* partial, int32_t c, int64_t count, const float* gamma,
                                    const float* save_mean, const float* save_invstd, float* coef, float* dgamma,
-                                   float* dbeta, int32_t accumulate, ctl_stream stream) {
-    CTL_REQUIRE(partial && gamma && save_mean && save_invstd && coef && c > 0 && count > 0, "bn_bwd_finalize: bad arguments");
+                                   float* dbeta, int32_t accumulate, int32_t groups, ctl_stream stream) {
+    CTL_REQUIRE(partial && gamma && save_mean && save_invstd && coef && c > 0 && count > 0 && groups >= 1, "bn_bwd_finalize: bad arguments");
     bn_bwd_finalize_kernel<<<dim3(c), dim3(EB), 0, S_>>>(partial, CTL_RED_BLOCKS, c, (double)count, gamma, save_mean,
-                                                          save_invstd, coef, dgamma, dbeta, accumulate);
+                                                          save_invstd, coef, dgamma, dbeta, accumulate, groups);
     CTL_LAUNCH_CHECK("bn_bwd_finalize");
     return CTL_OK;
 }
 extern "C" int ctl_bwd_apply(int32_t mode, const float* dy, const float* act_src, const float* bn_src,
                              const float* scale, const float* shift, float slope, const float* coef, int64_t pixels,
-                             int32_t c, float* ds, float* dx, ctl_stream stream) {
-    CTL_REQUIRE(dy && bn_src && coef && dx && pixels > 0 && c % 4 == 0, "bwd_apply: bad arguments");
+                             int32_t c, float* ds, float* dx, int32_t groups, ctl_stream stream) {
+    CTL_REQUIRE(dy && bn_src && coef && dx && pixels > 0 && c % 4 == 0 && groups >= 1 && pixels % groups == 0, "bwd_apply: bad arguments");
     const int64_t quads = pixels * (c / 4);
     const dim3 grid(stream_blocks(quads)), blk(EB);
     if (mode == 0) {
         CTL_REQUIRE(act_src, "bwd_apply mode 0 needs act_src");
         bwd_apply_kernel<0><<<grid, blk, 0, S_>>>((const f32x4*)dy, (const f32x4*)act_src, (const f32x4*)bn_src, nullptr,
-                                                 nullptr, slope, (const f32x4*)coef, quads, c / 4, (f32x4*)ds, (f32x4*)dx);
+                                                 nullptr, slope, (const f32x4*)coef, quads, c / 4, (f32x4*)ds, (f32x4*)dx, quads / groups);
     } else if (mode == 1) {
         CTL_REQUIRE(scale && shift, "bwd_apply mode 1 needs scale and shift");
         bwd_apply_kernel<1><<<grid, blk, 0, S_>>>((const f32x4*)dy, nullptr, (const f32x4*)bn_src, (const f32x4*)scale,
                                                  (const f32x4*)shift, slope, (const f32x4*)coef, quads, c / 4, nullptr,
-                                                 (f32x4*)dx);
+                                                 (f32x4*)dx, quads / groups);
     } else {
         CTL_FAIL(CTL_EINVAL, "bwd_apply: mode %d", mode);
     }

@@ -107,7 +107,7 @@ extern "C" const char* ctl_last_error(void) { return g_err; }
 extern "C" size_t ctl_sizeof_op(void) { return sizeof(ctl_op); }
 extern "C" size_t ctl_sizeof_conv(void) { return sizeof(ctl_conv); }
 
-static_assert(sizeof(ctl_conv) == 22 * 4, "ctl_conv must be 22 32-bit words (it is embedded in ctl_op.i)");
+static_assert(sizeof(ctl_conv) == 23 * 4, "ctl_conv must be 23 32-bit words (it is embedded in ctl_op.i[0..22]; i[23] and i[26] are taken)");
 
 // Side lane: ops with i[26] == 1 (weight gradients and their batched reduction: off the critical dgrad chain) run on a
 // library-owned second stream so that their launches fill the ramp-up / tail bubbles of the main chain.  Fork = event
@@ -160,6 +160,7 @@ extern "C" int ctl_plan_run(const ctl_op* ops, int32_t n_ops, void* const* bases
             t[a] = (char*)bases[s] + op.off[a];
         }
 #define F(a) ((float*)t[a])
+#define NG(v) ((v) > 0 ? (v) : 1)      /* BatchNorm groups: 0 in a record means one group */
 #define CF(a) ((const float*)t[a])
         int rc = CTL_OK;
         ctl_conv d;
@@ -181,22 +182,22 @@ extern "C" int ctl_plan_run(const ctl_op* ops, int32_t n_ops, void* const* bases
                 break;
             case CTL_OP_BN_FINALIZE:
                 rc = ctl_bn_finalize(CF(0), op.i[0], op.i[1], op.l[0], CF(1), CF(2), op.f[0], op.f[1], op.i[2], F(3), F(4),
-                                     (int64_t*)t[5], F(6), F(7), F(8), F(9), stream);
+                                     (int64_t*)t[5], F(6), F(7), F(8), F(9), NG(op.i[3]), stream);
                 break;
             case CTL_OP_BN_EVAL:
-                rc = ctl_bn_eval_coeffs(op.i[0], CF(0), CF(1), CF(2), CF(3), op.f[0], F(4), F(5), stream);
+                rc = ctl_bn_eval_coeffs(op.i[0], CF(0), CF(1), CF(2), CF(3), op.f[0], F(4), F(5), NG(op.i[1]), stream);
                 break;
             case CTL_OP_BN_ACT:
-                rc = ctl_bn_act(CF(0), CF(1), CF(2), op.f[0], F(3), op.l[0], op.i[0], stream);
+                rc = ctl_bn_act(CF(0), CF(1), CF(2), op.f[0], F(3), op.l[0], op.i[0], NG(op.i[1]), stream);
                 break;
             case CTL_OP_BWD_REDUCE:
-                rc = ctl_bwd_reduce(op.i[0], CF(0), CF(1), CF(2), CF(3), CF(4), op.f[0], op.l[0], op.i[1], F(5), stream);
+                rc = ctl_bwd_reduce(op.i[0], CF(0), CF(1), CF(2), CF(3), CF(4), op.f[0], op.l[0], op.i[1], F(5), NG(op.i[2]), stream);
                 break;
             case CTL_OP_BN_BWD_FINALIZE:
-                rc = ctl_bn_bwd_finalize(CF(0), op.i[0], op.l[0], CF(1), CF(2), CF(3), F(4), F(5), F(6), op.i[1], stream);
+                rc = ctl_bn_bwd_finalize(CF(0), op.i[0], op.l[0], CF(1), CF(2), CF(3), F(4), F(5), F(6), op.i[1], NG(op.i[2]), stream);
                 break;
             case CTL_OP_BWD_APPLY:
-                rc = ctl_bwd_apply(op.i[0], CF(0), CF(1), CF(2), CF(3), CF(4), op.f[0], CF(5), op.l[0], op.i[1], F(6), F(7), stream);
+                rc = ctl_bwd_apply(op.i[0], CF(0), CF(1), CF(2), CF(3), CF(4), op.f[0], CF(5), op.l[0], op.i[1], F(6), F(7), NG(op.i[2]), stream);
                 break;
             case CTL_OP_CHAN_SUM_FINALIZE:
                 rc = ctl_chan_sum_finalize(CF(0), op.i[0], F(1), op.i[1], stream);
@@ -230,6 +231,7 @@ extern "C" int ctl_plan_run(const ctl_op* ops, int32_t n_ops, void* const* bases
         }
 #undef F
 #undef CF
+#undef NG
         if (rc != CTL_OK) {
             char msg[400];
             snprintf(msg, sizeof(msg), "%s", g_err);

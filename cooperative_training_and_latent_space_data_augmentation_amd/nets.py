@@ -37,6 +37,7 @@ N_SLOTS = 15
 SLOPE = 0.2
 EPS = 1e-5
 MOMENTUM = 0.1
+CONV_WORDS = _ffi.CONV_DTYPE.itemsize // 4      # ctl_conv as int32 words at the head of ctl_op.i
 ALIGN_F = 64            # floats (256 B)
 
 T = namedtuple("T", "ref n h w c")     # tensor descriptor: ref = (slot, byte offset), NHWC dims
@@ -92,12 +93,14 @@ class Arena:
 
 
 class Plan:
-    __slots__ = ("ops", "n_ops", "act_bytes", "scr_bytes", "bscr_bytes", "rec", "out_shapes", "table_np", "table_dev")
+    __slots__ = ("ops", "n_ops", "act_bytes", "scr_bytes", "bscr_bytes", "rec", "out_shapes", "table_np", "table_dev", "groups")
 
 
 class PlanBuilder:
     def __init__(self, net: "CtlNet"):
         self.net = net
+        # BatchNorm groups: independent passes batched along n (each keeps its own statistics), see ctl_conv.groups
+        self.groups = int(getattr(net, "_cur_groups", 1))
         self.ops: List[np.ndarray] = []
         self.act = Arena(S_ACT)
         self.bscr = Arena(S_BSCR)
@@ -143,6 +146,7 @@ class PlanBuilder:
                            pro_slope=pro[2] if pro else 0.0, epi_flags=flags, epi_act=act, epi_slope=slope)
         if nsub == 4:
             d["out_h"], d["out_w"], d["out_sy"], d["out_sx"], d["nsub"], d["out_sub"] = 2 * hout, 2 * wout, 2, 2, 4, 1
+        d["groups"] = self.groups
         return d
 
     def conv(self, x: T, wp_ref, cout, ks, *, stride=1, in_mode=0, pro=None, bias_ref=None, stats=False, act=0,
@@ -165,13 +169,13 @@ class PlanBuilder:
             out = (arena or self.act).tensor(x.n, oh, ow, cout)
         assert (out.n, out.h, out.w, out.c) == (x.n, oh, ow, cout), (out, x.n, oh, ow, cout)
         op = self.op(_ffi.OP_CONV)
-        op["i"][:22] = np.frombuffer(d.tobytes(), dtype="<i4")
+        op["i"][:CONV_WORDS] = np.frombuffer(d.tobytes(), dtype="<i4")
         stats_ref, blocks = None, 0
         if stats:
             blocks = lib.ctl_conv_stats_blocks(_ffi.desc_ptr(d))
             if blocks <= 0:
                 raise _ffi.CtlError("conv plan: " + lib.ctl_last_error().decode())
-            stats_ref, = self.scr(4 * blocks * 2 * cout)
+            stats_ref, = self.scr(4 * self.groups * blocks * 2 * cout)
         for idx, ref in enumerate([x.ref, wp_ref, bias_ref, pro[0] if pro else None, pro[1] if pro else None,
                                    res[0].ref if res else None, res[1] if res else None, res[2] if res else None,
                                    out.ref, stats_ref]):
@@ -190,7 +194,7 @@ class PlanBuilder:
         bref = self.bscr.alloc(bb) if dbias_ref is not None else None
         words = np.frombuffer(d.tobytes(), dtype="<i4")
         op = self.op(_ffi.OP_WGRAD)
-        op["i"][:22] = words
+        op["i"][:CONV_WORDS] = words
         op["i"][26] = 1                    # side lane: off the critical dgrad chain (see ctl_plan.cpp)
         for idx, ref in enumerate([x.ref, pro[0] if pro else None, pro[1] if pro else None, dy.ref, wref, bref]):
             self.set_t(op, idx, ref)
@@ -218,18 +222,20 @@ class PlanBuilder:
     # -- BatchNorm
     def bn_forward(self, bn: BNInfo, stats_ref, blocks, count, mode: str):
         """Returns dict(scale, shift, mean, invstd) of refs living in the ACT arena."""
-        c = bn.c
-        co = {k: self.act.alloc(4 * c) for k in ("scale", "shift", "mean", "invstd")}
+        c, G = bn.c, self.groups
+        assert count % G == 0
+        count //= G                                   # the statistics of one group
+        co = {k: self.act.alloc(4 * c * G) for k in ("scale", "shift", "mean", "invstd")}      # [groups][c] each
         if mode == "C":
             op = self.op(_ffi.OP_BN_EVAL)
-            op["i"][0] = c
+            op["i"][0], op["i"][1] = c, G
             op["f"][0] = EPS
             for idx, ref in enumerate([self.P(bn.g_off), self.P(bn.b_off), (S_B, 4 * bn.rm_off), (S_B, 4 * bn.rv_off),
                                        co["scale"], co["shift"]]):
                 self.set_t(op, idx, ref)
             return co
         op = self.op(_ffi.OP_BN_FINALIZE)
-        op["i"][0], op["i"][1], op["i"][2] = blocks, c, 1 if mode == "A" else 0
+        op["i"][0], op["i"][1], op["i"][2], op["i"][3] = blocks, c, 1 if mode == "A" else 0, G
         op["l"][0] = count
         op["f"][0], op["f"][1] = EPS, MOMENTUM
         for idx, ref in enumerate([stats_ref, self.P(bn.g_off), self.P(bn.b_off), (S_B, 4 * bn.rm_off),
@@ -240,7 +246,7 @@ class PlanBuilder:
 
     def bn_act(self, x: T, co, slope, out: T):
         op = self.op(_ffi.OP_BN_ACT)
-        op["i"][0] = x.c
+        op["i"][0], op["i"][1] = x.c, self.groups
         op["l"][0] = x.n * x.h * x.w
         op["f"][0] = slope
         for idx, ref in enumerate([x.ref, co["scale"], co["shift"], out.ref]):
@@ -249,23 +255,23 @@ class PlanBuilder:
     def bn_backward(self, mode_kind: int, dy: T, act_src: Optional[T], bn_src: T, bn: BNInfo, co, slope, *, ds: Optional[T],
                     dx: T, affine_grad: bool):
         """reduce -> finalize -> apply.  mode_kind 0 = residual tail, 1 = BN->activation tail."""
-        c, pixels = bn_src.c, bn_src.n * bn_src.h * bn_src.w
-        part, = self.scr(4 * _ffi.RED_BLOCKS * 2 * c)
-        coef = self.bscr.alloc(4 * 3 * c)
+        c, pixels, G = bn_src.c, bn_src.n * bn_src.h * bn_src.w, self.groups
+        part, = self.scr(4 * G * _ffi.RED_BLOCKS * 2 * c)
+        coef = self.bscr.alloc(4 * 3 * c * G)
         op = self.op(_ffi.OP_BWD_REDUCE)
-        op["i"][0], op["i"][1] = mode_kind, c
+        op["i"][0], op["i"][1], op["i"][2] = mode_kind, c, G
         op["l"][0] = pixels
         op["f"][0] = slope
         for idx, ref in enumerate([dy.ref, act_src.ref if act_src else None, bn_src.ref, co["scale"], co["shift"], part]):
             self.set_t(op, idx, ref)
         op = self.op(_ffi.OP_BN_BWD_FINALIZE)
-        op["i"][0], op["i"][1] = c, 0
-        op["l"][0] = pixels
+        op["i"][0], op["i"][1], op["i"][2] = c, 0, G
+        op["l"][0] = pixels // G
         for idx, ref in enumerate([part, self.P(bn.g_off), co["mean"], co["invstd"], coef,
                                    self.G(bn.g_off) if affine_grad else None, self.G(bn.b_off) if affine_grad else None]):
             self.set_t(op, idx, ref)
         op = self.op(_ffi.OP_BWD_APPLY)
-        op["i"][0], op["i"][1] = mode_kind, c
+        op["i"][0], op["i"][1], op["i"][2] = mode_kind, c, G
         op["l"][0] = pixels
         op["f"][0] = slope
         for idx, ref in enumerate([dy.ref, act_src.ref if act_src else None, bn_src.ref, co["scale"], co["shift"], coef,
@@ -317,6 +323,7 @@ class PlanBuilder:
         p.n_ops = len(self.ops)
         p.act_bytes, p.scr_bytes, p.bscr_bytes = self.act.size, self.scr_bytes, self.bscr.size
         p.rec, p.out_shapes = rec, out_shapes
+        p.groups = self.groups
         return p
 
 
@@ -614,15 +621,22 @@ class CtlNet(nn.Module):
         n, h, w, c = shape
         return torch.empty((n, c, h, w), dtype=torch.float32, device=self.device, memory_format=torch.channels_last)
 
-    def run_forward(self, x: torch.Tensor, mode: str):
-        """Returns (outputs tuple, act workspace tensor, plan).  x: logical NCHW, NHWC memory."""
+    def run_forward(self, x: torch.Tensor, mode: str, groups: int = 1):
+        """Returns (outputs tuple, act workspace tensor, plan).  x: logical NCHW, NHWC memory.  groups > 1: x stacks that many
+        independent batches along n; BatchNorm treats each on its own (statistics, running-stat updates in order)."""
         n, c, h, w = x.shape
         if c != self.cin:
             raise ValueError(f"{type(self).__name__}: expected {self.cin} input channels, got {c}")
-        key = ("f", n, h, w, mode)
+        if groups < 1 or n % groups:
+            raise ValueError(f"{type(self).__name__}: batch {n} cannot be split into {groups} groups")
+        key = ("f", n, h, w, mode, groups)
         plan = self._plans.get(key)
         if plan is None:
-            plan = self._plans[key] = self._compile_forward(n, h, w, mode)
+            self._cur_groups = groups
+            try:
+                plan = self._plans[key] = self._compile_forward(n, h, w, mode)
+            finally:
+                self._cur_groups = 1
         self.ensure_packed()
         act = torch.empty(max(plan.act_bytes, 256), dtype=torch.uint8, device=self.device)
         outs = [self._alloc_out(s) for s in plan.out_shapes]
@@ -636,10 +650,14 @@ class CtlNet(nn.Module):
         """Returns (dx or None, flat parameter gradient or None)."""
         n, c, h, w = x.shape
         mask = tuple(d is not None for d in douts)
-        key = ("b", n, h, w, mode, mask, need_dx, need_w, affine)
+        key = ("b", n, h, w, mode, mask, need_dx, need_w, affine, fwd_plan.groups)
         plan = self._plans.get(key)
         if plan is None:
-            plan = self._plans[key] = self._compile_backward(fwd_plan, mode, mask, need_dx, need_w, affine)
+            self._cur_groups = fwd_plan.groups
+            try:
+                plan = self._plans[key] = self._compile_backward(fwd_plan, mode, mask, need_dx, need_w, affine)
+            finally:
+                self._cur_groups = 1
         bscr = torch.empty(max(plan.bscr_bytes, 256), dtype=torch.uint8, device=self.device)
         self._dbg_last = (plan, bscr)          # lets tests inspect intermediate gradients
         tensors = {S_X: x, S_P: self._flat_data, S_WP: self._wp, S_ACT: act, S_BSCR: bscr, S_OUT0: outs[0]}

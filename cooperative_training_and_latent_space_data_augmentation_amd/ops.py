@@ -88,20 +88,21 @@ def conv_wgrad(d: np.ndarray, x, dy, dw: torch.Tensor, strides, dbias: Optional[
 
 
 # ---------------------------------------------------------------------------------------------- BN pieces
-def bn_finalize(partial, c, count, gamma, beta, eps=1e-5, momentum=0.1, running_mean=None, running_var=None, nbt=None):
+def bn_finalize(partial, c, count, gamma, beta, eps=1e-5, momentum=0.1, running_mean=None, running_var=None, nbt=None, groups=1):
+    """partial: [groups][blocks][2][c]; `count` = pixels of one group.  Returns scale, shift, mean, invstd, each [groups*c]."""
     dev = partial.device
-    scale, shift, mean, invstd = (torch.empty(c, dtype=torch.float32, device=dev) for _ in range(4))
-    blocks = partial.numel() // (2 * c)
+    scale, shift, mean, invstd = (torch.empty(groups * c, dtype=torch.float32, device=dev) for _ in range(4))
+    blocks = partial.numel() // (2 * c * groups)
     check(lib.ctl_bn_finalize(ptr(partial), blocks, c, count, ptr(gamma), ptr(beta), eps, momentum,
                               int(running_mean is not None), ptr(running_mean), ptr(running_var), ptr(nbt), ptr(scale),
-                              ptr(shift), ptr(mean), ptr(invstd), stream_ptr()), "ctl_bn_finalize")
+                              ptr(shift), ptr(mean), ptr(invstd), groups, stream_ptr()), "ctl_bn_finalize")
     return scale, shift, mean, invstd
 
 
-def bn_act(x, scale, shift, slope):
+def bn_act(x, scale, shift, slope, groups=1):
     y = torch.empty_like(x)
     n, c, h, w = x.shape
-    check(lib.ctl_bn_act(ptr(x), ptr(scale), ptr(shift), slope, ptr(y), n * h * w, c, stream_ptr()), "ctl_bn_act")
+    check(lib.ctl_bn_act(ptr(x), ptr(scale), ptr(shift), slope, ptr(y), n * h * w, c, groups, stream_ptr()), "ctl_bn_act")
     return y
 
 

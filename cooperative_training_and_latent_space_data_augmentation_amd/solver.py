@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .autograd import cross_entropy_2D, scaled_mse, softmax_t
+from .autograd import cross_entropy_2D, net_apply, scaled_mse, softmax_t
 from .metrics import runningScore
 from .model_util import (_disable_tracking_bn_stats, _draw_seed, mask_latent_code_channel_wise,
                          mask_latent_code_spatial_wise, set_grad)
@@ -64,6 +64,9 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
         self.z_i = self.z_s = None
         self.last_masks = {}
         self.grad_scale = 1.0          # set to 1/world_size by the data-parallel wrapper
+        # independent STN passes of one step that share the BatchNorm mode run as one grouped pass (recon_shape_pair); off = one
+        # pass per reference call
+        self.group_stn_passes = os.environ.get("CTL_GROUP_STN", "1") != "0"
         self.training = True
 
     # ------------------------------------------------------------------ construction / checkpoints
@@ -216,6 +219,28 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
     def recon_shape(self, segmentation_logit, is_label_map=False, disable_track_bn_stats=False):
         return self.decode_shape(self.encode_shape(segmentation_logit, is_label_map, disable_track_bn_stats), disable_track_bn_stats)
 
+    def recon_shape_pair(self, seg_a, a_is_label_map, seg_b, b_is_label_map, disable_track_bn_stats=False, temperature=2):
+        """recon_shape(seg_a, a_is_label_map) followed by recon_shape(seg_b, b_is_label_map) in the same BatchNorm mode, run as
+        ONE pass over the stacked batch with per-call BatchNorm statistics (ctl_conv.groups): the same numbers as the two
+        calls (running statistics updated in call order), half the launches.  Returns (recon_a, recon_b)."""
+        def stn_input(seg, is_label_map):
+            return ops.onehot(seg, self.num_classes) if is_label_map else softmax_t(seg, temperature)
+        ia, ib = stn_input(seg_a, a_is_label_map), stn_input(seg_b, b_is_label_map)
+        n = ia.shape[0]
+        if ib.shape != ia.shape:
+            raise ValueError("recon_shape_pair: both inputs must have the same shape")
+        inp = torch.cat([ia, ib], 0)
+        enc, dec = self.model["shape_encoder"], self.model["shape_decoder"]
+        if disable_track_bn_stats:
+            with _disable_tracking_bn_stats(enc), _disable_tracking_bn_stats(dec):
+                code = net_apply(enc, inp, groups=2)[0]
+                out = net_apply(dec, code, groups=2)[0]
+        else:
+            code = net_apply(enc, inp, groups=2)[0]
+            out = net_apply(dec, code, groups=2)[0]
+        self.latent_code["shape"] = code[n:]
+        return out[:n], out[n:]
+
     def recon_image(self, image, disable_track_bn_stats=False):
         z_i, _ = self.encode_image(image, disable_track_bn_stats)
         return self.decode_image(z_i, disable_track_bn_stats)
@@ -261,13 +286,18 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
         standard_supervised_loss = basic_loss_fn(y_0, label_l.detach(), "cross entropy")
         image_recon = self.decode_image(z_i)                           # always BN mode A, as upstream (model.py:444)
         image_recon_loss = scaled_mse(image_recon, clean_image_l, 0.5)
-        if compute_gt_recon:
-            gt_recon = self.recon_shape(label_l.detach(), is_label_map=True)
+        y_0_new = y_0.detach() if separate_training else y_0
+        if compute_gt_recon and self.group_stn_passes and not disable_track_bn_stats and self.training:
+            # the two STN passes are independent and share the BatchNorm mode: one grouped pass (same order: gt, then p)
+            gt_recon, p_recon = self.recon_shape_pair(label_l.detach(), True, y_0_new, False)
             gt_shape_recon_loss = basic_loss_fn(gt_recon, label_l, "cross entropy")
         else:
-            gt_shape_recon_loss = zero
-        y_0_new = y_0.detach() if separate_training else y_0
-        p_recon = self.recon_shape(y_0_new, is_label_map=False, disable_track_bn_stats=disable_track_bn_stats)
+            if compute_gt_recon:
+                gt_recon = self.recon_shape(label_l.detach(), is_label_map=True)
+                gt_shape_recon_loss = basic_loss_fn(gt_recon, label_l, "cross entropy")
+            else:
+                gt_shape_recon_loss = zero
+            p_recon = self.recon_shape(y_0_new, is_label_map=False, disable_track_bn_stats=disable_track_bn_stats)
         pred_shape_recon_loss = basic_loss_fn(p_recon, label_l, "cross entropy")
         return standard_supervised_loss, image_recon_loss, gt_shape_recon_loss, pred_shape_recon_loss
 
@@ -275,6 +305,19 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
         dev = clean_image_l.device
         zero = torch.zeros((), device=dev)
         seg_loss = recon_loss = shape_loss = perturbed_p_recon_loss = zero
+        if perturbed_image is not None and perturbed_seg is not None and self.group_stn_passes and self.training:
+            # FTN pass on the hard image, then both STN passes (prediction of the hard image, corrupted segmentation: independent,
+            # both with frozen BatchNorm statistics tracking) as one grouped pass
+            (z_i, _), y_0 = self.fast_predict(perturbed_image.detach(), disable_track_bn_stats=True)
+            seg_loss = basic_loss_fn(y_0, label_l.detach(), "cross entropy")
+            recon_loss = scaled_mse(self.decode_image(z_i), clean_image_l, 0.5)
+            if separate_training:
+                perturbed_seg = perturbed_seg.detach()
+            p_recon, perturbed_p_recon = self.recon_shape_pair(y_0.detach() if separate_training else y_0, False, perturbed_seg, False,
+                                                               disable_track_bn_stats=True)
+            shape_loss = basic_loss_fn(p_recon, label_l, "cross entropy")
+            perturbed_p_recon_loss = basic_loss_fn(perturbed_p_recon, label_l, "cross entropy")
+            return seg_loss, recon_loss, shape_loss, perturbed_p_recon_loss
         if perturbed_image is not None:
             seg_loss, recon_loss, _, shape_loss = self.standard_training(
                 clean_image_l=clean_image_l, label_l=label_l, perturbed_image=perturbed_image.detach(), compute_gt_recon=False,

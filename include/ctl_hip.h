@@ -55,11 +55,14 @@ typedef struct ctl_conv {
     int32_t out_h, out_w;            /* output tensor [n,out_h,out_w,cout]; pixel (ho,wo) of sub-problem z     */
     int32_t out_sy, out_sx;          /*   lands at (ho*out_sy + z/2*out_sub, wo*out_sx + z%2*out_sub)          */
     int32_t nsub, out_sub;           /* nsub = 1 (plain) or 4 (ConvTranspose k2s2: out_sy=out_sx=2,out_sub=1)  */
+    int32_t groups;                  /* BatchNorm groups along n (0/1 = one): images [g*n/groups, (g+1)*n/groups) use row g of
+                                        pro_scale/pro_shift/res_scale/res_shift ([groups][c]) and get their own statistics
+                                        partials -- several independent passes of one network batched into one launch   */
 } ctl_conv;
 
 /* number of floats of the packed weight buffer for one sub-problem, and of the statistics partial buffer */
 size_t ctl_conv_wpack_floats(int32_t cin, int32_t cout, int32_t ks);
-size_t ctl_conv_stats_floats(const ctl_conv* d);     /* [blocks][2][cout] */
+size_t ctl_conv_stats_floats(const ctl_conv* d);     /* [groups][blocks][2][cout] */
 int    ctl_conv_stats_blocks(const ctl_conv* d);
 
 /* Pack weights into MFMA-fragment order.  Element (co,ci,kh,kw) of the *effective* conv is read from
@@ -99,19 +102,22 @@ int ctl_wgrad_reduce_batched(const float* scratch, float* grad, const int64_t* t
 
 /* ------------------------------------------------------------------------------------------------ BatchNorm2d
  * encdec.py: every `norm(out_ch)`; three modes of SURVEY 8a row 4 (util.py:414-451).
+ * `groups` (>= 1): independent passes of one network batched along n (ctl_conv.groups).  Statistics partials are
+ * [groups][blocks][2][c], every coefficient vector is [groups][c] (coef: [groups][3][c]), `count` is the pixel count of
+ * ONE group, `pixels` the total; running statistics and dgamma/dbeta see the groups in order, as consecutive calls would.
  * finalize: partial [blocks][2][c] (sum, sum of squares over `count` pixels) -> scale=gamma*invstd,
  * shift=beta-mean*scale, save_mean, save_invstd; if update_running: running stats (momentum, unbiased var) and
  * num_batches_tracked (int64) are updated in place. */
 int ctl_bn_finalize(const float* partial, int32_t blocks, int32_t c, int64_t count, const float* gamma,
                     const float* beta, float eps, float momentum, int32_t update_running, float* running_mean,
                     float* running_var, int64_t* num_batches_tracked, float* scale, float* shift, float* save_mean,
-                    float* save_invstd, ctl_stream stream);
+                    float* save_invstd, int32_t groups, ctl_stream stream);
 /* eval mode: scale = gamma/sqrt(running_var+eps), shift = beta - running_mean*scale */
 int ctl_bn_eval_coeffs(int32_t c, const float* gamma, const float* beta, const float* running_mean,
-                       const float* running_var, float eps, float* scale, float* shift, ctl_stream stream);
+                       const float* running_var, float eps, float* scale, float* shift, int32_t groups, ctl_stream stream);
 /* y = leaky(x*scale[c]+shift[c], slope)  (slope 0 = ReLU, slope 1 = identity) */
 int ctl_bn_act(const float* x, const float* scale, const float* shift, float slope, float* y, int64_t pixels,
-               int32_t c, ctl_stream stream);
+               int32_t c, int32_t groups, ctl_stream stream);
 
 /* backward helpers; `partial` buffers are [CTL_RED_BLOCKS][2][c] floats */
 #define CTL_RED_BLOCKS 512
@@ -119,16 +125,17 @@ int ctl_bn_act(const float* x, const float* scale, const float* shift, float slo
  * mode 1 (BN->act tail):                    g = da * leaky'(u*scale+shift); sums: sum g, sum g*u
  * mode 2 (plain):                           g = da;                         sums: sum g, (unused)          */
 int ctl_bwd_reduce(int32_t mode, const float* dy, const float* act_src, const float* bn_src, const float* scale,
-                   const float* shift, float slope, int64_t pixels, int32_t c, float* partial, ctl_stream stream);
+                   const float* shift, float slope, int64_t pixels, int32_t c, float* partial, int32_t groups,
+                   ctl_stream stream);
 /* partial -> coefficients A,B,C with dx = A*g + B*bn_src + C (training-mode BN backward), and, if dgamma/dbeta
  * are non-NULL, dgamma += sum g*xhat, dbeta += sum g (accumulate ? += : =). */
 int ctl_bn_bwd_finalize(const float* partial, int32_t c, int64_t count, const float* gamma, const float* save_mean,
                         const float* save_invstd, float* coef, float* dgamma, float* dbeta, int32_t accumulate,
-                        ctl_stream stream);
+                        int32_t groups, ctl_stream stream);
 /* mode 0: ds = dout*leaky'(out) (written if ds != NULL), dv = A*ds + B*v + C;  mode 1: du = A*g + B*u + C */
 int ctl_bwd_apply(int32_t mode, const float* dy, const float* act_src, const float* bn_src, const float* scale,
                   const float* shift, float slope, const float* coef, int64_t pixels, int32_t c, float* ds,
-                  float* dx, ctl_stream stream);
+                  float* dx, int32_t groups, ctl_stream stream);
 /* partial[blocks][2][c] -> out[c] (+)= sum over blocks of row 0 (bias gradient of ConvTranspose2d) */
 int ctl_chan_sum_finalize(const float* partial, int32_t c, float* out, int32_t accumulate, ctl_stream stream);
 /* nearest-upsample backward: dx[n,h,w,c] = sum of the 2x2 block of dup[n,2h,2w,c]; accumulate ? += : = */
@@ -197,7 +204,7 @@ enum ctl_op_kind {
 #define CTL_OP_MAX_T 12
 typedef struct ctl_op {
     int32_t kind;
-    int32_t i[27];                    /* CONV/WGRAD/WGRAD_REDUCE: i[0..21] = ctl_conv as int32 words, i[23] = accumulate; others: see
+    int32_t i[27];                    /* CONV/WGRAD/WGRAD_REDUCE: i[0..22] = ctl_conv as int32 words, i[23] = accumulate; others: see
                                          ctl_plan.cpp; i[26] = lane (0 main stream, 1 side stream: weight-gradient work) */
     float   f[4];
     int32_t slot[CTL_OP_MAX_T];       /* -1 = NULL */

@@ -131,6 +131,55 @@ def test_network_forward_backward_vs_oracle(name, mode, golden_sd):
         assert int(hb[[k for k in hb if k.endswith("num_batches_tracked")][0]]) == 0
 
 
+@pytest.mark.parametrize("mode", ["A", "B"])
+@pytest.mark.parametrize("name,n", [("shape_encoder", 3), ("shape_decoder", 2), ("image_encoder", 16), ("segmentation_decoder", 5)])
+def test_grouped_pass_equals_consecutive_passes(name, n, mode, golden_sd):
+    """One pass over two stacked batches with BatchNorm groups (ctl_conv.groups = 2) == the two passes one after the other:
+    outputs, input gradients, accumulated parameter gradients, running statistics (updated in call order)."""
+    from cooperative_training_and_latent_space_data_augmentation_amd.autograd import net_apply
+    c, h, w = NET_INPUT[name]
+    if name == "image_encoder":
+        h, w = 96, 80                       # several tiles per image and 16 images: blocks walk across the group boundary
+    if "decoder" in name:
+        h, w = 4 * h, 4 * w                 # enough pixels per BatchNorm group for a well-conditioned backward
+    g = torch.Generator().manual_seed(11)
+    xa, xb = torch.rand(n, c, h, w, generator=g), torch.rand(n, c, h, w, generator=g) * 1.7 - 0.2
+    nets_ = [nets.build_networks(device=DEV, state_dicts={name: golden_sd[name]})[name] for _ in range(2)]
+    res = []
+    for net, grouped in zip(nets_, (False, True)):
+        net.train()
+        xs = [dev(xa).requires_grad_(True), dev(xb).requires_grad_(True)]
+        ctx = _disable_tracking_bn_stats(net) if mode == "B" else None
+        if ctx is not None:
+            ctx.__enter__()
+        if grouped:
+            outs = net_apply(net, torch.cat(xs, 0), groups=2)
+            outs = [tuple(o[:n] for o in outs), tuple(o[n:] for o in outs)]
+        else:
+            outs = [net_apply(net, xs[0]), net_apply(net, xs[1])]
+        if ctx is not None:
+            ctx.__exit__(None, None, None)
+        gg = torch.Generator().manual_seed(5)
+        douts = [[torch.randn(o.shape, generator=gg) for o in oo] for oo in outs]
+        torch.autograd.backward([o for oo in outs for o in oo], [dev(d) for dd in douts for d in dd])
+        res.append((outs, [x.grad for x in xs], {k: v.grad.clone() for k, v in net.named_parameters()},
+                    {k: v.clone() for k, v in net.named_buffers()}))
+    (o1, dx1, g1, b1), (o2, dx2, g2, b2) = res
+    for oa, ob in zip(o1, o2):
+        for a, b in zip(oa, ob):
+            close(b, a, atol=2e-5, rel=1e-5, what=f"{name} grouped output")
+    for a, b in zip(dx1, dx2):
+        close(b, a, atol=1e-6, rel=2e-4, what=f"{name} grouped dx")
+    for k in g1:
+        if is_dead_bias(k):
+            continue
+        close(g2[k], g1[k], atol=2e-6, rel=2e-4, what=f"{name} grouped grad {k}")
+    for k in b1:
+        close(b2[k].double(), b1[k].double(), atol=1e-6, rel=1e-6, what=f"{name} grouped buffer {k}")
+    nbt = [k for k in b2 if k.endswith("num_batches_tracked")][0]
+    assert int(b2[nbt]) == (2 if mode == "A" else 0)
+
+
 @pytest.mark.parametrize("name", list(NET_INPUT))
 def test_network_eval_mode_vs_oracle(name, golden_sd):
     onet, hnet = make_pair(name, golden_sd)

@@ -165,7 +165,7 @@ def test_conv_transpose2x2_forward_dgrad_wgrad(n, c, h, w):
     part = torch.empty(_ffi.RED_BLOCKS * 2 * c, device=DEV)
     db = torch.zeros(c, device=DEV)
     dyd = dev(dy)
-    check(lib.ctl_bwd_reduce(2, dyd.data_ptr(), None, None, None, None, 0.0, n * 4 * h * w, c, part.data_ptr(), ops.stream_ptr()))
+    check(lib.ctl_bwd_reduce(2, dyd.data_ptr(), None, None, None, None, 0.0, n * 4 * h * w, c, part.data_ptr(), 1, ops.stream_ptr()))
     check(lib.ctl_chan_sum_finalize(part.data_ptr(), c, db.data_ptr(), 0, ops.stream_ptr()))
     close(db, b.grad, what="convT bias grad")
 
@@ -224,7 +224,7 @@ def test_batchnorm_forward_stats_and_backward(n, c, h, w):
     part = torch.empty(_ffi.RED_BLOCKS * 2 * c, device=DEV)
     # sum u and sum u*u through bwd_reduce mode 0 with act_src=ones (leaky'(1)=1): g=u, sums: sum u, sum u*u
     ones = torch.ones_like(ud)
-    check(lib.ctl_bwd_reduce(0, ud.data_ptr(), ones.data_ptr(), ud.data_ptr(), None, None, 0.2, M, c, part.data_ptr(), ops.stream_ptr()))
+    check(lib.ctl_bwd_reduce(0, ud.data_ptr(), ones.data_ptr(), ud.data_ptr(), None, None, 0.2, M, c, part.data_ptr(), 1, ops.stream_ptr()))
     rmd, rvd, nbt = dev(rm0), dev(rv0), torch.zeros(1, dtype=torch.int64, device=DEV)
     scale, shift, mean, invstd = ops.bn_finalize(part, c, M, dev(gamma.detach()), dev(beta.detach()), running_mean=rmd,
                                                  running_var=rvd, nbt=nbt)
@@ -238,13 +238,13 @@ def test_batchnorm_forward_stats_and_backward(n, c, h, w):
     dad = dev(da)
     coef = torch.empty(3 * c, device=DEV)
     dgamma, dbeta = torch.zeros(c, device=DEV), torch.zeros(c, device=DEV)
-    check(lib.ctl_bwd_reduce(1, dad.data_ptr(), None, ud.data_ptr(), scale.data_ptr(), shift.data_ptr(), 0.2, M, c, part.data_ptr(), ops.stream_ptr()))
+    check(lib.ctl_bwd_reduce(1, dad.data_ptr(), None, ud.data_ptr(), scale.data_ptr(), shift.data_ptr(), 0.2, M, c, part.data_ptr(), 1, ops.stream_ptr()))
     gd = dev(gamma.detach())
     check(lib.ctl_bn_bwd_finalize(part.data_ptr(), c, M, gd.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
-                                  coef.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), 0, ops.stream_ptr()))
+                                  coef.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), 0, 1, ops.stream_ptr()))
     du = torch.empty_like(ud)
     check(lib.ctl_bwd_apply(1, dad.data_ptr(), None, ud.data_ptr(), scale.data_ptr(), shift.data_ptr(), 0.2, coef.data_ptr(), M, c,
-                            None, du.data_ptr(), ops.stream_ptr()))
+                            None, du.data_ptr(), 1, ops.stream_ptr()))
     close(du, u.grad, rel=5e-4, what="BN backward dx")
     close(dgamma, gamma.grad, rel=5e-4, what="dgamma")
     close(dbeta, beta.grad, rel=5e-4, what="dbeta")
@@ -266,12 +266,12 @@ def test_residual_tail_backward():
     part = torch.empty(_ffi.RED_BLOCKS * 2 * c, device=DEV)
     coef = torch.empty(3 * c, device=DEV)
     gd, md, isd = dev(gamma), dev(mean), dev(invstd)     # keep alive: raw pointers below
-    check(lib.ctl_bwd_reduce(0, doutd.data_ptr(), outd.data_ptr(), vd.data_ptr(), None, None, 0.2, M, c, part.data_ptr(), ops.stream_ptr()))
+    check(lib.ctl_bwd_reduce(0, doutd.data_ptr(), outd.data_ptr(), vd.data_ptr(), None, None, 0.2, M, c, part.data_ptr(), 1, ops.stream_ptr()))
     check(lib.ctl_bn_bwd_finalize(part.data_ptr(), c, M, gd.data_ptr(), md.data_ptr(), isd.data_ptr(),
-                                  coef.data_ptr(), None, None, 0, ops.stream_ptr()))
+                                  coef.data_ptr(), None, None, 0, 1, ops.stream_ptr()))
     ds, dv = torch.empty_like(vd), torch.empty_like(vd)
     check(lib.ctl_bwd_apply(0, doutd.data_ptr(), outd.data_ptr(), vd.data_ptr(), None, None, 0.2, coef.data_ptr(), M, c,
-                            ds.data_ptr(), dv.data_ptr(), ops.stream_ptr()))
+                            ds.data_ptr(), dv.data_ptr(), 1, ops.stream_ptr()))
     close(ds, r.grad, rel=1e-5, what="ds")
     close(dv, v.grad, rel=5e-4, what="dv")
 
