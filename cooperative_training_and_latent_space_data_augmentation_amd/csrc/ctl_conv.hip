@@ -553,10 +553,12 @@ __global__ __launch_bounds__(256, (MT * NT >= 8) ? 2 : ((MT * NT >= 4) ? CTL_LB_
         if (g2 == 0) cur = nxt;
         g = g2;
     }
+#ifndef CTL_TIMING_WGRAD
 #ifdef CTL_TIMING_DOMINANT_ONLY
     if (KS == 3 && S == 1 && MODE == 0 && MT == 4 && TW == 32 && NT == 1 && EPI == 0)
 #endif
     TM_FLUSH
+#endif
 
     if (flags & CTL_EPI_STATS) flush_stats(cur_grp);
 }
@@ -639,6 +641,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ctl_conv d, const
     };
     TileWalk cur;
     cur.init(blockIdx.x, gridDim.x, tiles_h, tiles_w);
+    TM_DECL
     if ((int)blockIdx.x < ntiles) {
         xs.load(rx, d, cur.n, cur.th * G::TH, cur.tw * TW, g);
         dyload(cur.n, cur.th * G::TH, cur.tw * TW);
@@ -646,13 +649,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ctl_conv d, const
         dystore();
     }
     __syncthreads();
+    TM(7)
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        TM_COUNT(6)
         const bool has_next = tile + (int)gridDim.x < ntiles;
         if (has_next) {                   // next tile's loads fly while this tile's MFMAs run
             cur.next();
             xs.load(rx, d, cur.n, cur.th * G::TH, cur.tw * TW, g);
             dyload(cur.n, cur.th * G::TH, cur.tw * TW);
         }
+        TM(0)
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const int mt = wave * MT + m;
@@ -676,41 +682,63 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ctl_conv d, const
                 }
             }
         }
+        TM(1)
         ctl_barrier_lds_reads_done();
+        TM(2)
         if (has_next) {
             xs.store(xt, d, g, pro_scale, pro_shift, (cur.n / group_n) * d.cin);
             dystore();
         }
+        TM(3)
         ctl_barrier_lds_writes_done();
+        TM(4)
     }
     __syncthreads();
+#ifdef CTL_TIMING_WGRAD
+    const unsigned long long tm_loop_end = __builtin_amdgcn_s_memtime();
+#endif
 
-    // ---------------- sum the four waves through LDS, tap by tap, and write this split's partial
+    // ---------------- sum the four waves through LDS, several taps per round, and write this split's partial.  Raw LDS
+    // barriers: a __syncthreads() here would drain the partial stores of the previous round (vmcnt(0)) 18 times per block.
     float* red = lds;
+    constexpr int TAP_FLOATS = 4 * NTW * 256;
+    constexpr int TPR = (LDS_FLOATS / TAP_FLOATS) < TAPS ? (LDS_FLOATS / TAP_FLOATS) : TAPS;     // taps per round (>= 1)
     const int64_t split_base = (int64_t)blockIdx.x * TAPS * cin_p * cout_p;
 #pragma unroll
-    for (int tap = 0; tap < TAPS; ++tap) {
-        __syncthreads();
+    for (int tap0 = 0; tap0 < TAPS; tap0 += TPR) {
+        if (tap0 > 0) ctl_barrier_lds_reads_done();     // the sums of the previous round were consumed by their stores
 #pragma unroll
-        for (int t = 0; t < NTW; ++t) {
-            red[((wave * NTW + t) * 4 + 0) * 64 + lane] = acc[tap][t].x;
-            red[((wave * NTW + t) * 4 + 1) * 64 + lane] = acc[tap][t].y;
-            red[((wave * NTW + t) * 4 + 2) * 64 + lane] = acc[tap][t].z;
-            red[((wave * NTW + t) * 4 + 3) * 64 + lane] = acc[tap][t].w;
+        for (int tp = 0; tp < TPR; ++tp) {
+            const int tap = tap0 + tp;
+            if (tap < TAPS) {
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) {
+                    float* r0 = red + tp * TAP_FLOATS + ((wave * NTW + t) * 4) * 64 + lane;
+                    r0[0] = acc[tap][t].x; r0[64] = acc[tap][t].y; r0[128] = acc[tap][t].z; r0[192] = acc[tap][t].w;
+                }
+            }
         }
-        __syncthreads();
-        for (int e = tid; e < NTW * 256; e += 256) {
-            const int t = e >> 8, r = (e >> 6) & 3, l = e & 63;
-            float v = 0.f;
+        ctl_barrier_lds_writes_done();
 #pragma unroll
-            for (int w = 0; w < 4; ++w) v += red[((w * NTW + t) * 4 + r) * 64 + l];
-            const int ci = g * 16 + (l >> 4) * 4 + r;
-            const int co = (cot0 + t) * 16 + (l & 15);
-            if (co < cout_p) w_partial[split_base + ((int64_t)tap * cin_p + ci) * cout_p + co] = v;
+        for (int tp = 0; tp < TPR; ++tp) {
+            const int tap = tap0 + tp;
+            if (tap < TAPS) {
+#pragma unroll
+                for (int e0 = 0; e0 < NTW * 256; e0 += 256) {
+                    const int e = e0 + tid;
+                    const int t = e >> 8, r = (e >> 6) & 3, l = e & 63;
+                    float v = 0.f;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) v += red[tp * TAP_FLOATS + ((w * NTW + t) * 4 + r) * 64 + l];
+                    const int ci = g * 16 + (l >> 4) * 4 + r;
+                    const int co = (cot0 + t) * 16 + (l & 15);
+                    if (co < cout_p) w_partial[split_base + ((int64_t)tap * cin_p + ci) * cout_p + co] = v;
+                }
+            }
         }
     }
     if (g == 0 && b_partial != nullptr) {  // bias gradient: column sums of dy
-        __syncthreads();
+        ctl_barrier_lds_reads_done();
 #pragma unroll
         for (int t = 0; t < NTW; ++t) {
             float v = bsum[t];
@@ -718,7 +746,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ctl_conv d, const
             v += __shfl_xor(v, 32);
             if (q == 0) red[(wave * NTW + t) * 16 + p] = v;
         }
-        __syncthreads();
+        ctl_barrier_lds_writes_done();
         if (tid < NTW * 16) {
             float v = 0.f;
 #pragma unroll
@@ -727,6 +755,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ctl_conv d, const
             if (co < cout_p) b_partial[(int64_t)blockIdx.x * cout_p + co] = v;
         }
     }
+#ifdef CTL_TIMING_WGRAD
+    tm_acc[5] += __builtin_amdgcn_s_memtime() - tm_loop_end;      // [5] = the cross-wave reduction + partial write
+    TM_FLUSH
+#endif
 }
 
 // Sums the per-split partials: a block owns 32 consecutive weight elements (contiguous in the partial layout) and
@@ -922,7 +954,7 @@ int ctl_conv_pick_cfg(const ctl_conv* d, ctl_conv_cfg* c, int for_wgrad) {
         const char* f = getenv("CTL_FORCE_CFG");
         int fm, ft, fn;
         if (f && sscanf(f, "%d,%d,%d", &fm, &ft, &fn) == 3) {
-            const bool tile_ok = (fm == 4 && ft == 32 && d->stride == 1) || (fm == 2 && ft == 16) || (fm == 1 && ft == 16);
+            const bool tile_ok = (fm == 4 && ft == 32 && d->stride == 1 && !for_wgrad) || (fm == 2 && ft == 16) || (fm == 1 && ft == 16);
             if (tile_ok) { mt = fm; tw = ft; }
             if ((fn == 1 || fn == 2) && c->cot % fn == 0) c->nt = fn;
         }
@@ -1062,23 +1094,76 @@ extern "C" int ctl_conv_forward(const ctl_conv* d, const float* x, const float* 
 // ---- wgrad host side
 struct wgrad_cfg { ctl_conv_cfg c; int ntw, splits, ntiles, cin_p, cout_p; };
 
+struct wgrad_call {
+    const ctl_conv* d; wgrad_cfg* w;
+    const float *x, *pro_scale, *pro_shift, *dy;
+    float *w_partial, *b_partial;
+    hipStream_t stream;
+    bool query;          // only compute w->splits
+};
+
+// splits = blocks along x: the grid (splits x cin chunks x cout tile groups) is what is resident at once (256 CUs x the
+// kernel's occupancy, at most CTL_PERSIST = 4 per CU).  More blocks would run in rounds and pay the per-block setup and the
+// cross-wave reduction + partial write again (each ~1.5 tiles worth of time), and write / re-read more partials.
+template <int KS, int S, int MODE, int MT, int TW, int NTW>
+static void wgrad_go(wgrad_call& a) {
+    static int occ = 0;
+    if (!occ) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_wgrad_kernel<KS, S, MODE, MT, TW, NTW>, 256, 0) != hipSuccess || n < 1) {
+            (void)hipGetLastError();
+            n = 2;
+        }
+        occ = n;
+    }
+    wgrad_cfg& w = *a.w;
+    static int per_cu = -1;
+    if (per_cu < 0) {
+        const char* e = getenv("CTL_PERSIST");
+        per_cu = e ? atoi(e) : 4;
+        if (per_cu < 1) per_cu = 1;
+    }
+    const int par = w.c.g * (w.c.cot / NTW);
+    int splits = (256 * (occ < per_cu ? occ : per_cu)) / par;
+    if (splits > 512) splits = 512;
+    if (splits > w.ntiles) splits = w.ntiles;
+    if (splits < 1) splits = 1;
+    w.splits = splits;
+    if (a.query) return;
+    const dim3 grid((unsigned)splits, (unsigned)w.c.g, (unsigned)(w.c.cot / NTW));
+    conv_wgrad_kernel<KS, S, MODE, MT, TW, NTW><<<grid, dim3(256), 0, a.stream>>>(
+        *a.d, a.x, a.pro_scale, a.pro_shift, a.dy, a.w_partial, a.b_partial, w.c.tiles_h, w.c.tiles_w, w.ntiles, w.cin_p, w.cout_p);
+}
+template <int KS, int S, int MODE>
+static void wgrad_go_tile(wgrad_call& a) {
+    const wgrad_cfg& w = *a.w;
+    if (w.c.mt == 2) { if (w.ntw == 2) wgrad_go<KS, S, MODE, 2, 16, 2>(a); else wgrad_go<KS, S, MODE, 2, 16, 1>(a); }
+    else { if (w.ntw == 2) wgrad_go<KS, S, MODE, 1, 16, 2>(a); else wgrad_go<KS, S, MODE, 1, 16, 1>(a); }
+}
+static int wgrad_dispatch(wgrad_call& a) {
+    const int k = a.d->ks, s = a.d->stride, m = a.d->in_mode;
+    if (k == 3 && s == 1 && m == CTL_IN_PLAIN) wgrad_go_tile<3, 1, CTL_IN_PLAIN>(a);
+    else if (k == 3 && s == 1 && m == CTL_IN_UP2) wgrad_go_tile<3, 1, CTL_IN_UP2>(a);
+    else if (k == 3 && s == 2) wgrad_go_tile<3, 2, CTL_IN_PLAIN>(a);
+    else if (k == 1 && m == CTL_IN_PLAIN) wgrad_go_tile<1, 1, CTL_IN_PLAIN>(a);
+    else if (k == 1 && m == CTL_IN_UP2) wgrad_go_tile<1, 1, CTL_IN_UP2>(a);
+    else if (k == 2 && s == 2) wgrad_go_tile<2, 2, CTL_IN_PLAIN>(a);
+    else CTL_FAIL(CTL_EUNSUPPORTED, "conv_wgrad: no kernel for this combination");
+    return CTL_OK;
+}
+
 static int wgrad_pick(const ctl_conv* d, wgrad_cfg* w) {
     CTL_REQUIRE(d->nsub == 1, "wgrad: nsub must be 1");
     CTL_REQUIRE(d->in_mode != CTL_IN_ZINS2, "wgrad: zero-insert input is not a forward mode");
     int rc = ctl_conv_pick_cfg(d, &w->c, 1);
     if (rc != CTL_OK) return rc;
-    // the wgrad kernel reuses the forward tile shapes; cap LDS by keeping (4,32) only for stride 1
     w->ntw = (w->c.cot >= 2 && w->c.cot % 2 == 0) ? 2 : 1;
     w->ntiles = d->n * w->c.tiles_h * w->c.tiles_w;
     w->cin_p = w->c.g * 16;
     w->cout_p = w->c.cot * 16;
-    const int par = w->c.g * (w->c.cot / w->ntw);
-    int splits = ctl_cdiv(1024, par);          // ~4 blocks per CU in total; every block then walks >= a few tiles
-    if (splits > 512) splits = 512;
-    if (splits > w->ntiles) splits = w->ntiles;
-    if (splits < 1) splits = 1;
-    w->splits = splits;
-    return CTL_OK;
+    wgrad_call a = {};
+    a.d = d; a.w = w; a.query = true;
+    return wgrad_dispatch(a);
 }
 
 extern "C" int ctl_wgrad_splits(const ctl_conv* d) {
@@ -1096,47 +1181,24 @@ extern "C" size_t ctl_wgrad_bias_partial_floats(const ctl_conv* d) {
     return (size_t)w.splits * w.cout_p;
 }
 
-#define WGRAD_ARGS *d, x, pro_scale, pro_shift, dy, w_partial, b_partial, w.c.tiles_h, w.c.tiles_w, w.ntiles, w.cin_p, w.cout_p
-#define LAUNCH_WG(KS, S, MODE, MT, TW, NTW)                                                              \
-    conv_wgrad_kernel<KS, S, MODE, MT, TW, NTW><<<grid, dim3(256), 0, (hipStream_t)stream>>>(WGRAD_ARGS)
-#define WG_NT(KS, S, MODE, MT, TW)                       \
-    do {                                                 \
-        if (w.ntw == 2) LAUNCH_WG(KS, S, MODE, MT, TW, 2); \
-        else LAUNCH_WG(KS, S, MODE, MT, TW, 1);          \
-    } while (0)
-#define WG_TILE(KS, S, MODE)                                      \
-    do {                                                          \
-        if (w.c.mt == 4 && w.c.tw == 32) WG_NT(KS, S, MODE, 4, 32); \
-        else if (w.c.mt == 2) WG_NT(KS, S, MODE, 2, 16);          \
-        else WG_NT(KS, S, MODE, 1, 16);                           \
-    } while (0)
-#define WG_TILE_S2(KS, S, MODE)                         \
-    do {                                                \
-        if (w.c.mt == 2) WG_NT(KS, S, MODE, 2, 16);     \
-        else WG_NT(KS, S, MODE, 1, 16);                 \
-    } while (0)
-
 extern "C" int ctl_conv_wgrad(const ctl_conv* d, const float* x, const float* pro_scale, const float* pro_shift,
                               const float* dy, float* w_partial, float* b_partial, ctl_stream stream) {
     CTL_REQUIRE(d && x && dy && w_partial, "conv_wgrad: null argument");
     CTL_REQUIRE(!d->pro_affine || (pro_scale && pro_shift), "conv_wgrad: prologue without scale/shift");
+    CTL_REQUIRE(!d->pro_affine || (d->pro_slope >= 0.f && d->pro_slope <= 1.f), "conv_wgrad: prologue slope must be in [0, 1]");
     CTL_REQUIRE((int64_t)d->n * d->hin * d->win * d->cin * 4 < (1ll << 31) &&
                 (int64_t)d->n * d->hout * d->wout * d->cout * 4 < (1ll << 31),
                 "conv_wgrad: tensors must stay below 2 GiB (32-bit buffer offsets)");
     wgrad_cfg w;
     int rc = wgrad_pick(d, &w);
     if (rc != CTL_OK) return rc;
-    const dim3 grid((unsigned)w.splits, (unsigned)w.c.g, (unsigned)(w.c.cot / w.ntw));
-    const int k = d->ks, s = d->stride, m = d->in_mode;
-    const int ptok = ctl_prof_begin("conv_wgrad", d, &w.c, w.ntw, (hipStream_t)stream);
-    if (k == 3 && s == 1 && m == CTL_IN_PLAIN) WG_TILE(3, 1, CTL_IN_PLAIN);
-    else if (k == 3 && s == 1 && m == CTL_IN_UP2) WG_TILE(3, 1, CTL_IN_UP2);
-    else if (k == 3 && s == 2) WG_TILE_S2(3, 2, CTL_IN_PLAIN);
-    else if (k == 1 && m == CTL_IN_PLAIN) WG_TILE(1, 1, CTL_IN_PLAIN);
-    else if (k == 1 && m == CTL_IN_UP2) WG_TILE(1, 1, CTL_IN_UP2);
-    else if (k == 2 && s == 2) WG_TILE_S2(2, 2, CTL_IN_PLAIN);
-    else CTL_FAIL(CTL_EUNSUPPORTED, "conv_wgrad: no kernel for this combination");
-    ctl_prof_end(ptok, (hipStream_t)stream);
+    wgrad_call a = {};
+    a.d = d; a.w = &w; a.x = x; a.pro_scale = pro_scale; a.pro_shift = pro_shift; a.dy = dy; a.w_partial = w_partial;
+    a.b_partial = b_partial; a.stream = (hipStream_t)stream;
+    const int ptok = ctl_prof_begin("conv_wgrad", d, &w.c, w.ntw, a.stream);
+    rc = wgrad_dispatch(a);
+    if (rc != CTL_OK) return rc;
+    ctl_prof_end(ptok, a.stream);
     CTL_LAUNCH_CHECK("conv_wgrad");
     return CTL_OK;
 }

@@ -46,7 +46,7 @@ def child(kind):
             res[name] = None; continue
         torch.cuda.synchronize()
         tm = (C.c_ulonglong * 12)()
-        has_tm = kind == "fwd" and hasattr(lib, "ctl_debug_timing")      # -DCTL_TIMING variant build (tools/build_variant.sh)
+        has_tm = hasattr(lib, "ctl_debug_timing")      # -DCTL_TIMING variant build (tools/build_variant.sh)
         if has_tm: lib.ctl_debug_timing(tm)                               # reset
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -57,7 +57,7 @@ def child(kind):
         if has_tm:
             lib.ctl_debug_timing(tm)
             steps = max(tm[6], 1)          # (tile, chunk) steps summed over waves
-            names = ["issue", "mfma", "bar_rd", "stage", "bar_wr", "epi"]
+            names = ["issue", "mfma", "bar_rd", "stage", "bar_wr", "epi" if kind == "fwd" else "tail(total)"]
             res[name] = res[name] + ({k: round(tm[i] / steps) for i, k in enumerate(names)}, {"setup/step": round(tm[7] / steps, 1), "steps/launch": steps // 20, "memtime_MHz": round(100.0 * tm[8] / max(tm[9], 1), 1), "span_mean_us": round(tm[9] / max(tm[11], 1) / 20 / 100.0, 1), "span_max_us": round(tm[10] / 20 / (100.0 * tm[8] / max(tm[9], 1)), 1)})
     print("RESULT " + json.dumps(res))
 
