@@ -622,11 +622,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ctl_conv d, const
         const int pr = pix / TW, pc = pix % TW;
         const int co = (cot0 + t) * 16 + cq * 4;
         drc[i] = (co < d.cout) ? (pr | (pc << 16)) : 0x7fff7fff;
-        drel[i] = ((pr * d.wout + pc) * d.cout + co) * 4;
+        drel[i] = (co < d.cout) ? ((pr * d.wout + pc) * d.cout + co) * 4 : CTL_OOB;
         dlds[i] = (t * G::TP + pix) * 16 + cq * 4;
     }
     auto dyload = [&](int n, int ho0, int wo0) {
         const int tb = ((n * d.hout + ho0) * d.wout + wo0) * d.cout * 4;
+        if (ho0 + G::TH <= d.hout && wo0 + TW <= d.wout && d.cout >= 4) {      // whole tile: scalar tile offset, no per-unit VALU
+#pragma unroll
+            for (int i = 0; i < ND; ++i) dv[i] = ctl_bload4s(rdy, drel[i], tb);
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < ND; ++i) {
             const bool ok = (unsigned)(ho0 + (drc[i] & 0xffff)) < (unsigned)d.hout && (unsigned)(wo0 + (drc[i] >> 16)) < (unsigned)d.wout;
