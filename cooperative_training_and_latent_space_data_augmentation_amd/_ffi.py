@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("CTL_HIP_LIB") or os.path.join(_HERE, "csrc", "libctl_
 # enums of ctl_hip.h
 IN_PLAIN, IN_UP2, IN_ZINS2 = 0, 1, 2
 ACT_NONE, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2
-EPI_BIAS, EPI_ACCUM, EPI_RES, EPI_STATS = 1, 2, 4, 8
+EPI_BIAS, EPI_ACCUM, EPI_RES, EPI_STATS, EPI_BNBWD = 1, 2, 4, 8, 16
 RED_BLOCKS = 512
 (OP_CONV, OP_WGRAD, OP_WGRAD_REDUCE, OP_PACK, OP_BN_FINALIZE, OP_BN_EVAL, OP_BN_ACT, OP_BWD_REDUCE, OP_BN_BWD_FINALIZE,
  OP_BWD_APPLY, OP_CHAN_SUM_FINALIZE, OP_SUMPOOL2, OP_SIGMOID_BWD, OP_ZERO, OP_COPY, OP_PACK_BATCH, OP_WGRAD_REDUCE_BATCH) = range(1, 18)
@@ -62,7 +62,7 @@ class _Lib:
             "ctl_bn_eval_coeffs": [i32, p, p, p, p, f32, p, p, i32, p],
             "ctl_bn_act": [p, p, p, f32, p, i64, i32, i32, p],
             "ctl_bwd_reduce": [i32, p, p, p, p, p, f32, i64, i32, p, i32, p],
-            "ctl_bn_bwd_finalize": [p, i32, i64, p, p, p, p, p, p, i32, i32, p],
+            "ctl_bn_bwd_finalize": [p, i32, i64, p, p, p, p, p, p, i32, i32, i32, p],
             "ctl_bwd_apply": [i32, p, p, p, p, p, f32, p, i64, i32, p, p, i32, p],
             "ctl_chan_sum_finalize": [p, i32, p, i32, p],
             "ctl_sumpool2": [p, p, i32, i32, i32, i32, i32, p],

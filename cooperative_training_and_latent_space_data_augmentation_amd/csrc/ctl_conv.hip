@@ -471,7 +471,9 @@ __global__ __launch_bounds__(256, (MT * NT >= 8) ? 2 : ((MT * NT >= 4) ? CTL_LB_
         if (g == G_chunks - 1) {
             // ---------------- epilogue: lane (p,q) holds channels co0..co0+3 of pixel p of each M-tile.  Buffer stores with
             // hardware bounds checks; nothing here is waited for in the loop.  Whole tiles with whole channel tiles (FULL) put
-            // the tile origin into the scalar offset and skip every mask; ragged ones redirect dropped lanes to CTL_OOB.
+            // the tile origin into the scalar offset of the loads and skip every mask; ragged ones redirect dropped lanes to
+            // CTL_OOB.  (Requesting the residual / accumulate operands before the barriers was measured: the extra live
+            // registers cost more than the hidden latency gains.)
             const int grp = n / group_n;
             if ((flags & CTL_EPI_STATS) && grp != cur_grp) {
                 flush_stats(cur_grp);
@@ -500,10 +502,10 @@ __global__ __launch_bounds__(256, (MT * NT >= 8) ? 2 : ((MT * NT >= 4) ? CTL_LB_
                             const int so = FULL ? ybase : 0;
                             rv[m][t] = ov[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
                             if (d.cout >= 4) {
-                                if (flags & CTL_EPI_RES) rv[m][t] = ctl_bload4s(rres, vo, so);
+                                if (flags & (CTL_EPI_RES | CTL_EPI_BNBWD)) rv[m][t] = ctl_bload4s(rres, vo, so);
                                 if (flags & CTL_EPI_ACCUM) ov[m][t] = ctl_bload4s(ry, vo, so);
                             } else {
-                                if (flags & CTL_EPI_RES) rv[m][t].x = ctl_bload1(rres, vo);
+                                if (flags & (CTL_EPI_RES | CTL_EPI_BNBWD)) rv[m][t].x = ctl_bload1(rres, vo);
                                 if (flags & CTL_EPI_ACCUM) ov[m][t].x = ctl_bload1(ry, vo);
                             }
                         }
@@ -515,7 +517,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 8) ? 2 : ((MT * NT >= 4) ? CTL_LB_
                     const bool cok = FULL || co0 < d.cout;
                     const int cc = cok ? co0 : 0;
                     f32x4 rs = {0.f, 0.f, 0.f, 0.f}, rh = {0.f, 0.f, 0.f, 0.f};
-                    if (EPI && (flags & CTL_EPI_RES)) {
+                    if (EPI && (flags & (CTL_EPI_RES | CTL_EPI_BNBWD))) {
                         if (d.cout >= 4) {
                             rs = *reinterpret_cast<const f32x4*>(res_scale + grp * d.cout + cc);
                             rh = *reinterpret_cast<const f32x4*>(res_shift + grp * d.cout + cc);
@@ -524,10 +526,20 @@ __global__ __launch_bounds__(256, (MT * NT >= 8) ? 2 : ((MT * NT >= 4) ? CTL_LB_
 #pragma unroll
                     for (int m = 0; m < MT; ++m) {
                         f32x4 v = acc[m][t];
-                        if (EPI) v += rv[m][t] * rs + rh;
-                        if (flags & CTL_EPI_STATS) {
-                            if (FULL) { ssum[t] += v; ssq[t] += v * v; }
-                            else if (pv[m]) { ssum[t] += v; ssq[t] += v * v; }
+                        if (EPI && (flags & CTL_EPI_BNBWD)) {
+                            // this conv produced dL/da of a = leaky(BN(u)): turn it into g = dL/da * leaky'(BN(u)) and take the two
+                            // sums of the BatchNorm backward (sum g, sum g*u) here instead of in a separate pass over da and u
+                            const f32x4 u = rv[m][t], sa = u * rs + rh;
+                            const float sl = d.epi_slope;
+                            v.x *= sa.x > 0.f ? 1.f : sl; v.y *= sa.y > 0.f ? 1.f : sl;
+                            v.z *= sa.z > 0.f ? 1.f : sl; v.w *= sa.w > 0.f ? 1.f : sl;
+                            if (FULL || pv[m]) { ssum[t] += v; ssq[t] += v * u; }
+                        } else {
+                            if (EPI) v += rv[m][t] * rs + rh;
+                            if (flags & CTL_EPI_STATS) {
+                                if (FULL) { ssum[t] += v; ssq[t] += v * v; }
+                                else if (pv[m]) { ssum[t] += v; ssq[t] += v * v; }
+                            }
                         }
                         if (d.epi_act == CTL_ACT_LEAKY) {
                             v = ctl_leaky01(v, d.epi_slope);
@@ -1029,7 +1041,7 @@ static void conv_go(conv_call& a) {
 }
 template <int KS, int S, int MODE, int MT, int TW>
 static void conv_go_nt(conv_call& a) {
-    const bool epi = (a.d->epi_flags & (CTL_EPI_RES | CTL_EPI_ACCUM)) != 0;
+    const bool epi = (a.d->epi_flags & (CTL_EPI_RES | CTL_EPI_ACCUM | CTL_EPI_BNBWD)) != 0;
     if (a.c.nt == 2) { if (epi) conv_go<KS, S, MODE, MT, TW, 2, 1>(a); else conv_go<KS, S, MODE, MT, TW, 2, 0>(a); }
     else { if (epi) conv_go<KS, S, MODE, MT, TW, 1, 1>(a); else conv_go<KS, S, MODE, MT, TW, 1, 0>(a); }
 }
@@ -1077,6 +1089,9 @@ extern "C" int ctl_conv_forward(const ctl_conv* d, const float* x, const float* 
     CTL_REQUIRE(!(d->epi_flags & CTL_EPI_BIAS) || bias, "conv_forward: CTL_EPI_BIAS without bias");
     CTL_REQUIRE(!(d->epi_flags & CTL_EPI_RES) || (res && res_scale && res_shift), "conv_forward: CTL_EPI_RES without res");
     CTL_REQUIRE(!(d->epi_flags & CTL_EPI_STATS) || (stats_partial && d->nsub == 1), "conv_forward: bad CTL_EPI_STATS use");
+    CTL_REQUIRE(!(d->epi_flags & CTL_EPI_BNBWD) || ((d->epi_flags & CTL_EPI_STATS) && res && res_scale && res_shift &&
+                                                    !(d->epi_flags & (CTL_EPI_RES | CTL_EPI_ACCUM | CTL_EPI_BIAS)) && d->epi_act == CTL_ACT_NONE),
+                "conv_forward: CTL_EPI_BNBWD needs CTL_EPI_STATS + res (= u) + res_scale/res_shift (BatchNorm coefficients) and nothing else");
     CTL_REQUIRE(!d->pro_affine || (pro_scale && pro_shift), "conv_forward: prologue without scale/shift");
     CTL_REQUIRE(!d->pro_affine || (d->pro_slope >= 0.f && d->pro_slope <= 1.f), "conv_forward: prologue slope must be in [0, 1]");
     CTL_REQUIRE(d->epi_act != CTL_ACT_LEAKY || (d->epi_slope >= 0.f && d->epi_slope <= 1.f), "conv_forward: LeakyReLU slope must be in [0, 1]");

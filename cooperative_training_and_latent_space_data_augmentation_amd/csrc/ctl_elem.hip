@@ -204,7 +204,7 @@ __global__ __launch_bounds__(EB) void bwd_apply_kernel(const f32x4* __restrict__
             g.x *= ctl_leaky_grad(o.x, slope); g.y *= ctl_leaky_grad(o.y, slope);
             g.z *= ctl_leaky_grad(o.z, slope); g.w *= ctl_leaky_grad(o.w, slope);
             if (ds) ds[i] = g;
-        } else {
+        } else if (MODE == 1) {
             const f32x4 sc = scale[gi * cq + q], sh = shift[gi * cq + q];
             g.x *= ctl_leaky_grad(u.x * sc.x + sh.x, slope); g.y *= ctl_leaky_grad(u.y * sc.y + sh.y, slope);
             g.z *= ctl_leaky_grad(u.z * sc.z + sh.z, slope); g.w *= ctl_leaky_grad(u.w * sc.w + sh.w, slope);
@@ -447,9 +447,9 @@ extern "C" int ctl_bwd_reduce(int32_t mode, const float* dy, const float* act_sr
 }
 extern "C" int ctl_bn_bwd_finalize(const float* partial, int32_t c, int64_t count, const float* gamma,
                                    const float* save_mean, const float* save_invstd, float* coef, float* dgamma,
-                                   float* dbeta, int32_t accumulate, int32_t groups, ctl_stream stream) {
-    CTL_REQUIRE(partial && gamma && save_mean && save_invstd && coef && c > 0 && count > 0 && groups >= 1, "bn_bwd_finalize: bad arguments");
-    bn_bwd_finalize_kernel<<<dim3(c), dim3(EB), 0, S_>>>(partial, CTL_RED_BLOCKS, c, (double)count, gamma, save_mean,
+                                   float* dbeta, int32_t accumulate, int32_t groups, int32_t blocks, ctl_stream stream) {
+    CTL_REQUIRE(partial && gamma && save_mean && save_invstd && coef && c > 0 && count > 0 && groups >= 1 && blocks >= 0, "bn_bwd_finalize: bad arguments");
+    bn_bwd_finalize_kernel<<<dim3(c), dim3(EB), 0, S_>>>(partial, blocks > 0 ? blocks : CTL_RED_BLOCKS, c, (double)count, gamma, save_mean,
                                                           save_invstd, coef, dgamma, dbeta, accumulate, groups);
     CTL_LAUNCH_CHECK("bn_bwd_finalize");
     return CTL_OK;
@@ -469,6 +469,9 @@ extern "C" int ctl_bwd_apply(int32_t mode, const float* dy, const float* act_src
         bwd_apply_kernel<1><<<grid, blk, 0, S_>>>((const f32x4*)dy, nullptr, (const f32x4*)bn_src, (const f32x4*)scale,
                                                  (const f32x4*)shift, slope, (const f32x4*)coef, quads, c / 4, nullptr,
                                                  (f32x4*)dx, quads / groups);
+    } else if (mode == 2) {
+        bwd_apply_kernel<2><<<grid, blk, 0, S_>>>((const f32x4*)dy, nullptr, (const f32x4*)bn_src, nullptr, nullptr, slope,
+                                                 (const f32x4*)coef, quads, c / 4, nullptr, (f32x4*)dx, quads / groups);
     } else {
         CTL_FAIL(CTL_EINVAL, "bwd_apply: mode %d", mode);
     }

@@ -194,7 +194,7 @@ extern "C" int ctl_plan_run(const ctl_op* ops, int32_t n_ops, void* const* bases
                 rc = ctl_bwd_reduce(op.i[0], CF(0), CF(1), CF(2), CF(3), CF(4), op.f[0], op.l[0], op.i[1], F(5), NG(op.i[2]), stream);
                 break;
             case CTL_OP_BN_BWD_FINALIZE:
-                rc = ctl_bn_bwd_finalize(CF(0), op.i[0], op.l[0], CF(1), CF(2), CF(3), F(4), F(5), F(6), op.i[1], NG(op.i[2]), stream);
+                rc = ctl_bn_bwd_finalize(CF(0), op.i[0], op.l[0], CF(1), CF(2), CF(3), F(4), F(5), F(6), op.i[1], NG(op.i[2]), op.i[3], stream);
                 break;
             case CTL_OP_BWD_APPLY:
                 rc = ctl_bwd_apply(op.i[0], CF(0), CF(1), CF(2), CF(3), CF(4), op.f[0], CF(5), op.l[0], op.i[1], F(6), F(7), NG(op.i[2]), stream);

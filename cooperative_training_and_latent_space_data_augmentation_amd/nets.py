@@ -21,6 +21,8 @@ without gamma/beta gradients, "C" eval (running statistics).
 """
 from __future__ import annotations
 
+import os
+
 import ctypes
 from collections import namedtuple
 from typing import Dict, List, Optional, Tuple
@@ -37,6 +39,7 @@ N_SLOTS = 15
 SLOPE = 0.2
 EPS = 1e-5
 MOMENTUM = 0.1
+FUSE_BNBWD = os.environ.get("CTL_FUSE_BNBWD", "0") == "1"   # BN1-backward reduction inside the dgrad conv epilogue (measured: no gain)
 CONV_WORDS = _ffi.CONV_DTYPE.itemsize // 4      # ctl_conv as int32 words at the head of ctl_op.i
 ALIGN_F = 64            # floats (256 B)
 
@@ -151,9 +154,14 @@ class PlanBuilder:
 
     def conv(self, x: T, wp_ref, cout, ks, *, stride=1, in_mode=0, pro=None, bias_ref=None, stats=False, act=0,
              slope=0.0, res=None, accum=False, out: Optional[T] = None, arena: Optional[Arena] = None, nsub=1,
-             hout=None, wout=None):
+             hout=None, wout=None, bnbwd=None):
         """Emit one CTL_OP_CONV.  pro = (scale_ref, shift_ref, slope); res = (T v, scale_ref, shift_ref).
+        bnbwd = (T u, scale_ref, shift_ref, slope): data-gradient conv whose result is dL/d leaky(BN(u)); the epilogue writes
+        g = result * leaky'(BN(u)) and the BatchNorm-backward sums go to the statistics partials (CTL_EPI_BNBWD).
         Returns (T y, stats_ref or None, stats_blocks)."""
+        if bnbwd is not None:
+            assert res is None and not accum and bias_ref is None and act == 0
+            stats, res, slope = True, (bnbwd[0], bnbwd[1], bnbwd[2]), bnbwd[3]
         if hout is None:
             if in_mode == _ffi.IN_UP2:
                 hout, wout = 2 * x.h, 2 * x.w
@@ -162,7 +170,7 @@ class PlanBuilder:
             else:
                 hout, wout = x.h, x.w
         flags = (_ffi.EPI_BIAS if bias_ref is not None else 0) | (_ffi.EPI_STATS if stats else 0) | \
-                (_ffi.EPI_RES if res is not None else 0) | (_ffi.EPI_ACCUM if accum else 0)
+                ((_ffi.EPI_BNBWD if bnbwd is not None else _ffi.EPI_RES) if res is not None else 0) | (_ffi.EPI_ACCUM if accum else 0)
         d = self._conv_desc(x, cout, ks, stride, in_mode, hout, wout, pro, flags, act, slope, nsub)
         oh, ow = (2 * hout, 2 * wout) if nsub == 4 else (hout, wout)
         if out is None:
@@ -276,6 +284,22 @@ class PlanBuilder:
         op["f"][0] = slope
         for idx, ref in enumerate([dy.ref, act_src.ref if act_src else None, bn_src.ref, co["scale"], co["shift"], coef,
                                    ds.ref if ds else None, dx.ref]):
+            self.set_t(op, idx, ref)
+
+    def bn_backward_from_stats(self, g: T, bn_src: T, bn: BNInfo, co, stats_ref, blocks, *, dx: T, affine_grad: bool):
+        """BatchNorm backward whose reduction already happened in the producing conv (conv(..., bnbwd=...)): finalize + apply."""
+        c, pixels, G = bn_src.c, bn_src.n * bn_src.h * bn_src.w, self.groups
+        coef = self.bscr.alloc(4 * 3 * c * G)
+        op = self.op(_ffi.OP_BN_BWD_FINALIZE)
+        op["i"][0], op["i"][1], op["i"][2], op["i"][3] = c, 0, G, blocks
+        op["l"][0] = pixels // G
+        for idx, ref in enumerate([stats_ref, self.P(bn.g_off), co["mean"], co["invstd"], coef,
+                                   self.G(bn.g_off) if affine_grad else None, self.G(bn.b_off) if affine_grad else None]):
+            self.set_t(op, idx, ref)
+        op = self.op(_ffi.OP_BWD_APPLY)
+        op["i"][0], op["i"][1], op["i"][2] = 2, c, G
+        op["l"][0] = pixels
+        for idx, ref in enumerate([g.ref, None, bn_src.ref, None, None, coef, None, dx.ref]):
             self.set_t(op, idx, ref)
 
     def chan_sum(self, dy: T, out_ref):
@@ -564,10 +588,18 @@ class CtlNet(nn.Module):
         k9 = 9
         if need_w:
             pb.wgrad(u, dv, 3, pro=pro1, dw_ref=pb.G(c3.w_off), strides=(c3.cin * k9, k9, 3, 1), dbias_ref=pb.G(c3.b_off))
-        da, _, _ = pb.conv(dv, self._wp_ref(c3.wp_dgrad), c3.cin, 3, arena=A)
-        # BN1 -> LeakyReLU tail (in place: dU overwrites dA)
-        pb.bn_backward(1, da, None, u, B[prefix + ".conv.1"], rec["co1"], SLOPE, ds=None, dx=da, affine_grad=need_w and affine)
-        du = da
+        # dgrad of conv.3; its epilogue already multiplies by leaky'(BN1(u)) and takes the BatchNorm-backward sums (no
+        # separate reduction pass); the apply runs in place
+        if FUSE_BNBWD:
+            g1, st, blk = pb.conv(dv, self._wp_ref(c3.wp_dgrad), c3.cin, 3, arena=A,
+                                  bnbwd=(u, rec["co1"]["scale"], rec["co1"]["shift"], SLOPE))
+            pb.bn_backward_from_stats(g1, u, B[prefix + ".conv.1"], rec["co1"], st, blk, dx=g1, affine_grad=need_w and affine)
+            du = g1
+        else:
+            da, _, _ = pb.conv(dv, self._wp_ref(c3.wp_dgrad), c3.cin, 3, arena=A)
+            # BN1 -> LeakyReLU tail (in place: dU overwrites dA)
+            pb.bn_backward(1, da, None, u, B[prefix + ".conv.1"], rec["co1"], SLOPE, ds=None, dx=da, affine_grad=need_w and affine)
+            du = da
         if need_w:
             pb.wgrad(src, du, 3, in_mode=src_mode, dw_ref=pb.G(c0.w_off), strides=(c0.cin * k9, k9, 3, 1), dbias_ref=pb.G(c0.b_off))
             pb.wgrad(src, ds, 1, in_mode=src_mode, dw_ref=pb.G(c1.w_off), strides=(c1.cin, 1, 1, 1), dbias_ref=pb.G(c1.b_off))

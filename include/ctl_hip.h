@@ -40,7 +40,7 @@ const char* ctl_last_error(void);
  */
 enum { CTL_IN_PLAIN = 0, CTL_IN_UP2 = 1, CTL_IN_ZINS2 = 2 };
 enum { CTL_ACT_NONE = 0, CTL_ACT_LEAKY = 1, CTL_ACT_SIGMOID = 2 };
-enum { CTL_EPI_BIAS = 1, CTL_EPI_ACCUM = 2, CTL_EPI_RES = 4, CTL_EPI_STATS = 8 };
+enum { CTL_EPI_BIAS = 1, CTL_EPI_ACCUM = 2, CTL_EPI_RES = 4, CTL_EPI_STATS = 8, CTL_EPI_BNBWD = 16 };
 
 typedef struct ctl_conv {
     int32_t n, hin, win, cin;        /* stored input tensor [n,hin,win,cin]                                   */
@@ -72,7 +72,10 @@ int ctl_pack_weights(const float* src, float* dst, int32_t cout, int32_t cin, in
                      int64_t s_co, int64_t s_ci, int64_t s_kh, int64_t s_kw, int32_t flip, ctl_stream stream);
 
 /* y = epi( conv(pro(x)) ).  res/res_scale/res_shift: CTL_EPI_RES adds res*res_scale[c]+res_shift[c] (the
- * BatchNorm'ed main branch of res_convdown / res_up_family, encdec.py:64,344).  stats_partial: CTL_EPI_STATS. */
+ * BatchNorm'ed main branch of res_convdown / res_up_family, encdec.py:64,344).  stats_partial: CTL_EPI_STATS.
+ * CTL_EPI_BNBWD (with CTL_EPI_STATS; a data-gradient conv whose result is dL/da of a = leaky(BN(u), epi_slope)): res = u,
+ * res_scale/res_shift = the BatchNorm coefficients; y = g = conv * leaky'(u*scale+shift) and stats_partial receives
+ * (sum g, sum g*u) -- the reduction pass of the BatchNorm backward (ctl_bwd_reduce mode 1) folded into the producer. */
 int ctl_conv_forward(const ctl_conv* d, const float* x, const float* wpack, const float* bias,
                      const float* pro_scale, const float* pro_shift,
                      const float* res, const float* res_scale, const float* res_shift,
@@ -129,10 +132,13 @@ int ctl_bwd_reduce(int32_t mode, const float* dy, const float* act_src, const fl
                    ctl_stream stream);
 /* partial -> coefficients A,B,C with dx = A*g + B*bn_src + C (training-mode BN backward), and, if dgamma/dbeta
  * are non-NULL, dgamma += sum g*xhat, dbeta += sum g (accumulate ? += : =). */
+/* `blocks` = rows per group of `partial` (0 = CTL_RED_BLOCKS, i.e. written by ctl_bwd_reduce; a conv with CTL_EPI_BNBWD
+ * writes ctl_conv_stats_blocks rows) */
 int ctl_bn_bwd_finalize(const float* partial, int32_t c, int64_t count, const float* gamma, const float* save_mean,
                         const float* save_invstd, float* coef, float* dgamma, float* dbeta, int32_t accumulate,
-                        int32_t groups, ctl_stream stream);
-/* mode 0: ds = dout*leaky'(out) (written if ds != NULL), dv = A*ds + B*v + C;  mode 1: du = A*g + B*u + C */
+                        int32_t groups, int32_t blocks, ctl_stream stream);
+/* mode 0: ds = dout*leaky'(out) (written if ds != NULL), dv = A*ds + B*v + C;  mode 1: du = A*g + B*u + C with g = dy*leaky'(..);
+ * mode 2: dy is already g (CTL_EPI_BNBWD): du = A*dy + B*u + C */
 int ctl_bwd_apply(int32_t mode, const float* dy, const float* act_src, const float* bn_src, const float* scale,
                   const float* shift, float slope, const float* coef, int64_t pixels, int32_t c, float* ds,
                   float* dx, int32_t groups, ctl_stream stream);

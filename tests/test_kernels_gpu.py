@@ -66,6 +66,31 @@ def test_conv3x3_s1_forward_bias_prologue_stats(n, cin, cout, h, w):
     close(y2, ref2, what="conv3x3+prologue")
 
 
+@pytest.mark.parametrize("n,c,cout,h,w,groups", [(2, 32, 16, 24, 20, 1), (16, 16, 16, 64, 64, 1), (4, 64, 32, 40, 36, 2), (32, 16, 16, 64, 64, 2)])
+def test_conv_epilogue_bn_backward_reduction(n, c, cout, h, w, groups):
+    """CTL_EPI_BNBWD: y = conv(x) * leaky'(u*scale+shift) and the partials hold (sum y, sum y*u) per BatchNorm group."""
+    g = torch.Generator().manual_seed(c + h + groups)
+    x = torch.randn(n, c, h, w, generator=g)
+    wt = torch.randn(cout, c, 3, 3, generator=g) * 0.2
+    u = torch.randn(n, cout, h, w, generator=g)
+    scale, shift = torch.rand(groups, cout, generator=g) + 0.5, torch.randn(groups, cout, generator=g) * 0.3
+    d = _ffi.conv_desc(n=n, hin=h, win=w, cin=c, hout=h, wout=w, cout=cout, ks=3, groups=groups,
+                       epi_flags=_ffi.EPI_BNBWD | _ffi.EPI_STATS, epi_slope=0.2)
+    y, st = ops.conv_forward(d, dev(x), ops.pack_oihw_fwd(dev(wt)), res=dev(u), res_scale=dev(scale), res_shift=dev(shift),
+                             want_stats=True)
+    gi = torch.arange(n) // (n // groups)
+    sa = u * scale[gi].view(n, cout, 1, 1) + shift[gi].view(n, cout, 1, 1)
+    ref = F.conv2d(x, wt, padding=1) * torch.where(sa > 0, 1.0, 0.2)
+    close(y, ref, what="conv+bnbwd g")
+    blocks = lib.ctl_conv_stats_blocks(_ffi.desc_ptr(d))
+    part = st.cpu().double().view(groups, blocks, 2, cout).sum(1)
+    for k in range(groups):
+        sel = gi == k
+        r0, r1 = ref[sel].double().sum((0, 2, 3)), (ref[sel].double() * u[sel].double()).sum((0, 2, 3))
+        assert float((part[k, 0] - r0).abs().max()) <= 2e-4 * float(r0.abs().max()) + 1e-2, "sum g"
+        assert float((part[k, 1] - r1).abs().max()) <= 2e-4 * float(r1.abs().max()) + 1e-2, "sum g*u"
+
+
 @pytest.mark.parametrize("n,c,cout,h,w", [(2, 16, 16, 32, 32), (2, 32, 32, 17, 23), (4, 64, 64, 16, 16), (2, 128, 128, 6, 6),
                                            (16, 16, 16, 128, 128), (2, 32, 64, 80, 72), (2, 64, 32, 50, 90)])
 def test_conv3x3_s2_forward_and_zero_insert_dgrad(n, c, cout, h, w):
@@ -241,7 +266,7 @@ def test_batchnorm_forward_stats_and_backward(n, c, h, w):
     check(lib.ctl_bwd_reduce(1, dad.data_ptr(), None, ud.data_ptr(), scale.data_ptr(), shift.data_ptr(), 0.2, M, c, part.data_ptr(), 1, ops.stream_ptr()))
     gd = dev(gamma.detach())
     check(lib.ctl_bn_bwd_finalize(part.data_ptr(), c, M, gd.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
-                                  coef.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), 0, 1, ops.stream_ptr()))
+                                  coef.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), 0, 1, 0, ops.stream_ptr()))
     du = torch.empty_like(ud)
     check(lib.ctl_bwd_apply(1, dad.data_ptr(), None, ud.data_ptr(), scale.data_ptr(), shift.data_ptr(), 0.2, coef.data_ptr(), M, c,
                             None, du.data_ptr(), 1, ops.stream_ptr()))
@@ -268,7 +293,7 @@ def test_residual_tail_backward():
     gd, md, isd = dev(gamma), dev(mean), dev(invstd)     # keep alive: raw pointers below
     check(lib.ctl_bwd_reduce(0, doutd.data_ptr(), outd.data_ptr(), vd.data_ptr(), None, None, 0.2, M, c, part.data_ptr(), 1, ops.stream_ptr()))
     check(lib.ctl_bn_bwd_finalize(part.data_ptr(), c, M, gd.data_ptr(), md.data_ptr(), isd.data_ptr(),
-                                  coef.data_ptr(), None, None, 0, 1, ops.stream_ptr()))
+                                  coef.data_ptr(), None, None, 0, 1, 0, ops.stream_ptr()))
     ds, dv = torch.empty_like(vd), torch.empty_like(vd)
     check(lib.ctl_bwd_apply(0, doutd.data_ptr(), outd.data_ptr(), vd.data_ptr(), None, None, 0.2, coef.data_ptr(), M, c,
                             ds.data_ptr(), dv.data_ptr(), 1, ops.stream_ptr()))
