@@ -960,8 +960,9 @@ int ctl_conv_pick_cfg(const ctl_conv* d, ctl_conv_cfg* c, int for_wgrad) {
         else { mt = 1; tw = 16; }
     } else if (d->stride == 2) {
         if (blocks(2, 16) >= 384) { mt = 2; tw = 16; } else { mt = 1; tw = 16; }
-    } else if (d->wout >= 32 && blocks(4, 32) >= 512) {
-        mt = 4; tw = 32;
+    } else if (d->wout >= 32 && blocks(4, 32) >= 512 && !(c->nt == 2 && blocks(4, 32) > 768)) {
+        mt = 4; tw = 32;          // (with 32 output channels per block the 8x32 kernel sits at 2 blocks per CU: once there are more
+                                  //  tiles than that the 8x16 kernel at 3 per CU is faster, e.g. 32->32 at 128^2: 53 vs 57 us)
     } else if (blocks(2, 16) >= 384) {
         mt = 2; tw = 16;
     } else {
