@@ -421,8 +421,9 @@ __global__ __launch_bounds__(256, (MT * NT >= 8) ? 2 : ((MT * NT >= 4) ? CTL_LB_
 #pragma unroll
                 for (int t = 0; t < NT; ++t) acc[m][t] = bias4[t];
         }
-        {   // operands of tap+1 are read from LDS while the MFMAs of tap run (explicit double buffer; the sched_barriers keep
-            // the scheduler from sinking the read-ahead back down to its uses)
+        {   // operands of tap+1 are requested before the MFMAs of tap.  The machine scheduler sinks the reads back to their uses
+            // (register pressure); pinning them with sched_barriers (-DCTL_PIN_READ_AHEAD) costs 12 VGPRs and measures the
+            // same: with fp32 MFMA on the VALU port the LDS latency of one wave is covered by the other waves of the SIMD.
             f32x4 wf[2][NT], xf[2][MT];
             auto lds_operands = [&](int tap, int b) {
                 const int kh = tap / KS, kw = tap % KS;
@@ -438,7 +439,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 8) ? 2 : ((MT * NT >= 4) ? CTL_LB_
             for (int tap = 0; tap < TAPS; ++tap) {
                 const int b = tap & 1;
                 if (tap + 1 < TAPS) lds_operands(tap + 1, b ^ 1);
-#ifndef CTL_NO_SCHED_BARRIER
+#ifdef CTL_PIN_READ_AHEAD
                 __builtin_amdgcn_sched_barrier(0);
 #endif
 #pragma unroll
@@ -451,7 +452,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 8) ? 2 : ((MT * NT >= 4) ? CTL_LB_
                         acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[b][t].w, xf[b][m].w, acc[m][t], 0, 0, 0);
                     }
                 }
-#ifndef CTL_NO_SCHED_BARRIER
+#ifdef CTL_PIN_READ_AHEAD
                 __builtin_amdgcn_sched_barrier(0);
 #endif
             }
