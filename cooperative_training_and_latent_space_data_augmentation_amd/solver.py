@@ -67,6 +67,11 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
         # independent STN passes of one step that share the BatchNorm mode run as one grouped pass (recon_shape_pair); off = one
         # pass per reference call
         self.group_stn_passes = os.environ.get("CTL_GROUP_STN", "1") != "0"
+        # the image decoder consumes z_i only: its launch chain (forward, loss, and through autograd its backward) can run on a
+        # second HIP stream next to D_seg -> STN on the main stream
+        self.two_streams = os.environ.get("CTL_TWO_STREAMS", "1") != "0"
+        self._side = torch.cuda.Stream(device=self.device) if self.two_streams else None
+        self._side_pending = False
         self.training = True
 
     # ------------------------------------------------------------------ construction / checkpoints
@@ -203,6 +208,32 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
     def decode_image(self, latent_code, disable_track_bn_stats=False):
         return self._call(self.model["image_decoder"], latent_code, disable_track_bn_stats)
 
+    def _fork_side(self, fn, *inputs):
+        """Run fn() on the side stream (after everything issued so far on the current stream) when two_streams is on; the result
+        must not be touched on the main stream before _join_side()."""
+        if not self.two_streams:
+            return fn()
+        cur = torch.cuda.current_stream()
+        self._side.wait_stream(cur)
+        for t in inputs:
+            t.record_stream(self._side)
+        with torch.cuda.stream(self._side):
+            out = fn()
+        for t in (out if isinstance(out, tuple) else (out,)):
+            t.record_stream(cur)
+        self._side_pending = True
+        return out
+
+    def _join_side(self):
+        if self._side_pending:
+            torch.cuda.current_stream().wait_stream(self._side)
+            self._side_pending = False
+
+    def _image_recon_loss(self, z_i, clean_image_l, disable_track_bn_stats=False):
+        def work():
+            return scaled_mse(self.decode_image(z_i, disable_track_bn_stats), clean_image_l, 0.5)
+        return self._fork_side(work, z_i, clean_image_l)
+
     def encode_shape(self, segmentation, is_label_map=False, disable_track_bn_stats=False, temperature=2):
         """construct_input (basic_operations.py:110-158): one-hot(label) or softmax(logit / T)."""
         if is_label_map:
@@ -280,12 +311,19 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
     def standard_training(self, clean_image_l, label_l, perturbed_image, separate_training=False, compute_gt_recon=True,
                           update_latent=True, disable_track_bn_stats=False):
         zero = torch.zeros((), device=clean_image_l.device)
-        (z_i, z_s), y_0 = self.fast_predict(perturbed_image, disable_track_bn_stats=disable_track_bn_stats)
+        if self.two_streams and self.training:
+            z_i, z_s = self._enc(perturbed_image, disable_track_bn_stats)
+            image_recon_loss = self._image_recon_loss(z_i, clean_image_l)      # side stream, next to D_seg -> STN below
+            y_0 = self._call(self.model["segmentation_decoder"], z_s, disable_track_bn_stats)
+        else:
+            (z_i, z_s), y_0 = self.fast_predict(perturbed_image, disable_track_bn_stats=disable_track_bn_stats)
+            image_recon_loss = None
         if update_latent:
             self.z_i, self.z_s = z_i, z_s
         standard_supervised_loss = basic_loss_fn(y_0, label_l.detach(), "cross entropy")
-        image_recon = self.decode_image(z_i)                           # always BN mode A, as upstream (model.py:444)
-        image_recon_loss = scaled_mse(image_recon, clean_image_l, 0.5)
+        if image_recon_loss is None:
+            image_recon = self.decode_image(z_i)                       # always BN mode A, as upstream (model.py:444)
+            image_recon_loss = scaled_mse(image_recon, clean_image_l, 0.5)
         y_0_new = y_0.detach() if separate_training else y_0
         if compute_gt_recon and self.group_stn_passes and not disable_track_bn_stats and self.training:
             # the two STN passes are independent and share the BatchNorm mode: one grouped pass (same order: gt, then p)
@@ -299,6 +337,7 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
                 gt_shape_recon_loss = zero
             p_recon = self.recon_shape(y_0_new, is_label_map=False, disable_track_bn_stats=disable_track_bn_stats)
         pred_shape_recon_loss = basic_loss_fn(p_recon, label_l, "cross entropy")
+        self._join_side()
         return standard_supervised_loss, image_recon_loss, gt_shape_recon_loss, pred_shape_recon_loss
 
     def hard_example_training(self, perturbed_image, clean_image_l, perturbed_seg, label_l, separate_training=False, use_gpu=True):
@@ -308,15 +347,17 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
         if perturbed_image is not None and perturbed_seg is not None and self.group_stn_passes and self.training:
             # FTN pass on the hard image, then both STN passes (prediction of the hard image, corrupted segmentation: independent,
             # both with frozen BatchNorm statistics tracking) as one grouped pass
-            (z_i, _), y_0 = self.fast_predict(perturbed_image.detach(), disable_track_bn_stats=True)
+            z_i, z_s = self._enc(perturbed_image.detach(), True)
+            recon_loss = self._image_recon_loss(z_i, clean_image_l)              # (side stream when two_streams)
+            y_0 = self._call(self.model["segmentation_decoder"], z_s, True)
             seg_loss = basic_loss_fn(y_0, label_l.detach(), "cross entropy")
-            recon_loss = scaled_mse(self.decode_image(z_i), clean_image_l, 0.5)
             if separate_training:
                 perturbed_seg = perturbed_seg.detach()
             p_recon, perturbed_p_recon = self.recon_shape_pair(y_0.detach() if separate_training else y_0, False, perturbed_seg, False,
                                                                disable_track_bn_stats=True)
             shape_loss = basic_loss_fn(p_recon, label_l, "cross entropy")
             perturbed_p_recon_loss = basic_loss_fn(perturbed_p_recon, label_l, "cross entropy")
+            self._join_side()
             return seg_loss, recon_loss, shape_loss, perturbed_p_recon_loss
         if perturbed_image is not None:
             seg_loss, recon_loss, _, shape_loss = self.standard_training(
@@ -372,7 +413,9 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
                                                 random_threshold=img_cfg["random_threshold"], if_detach=True,
                                                 if_soft=img_cfg["if_soft"], override=image_override)
                 self.last_masks["image"] = m
-                perturbed_image_0 = self.decoder_inference(d_img, z, eval=False, disable_track_bn_stats=True)
+                zi_masked = z
+                perturbed_image_0 = self._fork_side(lambda: self.decoder_inference(d_img, zi_masked, eval=False, disable_track_bn_stats=True),
+                                                    zi_masked)
             if gen_corrupted_seg:
                 self.reset_all_optimizers()
                 z, m = self.perturb_latent_code(self.z_s, d_seg, label_y=label_l, perturb_type=seg_cfg["mask_type"],
@@ -381,6 +424,7 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
                                                 if_soft=seg_cfg["if_soft"], override=seg_override)
                 self.last_masks["seg"] = m
                 perturbed_y_0 = self.decoder_inference(d_seg, z, eval=False, disable_track_bn_stats=True)
+            self._join_side()
         finally:
             set_grad(d_seg, requires_grad=True)
             set_grad(d_img, requires_grad=True)

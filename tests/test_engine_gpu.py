@@ -294,6 +294,29 @@ def test_full_cooperative_step_vs_golden(golden_cases, golden_sd, case):
         k, n = key.split("/")
         close(dict(s.model[k].named_parameters())[n], p, atol=2.1e-4, what=key)
 
+def test_two_stream_step_is_bitwise_identical(golden_cases, golden_sd):
+    """The image decoder's launch chain runs on a second HIP stream (solver.two_streams).  Every kernel is deterministic, so two
+    training steps must leave bit-identical weights and losses with and without it -- a race would show up here."""
+    C = golden_cases["D_step_dropout"]
+    outs = []
+    for two in (False, True, True):
+        s = _solver(golden_sd)
+        s.two_streams = two
+        if two and s._side is None:
+            s._side = torch.cuda.Stream(device=s.device)
+        ov_img, ov_seg = _overrides(C, (C["img_cfg"], C["seg_cfg"]))
+        for _ in range(2):
+            losses = s.cooperative_step(dev(C["clean"]), dev(C["label"]), dev(C["noisy"]), C["img_cfg"], C["seg_cfg"],
+                                        image_override=ov_img, seg_override=ov_seg)
+        torch.cuda.synchronize()
+        outs.append((torch.stack([v.detach().float() for v in losses]).cpu(),
+                     {k: m._flat_data.detach().cpu().clone() for k, m in s.model.items()}))
+    for l, w in outs[1:]:
+        assert torch.equal(l, outs[0][0])
+        for k in w:
+            assert torch.equal(w[k], outs[0][1][k]), k
+
+
 
 def test_predict_vs_golden(golden_cases, golden_sd):
     F_ = golden_cases["F_predict"]

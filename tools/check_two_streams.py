@@ -1,0 +1,32 @@
+"""Race check for the two-stream step: N training steps with and without CTL_TWO_STREAMS from the same seed must give the
+same losses and the same weights (bitwise: every kernel is deterministic), several times in a row."""
+import os, sys, subprocess, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+def child():
+    import torch, hashlib
+    from cooperative_training_and_latent_space_data_augmentation_amd.solver import AdvancedTripletReconSegmentationModel
+    import bench
+    torch.manual_seed(0)
+    s = AdvancedTripletReconSegmentationModel(use_gpu=True)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    clean = torch.rand(16, 1, 256, 256, device="cuda", generator=g); noisy = (clean + 0.1 * torch.randn(clean.shape, device="cuda", generator=g)).clamp(0, 1)
+    label = torch.randint(0, 4, (16, 256, 256), device="cuda", generator=g)
+    keep_i = (torch.rand(16, 128, device="cuda", generator=g) > 0.3).float(); keep_s = (torch.rand(16, 128, device="cuda", generator=g) > 0.3).float()
+    for it in range(12):
+        losses = s.cooperative_step(clean, label, noisy, bench.DROP_IMG, bench.DROP_SEG, image_override={"keep": keep_i}, seg_override={"keep": keep_s})
+    torch.cuda.synchronize()
+    h = hashlib.sha256()
+    for k in sorted(s.model):
+        h.update(s.model[k]._flat_data.detach().cpu().numpy().tobytes())
+    print("RESULT " + json.dumps({"losses": [float(v) for v in losses], "weights_sha": h.hexdigest()}))
+if __name__ == "__main__":
+    if len(sys.argv) > 1: child(); sys.exit(0)
+    res = []
+    for mode in ("0", "1", "1", "1", "0"):
+        env = dict(os.environ, CTL_TWO_STREAMS=mode)
+        out = subprocess.run([sys.executable, __file__, "child"], env=env, capture_output=True, text=True)
+        line = [l for l in out.stdout.splitlines() if l.startswith("RESULT ")]
+        if not line: print(out.stderr[-2000:]); sys.exit(1)
+        r = json.loads(line[0][7:]); res.append(r); print("two_streams=" + mode, r["weights_sha"][:16], ["%.6f" % v for v in r["losses"]])
+    ok = all(r["weights_sha"] == res[0]["weights_sha"] and r["losses"] == res[0]["losses"] for r in res)
+    print("IDENTICAL" if ok else "MISMATCH"); sys.exit(0 if ok else 1)
