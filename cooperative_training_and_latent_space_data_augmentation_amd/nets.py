@@ -364,7 +364,7 @@ class CtlNet(nn.Module):
         self._bns: Dict[str, BNInfo] = {}
         self._plans: Dict[tuple, Plan] = {}
         self._packed_ok = False
-        self._scr: Optional[torch.Tensor] = None
+        self._scr: Optional[dict] = None          # stream handle -> scratch tensor
         self._build_tree()
         self._finalize_storage(torch.device(device))
 
@@ -522,11 +522,17 @@ class CtlNet(nn.Module):
     def _run(self, plan: Plan, tensors: Dict[int, torch.Tensor]):
         if not self._flat_data.is_cuda:
             raise _ffi.CtlError("the HIP engine needs the network on a GPU device; there is no CPU fallback")
+        stream = torch.cuda.current_stream()
         if plan.scr_bytes:
-            if self._scr is None or self._scr.numel() < plan.scr_bytes:
-                self._scr = torch.empty(plan.scr_bytes, dtype=torch.uint8, device=self.device)
+            # transient scratch (statistics / reduction partials), reused by consecutive plans: one buffer PER STREAM -- two
+            # passes of this network may be in flight on different streams (solver._two_chain_forward)
+            if self._scr is None:
+                self._scr = {}
+            scr = self._scr.get(stream.cuda_stream)
+            if scr is None or scr.numel() < plan.scr_bytes:
+                scr = self._scr[stream.cuda_stream] = torch.empty(plan.scr_bytes, dtype=torch.uint8, device=self.device)
             tensors = dict(tensors)
-            tensors[S_SCR] = self._scr
+            tensors[S_SCR] = scr
         if plan.table_np is not None:
             if plan.table_dev is None or plan.table_dev.device != self.device:
                 plan.table_dev = torch.from_numpy(plan.table_np).to(self.device)
@@ -535,7 +541,7 @@ class CtlNet(nn.Module):
         bases = (ctypes.c_void_p * N_SLOTS)()
         for s, t in tensors.items():
             bases[s] = t.data_ptr()
-        check(lib.ctl_plan_run(plan.ops.ctypes.data, plan.n_ops, bases, N_SLOTS, torch.cuda.current_stream().cuda_stream),
+        check(lib.ctl_plan_run(plan.ops.ctypes.data, plan.n_ops, bases, N_SLOTS, stream.cuda_stream),
               f"{type(self).__name__} plan")
 
     def bn_mode(self) -> str:

@@ -72,6 +72,7 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
         self.two_streams = os.environ.get("CTL_TWO_STREAMS", "1") != "0"
         self._side = torch.cuda.Stream(device=self.device) if self.two_streams else None
         self._side_pending = False
+        self._in_side = False            # True while the hard-example branch of cooperative_step is being issued on the side stream
         self.training = True
 
     # ------------------------------------------------------------------ construction / checkpoints
@@ -211,7 +212,7 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
     def _fork_side(self, fn, *inputs):
         """Run fn() on the side stream (after everything issued so far on the current stream) when two_streams is on; the result
         must not be touched on the main stream before _join_side()."""
-        if not self.two_streams:
+        if not self.two_streams or self._in_side:
             return fn()
         cur = torch.cuda.current_stream()
         self._side.wait_stream(cur)
@@ -309,9 +310,14 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
 
     # ------------------------------------------------------------------ losses of one step (model.py:414-467, 525-559)
     def standard_training(self, clean_image_l, label_l, perturbed_image, separate_training=False, compute_gt_recon=True,
-                          update_latent=True, disable_track_bn_stats=False):
+                          update_latent=True, disable_track_bn_stats=False, _pre=None):
+        """`_pre = (z_i, z_s, image_recon_loss)`: the FTN encoder pass and the image branch were already issued by the caller
+        (cooperative_step runs the image branch and the whole hard-example branch on the second stream)."""
         zero = torch.zeros((), device=clean_image_l.device)
-        if self.two_streams and self.training:
+        if _pre is not None:
+            z_i, z_s, image_recon_loss = _pre
+            y_0 = self._call(self.model["segmentation_decoder"], z_s, disable_track_bn_stats)
+        elif self.two_streams and self.training and not self._in_side:
             z_i, z_s = self._enc(perturbed_image, disable_track_bn_stats)
             image_recon_loss = self._image_recon_loss(z_i, clean_image_l)      # side stream, next to D_seg -> STN below
             y_0 = self._call(self.model["segmentation_decoder"], z_s, disable_track_bn_stats)
@@ -470,12 +476,57 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
         return torch.abs(input - recon), torch.abs(refined - first), first, refined, recon
 
     # ------------------------------------------------------------------ one full iteration (train...py:171-237)
+    def _two_chain_forward(self, clean_image_l, label_l, image_l, img_cfg, seg_cfg, separate_training, image_override, seg_override):
+        """Forward of one iteration as two launch chains.  After the FTN encoder everything the hard-example branch needs exists
+        (z_i, z_s): image decoder + its loss, hard-example generation and the whole hard-example training forward go to the
+        second stream; D_seg -> STN of the standard phase stay on the main stream.  Same calls, same order per network (so the
+        BatchNorm running statistics see the same sequence), same numbers -- the launch-latency-bound low-resolution layers of one
+        chain fill the gaps of the other.  autograd runs every backward node on the stream of its forward, so the backward
+        overlaps the same way.  Weights are packed before the fork (the pack kernels must not race between the streams)."""
+        for net in self.model.values():
+            net.ensure_packed()
+        cur, side = torch.cuda.current_stream(), self._side
+        z_i, z_s = self._enc(image_l)
+        self.z_i, self.z_s = z_i, z_s
+        side.wait_stream(cur)
+        for t in (z_i, z_s, clean_image_l, label_l):
+            t.record_stream(side)
+        self._in_side = True
+        try:
+            with torch.cuda.stream(side):
+                image_recon_loss = scaled_mse(self.decode_image(z_i), clean_image_l, 0.5)
+                xh, yh = self.hard_example_generation(clean_image_l.detach(), label_l.detach(), gen_corrupted_seg=seg_cfg is not None,
+                                                      gen_corrupted_image=img_cfg is not None, corrupted_image_DA_config=img_cfg,
+                                                      corrupted_seg_DA_config=seg_cfg, image_override=image_override,
+                                                      seg_override=seg_override)
+                hard = self.hard_example_training(perturbed_image=xh, perturbed_seg=yh, clean_image_l=clean_image_l, label_l=label_l,
+                                                  separate_training=separate_training)
+        finally:
+            self._in_side = False
+        std = self.standard_training(clean_image_l, label_l, perturbed_image=image_l, separate_training=separate_training,
+                                     _pre=(z_i, z_s, image_recon_loss))
+        cur.wait_stream(side)
+        for t in (image_recon_loss,) + tuple(hard):
+            t.record_stream(cur)
+        return std, hard
+
     def cooperative_step(self, clean_image_l, label_l, image_l, img_cfg=None, seg_cfg=None, latent_DA=True, separate_training=False,
                          image_override=None, seg_override=None, do_optim=True, grad_hook=None):
         """The loop body of `train_network`, without its ten `.item()` syncs / `empty_cache()` stalls.  Returns the
         8 loss tensors (device scalars): standard (seg, image, gt_shape, shape) + hard (seg, image, shape, perturbed)."""
         self.train()
         self.reset_all_optimizers()
+        if self.two_streams and latent_DA:
+            std, hard = self._two_chain_forward(clean_image_l, label_l, image_l, img_cfg, seg_cfg, separate_training, image_override,
+                                                seg_override)
+            loss = (std[0] + std[1] + std[3] + std[2]) + (hard[0] + hard[1] + hard[2] + hard[3])
+            self.reset_all_optimizers()
+            loss.backward()
+            if grad_hook is not None:
+                grad_hook(self)
+            if do_optim:
+                self.optimize_all_params()
+            return tuple(std) + tuple(hard)
         std = self.standard_training(clean_image_l, label_l, perturbed_image=image_l, separate_training=separate_training)
         loss = std[0] + std[1] + std[3] + std[2]
         zero = torch.zeros((), device=clean_image_l.device)

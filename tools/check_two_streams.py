@@ -12,8 +12,13 @@ def child():
     clean = torch.rand(16, 1, 256, 256, device="cuda", generator=g); noisy = (clean + 0.1 * torch.randn(clean.shape, device="cuda", generator=g)).clamp(0, 1)
     label = torch.randint(0, 4, (16, 256, 256), device="cuda", generator=g)
     keep_i = (torch.rand(16, 128, device="cuda", generator=g) > 0.3).float(); keep_s = (torch.rand(16, 128, device="cuda", generator=g) > 0.3).float()
+    TGT_IMG = {"loss_name": "mse", "mask_type": "channel", "max_threshold": 0.5, "random_threshold": False, "if_soft": False}
+    TGT_SEG = {"loss_name": "ce", "mask_type": "spatial", "max_threshold": 0.5, "random_threshold": False, "if_soft": False}
     for it in range(12):
-        losses = s.cooperative_step(clean, label, noisy, bench.DROP_IMG, bench.DROP_SEG, image_override={"keep": keep_i}, seg_override={"keep": keep_s})
+        if os.environ.get("CHECK_TARGETED") == "1":
+            losses = s.cooperative_step(clean, label, noisy, TGT_IMG, TGT_SEG)
+        else:
+            losses = s.cooperative_step(clean, label, noisy, bench.DROP_IMG, bench.DROP_SEG, image_override={"keep": keep_i}, seg_override={"keep": keep_s})
     torch.cuda.synchronize()
     h = hashlib.sha256()
     for k in sorted(s.model):
@@ -22,7 +27,7 @@ def child():
 if __name__ == "__main__":
     if len(sys.argv) > 1: child(); sys.exit(0)
     res = []
-    for mode in ("0", "1", "1", "1", "0"):
+    for mode in ("0", "1", "1", "1", "1", "1", "0"):
         env = dict(os.environ, CTL_TWO_STREAMS=mode)
         out = subprocess.run([sys.executable, __file__, "child"], env=env, capture_output=True, text=True)
         line = [l for l in out.stdout.splitlines() if l.startswith("RESULT ")]
