@@ -212,8 +212,20 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
     def _fork_side(self, fn, *inputs):
         """Run fn() on the side stream (after everything issued so far on the current stream) when two_streams is on; the result
         must not be touched on the main stream before _join_side()."""
-        if not self.two_streams or self._in_side:
+        if not self.two_streams:
             return fn()
+        if self._in_side:
+            # issued from the hard-example branch (which itself lives on the second stream): hand this piece back to the main
+            # stream, which has finished the standard phase's D_seg -> STN by the time the hard image is encoded
+            main, side = self._main, self._side
+            main.wait_stream(side)
+            for t in inputs:
+                t.record_stream(main)
+            with torch.cuda.stream(main):
+                out = fn()
+            for t in (out if isinstance(out, tuple) else (out,)):
+                t.record_stream(side)
+            return out
         cur = torch.cuda.current_stream()
         self._side.wait_stream(cur)
         for t in inputs:
@@ -327,7 +339,7 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
         if update_latent:
             self.z_i, self.z_s = z_i, z_s
         standard_supervised_loss = basic_loss_fn(y_0, label_l.detach(), "cross entropy")
-        if image_recon_loss is None:
+        if image_recon_loss is None and _pre is None:
             image_recon = self.decode_image(z_i)                       # always BN mode A, as upstream (model.py:444)
             image_recon_loss = scaled_mse(image_recon, clean_image_l, 0.5)
         y_0_new = y_0.detach() if separate_training else y_0
@@ -420,8 +432,8 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
                                                 if_soft=img_cfg["if_soft"], override=image_override)
                 self.last_masks["image"] = m
                 zi_masked = z
-                perturbed_image_0 = self._fork_side(lambda: self.decoder_inference(d_img, zi_masked, eval=False, disable_track_bn_stats=True),
-                                                    zi_masked)
+                gen_img = lambda: self.decoder_inference(d_img, zi_masked, eval=False, disable_track_bn_stats=True)
+                perturbed_image_0 = gen_img() if self._in_side else self._fork_side(gen_img, zi_masked)
             if gen_corrupted_seg:
                 self.reset_all_optimizers()
                 z, m = self.perturb_latent_code(self.z_s, d_seg, label_y=label_l, perturb_type=seg_cfg["mask_type"],
@@ -486,11 +498,15 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
         for net in self.model.values():
             net.ensure_packed()
         cur, side = torch.cuda.current_stream(), self._side
+        self._main = cur
         z_i, z_s = self._enc(image_l)
         self.z_i, self.z_s = z_i, z_s
-        side.wait_stream(cur)
+        side.wait_stream(cur)                       # fork point: right after the encoder
         for t in (z_i, z_s, clean_image_l, label_l):
             t.record_stream(side)
+        # main chain first (the CPU issues in program order; the GPU starts on it at once): D_seg -> STN of the standard phase
+        std = self.standard_training(clean_image_l, label_l, perturbed_image=image_l, separate_training=separate_training,
+                                     _pre=(z_i, z_s, None))
         self._in_side = True
         try:
             with torch.cuda.stream(side):
@@ -503,12 +519,10 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
                                                   separate_training=separate_training)
         finally:
             self._in_side = False
-        std = self.standard_training(clean_image_l, label_l, perturbed_image=image_l, separate_training=separate_training,
-                                     _pre=(z_i, z_s, image_recon_loss))
         cur.wait_stream(side)
         for t in (image_recon_loss,) + tuple(hard):
             t.record_stream(cur)
-        return std, hard
+        return (std[0], image_recon_loss, std[2], std[3]), hard
 
     def cooperative_step(self, clean_image_l, label_l, image_l, img_cfg=None, seg_cfg=None, latent_DA=True, separate_training=False,
                          image_override=None, seg_override=None, do_optim=True, grad_hook=None):
