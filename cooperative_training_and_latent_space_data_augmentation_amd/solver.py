@@ -71,6 +71,9 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
         # second HIP stream next to D_seg -> STN on the main stream
         self.two_streams = os.environ.get("CTL_TWO_STREAMS", "1") != "0"
         self._side = torch.cuda.Stream(device=self.device) if self.two_streams else None
+        if self.two_streams and hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
+            # the flat-parameter leaves live on the main stream while part of their gradient is produced on the second one: intended
+            torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
         self._side_pending = False
         self._in_side = False            # True while the hard-example branch of cooperative_step is being issued on the side stream
         self.training = True
