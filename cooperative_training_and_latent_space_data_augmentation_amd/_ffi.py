@@ -47,7 +47,7 @@ class _Lib:
         lib.ctl_version.restype = C.c_int
         for name in ("ctl_conv_wpack_floats", "ctl_conv_stats_floats", "ctl_wgrad_partial_floats",
                      "ctl_wgrad_bias_partial_floats", "ctl_latent_score_ws_floats", "ctl_latent_mask_apply_ws_floats",
-                     "ctl_sizeof_op", "ctl_sizeof_conv"):
+                     "ctl_rescale_intensity_ws_floats", "ctl_sizeof_op", "ctl_sizeof_conv"):
             getattr(lib, name).restype = C.c_size_t
         p, i32, i64, f32, u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64
         sig = {
@@ -58,6 +58,11 @@ class _Lib:
             "ctl_conv_forward": [p] * 12,
             "ctl_conv_wgrad": [p] * 8,
             "ctl_wgrad_reduce": [p, p, p, p, i64, i64, i64, i64, p, i32, p],
+            "ctl_confusion_hist": [p, p, i64, i32, p, p],
+            "ctl_rescale_intensity": [p, p, p, i32, i64, f32, f32, f32, p],
+            "ctl_noise_clamp": [p, p, u64, f32, f32, f32, p, i64, p],
+            "ctl_rescale_intensity_ws_floats": [i32],
+            "ctl_crop_or_pad": [p, p, i32, i32, i32, i32, i32, i32, p],
             "ctl_bn_finalize": [p, i32, i32, i64, p, p, f32, f32, i32, p, p, p, p, p, p, p, i32, p],
             "ctl_bn_eval_coeffs": [i32, p, p, p, p, f32, p, p, i32, p],
             "ctl_bn_act": [p, p, p, f32, p, i64, i32, i32, p],
@@ -109,7 +114,8 @@ EXPORTED = ["ctl_version", "ctl_last_error", "ctl_conv_wpack_floats", "ctl_conv_
             "ctl_mse_fwd", "ctl_mse_bwd", "ctl_argmax_c", "ctl_latent_score_ws_floats", "ctl_latent_score",
             "ctl_latent_mask_apply", "ctl_latent_mask_apply_ws_floats", "ctl_dropout2d", "ctl_uniform", "ctl_adam", "ctl_plan_run", "ctl_sizeof_op",
             "ctl_sizeof_conv", "ctl_prof_start", "ctl_prof_stop", "ctl_pack_weights_batched",
-            "ctl_wgrad_reduce_batched"]
+            "ctl_wgrad_reduce_batched", "ctl_confusion_hist", "ctl_rescale_intensity_ws_floats", "ctl_rescale_intensity",
+            "ctl_noise_clamp", "ctl_crop_or_pad"]
 
 
 def prof_start(kernel_filter: str = "") -> None:

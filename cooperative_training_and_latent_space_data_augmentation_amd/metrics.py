@@ -15,11 +15,24 @@ class runningScore(object):
         return np.bincount(idx, minlength=n_class ** 2).reshape(n_class, n_class)
 
     def update(self, label_trues, label_preds):
+        """Device tensors (both on the GPU) are accumulated by the HIP kernel into an int64 matrix that stays on the device: no
+        host round trip per batch; numpy inputs follow the upstream host path."""
+        import torch
+        if torch.is_tensor(label_trues) and torch.is_tensor(label_preds) and label_trues.is_cuda and label_preds.is_cuda:
+            from . import ops
+            self._dev_hist = ops.confusion_hist(label_trues, label_preds, self.n_classes, getattr(self, "_dev_hist", None))
+            return
         for lt, lp in zip(label_trues, label_preds):
             self.confusion_matrix += self._fast_hist(np.asarray(lt).flatten(), np.asarray(lp).flatten(), self.n_classes)
 
-    def get_scores(self):
+    def _total(self):
         h = self.confusion_matrix
+        if getattr(self, "_dev_hist", None) is not None:
+            h = h + self._dev_hist.cpu().numpy().astype(np.float64)          # the one synchronisation of an evaluation
+        return h
+
+    def get_scores(self):
+        h = self._total()
         with np.errstate(divide="ignore", invalid="ignore"):
             acc = np.diag(h).sum() / h.sum()
             acc_cls = np.nanmean(np.diag(h) / h.sum(axis=1))
@@ -30,6 +43,14 @@ class runningScore(object):
 
     def reset(self):
         self.confusion_matrix = np.zeros((self.n_classes, self.n_classes))
+        self._dev_hist = None
+
+
+def dice_from_confusion(confusion) -> np.ndarray:
+    """Per-class Dice of one volume from its confusion matrix: 2*h_cc / (row_c + col_c) == dc(pred == c, gt == c) (measure.py:52-99)."""
+    h = np.asarray(confusion, dtype=np.float64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return 2.0 * np.diag(h) / (h.sum(axis=1) + h.sum(axis=0))
 
 
 def dice(result, reference) -> float:

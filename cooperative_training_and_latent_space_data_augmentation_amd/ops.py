@@ -225,3 +225,58 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
     require_gpu(p, g, m, v)
     check(lib.ctl_adam(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, step, grad_scale, stream_ptr()),
           "ctl_adam")
+
+
+# ---------------------------------------------------------------------------------------------- metrics + input pipeline
+def confusion_hist(label_true: torch.Tensor, label_pred: torch.Tensor, n_class: int, hist: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Accumulate `runningScore._fast_hist` (metrics.py:18-23) into `hist` (int64 [n_class, n_class], created zeroed if None)."""
+    require_gpu(label_true, label_pred)
+    lt = label_true.long().contiguous()
+    lp = label_pred.to(torch.uint8).contiguous()
+    if lt.numel() != lp.numel():
+        raise ValueError("confusion_hist: label_true and label_pred differ in size")
+    if hist is None:
+        hist = torch.zeros((n_class, n_class), dtype=torch.int64, device=lt.device)
+    check(lib.ctl_confusion_hist(ptr(lt), ptr(lp), lt.numel(), n_class, ptr(hist), stream_ptr()), "ctl_confusion_hist")
+    return hist
+
+
+def rescale_intensity(data: torch.Tensor, new_min: float = 0.0, new_max: float = 1.0, eps: float = 1e-20) -> torch.Tensor:
+    """basic_operations.py:232-245 on device; data: [N,C,H,W] float32 in plain NCHW memory (each (n,c) plane contiguous)."""
+    require_gpu(data)
+    x = data.float().contiguous()
+    n, c, h, w = x.shape
+    out = torch.empty_like(x)
+    ws = torch.empty(lib.ctl_rescale_intensity_ws_floats(n * c), dtype=torch.float32, device=x.device)
+    check(lib.ctl_rescale_intensity(ptr(x), ptr(out), ptr(ws), n * c, h * w, new_min, new_max, eps, stream_ptr()), "ctl_rescale_intensity")
+    return out
+
+
+def noise_clamp(x: torch.Tensor, noise: Optional[torch.Tensor] = None, sigma: float = 0.05, lo: float = 0.0, hi: float = 1.0,
+                seed: int = 0) -> torch.Tensor:
+    """clamp(x + noise, lo, hi); noise=None draws sigma*N(0,1) on device from `seed` (train...py:185-187)."""
+    require_gpu(x)
+    x = x.float().contiguous()
+    if noise is not None:
+        noise = noise.float().contiguous()
+        if noise.shape != x.shape:
+            raise ValueError("noise_clamp: noise must have the shape of x")
+    out = torch.empty_like(x)
+    check(lib.ctl_noise_clamp(ptr(x), ptr(noise), seed & (2 ** 64 - 1), sigma, lo, hi, ptr(out), x.numel(), stream_ptr()), "ctl_noise_clamp")
+    return out
+
+
+def crop_or_pad(image: torch.Tensor, crop_size, label: Optional[torch.Tensor] = None):
+    """basic_operations.py:173-220 for [n,h,w] (or [h,w]) device tensors: (image, label) cropped / zero-padded to crop_size."""
+    def one(a):
+        require_gpu(a)
+        squeeze = a.dim() == 2
+        a3 = (a.unsqueeze(0) if squeeze else a).contiguous()
+        if a3.dim() != 3 or a3.element_size() not in (1, 4, 8):
+            raise ValueError("crop_or_pad: expected a [n,h,w] or [h,w] tensor with 1-, 4- or 8-byte elements")
+        n, h, w = a3.shape
+        out = torch.empty((n, int(crop_size[0]), int(crop_size[1])), dtype=a3.dtype, device=a3.device)
+        check(lib.ctl_crop_or_pad(ptr(a3), ptr(out), a3.element_size(), n, h, w, int(crop_size[0]), int(crop_size[1]), stream_ptr()),
+              "ctl_crop_or_pad")
+        return out[0] if squeeze else out
+    return one(image), (None if label is None else one(label))

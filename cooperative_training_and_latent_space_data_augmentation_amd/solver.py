@@ -476,7 +476,14 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
         n_iter = self.n_iter if n_iter is None else n_iter
         self.train(if_testing=True)
         pred = self.predict(input, n_iter=n_iter)
-        pred_npy = ops.argmax_c(pred).cpu().numpy()
+        pred_lab = ops.argmax_c(pred)
+        if torch.is_tensor(targets_npy) and targets_npy.is_cuda:
+            # ground truth already on the device -> confusion matrix accumulated there, nothing is copied to
+            # the host per batch (the cur_eval_* visualisation copies are made lazily by whoever asks for them)
+            self.running_metric.update(label_trues=targets_npy, label_preds=pred_lab)
+            self.cur_eval_images, self.cur_eval_predicts, self.cur_eval_gts = input.detach()[:, 0], pred_lab, targets_npy
+            return pred
+        pred_npy = pred_lab.cpu().numpy()
         self.running_metric.update(label_trues=targets_npy, label_preds=pred_npy)
         self.cur_eval_images = input.detach().cpu().numpy()[:, 0, :, :]
         self.cur_eval_predicts, self.cur_eval_gts = pred_npy, targets_npy

@@ -192,6 +192,27 @@ int ctl_dropout2d(const float* z, const float* keep, uint64_t seed, float p, flo
 /* 0.5*U[0,1) style uniform fill from the same counter hash (soft-mask noise, util.py:239) */
 int ctl_uniform(float* out, int64_t count, uint64_t seed, ctl_stream stream);
 
+/* ------------------------------------------------------------------------------------------------ SURVEY 8(f) rows 1, 3
+ * Validation metrics and the input pipeline on device (no host round trip per batch).
+ * ctl_confusion_hist: `runningScore._fast_hist` (medseg/common_utils/metrics.py:18-23): hist[n_class*t + p] += 1 for every
+ *   element with 0 <= t < n_class (p = predicted label, uint8 as written by ctl_argmax_c); hist is int64 [n_class*n_class] and
+ *   ACCUMULATES (zero it to start a new evaluation); n_class <= 16.  Integer atomics only: order-independent, bit-exact.
+ * ctl_rescale_intensity: per plane (n*c planes of plane_elems floats) (x-min)/(max-min+eps)*(new_max-new_min)+new_min
+ *   (medseg/common_utils/basic_operations.py:232-245), torch's operation order, one rounding per operation.
+ * ctl_noise_clamp: out = clamp(x + noise, lo, hi) (train_adv_supervised_segmentation_triplet.py:185-187); noise == NULL:
+ *   sigma * N(0,1) drawn on device from a counter hash of (seed, index) (Box-Muller).
+ * ctl_crop_or_pad: centre crop / zero pad of [n,h,w] arrays to [n,new_h,new_w] (medseg/common_utils/basic_operations.py:
+ *   173-220): dst[y][x] = src[y + floor((h-new_h)/2)][x + floor((w-new_w)/2)] or 0 outside; elem_bytes 1, 4 or 8. */
+int ctl_confusion_hist(const int64_t* label_true, const uint8_t* label_pred, int64_t count, int32_t n_class, int64_t* hist,
+                       ctl_stream stream);
+size_t ctl_rescale_intensity_ws_floats(int32_t planes);
+int ctl_rescale_intensity(const float* x, float* out, float* workspace, int32_t planes, int64_t plane_elems, float new_min,
+                          float new_max, float eps, ctl_stream stream);
+int ctl_noise_clamp(const float* x, const float* noise, uint64_t seed, float sigma, float lo, float hi, float* out,
+                    int64_t count, ctl_stream stream);
+int ctl_crop_or_pad(const void* src, void* dst, int32_t elem_bytes, int32_t n, int32_t h, int32_t w, int32_t new_h,
+                    int32_t new_w, ctl_stream stream);
+
 /* ------------------------------------------------------------------------------------------------ optimizer
  * torch.optim.Adam defaults (model.py:774-785), one flat buffer: p,g,m,v [count].  step = 1-based step index.
  * grad_scale folds the 1/world_size of the data-parallel all-reduce. */

@@ -527,6 +527,55 @@ def confusion_hist(label_true: np.ndarray, label_pred: np.ndarray, n_class: int)
     return np.bincount(n_class * lt[m].astype(int) + lp[m], minlength=n_class ** 2).reshape(n_class, n_class)
 
 
+# ---------------------------------------------------------------------------------------------- SURVEY 8(f) rows 1 and 3
+def rescale_intensity(data: torch.Tensor, new_min: float = 0.0, new_max: float = 1.0, eps: float = 1e-20) -> torch.Tensor:
+    """Min-max rescale per (n, c) plane (medseg/common_utils/basic_operations.py:232-245)."""
+    bs, c, h, w = data.shape
+    flat = data.reshape(bs * c, -1)
+    old_max = flat.max(dim=1, keepdim=True).values
+    old_min = flat.min(dim=1, keepdim=True).values
+    return ((flat - old_min) / (old_max - old_min + eps) * (new_max - new_min) + new_min).reshape(bs, c, h, w)
+
+
+def crop_or_pad(image: np.ndarray, crop_size, label: np.ndarray = None):
+    """Centre crop / zero pad [n,h,w] arrays to crop_size (medseg/common_utils/basic_operations.py:173-220): per axis the source
+    index is `dst + (size - new)//2` (floor division, negative when padding), zero outside the source."""
+    def one(a):
+        n, h, w = a.shape
+        nh, nw = crop_size
+        hs, ws = (h - nh) // 2, (w - nw) // 2
+        out = np.zeros((n, nh, nw), dtype=a.dtype)
+        ys, xs = np.arange(nh) + hs, np.arange(nw) + ws
+        vy, vx = (ys >= 0) & (ys < h), (xs >= 0) & (xs < w)
+        out[:, np.ix_(vy, vx)[0], np.ix_(vy, vx)[1]] = a[:, ys[vy]][:, :, xs[vx]]
+        return out
+    return one(image), (None if label is None else one(label))
+
+
+def noise_clamp(clean: torch.Tensor, noise: torch.Tensor, lo: float = 0.0, hi: float = 1.0) -> torch.Tensor:
+    """`clamp(clean + noise, 0, 1)` with noise = 0.05 * N(0,1) (medseg/train_adv_supervised_segmentation_triplet.py:185-187)."""
+    return torch.clamp(clean + noise, lo, hi)
+
+
+def running_scores(confusion: np.ndarray):
+    """`runningScore.get_scores` (medseg/common_utils/metrics.py:33-54) from an accumulated confusion matrix."""
+    h = np.asarray(confusion, dtype=np.float64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        acc = np.diag(h).sum() / h.sum()
+        acc_cls = np.nanmean(np.diag(h) / h.sum(axis=1))
+        iu = np.diag(h) / (h.sum(axis=1) + h.sum(axis=0) - np.diag(h))
+        freq = h.sum(axis=1) / h.sum()
+    return ({"Overall Acc: \t": acc, "Mean Acc : \t": acc_cls, "FreqW Acc : \t": (freq[freq > 0] * iu[freq > 0]).sum(),
+             "Mean IoU : \t": np.nanmean(iu)}, dict(zip(range(h.shape[0]), iu)))
+
+
+def dice_from_confusion(confusion: np.ndarray) -> np.ndarray:
+    """Per-class Dice of one volume from its confusion matrix: 2*h_cc / (row_c + col_c) = `dc(pred == c, gt == c)` (measure.py:52-99)."""
+    h = np.asarray(confusion, dtype=np.float64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return 2.0 * np.diag(h) / (h.sum(axis=1) + h.sum(axis=0))
+
+
 def synthetic_batch(n: int, h: int, w: int, num_classes: int = 4, seed: int = 0, structured: bool = False):
     """SURVEY 8d synthetic inputs: U[0,1) images, randint labels (or a concentric-ellipse phantom),
     0.05*N(0,1) input noise clamped to [0,1] (train...py:185-187)."""

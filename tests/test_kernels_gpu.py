@@ -397,3 +397,70 @@ def test_dropout2d_injected_and_device_rng():
     assert torch.equal(out2.cpu(), z * k2.cpu().view(4, 128, 1, 1) * 2.0)
     u = ops.uniform((1 << 16,), DEV, 99).cpu()
     assert 0 <= float(u.min()) and float(u.max()) < 1 and abs(float(u.mean()) - 0.5) < 0.01
+
+
+# ---------------------------------------------------------------------------------------------- SURVEY 8(f) rows 1 and 3
+def _io_cases():
+    import os
+    return torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "io_cases.pt"), weights_only=False)
+
+
+def test_input_pipeline_kernels_bit_exact_vs_reference_vectors():
+    io = _io_cases()
+    for r in io["rescale"]:
+        y = ops.rescale_intensity(r["x"].to(DEV), r["new_min"], r["new_max"])
+        assert torch.equal(y.cpu(), r["y"]), float((y.cpu() - r["y"]).abs().max())
+    for r in io["crop_or_pad"]:
+        a, b = ops.crop_or_pad(r["image"].to(DEV), r["size"], r["label"].to(DEV))
+        assert torch.equal(a.cpu(), r["image_out"]) and torch.equal(b.cpu(), r["label_out"])
+        u8, _ = ops.crop_or_pad(r["label"].to(torch.uint8).to(DEV), r["size"])
+        assert torch.equal(u8.cpu(), r["label_out"].to(torch.uint8))
+    r = io["noise_clamp"][0]
+    assert torch.equal(ops.noise_clamp(r["clean"].to(DEV), r["noise"].to(DEV)).cpu(), r["out"])
+    # device RNG: reproducible from the seed, ~N(0, sigma^2) before clamping, bounds respected
+    x = torch.full((64, 1, 128, 128), 0.5, device=DEV)
+    a, b, c = ops.noise_clamp(x, sigma=0.05, seed=3), ops.noise_clamp(x, sigma=0.05, seed=3), ops.noise_clamp(x, sigma=0.05, seed=4)
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    dlt = (a - 0.5).double()
+    assert abs(float(dlt.mean())) < 3e-4 and abs(float(dlt.std()) - 0.05) < 5e-4
+    wide = ops.noise_clamp(x, sigma=2.0, seed=5)
+    assert float(wide.min()) == 0.0 and float(wide.max()) == 1.0
+
+
+def test_confusion_matrix_on_device_vs_reference_vectors():
+    from cooperative_training_and_latent_space_data_augmentation_amd.metrics import runningScore, dice_from_confusion
+    r = _io_cases()["running_score"][0]
+    rs = runningScore(4)
+    for lt, lp in r["batches"]:
+        rs.update(lt.to(DEV), lp.to(DEV))
+    assert torch.equal(rs._dev_hist.cpu(), r["confusion"].long())          # integer-exact
+    score, iu = rs.get_scores()
+    for k, v in r["score"].items():
+        assert score[k] == v or (np.isnan(score[k]) and np.isnan(v))
+    for k, v in r["cls_iu"].items():
+        assert iu[k] == v or (np.isnan(iu[k]) and np.isnan(v))
+    # a big one: 16 x 256 x 256 labels, against numpy bincount
+    g = torch.Generator().manual_seed(0)
+    lt = torch.randint(-1, 5, (16, 256, 256), generator=g)
+    lp = torch.randint(0, 4, (16, 256, 256), generator=g).to(torch.uint8)
+    h = ops.confusion_hist(lt.to(DEV), lp.to(DEV), 4).cpu().numpy()
+    keep = (lt >= 0) & (lt < 4)
+    ref = np.bincount((4 * lt[keep] + lp[keep].long()).numpy(), minlength=16).reshape(4, 4)
+    assert np.array_equal(h, ref)
+    d = dice_from_confusion(h)
+    assert all(0.0 <= v <= 1.0 for v in d)
+
+
+def test_basic_operations_module_matches_upstream_return_convention():
+    from cooperative_training_and_latent_space_data_augmentation_amd import basic_operations as B
+    io = _io_cases()
+    r = io["crop_or_pad"][0]                      # (2, 11, 14) -> (8, 8): crop both axes
+    out = B.crop_or_pad(r["image"].to(DEV), r["size"], r["label"].to(DEV))
+    assert len(out) == 6 and torch.equal(out[0].cpu(), r["image_out"]) and out[2:] == ((11 - 8) // 2, (14 - 8) // 2, 11, 14)
+    r = io["crop_or_pad"][3]                      # already the right size: upstream returns the pair unchanged
+    out = B.crop_or_pad(r["image"].to(DEV), r["size"], r["label"].to(DEV))
+    assert len(out) == 2 and torch.equal(out[0].cpu(), r["image_out"])
+    r = io["rescale"][0]
+    assert torch.equal(B.rescale_intensity(r["x"].to(DEV)).cpu(), r["y"])
+    n = io["noise_clamp"][0]
+    assert torch.equal(B.add_input_noise(n["clean"].to(DEV), noise=n["noise"].to(DEV)).cpu(), n["out"])

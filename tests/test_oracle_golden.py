@@ -171,3 +171,39 @@ def test_dice_and_hist():
     assert np.isnan(O.dice(a == 3, b == 3))
     h = O.confusion_hist(a, b, 3)
     assert h.sum() == 6 and h[1, 1] == 1 and h[1, 0] == 1 and h[2, 1] == 1
+
+
+# ---------------------------------------------------------------------------------------------- SURVEY 8(f) rows 1 and 3
+@pytest.fixture(scope="module")
+def io_cases():
+    import os
+    return torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "io_cases.pt"), weights_only=False)
+
+
+def test_input_pipeline_and_metrics_restatements_vs_reference(io_cases):
+    """rescale_intensity / crop_or_pad / input noise / runningScore of the oracle against vectors produced by the reference's own
+    functions (tools/gen_golden_io.py): bit-exact."""
+    import numpy as np
+    for r in io_cases["rescale"]:
+        assert torch.equal(O.rescale_intensity(r["x"], r["new_min"], r["new_max"]), r["y"])
+    for r in io_cases["crop_or_pad"]:
+        a, b = O.crop_or_pad(r["image"].numpy(), r["size"], r["label"].numpy())
+        assert np.array_equal(a, r["image_out"].numpy()) and np.array_equal(b, r["label_out"].numpy())
+    r = io_cases["running_score"][0]
+    h = sum(O.confusion_hist(lt.numpy(), lp.numpy(), 4) for lt, lp in r["batches"])
+    assert np.array_equal(h, r["confusion"].numpy())
+    score, iu = O.running_scores(h)
+    for k, v in r["score"].items():
+        assert score[k] == v or (np.isnan(score[k]) and np.isnan(v))
+    for k, v in r["cls_iu"].items():
+        assert iu[k] == v or (np.isnan(iu[k]) and np.isnan(v))
+    r = io_cases["noise_clamp"][0]
+    assert torch.equal(O.noise_clamp(r["clean"], r["noise"]), r["out"])
+    # Dice from a confusion matrix == dc() on the binarised maps
+    lt, lp = r_lt_lp = io_cases["running_score"][0]["batches"][0]
+    keep = (lt >= 0) & (lt < 4)
+    hist = O.confusion_hist(lt.numpy(), lp.numpy(), 4)
+    d = O.dice_from_confusion(hist)
+    for c in range(4):
+        ref = O.dice((lp.numpy() == c) & keep.numpy(), (lt.numpy() == c))
+        assert (np.isnan(d[c]) and np.isnan(ref)) or abs(d[c] - ref) < 1e-15
