@@ -49,8 +49,11 @@ __device__ __forceinline__ f32x4 ctl_bload4(__amdgpu_buffer_rsrc_t r, int voff) 
 __device__ __forceinline__ float ctl_bload1(__amdgpu_buffer_rsrc_t r, int voff) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, 0, 0));
 }
+#ifndef CTL_STORE_AUX
+#define CTL_STORE_AUX 0      // cache-policy bits of the epilogue stores (experiment hook: sc0 = 1, nt = 2, sc1 = 16 on gfx94x/95x)
+#endif
 __device__ __forceinline__ void ctl_bstore4(__amdgpu_buffer_rsrc_t r, int voff, f32x4 v) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, 0, CTL_STORE_AUX);
 }
 __device__ __forceinline__ void ctl_bstore1(__amdgpu_buffer_rsrc_t r, int voff, float v) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), r, voff, 0, 0);

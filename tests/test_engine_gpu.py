@@ -294,9 +294,10 @@ def test_full_cooperative_step_vs_golden(golden_cases, golden_sd, case):
         k, n = key.split("/")
         close(dict(s.model[k].named_parameters())[n], p, atol=2.1e-4, what=key)
 
-def test_two_stream_step_is_bitwise_identical(golden_cases, golden_sd):
-    """The image decoder's launch chain runs on a second HIP stream (solver.two_streams).  Every kernel is deterministic, so two
-    training steps must leave bit-identical weights and losses with and without it -- a race would show up here."""
+@pytest.mark.parametrize("variant", ["both", "image_only", "seg_only", "no_latent_DA", "separate_training"])
+def test_two_stream_step_is_bitwise_identical(golden_cases, golden_sd, variant):
+    """The iteration is issued as two launch chains on two HIP streams (solver.two_streams).  Every kernel is deterministic, so
+    two training steps must leave bit-identical weights and losses with and without it -- a race would show up here."""
     C = golden_cases["D_step_dropout"]
     outs = []
     for two in (False, True, True):
@@ -305,9 +306,17 @@ def test_two_stream_step_is_bitwise_identical(golden_cases, golden_sd):
         if two and s._side is None:
             s._side = torch.cuda.Stream(device=s.device)
         ov_img, ov_seg = _overrides(C, (C["img_cfg"], C["seg_cfg"]))
+        kw = dict(img_cfg=C["img_cfg"], seg_cfg=C["seg_cfg"], image_override=ov_img, seg_override=ov_seg)
+        if variant == "image_only":
+            kw.update(seg_cfg=None, seg_override=None)
+        elif variant == "seg_only":
+            kw.update(img_cfg=None, image_override=None)
+        elif variant == "no_latent_DA":
+            kw.update(latent_DA=False)
+        elif variant == "separate_training":
+            kw.update(separate_training=True)
         for _ in range(2):
-            losses = s.cooperative_step(dev(C["clean"]), dev(C["label"]), dev(C["noisy"]), C["img_cfg"], C["seg_cfg"],
-                                        image_override=ov_img, seg_override=ov_seg)
+            losses = s.cooperative_step(dev(C["clean"]), dev(C["label"]), dev(C["noisy"]), **kw)
         torch.cuda.synchronize()
         outs.append((torch.stack([v.detach().float() for v in losses]).cpu(),
                      {k: m._flat_data.detach().cpu().clone() for k, m in s.model.items()}))
