@@ -200,6 +200,10 @@ def main():
                                "algorithmic_gflop_per_launch": rec["flops"] / rec["launches"] / 1e9,
                                "algorithmic_mb_per_launch": rec["bytes"] / rec["launches"] / 1e6,
                                "hbm_gbs": gbs, "hbm_frac": f_hbm, "share_of_step_time": secs / dt}
+            if getattr(solver, "two_streams", False):
+                out["roofline"]["note"] = ("timed region: two launch chains share the GPU, so this kernel's event-timed duration includes the "
+                                           "time it shares the CUs with the other chain (the step is 14 % faster for it); kernel quality "
+                                           "= single_stream below")
             if kid in prof_single:
                 r1 = prof_single[kid]
                 tf1, gb1 = r1["flops"] / r1["ms"] / 1e9, r1["bytes"] / r1["ms"] / 1e6
