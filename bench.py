@@ -118,6 +118,8 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--prof-filter", default=DOMINANT)
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even for a world of 1")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo only for control-flow tests)")
+    ap.add_argument("--all-on-device0", action="store_true", help="test aid: every rank uses GPU 0 (needs --backend gloo)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -127,6 +129,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback of the product path)")
+    if args.all_on_device0:
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     import torch.distributed as dist
@@ -135,7 +139,10 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
 
     from cooperative_training_and_latent_space_data_augmentation_amd import _ffi
     from cooperative_training_and_latent_space_data_augmentation_amd.solver import AdvancedTripletReconSegmentationModel
@@ -177,16 +184,18 @@ def main():
     # the time it shares the CUs with the other chain.  For the kernel-quality figure the same step is replayed on ONE stream
     # afterwards (outside the timed region): that is also what rocprofv3 --kernel-trace shows, because it serialises dispatches.
     prof_single = {}
-    if rank == 0 and getattr(solver, "two_streams", False):
+    if getattr(solver, "two_streams", False):          # EVERY rank replays (step() contains the gradient all-reduce); rank 0 profiles
         solver.two_streams = False
         for _ in range(2):
             step()
         torch.cuda.synchronize()
-        _ffi.prof_start(args.prof_filter)
+        if rank == 0:
+            _ffi.prof_start(args.prof_filter)
         for _ in range(5):
             step()
         torch.cuda.synchronize()
-        prof_single = _ffi.prof_stop()
+        if rank == 0:
+            prof_single = _ffi.prof_stop()
         solver.two_streams = True
     if phase_tm is not None:
         _ffi.lib.ctl_debug_timing(phase_tm)

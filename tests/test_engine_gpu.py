@@ -390,3 +390,21 @@ def test_full_size_step_properties(golden_sd):
     delta = (s.model["shape_decoder"]._flat_data - before).abs().max().item()
     assert 0 < delta <= 1.001e-4           # |Adam's first step| <= lr (+ fp32 rounding of the weight)
     assert int(s.model["image_encoder"]._nbt[0]) == 1 and int(s.model["image_decoder"]._nbt[0]) == 3
+
+
+def test_bench_two_ranks_control_flow():
+    """bench.py under the driver's launcher with TWO ranks (both on GPU 0, gloo): every rank must reach every collective (timed
+    steps, barrier, the single-stream replay after the timed region) -- a rank-0-only step would hang here."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29547", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--size", "64",
+           "--batch", "4", "--backend", "gloo", "--all-on-device0"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 8 and rec["value"] > 0
