@@ -349,7 +349,8 @@ class OracleSolver:
     """Restatement of `AdvancedTripletReconSegmentationModel` (model.py:24-813), hot-path methods only."""
 
     def __init__(self, image_ch: int = 1, num_classes: int = 4, learning_rate: float = 1e-4, n_iter: int = 1,
-                 state_dicts: Optional[Dict[str, dict]] = None):
+                 state_dicts: Optional[Dict[str, dict]] = None, network_type: str = "FCN_16_standard"):
+        self.network_type = network_type        # + "_share_code" / "_w_o_filter": the ablation variants of model.py:199-203
         self.num_classes = num_classes
         self.n_iter = n_iter
         self.learning_rate = learning_rate
@@ -395,6 +396,10 @@ class OracleSolver:
     def fast_predict(self, x, no_track=False):
         """model.py:561-601."""
         z_i, z_s = _run(self.model["image_encoder"], x, no_track)
+        if "share_code" in self.network_type:         # model.py:199-203 (ablation study: one shared code)
+            z_i = z_s
+        elif "w_o_filter" in self.network_type:
+            z_s = z_i
         y0 = _run(self.model["segmentation_decoder"], z_s, no_track)
         return (z_i, z_s), y0
 

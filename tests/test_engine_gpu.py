@@ -408,3 +408,58 @@ def test_bench_two_ranks_control_flow():
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     rec = json.loads(line)
     assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 8 and rec["value"] > 0
+
+
+# ---------------------------------------------------------------------------------------------- SURVEY 8(f) rows 1, 2, 4
+def test_checkpoint_interop_and_resume(golden_cases, golden_sd, tmp_path):
+    """save_model writes upstream-format state dicts (model.py:666-678): they load strictly into the oracle's torch modules
+    (= the reference's key names and shapes) and into a fresh engine; a snapshot (model.py:680-738) resumes training bit-exactly."""
+    C = golden_cases["D_step_dropout"]
+    ov = _overrides(C, (C["img_cfg"], C["seg_cfg"]))
+    args = (dev(C["clean"]), dev(C["label"]), dev(C["noisy"]), C["img_cfg"], C["seg_cfg"])
+    a = _solver(golden_sd)
+    a.cooperative_step(*args, image_override=ov[0], seg_override=ov[1])
+    a.save_model(str(tmp_path), 3, save_optimizers=True)
+    snap = a.save_snapshots(str(tmp_path), epoch=3)
+    ckpt = tmp_path / "3" / "checkpoints"
+    onets = O.build_networks(init=False)
+    for name, net in onets.items():
+        missing = net.load_state_dict(torch.load(ckpt / f"{name}.pth"), strict=True)
+        assert not missing.missing_keys and not missing.unexpected_keys
+    b = AdvancedTripletReconSegmentationModel(use_gpu=True, checkpoint_dir=str(ckpt))
+    x = dev(C["noisy"])
+    assert torch.equal(a.predict(x), b.predict(x))
+    c = _solver(golden_sd)
+    assert c.load_snapshots(snap) == 3
+    la = a.cooperative_step(*args, image_override=ov[0], seg_override=ov[1])
+    lc = c.cooperative_step(*args, image_override=ov[0], seg_override=ov[1])
+    assert all(torch.equal(u.detach(), v.detach()) for u, v in zip(la, lc))
+    for k in a.model:
+        assert torch.equal(a.model[k]._flat_data, c.model[k]._flat_data), k
+
+
+@pytest.mark.parametrize("variant", ["FCN_16_standard_share_code", "FCN_16_standard_w_o_filter"])
+def test_ablation_variants_vs_oracle(golden_cases, golden_sd, variant):
+    """model.py:199-203: share_code (z_i := z_s) and w_o_filter (z_s := z_i) are flags of the same solver."""
+    A = golden_cases["A_standard"]
+    s = AdvancedTripletReconSegmentationModel(network_type=variant, use_gpu=True)
+    for k, m in s.model.items():
+        m.load_state_dict(golden_sd[k])
+    o = O.OracleSolver(state_dicts=golden_sd, network_type=variant)
+    got = s.standard_training(dev(A["clean"]), dev(A["label"]), dev(A["noisy"]))
+    ref = o.standard_training(A["clean"], A["label"], A["noisy"])
+    for g, r in zip(got, ref):
+        assert abs(float(g) - float(r)) < 1e-4
+    close(s.z_i, o.z_i, what="z_i")
+    close(s.z_s, o.z_s, what="z_s")
+    assert torch.equal(s.z_i, s.z_s)
+
+
+def test_evaluate_with_device_targets_matches_host_path(golden_cases, golden_sd):
+    F_ = golden_cases["F_predict"]
+    a, b = _solver(golden_sd), _solver(golden_sd)
+    a.evaluate(dev(F_["vol"]), F_["vlab"].numpy(), n_iter=2)              # upstream path: numpy targets, host confusion matrix
+    b.evaluate(dev(F_["vol"]), dev(F_["vlab"]), n_iter=2)                  # device targets: confusion matrix stays on the GPU
+    sa, ia = a.running_metric.get_scores()
+    sb, ib = b.running_metric.get_scores()
+    assert sa == sb and all((ia[k] == ib[k]) or (np.isnan(ia[k]) and np.isnan(ib[k])) for k in ia)
