@@ -616,12 +616,18 @@ class CtlNet(nn.Module):
             dsrc_shape = (src.n, 2 * src.h, 2 * src.w, src.c)
         dsrc = A.tensor(*dsrc_shape)
         pb.conv(du, self._wp_ref(c0.wp_dgrad), c0.cin, 3, out=dsrc)
-        pb.conv(ds, self._wp_ref(c1.wp_dgrad), c1.cin, 1, out=dsrc, accum=True)
         if d_in is None:
             d_in = A.tensor(xin.n, xin.h, xin.w, xin.c)
         if pre == "nn":
+            # nearest-upsample backward = 2x2 sum-pool.  Pooling commutes with the pointwise 1x1 data gradient, so that one runs
+            # on the pooled dS at a quarter of the pixels instead of accumulating into the full-resolution tensor
             pb.sumpool2(dsrc, d_in)
-        elif pre == "convT":
+            ds_low = A.tensor(ds.n, ds.h // 2, ds.w // 2, ds.c)
+            pb.sumpool2(ds, ds_low)
+            pb.conv(ds_low, self._wp_ref(c1.wp_dgrad), c1.cin, 1, out=d_in, accum=True)
+            return d_in
+        pb.conv(ds, self._wp_ref(c1.wp_dgrad), c1.cin, 1, out=dsrc, accum=True)
+        if pre == "convT":
             ci = C[prefix + ".up"]
             if need_w:
                 pb.chan_sum(dsrc, pb.G(ci.b_off))
