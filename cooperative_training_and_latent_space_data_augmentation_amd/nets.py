@@ -606,9 +606,18 @@ class CtlNet(nn.Module):
             # BN1 -> LeakyReLU tail (in place: dU overwrites dA)
             pb.bn_backward(1, da, None, u, B[prefix + ".conv.1"], rec["co1"], SLOPE, ds=None, dx=da, affine_grad=need_w and affine)
             du = da
+        ds_low = None
+        if pre == "nn":
+            # nearest-upsample backward = 2x2 sum-pool; it commutes with pointwise (1x1) convs, so both the 1x1 weight gradient
+            # (sum up(x)*dS == sum x*pool(dS)) and the 1x1 data gradient below run on the pooled dS at a quarter of the pixels
+            ds_low = A.tensor(ds.n, ds.h // 2, ds.w // 2, ds.c)
+            pb.sumpool2(ds, ds_low)
         if need_w:
             pb.wgrad(src, du, 3, in_mode=src_mode, dw_ref=pb.G(c0.w_off), strides=(c0.cin * k9, k9, 3, 1), dbias_ref=pb.G(c0.b_off))
-            pb.wgrad(src, ds, 1, in_mode=src_mode, dw_ref=pb.G(c1.w_off), strides=(c1.cin, 1, 1, 1), dbias_ref=pb.G(c1.b_off))
+            if ds_low is not None:
+                pb.wgrad(xin, ds_low, 1, dw_ref=pb.G(c1.w_off), strides=(c1.cin, 1, 1, 1), dbias_ref=pb.G(c1.b_off))
+            else:
+                pb.wgrad(src, ds, 1, in_mode=src_mode, dw_ref=pb.G(c1.w_off), strides=(c1.cin, 1, 1, 1), dbias_ref=pb.G(c1.b_off))
         # gradient w.r.t. x' (full resolution of this block)
         if pre == "down" or pre == "convT":
             dsrc_shape = (src.n, src.h, src.w, src.c)
@@ -619,11 +628,7 @@ class CtlNet(nn.Module):
         if d_in is None:
             d_in = A.tensor(xin.n, xin.h, xin.w, xin.c)
         if pre == "nn":
-            # nearest-upsample backward = 2x2 sum-pool.  Pooling commutes with the pointwise 1x1 data gradient, so that one runs
-            # on the pooled dS at a quarter of the pixels instead of accumulating into the full-resolution tensor
             pb.sumpool2(dsrc, d_in)
-            ds_low = A.tensor(ds.n, ds.h // 2, ds.w // 2, ds.c)
-            pb.sumpool2(ds, ds_low)
             pb.conv(ds_low, self._wp_ref(c1.wp_dgrad), c1.cin, 1, out=d_in, accum=True)
             return d_in
         pb.conv(ds, self._wp_ref(c1.wp_dgrad), c1.cin, 1, out=dsrc, accum=True)
