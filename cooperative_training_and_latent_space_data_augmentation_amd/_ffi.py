@@ -142,7 +142,7 @@ def check(rc: int, what: str = "") -> None:
 def conv_desc(**kw) -> np.ndarray:
     """Build a ctl_conv record (numpy scalar array of CONV_DTYPE) with defaults for the plain, non-scattered case."""
     d = np.zeros((), dtype=CONV_DTYPE)
-    d["pad"] = 1 if kw.get("ks", 3) == 3 else 0
+    d["pad"] = 1 if kw.get("ks", 3) in (3, 4) else 0
     d["stride"] = 1
     d["nsub"] = 1
     d["groups"] = 1

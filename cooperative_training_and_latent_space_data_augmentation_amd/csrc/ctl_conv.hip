@@ -31,7 +31,7 @@ struct Geom {
     static constexpr int IWP = (S == 2) ? 2 * IWH : IW;
     static constexpr int XT_IMAGE = IH * IWP * 16;
     static constexpr int XT_FLOATS = XT_IMAGE + 4;   // + one 16-byte dump slot for the staging units past the tile
-    static constexpr int PAD = (KS == 3) ? 1 : 0;
+    static constexpr int PAD = (KS >= 3) ? 1 : 0;     // 3x3 and the 4x4 stride-2 form of a pooled 3x3 data gradient: pad 1
     __device__ static __forceinline__ int ldscol(int c) { return (S == 2) ? ((c & 1) * IWH + (c >> 1)) : c; }
 };
 
@@ -252,7 +252,7 @@ extern "C" int ctl_debug_timing(unsigned long long* out8) {
 #define CTL_LB_SMALL 4
 #endif
 template <int KS, int S, int MODE, int MT, int TW, int NT, int EPI>
-__global__ __launch_bounds__(256, (MT * NT >= 8) ? 2 : ((MT * NT >= 4) ? CTL_LB_MID : CTL_LB_SMALL)) void conv_igemm_kernel(const ctl_conv d, const float* __restrict__ x,
+__global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : ((MT * NT >= 4) ? CTL_LB_MID : CTL_LB_SMALL)) void conv_igemm_kernel(const ctl_conv d, const float* __restrict__ x,
                                                           const float* __restrict__ wpack,
                                                           const float* __restrict__ bias,
                                                           const float* __restrict__ pro_scale,
@@ -862,9 +862,25 @@ __global__ void pack_weights_batched_kernel(const float* __restrict__ params, fl
     const int co = cot * 16 + (lane & 15);
     const int ci = g * 16 + (lane >> 4) * 4 + j;
     int kh = tap / ks, kw = tap % ks;
-    if (flip) { kh = ks - 1 - kh; kw = ks - 1 - kw; }
     float v = 0.f;
-    if (co < cout && ci < cin) v = src[co * r[6] + ci * r[7] + kh * r[8] + kw * r[9]];
+    if (r[11] == 1) {
+        // 4x4 stride-2 pad-1 kernel K of  dx = sumpool2(conv3x3^T(dy))  (data gradient of a 3x3 conv on a nearest-upsampled input):
+        // dx[i] = sum_a dx'[2i+a] = sum_{a,kh'} W[kh']^T dy[2i + a + 1 - kh']  ==>  K[u] = sum_{a in {0,1}, kh' = a+2-u in [0,2]} W[kh']
+        if (co < cout && ci < cin) {
+            for (int a = 0; a < 2; ++a) {
+                const int sh = a + 2 - kh;
+                if (sh < 0 || sh > 2) continue;
+                for (int b = 0; b < 2; ++b) {
+                    const int sw = b + 2 - kw;
+                    if (sw < 0 || sw > 2) continue;
+                    v += src[co * r[6] + ci * r[7] + sh * r[8] + sw * r[9]];
+                }
+            }
+        }
+    } else {
+        if (flip) { kh = ks - 1 - kh; kw = ks - 1 - kw; }
+        if (co < cout && ci < cin) v = src[co * r[6] + ci * r[7] + kh * r[8] + kw * r[9]];
+    }
     dst[idx] = v;
 }
 
@@ -937,6 +953,7 @@ static bool conv_combo_ok(const ctl_conv* d) {
     if (k == 3 && s == 2 && pd == 1 && m == CTL_IN_PLAIN) return true;
     if (k == 1 && s == 1 && pd == 0 && m != CTL_IN_ZINS2) return true;
     if (k == 2 && s == 2 && pd == 0 && m == CTL_IN_PLAIN) return true;
+    if (k == 4 && s == 2 && pd == 1 && m == CTL_IN_PLAIN) return true;     // pooled 3x3 data gradient (nearest-upsample blocks)
     return false;
 }
 
@@ -964,6 +981,7 @@ int ctl_conv_pick_cfg(const ctl_conv* d, ctl_conv_cfg* c, int for_wgrad) {
         else { mt = 1; tw = 16; }
     } else if (d->stride == 2) {
         if (blocks(2, 16) >= 384) { mt = 2; tw = 16; } else { mt = 1; tw = 16; }
+        if (d->ks == 4 && c->nt == 2) { mt = 1; tw = 16; }       // 16-tap weight image + 18x34 input tile would exceed 64 KiB of LDS
     } else if (d->wout >= 32 && blocks(4, 32) >= 512 && !(c->nt == 2 && blocks(4, 32) > 768)) {
         mt = 4; tw = 32;          // (with 32 output channels per block the 8x32 kernel sits at 2 blocks per CU: once there are more
                                   //  tiles than that the 8x16 kernel at 3 per CU is faster, e.g. 32->32 at 128^2: 53 vs 57 us)
@@ -979,6 +997,7 @@ int ctl_conv_pick_cfg(const ctl_conv* d, ctl_conv_cfg* c, int for_wgrad) {
             const bool tile_ok = (fm == 4 && ft == 32 && d->stride == 1 && !for_wgrad) || (fm == 2 && ft == 16) || (fm == 1 && ft == 16);
             if (tile_ok) { mt = fm; tw = ft; }
             if ((fn == 1 || fn == 2) && c->cot % fn == 0) c->nt = fn;
+            if (d->ks == 4 && c->nt == 2) { mt = 1; tw = 16; }
         }
     }
     c->mt = mt; c->tw = tw; c->th = 4 * mt * 16 / tw;
@@ -1007,7 +1026,7 @@ static int conv_grid_x(int ntiles, int other, int occ) {
 
 extern "C" int ctl_pack_weights(const float* src, float* dst, int32_t cout, int32_t cin, int32_t ks, int64_t s_co,
                                 int64_t s_ci, int64_t s_kh, int64_t s_kw, int32_t flip, ctl_stream stream) {
-    CTL_REQUIRE(src && dst && cout > 0 && cin > 0 && ks >= 1 && ks <= 3, "pack_weights: bad arguments");
+    CTL_REQUIRE(src && dst && cout > 0 && cin > 0 && ks >= 1 && ks <= 4, "pack_weights: bad arguments");
     const int64_t total = (int64_t)ctl_conv_wpack_floats(cin, cout, ks);
     pack_weights_kernel<<<dim3((unsigned)ctl_cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream>>>(
         src, dst, cout, cin, ks, ctl_cdiv(cin, 16), total, s_co, s_ci, s_kh, s_kw, flip);
@@ -1065,6 +1084,12 @@ static int conv_dispatch(conv_call& a) {
     else if (k == 1 && m == CTL_IN_PLAIN) conv_go_tile<1, 1, CTL_IN_PLAIN>(a);
     else if (k == 1 && m == CTL_IN_UP2) conv_go_tile<1, 1, CTL_IN_UP2>(a);
     else if (k == 2 && s == 2) conv_go_tile<2, 2, CTL_IN_PLAIN>(a);
+    else if (k == 4 && s == 2) {          // only the LDS-feasible shapes are instantiated
+        const bool epi = (a.d->epi_flags & (CTL_EPI_RES | CTL_EPI_ACCUM | CTL_EPI_BNBWD)) != 0;
+        if (a.c.mt == 2 && a.c.nt == 1) { if (epi) conv_go<4, 2, CTL_IN_PLAIN, 2, 16, 1, 1>(a); else conv_go<4, 2, CTL_IN_PLAIN, 2, 16, 1, 0>(a); }
+        else if (a.c.nt == 2) { if (epi) conv_go<4, 2, CTL_IN_PLAIN, 1, 16, 2, 1>(a); else conv_go<4, 2, CTL_IN_PLAIN, 1, 16, 2, 0>(a); }
+        else { if (epi) conv_go<4, 2, CTL_IN_PLAIN, 1, 16, 1, 1>(a); else conv_go<4, 2, CTL_IN_PLAIN, 1, 16, 1, 0>(a); }
+    }
     else CTL_FAIL(CTL_EUNSUPPORTED, "conv_forward: no kernel for this combination");
     return CTL_OK;
 }

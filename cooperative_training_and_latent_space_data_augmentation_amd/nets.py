@@ -75,7 +75,7 @@ class _BNP(nn.Module):
 
 
 class ConvInfo:
-    __slots__ = ("key", "cin", "cout", "ks", "transposed", "w_off", "b_off", "wp_fwd", "wp_dgrad", "wp_sub")
+    __slots__ = ("key", "cin", "cout", "ks", "transposed", "w_off", "b_off", "wp_fwd", "wp_dgrad", "wp_sub", "wp_up")
 
 
 class BNInfo:
@@ -145,7 +145,7 @@ class PlanBuilder:
     # -- conv family
     def _conv_desc(self, x: T, cout, ks, stride, in_mode, hout, wout, pro, flags, act, slope, nsub=1):
         d = _ffi.conv_desc(n=x.n, hin=x.h, win=x.w, cin=x.c, hout=hout, wout=wout, cout=cout, ks=ks, stride=stride,
-                           pad=1 if ks == 3 else 0, in_mode=in_mode, pro_affine=1 if pro else 0,
+                           pad=1 if ks in (3, 4) else 0, in_mode=in_mode, pro_affine=1 if pro else 0,
                            pro_slope=pro[2] if pro else 0.0, epi_flags=flags, epi_act=act, epi_slope=slope)
         if nsub == 4:
             d["out_h"], d["out_w"], d["out_sy"], d["out_sx"], d["nsub"], d["out_sub"] = 2 * hout, 2 * wout, 2, 2, 4, 1
@@ -442,6 +442,11 @@ class CtlNet(nn.Module):
                     ci.wp_sub = 0
                     ci.wp_fwd, wp = wp, wp + lib.ctl_conv_wpack_floats(ci.cin, ci.cout, ci.ks)
                     ci.wp_dgrad, wp = wp, wp + lib.ctl_conv_wpack_floats(ci.cout, ci.cin, ci.ks)
+                ci.wp_up = -1
+                if getattr(self, "up_type", None) == "NN" and ci.ks == 3 and key.startswith("up") and key.endswith(".conv.0"):
+                    # first conv of a nearest-upsample block: its data gradient followed by the upsample backward (2x2 sum-pool)
+                    # is ONE 4x4 stride-2 conv over dU (16 taps per low-res pixel instead of 36 + a full-resolution round trip)
+                    ci.wp_up, wp = wp, wp + lib.ctl_conv_wpack_floats(ci.cout, ci.cin, 4)
                 self._convs[key] = ci
         self._wp = torch.zeros(max(wp, 1), dtype=torch.float32, device=device)
         self._pack_plan = self._build_pack_plan()
@@ -491,9 +496,9 @@ class CtlNet(nn.Module):
         pb = PlanBuilder(self)
         recs = []
 
-        def pack(src_off_f, dst_off_f, cout, cin, ks, strides, flip):
+        def pack(src_off_f, dst_off_f, cout, cin, ks, strides, flip, mode=0):
             total = lib.ctl_conv_wpack_floats(cin, cout, ks)
-            recs.append([src_off_f, dst_off_f, cout, cin, ks, 1 if flip else 0, *strides, total, 0])
+            recs.append([src_off_f, dst_off_f, cout, cin, ks, 1 if flip else 0, *strides, total, mode])
 
         for ci in self._convs.values():
             k2 = ci.ks * ci.ks
@@ -504,6 +509,8 @@ class CtlNet(nn.Module):
             else:                  # weight [Cout][Cin][ks][ks]
                 pack(ci.w_off, ci.wp_fwd, ci.cout, ci.cin, ci.ks, (ci.cin * k2, k2, ci.ks, 1), False)
                 pack(ci.w_off, ci.wp_dgrad, ci.cin, ci.cout, ci.ks, (k2, ci.cin * k2, ci.ks, 1), True)
+                if ci.wp_up >= 0:      # mode 1: the 4x4 kernel is summed from the 3x3 taps inside the pack kernel
+                    pack(ci.w_off, ci.wp_up, ci.cin, ci.cout, 4, (k2, ci.cin * k2, ci.ks, 1), False, mode=1)
         pb.table = np.asarray(recs, dtype=np.int64)
         op = pb.op(_ffi.OP_PACK_BATCH)                 # ONE launch re-packs every conv of the network
         op["i"][0] = len(recs)
@@ -623,14 +630,15 @@ class CtlNet(nn.Module):
             dsrc_shape = (src.n, src.h, src.w, src.c)
         else:
             dsrc_shape = (src.n, 2 * src.h, 2 * src.w, src.c)
-        dsrc = A.tensor(*dsrc_shape)
-        pb.conv(du, self._wp_ref(c0.wp_dgrad), c0.cin, 3, out=dsrc)
         if d_in is None:
             d_in = A.tensor(xin.n, xin.h, xin.w, xin.c)
         if pre == "nn":
-            pb.sumpool2(dsrc, d_in)
+            # sumpool2(conv3x3^T(dU)) as one 4x4 stride-2 conv (no full-resolution gradient tensor at all), then the 1x1 part
+            pb.conv(du, self._wp_ref(c0.wp_up), c0.cin, 4, stride=2, out=d_in)
             pb.conv(ds_low, self._wp_ref(c1.wp_dgrad), c1.cin, 1, out=d_in, accum=True)
             return d_in
+        dsrc = A.tensor(*dsrc_shape)
+        pb.conv(du, self._wp_ref(c0.wp_dgrad), c0.cin, 3, out=dsrc)
         pb.conv(ds, self._wp_ref(c1.wp_dgrad), c1.cin, 1, out=dsrc, accum=True)
         if pre == "convT":
             ci = C[prefix + ".up"]

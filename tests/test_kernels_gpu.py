@@ -66,6 +66,30 @@ def test_conv3x3_s1_forward_bias_prologue_stats(n, cin, cout, h, w):
     close(y2, ref2, what="conv3x3+prologue")
 
 
+@pytest.mark.parametrize("n,c,cout,h,w", [(2, 16, 16, 32, 32), (2, 32, 64, 24, 40), (3, 128, 64, 12, 8), (16, 16, 16, 128, 128), (2, 64, 32, 6, 6)])
+def test_conv4x4_s2_is_pooled_3x3_data_gradient(n, c, cout, h, w):
+    """4x4 stride-2 pad-1 conv (generic weights) and its use: sumpool2(conv3x3^T(dy)) == conv4x4s2(dy; K) with K summed from the
+    3x3 taps (the weight-pack mode of the nearest-upsample blocks)."""
+    g = torch.Generator().manual_seed(c + h)
+    dy = torch.randn(n, c, h, w, generator=g)
+    k4 = torch.randn(cout, c, 4, 4, generator=g) * 0.2
+    d = _ffi.conv_desc(n=n, hin=h, win=w, cin=c, hout=h // 2, wout=w // 2, cout=cout, ks=4, stride=2)
+    y, _ = ops.conv_forward(d, dev(dy), ops.pack_oihw_fwd(dev(k4)))
+    close(y, F.conv2d(dy, k4, stride=2, padding=1), what="conv4x4 s2")
+    # data gradient of y' = conv3x3(up2(x)) with respect to x: forward weights W [c_out_f = c][c_in_f = cout][3][3]
+    wf = torch.randn(c, cout, 3, 3, generator=g) * 0.2
+    x = torch.randn(n, cout, h // 2, w // 2, generator=g, requires_grad=True)
+    F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), wf, padding=1).backward(dy)
+    K = torch.zeros(cout, c, 4, 4)
+    for a in range(2):
+        for b in range(2):
+            for kh in range(3):
+                for kw in range(3):
+                    K[:, :, a + 2 - kh, b + 2 - kw] += wf[:, :, kh, kw].t()
+    y2, _ = ops.conv_forward(d, dev(dy), ops.pack_oihw_fwd(dev(K)))
+    close(y2, x.grad, what="pooled dgrad via 4x4 s2")
+
+
 @pytest.mark.parametrize("n,c,cout,h,w,groups", [(2, 32, 16, 24, 20, 1), (16, 16, 16, 64, 64, 1), (4, 64, 32, 40, 36, 2), (32, 16, 16, 64, 64, 2)])
 def test_conv_epilogue_bn_backward_reduction(n, c, cout, h, w, groups):
     """CTL_EPI_BNBWD: y = conv(x) * leaky'(u*scale+shift) and the partials hold (sum y, sum y*u) per BatchNorm group."""
