@@ -86,6 +86,7 @@ struct XStage {
     int lds[NU];        // LDS float offset; the units past the tile write a dump slot behind the image
     f32x4 v[NU];
     unsigned vmask;     // bit i: unit i of the tile held in v[] lies inside the image (gets the prologue)
+    int pad_h, pad_w;   // top / left padding of this block's problem (G::PAD except for the phase problems of the 2x2 kernels)
     bool all_in;        // wave-uniform: every unit of the tile held in v[] is inside the image and the channel range
 
     __device__ __forceinline__ void init(const ctl_conv& d) {
@@ -108,10 +109,11 @@ struct XStage {
         }
         vmask = 0;
         all_in = false;
+        pad_h = pad_w = G::PAD;
     }
 
     __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rx, const ctl_conv& d, int n, int ho0, int wo0, int g) {
-        const int vh0 = ho0 * S - G::PAD, vw0 = wo0 * S - G::PAD;
+        const int vh0 = ho0 * S - pad_h, vw0 = wo0 * S - pad_w;
         const unsigned hv = (MODE == CTL_IN_PLAIN) ? d.hin : 2 * d.hin;
         const unsigned wv = (MODE == CTL_IN_PLAIN) ? d.win : 2 * d.win;
         const int oh = (MODE == CTL_IN_PLAIN) ? vh0 : ((ho0 >> 1) - PADH);
@@ -330,6 +332,12 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : ((MT * NT >= 4
 
     XStage<KS, S, MODE, MT, TW> xs;
     xs.init(d);
+    if (KS == 2 && S == 1) {
+        // phase problems (z = 2a + b, outputs at (2i+a, 2j+b)): d.pad == 2 -> 3x3 conv on a nearest-upsampled input, phase (a,b)
+        // reads rows i+a-1, i+a (pad 1-a); d.pad == 0 -> data gradient of a stride-2 3x3 conv, every phase reads rows i, i+1
+        xs.pad_h = d.pad == 2 ? 1 - (z >> 1) : 0;
+        xs.pad_w = d.pad == 2 ? 1 - (z & 1) : 0;
+    }
     // weight chunk g: [tap][t][64 lanes][4] floats; per-thread byte offsets are loop-invariant, the chunk goes in the scalar offset
     const __amdgpu_buffer_rsrc_t rw = ctl_rsrc(wp, (int64_t)ctl_cdiv(d.cout, 16) * TAPS * G_chunks * 1024);
     f32x4 wv[NW];
@@ -367,6 +375,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : ((MT * NT >= 4
 
     // Statistics of one BatchNorm group: block-level sum through LDS -> stats_partial[group][block][2][cout].  Called when the
     // walk enters the next group (tiles are visited in increasing order) and once at the end; every wave takes part.
+    const int srows = gridDim.x * gridDim.z, srow = z * gridDim.x + blockIdx.x;       // statistics rows of one group: [sub-problem][block]
     auto flush_stats = [&](int grp) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -393,7 +402,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : ((MT * NT >= 4
 #pragma unroll
             for (int w = 0; w < 4; ++w) v += sred[((w * NT * 16) + cl) * 2 + stat];
             const int co = cot0 * 16 + cl;
-            if (co < d.cout) stats_partial[(((int64_t)grp * gridDim.x + blockIdx.x) * 2 + stat) * d.cout + co] = v;
+            if (co < d.cout) stats_partial[(((int64_t)grp * srows + srow) * 2 + stat) * d.cout + co] = v;
         }
         __syncthreads();
     };
@@ -401,7 +410,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : ((MT * NT >= 4
     if ((flags & CTL_EPI_STATS) && ngroups > 1 && tid < NT * 16 * 2) {      // groups this block never visits contribute zeros
         const int stat = tid / (NT * 16), co = cot0 * 16 + tid % (NT * 16);
         if (co < d.cout)
-            for (int gi = 0; gi < ngroups; ++gi) stats_partial[(((int64_t)gi * gridDim.x + blockIdx.x) * 2 + stat) * d.cout + co] = 0.f;
+            for (int gi = 0; gi < ngroups; ++gi) stats_partial[(((int64_t)gi * srows + srow) * 2 + stat) * d.cout + co] = 0.f;
     }
 
     TM(7)
@@ -877,6 +886,25 @@ __global__ void pack_weights_batched_kernel(const float* __restrict__ params, fl
                 }
             }
         }
+    } else if (r[11] == 2) {
+        // phase z = 2a+b (in r[5]) of a 3x3 conv on a nearest-upsampled input, as a 2x2 conv on the stored input:
+        // y[2i+a] = sum_kh W[kh] x[(2i+a+kh-1)>>1]:  a=0: tap 0 <- W[0], tap 1 <- W[1]+W[2];  a=1: tap 0 <- W[0]+W[1], tap 1 <- W[2]
+        if (co < cout && ci < cin) {
+            const int a = flip >> 1, b = flip & 1;
+            const int h0 = (kh == 0) ? 0 : (a ? 2 : 1), h1 = (kh == 0) ? (a ? 1 : 0) : 2;
+            const int w0 = (kw == 0) ? 0 : (b ? 2 : 1), w1 = (kw == 0) ? (b ? 1 : 0) : 2;
+            for (int sh = h0; sh <= h1; ++sh)
+                for (int sw = w0; sw <= w1; ++sw) v += src[co * r[6] + ci * r[7] + sh * r[8] + sw * r[9]];
+        }
+    } else if (r[11] == 3) {
+        // phase z = 2a+b of the data gradient of a stride-2 pad-1 3x3 conv: dx[2i+a] = sum over kh with (a+1-kh) even of
+        // W[kh]^T dy[i + (a+1-kh)/2]:  a=0: tap 0 <- W[1];  a=1: tap 0 <- W[2], tap 1 <- W[0]   (the other taps are zero)
+        if (co < cout && ci < cin) {
+            const int a = flip >> 1, b = flip & 1;
+            const int sh = a ? (kh == 0 ? 2 : 0) : (kh == 0 ? 1 : -1);
+            const int sw = b ? (kw == 0 ? 2 : 0) : (kw == 0 ? 1 : -1);
+            if (sh >= 0 && sw >= 0) v = src[co * r[6] + ci * r[7] + sh * r[8] + sw * r[9]];
+        }
     } else {
         if (flip) { kh = ks - 1 - kh; kw = ks - 1 - kw; }
         if (co < cout && ci < cin) v = src[co * r[6] + ci * r[7] + kh * r[8] + kw * r[9]];
@@ -954,6 +982,7 @@ static bool conv_combo_ok(const ctl_conv* d) {
     if (k == 1 && s == 1 && pd == 0 && m != CTL_IN_ZINS2) return true;
     if (k == 2 && s == 2 && pd == 0 && m == CTL_IN_PLAIN) return true;
     if (k == 4 && s == 2 && pd == 1 && m == CTL_IN_PLAIN) return true;     // pooled 3x3 data gradient (nearest-upsample blocks)
+    if (k == 2 && s == 1 && (pd == 0 || pd == 2) && m == CTL_IN_PLAIN && d->nsub == 4) return true;   // four scattered phase problems
     return false;
 }
 
@@ -1084,6 +1113,7 @@ static int conv_dispatch(conv_call& a) {
     else if (k == 1 && m == CTL_IN_PLAIN) conv_go_tile<1, 1, CTL_IN_PLAIN>(a);
     else if (k == 1 && m == CTL_IN_UP2) conv_go_tile<1, 1, CTL_IN_UP2>(a);
     else if (k == 2 && s == 2) conv_go_tile<2, 2, CTL_IN_PLAIN>(a);
+    else if (k == 2 && s == 1) conv_go_tile<2, 1, CTL_IN_PLAIN>(a);
     else if (k == 4 && s == 2) {          // only the LDS-feasible shapes are instantiated
         const bool epi = (a.d->epi_flags & (CTL_EPI_RES | CTL_EPI_ACCUM | CTL_EPI_BNBWD)) != 0;
         if (a.c.mt == 2 && a.c.nt == 1) { if (epi) conv_go<4, 2, CTL_IN_PLAIN, 2, 16, 1, 1>(a); else conv_go<4, 2, CTL_IN_PLAIN, 2, 16, 1, 0>(a); }
@@ -1100,7 +1130,7 @@ extern "C" int ctl_conv_stats_blocks(const ctl_conv* d) {
     if (ctl_conv_pick_cfg(d, &a.c, 0) != CTL_OK) return -1;
     a.query = true;
     if (conv_dispatch(a) != CTL_OK) return -1;
-    return a.grid_x;
+    return a.grid_x * d->nsub;          // rows per group: [sub-problem][block]
 }
 extern "C" size_t ctl_conv_stats_floats(const ctl_conv* d) {
     const int b = ctl_conv_stats_blocks(d);
@@ -1118,7 +1148,7 @@ extern "C" int ctl_conv_forward(const ctl_conv* d, const float* x, const float* 
     if (rc != CTL_OK) return rc;
     CTL_REQUIRE(!(d->epi_flags & CTL_EPI_BIAS) || bias, "conv_forward: CTL_EPI_BIAS without bias");
     CTL_REQUIRE(!(d->epi_flags & CTL_EPI_RES) || (res && res_scale && res_shift), "conv_forward: CTL_EPI_RES without res");
-    CTL_REQUIRE(!(d->epi_flags & CTL_EPI_STATS) || (stats_partial && d->nsub == 1), "conv_forward: bad CTL_EPI_STATS use");
+    CTL_REQUIRE(!(d->epi_flags & CTL_EPI_STATS) || stats_partial, "conv_forward: CTL_EPI_STATS without a partial buffer");
     CTL_REQUIRE(!(d->epi_flags & CTL_EPI_BNBWD) || ((d->epi_flags & CTL_EPI_STATS) && res && res_scale && res_shift &&
                                                     !(d->epi_flags & (CTL_EPI_RES | CTL_EPI_ACCUM | CTL_EPI_BIAS)) && d->epi_act == CTL_ACT_NONE),
                 "conv_forward: CTL_EPI_BNBWD needs CTL_EPI_STATS + res (= u) + res_scale/res_shift (BatchNorm coefficients) and nothing else");

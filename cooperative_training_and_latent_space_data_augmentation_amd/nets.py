@@ -39,6 +39,7 @@ N_SLOTS = 15
 SLOPE = 0.2
 EPS = 1e-5
 MOMENTUM = 0.1
+PHASE_CONVS = os.environ.get("CTL_PHASE_CONVS", "1") != "0"     # 2x2 phase forms of the up-sampled forward / stride-2 data gradient
 FUSE_BNBWD = os.environ.get("CTL_FUSE_BNBWD", "0") == "1"   # BN1-backward reduction inside the dgrad conv epilogue (measured: no gain)
 CONV_WORDS = _ffi.CONV_DTYPE.itemsize // 4      # ctl_conv as int32 words at the head of ctl_op.i
 ALIGN_F = 64            # floats (256 B)
@@ -75,7 +76,7 @@ class _BNP(nn.Module):
 
 
 class ConvInfo:
-    __slots__ = ("key", "cin", "cout", "ks", "transposed", "w_off", "b_off", "wp_fwd", "wp_dgrad", "wp_sub", "wp_up")
+    __slots__ = ("key", "cin", "cout", "ks", "transposed", "w_off", "b_off", "wp_fwd", "wp_dgrad", "wp_sub", "wp_up", "wp_upf", "wp_s2d", "wp_ph")
 
 
 class BNInfo:
@@ -143,9 +144,9 @@ class PlanBuilder:
         return (S_GRAD, 4 * off_floats)
 
     # -- conv family
-    def _conv_desc(self, x: T, cout, ks, stride, in_mode, hout, wout, pro, flags, act, slope, nsub=1):
+    def _conv_desc(self, x: T, cout, ks, stride, in_mode, hout, wout, pro, flags, act, slope, nsub=1, pad=None):
         d = _ffi.conv_desc(n=x.n, hin=x.h, win=x.w, cin=x.c, hout=hout, wout=wout, cout=cout, ks=ks, stride=stride,
-                           pad=1 if ks in (3, 4) else 0, in_mode=in_mode, pro_affine=1 if pro else 0,
+                           pad=(1 if ks in (3, 4) else 0) if pad is None else pad, in_mode=in_mode, pro_affine=1 if pro else 0,
                            pro_slope=pro[2] if pro else 0.0, epi_flags=flags, epi_act=act, epi_slope=slope)
         if nsub == 4:
             d["out_h"], d["out_w"], d["out_sy"], d["out_sx"], d["nsub"], d["out_sub"] = 2 * hout, 2 * wout, 2, 2, 4, 1
@@ -154,7 +155,7 @@ class PlanBuilder:
 
     def conv(self, x: T, wp_ref, cout, ks, *, stride=1, in_mode=0, pro=None, bias_ref=None, stats=False, act=0,
              slope=0.0, res=None, accum=False, out: Optional[T] = None, arena: Optional[Arena] = None, nsub=1,
-             hout=None, wout=None, bnbwd=None):
+             hout=None, wout=None, bnbwd=None, pad=None):
         """Emit one CTL_OP_CONV.  pro = (scale_ref, shift_ref, slope); res = (T v, scale_ref, shift_ref).
         bnbwd = (T u, scale_ref, shift_ref, slope): data-gradient conv whose result is dL/d leaky(BN(u)); the epilogue writes
         g = result * leaky'(BN(u)) and the BatchNorm-backward sums go to the statistics partials (CTL_EPI_BNBWD).
@@ -171,7 +172,7 @@ class PlanBuilder:
                 hout, wout = x.h, x.w
         flags = (_ffi.EPI_BIAS if bias_ref is not None else 0) | (_ffi.EPI_STATS if stats else 0) | \
                 ((_ffi.EPI_BNBWD if bnbwd is not None else _ffi.EPI_RES) if res is not None else 0) | (_ffi.EPI_ACCUM if accum else 0)
-        d = self._conv_desc(x, cout, ks, stride, in_mode, hout, wout, pro, flags, act, slope, nsub)
+        d = self._conv_desc(x, cout, ks, stride, in_mode, hout, wout, pro, flags, act, slope, nsub, pad)
         oh, ow = (2 * hout, 2 * wout) if nsub == 4 else (hout, wout)
         if out is None:
             out = (arena or self.act).tensor(x.n, oh, ow, cout)
@@ -447,6 +448,17 @@ class CtlNet(nn.Module):
                     # first conv of a nearest-upsample block: its data gradient followed by the upsample backward (2x2 sum-pool)
                     # is ONE 4x4 stride-2 conv over dU (16 taps per low-res pixel instead of 36 + a full-resolution round trip)
                     ci.wp_up, wp = wp, wp + lib.ctl_conv_wpack_floats(ci.cout, ci.cin, 4)
+                ci.wp_upf = ci.wp_s2d = -1
+                ci.wp_ph = 0
+                if ci.wp_up >= 0 and PHASE_CONVS:
+                    # ... and its forward on the nearest-upsampled input is four 2x2 phase convs on the stored input
+                    ci.wp_ph = lib.ctl_conv_wpack_floats(ci.cin, ci.cout, 2)
+                    ci.wp_upf, wp = wp, wp + 4 * ci.wp_ph
+                if PHASE_CONVS and ci.ks == 3 and not ci.transposed and key.endswith(".down"):
+                    # stride-2 conv of a down block: its data gradient is four phase convs with <= 2x2 taps over dy (instead of a
+                    # 3x3 conv over a zero-inserted tensor that is 75 % zeros)
+                    ci.wp_ph = lib.ctl_conv_wpack_floats(ci.cout, ci.cin, 2)
+                    ci.wp_s2d, wp = wp, wp + 4 * ci.wp_ph
                 self._convs[key] = ci
         self._wp = torch.zeros(max(wp, 1), dtype=torch.float32, device=device)
         self._pack_plan = self._build_pack_plan()
@@ -498,7 +510,7 @@ class CtlNet(nn.Module):
 
         def pack(src_off_f, dst_off_f, cout, cin, ks, strides, flip, mode=0):
             total = lib.ctl_conv_wpack_floats(cin, cout, ks)
-            recs.append([src_off_f, dst_off_f, cout, cin, ks, 1 if flip else 0, *strides, total, mode])
+            recs.append([src_off_f, dst_off_f, cout, cin, ks, int(flip), *strides, total, mode])
 
         for ci in self._convs.values():
             k2 = ci.ks * ci.ks
@@ -511,6 +523,11 @@ class CtlNet(nn.Module):
                 pack(ci.w_off, ci.wp_dgrad, ci.cin, ci.cout, ci.ks, (k2, ci.cin * k2, ci.ks, 1), True)
                 if ci.wp_up >= 0:      # mode 1: the 4x4 kernel is summed from the 3x3 taps inside the pack kernel
                     pack(ci.w_off, ci.wp_up, ci.cin, ci.cout, 4, (k2, ci.cin * k2, ci.ks, 1), False, mode=1)
+                for z in range(4):     # modes 2 / 3: the `flip` field carries the phase
+                    if ci.wp_upf >= 0:
+                        pack(ci.w_off, ci.wp_upf + z * ci.wp_ph, ci.cout, ci.cin, 2, (ci.cin * k2, k2, ci.ks, 1), z, mode=2)
+                    if ci.wp_s2d >= 0:
+                        pack(ci.w_off, ci.wp_s2d + z * ci.wp_ph, ci.cin, ci.cout, 2, (k2, ci.cin * k2, ci.ks, 1), z, mode=3)
         pb.table = np.asarray(recs, dtype=np.int64)
         op = pb.op(_ffi.OP_PACK_BATCH)                 # ONE launch re-packs every conv of the network
         op["i"][0] = len(recs)
@@ -576,7 +593,12 @@ class CtlNet(nn.Module):
         else:
             src, src_mode = xin, _ffi.IN_UP2
         c0, c3, c1 = C[prefix + ".conv.0"], C[prefix + ".conv.3"], C[prefix + ".conv_input"]
-        u, st, blk = pb.conv(src, self._wp_ref(c0.wp_fwd), c0.cout, 3, in_mode=src_mode, bias_ref=pb.P(c0.b_off), stats=train)
+        if pre == "nn" and c0.wp_upf >= 0:
+            # conv3x3(nearest_up(x)) as four 2x2 phase convs on x, outputs scattered to (2i+a, 2j+b): 16 taps per 4 outputs, not 36
+            u, st, blk = pb.conv(xin, self._wp_ref(c0.wp_upf), c0.cout, 2, nsub=4, pad=2, hout=xin.h, wout=xin.w,
+                                 bias_ref=pb.P(c0.b_off), stats=train)
+        else:
+            u, st, blk = pb.conv(src, self._wp_ref(c0.wp_fwd), c0.cout, 3, in_mode=src_mode, bias_ref=pb.P(c0.b_off), stats=train)
         co1 = pb.bn_forward(B[prefix + ".conv.1"], st, blk, u.n * u.h * u.w, mode)
         v, st, blk = pb.conv(u, self._wp_ref(c3.wp_fwd), c3.cout, 3, pro=(co1["scale"], co1["shift"], SLOPE),
                              bias_ref=pb.P(c3.b_off), stats=train)
@@ -652,7 +674,10 @@ class CtlNet(nn.Module):
             if need_w:
                 pb.wgrad(xin, dsrc, 3, stride=2, pro=rec["xin_pro"], dw_ref=pb.G(ci.w_off), strides=(ci.cin * k9, k9, 3, 1),
                          dbias_ref=pb.G(ci.b_off))
-            pb.conv(dsrc, self._wp_ref(ci.wp_dgrad), ci.cin, 3, in_mode=_ffi.IN_ZINS2, out=d_in, hout=xin.h, wout=xin.w)
+            if ci.wp_s2d >= 0 and xin.h == 2 * dsrc.h and xin.w == 2 * dsrc.w:
+                pb.conv(dsrc, self._wp_ref(ci.wp_s2d), ci.cin, 2, nsub=4, pad=0, hout=dsrc.h, wout=dsrc.w, out=d_in)
+            else:       # odd sizes: 3x3 conv over the zero-inserted gradient
+                pb.conv(dsrc, self._wp_ref(ci.wp_dgrad), ci.cin, 3, in_mode=_ffi.IN_ZINS2, out=d_in, hout=xin.h, wout=xin.w)
         return d_in
 
     def _emit_conv_bn_pair_bwd(self, pb, conv_key, bn_key, x: T, x_pro, u: T, co, slope, d_act: T, d_x: Optional[T], need_w, affine,

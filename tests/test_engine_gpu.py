@@ -168,12 +168,14 @@ def test_grouped_pass_equals_consecutive_passes(name, n, mode, golden_sd):
     for oa, ob in zip(o1, o2):
         for a, b in zip(oa, ob):
             close(b, a, atol=2e-5, rel=1e-5, what=f"{name} grouped output")
+    # gradients: robust comparison (a LeakyReLU input within rounding of 0 may take the other slope when the order of the
+    # statistics partial sums changes -- see grads_close_robust)
     for a, b in zip(dx1, dx2):
-        close(b, a, atol=1e-6, rel=2e-4, what=f"{name} grouped dx")
+        grads_close_robust(b, a, f"{name} grouped dx")
     for k in g1:
         if is_dead_bias(k):
             continue
-        close(g2[k], g1[k], atol=2e-6, rel=2e-4, what=f"{name} grouped grad {k}")
+        grads_close_robust(g2[k], g1[k], f"{name} grouped grad {k}")
     for k in b1:
         close(b2[k].double(), b1[k].double(), atol=1e-6, rel=1e-6, what=f"{name} grouped buffer {k}")
     nbt = [k for k in b2 if k.endswith("num_batches_tracked")][0]

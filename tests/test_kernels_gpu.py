@@ -90,6 +90,46 @@ def test_conv4x4_s2_is_pooled_3x3_data_gradient(n, c, cout, h, w):
     close(y2, x.grad, what="pooled dgrad via 4x4 s2")
 
 
+def _pack_phases(w, cout_eff, cin_eff, strides, mode):
+    """Four 2x2 phase packs of a 3x3 weight through the table-driven pack kernel (modes 2 / 3 of ctl_pack_weights_batched)."""
+    sub = lib.ctl_conv_wpack_floats(cin_eff, cout_eff, 2)
+    table = np.asarray([[0, z * sub, cout_eff, cin_eff, 2, z, *strides, sub, mode] for z in range(4)], dtype=np.int64)
+    wd, td = dev(w).contiguous(), torch.from_numpy(table).to(DEV)
+    out = torch.zeros(4 * sub, device=DEV)
+    check(lib.ctl_pack_weights_batched(wd.data_ptr(), out.data_ptr(), td.data_ptr(), 4, sub, ops.stream_ptr()))
+    return out
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w", [(2, 16, 16, 16, 16), (2, 128, 64, 4, 4), (3, 32, 16, 24, 20), (16, 16, 16, 64, 64), (2, 64, 32, 40, 36)])
+def test_phase_convs_upsampled_forward_and_stride2_dgrad(n, cin, cout, h, w):
+    g = torch.Generator().manual_seed(cin + h)
+    # (i) conv3x3(nearest_up(x)) == four 2x2 phase convs on x (pad code 2), with bias and BatchNorm statistics
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * 0.2
+    b = torch.randn(cout, generator=g)
+    d = _ffi.conv_desc(n=n, hin=h, win=w, cin=cin, hout=h, wout=w, cout=cout, ks=2, stride=1, pad=2, nsub=4, out_h=2 * h, out_w=2 * w,
+                       out_sy=2, out_sx=2, out_sub=1, epi_flags=_ffi.EPI_BIAS | _ffi.EPI_STATS)
+    y = ops.empty_nhwc(n, cout, 2 * h, 2 * w, DEV)
+    _, st = ops.conv_forward(d, dev(x), _pack_phases(wt, cout, cin, (cin * 9, 9, 3, 1), 2), bias=dev(b), y=y, want_stats=True)
+    ref = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), wt, b, padding=1)
+    close(y, ref, what="phase forward of conv3x3(up2(x))")
+    rows = lib.ctl_conv_stats_blocks(_ffi.desc_ptr(d))
+    part = st.cpu().double().view(rows, 2, cout).sum(0)
+    assert float((part[0] - ref.double().sum((0, 2, 3))).abs().max()) <= 2e-4 * float(ref.double().sum((0, 2, 3)).abs().max()) + 1e-2
+    assert float((part[1] - (ref.double() ** 2).sum((0, 2, 3))).abs().max()) <= 2e-4 * float((ref.double() ** 2).sum((0, 2, 3)).max())
+    # (ii) data gradient of a stride-2 pad-1 3x3 conv == four phase convs over dy (pad code 0)
+    xs = torch.randn(n, cin, 2 * h, 2 * w, generator=g, requires_grad=True)
+    ws = torch.randn(cout, cin, 3, 3, generator=g) * 0.2
+    ys = F.conv2d(xs, ws, stride=2, padding=1)
+    dy = torch.randn(ys.shape, generator=g)
+    ys.backward(dy)
+    d2 = _ffi.conv_desc(n=n, hin=h, win=w, cin=cout, hout=h, wout=w, cout=cin, ks=2, stride=1, pad=0, nsub=4, out_h=2 * h, out_w=2 * w,
+                        out_sy=2, out_sx=2, out_sub=1)
+    dx = ops.empty_nhwc(n, cin, 2 * h, 2 * w, DEV)
+    ops.conv_forward(d2, dev(dy), _pack_phases(ws, cin, cout, (9, cin * 9, 3, 1), 3), y=dx)
+    close(dx, xs.grad, what="phase data gradient of conv3x3 s2")
+
+
 @pytest.mark.parametrize("n,c,cout,h,w,groups", [(2, 32, 16, 24, 20, 1), (16, 16, 16, 64, 64, 1), (4, 64, 32, 40, 36, 2), (32, 16, 16, 64, 64, 2)])
 def test_conv_epilogue_bn_backward_reduction(n, c, cout, h, w, groups):
     """CTL_EPI_BNBWD: y = conv(x) * leaky'(u*scale+shift) and the partials hold (sum y, sum y*u) per BatchNorm group."""
