@@ -34,35 +34,6 @@ __device__ __forceinline__ float ctl_leaky(float v, float slope) { return v > 0.
 // derivative factor chosen from the sign of the activation *output* (== sign of its input for slope >= 0)
 __device__ __forceinline__ float ctl_leaky_grad(float out, float slope) { return out > 0.f ? 1.f : slope; }
 
-// XCD-aware bijective remap of a 1-D block index: blocks b and b+8 share an XCD (observed round-robin), so give
-// every XCD a contiguous chunk of the tile list -> neighbouring tiles (shared halos) meet in one L2.
-__device__ __forceinline__ int ctl_xcd_remap(int bid, int nblk) {
-    const int q = nblk >> 3, r = nblk & 7, x = bid & 7;
-    const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
-    return base + (bid >> 3);
-}
-
-// Co-resident workgroups of a persistent kernel run the same phase sequence (load | MFMA | epilogue) and, started together,
-// stay in lockstep: all fight for the matrix pipe, then all leave it idle (measured: kernel time = MFMA time + memory time).
-// Giving the waves that share a SIMD different static priorities (keyed by the hardware wave slot) breaks the symmetry:
-// the highest-priority wave finishes its MFMA phase first and moves on while the others compute.
-__device__ __forceinline__ void ctl_stagger_priority() {
-    const unsigned hw = __builtin_amdgcn_s_getreg((4) | (0 << 6) | ((4 - 1) << 11));   // HW_REG_HW_ID[3:0] = wave slot
-    switch (hw & 3u) {
-        case 0: __builtin_amdgcn_s_setprio(0); break;
-        case 1: __builtin_amdgcn_s_setprio(1); break;
-        case 2: __builtin_amdgcn_s_setprio(2); break;
-        default: __builtin_amdgcn_s_setprio(3); break;
-    }
-}
-// Explicit start stagger: waves sharing a SIMD start `slot * units` x 64 cycles apart (experiment hook, units = 0: off).
-__device__ __forceinline__ void ctl_stagger_sleep(int units) {
-    if (units <= 0) return;
-    const unsigned hw = __builtin_amdgcn_s_getreg((4) | (0 << 6) | ((4 - 1) << 11));
-    const int n = (int)(hw & 3u) * units;
-    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(16);      // 16 x 64 = 1024 cycles per iteration
-}
-
 // Workgroup barriers for the pipelined loops.  __syncthreads() is a workgroup-scope FENCE + barrier: hipcc puts
 // s_waitcnt vmcnt(0) in front of it, which drains every in-flight global load AND store of the wave (seen in the ISA; it made
 // prefetch and epilogue stores strictly serial with the MFMA phase).  The loops only need LDS ordering:
