@@ -75,6 +75,7 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
             # the flat-parameter leaves live on the main stream while part of their gradient is produced on the second one: intended
             torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
         self._side_pending = False
+        self._chain_events = None        # list collecting per-step stream events (tools/chain_timing.py)
         self._in_side = False            # True while the hard-example branch of cooperative_step is being issued on the side stream
         self.training = True
 
@@ -511,16 +512,21 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
         self._main = cur
         z_i, z_s = self._enc(image_l)
         self.z_i, self.z_s = z_i, z_s
+        if self._chain_events is not None:
+            self._fork_event = torch.cuda.Event(enable_timing=True)
+            self._fork_event.record(cur)
         side.wait_stream(cur)                       # fork point: right after the encoder
         for t in (z_i, z_s, clean_image_l, label_l):
             t.record_stream(side)
         # main chain first (the CPU issues in program order; the GPU starts on it at once): D_seg -> STN of the standard phase
         std = self.standard_training(clean_image_l, label_l, perturbed_image=image_l, separate_training=separate_training,
                                      _pre=(z_i, z_s, None))
+        # the standard image branch stays on the main chain: measured (tools/chain_timing.py), the second chain (generation, FTN on
+        # the hard image, its STN pair, and all of that again in the backward) is the longer one
+        image_recon_loss = scaled_mse(self.decode_image(z_i), clean_image_l, 0.5)
         self._in_side = True
         try:
             with torch.cuda.stream(side):
-                image_recon_loss = scaled_mse(self.decode_image(z_i), clean_image_l, 0.5)
                 xh, yh = self.hard_example_generation(clean_image_l.detach(), label_l.detach(), gen_corrupted_seg=seg_cfg is not None,
                                                       gen_corrupted_image=img_cfg is not None, corrupted_image_DA_config=img_cfg,
                                                       corrupted_seg_DA_config=seg_cfg, image_override=image_override,
@@ -529,8 +535,14 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
                                                   separate_training=separate_training)
         finally:
             self._in_side = False
+        if self._chain_events is not None:          # tools/chain_timing.py: when does each chain finish its forward?
+            ev = {k: torch.cuda.Event(enable_timing=True) for k in ("fork", "main_done", "side_done")}
+            ev["fork"] = self._fork_event
+            ev["main_done"].record(cur)
+            ev["side_done"].record(side)
+            self._chain_events.append(ev)
         cur.wait_stream(side)
-        for t in (image_recon_loss,) + tuple(hard):
+        for t in tuple(hard):
             t.record_stream(cur)
         return (std[0], image_recon_loss, std[2], std[3]), hard
 
