@@ -518,23 +518,28 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
         side.wait_stream(cur)                       # fork point: right after the encoder
         for t in (z_i, z_s, clean_image_l, label_l):
             t.record_stream(side)
-        # main chain first (the CPU issues in program order; the GPU starts on it at once): D_seg -> STN of the standard phase
-        std = self.standard_training(clean_image_l, label_l, perturbed_image=image_l, separate_training=separate_training,
-                                     _pre=(z_i, z_s, None))
-        # the standard image branch stays on the main chain: measured (tools/chain_timing.py), the second chain (generation, FTN on
-        # the hard image, its STN pair, and all of that again in the backward) is the longer one
-        image_recon_loss = scaled_mse(self.decode_image(z_i), clean_image_l, 0.5)
-        self._in_side = True
-        try:
-            with torch.cuda.stream(side):
-                xh, yh = self.hard_example_generation(clean_image_l.detach(), label_l.detach(), gen_corrupted_seg=seg_cfg is not None,
-                                                      gen_corrupted_image=img_cfg is not None, corrupted_image_DA_config=img_cfg,
-                                                      corrupted_seg_DA_config=seg_cfg, image_override=image_override,
-                                                      seg_override=seg_override)
-                hard = self.hard_example_training(perturbed_image=xh, perturbed_seg=yh, clean_image_l=clean_image_l, label_l=label_l,
-                                                  separate_training=separate_training)
-        finally:
-            self._in_side = False
+        def main_chain():
+            std = self.standard_training(clean_image_l, label_l, perturbed_image=image_l, separate_training=separate_training,
+                                         _pre=(z_i, z_s, None))
+            return std, scaled_mse(self.decode_image(z_i), clean_image_l, 0.5)
+
+        def side_chain():
+            self._in_side = True
+            try:
+                with torch.cuda.stream(side):
+                    xh, yh = self.hard_example_generation(clean_image_l.detach(), label_l.detach(), gen_corrupted_seg=seg_cfg is not None,
+                                                          gen_corrupted_image=img_cfg is not None, corrupted_image_DA_config=img_cfg,
+                                                          corrupted_seg_DA_config=seg_cfg, image_override=image_override,
+                                                          seg_override=seg_override)
+                    return self.hard_example_training(perturbed_image=xh, perturbed_seg=yh, clean_image_l=clean_image_l, label_l=label_l,
+                                                      separate_training=separate_training)
+            finally:
+                self._in_side = False
+
+        # main chain first: the CPU issues in program order and the GPU starts on it at once (issuing the second chain first was
+        # measured: 797 vs 809 slices/s)
+        std, image_recon_loss = main_chain()
+        hard = side_chain()
         if self._chain_events is not None:          # tools/chain_timing.py: when does each chain finish its forward?
             ev = {k: torch.cuda.Event(enable_timing=True) for k in ("fork", "main_done", "side_done")}
             ev["fork"] = self._fork_event
