@@ -40,7 +40,7 @@ void ctl_set_error(const char* fmt, ...) {
 #include <string>
 #include <vector>
 namespace {
-struct ProfRec { std::string id; hipEvent_t a, b; double flops, bytes; };
+struct ProfRec { std::string id; hipEvent_t a, b; double flops, bytes; void* stream; };
 bool g_prof_on = false;
 std::string g_prof_filter;
 std::vector<ProfRec> g_prof;
@@ -53,6 +53,7 @@ int ctl_prof_begin(const char* kind, const ctl_conv* d, const ctl_conv_cfg* c, i
     if (!g_prof_filter.empty() && std::string(id).find(g_prof_filter) == std::string::npos) return -1;
     ProfRec r;
     r.id = id;
+    r.stream = (void*)stream;
     if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return -1;
     const double pix = (double)d->n * d->hout * d->wout * d->nsub;
     r.flops = 2.0 * pix * d->cout * d->cin * d->ks * d->ks;
@@ -78,16 +79,25 @@ extern "C" int ctl_prof_stop(char* out, size_t cap) {
     g_prof_on = false;
     struct Agg { long n = 0; double ms = 0, flops = 0, bytes = 0; };
     std::map<std::string, Agg> agg;
+    // CTL_PROF_TIMELINE=<file>: raw per-launch intervals (ms since the first bracketed launch) with their stream -- the real
+    // overlap of concurrent launch chains, which rocprofv3's kernel trace hides by serialising the dispatches
+    FILE* tl = nullptr;
+    if (const char* path = getenv("CTL_PROF_TIMELINE")) tl = fopen(path, "w");
     for (auto& r : g_prof) {
+        if (tl && !g_prof.empty() && hipEventSynchronize(r.b) == hipSuccess) {
+            float t0 = 0.f, t1 = 0.f;
+            if (hipEventElapsedTime(&t0, g_prof[0].a, r.a) == hipSuccess && hipEventElapsedTime(&t1, g_prof[0].a, r.b) == hipSuccess)
+                fprintf(tl, "%s %p %.6f %.6f\n", r.id.c_str(), r.stream, t0, t1);
+        }
         float ms = 0.f;
         if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
             Agg& a = agg[r.id];
             a.n++; a.ms += ms; a.flops += r.flops; a.bytes += r.bytes;
         }
-        (void)hipEventDestroy(r.a);
-        (void)hipEventDestroy(r.b);
     }
+    for (auto& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     g_prof.clear();
+    if (tl) fclose(tl);
     std::string text;
     for (auto& kv : agg) {
         char line[320];

@@ -1,0 +1,38 @@
+"""Real concurrent timeline of the conv-family launches of ONE training step (events on each kernel's own stream; rocprofv3
+serialises dispatches and cannot show this).  Prints per 1-ms bucket how busy each stream is and the phase boundaries."""
+import os, sys, collections
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["CTL_PROF_TIMELINE"] = "/tmp/ctl_timeline.txt"
+import torch
+from cooperative_training_and_latent_space_data_augmentation_amd import _ffi
+from cooperative_training_and_latent_space_data_augmentation_amd.solver import AdvancedTripletReconSegmentationModel
+import bench
+torch.manual_seed(0)
+s = AdvancedTripletReconSegmentationModel(use_gpu=True)
+clean = torch.rand(16, 1, 256, 256, device="cuda"); noisy = (clean + 0.1 * torch.randn_like(clean)).clamp(0, 1)
+label = torch.randint(0, 4, (16, 256, 256), device="cuda")
+for _ in range(5): s.cooperative_step(clean, label, noisy, bench.DROP_IMG, bench.DROP_SEG)
+torch.cuda.synchronize()
+_ffi.prof_start("")
+s.cooperative_step(clean, label, noisy, bench.DROP_IMG, bench.DROP_SEG)
+torch.cuda.synchronize()
+_ffi.prof_stop()
+rows = [l.split() for l in open("/tmp/ctl_timeline.txt")]
+ev = [(r[0], r[1], float(r[2]), float(r[3])) for r in rows]
+streams = sorted(set(e[1] for e in ev), key=lambda st: min(e[2] for e in ev if e[1] == st))
+end = max(e[3] for e in ev)
+print(f"{len(ev)} conv-family launches, span {end:.2f} ms (event bracketing slows the step), streams: {len(streams)}")
+B = 0.5
+nb = int(end / B) + 1
+busy = {st: [0.0] * nb for st in streams}
+for name, st, a, b in ev:
+    i = int(a / B)
+    while a < b:
+        nxt = min(b, (i + 1) * B)
+        busy[st][i] += nxt - a
+        a = nxt; i += 1
+print("bucket(ms)  " + "  ".join(f"stream{k}" for k in range(len(streams))))
+for i in range(nb):
+    print(f"{i*B:6.1f}      " + "  ".join(f"{100*busy[st][i]/B:6.0f}%" for st in streams))
+tot = {st: sum(busy[st]) for st in streams}
+print("conv-family busy per stream (ms):", {f"stream{k}": round(tot[st], 2) for k, st in enumerate(streams)})
