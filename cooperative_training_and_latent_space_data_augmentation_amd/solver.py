@@ -219,17 +219,7 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
         if not self.two_streams:
             return fn()
         if self._in_side:
-            # issued from the hard-example branch (which itself lives on the second stream): hand this piece back to the main
-            # stream, which has finished the standard phase's D_seg -> STN by the time the hard image is encoded
-            main, side = self._main, self._side
-            main.wait_stream(side)
-            for t in inputs:
-                t.record_stream(main)
-            with torch.cuda.stream(main):
-                out = fn()
-            for t in (out if isinstance(out, tuple) else (out,)):
-                t.record_stream(side)
-            return out
+            return fn()
         cur = torch.cuda.current_stream()
         self._side.wait_stream(cur)
         for t in inputs:
@@ -518,28 +508,47 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
         side.wait_stream(cur)                       # fork point: right after the encoder
         for t in (z_i, z_s, clean_image_l, label_l):
             t.record_stream(side)
-        def main_chain():
-            std = self.standard_training(clean_image_l, label_l, perturbed_image=image_l, separate_training=separate_training,
-                                         _pre=(z_i, z_s, None))
-            return std, scaled_mse(self.decode_image(z_i), clean_image_l, 0.5)
-
-        def side_chain():
-            self._in_side = True
+        # Assignment of the work to the two chains, from the measured timeline (tools/timeline.py): pieces with a backward are split
+        # so that BOTH directions balance -- main: D_seg -> STN (standard) + image decoder (standard), then the FTN encoder's backward;
+        # side: FTN on the hard image, its D_seg, image decoder and STN pair.  The forward-only generation passes go where the
+        # forward has room: image part at the head of the side chain (the hard image is needed first), segmentation part at the
+        # head of the main chain (its result is needed last, by the hard STN pair).  Python order = reference order (image
+        # perturbation before segmentation perturbation: same RNG draws).
+        gen_kw = dict(corrupted_image_DA_config=img_cfg, corrupted_seg_DA_config=seg_cfg, image_override=image_override,
+                      seg_override=seg_override)
+        xh = yh = None
+        self._in_side = True
+        try:
+            with torch.cuda.stream(side):
+                if img_cfg is not None:
+                    xh, _ = self.hard_example_generation(clean_image_l.detach(), label_l.detach(), gen_corrupted_seg=False,
+                                                         gen_corrupted_image=True, **gen_kw)
+        finally:
+            self._in_side = False
+        if seg_cfg is not None:
+            self._in_side = True               # (no nested fork inside the generation)
             try:
-                with torch.cuda.stream(side):
-                    xh, yh = self.hard_example_generation(clean_image_l.detach(), label_l.detach(), gen_corrupted_seg=seg_cfg is not None,
-                                                          gen_corrupted_image=img_cfg is not None, corrupted_image_DA_config=img_cfg,
-                                                          corrupted_seg_DA_config=seg_cfg, image_override=image_override,
-                                                          seg_override=seg_override)
-                    return self.hard_example_training(perturbed_image=xh, perturbed_seg=yh, clean_image_l=clean_image_l, label_l=label_l,
-                                                      separate_training=separate_training)
+                _, yh = self.hard_example_generation(clean_image_l.detach(), label_l.detach(), gen_corrupted_seg=True,
+                                                     gen_corrupted_image=False, **gen_kw)
             finally:
                 self._in_side = False
-
-        # main chain first: the CPU issues in program order and the GPU starts on it at once (issuing the second chain first was
-        # measured: 797 vs 809 slices/s)
-        std, image_recon_loss = main_chain()
-        hard = side_chain()
+            yh.record_stream(side)
+        seg_ready = torch.cuda.Event()
+        seg_ready.record(cur)
+        # the standard image decoder goes FIRST on the main chain: autograd replays a chain in reverse, and where two passes of a
+        # network sit on different streams the later gradient has to wait for the earlier one at the accumulation -- as the first
+        # backward node of the main chain it stalled 5 ms on the hard image decoder's backward, which comes late on the side chain
+        image_recon_loss = scaled_mse(self.decode_image(z_i), clean_image_l, 0.5)
+        std = self.standard_training(clean_image_l, label_l, perturbed_image=image_l, separate_training=separate_training,
+                                     _pre=(z_i, z_s, None))
+        self._in_side = True
+        try:
+            with torch.cuda.stream(side):
+                side.wait_event(seg_ready)
+                hard = self.hard_example_training(perturbed_image=xh, perturbed_seg=yh, clean_image_l=clean_image_l, label_l=label_l,
+                                                  separate_training=separate_training)
+        finally:
+            self._in_side = False
         if self._chain_events is not None:          # tools/chain_timing.py: when does each chain finish its forward?
             ev = {k: torch.cuda.Event(enable_timing=True) for k in ("fork", "main_done", "side_done")}
             ev["fork"] = self._fork_event
