@@ -539,8 +539,9 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
         # network sit on different streams the later gradient has to wait for the earlier one at the accumulation -- as the first
         # backward node of the main chain it stalled 5 ms on the hard image decoder's backward, which comes late on the side chain
         image_recon_loss = scaled_mse(self.decode_image(z_i), clean_image_l, 0.5)
-        std = self.standard_training(clean_image_l, label_l, perturbed_image=image_l, separate_training=separate_training,
-                                     _pre=(z_i, z_s, None))
+        # CPU issue order (one Python thread feeds both streams): the side chain's long part is issued BEFORE the main chain's
+        # D_seg -> STN, while the GPU is still busy with what both streams already have -- issued after it, the side stream sat
+        # idle for ~1.5 ms waiting for the host (tools/timeline.py)
         self._in_side = True
         try:
             with torch.cuda.stream(side):
@@ -549,6 +550,8 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
                                                   separate_training=separate_training)
         finally:
             self._in_side = False
+        std = self.standard_training(clean_image_l, label_l, perturbed_image=image_l, separate_training=separate_training,
+                                     _pre=(z_i, z_s, None))
         if self._chain_events is not None:          # tools/chain_timing.py: when does each chain finish its forward?
             ev = {k: torch.cuda.Event(enable_timing=True) for k in ("fork", "main_done", "side_done")}
             ev["fork"] = self._fork_event
