@@ -65,6 +65,21 @@ int ctl_prof_begin(const char* kind, const ctl_conv* d, const ctl_conv_cfg* c, i
     g_prof.push_back(r);
     return (int)g_prof.size() - 1;
 }
+// non-conv plan ops: bracketed only for the timeline dump (CTL_PROF_TIMELINE), no algorithmic work attached
+static int prof_begin_op(int kind, hipStream_t stream) {
+    static const bool want = getenv("CTL_PROF_TIMELINE") != nullptr;
+    if (!g_prof_on || !want || !g_prof_filter.empty()) return -1;
+    ProfRec r;
+    char id[32];
+    snprintf(id, sizeof(id), "op%d", kind);
+    r.id = id;
+    r.stream = (void*)stream;
+    r.flops = r.bytes = 0.0;
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return -1;
+    (void)hipEventRecord(r.a, stream);
+    g_prof.push_back(r);
+    return (int)g_prof.size() - 1;
+}
 void ctl_prof_end(int token, hipStream_t stream) {
     if (token >= 0 && token < (int)g_prof.size()) (void)hipEventRecord(g_prof[token].b, stream);
 }
@@ -174,6 +189,7 @@ extern "C" int ctl_plan_run(const ctl_op* ops, int32_t n_ops, void* const* bases
 #define CF(a) ((const float*)t[a])
         int rc = CTL_OK;
         ctl_conv d;
+        const int ptok = (op.kind == CTL_OP_CONV || op.kind == CTL_OP_WGRAD) ? -1 : prof_begin_op(op.kind, (hipStream_t)stream);
         switch (op.kind) {
             case CTL_OP_CONV:
                 memcpy(&d, op.i, sizeof(d));
@@ -242,6 +258,7 @@ extern "C" int ctl_plan_run(const ctl_op* ops, int32_t n_ops, void* const* bases
 #undef F
 #undef CF
 #undef NG
+        if (ptok >= 0) ctl_prof_end(ptok, (hipStream_t)stream);
         if (rc != CTL_OK) {
             char msg[400];
             snprintf(msg, sizeof(msg), "%s", g_err);

@@ -1,4 +1,4 @@
-"""Real concurrent timeline of the conv-family launches of ONE training step (events on each kernel's own stream; rocprofv3
+"""Real concurrent timeline of the plan ops of ONE training step (events on each kernel's own stream; rocprofv3
 serialises dispatches and cannot show this).  Prints per 1-ms bucket how busy each stream is and the phase boundaries."""
 import os, sys, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -21,7 +21,8 @@ rows = [l.split() for l in open("/tmp/ctl_timeline.txt")]
 ev = [(r[0], r[1], float(r[2]), float(r[3])) for r in rows]
 streams = sorted(set(e[1] for e in ev), key=lambda st: min(e[2] for e in ev if e[1] == st))
 end = max(e[3] for e in ev)
-print(f"{len(ev)} conv-family launches, span {end:.2f} ms (event bracketing slows the step), streams: {len(streams)}")
+print(f"{len(ev)} bracketed plan ops (conv family + element-wise; losses / masks / Adam / torch ops are not bracketed), span {end:.2f} ms "
+      f"(event bracketing slows the step), streams: {len(streams)}")
 B = 0.5
 nb = int(end / B) + 1
 busy = {st: [0.0] * nb for st in streams}
@@ -35,4 +36,4 @@ print("bucket(ms)  " + "  ".join(f"stream{k}" for k in range(len(streams))))
 for i in range(nb):
     print(f"{i*B:6.1f}      " + "  ".join(f"{100*busy[st][i]/B:6.0f}%" for st in streams))
 tot = {st: sum(busy[st]) for st in streams}
-print("conv-family busy per stream (ms):", {f"stream{k}": round(tot[st], 2) for k, st in enumerate(streams)})
+print("plan-op busy per stream (ms):", {f"stream{k}": round(tot[st], 2) for k, st in enumerate(streams)})
