@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CTL_HIP_LIB") or os.path.join(_HERE, "csrc", "libctl_hip.so")   # override: A/B builds of the kernels
 
 # enums of ctl_hip.h
-IN_PLAIN, IN_UP2, IN_ZINS2 = 0, 1, 2
+IN_PLAIN, IN_UP2, IN_ZINS2, IN_C4 = 0, 1, 2, 3
 ACT_NONE, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2
 EPI_BIAS, EPI_ACCUM, EPI_RES, EPI_STATS, EPI_BNBWD = 1, 2, 4, 8, 16
 RED_BLOCKS = 512

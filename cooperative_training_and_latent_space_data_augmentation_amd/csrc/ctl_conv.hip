@@ -75,6 +75,9 @@ __device__ __forceinline__ f32x4 ctl_leaky01(f32x4 v, float slope) {
 // depends only on the thread (tile-relative coordinates, source byte offset, LDS offset) is computed ONCE (init); per tile a
 // unit costs two adds + two unsigned compares (bounds) + one select for the buffer offset.  LOAD issues all buffer loads of
 // the tile back to back (nothing consumes them), STORE (after the MFMA phase) applies the prologue and writes LDS.
+// CTL_IN_C4: plain stored input with <= 4 channels whose 3x3 taps are K-packed (see conv_igemm_kernel)
+#define CTL_MODE_IS_PLAIN(M) ((M) == CTL_IN_PLAIN || (M) == CTL_IN_C4)
+
 template <int KS, int S, int MODE, int MT, int TW>
 struct XStage {
     using G = Geom<KS, S, MT, TW>;
@@ -101,8 +104,8 @@ struct XStage {
             // source = virtual for plain inputs; for x2 nearest / zero-insert inputs the tile origin is even, so
             // (origin - PAD + r) >> 1 = origin/2 + ((r - PAD) >> 1); the source origin is moved up/left by PADH so that
             // the per-thread offsets are never negative (they are unsigned voffsets next to a scalar tile offset)
-            const int rr = (MODE == CTL_IN_PLAIN) ? r : (((r - G::PAD) >> 1) + PADH);
-            const int cc = (MODE == CTL_IN_PLAIN) ? c : (((c - G::PAD) >> 1) + PADH);
+            const int rr = CTL_MODE_IS_PLAIN(MODE) ? r : (((r - G::PAD) >> 1) + PADH);
+            const int cc = CTL_MODE_IS_PLAIN(MODE) ? c : (((c - G::PAD) >> 1) + PADH);
             rel[i] = in ? ((rr * d.win + cc) * d.cin + cq * 4) * 4 : CTL_OOB;
             rc[i] = in ? (r | (c << 16)) : 0x7fff7fff;
             lds[i] = in ? ((r * G::IWP + G::ldscol(c)) * 16 + cq * 4) : G::XT_IMAGE;
@@ -114,10 +117,10 @@ struct XStage {
 
     __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rx, const ctl_conv& d, int n, int ho0, int wo0, int g) {
         const int vh0 = ho0 * S - pad_h, vw0 = wo0 * S - pad_w;
-        const unsigned hv = (MODE == CTL_IN_PLAIN) ? d.hin : 2 * d.hin;
-        const unsigned wv = (MODE == CTL_IN_PLAIN) ? d.win : 2 * d.win;
-        const int oh = (MODE == CTL_IN_PLAIN) ? vh0 : ((ho0 >> 1) - PADH);
-        const int ow = (MODE == CTL_IN_PLAIN) ? vw0 : ((wo0 >> 1) - PADH);
+        const unsigned hv = CTL_MODE_IS_PLAIN(MODE) ? d.hin : 2 * d.hin;
+        const unsigned wv = CTL_MODE_IS_PLAIN(MODE) ? d.win : 2 * d.win;
+        const int oh = CTL_MODE_IS_PLAIN(MODE) ? vh0 : ((ho0 >> 1) - PADH);
+        const int ow = CTL_MODE_IS_PLAIN(MODE) ? vw0 : ((wo0 >> 1) - PADH);
         const int tb = (((n * d.hin + oh) * d.win + ow) * d.cin + g * 16) * 4;      // uniform; may be negative at the border
         // interior tile (most of them): every unit is in range -> the tile origin goes into the scalar offset of the buffer
         // loads and the per-thread offsets are the loop-invariant rel[]: no VALU at all (fp32 MFMA shares the VALU issue
@@ -266,13 +269,19 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : ((MT * NT >= 4
                                                           int G_chunks, int64_t wpack_sub_stride, int ntiles) {
     using G = Geom<KS, S, MT, TW>;
     constexpr int TAPS = KS * KS;
+    // C4: input with <= 4 channels.  The four lane groups of an MFMA (its k index) carry four different TAPS (channels 0-3 each)
+    // instead of four channel groups of one tap: 3 fragments ("quads" of taps 0-3, 4-7, 8) cover the 3x3 kernel, so a pixel tile
+    // costs 12 MFMAs instead of 36.  Only the per-lane LDS read base and the weight fragment order differ from the plain path.
+    constexpr bool C4 = (MODE == CTL_IN_C4);
+    static_assert(!C4 || (KS == 3 && S == 1), "K-packed taps: 3x3 stride-1 only");
+    constexpr int NFRAG = C4 ? 3 : TAPS;             // weight fragments per cout tile and chunk
     constexpr int RED_FLOATS = 4 * NT * 16 * 2;
-    constexpr int WT_FLOATS = TAPS * NT * 256;
+    constexpr int WT_FLOATS = NFRAG * NT * 256;
     constexpr int XT_ALLOC = G::XT_FLOATS;
     __shared__ __attribute__((aligned(16))) float xt[XT_ALLOC + WT_FLOATS + RED_FLOATS];
     float* wt = xt + XT_ALLOC;
     float* sred = wt + WT_FLOATS;        // statistics reduction scratch (a flush can happen while xt holds the next tile)
-    constexpr int WU = TAPS * NT * 64, NW = (WU + 255) / 256;
+    constexpr int WU = NFRAG * NT * 64, NW = (WU + 255) / 256;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -329,6 +338,12 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : ((MT * NT >= 4
     // LDS operand addresses: one per-thread base; (M-tile, tap) offsets are compile-time immediates of the ds_read
     const float* xrd = xt + ((wrow * S) * G::IWP + p) * 16 + q * 4;
     const float* wrd = wt + lane * 4;
+    const float* xrd4[3];            // C4: lane group q reads channels 0-3 of the pixel shifted by tap 4j+q (tap 8 only for q = 0)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int tp = (4 * j + q < 9) ? 4 * j + q : 8;
+        xrd4[j] = xt + ((wrow + tp / 3) * G::IWP + p + tp % 3) * 16;
+    }
 
     XStage<KS, S, MODE, MT, TW> xs;
     xs.init(d);
@@ -339,7 +354,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : ((MT * NT >= 4
         xs.pad_w = d.pad == 2 ? 1 - (z & 1) : 0;
     }
     // weight chunk g: [tap][t][64 lanes][4] floats; per-thread byte offsets are loop-invariant, the chunk goes in the scalar offset
-    const __amdgpu_buffer_rsrc_t rw = ctl_rsrc(wp, (int64_t)ctl_cdiv(d.cout, 16) * TAPS * G_chunks * 1024);
+    const __amdgpu_buffer_rsrc_t rw = ctl_rsrc(wp, (int64_t)ctl_cdiv(d.cout, 16) * NFRAG * G_chunks * 1024);
     f32x4 wv[NW];
     int wrel[NW];
 #pragma unroll
@@ -347,7 +362,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : ((MT * NT >= 4
         const int u = tid + i * 256;
         const int tt = u >> 6, l = u & 63;           // tt = tap * NT + t
         const int tap = tt / NT, t = tt - tap * NT;
-        wrel[i] = (u < WU) ? ((((cot0 + t) * TAPS + tap) * G_chunks) * 64 + l) * 16 : CTL_OOB;
+        wrel[i] = (u < WU) ? ((((cot0 + t) * NFRAG + tap) * G_chunks) * 64 + l) * 16 : CTL_OOB;
     }
     auto wload = [&](int g) {
 #pragma unroll
@@ -443,14 +458,16 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : ((MT * NT >= 4
 #pragma unroll
                 for (int t = 0; t < NT; ++t) wf[b][t] = *reinterpret_cast<const f32x4*>(wrd + (tap * NT + t) * 256);
 #pragma unroll
-                for (int m = 0; m < MT; ++m)
-                    xf[b][m] = *reinterpret_cast<const f32x4*>(xrd + (((m / TWT) * S + kh) * G::IWP + (m % TWT) * 16 + kcol) * 16);
+                for (int m = 0; m < MT; ++m) {
+                    if (C4) xf[b][m] = *reinterpret_cast<const f32x4*>(xrd4[tap] + ((m / TWT) * G::IWP + (m % TWT) * 16) * 16);   // tap = quad
+                    else xf[b][m] = *reinterpret_cast<const f32x4*>(xrd + (((m / TWT) * S + kh) * G::IWP + (m % TWT) * 16 + kcol) * 16);
+                }
             };
             lds_operands(0, 0);
 #pragma unroll
-            for (int tap = 0; tap < TAPS; ++tap) {
+            for (int tap = 0; tap < NFRAG; ++tap) {
                 const int b = tap & 1;
-                if (tap + 1 < TAPS) lds_operands(tap + 1, b ^ 1);
+                if (tap + 1 < NFRAG) lds_operands(tap + 1, b ^ 1);
 #ifdef CTL_PIN_READ_AHEAD
                 __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -872,6 +889,14 @@ __global__ void pack_weights_batched_kernel(const float* __restrict__ params, fl
     const int ci = g * 16 + (lane >> 4) * 4 + j;
     int kh = tap / ks, kw = tap % ks;
     float v = 0.f;
+    if (r[11] == 4) {
+        // K-packed 3x3 weights for inputs with <= 4 channels: [cot][quad j][lane][c] = W[co][c][tap 4j + (lane>>4)] (0 past tap 8 / cin)
+        const int c = j, quad = (int)((idx >> 8) % 3), cot4 = (int)((idx >> 8) / 3);
+        const int co4 = cot4 * 16 + (lane & 15), tp = 4 * quad + (lane >> 4);
+        if (co4 < cout && c < cin && tp < 9) v = src[co4 * r[6] + c * r[7] + (tp / 3) * r[8] + (tp % 3) * r[9]];
+        dst[idx] = v;
+        return;
+    }
     if (r[11] == 1) {
         // 4x4 stride-2 pad-1 kernel K of  dx = sumpool2(conv3x3^T(dy))  (data gradient of a 3x3 conv on a nearest-upsampled input):
         // dx[i] = sum_a dx'[2i+a] = sum_{a,kh'} W[kh']^T dy[2i + a + 1 - kh']  ==>  K[u] = sum_{a in {0,1}, kh' = a+2-u in [0,2]} W[kh']
@@ -977,7 +1002,8 @@ extern "C" size_t ctl_conv_wpack_floats(int32_t cin, int32_t cout, int32_t ks) {
 
 static bool conv_combo_ok(const ctl_conv* d) {
     const int k = d->ks, s = d->stride, m = d->in_mode, pd = d->pad;
-    if (k == 3 && s == 1 && pd == 1) return true;
+    if (k == 3 && s == 1 && pd == 1 && m != CTL_IN_C4) return true;
+    if (k == 3 && s == 1 && pd == 1 && m == CTL_IN_C4 && d->cin <= 4 && d->nsub == 1) return true;     // K-packed taps (first layers)
     if (k == 3 && s == 2 && pd == 1 && m == CTL_IN_PLAIN) return true;
     if (k == 1 && s == 1 && pd == 0 && m != CTL_IN_ZINS2) return true;
     if (k == 2 && s == 2 && pd == 0 && m == CTL_IN_PLAIN) return true;
@@ -1109,6 +1135,7 @@ static int conv_dispatch(conv_call& a) {
     if (k == 3 && s == 1 && m == CTL_IN_PLAIN) conv_go_tile<3, 1, CTL_IN_PLAIN>(a);
     else if (k == 3 && s == 1 && m == CTL_IN_UP2) conv_go_tile<3, 1, CTL_IN_UP2>(a);
     else if (k == 3 && s == 1 && m == CTL_IN_ZINS2) conv_go_tile<3, 1, CTL_IN_ZINS2>(a);
+    else if (k == 3 && s == 1 && m == CTL_IN_C4) conv_go_tile<3, 1, CTL_IN_C4>(a);
     else if (k == 3 && s == 2) conv_go_tile<3, 2, CTL_IN_PLAIN>(a);
     else if (k == 1 && m == CTL_IN_PLAIN) conv_go_tile<1, 1, CTL_IN_PLAIN>(a);
     else if (k == 1 && m == CTL_IN_UP2) conv_go_tile<1, 1, CTL_IN_UP2>(a);

@@ -39,6 +39,7 @@ N_SLOTS = 15
 SLOPE = 0.2
 EPS = 1e-5
 MOMENTUM = 0.1
+SMALL_CIN = os.environ.get("CTL_SMALL_CIN", "1") != "0"          # K-packed taps for the Cin <= 4 first layers
 PHASE_CONVS = os.environ.get("CTL_PHASE_CONVS", "1") != "0"     # 2x2 phase forms of the up-sampled forward / stride-2 data gradient
 FUSE_BNBWD = os.environ.get("CTL_FUSE_BNBWD", "0") == "1"   # BN1-backward reduction inside the dgrad conv epilogue (measured: no gain)
 CONV_WORDS = _ffi.CONV_DTYPE.itemsize // 4      # ctl_conv as int32 words at the head of ctl_op.i
@@ -76,7 +77,7 @@ class _BNP(nn.Module):
 
 
 class ConvInfo:
-    __slots__ = ("key", "cin", "cout", "ks", "transposed", "w_off", "b_off", "wp_fwd", "wp_dgrad", "wp_sub", "wp_up", "wp_upf", "wp_s2d", "wp_ph")
+    __slots__ = ("key", "cin", "cout", "ks", "transposed", "w_off", "b_off", "wp_fwd", "wp_dgrad", "wp_sub", "wp_up", "wp_upf", "wp_s2d", "wp_ph", "wp_c4")
 
 
 class BNInfo:
@@ -448,8 +449,11 @@ class CtlNet(nn.Module):
                     # first conv of a nearest-upsample block: its data gradient followed by the upsample backward (2x2 sum-pool)
                     # is ONE 4x4 stride-2 conv over dU (16 taps per low-res pixel instead of 36 + a full-resolution round trip)
                     ci.wp_up, wp = wp, wp + lib.ctl_conv_wpack_floats(ci.cout, ci.cin, 4)
-                ci.wp_upf = ci.wp_s2d = -1
+                ci.wp_upf = ci.wp_s2d = ci.wp_c4 = -1
                 ci.wp_ph = 0
+                if SMALL_CIN and ci.ks == 3 and not ci.transposed and ci.cin <= 4:
+                    # first layer (image: 1 channel, STN input: 4): the 3x3 taps are K-packed, 3 fragments per cout tile
+                    ci.wp_c4, wp = wp, wp + ((ci.cout + 15) // 16) * 3 * 256
                 if ci.wp_up >= 0 and PHASE_CONVS:
                     # ... and its forward on the nearest-upsampled input is four 2x2 phase convs on the stored input
                     ci.wp_ph = lib.ctl_conv_wpack_floats(ci.cin, ci.cout, 2)
@@ -523,6 +527,8 @@ class CtlNet(nn.Module):
                 pack(ci.w_off, ci.wp_dgrad, ci.cin, ci.cout, ci.ks, (k2, ci.cin * k2, ci.ks, 1), True)
                 if ci.wp_up >= 0:      # mode 1: the 4x4 kernel is summed from the 3x3 taps inside the pack kernel
                     pack(ci.w_off, ci.wp_up, ci.cin, ci.cout, 4, (k2, ci.cin * k2, ci.ks, 1), False, mode=1)
+                if ci.wp_c4 >= 0:      # mode 4: K-packed first-layer weights
+                    recs.append([ci.w_off, ci.wp_c4, ci.cout, ci.cin, 3, 0, ci.cin * k2, k2, ci.ks, 1, ((ci.cout + 15) // 16) * 3 * 256, 4])
                 for z in range(4):     # modes 2 / 3: the `flip` field carries the phase
                     if ci.wp_upf >= 0:
                         pack(ci.w_off, ci.wp_upf + z * ci.wp_ph, ci.cout, ci.cin, 2, (ci.cin * k2, k2, ci.ks, 1), z, mode=2)
@@ -775,7 +781,10 @@ class MyEncoder(CtlNet):
         C, B, px = self._convs, self._bns, self._px
         train = mode != "C"
         c0, c3 = C[px + "inc.0"], C[px + "inc.3"]
-        u0, st, blk = pb.conv(x, self._wp_ref(c0.wp_fwd), c0.cout, 3, bias_ref=pb.P(c0.b_off), stats=train)
+        if c0.wp_c4 >= 0:
+            u0, st, blk = pb.conv(x, self._wp_ref(c0.wp_c4), c0.cout, 3, in_mode=_ffi.IN_C4, bias_ref=pb.P(c0.b_off), stats=train)
+        else:
+            u0, st, blk = pb.conv(x, self._wp_ref(c0.wp_fwd), c0.cout, 3, bias_ref=pb.P(c0.b_off), stats=train)
         co0 = pb.bn_forward(B[px + "inc.1"], st, blk, u0.n * u0.h * u0.w, mode)
         v0, st, blk = pb.conv(u0, self._wp_ref(c3.wp_fwd), c3.cout, 3, pro=(co0["scale"], co0["shift"], SLOPE),
                               bias_ref=pb.P(c3.b_off), stats=train)

@@ -38,7 +38,8 @@ const char* ctl_last_error(void);
  * with BatchNorm-apply + LeakyReLU fused into the input staging ("prologue") and bias / residual / activation /
  * BatchNorm statistics fused into the epilogue.
  */
-enum { CTL_IN_PLAIN = 0, CTL_IN_UP2 = 1, CTL_IN_ZINS2 = 2 };
+enum { CTL_IN_PLAIN = 0, CTL_IN_UP2 = 1, CTL_IN_ZINS2 = 2, CTL_IN_C4 = 3 /* plain input with <= 4 channels, 3x3 stride 1: the taps are
+       K-packed (weights from ctl_pack_weights_batched mode 4); 12 MFMAs per pixel tile instead of 36 */ };
 enum { CTL_ACT_NONE = 0, CTL_ACT_LEAKY = 1, CTL_ACT_SIGMOID = 2 };
 enum { CTL_EPI_BIAS = 1, CTL_EPI_ACCUM = 2, CTL_EPI_RES = 4, CTL_EPI_STATS = 8, CTL_EPI_BNBWD = 16 };
 

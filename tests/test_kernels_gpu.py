@@ -130,6 +130,27 @@ def test_phase_convs_upsampled_forward_and_stride2_dgrad(n, cin, cout, h, w):
     close(dx, xs.grad, what="phase data gradient of conv3x3 s2")
 
 
+@pytest.mark.parametrize("n,cin,cout,h,w", [(2, 4, 16, 32, 32), (16, 1, 16, 64, 64), (3, 4, 32, 20, 12), (2, 1, 16, 9, 7), (16, 4, 16, 128, 128)])
+def test_conv3x3_small_cin_k_packed_taps(n, cin, cout, h, w):
+    """CTL_IN_C4: first-layer convs (1 or 4 input channels) with the 3x3 taps packed into the MFMA k dimension (pack mode 4)."""
+    g = torch.Generator().manual_seed(cin * 31 + h)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * 0.3
+    b = torch.randn(cout, generator=g)
+    total = ((cout + 15) // 16) * 3 * 256
+    table = torch.tensor([[0, 0, cout, cin, 3, 0, cin * 9, 9, 3, 1, total, 4]], dtype=torch.int64, device=DEV)
+    wp = torch.zeros(total, device=DEV)
+    wd = dev(wt).contiguous()
+    check(lib.ctl_pack_weights_batched(wd.data_ptr(), wp.data_ptr(), table.data_ptr(), 1, total, ops.stream_ptr()))
+    d = _ffi.conv_desc(n=n, hin=h, win=w, cin=cin, hout=h, wout=w, cout=cout, ks=3, in_mode=_ffi.IN_C4, epi_flags=_ffi.EPI_BIAS | _ffi.EPI_STATS)
+    xin = dev(x) if cin > 1 else x.to(DEV).contiguous()
+    y, st = ops.conv_forward(d, xin, wp, bias=dev(b), want_stats=True)
+    ref = F.conv2d(x, wt, b, padding=1)
+    close(y, ref, what="K-packed first-layer conv")
+    part = st.cpu().double().view(-1, 2, cout).sum(0)
+    assert float((part[0] - ref.double().sum((0, 2, 3))).abs().max()) <= 2e-4 * float(ref.double().sum((0, 2, 3)).abs().max()) + 1e-2
+
+
 @pytest.mark.parametrize("n,c,cout,h,w,groups", [(2, 32, 16, 24, 20, 1), (16, 16, 16, 64, 64, 1), (4, 64, 32, 40, 36, 2), (32, 16, 16, 64, 64, 2)])
 def test_conv_epilogue_bn_backward_reduction(n, c, cout, h, w, groups):
     """CTL_EPI_BNBWD: y = conv(x) * leaky'(u*scale+shift) and the partials hold (sum y, sum y*u) per BatchNorm group."""
