@@ -638,11 +638,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ctl_conv d, const
     const int cot0 = blockIdx.z * NTW;
     const int group_n = d.n / (d.groups > 1 ? d.groups : 1);        // images per BatchNorm group (prologue coefficients)
 
-    f32x4 acc[TAPS][NTW];
+    // C4 (input with <= 4 channels): the 16 rows of an MFMA result hold (tap 4j + i/4, channel i%4) instead of 16 channels of one
+    // tap: 3 MFMA groups cover the 3x3 taps instead of 9; the partial layout [tap][ci][co] and the reduction are unchanged.
+    constexpr bool C4 = (MODE == CTL_IN_C4);
+    static_assert(!C4 || (KS == 3 && S == 1), "row-packed taps: 3x3 stride-1 only");
+    constexpr int NACC = C4 ? 3 : TAPS;
+    f32x4 acc[NACC][NTW];
 #pragma unroll
-    for (int a = 0; a < TAPS; ++a)
+    for (int a = 0; a < NACC; ++a)
 #pragma unroll
         for (int t = 0; t < NTW; ++t) acc[a][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int c4off[3];                   // C4: LDS float offset of this lane's (tap, channel) relative to the k-slot pixel, per MFMA group
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int tp = (4 * j + (p >> 2) < 9) ? 4 * j + (p >> 2) : 8;      // rows past tap 8 are computed on tap 8 and dropped
+        c4off[j] = ((tp / 3) * G::IWP + tp % 3) * 16 + (p & 3);
+    }
     float bsum[NTW];
 #pragma unroll
     for (int t = 0; t < NTW; ++t) bsum[t] = 0.f;
@@ -720,9 +731,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ctl_conv d, const
                     bsum[t] += bf[t];
                 }
 #pragma unroll
-                for (int tap = 0; tap < TAPS; ++tap) {
+                for (int tap = 0; tap < NACC; ++tap) {
                     const int kh = tap / KS, kw = tap % KS;
-                    const float af = xt[((tr * S + kh) * G::IWP + G::ldscol(pc * S + kw)) * 16 + p];
+                    const float af = C4 ? xt[(tr * G::IWP + pc) * 16 + c4off[tap]]
+                                        : xt[((tr * S + kh) * G::IWP + G::ldscol(pc * S + kw)) * 16 + p];
 #pragma unroll
                     for (int t = 0; t < NTW; ++t)
                         acc[tap][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf[t], acc[tap][t], 0, 0, 0);
@@ -749,15 +761,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ctl_conv d, const
     // barriers: a __syncthreads() here would drain the partial stores of the previous round (vmcnt(0)) 18 times per block.
     float* red = lds;
     constexpr int TAP_FLOATS = 4 * NTW * 256;
-    constexpr int TPR = (LDS_FLOATS / TAP_FLOATS) < TAPS ? (LDS_FLOATS / TAP_FLOATS) : TAPS;     // taps per round (>= 1)
+    constexpr int TPR = (LDS_FLOATS / TAP_FLOATS) < NACC ? (LDS_FLOATS / TAP_FLOATS) : NACC;     // taps per round (>= 1)
     const int64_t split_base = (int64_t)blockIdx.x * TAPS * cin_p * cout_p;
 #pragma unroll
-    for (int tap0 = 0; tap0 < TAPS; tap0 += TPR) {
+    for (int tap0 = 0; tap0 < NACC; tap0 += TPR) {
         if (tap0 > 0) ctl_barrier_lds_reads_done();     // the sums of the previous round were consumed by their stores
 #pragma unroll
         for (int tp = 0; tp < TPR; ++tp) {
             const int tap = tap0 + tp;
-            if (tap < TAPS) {
+            if (tap < NACC) {
 #pragma unroll
                 for (int t = 0; t < NTW; ++t) {
                     float* r0 = red + tp * TAP_FLOATS + ((wave * NTW + t) * 4) * 64 + lane;
@@ -769,7 +781,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ctl_conv d, const
 #pragma unroll
         for (int tp = 0; tp < TPR; ++tp) {
             const int tap = tap0 + tp;
-            if (tap < TAPS) {
+            if (tap < NACC) {
 #pragma unroll
                 for (int e0 = 0; e0 < NTW * 256; e0 += 256) {
                     const int e = e0 + tid;
@@ -777,9 +789,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ctl_conv d, const
                     float v = 0.f;
 #pragma unroll
                     for (int w = 0; w < 4; ++w) v += red[tp * TAP_FLOATS + ((w * NTW + t) * 4 + r) * 64 + l];
-                    const int ci = g * 16 + (l >> 4) * 4 + r;
                     const int co = (cot0 + t) * 16 + (l & 15);
-                    if (co < cout_p) w_partial[split_base + ((int64_t)tap * cin_p + ci) * cout_p + co] = v;
+                    if (C4) {      // result row 4*(l>>4) + r = (tap 4*group + (l>>4), channel r)
+                        const int wtap = 4 * tap + (l >> 4);
+                        if (wtap < TAPS && co < cout_p) w_partial[split_base + ((int64_t)wtap * cin_p + r) * cout_p + co] = v;
+                    } else {
+                        const int ci = g * 16 + (l >> 4) * 4 + r;
+                        if (co < cout_p) w_partial[split_base + ((int64_t)tap * cin_p + ci) * cout_p + co] = v;
+                    }
                 }
             }
         }
@@ -1251,6 +1268,7 @@ static int wgrad_dispatch(wgrad_call& a) {
     const int k = a.d->ks, s = a.d->stride, m = a.d->in_mode;
     if (k == 3 && s == 1 && m == CTL_IN_PLAIN) wgrad_go_tile<3, 1, CTL_IN_PLAIN>(a);
     else if (k == 3 && s == 1 && m == CTL_IN_UP2) wgrad_go_tile<3, 1, CTL_IN_UP2>(a);
+    else if (k == 3 && s == 1 && m == CTL_IN_C4) wgrad_go_tile<3, 1, CTL_IN_C4>(a);
     else if (k == 3 && s == 2) wgrad_go_tile<3, 2, CTL_IN_PLAIN>(a);
     else if (k == 1 && m == CTL_IN_PLAIN) wgrad_go_tile<1, 1, CTL_IN_PLAIN>(a);
     else if (k == 1 && m == CTL_IN_UP2) wgrad_go_tile<1, 1, CTL_IN_UP2>(a);

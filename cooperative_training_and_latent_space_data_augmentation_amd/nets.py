@@ -696,7 +696,8 @@ class CtlNet(nn.Module):
         pb.bn_backward(1, d_act, None, u, bn, co, slope, ds=None, dx=du, affine_grad=need_w and affine)
         k2 = ci.ks * ci.ks
         if need_w:
-            pb.wgrad(x, du, ci.ks, pro=x_pro, dw_ref=pb.G(ci.w_off), strides=(ci.cin * k2, k2, ci.ks, 1), dbias_ref=pb.G(ci.b_off))
+            pb.wgrad(x, du, ci.ks, pro=x_pro, in_mode=_ffi.IN_C4 if ci.wp_c4 >= 0 else 0, dw_ref=pb.G(ci.w_off),
+                     strides=(ci.cin * k2, k2, ci.ks, 1), dbias_ref=pb.G(ci.b_off))
         if not need_dx:
             return None
         if d_x is None:

@@ -149,6 +149,16 @@ def test_conv3x3_small_cin_k_packed_taps(n, cin, cout, h, w):
     close(y, ref, what="K-packed first-layer conv")
     part = st.cpu().double().view(-1, 2, cout).sum(0)
     assert float((part[0] - ref.double().sum((0, 2, 3))).abs().max()) <= 2e-4 * float(ref.double().sum((0, 2, 3)).abs().max()) + 1e-2
+    # weight gradient with (tap, channel) pairs packed into the MFMA rows
+    xg = x.clone().requires_grad_(True)
+    wg = wt.clone().requires_grad_(True)
+    dy = torch.randn(n, cout, h, w, generator=g)
+    F.conv2d(xg, wg, padding=1).backward(dy)
+    dw, db = torch.zeros(cout, cin, 3, 3, device=DEV), torch.zeros(cout, device=DEV)
+    dd = _ffi.conv_desc(n=n, hin=h, win=w, cin=cin, hout=h, wout=w, cout=cout, ks=3, in_mode=_ffi.IN_C4)
+    ops.conv_wgrad(dd, xin, dev(dy), dw, (cin * 9, 9, 3, 1), dbias=db)
+    close(dw, wg.grad, what="row-packed first-layer wgrad")
+    close(db, dy.sum((0, 2, 3)), what="first-layer bias grad")
 
 
 @pytest.mark.parametrize("n,c,cout,h,w,groups", [(2, 32, 16, 24, 20, 1), (16, 16, 16, 64, 64, 1), (4, 64, 32, 40, 36, 2), (32, 16, 16, 64, 64, 2)])
