@@ -58,3 +58,106 @@ def dice(result, reference) -> float:
     a, b = np.asarray(result).astype(bool), np.asarray(reference).astype(bool)
     den = int(a.sum()) + int(b.sum())
     return float("nan") if den == 0 else 2.0 * int((a & b).sum()) / den
+
+
+class runningMySegmentationScore(object):
+    """Patient-wise scores of 3-D predictions (metrics.py:139-291): one row per patient, one column per (foreground class, metric).
+
+    'Dice', 'VolError' and 'VolSim' are functions of three voxel counts per class (|pred|, |gt|, |pred & gt|); for device tensors
+    those come from the confusion-matrix kernel (one launch pair and one 2*n^2-word readback per patient instead of 2*(n-1)
+    full-volume host copies and masks).  The surface-distance metrics ('HD', 'ASD': scipy distance transforms on the host,
+    measure.py:102-330) are outside the accelerated path and are refused here."""
+    SUPPORTED = ("Dice", "VolError", "VolSim")
+
+    def __init__(self, n_classes, idx2cls_dict=None, metrics_list=("Dice",), foreground_only=False):
+        self.n_classes, self.metrics, self.foreground_only = n_classes, list(metrics_list), foreground_only
+        if idx2cls_dict is None:
+            idx2cls_dict = {1: "foreground"} if foreground_only else {c: str(c) for c in range(n_classes)}
+        self.idx2cls_dict = idx2cls_dict
+        self.multi_scores, self.tables, self.header = {}, [], ["patient_id"]
+        for c, name in idx2cls_dict.items():
+            if c > 0:
+                for m in self.metrics:
+                    if m not in self.SUPPORTED:
+                        raise NotImplementedError(f"metric {m!r}: only {self.SUPPORTED} are computed by this build")
+                    self.multi_scores[name + "_" + m] = []
+                    self.header.append(name + "_" + m)
+
+    def _counts(self, preds, gts):
+        """-> (pred_count[c], gt_count[c], intersection[c]) as the reference's per-class binarisation counts them
+        (metrics.py:205-223): a ground-truth label outside [0, n) belongs to no class, the predicted voxel under it still counts."""
+        import torch
+        n = self.n_classes
+        if torch.is_tensor(preds) and torch.is_tensor(gts) and preds.is_cuda and gts.is_cuda:
+            from . import ops
+            both = torch.stack([ops.confusion_hist(gts, preds, n), ops.confusion_hist(preds, preds, n)]).cpu().numpy()
+            h, hp = both[0], both[1]
+            if self.foreground_only and int(h.sum()) != gts.numel():
+                raise ValueError("foreground_only with labels outside [0, n_classes): pass host arrays")
+            pc, gc, ic = np.diag(hp).copy(), h.sum(axis=1), np.diag(h).copy()
+        else:
+            p, g = np.asarray(preds).reshape(-1).astype(np.int64), np.asarray(gts).reshape(-1).astype(np.int64)
+            if self.foreground_only:                       # gt > 0 / pred > 0 (any positive label is foreground upstream)
+                p, g = (p > 0).astype(np.int64), (g > 0).astype(np.int64)
+            pc = np.bincount(p[(p >= 0) & (p < n)], minlength=n)
+            gc = np.bincount(g[(g >= 0) & (g < n)], minlength=n)
+            same = p[(p == g) & (p >= 0) & (p < n)]
+            ic = np.bincount(same, minlength=n)
+            return pc, gc, ic
+        if self.foreground_only:                           # everything that is not background, on both sides
+            fg_i = h[1:, 1:].sum()
+            pc, gc, ic = np.array([0, pc[1:].sum()]), np.array([0, gc[1:].sum()]), np.array([0, fg_i])
+        return pc, gc, ic
+
+    def update(self, pid, preds, gts, voxel_spacing=None):
+        """preds / gts: integer volumes [n_slices, H, W] (numpy, or both torch tensors on the GPU); returns the patient's row."""
+        if tuple(preds.shape) != tuple(gts.shape):
+            raise AssertionError(f"pid :{pid} shape not consistent: pred {tuple(preds.shape)} vs gt {tuple(gts.shape)}")
+        if voxel_spacing is not None and len(voxel_spacing) != 3:
+            raise AssertionError(f"check voxel spacing, {voxel_spacing}")
+        pc, gc, ic = self._counts(preds, gts)
+        row = [str(pid)]
+        for c, name in self.idx2cls_dict.items():
+            if c == 0:
+                continue
+            v1, v2, inter = int(pc[c]), int(gc[c]), int(ic[c])
+            for m in self.metrics:
+                if m == "Dice":                            # medpy dc: ZeroDivisionError -> 0.0
+                    score = 2.0 * inter / float(v1 + v2) if v1 + v2 else 0.0
+                elif m == "VolError":                      # (pred - gt) / gt, numpy float division (inf / nan on an empty gt)
+                    with np.errstate(divide="ignore", invalid="ignore"):
+                        score = float(np.float64(v1 - v2) / np.float64(1.0 * v2))
+                else:                                      # VolSim, measure.py:668-722
+                    if v2 == 0:
+                        raise RuntimeError("The second supplied array does not contain any binary object.")
+                    score = float(1 - np.abs(v1 - v2) / np.abs(float(v2 + v1)))
+                self.multi_scores[name + "_" + m].append(score)
+                row.append(score)
+        self.tables.append(row)
+        return row
+
+    def get_scores(self, save_path=None):
+        """-> ({col_mean, col_std}, [[means as '%.3f'], [stds]], header); written as csv when save_path is given."""
+        summary, rows, header = {}, [[], []], []
+        for k, vals in self.multi_scores.items():
+            mean, std = np.mean(vals), np.std(vals)
+            summary[k + "_mean"], summary[k + "_std"] = mean, std
+            rows[0].append("{:.3f}".format(mean))
+            rows[1].append("{:.3f}".format(std))
+            header.append(k)
+        if save_path is not None:
+            import pandas as pd
+            pd.DataFrame(rows, columns=header).to_csv(save_path, index=False)
+        return summary, rows, header
+
+    def save_patient_wise_result_to_csv(self, save_path):
+        import pandas as pd
+        df = pd.DataFrame(self.tables, columns=self.header)
+        if save_path is not None:
+            df.to_csv(save_path, index=False)
+        return df
+
+    def reset(self):
+        for k in self.multi_scores:
+            self.multi_scores[k] = []
+        self.tables = []

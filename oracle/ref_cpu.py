@@ -581,6 +581,30 @@ def dice_from_confusion(confusion: np.ndarray) -> np.ndarray:
         return 2.0 * np.diag(h) / (h.sum(axis=1) + h.sum(axis=0))
 
 
+def patient_scores(preds: np.ndarray, gts: np.ndarray, classes, metrics=("Dice", "VolError", "VolSim"), foreground_only: bool = False):
+    """One patient's row of `runningMySegmentationScore.update` (medseg/common_utils/metrics.py:185-252), mask by mask as the
+    reference does it: per class c > 0 binarise both volumes, then Dice (medpy 0.4.0 `metric.binary.dc`: 2|A&B|/(|A|+|B|), 0.0 when
+    both are empty), VolError (pred - gt) / gt and VolSim 1 - |v1 - v2| / |v1 + v2| (measure.py:668-722)."""
+    row = []
+    for c in classes:
+        if c == 0:
+            continue
+        g = (gts > 0) if foreground_only else (gts == c)
+        p = (preds > 0) if foreground_only else (preds == c)
+        v1, v2, inter = int(np.count_nonzero(p)), int(np.count_nonzero(g)), int(np.count_nonzero(p & g))
+        for m in metrics:
+            if m == "Dice":
+                row.append(2.0 * inter / float(v1 + v2) if v1 + v2 else 0.0)
+            elif m == "VolError":
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    row.append(float(np.float64(v1 - v2) / np.float64(1.0 * v2)))
+            elif m == "VolSim":
+                row.append(float(1 - np.abs(v1 - v2) / np.abs(float(v2 + v1))))
+            else:
+                raise ValueError(m)
+    return row
+
+
 def synthetic_batch(n: int, h: int, w: int, num_classes: int = 4, seed: int = 0, structured: bool = False):
     """SURVEY 8d synthetic inputs: U[0,1) images, randint labels (or a concentric-ellipse phantom),
     0.05*N(0,1) input noise clamped to [0,1] (train...py:185-187)."""

@@ -465,3 +465,55 @@ def test_evaluate_with_device_targets_matches_host_path(golden_cases, golden_sd)
     sa, ia = a.running_metric.get_scores()
     sb, ib = b.running_metric.get_scores()
     assert sa == sb and all((ia[k] == ib[k]) or (np.isnan(ia[k]) and np.isnan(ib[k])) for k in ia)
+
+
+class _VolumeSet:
+    """The slice of the reference dataset interface the patient-wise tester reads (test_basic_segmentation_solver.py:68-72, 98)."""
+    formalized_label_dict = {0: "BG", 1: "LV", 2: "MYO", 3: "RV"}
+
+    def __init__(self, volumes):
+        self.volumes, self.patient_number, self._cur = volumes, len(volumes), None
+
+    def get_patient_data_for_testing(self, i, crop_size=None):
+        self._cur = i
+        return {"image": self.volumes[i][0], "label": self.volumes[i][1]}
+
+    def get_id(self):
+        return "patient%03d" % self._cur
+
+    def get_voxel_spacing(self):
+        return [1.25, 1.25, 10.0]
+
+
+def test_patient_wise_tester_volume_in_dice_out(golden_cases, golden_sd, tmp_path):
+    """SURVEY 8(f) row 1 end to end: chunked predict + device arg-max + device voxel counts give the rows the reference's
+    mask-by-mask bookkeeping gives on the same label maps (exactly), and those label maps are the reference's own away from ties."""
+    from cooperative_training_and_latent_space_data_augmentation_amd.tester import TestSegmentationNetwork
+    F_ = golden_cases["F_predict"]
+    s = _solver(golden_sd)
+    s.train()
+    with torch.no_grad():
+        for i in range(3):
+            c_, l_, n_ = O.synthetic_batch(2, 64, 64, seed=10 + i, structured=True)
+            s.standard_training(dev(c_), dev(l_), dev(n_))
+    s.n_iter = 2                                                            # FTN + STN refinement (model.py:375-394)
+    vol, lab = F_["vol"], F_["vlab"]
+    data = _VolumeSet([(vol, lab), (torch.cat([vol, vol.flip(0)], 0), torch.cat([lab, lab.flip(0)], 0))])
+    t = TestSegmentationNetwork(data, crop_size=None, segmentation_model=s, save_path=str(tmp_path), metrics_list=["Dice", "VolError"])
+    pack = data.get_patient_data_for_testing(0)
+    pid, res = t.evaluate(0, pack, 2, maximum_batch_size=2)                 # chunks of 2 + 1 slices
+    top2 = F_["logits_n2"].topk(2, dim=1)[0]
+    safe = ((top2[:, 0] - top2[:, 1]) > 1e-3).numpy()
+    assert pid == "patient000" and np.array_equal(res["pred"][safe], F_["argmax_n2"].numpy()[safe])
+    assert np.abs(res["soft_pred"] - F_["logits_n2"].numpy()).max() < 2e-4
+    row = t.segmentation_metric.tables[0]
+    assert row[1:] == O.patient_scores(res["pred"], lab.numpy(), data.formalized_label_dict.keys(), metrics=("Dice", "VolError"))
+    ref = O.patient_scores(F_["argmax_n2"].numpy(), lab.numpy(), data.formalized_label_dict.keys(), metrics=("Dice", "VolError"))
+    assert max(abs(a - b) for a, b in zip(row[1:], ref)) < 1e-3
+    t.segmentation_metric.reset()
+    df = t.run()
+    assert list(df.columns) == ["patient_id", "LV_Dice", "LV_VolError", "MYO_Dice", "MYO_VolError", "RV_Dice", "RV_VolError"]
+    assert list(df["patient_id"]) == ["patient000", "patient001"] and (tmp_path / "result.csv").exists() and (tmp_path / "details.csv").exists()
+    # a volume and the same volume followed by its mirror in the slice order have the same per-class counts ratio -> the same Dice
+    assert np.allclose(df.iloc[0, 1::2].to_numpy(float), df.iloc[1, 1::2].to_numpy(float), atol=1e-12)
+    assert t.get_top_k_results(1, "MYO_Dice").shape[0] == 1

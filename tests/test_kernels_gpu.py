@@ -559,3 +559,23 @@ def test_basic_operations_module_matches_upstream_return_convention():
     assert torch.equal(B.rescale_intensity(r["x"].to(DEV)).cpu(), r["y"])
     n = io["noise_clamp"][0]
     assert torch.equal(B.add_input_noise(n["clean"].to(DEV), noise=n["noise"].to(DEV)).cpu(), n["out"])
+
+
+def test_patient_wise_scores_device_path_vs_reference():
+    """runningMySegmentationScore with device tensors (voxel counts from the confusion-matrix kernel) == the reference's rows."""
+    from cooperative_training_and_latent_space_data_augmentation_amd.metrics import runningMySegmentationScore
+    for r in _io_cases()["patient_scores"]:
+        ms = runningMySegmentationScore(4, idx2cls_dict=None if r["foreground_only"] else r["idx2cls"],
+                                        metrics_list=["Dice", "VolError", "VolSim"], foreground_only=r["foreground_only"])
+        for k, ((pr, gt), row) in enumerate(zip(r["volumes"], r["rows"])):
+            assert ms.update("p%d" % k, pr.cuda(), gt.cuda()) == row
+        assert ms.get_scores()[0] == r["summary"]
+    # a ground-truth label outside [0, n): belongs to no class, the prediction under it still counts (metrics.py:205-223)
+    rng = np.random.RandomState(3)
+    gt = rng.randint(-1, 6, (4, 16, 16)).astype(np.int64)
+    pr = rng.randint(0, 4, gt.shape).astype(np.uint8)
+    ms = runningMySegmentationScore(4, metrics_list=["Dice", "VolError"])
+    from oracle import ref_cpu as O_
+    assert ms.update("x", torch.from_numpy(pr).cuda(), torch.from_numpy(gt).cuda())[1:] == O_.patient_scores(pr, gt, range(4), ("Dice", "VolError"))
+    with pytest.raises(ValueError):
+        runningMySegmentationScore(4, foreground_only=True).update("x", torch.from_numpy(pr).cuda(), torch.from_numpy(gt).cuda())

@@ -207,3 +207,29 @@ def test_input_pipeline_and_metrics_restatements_vs_reference(io_cases):
     for c in range(4):
         ref = O.dice((lp.numpy() == c) & keep.numpy(), (lt.numpy() == c))
         assert (np.isnan(d[c]) and np.isnan(ref)) or abs(d[c] - ref) < 1e-15
+
+
+def test_patient_wise_scores_vs_reference(io_cases, tmp_path):
+    """runningMySegmentationScore (metrics.py:139-291): the oracle's mask-by-mask row and the product's host path (counts from
+    bincounts) both reproduce the reference's rows, summary and csv headers exactly."""
+    import numpy as np
+    from cooperative_training_and_latent_space_data_augmentation_amd.metrics import runningMySegmentationScore
+    for r in io_cases["patient_scores"]:
+        ms = runningMySegmentationScore(4, idx2cls_dict=None if r["foreground_only"] else r["idx2cls"],
+                                        metrics_list=["Dice", "VolError", "VolSim"], foreground_only=r["foreground_only"])
+        assert ms.header == r["table_header"]
+        for k, ((pr, gt), row) in enumerate(zip(r["volumes"], r["rows"])):
+            assert O.patient_scores(pr.numpy(), gt.numpy(), r["idx2cls"].keys(), foreground_only=r["foreground_only"]) == row[1:]
+            got = ms.update("p%d" % k, pr.numpy(), gt.numpy(), voxel_spacing=[1.25, 1.25, 10.0])
+            assert got == row
+        summary, summary_list, header = ms.get_scores(save_path=str(tmp_path / "summary.csv"))
+        assert header == r["header"] and summary_list == r["summary_list"]
+        assert summary == r["summary"]
+        df = ms.save_patient_wise_result_to_csv(str(tmp_path / "details.csv"))
+        assert list(df.columns) == r["table_header"] and len(df) == 3
+        ms.reset()
+        assert ms.tables == [] and all(v == [] for v in ms.multi_scores.values())
+    with pytest.raises(NotImplementedError):
+        runningMySegmentationScore(4, metrics_list=["HD"])
+    empty = runningMySegmentationScore(3, metrics_list=["Dice"])          # both masks empty: medpy's dc gives 0.0
+    assert empty.update("e", np.zeros((2, 4, 4), np.uint8), np.zeros((2, 4, 4), np.int64)) == ["e", 0.0, 0.0]

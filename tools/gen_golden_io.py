@@ -15,7 +15,13 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 from medseg.common_utils.basic_operations import crop_or_pad, rescale_intensity  # noqa: E402
-from medseg.common_utils.metrics import runningScore  # noqa: E402
+import medseg.common_utils.metrics as ref_metrics  # noqa: E402
+from medseg.common_utils.measure import dc as ref_dc  # noqa: E402
+from medseg.common_utils.metrics import runningMySegmentationScore, runningScore  # noqa: E402
+
+# metrics.py:5 takes `dc` from medpy 0.4.0 (absent here); measure.py:52-99 is the reference's own copy of that function and differs
+# from it only when both masks are empty (NaN instead of medpy's 0.0) -- the cases below keep every class non-empty somewhere.
+ref_metrics.dc = ref_dc
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "tests", "golden", "io_cases.pt")
@@ -24,7 +30,7 @@ OUT = os.path.join(ROOT, "tests", "golden", "io_cases.pt")
 def main():
     g = torch.Generator().manual_seed(7)
     rng = np.random.RandomState(7)
-    cases = {"rescale": [], "crop_or_pad": [], "running_score": [], "noise_clamp": []}
+    cases = {"rescale": [], "crop_or_pad": [], "running_score": [], "noise_clamp": [], "patient_scores": []}
     # rescale_intensity (basic_operations.py:232-245): N*C*H*W, per (n, c) plane; includes a constant plane (max == min)
     for shape, lo, hi in [((3, 1, 17, 23), 0.0, 1.0), ((2, 2, 32, 32), -1.0, 2.5), ((16, 1, 64, 64), 0.0, 1.0)]:
         x = torch.randn(shape, generator=g) * 3.0 + 1.0
@@ -53,6 +59,21 @@ def main():
     clean = torch.rand(4, 1, 32, 32, generator=g)
     noise = 0.05 * torch.randn(4, 1, 32, 32, generator=g)
     cases["noise_clamp"].append({"clean": clean, "noise": noise, "out": torch.clamp(clean + noise, 0, 1)})
+    # patient-wise 3-D scores (metrics.py:139-291): three volumes, per-class and foreground-only bookkeeping
+    for fg in (False, True):
+        ms = runningMySegmentationScore(n_classes=4, idx2cls_dict=None if fg else {0: "BG", 1: "LV", 2: "MYO", 3: "RV"},
+                                        metrics_list=["Dice", "VolError", "VolSim"], foreground_only=fg)
+        vols, rows = [], []
+        for k in range(3):
+            gt = rng.randint(0, 4, (5 + k, 24, 20)).astype(np.int64)
+            pr = np.where(rng.rand(*gt.shape) < 0.7, gt, rng.randint(0, 4, gt.shape)).astype(np.uint8)
+            rows.append(ms.update(pid="p%d" % k, preds=pr.copy(), gts=gt.copy(), voxel_spacing=[1.25, 1.25, 10.0]))
+            vols.append((torch.from_numpy(pr), torch.from_numpy(gt)))
+        summary, summary_list, header = ms.get_scores()
+        cases["patient_scores"].append({"foreground_only": fg, "idx2cls": ms.idx2cls_dict, "volumes": vols,
+                                        "rows": [[r[0]] + [float(v) for v in r[1:]] for r in rows],
+                                        "summary": {k: float(v) for k, v in summary.items()}, "summary_list": summary_list,
+                                        "header": header, "table_header": ms.header})
     torch.save(cases, OUT)
     print("wrote", OUT, os.path.getsize(OUT), "bytes")
 
