@@ -39,6 +39,8 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // Byte offset that is out of range for every tensor (all are < 2 GiB, checked on the host): a buffer load from it returns 0
 // and a buffer store to it is dropped by the hardware bounds check -> zero padding / ragged edges cost no branch and no select.
 #define CTL_OOB ((int)0x80000000)
+// prologue coefficients (BatchNorm scale / shift per [group][cin]) are copied to LDS once per block: groups * cin <= CTL_PRO_MAX
+#define CTL_PRO_MAX 256
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t ctl_rsrc(const void* p, int64_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
@@ -157,9 +159,11 @@ struct XStage {
         }
     }
 
-    // `goff` = BatchNorm group of the tile held in v[] times cin (row of the [groups][cin] prologue coefficients)
+    // `goff` = BatchNorm group of the tile held in v[] times cin (row of the [groups][cin] prologue coefficients).  The
+    // coefficients are read from the block's LDS copy: a global load here sits between the two barriers of a step with nothing
+    // to hide its latency behind
     __device__ __forceinline__ void store(float* __restrict__ xt, const ctl_conv& d, int g,
-                                          const float* __restrict__ pro_scale, const float* __restrict__ pro_shift, int goff) {
+                                          const float* pro_scale, const float* pro_shift, int goff) {
         if (!d.pro_affine) {      // out-of-range units were loaded as hardware zeros: nothing to compute
 #pragma unroll
             for (int i = 0; i < NU; ++i) *reinterpret_cast<f32x4*>(xt + lds[i]) = v[i];
@@ -278,9 +282,11 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : ((MT * NT >= 4
     constexpr int RED_FLOATS = 4 * NT * 16 * 2;
     constexpr int WT_FLOATS = NFRAG * NT * 256;
     constexpr int XT_ALLOC = G::XT_FLOATS;
-    __shared__ __attribute__((aligned(16))) float xt[XT_ALLOC + WT_FLOATS + RED_FLOATS];
+    __shared__ __attribute__((aligned(16))) float xt[XT_ALLOC + WT_FLOATS + RED_FLOATS + 2 * CTL_PRO_MAX];
     float* wt = xt + XT_ALLOC;
     float* sred = wt + WT_FLOATS;        // statistics reduction scratch (a flush can happen while xt holds the next tile)
+    float* cf_scale = sred + RED_FLOATS; // prologue coefficients [groups][cin]
+    float* cf_shift = cf_scale + CTL_PRO_MAX;
     constexpr int WU = NFRAG * NT * 64, NW = (WU + 255) / 256;
 
     const int tid = threadIdx.x;
@@ -334,6 +340,9 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : ((MT * NT >= 4
             else b.x = bias[0];
         }
         bias4[t] = b;
+        // pin the load's completion here: left to itself the wait-count pass puts an s_waitcnt vmcnt(0) in front of the first
+        // read of bias4 INSIDE the tile loop (the accumulator init), right behind the next tile's prefetch loads
+        asm volatile("" ::"v"(bias4[t]));
     }
     // LDS operand addresses: one per-thread base; (M-tile, tap) offsets are compile-time immediates of the ds_read
     const float* xrd = xt + ((wrow * S) * G::IWP + p) * 16 + q * 4;
@@ -383,7 +392,13 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : ((MT * NT >= 4
     if (total_it > 0) {
         xs.load(rx, d, cur.n, cur.th * G::TH, cur.tw * TW, 0);
         wload(0);
-        xs.store(xt, d, 0, pro_scale, pro_shift, (cur.n / group_n) * d.cin);
+    }
+    if (d.pro_affine) {      // behind the first tile's loads, in front of their use
+        for (int i = tid; i < ngroups * d.cin; i += 256) { cf_scale[i] = pro_scale[i]; cf_shift[i] = pro_shift[i]; }
+        __syncthreads();
+    }
+    if (total_it > 0) {
+        xs.store(xt, d, 0, cf_scale, cf_shift, (cur.n / group_n) * d.cin);
         wstore();
     }
     __syncthreads();
@@ -442,7 +457,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : ((MT * NT >= 4
             if (new_w) wload(g2);
         }
         TM(0)
-        if (g == 0) {
+        if (g == 0) {        // (taking the bias as the C operand of each accumulator's first MFMA instead costs 25-55 VGPRs)
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -491,7 +506,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : ((MT * NT >= 4
         ctl_barrier_lds_reads_done();    // every wave is done reading this step's LDS images
         TM(2)
         if (has_next) {    // refill LDS from the prefetched registers
-            xs.store(xt, d, g2, pro_scale, pro_shift, (nxt.n / group_n) * d.cin);   // v[] holds chunk g2 of tile nxt (== cur unless g2 == 0)
+            xs.store(xt, d, g2, cf_scale, cf_shift, (nxt.n / group_n) * d.cin);   // v[] holds chunk g2 of tile nxt (== cur unless g2 == 0)
             if (new_w) wstore();
         }
         TM(3)
@@ -517,6 +532,28 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : ((MT * NT >= 4
 #endif
             auto epilogue = [&](auto full_tag) {
                 constexpr bool FULL = decltype(full_tag)::value;
+#ifndef CTL_NO_FAST_EPI
+                if constexpr (!EPI && FULL) {
+                    // the common case (whole tile, no residual / accumulate operand, no activation): the stores read the accumulator
+                    // registers directly and the statistics sit behind a real branch.  Written as its own path because the generic
+                    // code below funnels every variant through one set of store registers (4 v_mov per fragment) and turns the
+                    // statistics flag into 8 v_cndmask per tile -- VALU issue slots taken from the matrix pipe.
+                    if (d.epi_act == CTL_ACT_NONE) {
+                        if (flags & CTL_EPI_STATS) {
+                            asm volatile("" ::: "memory");                  // keeps the branch (not a select)
+#pragma unroll
+                            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                                for (int m = 0; m < MT; ++m) { ssum[t] += acc[m][t]; ssq[t] += acc[m][t] * acc[m][t]; }
+                        }
+#pragma unroll
+                        for (int t = 0; t < NT; ++t)
+#pragma unroll
+                            for (int m = 0; m < MT; ++m) ctl_bstore4(ry, ybase + yrel[m] + t * 64, acc[m][t]);
+                        return;
+                    }
+                }
+#endif
                 bool pv[MT];
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
@@ -626,9 +663,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ctl_conv d, const
     constexpr int DYT_FLOATS = NTW * G::TP * 16;
     constexpr int RED_FLOATS = 4 * NTW * 256;
     constexpr int LDS_FLOATS = (G::XT_FLOATS + DYT_FLOATS > RED_FLOATS) ? (G::XT_FLOATS + DYT_FLOATS) : RED_FLOATS;
-    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS + 2 * CTL_PRO_MAX];
     float* xt = lds;
     float* dyt = lds + G::XT_FLOATS;
+    float* cf_scale = lds + LDS_FLOATS;  // prologue coefficients [groups][cin], see XStage::store
+    float* cf_shift = cf_scale + CTL_PRO_MAX;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -703,7 +742,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ctl_conv d, const
     if ((int)blockIdx.x < ntiles) {
         xs.load(rx, d, cur.n, cur.th * G::TH, cur.tw * TW, g);
         dyload(cur.n, cur.th * G::TH, cur.tw * TW);
-        xs.store(xt, d, g, pro_scale, pro_shift, (cur.n / group_n) * d.cin);
+    }
+    if (d.pro_affine) {
+        for (int i = tid; i < (d.groups > 1 ? d.groups : 1) * d.cin; i += 256) { cf_scale[i] = pro_scale[i]; cf_shift[i] = pro_shift[i]; }
+        __syncthreads();
+    }
+    if ((int)blockIdx.x < ntiles) {
+        xs.store(xt, d, g, cf_scale, cf_shift, (cur.n / group_n) * d.cin);
         dystore();
     }
     __syncthreads();
@@ -745,7 +790,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ctl_conv d, const
         ctl_barrier_lds_reads_done();
         TM(2)
         if (has_next) {
-            xs.store(xt, d, g, pro_scale, pro_shift, (cur.n / group_n) * d.cin);
+            xs.store(xt, d, g, cf_scale, cf_shift, (cur.n / group_n) * d.cin);
             dystore();
         }
         TM(3)
@@ -1197,6 +1242,7 @@ extern "C" int ctl_conv_forward(const ctl_conv* d, const float* x, const float* 
                                                     !(d->epi_flags & (CTL_EPI_RES | CTL_EPI_ACCUM | CTL_EPI_BIAS)) && d->epi_act == CTL_ACT_NONE),
                 "conv_forward: CTL_EPI_BNBWD needs CTL_EPI_STATS + res (= u) + res_scale/res_shift (BatchNorm coefficients) and nothing else");
     CTL_REQUIRE(!d->pro_affine || (pro_scale && pro_shift), "conv_forward: prologue without scale/shift");
+    CTL_REQUIRE(!d->pro_affine || (d->groups > 1 ? d->groups : 1) * d->cin <= CTL_PRO_MAX, "conv_forward: groups * cin = %d prologue coefficients exceed %d", (d->groups > 1 ? d->groups : 1) * d->cin, CTL_PRO_MAX);
     CTL_REQUIRE(!d->pro_affine || (d->pro_slope >= 0.f && d->pro_slope <= 1.f), "conv_forward: prologue slope must be in [0, 1]");
     CTL_REQUIRE(d->epi_act != CTL_ACT_LEAKY || (d->epi_slope >= 0.f && d->epi_slope <= 1.f), "conv_forward: LeakyReLU slope must be in [0, 1]");
     CTL_REQUIRE(d->n > 0 && d->hout > 0 && d->wout > 0, "conv_forward: empty problem");
@@ -1310,6 +1356,7 @@ extern "C" int ctl_conv_wgrad(const ctl_conv* d, const float* x, const float* pr
                               const float* dy, float* w_partial, float* b_partial, ctl_stream stream) {
     CTL_REQUIRE(d && x && dy && w_partial, "conv_wgrad: null argument");
     CTL_REQUIRE(!d->pro_affine || (pro_scale && pro_shift), "conv_wgrad: prologue without scale/shift");
+    CTL_REQUIRE(!d->pro_affine || (d->groups > 1 ? d->groups : 1) * d->cin <= CTL_PRO_MAX, "conv_wgrad: groups * cin = %d prologue coefficients exceed %d", (d->groups > 1 ? d->groups : 1) * d->cin, CTL_PRO_MAX);
     CTL_REQUIRE(!d->pro_affine || (d->pro_slope >= 0.f && d->pro_slope <= 1.f), "conv_wgrad: prologue slope must be in [0, 1]");
     CTL_REQUIRE((int64_t)d->n * d->hin * d->win * d->cin * 4 < (1ll << 31) &&
                 (int64_t)d->n * d->hout * d->wout * d->cout * 4 < (1ll << 31),
