@@ -901,8 +901,44 @@ class Dual_Branch_Encoder(MyEncoder):
         from .autograd import net_apply
         return net_apply(self, x)
 
+    def _compile_filter(self, n, h, w, mode) -> Plan:
+        """code_decoupler alone (encoder_decoder.py:496-498): z_i [n, h, w, C] in the input slot -> z_s."""
+        pb = PlanBuilder(self)
+        C, B = self._convs, self._bns
+        train = mode != "C"
+        d0, d3 = C["code_decoupler.0"], C["code_decoupler.3"]
+        z_i, z_s = T((S_X, 0), n, h, w, d0.cin), T((S_OUT0, 0), n, h, w, d3.cout)
+        ud, st, blk = pb.conv(z_i, self._wp_ref(d0.wp_fwd), d0.cout, 3, bias_ref=pb.P(d0.b_off), stats=train)
+        cod0 = pb.bn_forward(B["code_decoupler.1"], st, blk, ud.n * ud.h * ud.w, mode)
+        vd, st, blk = pb.conv(ud, self._wp_ref(d3.wp_fwd), d3.cout, 3, pro=(cod0["scale"], cod0["shift"], SLOPE),
+                              bias_ref=pb.P(d3.b_off), stats=train)
+        cod1 = pb.bn_forward(B["code_decoupler.4"], st, blk, vd.n * vd.h * vd.w, mode)
+        pb.bn_act(vd, cod1, 0.0, z_s)
+        return pb.finish({}, [(n, h, w, d3.cout)])
+
     def filter_code(self, z):
-        raise NotImplementedError("filter_code(z) alone is off the training hot path (SURVEY 8f rank 4)")
+        """z_s = code_decoupler(z_i) on its own, in the network's current BatchNorm mode.  Forward only: upstream never calls it
+        outside `forward` (advanced_triplet_recon_segmentation_model.py:208-221 is its one, unused, caller), so no backward plan
+        exists for it; a `z` that requires grad is refused instead of silently cutting the graph."""
+        from . import ops
+        ops.require_gpu(z)
+        if torch.is_grad_enabled() and z.requires_grad:
+            raise _ffi.CtlError("filter_code: forward-only entry (call the encoder's forward for a differentiable z_s)")
+        z = ops.as_nhwc(z.detach().float())
+        n, c, h, w = z.shape
+        d0 = self._convs["code_decoupler.0"]
+        if c != d0.cin:
+            raise ValueError(f"filter_code: expected {d0.cin} channels, got {c}")
+        mode = self.bn_mode()
+        key = ("filter", n, h, w, mode)
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = self._plans[key] = self._compile_filter(n, h, w, mode)
+        self.ensure_packed()
+        act = torch.empty(max(plan.act_bytes, 256), dtype=torch.uint8, device=self.device)
+        out = self._alloc_out(plan.out_shapes[0])
+        self._run(plan, {S_X: z, S_P: self._flat_data, S_B: self._bflat, S_NBT: self._nbt, S_WP: self._wp, S_ACT: act, S_OUT0: out})
+        return out
 
 
 # ================================================================================================ decoder

@@ -279,6 +279,25 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
         self.latent_code["shape"] = code[n:]
         return out[:n], out[n:]
 
+    def decode_segmentation_from_image_code(self, latent_code_i, disable_track_bn_stats=False):
+        """FTN: z_i -> z_s -> segmentation (model.py:208-221).  Forward only (`Dual_Branch_Encoder.filter_code`)."""
+        enc, dec = self.model["image_encoder"], self.model["segmentation_decoder"]
+        if disable_track_bn_stats:
+            with _disable_tracking_bn_stats(enc):
+                z_s = enc.filter_code(latent_code_i)
+            with _disable_tracking_bn_stats(dec):
+                return dec(z_s)
+        return dec(enc.filter_code(latent_code_i))
+
+    def predict_w_reconstructed_image(self, image):
+        """model.py:603-606: segment the FTN's own reconstruction of the image."""
+        return self.fast_predict(self.recon_image(image))[1]
+
+    def requires_grad_(self, requires_grad=True):
+        for module in self.model.values():
+            for p in module.parameters():
+                p.requires_grad = requires_grad
+
     def recon_image(self, image, disable_track_bn_stats=False):
         z_i, _ = self.encode_image(image, disable_track_bn_stats)
         return self.decode_image(z_i, disable_track_bn_stats)

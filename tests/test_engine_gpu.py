@@ -8,7 +8,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from oracle import ref_cpu as O  # noqa: E402
-from cooperative_training_and_latent_space_data_augmentation_amd import nets, ops  # noqa: E402
+from cooperative_training_and_latent_space_data_augmentation_amd import _ffi, nets, ops  # noqa: E402
 from cooperative_training_and_latent_space_data_augmentation_amd.model_util import _disable_tracking_bn_stats  # noqa: E402
 from cooperative_training_and_latent_space_data_augmentation_amd.solver import AdvancedTripletReconSegmentationModel  # noqa: E402
 
@@ -517,3 +517,33 @@ def test_patient_wise_tester_volume_in_dice_out(golden_cases, golden_sd, tmp_pat
     # a volume and the same volume followed by its mirror in the slice order have the same per-class counts ratio -> the same Dice
     assert np.allclose(df.iloc[0, 1::2].to_numpy(float), df.iloc[1, 1::2].to_numpy(float), atol=1e-12)
     assert t.get_top_k_results(1, "MYO_Dice").shape[0] == 1
+
+
+def test_filter_code_and_remaining_solver_entries(golden_cases, golden_sd):
+    """`Dual_Branch_Encoder.filter_code` (encoder_decoder.py:496-498) and the solver entries built on it
+    (model.py:208-221, 292-295, 603-606): same numbers as the full forward / the oracle, forward only."""
+    onet, hnet = make_pair("image_encoder", golden_sd)
+    x = torch.rand(2, 1, 64, 48, generator=torch.Generator().manual_seed(3))
+    with torch.no_grad():
+        for mode in ("train", "eval"):          # train: batch statistics, running statistics move once per call on both sides
+            if mode == "eval":
+                onet.eval(); hnet.eval()
+            z_i, z_s = hnet(dev(x))
+            f = hnet.filter_code(z_i)
+            assert torch.equal(f, z_s)          # same kernels on the same z_i: bitwise
+            close(f, onet.filter_code(onet(x)[0]), what=f"filter_code ({mode} mode)")
+    with pytest.raises(_ffi.CtlError):
+        hnet.filter_code(z_i.clone().requires_grad_(True))
+    with pytest.raises(ValueError):
+        hnet.filter_code(torch.zeros(1, 16, 4, 4, device=DEV))
+    s = _solver(golden_sd)
+    s.eval()
+    vol = dev(golden_cases["F_predict"]["vol"])
+    with torch.no_grad():
+        (z_i, z_s), pred = s.fast_predict(vol)
+        assert torch.equal(s.decode_segmentation_from_image_code(z_i), pred)
+        assert torch.equal(s.predict_w_reconstructed_image(vol), s.fast_predict(s.recon_image(vol))[1])
+    s.requires_grad_(False)
+    assert not any(p.requires_grad for m in s.model.values() for p in m.parameters())
+    s.requires_grad_(True)
+    assert all(p.requires_grad for m in s.model.values() for p in m.parameters())
