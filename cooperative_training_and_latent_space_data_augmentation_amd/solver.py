@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .autograd import cross_entropy_2D, net_apply, scaled_mse, softmax_t
+from .autograd import cross_entropy_2D, net_apply, scaled_mse, softmax_t, split_halves
 from .metrics import runningScore
 from .model_util import (_disable_tracking_bn_stats, _draw_seed, mask_latent_code_channel_wise,
                          mask_latent_code_spatial_wise, set_grad)
@@ -277,7 +277,7 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
             code = net_apply(enc, inp, groups=2)[0]
             out = net_apply(dec, code, groups=2)[0]
         self.latent_code["shape"] = code[n:]
-        return out[:n], out[n:]
+        return split_halves(out)
 
     def decode_segmentation_from_image_code(self, latent_code_i, disable_track_bn_stats=False):
         """FTN: z_i -> z_s -> segmentation (model.py:208-221).  Forward only (`Dual_Branch_Encoder.filter_code`)."""
