@@ -260,26 +260,66 @@ __global__ __launch_bounds__(EB) void sigmoid_bwd_kernel(const float* __restrict
 
 // ------------------------------------------------------------------------------------------------ STN input builders
 #define MAXC 16
-__global__ __launch_bounds__(EB) void softmax_t_fwd_kernel(const float* __restrict__ x, float inv_t, float* __restrict__ p,
-                                                            int64_t pixels, int c) {
-    const int64_t stride = (int64_t)gridDim.x * EB;
-    for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < pixels; i += stride) {
-        float v[MAXC];
-        float m = -INFINITY;
-        for (int k = 0; k < c; ++k) { v[k] = x[i * c + k] * inv_t; m = fmaxf(m, v[k]); }
-        float s = 0.f;
-        for (int k = 0; k < c; ++k) { v[k] = expf(v[k] - m); s += v[k]; }
-        const float r = 1.f / s;
-        for (int k = 0; k < c; ++k) p[i * c + k] = v[k] * r;
+// Per-pixel channel rows of the label-space tensors.  CT = 4 (the 4-class maps of the path): one 16-byte load / store per pixel
+// and fully unrolled loops; CT = 0: runtime channel count.  The arithmetic and its order are the same in both.
+template <int CT> __device__ __forceinline__ void row_load(const float* __restrict__ base, int64_t i, int c, float* v) {
+    if (CT == 4) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(base + i * 4);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else {
+        for (int k = 0; k < c; ++k) v[k] = base[i * c + k];
     }
 }
-__global__ __launch_bounds__(EB) void softmax_t_bwd_kernel(const float* __restrict__ p, const float* __restrict__ dp,
-                                                            float inv_t, float* __restrict__ dx, int64_t pixels, int c) {
+template <int CT> __device__ __forceinline__ void row_store(float* __restrict__ base, int64_t i, int c, const float* v) {
+    if (CT == 4) {
+        *reinterpret_cast<f32x4*>(base + i * 4) = f32x4{v[0], v[1], v[2], v[3]};
+    } else {
+        for (int k = 0; k < c; ++k) base[i * c + k] = v[k];
+    }
+}
+#define CTL_ROW_DISPATCH(kernel, vec4, grid, ...)                                \
+    do {                                                                         \
+        if (vec4) kernel<4><<<grid, dim3(EB), 0, S_>>>(__VA_ARGS__);             \
+        else kernel<0><<<grid, dim3(EB), 0, S_>>>(__VA_ARGS__);                  \
+    } while (0)
+static inline bool rows_vec4(int c, const void* a, const void* b = nullptr, const void* d = nullptr) {
+    return c == 4 && (((uintptr_t)a | (uintptr_t)b | (uintptr_t)d) & 15) == 0;      // 16-byte rows need 16-byte aligned tensors
+}
+template <int CT>
+__global__ __launch_bounds__(EB) void softmax_t_fwd_kernel(const float* __restrict__ x, float inv_t, float* __restrict__ p,
+                                                            int64_t pixels, int c_rt) {
+    const int c = CT ? CT : c_rt;
     const int64_t stride = (int64_t)gridDim.x * EB;
     for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < pixels; i += stride) {
+        float v[CT ? CT : MAXC];
+        row_load<CT>(x, i, c, v);
+        float m = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < c; ++k) { v[k] = v[k] * inv_t; m = fmaxf(m, v[k]); }
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < c; ++k) { v[k] = expf(v[k] - m); s += v[k]; }
+        const float r = 1.f / s;
+#pragma unroll
+        for (int k = 0; k < c; ++k) v[k] = v[k] * r;
+        row_store<CT>(p, i, c, v);
+    }
+}
+template <int CT>
+__global__ __launch_bounds__(EB) void softmax_t_bwd_kernel(const float* __restrict__ p, const float* __restrict__ dp,
+                                                            float inv_t, float* __restrict__ dx, int64_t pixels, int c_rt) {
+    const int c = CT ? CT : c_rt;
+    const int64_t stride = (int64_t)gridDim.x * EB;
+    for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < pixels; i += stride) {
+        float pv[CT ? CT : MAXC], dv[CT ? CT : MAXC];
+        row_load<CT>(p, i, c, pv);
+        row_load<CT>(dp, i, c, dv);
         float dot = 0.f;
-        for (int k = 0; k < c; ++k) dot += p[i * c + k] * dp[i * c + k];
-        for (int k = 0; k < c; ++k) dx[i * c + k] = p[i * c + k] * (dp[i * c + k] - dot) * inv_t;
+#pragma unroll
+        for (int k = 0; k < c; ++k) dot += pv[k] * dv[k];
+#pragma unroll
+        for (int k = 0; k < c; ++k) dv[k] = pv[k] * (dv[k] - dot) * inv_t;
+        row_store<CT>(dx, i, c, dv);
     }
 }
 __global__ __launch_bounds__(EB) void onehot_kernel(const int64_t* __restrict__ label, float* __restrict__ y,
@@ -292,20 +332,26 @@ __global__ __launch_bounds__(EB) void onehot_kernel(const int64_t* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------ losses
+template <int CT>
 __global__ __launch_bounds__(EB) void ce2d_partial_kernel(const float* __restrict__ logit,
-                                                           const int64_t* __restrict__ label, int64_t pixels, int c,
+                                                           const int64_t* __restrict__ label, int64_t pixels, int c_rt,
                                                            double* __restrict__ partial) {
     __shared__ double sm[8];
+    const int c = CT ? CT : c_rt;
     const int64_t stride = (int64_t)gridDim.x * EB;
     double acc = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < pixels; i += stride) {
-        float v[MAXC];
+        float v[CT ? CT : MAXC];
+        row_load<CT>(logit, i, c, v);
         float m = -INFINITY;
-        for (int k = 0; k < c; ++k) { v[k] = logit[i * c + k]; m = fmaxf(m, v[k]); }
+#pragma unroll
+        for (int k = 0; k < c; ++k) m = fmaxf(m, v[k]);
         float s = 0.f;
+#pragma unroll
         for (int k = 0; k < c; ++k) s += expf(v[k] - m);
         const int l = (int)label[i];
         float xl = 0.f;
+#pragma unroll
         for (int k = 0; k < c; ++k) xl = (k == l) ? v[k] : xl;
         acc += (double)(-(xl - m - logf(s)));
     }
@@ -320,20 +366,27 @@ __global__ __launch_bounds__(EB) void scalar_finalize_kernel(const double* __res
     s = block_sum_double(s, sm);
     if (threadIdx.x == 0) out[0] = (float)(s * mul);
 }
+template <int CT>
 __global__ __launch_bounds__(EB) void ce2d_bwd_kernel(const float* __restrict__ logit, const int64_t* __restrict__ label,
-                                                       const float* __restrict__ gout, int64_t pixels, int c,
+                                                       const float* __restrict__ gout, int64_t pixels, int c_rt,
                                                        float* __restrict__ dlogit) {
+    const int c = CT ? CT : c_rt;
     const float gs = gout[0] / (float)pixels;
     const int64_t stride = (int64_t)gridDim.x * EB;
     for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < pixels; i += stride) {
-        float v[MAXC];
+        float v[CT ? CT : MAXC];
+        row_load<CT>(logit, i, c, v);
         float m = -INFINITY;
-        for (int k = 0; k < c; ++k) { v[k] = logit[i * c + k]; m = fmaxf(m, v[k]); }
+#pragma unroll
+        for (int k = 0; k < c; ++k) m = fmaxf(m, v[k]);
         float s = 0.f;
+#pragma unroll
         for (int k = 0; k < c; ++k) { v[k] = expf(v[k] - m); s += v[k]; }
         const float r = 1.f / s;
         const int l = (int)label[i];
-        for (int k = 0; k < c; ++k) dlogit[i * c + k] = gs * (v[k] * r - ((k == l) ? 1.f : 0.f));
+#pragma unroll
+        for (int k = 0; k < c; ++k) v[k] = gs * (v[k] * r - ((k == l) ? 1.f : 0.f));
+        row_store<CT>(dlogit, i, c, v);
     }
 }
 __global__ __launch_bounds__(EB) void mse_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
@@ -500,14 +553,14 @@ extern "C" int ctl_sigmoid_bwd(const float* dy, const float* y, float* dx, int64
 }
 extern "C" int ctl_softmax_t_fwd(const float* x, float inv_t, float* p, int64_t pixels, int32_t c, ctl_stream stream) {
     CTL_REQUIRE(x && p && pixels > 0 && c > 0 && c <= MAXC, "softmax_t_fwd: bad arguments");
-    softmax_t_fwd_kernel<<<dim3(stream_blocks(pixels)), dim3(EB), 0, S_>>>(x, inv_t, p, pixels, c);
+    CTL_ROW_DISPATCH(softmax_t_fwd_kernel, rows_vec4(c, x, p), dim3(stream_blocks(pixels)), x, inv_t, p, pixels, c);
     CTL_LAUNCH_CHECK("softmax_t_fwd");
     return CTL_OK;
 }
 extern "C" int ctl_softmax_t_bwd(const float* p, const float* dp, float inv_t, float* dx, int64_t pixels, int32_t c,
                                  ctl_stream stream) {
     CTL_REQUIRE(p && dp && dx && pixels > 0 && c > 0 && c <= MAXC, "softmax_t_bwd: bad arguments");
-    softmax_t_bwd_kernel<<<dim3(stream_blocks(pixels)), dim3(EB), 0, S_>>>(p, dp, inv_t, dx, pixels, c);
+    CTL_ROW_DISPATCH(softmax_t_bwd_kernel, rows_vec4(c, p, dp, dx), dim3(stream_blocks(pixels)), p, dp, inv_t, dx, pixels, c);
     CTL_LAUNCH_CHECK("softmax_t_bwd");
     return CTL_OK;
 }
@@ -520,7 +573,7 @@ extern "C" int ctl_onehot(const int64_t* label, float* y, int64_t pixels, int32_
 extern "C" int ctl_ce2d_fwd(const float* logit, const int64_t* label, int64_t pixels, int32_t c, double* partial,
                             float* loss, ctl_stream stream) {
     CTL_REQUIRE(logit && label && partial && loss && pixels > 0 && c > 0 && c <= MAXC, "ce2d_fwd: bad arguments");
-    ce2d_partial_kernel<<<dim3(CTL_RED_BLOCKS), dim3(EB), 0, S_>>>(logit, label, pixels, c, partial);
+    CTL_ROW_DISPATCH(ce2d_partial_kernel, rows_vec4(c, logit), dim3(CTL_RED_BLOCKS), logit, label, pixels, c, partial);
     scalar_finalize_kernel<<<dim3(1), dim3(EB), 0, S_>>>(partial, CTL_RED_BLOCKS, 1.0 / (double)pixels, loss);
     CTL_LAUNCH_CHECK("ce2d_fwd");
     return CTL_OK;
@@ -528,7 +581,7 @@ extern "C" int ctl_ce2d_fwd(const float* logit, const int64_t* label, int64_t pi
 extern "C" int ctl_ce2d_bwd(const float* logit, const int64_t* label, const float* gout, int64_t pixels, int32_t c,
                             float* dlogit, ctl_stream stream) {
     CTL_REQUIRE(logit && label && gout && dlogit && pixels > 0 && c > 0 && c <= MAXC, "ce2d_bwd: bad arguments");
-    ce2d_bwd_kernel<<<dim3(stream_blocks(pixels)), dim3(EB), 0, S_>>>(logit, label, gout, pixels, c, dlogit);
+    CTL_ROW_DISPATCH(ce2d_bwd_kernel, rows_vec4(c, logit, dlogit), dim3(stream_blocks(pixels)), logit, label, gout, pixels, c, dlogit);
     CTL_LAUNCH_CHECK("ce2d_bwd");
     return CTL_OK;
 }
