@@ -60,14 +60,54 @@ def dice(result, reference) -> float:
     return float("nan") if den == 0 else 2.0 * int((a & b).sum()) / den
 
 
+def _border(mask: np.ndarray, connectivity: int) -> np.ndarray:
+    from scipy.ndimage import binary_erosion, generate_binary_structure
+    return mask ^ binary_erosion(mask, structure=generate_binary_structure(mask.ndim, connectivity), iterations=1)
+
+
+def surface_distances(result, reference, voxelspacing=None, connectivity=1) -> np.ndarray:
+    """Distances from every surface voxel of `result` to the nearest surface voxel of `reference` (the surface-distance
+    construction of medpy 0.4.0 `metric.binary`, carried by measure.py:1096-1128): surface = mask XOR its erosion, distances from
+    the Euclidean distance transform of the reference surface's complement.  Host code (scipy), as upstream."""
+    from scipy.ndimage import distance_transform_edt
+    a, b = np.atleast_1d(np.asarray(result).astype(bool)), np.atleast_1d(np.asarray(reference).astype(bool))
+    if not a.any():
+        raise RuntimeError("The first supplied array does not contain any binary object.")
+    if not b.any():
+        raise RuntimeError("The second supplied array does not contain any binary object.")
+    if voxelspacing is not None:
+        voxelspacing = np.ascontiguousarray(np.broadcast_to(np.asarray(voxelspacing, dtype=np.float64), (a.ndim,)))
+    return distance_transform_edt(~_border(b, connectivity), sampling=voxelspacing)[_border(a, connectivity)]
+
+
+def hd(result, reference, voxelspacing=None, connectivity=1) -> float:
+    """Symmetric Hausdorff distance (measure.py:333-378)."""
+    return max(surface_distances(result, reference, voxelspacing, connectivity).max(),
+               surface_distances(reference, result, voxelspacing, connectivity).max())
+
+
+def hd_2D_stack(result, reference, pixelspacing=None, connectivity=1) -> float:
+    """Mean in-plane Hausdorff distance over the slices where both masks are non-empty; -1 when there is none
+    (measure.py:381-399)."""
+    vals = [hd(r, g, pixelspacing, connectivity) for r, g in zip(result, reference) if r.sum() > 0 and g.sum() > 0]
+    return sum(vals) / len(vals) if vals else -1
+
+
+def asd(result, reference, voxelspacing=None, connectivity=1) -> float:
+    """Directed average surface distance result -> reference; 1e100 when either mask is empty (measure.py:458-548)."""
+    if np.sum(result) > 0 and np.sum(reference) > 0:
+        return surface_distances(result, reference, voxelspacing, connectivity).mean()
+    return 1e100
+
+
 class runningMySegmentationScore(object):
     """Patient-wise scores of 3-D predictions (metrics.py:139-291): one row per patient, one column per (foreground class, metric).
 
     'Dice', 'VolError' and 'VolSim' are functions of three voxel counts per class (|pred|, |gt|, |pred & gt|); for device tensors
     those come from the confusion-matrix kernel (one launch pair and one 2*n^2-word readback per patient instead of 2*(n-1)
-    full-volume host copies and masks).  The surface-distance metrics ('HD', 'ASD': scipy distance transforms on the host,
-    measure.py:102-330) are outside the accelerated path and are refused here."""
-    SUPPORTED = ("Dice", "VolError", "VolSim")
+    full-volume host copies and masks).  The surface-distance metrics 'HD' and 'ASD' are scipy distance transforms on the host,
+    as upstream (measure.py:333-548); asking for them brings the two label volumes to the host once per patient."""
+    SUPPORTED = ("Dice", "VolError", "VolSim", "HD", "ASD")
 
     def __init__(self, n_classes, idx2cls_dict=None, metrics_list=("Dice",), foreground_only=False):
         self.n_classes, self.metrics, self.foreground_only = n_classes, list(metrics_list), foreground_only
@@ -116,6 +156,14 @@ class runningMySegmentationScore(object):
         if voxel_spacing is not None and len(voxel_spacing) != 3:
             raise AssertionError(f"check voxel spacing, {voxel_spacing}")
         pc, gc, ic = self._counts(preds, gts)
+        surf = [m for m in self.metrics if m in ("HD", "ASD")]
+        if surf:
+            if voxel_spacing is None:
+                raise ValueError("'HD' / 'ASD' need the voxel spacing (x, y, z) of the volume")
+            if "HD" in surf:      # metrics.py:225-229: the in-plane pair is voxel_spacing[:2]; upstream's own guard on the axis order
+                assert voxel_spacing[0] >= voxel_spacing[2], "z spacing should be in last dim in the cardiac imaging"
+            p_h = preds.detach().cpu().numpy() if hasattr(preds, "detach") else np.asarray(preds)
+            g_h = gts.detach().cpu().numpy() if hasattr(gts, "detach") else np.asarray(gts)
         row = [str(pid)]
         for c, name in self.idx2cls_dict.items():
             if c == 0:
@@ -124,6 +172,14 @@ class runningMySegmentationScore(object):
             for m in self.metrics:
                 if m == "Dice":                            # medpy dc: ZeroDivisionError -> 0.0
                     score = 2.0 * inter / float(v1 + v2) if v1 + v2 else 0.0
+                elif m in ("HD", "ASD"):
+                    pm = (p_h > 0) if self.foreground_only else (p_h == c)
+                    gm = (g_h > 0) if self.foreground_only else (g_h == c)
+                    if m == "HD":                          # 2-D stack, 8-neighbourhood surfaces (metrics.py:224-230)
+                        score = hd_2D_stack(pm, gm, pixelspacing=voxel_spacing[:2], connectivity=2)
+                    else:
+                        score = asd(pm, gm, voxelspacing=voxel_spacing, connectivity=2)
+                    score = float(score)
                 elif m == "VolError":                      # (pred - gt) / gt, numpy float division (inf / nan on an empty gt)
                     with np.errstate(divide="ignore", invalid="ignore"):
                         score = float(np.float64(v1 - v2) / np.float64(1.0 * v2))

@@ -19,7 +19,7 @@ class TestSegmentationNetwork(object):
     __test__ = False                     # not a pytest class
 
     def __init__(self, test_dataset, crop_size, segmentation_model, use_gpu=True, save_path="", summary_report_file_name="result.csv",
-                 detailed_report_file_name="details.csv", patient_wise=True, metrics_list=("Dice",), foreground_only=False,
+                 detailed_report_file_name="details.csv", patient_wise=True, metrics_list=("Dice", "HD"), foreground_only=False,
                  save_soft_prediction=False, keep_results=True):
         if not use_gpu:
             raise ValueError("this build has no CPU path")

@@ -605,6 +605,32 @@ def patient_scores(preds: np.ndarray, gts: np.ndarray, classes, metrics=("Dice",
     return row
 
 
+def surface_scores(preds: np.ndarray, gts: np.ndarray, classes, spacing, foreground_only: bool = False):
+    """Per class c > 0: [HD, ASD] as `runningMySegmentationScore.update` asks for them (metrics.py:224-236): HD = mean over
+    the slices where both masks are non-empty of the in-plane symmetric Hausdorff distance with spacing[:2] (-1 if none),
+    ASD = mean distance from the prediction's surface voxels to the ground truth's surface over the volume with the full
+    spacing (1e100 if a mask is empty); surfaces = mask minus its erosion with the 8- / 26-neighbourhood; distances from the
+    Euclidean distance transform of the other surface's complement (medpy 0.4.0 metric.binary, measure.py:1096-1128)."""
+    from scipy import ndimage as ndi
+
+    def sd(a, b, sp):
+        st = ndi.generate_binary_structure(a.ndim, 2)
+        ea, eb = a & ~ndi.binary_erosion(a, structure=st), b & ~ndi.binary_erosion(b, structure=st)
+        return ndi.distance_transform_edt(~eb, sampling=sp)[ea]
+
+    row = []
+    for c in classes:
+        if c == 0:
+            continue
+        g = (gts > 0) if foreground_only else (gts == c)
+        p = (preds > 0) if foreground_only else (preds == c)
+        per_slice = [max(sd(p[z], g[z], spacing[:2]).max(), sd(g[z], p[z], spacing[:2]).max())
+                     for z in range(p.shape[0]) if p[z].any() and g[z].any()]
+        row.append(float(sum(per_slice) / len(per_slice)) if per_slice else -1.0)
+        row.append(float(sd(p, g, spacing).mean()) if p.any() and g.any() else 1e100)
+    return row
+
+
 def synthetic_batch(n: int, h: int, w: int, num_classes: int = 4, seed: int = 0, structured: bool = False):
     """SURVEY 8d synthetic inputs: U[0,1) images, randint labels (or a concentric-ellipse phantom),
     0.05*N(0,1) input noise clamped to [0,1] (train...py:185-187)."""

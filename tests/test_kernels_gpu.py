@@ -580,3 +580,14 @@ def test_patient_wise_scores_device_path_vs_reference():
     assert ms.update("x", torch.from_numpy(pr).cuda(), torch.from_numpy(gt).cuda())[1:] == O_.patient_scores(pr, gt, range(4), ("Dice", "VolError"))
     with pytest.raises(ValueError):
         runningMySegmentationScore(4, foreground_only=True).update("x", torch.from_numpy(pr).cuda(), torch.from_numpy(gt).cuda())
+
+
+def test_surface_scores_from_device_volumes():
+    """'HD' / 'ASD' with device volumes: counts from the confusion kernel, surface distances on the host copy -- same rows."""
+    from cooperative_training_and_latent_space_data_augmentation_amd.metrics import runningMySegmentationScore
+    for r in _io_cases()["surface_scores"]:
+        ms = runningMySegmentationScore(4, idx2cls_dict=None if r["foreground_only"] else r["idx2cls"],
+                                        metrics_list=["Dice", "HD", "ASD"], foreground_only=r["foreground_only"])
+        for k, ((pr, gt), row) in enumerate(zip(r["volumes"], r["rows"])):
+            got = ms.update("s%d" % k, pr.cuda(), gt.cuda(), voxel_spacing=r["spacing"])
+            assert np.allclose(got[1:], row[1:], rtol=0, atol=1e-12)

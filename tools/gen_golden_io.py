@@ -30,7 +30,7 @@ OUT = os.path.join(ROOT, "tests", "golden", "io_cases.pt")
 def main():
     g = torch.Generator().manual_seed(7)
     rng = np.random.RandomState(7)
-    cases = {"rescale": [], "crop_or_pad": [], "running_score": [], "noise_clamp": [], "patient_scores": []}
+    cases = {"rescale": [], "crop_or_pad": [], "running_score": [], "noise_clamp": [], "patient_scores": [], "surface_scores": []}
     # rescale_intensity (basic_operations.py:232-245): N*C*H*W, per (n, c) plane; includes a constant plane (max == min)
     for shape, lo, hi in [((3, 1, 17, 23), 0.0, 1.0), ((2, 2, 32, 32), -1.0, 2.5), ((16, 1, 64, 64), 0.0, 1.0)]:
         x = torch.randn(shape, generator=g) * 3.0 + 1.0
@@ -74,6 +74,26 @@ def main():
                                         "rows": [[r[0]] + [float(v) for v in r[1:]] for r in rows],
                                         "summary": {k: float(v) for k, v in summary.items()}, "summary_list": summary_list,
                                         "header": header, "table_header": ms.header})
+    # surface-distance metrics (measure.py:333-548 through metrics.py:224-236): ring phantoms, prediction = shifted / eroded rings,
+    # one slice without the class in the prediction, one volume per bookkeeping mode
+    import contextlib, io
+    yy, xx = np.mgrid[0:40, 0:36]
+    def rings(cy, cx, scale):
+        r = np.sqrt(((yy - cy) / scale) ** 2 + ((xx - cx) / (0.8 * scale)) ** 2)
+        return np.where(r < 4, 1, np.where(r < 7, 2, np.where(r < 10, 3, 0))).astype(np.int64)
+    for fg in (False, True):
+        ms = runningMySegmentationScore(n_classes=4, idx2cls_dict=None if fg else {0: "BG", 1: "LV", 2: "MYO", 3: "RV"},
+                                        metrics_list=["Dice", "HD", "ASD"], foreground_only=fg)
+        vols, rows = [], []
+        for k in range(2):
+            gt = np.stack([rings(20 + 0.5 * z, 18 - 0.3 * z, 1.0 + 0.05 * z) for z in range(6)])
+            pr = np.stack([rings(20.8 + 0.5 * z + k, 17.1 - 0.3 * z, 1.1 + 0.04 * z) for z in range(6)]).astype(np.uint8)
+            pr[0][pr[0] == 1] = 2                                      # class 1 missing from the first predicted slice
+            with contextlib.redirect_stdout(io.StringIO()):            # hd_2D_stack prints the slice index
+                rows.append(ms.update(pid="s%d" % k, preds=pr.copy(), gts=gt.copy(), voxel_spacing=[1.5, 1.25, 1.0]))
+            vols.append((torch.from_numpy(pr), torch.from_numpy(gt)))
+        cases["surface_scores"].append({"foreground_only": fg, "idx2cls": ms.idx2cls_dict, "volumes": vols, "spacing": [1.5, 1.25, 1.0],
+                                        "rows": [[r[0]] + [float(v) for v in r[1:]] for r in rows], "table_header": ms.header})
     torch.save(cases, OUT)
     print("wrote", OUT, os.path.getsize(OUT), "bytes")
 
