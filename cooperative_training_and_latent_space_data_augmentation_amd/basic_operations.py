@@ -28,3 +28,16 @@ def add_input_noise(clean_image: torch.Tensor, sigma: float = 0.05, seed: int = 
     """train_adv_supervised_segmentation_triplet.py:185-187: clamp(clean + 0.05 * N(0,1), 0, 1) in one kernel (noise drawn on
     device from `seed`, or injected)."""
     return ops.noise_clamp(clean_image, noise=noise, sigma=sigma, lo=0.0, hi=1.0, seed=seed)
+
+
+def set_seed(seed):
+    """Seeds the three host generators the training script seeds (basic_operations.py:22-34).  The engine draws the seeds of
+    its device-side counter hashes (dropout patterns, soft-mask noise, input noise) from torch's host generator, so a seeded run
+    repeats bit for bit (`tools/check_two_streams.py`); there is no autotuner whose choice could differ between runs."""
+    import random
+
+    import numpy as np
+    if seed is not None:
+        np.random.seed(seed)
+        random.seed(seed)
+        torch.manual_seed(seed)
