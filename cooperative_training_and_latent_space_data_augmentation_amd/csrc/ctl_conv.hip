@@ -1138,18 +1138,7 @@ static int conv_grid_x(int ntiles, int other, int occ) {
     int cap = (256 * resident) / other;
     if (other > 1 && cap >= 8) cap -= cap % 8;
     if (cap < 1) cap = 1;
-    if (ntiles <= cap) return ntiles;
-    static int balance = -1;
-    if (balance < 0) { const char* e = getenv("CTL_GRID_BALANCE"); balance = e ? atoi(e) : 0; }
-    if (balance) {
-        // same number of tile rounds with the fewest blocks: every block gets `rounds` tiles (or one less), and the slots not
-        // taken stay free for the kernels of the other launch chain
-        const int rounds = (ntiles + cap - 1) / cap;
-        int g = (ntiles + rounds - 1) / rounds;
-        if (other > 1 && g % 8) g += 8 - g % 8;
-        if (g < cap) cap = g;
-    }
-    return cap;
+    return ntiles < cap ? ntiles : cap;
 }
 
 extern "C" int ctl_pack_weights(const float* src, float* dst, int32_t cout, int32_t cin, int32_t ks, int64_t s_co,
