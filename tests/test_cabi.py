@@ -43,6 +43,17 @@ def test_invalid_arguments_fail_loudly():
     assert _ffi.lib.ctl_conv_stats_blocks(_ffi.desc_ptr(bad2)) == -1
 
 
+def test_prologue_coefficient_table_limit_is_enforced():
+    """The BatchNorm prologue coefficients live in a 256-entry LDS table per block (groups * cin): more is refused, not truncated."""
+    import ctypes
+    dummy = ctypes.cast((ctypes.c_float * 4)(), ctypes.c_void_p)          # never dereferenced: the check fails before any launch
+    d = _ffi.conv_desc(n=4, hin=8, win=8, cin=128, hout=8, wout=8, cout=16, ks=3, groups=4, pro_affine=1, pro_slope=0.2)
+    rc = _ffi.lib.ctl_conv_forward(_ffi.desc_ptr(d), dummy, dummy, None, dummy, dummy, None, None, None, dummy, None, None)
+    assert rc == -1 and b"prologue coefficients" in _ffi.lib.ctl_last_error()
+    rc = _ffi.lib.ctl_conv_wgrad(_ffi.desc_ptr(d), dummy, dummy, dummy, dummy, dummy, dummy, None)
+    assert rc == -1 and b"prologue coefficients" in _ffi.lib.ctl_last_error()
+
+
 def test_host_side_sizing_helpers():
     assert _ffi.lib.ctl_conv_wpack_floats(16, 16, 3) == 9 * 256
     assert _ffi.lib.ctl_conv_wpack_floats(4, 16, 3) == 9 * 256          # cin padded to one 16-chunk
