@@ -48,7 +48,8 @@ typedef struct ctl_conv {
     int32_t hout, wout, cout;        /* output pixel grid of this problem and its channel count               */
     int32_t ks, stride, pad;         /* 3/1|2/1, 1/1/0, 2/2/0                                                  */
     int32_t in_mode;                 /* CTL_IN_*: virtual input = stored | nearest-up x2 | zero-insert x2     */
-    int32_t pro_affine;              /* 1: x <- leaky(x*pro_scale[c]+pro_shift[c], pro_slope) while staging   */
+    int32_t pro_affine;              /* 1: x <- leaky(x*pro_scale[c]+pro_shift[c], pro_slope) while staging;
+                                        needs max(groups,1)*cin <= 256 (the coefficients sit in an LDS table)   */
     float   pro_slope;
     int32_t epi_flags;               /* CTL_EPI_*                                                             */
     int32_t epi_act;                 /* CTL_ACT_* applied after bias/residual                                  */
