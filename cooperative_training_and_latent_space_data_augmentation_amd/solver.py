@@ -238,6 +238,12 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
 
     def _image_recon_loss(self, z_i, clean_image_l, disable_track_bn_stats=False):
         def work():
+            ev = getattr(self, "_img_std_done", None)
+            if self._in_side and ev is not None:
+                # two-chain step: the image decoder is the one network whose BatchNorm running statistics are written on BOTH
+                # chains (standard pass on the main chain, this pass on the side chain; upstream's decode_image always tracks,
+                # model.py:444).  The standard pass comes first in the reference: make that an event, not a matter of timing.
+                torch.cuda.current_stream().wait_event(ev)
             return scaled_mse(self.decode_image(z_i, disable_track_bn_stats), clean_image_l, 0.5)
         return self._fork_side(work, z_i, clean_image_l)
 
@@ -558,6 +564,8 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
         # network sit on different streams the later gradient has to wait for the earlier one at the accumulation -- as the first
         # backward node of the main chain it stalled 5 ms on the hard image decoder's backward, which comes late on the side chain
         image_recon_loss = scaled_mse(self.decode_image(z_i), clean_image_l, 0.5)
+        self._img_std_done = torch.cuda.Event()
+        self._img_std_done.record(cur)               # the hard phase's image-decoder pass (side chain) waits for this one
         # CPU issue order (one Python thread feeds both streams): the side chain's long part is issued BEFORE the main chain's
         # D_seg -> STN, while the GPU is still busy with what both streams already have -- issued after it, the side stream sat
         # idle for ~1.5 ms waiting for the host (tools/timeline.py)
@@ -578,6 +586,7 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
             ev["side_done"].record(side)
             self._chain_events.append(ev)
         cur.wait_stream(side)
+        self._img_std_done = None
         for t in tuple(hard):
             t.record_stream(cur)
         return (std[0], image_recon_loss, std[2], std[3]), hard

@@ -321,11 +321,14 @@ def test_two_stream_step_is_bitwise_identical(golden_cases, golden_sd, variant):
             losses = s.cooperative_step(dev(C["clean"]), dev(C["label"]), dev(C["noisy"]), **kw)
         torch.cuda.synchronize()
         outs.append((torch.stack([v.detach().float() for v in losses]).cpu(),
-                     {k: m._flat_data.detach().cpu().clone() for k, m in s.model.items()}))
-    for l, w in outs[1:]:
+                     {k: m._flat_data.detach().cpu().clone() for k, m in s.model.items()},
+                     {k: (m._bflat.detach().cpu().clone(), m._nbt.detach().cpu().clone()) for k, m in s.model.items()}))
+    for l, w, b in outs[1:]:
         assert torch.equal(l, outs[0][0])
         for k in w:
             assert torch.equal(w[k], outs[0][1][k]), k
+            # BatchNorm running statistics too: the image decoder's are written on both chains, in an event-enforced order
+            assert torch.equal(b[k][0], outs[0][2][k][0]) and torch.equal(b[k][1], outs[0][2][k][1]), k
 
 
 

@@ -23,6 +23,8 @@ def child():
     h = hashlib.sha256()
     for k in sorted(s.model):
         h.update(s.model[k]._flat_data.detach().cpu().numpy().tobytes())
+        h.update(s.model[k]._bflat.detach().cpu().numpy().tobytes())      # BatchNorm running statistics: their update ORDER across the chains
+        h.update(s.model[k]._nbt.detach().cpu().numpy().tobytes())
     print("RESULT " + json.dumps({"losses": [float(v) for v in losses], "weights_sha": h.hexdigest()}))
 if __name__ == "__main__":
     if len(sys.argv) > 1: child(); sys.exit(0)
