@@ -469,19 +469,24 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
 
     # ------------------------------------------------------------------ inference (model.py:375-394, 608-664)
     def slow_refinement(self, pred_logit, n_steps=1, auto_stop=False, save_internal_predicts=False):
-        """Every pass re-feeds the ORIGINAL FTN logits (model.py:629), so all passes give the same tensor: run one."""
+        """model.py:608-641.  Every pass of ONE call re-feeds the call's input (`pred_logit.detach().clone()`, :629): with eval-mode
+        BatchNorm all passes give the same tensor, so one is run; with training-mode BatchNorm every pass moves the running
+        statistics, so all `n_steps` run.  (`auto_stop` compares consecutive passes, which are equal: it never changes the result.)"""
         n_steps = self.n_iter if n_steps is None else n_steps
         s_t = pred_logit
-        if n_steps >= 1:
+        stn_training = self.model["shape_encoder"].training or self.model["shape_decoder"].training
+        for _ in range(max(n_steps, 0) if stn_training else min(max(n_steps, 0), 1)):
             s_t = self.recon_shape(pred_logit.detach())
         return s_t, {0: [pred_logit]}
 
     def predict(self, input, softmax=False, n_iter=None):
+        """model.py:375-394: FTN prediction, then n_iter-1 calls of slow_refinement, each fed with the previous call's result
+        (n_iter = 3 composes two STN passes)."""
         self.eval()
         n_iter = self.n_iter if n_iter is None else n_iter
         with torch.no_grad():
             _, pred = self.fast_predict(input)
-            if n_iter >= 2:
+            for _ in range(max(n_iter - 1, 0)):
                 pred, _ = self.slow_refinement(pred, n_steps=n_iter)
         if softmax:
             pred = softmax_t(pred, 1.0)
@@ -542,12 +547,20 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
         gen_kw = dict(corrupted_image_DA_config=img_cfg, corrupted_seg_DA_config=seg_cfg, image_override=image_override,
                       seg_override=seg_override)
         xh = yh = None
+        img_saliency_done = None
         self._in_side = True
         try:
             with torch.cuda.stream(side):
                 if img_cfg is not None:
                     xh, _ = self.hard_example_generation(clean_image_l.detach(), label_l.detach(), gen_corrupted_seg=False,
                                                          gen_corrupted_image=True, **gen_kw)
+                    if self.last_scheme != "dropout":
+                        # targeted masks: the saliency pass decoded z_i through the image decoder with TRACKING BatchNorm (upstream
+                        # calls decoder_function(code) in train mode, model_util.py:214) -- a third writer of that network's running
+                        # statistics, on this chain.  The standard pass on the main chain must not overlap it: it waits for this
+                        # event (both passes decode the same z_i, so their two updates commute bit-exactly; only overlap is wrong).
+                        img_saliency_done = torch.cuda.Event()
+                        img_saliency_done.record(side)
         finally:
             self._in_side = False
         if seg_cfg is not None:
@@ -563,6 +576,8 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
         # the standard image decoder goes FIRST on the main chain: autograd replays a chain in reverse, and where two passes of a
         # network sit on different streams the later gradient has to wait for the earlier one at the accumulation -- as the first
         # backward node of the main chain it stalled 5 ms on the hard image decoder's backward, which comes late on the side chain
+        if img_saliency_done is not None:
+            cur.wait_event(img_saliency_done)
         image_recon_loss = scaled_mse(self.decode_image(z_i), clean_image_l, 0.5)
         self._img_std_done = torch.cuda.Event()
         self._img_std_done.record(cur)               # the hard phase's image-decoder pass (side chain) waits for this one

@@ -481,12 +481,12 @@ class OracleSolver:
         return l_seg, l_img, l_shape, l_pert
 
     def cooperative_step(self, clean, label, noisy, img_cfg, seg_cfg, latent_DA=True,
-                         image_override=None, seg_override=None, do_optim=True):
+                         image_override=None, seg_override=None, do_optim=True, separate_training=False):
         """One iteration of `train_network` (train_adv_supervised_segmentation_triplet.py:171-237), with the
         noisy input (`image_l`, :185-189) supplied by the caller.  Returns the 8 loss terms."""
         self.train()
         self.reset_all_optimizers()
-        std = self.standard_training(clean, label, noisy)
+        std = self.standard_training(clean, label, noisy, separate_training=separate_training)
         loss = std[0] + std[1] + std[3] + std[2]
         hard = (torch.tensor(0.0),) * 4
         if latent_DA:
@@ -496,7 +496,7 @@ class OracleSolver:
                                                   gen_corrupted_image=img_cfg is not None,
                                                   corrupted_image_DA_config=img_cfg, corrupted_seg_DA_config=seg_cfg,
                                                   image_override=image_override, seg_override=seg_override)
-            hard = self.hard_example_training(xh, clean, yh, label)
+            hard = self.hard_example_training(xh, clean, yh, label, separate_training=separate_training)
             loss = loss + (hard[0] + hard[1] + hard[2] + hard[3])
         self.reset_all_optimizers()
         loss.backward()
@@ -505,13 +505,14 @@ class OracleSolver:
         return tuple(float(v) for v in std) + tuple(float(v) for v in hard)
 
     def predict(self, x, softmax=False, n_iter=None):
-        """model.py:375-394 with 608-641: every refinement pass re-feeds the ORIGINAL FTN logits
-        (`pred_logit.detach().clone()`, :629), so n_iter>=2 always equals one STN pass."""
+        """model.py:375-394 with 608-641: `predict` calls `slow_refinement(pred, n_steps=n_iter)` n_iter-1 times, feeding each
+        call's result to the next (:387-389); INSIDE a call every pass re-feeds that call's input (`pred_logit.detach().clone()`,
+        :629), so with eval-mode BatchNorm a call equals one STN pass: n_iter = 1 + number of composed STN passes."""
         self.eval()
         n_iter = self.n_iter if n_iter is None else n_iter
         with torch.no_grad():
             _, pred = self.fast_predict(x)
-            if n_iter >= 2:
+            for _ in range(max(n_iter - 1, 0)):
                 pred = self.recon_shape(pred.detach().clone())
         return torch.softmax(pred, dim=1) if softmax else pred
 

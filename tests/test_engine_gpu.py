@@ -296,11 +296,12 @@ def test_full_cooperative_step_vs_golden(golden_cases, golden_sd, case):
         k, n = key.split("/")
         close(dict(s.model[k].named_parameters())[n], p, atol=2.1e-4, what=key)
 
-@pytest.mark.parametrize("variant", ["both", "image_only", "seg_only", "no_latent_DA", "separate_training"])
+@pytest.mark.parametrize("variant", ["both", "image_only", "seg_only", "no_latent_DA", "separate_training", "targeted_C", "targeted_E"])
 def test_two_stream_step_is_bitwise_identical(golden_cases, golden_sd, variant):
     """The iteration is issued as two launch chains on two HIP streams (solver.two_streams).  Every kernel is deterministic, so
-    two training steps must leave bit-identical weights and losses with and without it -- a race would show up here."""
-    C = golden_cases["D_step_dropout"]
+    two training steps must leave bit-identical weights, losses and BatchNorm buffers with and without it -- a race would show up
+    here.  targeted_C / targeted_E: channel / spatial masks, whose saliency pass is a third tracking pass of the image decoder."""
+    C = golden_cases[{"targeted_C": "C_step_channel_spatial", "targeted_E": "E_step_soft_random"}.get(variant, "D_step_dropout")]
     outs = []
     for two in (False, True, True):
         s = _solver(golden_sd)
@@ -317,7 +318,7 @@ def test_two_stream_step_is_bitwise_identical(golden_cases, golden_sd, variant):
             kw.update(latent_DA=False)
         elif variant == "separate_training":
             kw.update(separate_training=True)
-        for _ in range(2):
+        for _ in range(3 if variant.startswith("targeted") else 2):
             losses = s.cooperative_step(dev(C["clean"]), dev(C["label"]), dev(C["noisy"]), **kw)
         torch.cuda.synchronize()
         outs.append((torch.stack([v.detach().float() for v in losses]).cpu(),

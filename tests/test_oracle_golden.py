@@ -151,7 +151,8 @@ def test_case_F_predict(golden_cases, golden_sd):
         top2 = p.topk(2, dim=1)[0]
         safe = (top2[:, 0] - top2[:, 1]) > 1e-3
         assert torch.equal(p.max(1)[1].to(torch.uint8)[safe], F_[key][safe])      # integer label maps bit-exact
-    assert torch.allclose(s.predict(F_["vol"], n_iter=3), p2)                     # refinement re-feeds FTN logits
+    # n_iter = 3 composes two STN passes (model.py:387-389); pinned by tests/test_golden_r2.py::test_oracle_predict_192
+    assert torch.allclose(s.predict(F_["vol"], n_iter=3), s.recon_shape(p2), atol=1e-6)
 
 
 def test_case_G_bs16_256_checksum(golden_cases, golden_sd):

@@ -29,9 +29,9 @@ import medseg.models.advanced_triplet_recon_segmentation_model as ref_model  # n
 from oracle.ref_cpu import synthetic_batch, NET_NAMES  # noqa: E402  (inputs only; nothing of the oracle's math is used)
 
 
-def new_solver(seed=0):
+def new_solver(seed=0, network_type="FCN_16_standard"):
     torch.manual_seed(seed)
-    return AdvancedTripletReconSegmentationModel(network_type="FCN_16_standard", image_ch=1, num_classes=4,
+    return AdvancedTripletReconSegmentationModel(network_type=network_type, image_ch=1, num_classes=4,
                                                  learning_rate=1e-4, n_iter=1, use_gpu=False)
 
 
@@ -75,7 +75,8 @@ def pick(solver, what):
     for key in PICK_GRADS:
         k, n = key.split("/")
         p = dict(solver.model[k].named_parameters())[n]
-        out[key] = (p.grad if what == "grad" else p).detach().clone()
+        t = p.grad if what == "grad" else p
+        out[key] = None if t is None else t.detach().clone()      # (ablation variants leave whole branches without a gradient)
     return out
 
 
@@ -87,13 +88,16 @@ CFG_DROP_MSE = {"loss_name": "mse", "mask_type": "dropout", "max_threshold": 0.5
 CFG_DROP_CE = {"loss_name": "ce", "mask_type": "dropout", "max_threshold": 0.5, "random_threshold": True, "if_soft": True}
 
 
-def ref_step(solver, clean, label, noisy, img_cfg, seg_cfg, record):
-    """train_adv_supervised_segmentation_triplet.py:171-231 with the noise supplied; records every random draw."""
+def ref_step(solver, clean, label, noisy, img_cfg, seg_cfg, record, separate_training=False, keep_big=True):
+    """train_adv_supervised_segmentation_triplet.py:171-231 with the noise supplied; records every random draw.
+    keep_big=False (metric-sized cases): checksums instead of the activation-sized tensors."""
     solver.train()
     solver.reset_all_optimizers()
-    std = solver.standard_training(clean, label, perturbed_image=noisy, separate_training=False)
+    std = solver.standard_training(clean, label, perturbed_image=noisy, separate_training=separate_training)
     standard_loss = std[0] + std[1] + std[3] + std[2]
-    record["z_i"], record["z_s"] = solver.z_i.detach().clone(), solver.z_s.detach().clone()
+    if keep_big:
+        record["z_i"], record["z_s"] = solver.z_i.detach().clone(), solver.z_s.detach().clone()
+    record["z_i_stats"], record["z_s_stats"], record["z_shape"] = tensor_stats(solver.z_i), tensor_stats(solver.z_s), tuple(solver.z_i.shape)
     solver.reset_all_optimizers()
 
     # capture masks / k / soft-noise drawn inside the reference
@@ -137,9 +141,13 @@ def ref_step(solver, clean, label, noisy, img_cfg, seg_cfg, record):
         torch.rand_like = orig_rand_like
         ref_model.F.dropout2d = orig_dropout2d
     record["masks"], record["rand_draws"], record["soft_noises"], record["dropout_keeps"] = masks, ks, noises, keeps
-    record["x_hard"], record["y_hard"] = xh.detach().clone(), yh.detach().clone()
+    if keep_big:
+        record["x_hard"], record["y_hard"] = xh.detach().clone(), yh.detach().clone()
+    else:       # dropout masks of the reference are activation-sized equality masks: keep the [N,C] / [N,L] form only
+        record["masks"] = [m if m.numel() <= 1 << 16 else None for m in masks]
+    record["x_hard_stats"], record["y_hard_stats"] = tensor_stats(xh), tensor_stats(yh)
     hard = solver.hard_example_training(perturbed_image=xh, perturbed_seg=yh, clean_image_l=clean, label_l=label,
-                                        separate_training=False, use_gpu=False)
+                                        separate_training=separate_training, use_gpu=False)
     hard_loss = hard[0] + hard[1] + hard[2] + hard[3]
     loss = standard_loss + hard_loss
     solver.reset_all_optimizers()
