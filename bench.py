@@ -38,42 +38,39 @@ def synthetic(n, h, w, seed, device):
 
 
 def latent_mask_roofline(device):
-    """The north-star's named kernel: score + rank-select + apply, channel mode.  Algorithmic bytes = 3*N*C*h*w*4 (+ vectors).
-    Configured size (16x128x16x16, 2 MiB/tensor: cache-resident, launch-latency bound) and a 128 MiB/tensor problem (HBM-bound)."""
+    """The north-star's named kernel: score + rank-select + apply, channel mode, ONE launch (ctl_latent_mask_fused).  Algorithmic
+    bytes = 3*N*C*h*w*4 (+ vectors).  Configured size (16x128x16x16, 2 MiB/tensor: cache-resident, launch-latency bound) and a
+    128 MiB/tensor problem (HBM-bound).  Timed with events on torch's current stream, which is the stream the kernel is launched on."""
     from cooperative_training_and_latent_space_data_augmentation_amd import ops
     out = {}
     for tag, (n, c, h, w) in (("configured_16x128x16x16", (16, 128, 16, 16)), ("hbm_regime_64x128x64x64", (64, 128, 64, 64))):
         grad = torch.randn(n, c, h, w, device=device).contiguous(memory_format=torch.channels_last)
         code = torch.rand(n, c, h, w, device=device).contiguous(memory_format=torch.channels_last)
         for _ in range(3):
-            score = ops.latent_score(grad, 0)
-            ops.latent_mask_apply(code, score, 0, c // 3)
+            ops.latent_mask(grad, code, 0, c // 3)
         torch.cuda.synchronize()
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]      # the kernels run on torch's current stream
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
         iters = 20
         ev[0].record()
         for _ in range(iters):
-            score = ops.latent_score(grad, 0)
+            ops.latent_mask(grad, code, 0, c // 3)
         ev[1].record()
-        for _ in range(iters):
-            ops.latent_mask_apply(code, score, 0, c // 3)
-        ev[2].record()
         torch.cuda.synchronize()
-        us = (ev[0].elapsed_time(ev[1]) + ev[1].elapsed_time(ev[2])) * 1e3 / iters      # score pass + select/apply pass
-        nbytes = 12 * n * c * h * w + 12 * n * c
-        out[tag] = {"bound": "hbm", "achieved": nbytes / us / 1e3, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+        us = ev[0].elapsed_time(ev[1]) * 1e3 / iters
+        nbytes = 12 * n * c * h * w + 8 * n * c
+        out[tag] = {"bound": "hbm", "achieved": nbytes / us / 1e3, "peak": PEAK_HBM_GBS, "unit": "GB/s", "launches_per_call": 1,
                     "frac": nbytes / us / 1e3 / PEAK_HBM_GBS, "us_per_call": us, "algorithmic_mb": nbytes / 1e6}
         if n * c * h * w * 4 <= (8 << 20):
-            # at this size the Python loop above measures the host's launch rate (~10 us per call), not the kernels: replay the
-            # same launches from a captured HIP graph to time the GPU side alone
+            # at this size the Python loop above measures the host's launch rate, not the kernel: replay the same launches from a
+            # captured HIP graph (how the training step runs them in graph mode) to time the GPU side alone
             try:
                 g, side = torch.cuda.CUDAGraph(), torch.cuda.Stream()
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):
+                    ops.latent_mask(grad, code, 0, c // 3)          # the per-stream workspace must exist before capture
                     with torch.cuda.graph(g, stream=side):
                         for _ in range(10):
-                            sc = ops.latent_score(grad, 0)
-                            ops.latent_mask_apply(code, sc, 0, c // 3)
+                            ops.latent_mask(grad, code, 0, c // 3)
                 torch.cuda.current_stream().wait_stream(side)
                 g.replay()
                 torch.cuda.synchronize()
@@ -91,20 +88,24 @@ def latent_mask_roofline(device):
     return out
 
 
-def cpu_baseline(host_batch, threads):
-    from oracle import ref_cpu as O                      # the checker, timed as the reported CPU baseline
+def cpu_baseline(host_batch, threads, steps=3):
+    """BASELINE.md section 3 procedure: the full bs16 batch, 1 warm-up step + `steps` timed steps, median (the oracle is the checker,
+    timed here as the reported CPU baseline -- never on the product path)."""
+    from oracle import ref_cpu as O
     from cooperative_training_and_latent_space_data_augmentation_amd.init import reference_init_state_dicts
     torch.set_num_threads(threads)
     torch.manual_seed(0)
     s = O.OracleSolver(state_dicts=reference_init_state_dicts())
-    nb = min(8, host_batch[0].shape[0])                  # bounded sample: half a batch keeps this leg at ~10-30 s
-    clean, label, noisy = (t[:nb] for t in host_batch)
-    t0 = time.perf_counter()
-    s.cooperative_step(clean, label, noisy, DROP_IMG, DROP_SEG)
-    dt = time.perf_counter() - t0
-    return {"value": clean.shape[0] / dt, "unit": "slices/s", "cores": threads, "kind": "port",
-            "sample": f"1 full cooperative step (bs{clean.shape[0]} = half a GPU batch, 256x256, dropout masks) of oracle/ref_cpu.py, "
-                      f"{threads} torch threads, no warm-up, {dt:.1f} s"}
+    clean, label, noisy = host_batch
+    times = []
+    for i in range(1 + steps):
+        t0 = time.perf_counter()
+        s.cooperative_step(clean, label, noisy, DROP_IMG, DROP_SEG)
+        times.append(time.perf_counter() - t0)
+    med = sorted(times[1:])[len(times[1:]) // 2]
+    return {"value": clean.shape[0] / med, "unit": "slices/s", "cores": threads, "kind": "port",
+            "sample": f"full cooperative step (bs{clean.shape[0]}, {clean.shape[-1]}x{clean.shape[-1]}, dropout masks) of oracle/ref_cpu.py on {threads} torch "
+                      f"threads: 1 warm-up ({times[0]:.1f} s) + {steps} timed steps, median {med:.1f} s (all: {[round(t, 1) for t in times[1:]]})"}
 
 
 def main():
@@ -114,6 +115,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--mode", default="auto", choices=["auto", "eager", "graph"],
+                    help="eager: Python issues the ~1100 launches of a step on two HIP streams; graph: the whole step is one hipGraph replay "
+                         "(host-insensitive); auto: both are timed for a few untimed steps after the warm-up and the faster one is measured")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--prof-filter", default=DOMINANT)
@@ -152,11 +156,19 @@ def main():
     solver = AdvancedTripletReconSegmentationModel(network_type="FCN_16_standard", image_ch=1, num_classes=4,
                                                    learning_rate=1e-4, use_gpu=True)
     dp = DataParallel(solver) if use_dist else None
+    if use_dist:                                         # per-rank RNG streams (scheme / k / dropout / soft-noise draws), after the weight broadcast
+        import random
+        import numpy as np
+        torch.manual_seed(1234 + rank)
+        np.random.seed(1234 + rank)
+        random.seed(1234 + rank)
     clean, label, noisy, host_batch = synthetic(args.batch, args.size, args.size, 1000 + rank, device)
     hook = dp.sync_gradients if dp else None
 
-    def step():
+    def eager_step():
         return solver.cooperative_step(clean, label, noisy, DROP_IMG, DROP_SEG, grad_hook=hook)
+
+    step = eager_step
 
     def fence():
         torch.cuda.synchronize()
@@ -167,19 +179,60 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    # ---- execution mode (still untimed): the step as a hipGraph replay vs Python-issued launches
+    from cooperative_training_and_latent_space_data_augmentation_amd.graph import CooperativeStepGraph
+    calib, mode, gstep = {}, args.mode, None
+    if mode in ("auto", "graph"):
+        try:
+            gstep = CooperativeStepGraph(solver, DROP_IMG, DROP_SEG, grad_hook=hook)
+            graph_step = lambda: gstep(clean, label, noisy)
+            graph_step()                                  # capture + first replay
+            fence()
+        except Exception as exc:                          # capture is an optimisation: the eager path is the same computation
+            if mode == "graph":
+                raise
+            calib["graph_error"], gstep = f"{type(exc).__name__}: {str(exc)[:160]}", None
+    if mode == "auto":
+        def time_steps(fn, n=6):
+            fence()
+            t = time.perf_counter()
+            for _ in range(n):
+                fn()
+            fence()
+            return 1e3 * (time.perf_counter() - t) / n
+        calib["eager_ms"] = time_steps(eager_step)
+        if gstep is not None:
+            calib["graph_ms"] = time_steps(graph_step)
+        pick = torch.tensor([1.0 if (gstep is not None and calib["graph_ms"] < calib["eager_ms"]) else 0.0], device=device)
+        if use_dist:                                      # every rank must run the same mode: rank 0 decides
+            dist.broadcast(pick, 0)
+        mode = "graph" if pick.item() > 0 else "eager"
+    if mode == "graph":
+        step = graph_step
     phase_tm = None
     if rank == 0 and os.environ.get("CTL_HIP_LIB") and hasattr(_ffi.lib, "ctl_debug_timing"):
         import ctypes                                     # -DCTL_TIMING variant build: per-phase cycle counters of the conv kernel
         phase_tm = (ctypes.c_ulonglong * 12)()
         _ffi.lib.ctl_debug_timing(phase_tm)               # reset
-    if rank == 0:
+    if rank == 0 and mode == "eager":                     # per-launch HIP events cannot be recorded inside a graph replay
         _ffi.prof_start(args.prof_filter)
+    # per-step record: one event per step on the launch stream (no sync inside the timed region), the host's
+    # issue time per step, and the caching allocator's device-allocation counter (a hipMalloc inside the region = a one-off stall)
+    step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    issue_s = []
+    alloc0 = torch.cuda.memory_stats().get("num_device_alloc", 0)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    step_ev[0].record()
+    for i in range(args.steps):
+        ti = time.perf_counter()
         losses = step()
+        issue_s.append(time.perf_counter() - ti)
+        step_ev[i + 1].record()
     fence()
     dt = time.perf_counter() - t0
-    prof = _ffi.prof_stop() if rank == 0 else {}
+    step_ms = sorted(step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(args.steps))
+    allocs_in_region = torch.cuda.memory_stats().get("num_device_alloc", 0) - alloc0
+    prof = _ffi.prof_stop() if (rank == 0 and mode == "eager") else {}
     # In the timed region two launch chains share the GPU (solver.two_streams), so a kernel's event-timed duration includes
     # the time it shares the CUs with the other chain.  For the kernel-quality figure the same step is replayed on ONE stream
     # afterwards (outside the timed region): that is also what rocprofv3 --kernel-trace shows, because it serialises dispatches.
@@ -187,12 +240,12 @@ def main():
     if getattr(solver, "two_streams", False):          # EVERY rank replays (step() contains the gradient all-reduce); rank 0 profiles
         solver.two_streams = False
         for _ in range(2):
-            step()
+            eager_step()
         torch.cuda.synchronize()
         if rank == 0:
             _ffi.prof_start(args.prof_filter)
         for _ in range(5):
-            step()
+            eager_step()
         torch.cuda.synchronize()
         if rank == 0:
             prof_single = _ffi.prof_stop()
@@ -219,33 +272,44 @@ def main():
                                    "(FTN+STN standard + dropout latent masks + hard-example training + backward + 5x Adam), "
                                    "reference-init weights", "global_batch": world * args.batch,
                        "parallelism": f"dp{world}" if world > 1 else "single GPU"},
-            "final_losses": loss_vals,
+            "final_losses": loss_vals, "mode": mode, "mode_calibration": calib,
+            "step_ms": {"min": step_ms[0], "median": step_ms[len(step_ms) // 2], "max": step_ms[-1],
+                        "note": "GPU time between consecutive per-step events on the launch stream (rank 0)"},
+            "cpu_issue_ms": {"median": 1e3 * sorted(issue_s)[len(issue_s) // 2], "max": 1e3 * max(issue_s)},
+            "device_allocs_in_timed_region": int(allocs_in_region),
         }
-        if prof:
-            kid, rec = max(prof.items(), key=lambda kv: kv[1]["ms"])
+        def roofline_of(kid, rec, region_s=None):
             secs = rec["ms"] * 1e-3
             tf, gbs = rec["flops"] / secs / 1e12, rec["bytes"] / secs / 1e9
             f_mfma, f_hbm = tf / PEAK_MFMA_F32_TFLOPS, gbs / PEAK_HBM_GBS
             bound = "mfma" if f_mfma >= f_hbm else "hbm"
-            out["roofline"] = {"bound": bound, "achieved": tf if bound == "mfma" else gbs,
-                               "peak": PEAK_MFMA_F32_TFLOPS if bound == "mfma" else PEAK_HBM_GBS,
-                               "unit": "TFLOP/s" if bound == "mfma" else "GB/s", "frac": max(f_mfma, f_hbm), "traffic": None,
-                               "kernel": kid, "launches": int(rec["launches"]), "avg_us": 1e3 * rec["ms"] / rec["launches"],
-                               "algorithmic_gflop_per_launch": rec["flops"] / rec["launches"] / 1e9,
-                               "algorithmic_mb_per_launch": rec["bytes"] / rec["launches"] / 1e6,
-                               "hbm_gbs": gbs, "hbm_frac": f_hbm, "share_of_step_time": secs / dt}
-            if getattr(solver, "two_streams", False):
-                out["roofline"]["note"] = ("timed region: two launch chains share the GPU, so this kernel's event-timed duration includes the "
-                                           "time it shares the CUs with the other chain (the step is 14 % faster for it); kernel quality "
-                                           "= single_stream below")
+            r = {"bound": bound, "achieved": tf if bound == "mfma" else gbs,
+                 "peak": PEAK_MFMA_F32_TFLOPS if bound == "mfma" else PEAK_HBM_GBS,
+                 "unit": "TFLOP/s" if bound == "mfma" else "GB/s", "frac": max(f_mfma, f_hbm), "traffic": None,
+                 "kernel": kid, "launches": int(rec["launches"]), "avg_us": 1e3 * rec["ms"] / rec["launches"],
+                 "algorithmic_gflop_per_launch": rec["flops"] / rec["launches"] / 1e9,
+                 "algorithmic_mb_per_launch": rec["bytes"] / rec["launches"] / 1e6, "hbm_gbs": gbs, "hbm_frac": f_hbm}
+            if region_s:
+                r["share_of_step_time"] = secs / region_s
+            return r
+
+        if prof:                                          # eager mode: HIP events around every launch of the kernel INSIDE the timed region
+            kid, rec = max(prof.items(), key=lambda kv: kv[1]["ms"])
+            out["roofline"] = roofline_of(kid, rec, dt)
+            out["roofline"]["note"] = ("timed region: two launch chains share the GPU, so this kernel's event-timed duration includes the time it "
+                                       "shares the CUs with the other chain; kernel quality = single_stream below")
             if kid in prof_single:
-                r1 = prof_single[kid]
-                tf1, gb1 = r1["flops"] / r1["ms"] / 1e9, r1["bytes"] / r1["ms"] / 1e6
+                r1 = roofline_of(kid, prof_single[kid])
                 out["roofline"]["single_stream"] = {
-                    "achieved": tf1 if bound == "mfma" else gb1, "frac": (tf1 / PEAK_MFMA_F32_TFLOPS) if bound == "mfma" else gb1 / PEAK_HBM_GBS,
-                    "avg_us": 1e3 * r1["ms"] / r1["launches"], "launches": int(r1["launches"]),
+                    "achieved": r1["achieved"], "frac": r1["frac"], "avg_us": r1["avg_us"], "launches": r1["launches"],
                     "note": "same kernel, same step replayed on one stream after the timed region (no second chain sharing the CUs); "
                             "rocprofv3 --kernel-trace serialises dispatches and agrees with this duration"}
+        elif prof_single:                                 # graph mode: a replay has no per-launch events; same step, eager, one stream
+            kid, rec = max(prof_single.items(), key=lambda kv: kv[1]["ms"])
+            out["roofline"] = roofline_of(kid, rec)
+            out["roofline"]["note"] = ("timed region = hipGraph replays (no per-launch events possible): HIP events around every launch of this "
+                                       "kernel in 5 eager single-stream steps run right after the timed region, same process, same inputs; "
+                                       "rocprofv3 --kernel-trace agrees with this duration")
         tfile = os.path.join(ROOT, "profiles", "dominant_kernel_traffic.json")      # committed rocprofv3 --pmc measurement
         if "roofline" in out and os.path.exists(tfile):
             t = json.load(open(tfile))

@@ -47,7 +47,7 @@ class _Lib:
         lib.ctl_version.restype = C.c_int
         for name in ("ctl_conv_wpack_floats", "ctl_conv_stats_floats", "ctl_wgrad_partial_floats",
                      "ctl_wgrad_bias_partial_floats", "ctl_latent_score_ws_floats", "ctl_latent_mask_apply_ws_floats",
-                     "ctl_rescale_intensity_ws_floats", "ctl_sizeof_op", "ctl_sizeof_conv"):
+                     "ctl_rescale_intensity_ws_floats", "ctl_sizeof_op", "ctl_sizeof_conv", "ctl_latent_mask_fused_ws_floats"):
             getattr(lib, name).restype = C.c_size_t
         p, i32, i64, f32, u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64
         sig = {
@@ -84,8 +84,14 @@ class _Lib:
             "ctl_latent_score": [i32, p, p, p, i32, i32, i32, p],
             "ctl_latent_mask_apply": [i32, p, p, p, i32, p, p, p, p, i32, i32, i32, p],
             "ctl_latent_mask_apply_ws_floats": [i32, i32, i32, i32],
+            "ctl_latent_mask_fused_ws_floats": [i32, i32, i32, i32],
+            "ctl_latent_mask_fused": [i32, p, p, p, i32, p, p, p, p, p, i32, i32, i32, p],
             "ctl_dropout2d": [p, p, u64, f32, p, p, i32, i32, i32, p],
             "ctl_uniform": [p, i64, u64, p],
+            "ctl_step_tick": [p, p],
+            "ctl_dropout2d_ex": [p, p, u64, p, f32, p, p, p, i32, i32, i32, p],
+            "ctl_uniform_dev": [p, i64, u64, p, p],
+            "ctl_adam_dev": [p, p, p, p, i64, f32, f32, f32, f32, p, f32, p],
             "ctl_adam": [p, p, p, p, i64, f32, f32, f32, f32, i32, f32, p],
             "ctl_plan_run": [p, i32, p, i32, p],
             "ctl_prof_start": [C.c_char_p], "ctl_prof_stop": [p, C.c_size_t],
@@ -115,7 +121,8 @@ EXPORTED = ["ctl_version", "ctl_last_error", "ctl_conv_wpack_floats", "ctl_conv_
             "ctl_latent_mask_apply", "ctl_latent_mask_apply_ws_floats", "ctl_dropout2d", "ctl_uniform", "ctl_adam", "ctl_plan_run", "ctl_sizeof_op",
             "ctl_sizeof_conv", "ctl_prof_start", "ctl_prof_stop", "ctl_pack_weights_batched",
             "ctl_wgrad_reduce_batched", "ctl_confusion_hist", "ctl_rescale_intensity_ws_floats", "ctl_rescale_intensity",
-            "ctl_noise_clamp", "ctl_crop_or_pad"]
+            "ctl_noise_clamp", "ctl_crop_or_pad", "ctl_step_tick", "ctl_dropout2d_ex", "ctl_uniform_dev", "ctl_adam_dev",
+            "ctl_latent_mask_fused_ws_floats", "ctl_latent_mask_fused"]
 
 
 def prof_start(kernel_filter: str = "") -> None:

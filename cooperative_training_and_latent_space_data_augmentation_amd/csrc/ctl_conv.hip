@@ -1108,9 +1108,12 @@ int ctl_conv_pick_cfg(const ctl_conv* d, ctl_conv_cfg* c, int for_wgrad) {
         mt = 1; tw = 16;
     }
     {   // tuning hook (tools/bench_conv.py): CTL_FORCE_CFG="mt,tw,nt" overrides the heuristic when the combination is valid
-        const char* f = getenv("CTL_FORCE_CFG");
-        int fm, ft, fn;
-        if (f && sscanf(f, "%d,%d,%d", &fm, &ft, &fn) == 3) {
+        static int fm = 0, ft = 0, fn = 0;                 // read ONCE per process (this runs on every conv launch)
+        static const bool forced = [] {
+            const char* f = getenv("CTL_FORCE_CFG");
+            return f && sscanf(f, "%d,%d,%d", &fm, &ft, &fn) == 3;
+        }();
+        if (forced) {
             const bool tile_ok = (fm == 4 && ft == 32 && d->stride == 1 && !for_wgrad) || (fm == 2 && ft == 16) || (fm == 1 && ft == 16);
             if (tile_ok) { mt = fm; tw = ft; }
             if ((fn == 1 || fn == 2) && c->cot % fn == 0) c->nt = fn;

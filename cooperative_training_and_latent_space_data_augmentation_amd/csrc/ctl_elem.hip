@@ -425,8 +425,14 @@ __global__ __launch_bounds__(EB) void argmax_kernel(const float* __restrict__ lo
 // ------------------------------------------------------------------------------------------------ Adam
 __global__ __launch_bounds__(EB) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, int64_t count, float lr, float b1, float b2,
-                                                   float eps, float bc1, float bc2_sqrt, float gscale) {
+                                                   float eps, float bc1, float bc2_sqrt, float gscale,
+                                                   const int64_t* __restrict__ state) {
     // torch.optim.Adam (no amsgrad, no weight decay): denom = sqrt(v)/sqrt(bc2) + eps; p -= lr/bc1 * m/denom
+    if (state) {      // step count lives on the device (HIP-graph replays): same double-precision bias corrections as the host path
+        const double st = (double)state[2];
+        bc1 = (float)(1.0 - pow((double)b1, st));
+        bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, st));
+    }
     const int64_t stride = (int64_t)gridDim.x * EB;
     const float step_size = lr / bc1;
     for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < count; i += stride) {
@@ -612,7 +618,14 @@ extern "C" int ctl_adam(float* p, const float* g, float* m, float* v, int64_t co
     const double bc1 = 1.0 - pow((double)beta1, (double)step);
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
     adam_kernel<<<dim3(stream_blocks(count)), dim3(EB), 0, S_>>>(p, g, m, v, count, lr, beta1, beta2, eps, (float)bc1,
-                                                                 (float)sqrt(bc2), grad_scale);
+                                                                 (float)sqrt(bc2), grad_scale, nullptr);
     CTL_LAUNCH_CHECK("adam");
+    return CTL_OK;
+}
+extern "C" int ctl_adam_dev(float* p, const float* g, float* m, float* v, int64_t count, float lr, float beta1, float beta2,
+                            float eps, const int64_t* state, float grad_scale, ctl_stream stream) {
+    CTL_REQUIRE(p && g && m && v && count > 0 && state, "adam_dev: bad arguments");
+    adam_kernel<<<dim3(stream_blocks(count)), dim3(EB), 0, S_>>>(p, g, m, v, count, lr, beta1, beta2, eps, 1.f, 1.f, grad_scale, state);
+    CTL_LAUNCH_CHECK("adam_dev");
     return CTL_OK;
 }

@@ -14,7 +14,13 @@
 #define MB 256
 // pixels per block in the channel-mode score pass: 64 keeps the tiny configured problem (hw = 256) spread over 64 blocks;
 // large problems use 512-pixel slabs (more bytes in flight per block, 8x fewer partial rows)
-static inline int score_split_pix(int hw) { return hw >= 4096 ? 512 : 64; }
+// (the split fixes the summation order of the channel scores: the three-launch path and the fused kernel share it, so their scores are
+// bit-identical; >= ~1024 partial sums in flight where the problem allows)
+static inline int score_split_pix(int n, int hw) {
+    int sp = 512;
+    while (sp > 64 && (int64_t)n * ctl_cdiv(hw, sp) < 1024) sp >>= 1;
+    return sp;
+}
 
 // ---- channel mode, pass 1: partial[n][split][c] = sum over the split's pixels of grad[n][pix][c]
 __global__ __launch_bounds__(MB) void score_channel_partial_kernel(const f32x4* __restrict__ grad,
@@ -172,6 +178,124 @@ __global__ __launch_bounds__(MB) void mask_apply_thr_kernel(const f32x4* __restr
     }
 }
 
+// ---- ONE launch for the whole generator tail at latent-code sizes: one 1024-thread block per IMAGE, no
+// inter-block communication at all.  The block requests its image's grad AND code up front (all loads in flight at once), builds
+// the score row in LDS with exactly the summation order of the three-launch path (4 "virtual" 256-thread blocks each reduce one
+// 64-pixel split the way score_channel_partial_kernel does, then the splits are added in order like score_channel_finalize_kernel:
+// bit-identical scores), ranks (strict '>' of the reference, exact under ties) and stores code * mask from the registers it already holds.
+// Why not a multi-block kernel with a grid barrier (built and measured on MI355X, profiles/README.md): the 8 XCDs' L2s are not
+// coherent with each other, an agent-scope release is a write-back of the whole L2 per block (~60 us per launch at 128 blocks), and
+// even a fence-free barrier (write-through stores + relaxed atomics) pays ~0.15 us per same-address atomic, i.e. ~25 us at 128
+// blocks -- two kernel boundaries (~3 us each) are cheaper.  Hence: images up to 64 Ki elements take this kernel, larger problems
+// the HBM-streaming three-launch path (72 % of 8 TB/s at 128 MiB), both behind ctl_latent_mask_fused.
+#define IB 1024
+#define IPF 16      // quads of grad / code a thread holds: 1024 * 16 * 4 = 64 Ki elements per image
+template <int MODE>
+__global__ __launch_bounds__(IB) void latent_mask_image_kernel(const f32x4* __restrict__ grad, const f32x4* __restrict__ code,
+                                                                const float* __restrict__ soft_noise, int k_host,
+                                                                const int* __restrict__ k_dev, f32x4* __restrict__ masked,
+                                                                float* __restrict__ mask_out, float* __restrict__ score_out, int hw,
+                                                                int cq, int split_pix, int splits, int S, int slab_pix) {
+    // S blocks per image (small batches: more CUs at work): every block builds the WHOLE score row (the image's grad is re-read
+    // from L2 by its S blocks) but holds and stores only its own slab of the code
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int c = cq * 4, img = blockIdx.x / S, sl = blockIdx.x - img * S, tid = threadIdx.x;
+    const int L = (MODE == 0) ? c : hw;
+    float* srow = sm;                                                   // [L]
+    float* mval = sm + L;                                               // [L]
+    f32x4* red = reinterpret_cast<f32x4*>(mval + L);                    // [IB]
+    float* part = reinterpret_cast<float*>(red + IB);                   // [splits][c] (channel mode)
+    const int64_t base = (int64_t)img * hw * cq;
+    const int px0 = sl * slab_pix, px1 = min(hw, px0 + slab_pix);
+    const int quads = max(px1 - px0, 0) * cq, qoff = px0 * cq;          // this block's slab of the image
+    f32x4 cv[IPF];
+#pragma unroll
+    for (int j = 0; j < IPF; ++j) {                                     // code: consumed last, requested first
+        const int e = tid + j * IB;
+        cv[j] = e < quads ? code[base + qoff + e] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (MODE == 0) {
+        // virtual block vb reduces splits vb, vb + 4, ...: thread lt of it sums pixels p0 + prow, p0 + prow + ppb, ... (in that order)
+        const int vb = tid >> 8, lt = tid & 255;
+        const int q = lt % cq, prow = lt / cq, ppb = 256 / cq;
+        for (int sp0 = 0; sp0 < splits; sp0 += 4) {
+            const int sp = sp0 + vb;
+            f32x4 s = {0.f, 0.f, 0.f, 0.f};
+            if (sp < splits) {
+                const int p0 = sp * split_pix, p1 = min(hw, p0 + split_pix);
+                for (int pix = p0 + prow; pix < p1; pix += ppb) {
+                    const f32x4 v = grad[base + (int64_t)pix * cq + q];
+                    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+                }
+            }
+            red[tid] = s;
+            __syncthreads();
+            if (lt < cq && sp < splits) {
+                f32x4 t = {0.f, 0.f, 0.f, 0.f};
+                for (int kk = lt; kk < 256; kk += cq) { const f32x4 v = red[(vb << 8) + kk]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+                reinterpret_cast<f32x4*>(part)[sp * cq + lt] = t;
+            }
+            __syncthreads();
+        }
+        const float inv = 1.f / (float)hw;
+        for (int ch = tid; ch < c; ch += IB) {
+            float a = 0.f;
+            for (int s2 = 0; s2 < splits; ++s2) a += part[s2 * c + ch];
+            srow[ch] = a * inv;
+        }
+    } else {
+        // a group of cq lanes owns a pixel (cq | 64): the order of score_spatial_kernel
+        // (quad tid + j*IB of the image = channel quad tid % cq of pixel tid / cq + j * IB / cq: all of a thread's loads go out at once)
+        const int q = tid % cq, prow = tid / cq, ppb = IB / cq;
+        const int allq = hw * cq;
+        f32x4 gv[IPF];
+#pragma unroll
+        for (int j = 0; j < IPF; ++j) {
+            const int e = tid + j * IB;
+            gv[j] = e < allq ? grad[base + e] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int j = 0; j < IPF; ++j) {
+            const int pix = prow + j * ppb;
+            float sc = (gv[j].x + gv[j].y) + (gv[j].z + gv[j].w);
+            for (int o = cq >> 1; o > 0; o >>= 1) sc += __shfl_xor(sc, o);
+            if (q == 0 && pix < hw) srow[pix] = sc * (1.f / (float)c);
+        }
+    }
+    __syncthreads();
+    int k = k_dev ? k_dev[0] : k_host;
+    k = k < 0 ? 0 : (k > L - 1 ? L - 1 : k);
+    // entries this block needs: every channel (channel mode) / the pixels of its slab (spatial mode)
+    const int i0 = (MODE == 0) ? 0 : px0, i1 = (MODE == 0) ? c : px1;
+    for (int i = i0 + tid; i < i1; i += IB) {
+        const float si = srow[i];
+        int ge = 0;
+        for (int j = 0; j < L; ++j) ge += (srow[j] >= si) ? 1 : 0;
+        const float mv = (ge <= k) ? (soft_noise ? 0.5f * soft_noise[(int64_t)img * L + i] : 0.f) : 1.f;
+        mval[i] = mv;
+        if (MODE == 1 || sl == 0) {
+            mask_out[(int64_t)img * L + i] = mv;
+            if (score_out) score_out[(int64_t)img * L + i] = si;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < IPF; ++j) {
+        const int e = tid + j * IB;
+        if (e < quads) {
+            f32x4 v = cv[j];
+            if (MODE == 0) {
+                const f32x4 m = reinterpret_cast<const f32x4*>(mval)[e % cq];      // (qoff is a multiple of cq)
+                v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
+            } else {
+                const float m = mval[px0 + e / cq];
+                v.x *= m; v.y *= m; v.z *= m; v.w *= m;
+            }
+            masked[base + qoff + e] = v;
+        }
+    }
+}
+
 // ---- dropout2d and uniform noise from a counter hash (splitmix64): stateless, graph-replay safe given a seed buffer
 __device__ __forceinline__ float hash_uniform(uint64_t seed, uint64_t idx) {
     uint64_t z = seed + (idx + 1) * 0x9E3779B97F4A7C15ull;
@@ -180,12 +304,21 @@ __device__ __forceinline__ float hash_uniform(uint64_t seed, uint64_t idx) {
     z = z ^ (z >> 31);
     return (float)(z >> 40) * (1.0f / 16777216.0f);   // 24 random bits -> [0,1)
 }
+// Device-resident RNG state (HIP-graph replays: nothing may be baked into the launch): state[0] = seed, state[1] = step counter
+// advanced once per training step by ctl_step_tick; `salt` separates the call sites of one step.
+__device__ __forceinline__ uint64_t state_seed(const int64_t* __restrict__ state, uint64_t salt) {
+    uint64_t z = (uint64_t)state[0] + ((uint64_t)state[1] + 1) * 0xD1B54A32D192ED03ull + salt * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 32)) * 0xBF58476D1CE4E5B9ull;
+    return z ^ (z >> 29);
+}
 __global__ __launch_bounds__(MB) void dropout2d_kernel(const f32x4* __restrict__ z, const float* __restrict__ keep,
-                                                        uint64_t seed, float p, f32x4* __restrict__ out,
-                                                        float* __restrict__ keep_out, int hw, int cq, int slab_pix) {
+                                                        uint64_t seed, const int64_t* __restrict__ state, float p,
+                                                        f32x4* __restrict__ out, float* __restrict__ keep_out,
+                                                        f32x4* __restrict__ mask_full, int hw, int cq, int slab_pix) {
     extern __shared__ __attribute__((aligned(16))) float sm[];     // [c] multipliers
     const int c = cq * 4, n = blockIdx.y;
     const float inv = 1.f / (1.f - p);
+    if (state) seed = state_seed(state, seed);
     for (int ch = threadIdx.x; ch < c; ch += MB) {
         float kp = keep ? keep[(int64_t)n * c + ch] : (hash_uniform(seed, (uint64_t)n * c + ch) >= p ? 1.f : 0.f);
         if (keep_out && blockIdx.x == 0) keep_out[(int64_t)n * c + ch] = kp;
@@ -198,11 +331,16 @@ __global__ __launch_bounds__(MB) void dropout2d_kernel(const f32x4* __restrict__
     for (int e = threadIdx.x; e < quads; e += MB) {
         f32x4 v = z[base + e];
         const f32x4 m = reinterpret_cast<const f32x4*>(sm)[e % cq];
+        const f32x4 in = v;
         v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
         out[base + e] = v;
+        // upstream's `mask` (model.py:334-336): 1 where the dropped-out tensor EQUALS the input, else 0
+        if (mask_full) mask_full[base + e] = f32x4{v.x == in.x ? 1.f : 0.f, v.y == in.y ? 1.f : 0.f, v.z == in.z ? 1.f : 0.f, v.w == in.w ? 1.f : 0.f};
     }
 }
-__global__ __launch_bounds__(MB) void uniform_kernel(float* __restrict__ out, int64_t count, uint64_t seed) {
+__global__ __launch_bounds__(MB) void uniform_kernel(float* __restrict__ out, int64_t count, uint64_t seed,
+                                                      const int64_t* __restrict__ state) {
+    if (state) seed = state_seed(state, seed);
     const int64_t stride = (int64_t)gridDim.x * MB;
     for (int64_t i = (int64_t)blockIdx.x * MB + threadIdx.x; i < count; i += stride) out[i] = hash_uniform(seed, (uint64_t)i);
 }
@@ -218,7 +356,7 @@ static int slab_pixels(int n, int hw, int c) {
 }
 
 extern "C" size_t ctl_latent_score_ws_floats(int32_t mode, int32_t n, int32_t hw, int32_t c) {
-    return mode == 0 ? (size_t)n * ctl_cdiv(hw, score_split_pix(hw)) * c : 0;
+    return mode == 0 ? (size_t)n * ctl_cdiv(hw, score_split_pix(n, hw)) * c : 0;
 }
 
 extern "C" int ctl_latent_score(int32_t mode, const float* grad, float* score, float* scratch, int32_t n, int32_t hw,
@@ -228,7 +366,7 @@ extern "C" int ctl_latent_score(int32_t mode, const float* grad, float* score, f
     const int cq = c / 4;
     if (mode == 0) {
         CTL_REQUIRE(scratch, "latent_score: channel mode needs scratch");
-        const int sp_pix = score_split_pix(hw);
+        const int sp_pix = score_split_pix(n, hw);
         const int splits = ctl_cdiv(hw, sp_pix);
         score_channel_partial_kernel<<<dim3(splits, n), dim3(MB), 0, s>>>((const f32x4*)grad, scratch, hw, cq, splits, sp_pix);
         score_channel_finalize_kernel<<<dim3(ctl_cdiv(c, 64), n), dim3(64), 0, s>>>(scratch, score, c, splits, 1.f / (float)hw);
@@ -286,21 +424,100 @@ extern "C" int ctl_latent_mask_apply(int32_t mode, const float* code, const floa
     return CTL_OK;
 }
 
-extern "C" int ctl_dropout2d(const float* z, const float* keep, uint64_t seed, float p, float* out, float* keep_out,
-                             int32_t n, int32_t hw, int32_t c, ctl_stream stream) {
-    CTL_REQUIRE(z && out && n > 0 && hw > 0 && cq_ok(c) && p >= 0.f && p < 1.f, "dropout2d: bad arguments");
-    const int sp = slab_pixels(n, hw, c);
-    dropout2d_kernel<<<dim3(ctl_cdiv(hw, sp), n), dim3(MB), (size_t)c * sizeof(float), (hipStream_t)stream>>>(
-        (const f32x4*)z, keep, seed, p, (f32x4*)out, keep_out, hw, c / 4, sp);
-    CTL_LAUNCH_CHECK("dropout2d");
+
+// ---- fused generator tail, host side
+static bool image_kernel_ok(int mode, int hw, int c) {
+    const int L = mode == 0 ? c : hw, cq = c / 4;
+    return (int64_t)hw * c <= (int64_t)IB * IPF * 4 && L <= 1024 && 256 % cq == 0;
+}
+extern "C" size_t ctl_latent_mask_fused_ws_floats(int32_t mode, int32_t n, int32_t hw, int32_t c) {
+    if (image_kernel_ok(mode, hw, c)) return 0;
+    const size_t L = mode == 0 ? c : hw;          // multi-launch path: [score n*L][ctl_latent_score scratch][ctl_latent_mask_apply scratch]
+    return (size_t)n * L + ctl_latent_score_ws_floats(mode, n, hw, c) + ctl_latent_mask_apply_ws_floats(mode, n, hw, c);
+}
+extern "C" int ctl_latent_mask_fused(int32_t mode, const float* grad, const float* code, const float* soft_noise, int32_t k_host,
+                                     const int32_t* k_dev, float* masked, float* mask_out, float* score_out, float* workspace,
+                                     int32_t n, int32_t hw, int32_t c, ctl_stream stream) {
+    CTL_REQUIRE(grad && code && masked && mask_out && n > 0 && hw > 0 && cq_ok(c), "latent_mask_fused: bad arguments (c=%d)", c);
+    CTL_REQUIRE(mode == 0 || mode == 1, "latent_mask_fused: mode %d", mode);
+    const int L = mode == 0 ? c : hw;
+    CTL_REQUIRE(L <= 8192, "latent_mask_fused: row length %d > 8192", L);
+    CTL_REQUIRE(k_dev || (k_host >= 0 && k_host < L), "latent_mask_fused: k=%d out of range [0,%d)", k_host, L);
+    hipStream_t s = (hipStream_t)stream;
+    if (image_kernel_ok(mode, hw, c)) {
+        const int split_pix = score_split_pix(n, hw), splits = ctl_cdiv(hw, split_pix);
+        const size_t lds = ((size_t)2 * L + (mode == 0 ? (size_t)splits * c : 0)) * sizeof(float) + (size_t)IB * sizeof(f32x4);
+        int S = 1;                                    // blocks per image: at least ~64 blocks in flight when the batch is small
+        while (S < 8 && n * S < 64 && hw / (2 * S) >= 8) S *= 2;
+        const int slab_pix = ctl_cdiv(hw, S);
+        if (mode == 0)
+            latent_mask_image_kernel<0><<<dim3(n * S), dim3(IB), lds, s>>>((const f32x4*)grad, (const f32x4*)code, soft_noise, k_host, k_dev,
+                                                                          (f32x4*)masked, mask_out, score_out, hw, c / 4, split_pix, splits, S, slab_pix);
+        else
+            latent_mask_image_kernel<1><<<dim3(n * S), dim3(IB), lds, s>>>((const f32x4*)grad, (const f32x4*)code, soft_noise, k_host, k_dev,
+                                                                          (f32x4*)masked, mask_out, score_out, hw, c / 4, split_pix, splits, S, slab_pix);
+        CTL_LAUNCH_CHECK("latent_mask_fused");
+        return CTL_OK;
+    }
+    // HBM-streaming sizes: the score pass, the (long-row) threshold and the apply pass as separate launches
+    CTL_REQUIRE(workspace, "latent_mask_fused: this size needs ctl_latent_mask_fused_ws_floats() floats of workspace");
+    float* score = workspace;
+    float* ws_score = score + (size_t)n * L;
+    float* ws_apply = ws_score + ctl_latent_score_ws_floats(mode, n, hw, c);
+    int rc = ctl_latent_score(mode, grad, score, ws_score, n, hw, c, stream);
+    if (rc != CTL_OK) return rc;
+    rc = ctl_latent_mask_apply(mode, code, score, soft_noise, k_host, k_dev, masked, mask_out, ws_apply, n, hw, c, stream);
+    if (rc != CTL_OK) return rc;
+    if (score_out) {
+        hipError_t e = hipMemcpyAsync(score_out, score, (size_t)n * L * sizeof(float), hipMemcpyDeviceToDevice, s);
+        if (e != hipSuccess) CTL_FAIL(CTL_ELAUNCH, "latent_mask_fused: %s", hipGetErrorString(e));
+    }
     return CTL_OK;
 }
 
-extern "C" int ctl_uniform(float* out, int64_t count, uint64_t seed, ctl_stream stream) {
+static int dropout2d_launch(const float* z, const float* keep, uint64_t seed, const int64_t* state, float p, float* out,
+                            float* keep_out, float* mask_full, int32_t n, int32_t hw, int32_t c, ctl_stream stream) {
+    CTL_REQUIRE(z && out && n > 0 && hw > 0 && cq_ok(c) && p >= 0.f && p < 1.f, "dropout2d: bad arguments");
+    const int sp = slab_pixels(n, hw, c);
+    dropout2d_kernel<<<dim3(ctl_cdiv(hw, sp), n), dim3(MB), (size_t)c * sizeof(float), (hipStream_t)stream>>>(
+        (const f32x4*)z, keep, seed, state, p, (f32x4*)out, keep_out, (f32x4*)mask_full, hw, c / 4, sp);
+    CTL_LAUNCH_CHECK("dropout2d");
+    return CTL_OK;
+}
+extern "C" int ctl_dropout2d(const float* z, const float* keep, uint64_t seed, float p, float* out, float* keep_out,
+                             int32_t n, int32_t hw, int32_t c, ctl_stream stream) {
+    return dropout2d_launch(z, keep, seed, nullptr, p, out, keep_out, nullptr, n, hw, c, stream);
+}
+extern "C" int ctl_dropout2d_ex(const float* z, const float* keep, uint64_t seed_or_salt, const int64_t* state, float p,
+                                float* out, float* keep_out, float* mask_full, int32_t n, int32_t hw, int32_t c,
+                                ctl_stream stream) {
+    return dropout2d_launch(z, keep, seed_or_salt, state, p, out, keep_out, mask_full, n, hw, c, stream);
+}
+
+static int uniform_launch(float* out, int64_t count, uint64_t seed, const int64_t* state, ctl_stream stream) {
     CTL_REQUIRE(out && count > 0, "uniform: bad arguments");
     int64_t blocks = ctl_cdiv64(count, MB);
     if (blocks > 2048) blocks = 2048;
-    uniform_kernel<<<dim3((unsigned)blocks), dim3(MB), 0, (hipStream_t)stream>>>(out, count, seed);
+    uniform_kernel<<<dim3((unsigned)blocks), dim3(MB), 0, (hipStream_t)stream>>>(out, count, seed, state);
     CTL_LAUNCH_CHECK("uniform");
+    return CTL_OK;
+}
+extern "C" int ctl_uniform(float* out, int64_t count, uint64_t seed, ctl_stream stream) {
+    return uniform_launch(out, count, seed, nullptr, stream);
+}
+extern "C" int ctl_uniform_dev(float* out, int64_t count, uint64_t salt, const int64_t* state, ctl_stream stream) {
+    CTL_REQUIRE(state, "uniform_dev: null state");
+    return uniform_launch(out, count, salt, state, stream);
+}
+
+// One launch at the head of a (graph-replayed) training step: advances the device-resident step state
+//   state[0] RNG seed (constant)   state[1] RNG step counter   state[2] Adam step count
+__global__ void step_tick_kernel(int64_t* state) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) { state[1] += 1; state[2] += 1; }
+}
+extern "C" int ctl_step_tick(int64_t* state, ctl_stream stream) {
+    CTL_REQUIRE(state, "step_tick: null state");
+    step_tick_kernel<<<dim3(1), dim3(64), 0, (hipStream_t)stream>>>(state);
+    CTL_LAUNCH_CHECK("step_tick");
     return CTL_OK;
 }

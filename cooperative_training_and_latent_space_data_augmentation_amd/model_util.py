@@ -91,14 +91,14 @@ def _mask(latent_code, decoder_function, label, num_classes, percentile, random,
     code, grad = _saliency_grad(latent_code, decoder_function, label, num_classes, loss_type)
     n, c, h, w = code.shape
     L = c if mode == 0 else h * w
-    score = ops.latent_score(grad, mode)
     if k is None:
         if random:
             percentile = np.random.rand() * percentile
         k = int(L * percentile)
     if if_soft and soft_noise is None:
         soft_noise = ops.uniform((n, L), code.device, _draw_seed())
-    masked, mask = ops.latent_mask_apply(code, score, mode, k, soft_noise if if_soft else None)
+    # score -> rank-select -> apply in ONE launch (the three-launch path ops.latent_score + ops.latent_mask_apply computes the same bits)
+    masked, mask = ops.latent_mask(grad, code, mode, k, soft_noise if if_soft else None)
     if not if_detach:
         masked = latent_code * mask
     if hasattr(decoder_function, "zero_grad"):

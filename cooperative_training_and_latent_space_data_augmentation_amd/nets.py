@@ -97,6 +97,42 @@ class Arena:
         return T(self.alloc(4 * n * h * w * c), n, h, w, c)
 
 
+class _ArenaLease:
+    """One activation / backward arena on loan from a network's pool; goes back to the free list when the last holder (the autograd
+    context of the pass) dies."""
+    __slots__ = ("free", "t")
+
+    def __init__(self, free, t):
+        self.free, self.t = free, t
+
+    def __del__(self):
+        if self.free is not None:
+            self.free.append(self.t)
+
+
+class ArenaPool:
+    """Plan workspaces (saved activations: 289 MB for a bs16 256^2 decoder pass) are recycled per (stream, size) instead of going
+    through the caching allocator every pass: with two launch chains its block reuse depends on event timing, and a device
+    allocation inside a training step is a stall (bench.py counts them).  Reuse is safe without events: an arena is only handed out
+    again on the stream it was last used on (forward and backward of a pass run on one stream), i.e. in launch order.  Under HIP-graph
+    capture the pool is bypassed (the graph's private pool owns that memory)."""
+
+    def __init__(self):
+        self._free: Dict[tuple, list] = {}
+
+    def acquire(self, nbytes: int, device) -> "_ArenaLease":
+        nbytes = max(int(nbytes), 256)
+        if torch.cuda.is_current_stream_capturing():
+            return _ArenaLease(None, torch.empty(nbytes, dtype=torch.uint8, device=device))
+        free = self._free.setdefault((torch.cuda.current_stream().cuda_stream, nbytes), [])
+        t = free.pop() if free else torch.empty(nbytes, dtype=torch.uint8, device=device)
+        return _ArenaLease(free, t)
+
+    def clear(self):
+        for lst in self._free.values():
+            lst.clear()
+
+
 class Plan:
     __slots__ = ("ops", "n_ops", "act_bytes", "scr_bytes", "bscr_bytes", "rec", "out_shapes", "table_np", "table_dev", "groups")
 
@@ -366,7 +402,9 @@ class CtlNet(nn.Module):
         self._bns: Dict[str, BNInfo] = {}
         self._plans: Dict[tuple, Plan] = {}
         self._packed_ok = False
+        self._grad_written = True          # see zero_grad / FlatAdam.step
         self._scr: Optional[dict] = None          # stream handle -> scratch tensor
+        self._arenas = ArenaPool()
         self._build_tree()
         self._finalize_storage(torch.device(device))
 
@@ -492,6 +530,7 @@ class CtlNet(nn.Module):
         assert buf.numel() == self._pcount and buf.dtype == torch.float32 and buf.device == self._flat_data.device
         buf.copy_(self._flat.grad)
         self._flat.grad = buf
+        self._grad_written = True
         for n, p in self.named_parameters():
             p.grad = buf[self._poff[n]:self._poff[n] + p.numel()].view(p.shape)
 
@@ -499,6 +538,11 @@ class CtlNet(nn.Module):
         """Gradients are views of one flat buffer that is never re-allocated: zero it in place.  (upstream calls
         `decoder_function.zero_grad()` inside the masking functions, model_util.py:251-254)"""
         self._flat.grad.zero_()
+        self._grad_written = False        # FlatAdam skips a network no backward pass has written since (torch: `.grad is None`)
+
+    def mark_grad_written(self):
+        """Call after filling `.grad` by other means than a backward pass of this network (e.g. a hand-written gradient)."""
+        self._grad_written = True
 
     def weights_changed(self):
         """Call after modifying parameters in place by other means than the engine's optimizer / load_state_dict."""
@@ -727,9 +771,9 @@ class CtlNet(nn.Module):
             finally:
                 self._cur_groups = 1
         self.ensure_packed()
-        act = torch.empty(max(plan.act_bytes, 256), dtype=torch.uint8, device=self.device)
+        act = self._arenas.acquire(plan.act_bytes, self.device)        # lease: lives as long as the autograd context of this pass
         outs = [self._alloc_out(s) for s in plan.out_shapes]
-        tensors = {S_X: x, S_P: self._flat_data, S_B: self._bflat, S_NBT: self._nbt, S_WP: self._wp, S_ACT: act, S_OUT0: outs[0]}
+        tensors = {S_X: x, S_P: self._flat_data, S_B: self._bflat, S_NBT: self._nbt, S_WP: self._wp, S_ACT: act.t, S_OUT0: outs[0]}
         if len(outs) > 1:
             tensors[S_OUT1] = outs[1]
         self._run(plan, tensors)
@@ -747,9 +791,11 @@ class CtlNet(nn.Module):
                 plan = self._plans[key] = self._compile_backward(fwd_plan, mode, mask, need_dx, need_w, affine)
             finally:
                 self._cur_groups = 1
-        bscr = torch.empty(max(plan.bscr_bytes, 256), dtype=torch.uint8, device=self.device)
-        self._dbg_last = (plan, bscr)          # lets tests inspect intermediate gradients
-        tensors = {S_X: x, S_P: self._flat_data, S_WP: self._wp, S_ACT: act, S_BSCR: bscr, S_OUT0: outs[0]}
+        lease = self._arenas.acquire(plan.bscr_bytes, self.device)
+        bscr = lease.t
+        self._dbg_last = (plan, bscr)          # lets tests inspect intermediate gradients (valid until the next pass on this stream:
+                                               # the lease ends with this call and the arena is then reused in launch order)
+        tensors = {S_X: x, S_P: self._flat_data, S_WP: self._wp, S_ACT: act.t, S_BSCR: bscr, S_OUT0: outs[0]}
         if len(outs) > 1:
             tensors[S_OUT1] = outs[1]
         for slot, d in zip((S_DOUT0, S_DOUT1), douts):
@@ -762,6 +808,7 @@ class CtlNet(nn.Module):
         if need_w:
             gflat = torch.empty(self._pcount, dtype=torch.float32, device=self.device)
             tensors[S_GRAD] = gflat
+            self._grad_written = True
         self._run(plan, tensors)
         return dx, gflat
 
@@ -935,9 +982,9 @@ class Dual_Branch_Encoder(MyEncoder):
         if plan is None:
             plan = self._plans[key] = self._compile_filter(n, h, w, mode)
         self.ensure_packed()
-        act = torch.empty(max(plan.act_bytes, 256), dtype=torch.uint8, device=self.device)
+        act = self._arenas.acquire(plan.act_bytes, self.device)
         out = self._alloc_out(plan.out_shapes[0])
-        self._run(plan, {S_X: z, S_P: self._flat_data, S_B: self._bflat, S_NBT: self._nbt, S_WP: self._wp, S_ACT: act, S_OUT0: out})
+        self._run(plan, {S_X: z, S_P: self._flat_data, S_B: self._bflat, S_NBT: self._nbt, S_WP: self._wp, S_ACT: act.t, S_OUT0: out})
         return out
 
 

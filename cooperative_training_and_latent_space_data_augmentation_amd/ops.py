@@ -201,30 +201,73 @@ def latent_mask_apply(code: torch.Tensor, score: torch.Tensor, mode: int, k, sof
     return masked, (mask.view(n, c, 1, 1) if mode == 0 else mask.view(n, 1, h, w))
 
 
-def dropout2d(z: torch.Tensor, p: float, keep: Optional[torch.Tensor] = None, seed: int = 0):
-    """Returns (out, keep[N,C]).  keep=None draws the Bernoulli pattern on device from `seed`."""
+def latent_mask(grad: torch.Tensor, code: torch.Tensor, mode: int, k, soft_noise: Optional[torch.Tensor] = None, want_score: bool = False):
+    """The generator tail behind one call (`ctl_latent_mask_fused`): signed-mean score of `grad`, rank-select of the top-k entries
+    (strict '>', exact under ties), masked = code * mask; ONE launch at latent-code sizes.  Returns (masked, mask[, score]); mask is
+    [N,C,1,1] (mode 0) or [N,1,H,W] (mode 1).  `k`: int or 1-element int32 device tensor (graph replay)."""
+    require_gpu(grad, code)
+    grad, code = as_nhwc(grad), as_nhwc(code)
+    n, c, h, w = code.shape
+    if grad.shape != code.shape:
+        raise ValueError("latent_mask: grad and code must have the same shape")
+    L = c if mode == 0 else h * w
+    masked = torch.empty_like(code)
+    mask = torch.empty((n, L), dtype=torch.float32, device=code.device)
+    score = torch.empty((n, L), dtype=torch.float32, device=code.device) if want_score else None
+    k_dev = k if isinstance(k, torch.Tensor) else None
+    k_host = 0 if k_dev is not None else int(k)
+    if soft_noise is not None:
+        soft_noise = soft_noise.reshape(n, L).float().contiguous()
+    need = lib.ctl_latent_mask_fused_ws_floats(mode, n, h * w, c)
+    ws = torch.empty(need, dtype=torch.float32, device=code.device) if need else None
+    check(lib.ctl_latent_mask_fused(mode, ptr(grad), ptr(code), ptr(soft_noise), k_host, ptr(k_dev), ptr(masked), ptr(mask), ptr(score),
+                                    ptr(ws), n, h * w, c, stream_ptr()), "ctl_latent_mask_fused")
+    mask = mask.view(n, c, 1, 1) if mode == 0 else mask.view(n, 1, h, w)
+    return (masked, mask, score) if want_score else (masked, mask)
+
+
+def dropout2d(z: torch.Tensor, p: float, keep: Optional[torch.Tensor] = None, seed: int = 0, state: Optional[torch.Tensor] = None,
+              want_mask: bool = False):
+    """Returns (out, keep[N,C]) or, with want_mask, (out, keep, mask) where mask is upstream's full-size equality mask
+    (model.py:334-336).  keep=None draws the Bernoulli pattern on device from `seed`; with `state` (device int64[3], see
+    ctl_step_tick) `seed` is a call-site salt and nothing step-dependent is baked into the launch (HIP-graph replay)."""
     require_gpu(z)
     z = as_nhwc(z)
     n, c, h, w = z.shape
     out = torch.empty_like(z)
     keep_out = torch.empty((n, c), dtype=torch.float32, device=z.device)
+    mask = torch.empty_like(z) if want_mask else None
     if keep is not None:
         keep = keep.reshape(n, c).float().contiguous()
-    check(lib.ctl_dropout2d(ptr(z), ptr(keep), seed & (2 ** 64 - 1), p, ptr(out), ptr(keep_out), n, h * w, c, stream_ptr()),
-          "ctl_dropout2d")
-    return out, keep_out
+    check(lib.ctl_dropout2d_ex(ptr(z), ptr(keep), seed & (2 ** 64 - 1), ptr(state), p, ptr(out), ptr(keep_out), ptr(mask), n, h * w, c,
+                               stream_ptr()), "ctl_dropout2d_ex")
+    return (out, keep_out, mask) if want_mask else (out, keep_out)
 
 
-def uniform(shape, device, seed: int) -> torch.Tensor:
+def uniform(shape, device, seed: int, state: Optional[torch.Tensor] = None) -> torch.Tensor:
     out = torch.empty(shape, dtype=torch.float32, device=device)
-    check(lib.ctl_uniform(ptr(out), out.numel(), seed & (2 ** 64 - 1), stream_ptr()), "ctl_uniform")
+    if state is not None:
+        check(lib.ctl_uniform_dev(ptr(out), out.numel(), seed & (2 ** 64 - 1), ptr(state), stream_ptr()), "ctl_uniform_dev")
+    else:
+        check(lib.ctl_uniform(ptr(out), out.numel(), seed & (2 ** 64 - 1), stream_ptr()), "ctl_uniform")
     return out
 
 
-def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
+def step_tick(state: torch.Tensor) -> None:
+    """Advance the device-resident step state (RNG counter, Adam step): one launch at the head of a graph-replayed step."""
+    require_gpu(state)
+    assert state.dtype == torch.int64 and state.numel() >= 3
+    check(lib.ctl_step_tick(ptr(state), stream_ptr()), "ctl_step_tick")
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0, state: Optional[torch.Tensor] = None):
     require_gpu(p, g, m, v)
-    check(lib.ctl_adam(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, step, grad_scale, stream_ptr()),
-          "ctl_adam")
+    if state is not None:       # step count read from state[2] on the device
+        check(lib.ctl_adam_dev(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, ptr(state), grad_scale, stream_ptr()),
+              "ctl_adam_dev")
+    else:
+        check(lib.ctl_adam(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, step, grad_scale, stream_ptr()),
+              "ctl_adam")
 
 
 # ---------------------------------------------------------------------------------------------- SURVEY 8(f): metrics + input pipeline

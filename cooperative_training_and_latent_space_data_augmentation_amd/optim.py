@@ -19,13 +19,19 @@ class FlatAdam:
         self.step_count = 0
 
     def zero_grad(self, set_to_none: bool = False):
-        self.net._flat.grad.zero_()          # gradients are views of this one buffer; it is never re-allocated
+        self.net.zero_grad()                 # gradients are views of one flat buffer that is never re-allocated
 
-    def step(self, closure=None, grad_scale: float = 1.0):
+    def step(self, closure=None, grad_scale: float = 1.0, state=None):
+        """`state`: device int64[3] whose [2] holds the (already advanced) step count -- HIP-graph capture, where the host-side
+        count must not be a launch argument; the host count is still advanced as the mirror that state dicts report.
+        Like torch.optim.Adam (which skips parameters whose `.grad` is None) the step is skipped when no backward pass has written
+        this network's gradient since the last zero_grad() (set_to_none semantics of torch >= 2.0)."""
+        if not self.net._grad_written:
+            return
         g = self.param_groups[0]
         self.step_count += 1
         ops.adam_step(self.net._flat_data, self.net._flat.grad, self.exp_avg, self.exp_avg_sq, g["lr"], g["betas"][0],
-                      g["betas"][1], g["eps"], self.step_count, grad_scale)
+                      g["betas"][1], g["eps"], self.step_count, grad_scale, state=state)
         self.net.weights_changed()
 
     def _views(self, flat):

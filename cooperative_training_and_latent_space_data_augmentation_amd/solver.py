@@ -77,6 +77,12 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
         self._side_pending = False
         self._chain_events = None        # list collecting per-step stream events (tools/chain_timing.py)
         self._in_side = False            # True while the hard-example branch of cooperative_step is being issued on the side stream
+        # HIP-graph capture (graph.py): while set, nothing that changes from step to step may be a launch argument -- RNG seeds and the
+        # Adam step count come from the device int64[3] `_gstate` (advanced by ops.step_tick), random thresholds k from the device
+        # int32 buffers `_gk[...]` that the host refreshes before every replay
+        self._gstate = None
+        self._gk = None
+        self._perturb_calls = 0          # call-site salt of the device RNG within one step
         self.training = True
 
     # ------------------------------------------------------------------ construction / checkpoints
@@ -170,10 +176,10 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
 
     def optimize_all_params(self):
         for o in self.optimizers.values():
-            o.step(grad_scale=self.grad_scale)
+            o.step(grad_scale=self.grad_scale, state=self._gstate)
 
     def optimize_params(self, model_name):
-        self.optimizers[model_name].step(grad_scale=self.grad_scale)
+        self.optimizers[model_name].step(grad_scale=self.grad_scale, state=self._gstate)
 
     def reset_optimizer(self, model_name):
         self.optimizers[model_name].zero_grad()
@@ -409,7 +415,11 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
 
     # ------------------------------------------------------------------ latent-space hard examples (model.py:300-350, 469-523)
     def perturb_latent_code(self, latent_code, decoder_function, label_y=None, perturb_type="random", threshold=0.5,
-                            if_soft=False, random_threshold=False, loss_type="mse", if_detach=False, *, override=None):
+                            if_soft=False, random_threshold=False, loss_type="mse", if_detach=False, *, override=None,
+                            _keep_mask=False):
+        """model.py:300-350.  `mask`: [N,C,1,1] / [N,1,H,W] for the targeted schemes; for 'dropout' upstream's full-size mask
+        (1 where the dropped-out code EQUALS the input element, model.py:334-336) -- `_keep_mask=True` (the solver's own calls,
+        which only log the mask) returns the [N,C,1,1] keep pattern instead and skips that extra pass."""
         assert perturb_type in ["random", "dropout", "spatial", "channel"], "invalid method name"
         ov = override or {}
         perturb_type = ov.get("scheme", perturb_type)
@@ -418,17 +428,30 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
             random.shuffle(cands)
             perturb_type = cands[0]
         self.last_scheme = perturb_type
+        self._perturb_calls += 1
+        salt, gstate = self._perturb_calls, self._gstate
         if perturb_type == "dropout":
-            masked, keep = ops.dropout2d(latent_code.detach(), threshold, keep=ov.get("keep"), seed=_draw_seed())
-            mask = keep.view(keep.shape[0], keep.shape[1], 1, 1)      # the keep pattern (upstream's `mask` compares floats)
+            res = ops.dropout2d(latent_code.detach(), threshold, keep=ov.get("keep"), seed=salt if gstate is not None else _draw_seed(),
+                                state=gstate, want_mask=not _keep_mask)
+            masked, keep = res[0], res[1]
+            keep4 = keep.view(keep.shape[0], keep.shape[1], 1, 1)
+            mask = keep4 if _keep_mask else res[2]
             if not if_detach and latent_code.requires_grad:
-                masked = latent_code * (mask / (1.0 - threshold))
+                masked = latent_code * (keep4 / (1.0 - threshold))
         else:
             assert loss_type in ["mse", "ce", "corr"], "not implemented loss"
             fn = mask_latent_code_spatial_wise if perturb_type == "spatial" else mask_latent_code_channel_wise
+            k, noise = ov.get("k"), ov.get("soft_noise")
+            if gstate is not None:
+                n, c, h, w = latent_code.shape
+                L = c if perturb_type == "channel" else h * w
+                if k is None and random_threshold:
+                    k = self._gk[salt]                       # device int32: the host draws np.random per replay (graph.py)
+                if if_soft and noise is None:
+                    noise = ops.uniform((n, L), latent_code.device, seed=salt, state=gstate)
             masked, mask = fn(latent_code, num_classes=self.num_classes, decoder_function=decoder_function, label=label_y,
                               percentile=threshold, random=random_threshold, loss_type=loss_type, if_detach=if_detach,
-                              if_soft=if_soft, k=ov.get("k"), soft_noise=ov.get("soft_noise"))
+                              if_soft=if_soft, k=k, soft_noise=noise)
         if if_detach:
             masked = masked.detach()
         return masked, mask
@@ -448,7 +471,7 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
                 z, m = self.perturb_latent_code(self.z_i, d_img, label_y=clean_image_l, perturb_type=img_cfg["mask_type"],
                                                 loss_type=img_cfg["loss_name"], threshold=img_cfg["max_threshold"],
                                                 random_threshold=img_cfg["random_threshold"], if_detach=True,
-                                                if_soft=img_cfg["if_soft"], override=image_override)
+                                                if_soft=img_cfg["if_soft"], override=image_override, _keep_mask=True)
                 self.last_masks["image"] = m
                 zi_masked = z
                 gen_img = lambda: self.decoder_inference(d_img, zi_masked, eval=False, disable_track_bn_stats=True)
@@ -458,7 +481,7 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
                 z, m = self.perturb_latent_code(self.z_s, d_seg, label_y=label_l, perturb_type=seg_cfg["mask_type"],
                                                 loss_type=seg_cfg["loss_name"], threshold=seg_cfg["max_threshold"],
                                                 random_threshold=seg_cfg["random_threshold"], if_detach=True,
-                                                if_soft=seg_cfg["if_soft"], override=seg_override)
+                                                if_soft=seg_cfg["if_soft"], override=seg_override, _keep_mask=True)
                 self.last_masks["seg"] = m
                 perturbed_y_0 = self.decoder_inference(d_seg, z, eval=False, disable_track_bn_stats=True)
             self._join_side()
@@ -611,6 +634,9 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
         """The loop body of `train_network`, without its ten `.item()` syncs / `empty_cache()` stalls.  Returns the
         8 loss tensors (device scalars): standard (seg, image, gt_shape, shape) + hard (seg, image, shape, perturbed)."""
         self.train()
+        self._perturb_calls = 0
+        if self._gstate is not None:
+            ops.step_tick(self._gstate)           # (graph capture) RNG counter and Adam step advance on the device
         self.reset_all_optimizers()
         if self.two_streams and latent_DA:
             std, hard = self._two_chain_forward(clean_image_l, label_l, image_l, img_cfg, seg_cfg, separate_training, image_override,

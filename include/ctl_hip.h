@@ -187,12 +187,30 @@ size_t ctl_latent_mask_apply_ws_floats(int32_t mode, int32_t n, int32_t hw, int3
 int ctl_latent_mask_apply(int32_t mode, const float* code, const float* score, const float* soft_noise,
                           int32_t k_host, const int32_t* k_dev, float* masked, float* mask_out, float* scratch, int32_t n,
                           int32_t hw, int32_t c, ctl_stream stream);
+/* The whole generator tail behind one call (reference: util.py:224-249 / 285-312).  Latent codes up to 64 Ki elements per image with
+ * rows <= 1024 (the configured 128 x 16 x 16 included) run as ONE launch: one 1024-thread block per image holds the image's grad and
+ * code in registers, builds the score row in LDS, ranks, and stores code * mask -- no workspace (ctl_latent_mask_fused_ws_floats == 0).
+ * Larger problems are HBM streams and run as the score + apply launches above on `workspace`.  Scores (and therefore masks) are
+ * bit-identical between the two forms.  score_out (nullable) receives the [n,L] scores.  Rows up to 8192 entries. */
+size_t ctl_latent_mask_fused_ws_floats(int32_t mode, int32_t n, int32_t hw, int32_t c);
+int ctl_latent_mask_fused(int32_t mode, const float* grad, const float* code, const float* soft_noise, int32_t k_host,
+                          const int32_t* k_dev, float* masked, float* mask_out, float* score_out, float* workspace, int32_t n,
+                          int32_t hw, int32_t c, ctl_stream stream);
 /* F.dropout2d(z,p) (model.py:333): out = z * keep[n,c] / (1-p).  keep != NULL: injected {0,1} floats; else drawn on
  * device from a counter hash of (seed, n*c index) and written to keep_out. */
 int ctl_dropout2d(const float* z, const float* keep, uint64_t seed, float p, float* out, float* keep_out, int32_t n,
                   int32_t hw, int32_t c, ctl_stream stream);
 /* 0.5*U[0,1) style uniform fill from the same counter hash (soft-mask noise, util.py:239) */
 int ctl_uniform(float* out, int64_t count, uint64_t seed, ctl_stream stream);
+/* HIP-graph-safe forms: nothing that changes from step to step is a launch ARGUMENT.  `state` is a device int64[3]:
+ * [0] RNG seed, [1] RNG step counter, [2] Adam step count; ctl_step_tick (one launch at the head of a training step, replaces the
+ * host-side `step += 1` of torch.optim.Adam and the per-call host seed draw) advances [1] and [2].  With state != NULL the first
+ * integer argument is a per-call-site salt.  ctl_dropout2d_ex additionally writes (mask_full != NULL) upstream's dropout `mask`
+ * (model.py:334-336: 1 where the dropped-out tensor equals the input element, else 0; [n,hw,c] like out). */
+int ctl_step_tick(int64_t* state, ctl_stream stream);
+int ctl_dropout2d_ex(const float* z, const float* keep, uint64_t seed_or_salt, const int64_t* state, float p, float* out,
+                     float* keep_out, float* mask_full, int32_t n, int32_t hw, int32_t c, ctl_stream stream);
+int ctl_uniform_dev(float* out, int64_t count, uint64_t salt, const int64_t* state, ctl_stream stream);
 
 /* ------------------------------------------------------------------------------------------------ SURVEY 8(f) rows 1, 3
  * Validation metrics and the input pipeline on device (no host round trip per batch).
@@ -220,6 +238,9 @@ int ctl_crop_or_pad(const void* src, void* dst, int32_t elem_bytes, int32_t n, i
  * grad_scale folds the 1/world_size of the data-parallel all-reduce. */
 int ctl_adam(float* p, const float* g, float* m, float* v, int64_t count, float lr, float beta1, float beta2,
              float eps, int32_t step, float grad_scale, ctl_stream stream);
+/* same update with the step count read from state[2] on the device (bias corrections computed in double there) */
+int ctl_adam_dev(float* p, const float* g, float* m, float* v, int64_t count, float lr, float beta1, float beta2,
+                 float eps, const int64_t* state, float grad_scale, ctl_stream stream);
 
 /* ------------------------------------------------------------------------------------------------ plans
  * A plan is an array of ctl_op executed in order on one stream: one C call per network pass (the Python host builds

@@ -441,6 +441,9 @@ class OracleSolver:
             out, mask = fn(z, decoder, label_y, num_classes=self.num_classes, percentile=threshold,
                            random=random_threshold, loss_type=loss_type, if_detach=True, if_soft=if_soft,
                            k=ov.get("k"), soft_noise=ov.get("soft_noise"))
+        if ov.get("mask") is not None:          # a selection made elsewhere (the fp64 yardstick re-uses the fp32 run's masks: a near-tie
+            mask = ov["mask"].to(z.dtype)       # in the ranking must not make the two runs train on different hard examples)
+            out = z * mask
         return out.detach().clone(), mask
 
     def hard_example_generation(self, clean, label, gen_corrupted_seg=True, gen_corrupted_image=True,

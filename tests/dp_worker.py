@@ -1,0 +1,69 @@
+"""Worker of tests/test_dist_gpu.py: one data-parallel rank running REAL HIP cooperative steps on its shard (all ranks on GPU 0 over
+gloo when the box has one GPU; RCCL for the world-1 smoke).  Writes what the parent compares to <out>/rank<r>.pt."""
+import os
+import random
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import ref_cpu as O                                                                  # noqa: E402  (synthetic inputs only)
+from cooperative_training_and_latent_space_data_augmentation_amd.dist import DataParallel        # noqa: E402
+from cooperative_training_and_latent_space_data_augmentation_amd.solver import AdvancedTripletReconSegmentationModel      # noqa: E402
+
+CH_MSE = {"loss_name": "mse", "mask_type": "channel", "max_threshold": 0.5, "random_threshold": False, "if_soft": False}
+SP_CE = {"loss_name": "ce", "mask_type": "spatial", "max_threshold": 0.5, "random_threshold": False, "if_soft": False}
+DROP_MSE = {"loss_name": "mse", "mask_type": "dropout", "max_threshold": 0.5, "random_threshold": True, "if_soft": True}
+DROP_CE = {"loss_name": "ce", "mask_type": "dropout", "max_threshold": 0.5, "random_threshold": True, "if_soft": True}
+
+
+def shard(rank, device):
+    c, l, n = O.synthetic_batch(2, 64, 64, seed=50 + rank)
+    dev = lambda t: (t.to(device).contiguous(memory_format=torch.channels_last) if t.dim() == 4 else t.to(device))
+    return dev(c), dev(l), dev(n)
+
+
+def main():
+    backend, out = sys.argv[1], sys.argv[2]
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(0)
+    device = torch.device("cuda", 0)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    sd = torch.load(os.path.join(ROOT, "tests", "golden", "state_dicts_seed0.pt"), weights_only=False)
+    torch.manual_seed(100 + rank)                      # deliberately different weights before the broadcast
+    s = AdvancedTripletReconSegmentationModel(use_gpu=True)
+    if rank == 0:
+        for k, m in s.model.items():
+            m.load_state_dict(sd[k])
+    dp = DataParallel(s)
+    # per-rank RNG streams: seeded after the weight broadcast
+    torch.manual_seed(7000 + rank); np.random.seed(7000 + rank); random.seed(7000 + rank)
+    clean, label, noisy = shard(rank, device)
+    rec = {}
+
+    def hook(solver):
+        dp.sync_gradients(solver)
+        rec["bucket_sum"] = dp.bucket.buf.detach().cpu().clone()
+
+    losses = s.cooperative_step(clean, label, noisy, CH_MSE, SP_CE, grad_hook=hook)
+    torch.cuda.synchronize()
+    rec["losses"] = torch.stack([v.detach().float() for v in losses]).cpu()
+    rec["weights"] = {k: m._flat_data.detach().cpu().clone() for k, m in s.model.items()}
+    rec["buffers"] = {k: (m._bflat.detach().cpu().clone(), m._nbt.detach().cpu().clone()) for k, m in s.model.items()}
+    s.cooperative_step(clean, label, noisy, DROP_MSE, DROP_CE, grad_hook=dp.sync_gradients)     # per-rank dropout patterns
+    rec["drop_masks"] = {k: v.detach().cpu().clone() for k, v in s.last_masks.items()}
+    rec["weights2"] = {k: m._flat_data.detach().cpu().clone() for k, m in s.model.items()}
+    torch.cuda.synchronize()
+    torch.save(rec, os.path.join(out, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

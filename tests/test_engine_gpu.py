@@ -551,3 +551,22 @@ def test_filter_code_and_remaining_solver_entries(golden_cases, golden_sd):
     assert not any(p.requires_grad for m in s.model.values() for p in m.parameters())
     s.requires_grad_(True)
     assert all(p.requires_grad for m in s.model.values() for p in m.parameters())
+
+
+def test_adam_skips_a_network_without_gradient(golden_cases, golden_sd):
+    """torch.optim.Adam skips parameters whose .grad is None (zero_grad sets grads to None since torch 2.0): a network that got no
+    gradient in a step must not move, even with non-zero Adam moments; a network that did get one moves."""
+    C = golden_cases["D_step_dropout"]
+    ov = _overrides(C, (C["img_cfg"], C["seg_cfg"]))
+    s = _solver(golden_sd)
+    s.cooperative_step(dev(C["clean"]), dev(C["label"]), dev(C["noisy"]), C["img_cfg"], C["seg_cfg"], image_override=ov[0], seg_override=ov[1])
+    before = {k: m._flat_data.clone() for k, m in s.model.items()}
+    s.reset_all_optimizers()
+    rec = s.recon_shape(dev(C["label"]), is_label_map=True)                 # STN only: three networks never see a gradient
+    from cooperative_training_and_latent_space_data_augmentation_amd.autograd import cross_entropy_2D
+    cross_entropy_2D(rec, dev(C["label"])).backward()
+    s.optimize_all_params()
+    for k in ("image_encoder", "segmentation_decoder", "image_decoder"):
+        assert torch.equal(s.model[k]._flat_data, before[k]) and s.optimizers[k].step_count == 1, k
+    for k in ("shape_encoder", "shape_decoder"):
+        assert not torch.equal(s.model[k]._flat_data, before[k]) and s.optimizers[k].step_count == 2, k

@@ -1,0 +1,167 @@
+"""Whole-step HIP graphs (graph.py): a replayed step must be THE SAME computation as the eager step -- every kernel is
+deterministic, so with deterministic masks the weights, BatchNorm buffers and losses are compared bit for bit."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ref_cpu as O  # noqa: E402
+from cooperative_training_and_latent_space_data_augmentation_amd import ops  # noqa: E402
+from cooperative_training_and_latent_space_data_augmentation_amd.graph import CooperativeStepGraph  # noqa: E402
+from cooperative_training_and_latent_space_data_augmentation_amd.solver import AdvancedTripletReconSegmentationModel  # noqa: E402
+
+DEV = "cuda"
+CH_MSE = {"loss_name": "mse", "mask_type": "channel", "max_threshold": 0.5, "random_threshold": False, "if_soft": False}
+SP_CE = {"loss_name": "ce", "mask_type": "spatial", "max_threshold": 0.5, "random_threshold": False, "if_soft": False}
+CH_MSE_RT = dict(CH_MSE, random_threshold=True)
+SP_CE_RT = dict(SP_CE, random_threshold=True)
+RAND_MSE = {"loss_name": "mse", "mask_type": "random", "max_threshold": 0.5, "random_threshold": True, "if_soft": False}
+RAND_CE = {"loss_name": "ce", "mask_type": "random", "max_threshold": 0.5, "random_threshold": True, "if_soft": False}
+DROP_MSE = {"loss_name": "mse", "mask_type": "dropout", "max_threshold": 0.5, "random_threshold": True, "if_soft": True}
+DROP_CE = {"loss_name": "ce", "mask_type": "dropout", "max_threshold": 0.5, "random_threshold": True, "if_soft": True}
+
+
+def dev(x):
+    x = x.to(DEV)
+    return x.contiguous(memory_format=torch.channels_last) if x.dim() == 4 else x.contiguous()
+
+
+def _solver(golden_sd):
+    s = AdvancedTripletReconSegmentationModel(use_gpu=True)
+    for k, m in s.model.items():
+        m.load_state_dict(golden_sd[k])
+    return s
+
+
+def _state(s):
+    torch.cuda.synchronize()
+    return ({k: m._flat_data.detach().cpu().clone() for k, m in s.model.items()},
+            {k: (m._bflat.detach().cpu().clone(), m._nbt.detach().cpu().clone()) for k, m in s.model.items()},
+            {k: (o.exp_avg.cpu().clone(), o.exp_avg_sq.cpu().clone(), o.step_count) for k, o in s.optimizers.items()})
+
+
+def _same(a, b):
+    for k in a[0]:
+        assert torch.equal(a[0][k], b[0][k]), f"weights of {k}"
+        assert torch.equal(a[1][k][0], b[1][k][0]) and torch.equal(a[1][k][1], b[1][k][1]), f"BatchNorm buffers of {k}"
+        assert torch.equal(a[2][k][0], b[2][k][0]) and torch.equal(a[2][k][1], b[2][k][1]) and a[2][k][2] == b[2][k][2], f"Adam state of {k}"
+
+
+@pytest.mark.parametrize("cfgs", [(CH_MSE, SP_CE), (CH_MSE_RT, SP_CE_RT)], ids=["fixed_k", "random_k"])
+@pytest.mark.parametrize("two_streams", [True, False])
+def test_graph_replay_is_bitwise_the_eager_step(golden_sd, cfgs, two_streams):
+    """4 training steps, eager vs graph replay, from the same weights and the same seeded host RNG (the random thresholds k are drawn
+    by the host per replay in the reference's order and handed over in device memory)."""
+    clean, label, noisy = (dev(t) for t in O.synthetic_batch(4, 64, 64, seed=5))
+    res = []
+    for use_graph in (False, True):
+        s = _solver(golden_sd)
+        s.two_streams = two_streams
+        np.random.seed(3)
+        g = CooperativeStepGraph(s, *cfgs) if use_graph else None
+        losses = []
+        for _ in range(4):
+            l = g(clean, label, noisy) if use_graph else s.cooperative_step(clean, label, noisy, *cfgs)
+            losses.append(torch.stack([v.detach().float() for v in l]).cpu())
+        res.append((losses, _state(s), np.random.rand()))
+        if use_graph:
+            assert g.replays == 4 and len(g.entries) == 1
+    for a, b in zip(res[0][0], res[1][0]):
+        assert torch.equal(a, b), (a, b)
+    _same(res[0][1], res[1][1])
+    assert res[0][2] == res[1][2]                       # both consumed the same number of np.random draws
+
+
+def test_graph_capture_does_not_advance_training_state(golden_sd):
+    """Capturing (warm-up + capture) must leave weights, BatchNorm buffers, Adam state and the host RNG streams untouched; eager calls
+    mixed with replays keep working (weights are re-packed after a replay)."""
+    clean, label, noisy = (dev(t) for t in O.synthetic_batch(2, 64, 64, seed=6))
+    s = _solver(golden_sd)
+    s.cooperative_step(clean, label, noisy, CH_MSE, SP_CE)              # one eager step first: non-trivial Adam state
+    before = _state(s)
+    g = CooperativeStepGraph(s, CH_MSE, SP_CE)           # (draws the device RNG's seed from torch's host generator)
+    random.seed(1); np.random.seed(1); torch.manual_seed(1)
+    probe = (random.random(), np.random.rand(), float(torch.rand(1)))
+    random.seed(1); np.random.seed(1); torch.manual_seed(1)
+    g.static_in = (clean, label, noisy)
+    e = g._capture(g._draw_schemes())
+    _same(before, _state(s))
+    assert probe == (random.random(), np.random.rand(), float(torch.rand(1)))
+    g.entries[(CH_MSE["mask_type"], SP_CE["mask_type"])] = e
+    ref = _solver(golden_sd)
+    ref.cooperative_step(clean, label, noisy, CH_MSE, SP_CE)
+    for _ in range(2):
+        g(clean, label, noisy)
+        ref.cooperative_step(clean, label, noisy, CH_MSE, SP_CE)
+    assert torch.equal(s.predict(noisy), ref.predict(noisy))           # eager inference after replays sees the updated weights
+    la, lb = s.cooperative_step(clean, label, noisy, CH_MSE, SP_CE), ref.cooperative_step(clean, label, noisy, CH_MSE, SP_CE)
+    assert all(torch.equal(u.detach(), v.detach()) for u, v in zip(la, lb))
+    _same(_state(ref), _state(s))
+
+
+def test_graph_dropout_draws_a_new_pattern_every_replay(golden_sd):
+    """Dropout masks under replay: the pattern comes from the device-resident RNG state, so it changes from replay to replay and
+    keeps the Bernoulli(0.5) statistics; the Adam step count advances on the device."""
+    clean, label, noisy = (dev(t) for t in O.synthetic_batch(4, 64, 64, seed=7))
+    s = _solver(golden_sd)
+    g = CooperativeStepGraph(s, DROP_MSE, DROP_CE)
+    pats = []
+    for _ in range(4):
+        losses = g(clean, label, noisy)
+        assert all(torch.isfinite(v) for v in losses)
+        pats.append((s.last_masks["image"].clone(), s.last_masks["seg"].clone()))
+    for a, b in zip(pats, pats[1:]):
+        assert not torch.equal(a[0], b[0]) and not torch.equal(a[1], b[1])
+    assert not torch.equal(pats[0][0], pats[0][1])                      # image and segmentation codes get different patterns
+    frac = torch.cat([p[0].flatten() for p in pats]).mean().item()
+    assert 0.4 < frac < 0.6
+    assert int(g.state[2]) == 4 and all(o.step_count == 4 for o in s.optimizers.values())
+    s.cooperative_step(clean, label, noisy, DROP_MSE, DROP_CE)           # the eager path continues from the replayed state
+    assert all(o.step_count == 5 for o in s.optimizers.values())
+
+
+def test_graph_random_scheme_follows_the_seeded_host_draws(golden_sd):
+    """mask_type='random': one graph per (image scheme, segmentation scheme); the scheme sequence is the eager path's for the same seed."""
+    clean, label, noisy = (dev(t) for t in O.synthetic_batch(2, 64, 64, seed=8))
+    seqs = []
+    for use_graph in (False, True):
+        s = _solver(golden_sd)
+        random.seed(4); np.random.seed(4)
+        g = CooperativeStepGraph(s, RAND_MSE, RAND_CE) if use_graph else None
+        seq = []
+        for _ in range(6):
+            if use_graph:
+                sch = g._draw_schemes
+                drawn = []
+                g._draw_schemes = lambda: drawn.append(sch()) or drawn[-1]
+                losses = g(clean, label, noisy)
+                g._draw_schemes = sch
+                seq.append(drawn[0])
+            else:
+                got = []
+                orig = s.perturb_latent_code
+                s.perturb_latent_code = lambda *a, **kw: (lambda r: (got.append(s.last_scheme), r)[1])(orig(*a, **kw))
+                losses = s.cooperative_step(clean, label, noisy, RAND_MSE, RAND_CE)
+                s.perturb_latent_code = orig
+                seq.append(tuple(got))
+            assert all(torch.isfinite(v) for v in losses)
+        seqs.append(seq)
+        if use_graph:
+            assert len(g.entries) == len(set(seq)) >= 2
+    assert seqs[0] == seqs[1]
+
+
+def test_dropout_mask_has_the_reference_semantics(golden_sd):
+    """perturb_latent_code(..., 'dropout') returns upstream's mask (model.py:334-336): 1 where the dropped-out code EQUALS the input."""
+    s = _solver(golden_sd)
+    z = torch.relu(torch.randn(3, 128, 4, 4, generator=torch.Generator().manual_seed(2)))      # ReLU codes: exact zeros exist
+    keep = (torch.rand(3, 128, generator=torch.Generator().manual_seed(3)) > 0.5).float()
+    masked, mask = s.perturb_latent_code(dev(z), s.model["image_decoder"], perturb_type="dropout", threshold=0.5, if_detach=True,
+                                         override={"keep": keep.to(DEV)})
+    ref_masked, ref_mask = O.dropout2d_with_keep(z, 0.5, keep)
+    assert torch.equal(masked.cpu(), ref_masked) and torch.equal(mask.cpu(), ref_mask) and mask.shape == z.shape
+    out, kp, m2 = ops.dropout2d(dev(z), 0.5, seed=9, want_mask=True)
+    assert torch.equal(m2.cpu(), (out.cpu() == z).float())

@@ -479,6 +479,32 @@ def test_latent_mask_kernels(n, c, h, w):
     assert mask.cpu().view(2, 8).tolist() == [[0.0] + [1.0] * 7] * 2
 
 
+@pytest.mark.parametrize("n,c,h,w", [(16, 128, 16, 16), (2, 128, 4, 4), (3, 64, 6, 5), (4, 256, 32, 32), (3, 32, 48, 40), (2, 16, 64, 64),
+                                     (1, 8, 3, 3), (40, 128, 64, 64), (1200, 8, 4, 4)])
+def test_latent_mask_fused_is_bitwise_the_three_launch_path(n, c, h, w):
+    """ONE launch (score -> grid barrier -> rank-select -> apply) == ctl_latent_score + ctl_latent_mask_apply: scores, masks and masked
+    codes bit for bit, for both modes, hard / soft masks, host / device k, ragged sizes and grids that span several waves of blocks;
+    repeated launches reuse the barrier's sync words."""
+    g = torch.Generator().manual_seed(c + h)
+    grad, code = dev(torch.randn(n, c, h, w, generator=g)), dev(torch.rand(n, c, h, w, generator=g))
+    for mode in (0, 1):
+        L = c if mode == 0 else h * w
+        if L > 1024 and mode == 1:
+            ks = [L // 3]                               # (long rows: the two-call path takes its threshold from a bitonic sort)
+        else:
+            ks = [0, L // 2, L - 1, int(L * 0.37)]
+        score = ops.latent_score(grad, mode)
+        for rep, k in enumerate(ks):
+            noise = dev(torch.rand(n, L, generator=g)) if rep % 2 else None
+            m_ref, k_ref = ops.latent_mask_apply(code, score, mode, k, noise)
+            kk = torch.tensor([k], dtype=torch.int32, device=DEV) if rep == 1 else k
+            m, km, sc = ops.latent_mask(grad, code, mode, kk, noise, want_score=True)
+            assert torch.equal(sc, score), (mode, k)
+            assert torch.equal(km, k_ref) and torch.equal(m, m_ref), (mode, k)
+    with pytest.raises(_ffi.CtlError):
+        ops.latent_mask(grad, code, 0, c)               # k out of range
+
+
 def test_dropout2d_injected_and_device_rng():
     g = torch.Generator().manual_seed(6)
     z = torch.rand(4, 128, 8, 8, generator=g)

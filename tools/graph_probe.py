@@ -17,8 +17,15 @@ def timeit(fn, n=20):
     return 1e3 * (time.perf_counter() - t0) / n
 
 
-def capture(fn, warm=3):
+def capture(fn, warm=3, solver=None):
     import torch
+    if solver is not None:
+        # tensors the solver keeps (z_i, z_s, latent_code) hold the previous call's autograd graph alive, and with it the AccumulateGrad
+        # nodes of the flat parameters -- created on the stream of the FIRST call (the default stream).  Under capture they would pull
+        # the legacy stream into the capture (hip::Stream::EndCapture then segfaults): drop them so that the warm-up on the capture
+        # stream re-creates them there.
+        solver.z_i = solver.z_s = None
+        solver.latent_code = {"image": None, "segmentation": None, "shape": None}
     cap = torch.cuda.Stream()
     cap.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(cap):
@@ -97,6 +104,75 @@ def child(stage):
             a, b = s.recon_shape_pair(label, True, x, False)
             (a.sum() + b.sum()).backward()
             return a
+    elif stage == "stn_pair_fixed":
+        x = torch.randn(16, 4, 256, 256, device="cuda").contiguous(memory_format=torch.channels_last)
+        def fn():
+            s.reset_all_optimizers()
+            a, b = s.recon_shape_pair(label, True, x, False)
+            (a.sum() + b.sum()).backward()
+            return a
+    elif stage == "stn_pair_fwd":
+        x = torch.randn(16, 4, 256, 256, device="cuda").contiguous(memory_format=torch.channels_last)
+        def fn():
+            with torch.no_grad():
+                return s.recon_shape_pair(label, True, x, False)[0]
+    elif stage == "grouped_enc":
+        from cooperative_training_and_latent_space_data_augmentation_amd.autograd import net_apply
+        x = torch.rand(32, 4, 256, 256, device="cuda").contiguous(memory_format=torch.channels_last)
+        net = s.model["shape_encoder"]
+        def fn():
+            net.zero_grad()
+            y = net_apply(net, x, groups=2)[0]
+            y.backward(torch.ones_like(y))
+            return y
+    elif stage == "grouped_dec":
+        from cooperative_training_and_latent_space_data_augmentation_amd.autograd import net_apply
+        x = torch.rand(32, 128, 16, 16, device="cuda").contiguous(memory_format=torch.channels_last)
+        net = s.model["shape_decoder"]
+        def fn():
+            net.zero_grad()
+            y = net_apply(net, x, groups=2)[0]
+            y.backward(torch.ones_like(y))
+            return y
+    elif stage == "cat_split":
+        from cooperative_training_and_latent_space_data_augmentation_amd.autograd import split_halves
+        a0 = torch.rand(16, 4, 256, 256, device="cuda").contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        b0 = torch.rand(16, 4, 256, 256, device="cuda").contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        def fn():
+            a0.grad = b0.grad = None
+            u, v = split_halves(torch.cat([a0, b0], 0) * 2.0)
+            (u.sum() + 2 * v.sum()).backward()
+            return u
+    elif stage == "std_nogroup":
+        s.two_streams = False
+        s.group_stn_passes = False
+        def fn():
+            s.reset_all_optimizers()
+            l = s.standard_training(clean, label, noisy)
+            (l[0] + l[1] + l[2] + l[3]).backward()
+            return l
+    elif stage in ("two_chains", "two_chains_serial"):
+        # two independent launch chains (no cross edges between fork and join): does graph replay overlap them like two eager streams?
+        na, nb = s.model["shape_encoder"], s.model["image_decoder"]
+        xa = torch.rand(16, 4, 256, 256, device="cuda").contiguous(memory_format=torch.channels_last)
+        xb = torch.rand(16, 128, 16, 16, device="cuda").contiguous(memory_format=torch.channels_last)
+        side = torch.cuda.Stream()
+        def chain(net, x, reps=3):
+            for _ in range(reps):
+                net.zero_grad()
+                y = net(x)
+                y.backward(torch.ones_like(y))
+        def fn():
+            cur = torch.cuda.current_stream()
+            if stage == "two_chains":
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    chain(nb, xb)
+                chain(na, xa)
+                cur.wait_stream(side)
+            else:
+                chain(nb, xb)
+                chain(na, xa)
     elif stage == "two_nets":
         def fn():
             s.reset_all_optimizers()
@@ -143,7 +219,7 @@ def child(stage):
         fn = lambda: s.cooperative_step(clean, label, noisy, *cfg)
     for _ in range(3): fn()
     print(f"{stage}: eager {timeit(fn):.3f} ms", flush=True)
-    g, out = capture(fn)
+    g, out = capture(fn, solver=s)
     for _ in range(3): g.replay()
     print(f"{stage}: graph replay {timeit(g.replay):.3f} ms", flush=True)
 
