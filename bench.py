@@ -209,6 +209,14 @@ def main():
         mode = "graph" if pick.item() > 0 else "eager"
     if mode == "graph":
         step = graph_step
+    elif gstep is not None:                               # eager chosen: give the graph's private pool back and let the allocator settle
+        del gstep, graph_step
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        for _ in range(3):
+            eager_step()
+        fence()
     phase_tm = None
     if rank == 0 and os.environ.get("CTL_HIP_LIB") and hasattr(_ffi.lib, "ctl_debug_timing"):
         import ctypes                                     # -DCTL_TIMING variant build: per-phase cycle counters of the conv kernel

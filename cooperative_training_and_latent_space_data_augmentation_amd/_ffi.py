@@ -93,6 +93,7 @@ class _Lib:
             "ctl_uniform_dev": [p, i64, u64, p, p],
             "ctl_adam_dev": [p, p, p, p, i64, f32, f32, f32, f32, p, f32, p],
             "ctl_adam": [p, p, p, p, i64, f32, f32, f32, f32, i32, f32, p],
+            "ctl_accumulate": [p, p, i32, i64, p],
             "ctl_plan_run": [p, i32, p, i32, p],
             "ctl_prof_start": [C.c_char_p], "ctl_prof_stop": [p, C.c_size_t],
             "ctl_pack_weights_batched": [p, p, p, i32, i64, p], "ctl_wgrad_reduce_batched": [p, p, p, i32, i64, p],
@@ -122,7 +123,7 @@ EXPORTED = ["ctl_version", "ctl_last_error", "ctl_conv_wpack_floats", "ctl_conv_
             "ctl_sizeof_conv", "ctl_prof_start", "ctl_prof_stop", "ctl_pack_weights_batched",
             "ctl_wgrad_reduce_batched", "ctl_confusion_hist", "ctl_rescale_intensity_ws_floats", "ctl_rescale_intensity",
             "ctl_noise_clamp", "ctl_crop_or_pad", "ctl_step_tick", "ctl_dropout2d_ex", "ctl_uniform_dev", "ctl_adam_dev",
-            "ctl_latent_mask_fused_ws_floats", "ctl_latent_mask_fused"]
+            "ctl_latent_mask_fused_ws_floats", "ctl_latent_mask_fused", "ctl_accumulate"]
 
 
 def prof_start(kernel_filter: str = "") -> None:

@@ -18,7 +18,8 @@ class _NetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, net, mode, affine, groups, x, flat):
         outs, act, plan = net.run_forward(x, mode, groups)
-        ctx.net, ctx.mode, ctx.affine, ctx.act, ctx.plan = net, mode, affine, act, plan
+        net._pass_seq += 1
+        ctx.net, ctx.mode, ctx.affine, ctx.act, ctx.plan, ctx.seq = net, mode, affine, act, plan, net._pass_seq
         ctx.save_for_backward(x, *outs)
         ctx.set_materialize_grads(False)
         return outs
@@ -34,6 +35,13 @@ class _NetFn(torch.autograd.Function):
             return None, None, None, None, None, None
         douts = tuple(None if d is None else _nhwc(d) for d in douts)
         dx, gflat = ctx.net.run_backward(x, ctx.act, outs, ctx.plan, ctx.mode, douts, need_dx, need_w, ctx.affine)
+        if gflat is not None and ctx.net._defer_grads:
+            # parked for ONE accumulation per network after backward (CtlNet.collect_deferred_grads): handing it to autograd would make
+            # every pass a cross-stream dependency on the leaf's accumulation stream when the step runs as two launch chains
+            ev = torch.cuda.Event()
+            ev.record()
+            ctx.net._deferred.append((ctx.seq, gflat, ev))
+            gflat = None
         return None, None, None, None, dx, gflat
 
 

@@ -446,8 +446,29 @@ __global__ __launch_bounds__(EB) void adam_kernel(float* __restrict__ p, const f
     }
 }
 
+// dst += src[0] + src[1] + ... (fixed order): the parameter gradients of the passes of one network, summed once per step
+struct ctl_ptr8 { const float* p[8]; };
+__global__ __launch_bounds__(EB) void accumulate_kernel(float* __restrict__ dst, ctl_ptr8 src, int k, int64_t count) {
+    const int64_t stride = (int64_t)gridDim.x * EB;
+    for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < count; i += stride) {
+        float a = dst[i];
+        for (int j = 0; j < k; ++j) a += src.p[j][i];
+        dst[i] = a;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ launchers
 #define S_ (hipStream_t) stream
+
+extern "C" int ctl_accumulate(float* dst, const float* const* srcs, int32_t k, int64_t count, ctl_stream stream) {
+    CTL_REQUIRE(dst && srcs && k >= 1 && k <= 8 && count > 0, "accumulate: bad arguments (1 <= k <= 8)");
+    ctl_ptr8 a;
+    for (int j = 0; j < 8; ++j) a.p[j] = j < k ? srcs[j] : nullptr;
+    for (int j = 0; j < k; ++j) CTL_REQUIRE(a.p[j], "accumulate: null source %d", j);
+    accumulate_kernel<<<dim3(stream_blocks(count)), dim3(EB), 0, S_>>>(dst, a, k, count);
+    CTL_LAUNCH_CHECK("accumulate");
+    return CTL_OK;
+}
 
 extern "C" int ctl_bn_finalize(const float* partial, int32_t blocks, int32_t c, int64_t count, const float* gamma,
                                const float* beta, float eps, float momentum, int32_t update_running,

@@ -403,6 +403,11 @@ class CtlNet(nn.Module):
         self._plans: Dict[tuple, Plan] = {}
         self._packed_ok = False
         self._grad_written = True          # see zero_grad / FlatAdam.step
+        # deferred parameter gradients (solver.cooperative_step): while set, a backward pass parks its flat gradient here instead of
+        # handing it to autograd; collect_deferred_grads() adds them into `.grad` with ONE launch, in forward order
+        self._defer_grads = False
+        self._deferred: list = []
+        self._pass_seq = 0
         self._scr: Optional[dict] = None          # stream handle -> scratch tensor
         self._arenas = ArenaPool()
         self._build_tree()
@@ -539,6 +544,24 @@ class CtlNet(nn.Module):
         `decoder_function.zero_grad()` inside the masking functions, model_util.py:251-254)"""
         self._flat.grad.zero_()
         self._grad_written = False        # FlatAdam skips a network no backward pass has written since (torch: `.grad is None`)
+
+    def collect_deferred_grads(self):
+        """Add the parked per-pass gradients into the gradient buffer (fixed order: the order of the forward passes) on the current
+        stream, which first waits for the streams that produced them."""
+        if not self._deferred:
+            return
+        cur = torch.cuda.current_stream()
+        items = sorted(self._deferred, key=lambda it: it[0])
+        self._deferred = []
+        for _, g, ev in items:
+            cur.wait_event(ev)
+        for i in range(0, len(items), 8):
+            chunk = [g for _, g, _ in items[i:i + 8]]
+            arr = (ctypes.c_void_p * len(chunk))(*[g.data_ptr() for g in chunk])
+            check(lib.ctl_accumulate(self._flat.grad.data_ptr(), arr, len(chunk), self._pcount, cur.cuda_stream), "ctl_accumulate")
+            for g in chunk:
+                g.record_stream(cur)
+        self._grad_written = True
 
     def mark_grad_written(self):
         """Call after filling `.grad` by other means than a backward pass of this network (e.g. a hand-written gradient)."""

@@ -70,6 +70,8 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
         # the image decoder consumes z_i only: its launch chain (forward, loss, and through autograd its backward) can run on a
         # second HIP stream next to D_seg -> STN on the main stream
         self.two_streams = os.environ.get("CTL_TWO_STREAMS", "1") != "0"
+        # parameter gradients of the passes of a step are parked and added with one launch per network after backward (nets.py)
+        self.defer_param_grads = os.environ.get("CTL_DEFER_GRADS", "1") != "0"
         self._side = torch.cuda.Stream(device=self.device) if self.two_streams else None
         if self.two_streams and hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
             # the flat-parameter leaves live on the main stream while part of their gradient is produced on the second one: intended
@@ -638,13 +640,29 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
         if self._gstate is not None:
             ops.step_tick(self._gstate)           # (graph capture) RNG counter and Adam step advance on the device
         self.reset_all_optimizers()
+        for net in self.model.values():
+            net._defer_grads, net._deferred = self.defer_param_grads, []
+        try:
+            return self._cooperative_step(clean_image_l, label_l, image_l, img_cfg, seg_cfg, latent_DA, separate_training, image_override,
+                                          seg_override, do_optim, grad_hook)
+        finally:
+            for net in self.model.values():
+                net._defer_grads, net._deferred = False, []
+
+    def _backward(self, loss):
+        loss.backward()
+        for net in self.model.values():             # the parked per-pass parameter gradients: one accumulation launch per network
+            net.collect_deferred_grads()
+
+    def _cooperative_step(self, clean_image_l, label_l, image_l, img_cfg, seg_cfg, latent_DA, separate_training, image_override,
+                          seg_override, do_optim, grad_hook):
         if self.two_streams and latent_DA:
             std, hard = self._two_chain_forward(clean_image_l, label_l, image_l, img_cfg, seg_cfg, separate_training, image_override,
                                                 seg_override)
             # (two backward() calls, one per chain, were measured: 682 vs 751 slices/s -- every call ends by joining the streams)
             loss = (std[0] + std[1] + std[3] + std[2]) + (hard[0] + hard[1] + hard[2] + hard[3])
             self.reset_all_optimizers()
-            loss.backward()
+            self._backward(loss)
             if grad_hook is not None:
                 grad_hook(self)
             if do_optim:
@@ -663,7 +681,7 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
                                               separate_training=separate_training)
             loss = loss + (hard[0] + hard[1] + hard[2] + hard[3])
         self.reset_all_optimizers()
-        loss.backward()
+        self._backward(loss)
         if grad_hook is not None:
             grad_hook(self)          # data-parallel gradient all-reduce goes here
         if do_optim:

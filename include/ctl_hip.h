@@ -238,6 +238,10 @@ int ctl_crop_or_pad(const void* src, void* dst, int32_t elem_bytes, int32_t n, i
  * grad_scale folds the 1/world_size of the data-parallel all-reduce. */
 int ctl_adam(float* p, const float* g, float* m, float* v, int64_t count, float lr, float beta1, float beta2,
              float eps, int32_t step, float grad_scale, ctl_stream stream);
+/* dst[i] += srcs[0][i] + ... + srcs[k-1][i] in that order (1 <= k <= 8; `srcs` is a HOST array of device pointers): the flat parameter
+ * gradients that the passes of one network produced in a step, added into the network's gradient buffer by ONE launch after
+ * loss.backward() instead of one autograd accumulation per pass (which, with two launch chains, is a cross-stream dependency each). */
+int ctl_accumulate(float* dst, const float* const* srcs, int32_t k, int64_t count, ctl_stream stream);
 /* same update with the step count read from state[2] on the device (bias corrections computed in double there) */
 int ctl_adam_dev(float* p, const float* g, float* m, float* v, int64_t count, float lr, float beta1, float beta2,
                  float eps, const int64_t* state, float grad_scale, ctl_stream stream);
