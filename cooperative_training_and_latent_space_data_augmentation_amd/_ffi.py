@@ -23,7 +23,8 @@ CONV_DTYPE = np.dtype([
     ("n", "<i4"), ("hin", "<i4"), ("win", "<i4"), ("cin", "<i4"), ("hout", "<i4"), ("wout", "<i4"), ("cout", "<i4"),
     ("ks", "<i4"), ("stride", "<i4"), ("pad", "<i4"), ("in_mode", "<i4"), ("pro_affine", "<i4"), ("pro_slope", "<f4"),
     ("epi_flags", "<i4"), ("epi_act", "<i4"), ("epi_slope", "<f4"), ("out_h", "<i4"), ("out_w", "<i4"),
-    ("out_sy", "<i4"), ("out_sx", "<i4"), ("nsub", "<i4"), ("out_sub", "<i4"), ("groups", "<i4")])
+    ("out_sy", "<i4"), ("out_sx", "<i4"), ("nsub", "<i4"), ("out_sub", "<i4"), ("groups", "<i4"), ("dt", "<i4")])
+DT_BF16, DT_X16, DT_Y16, DT_RES16 = 1, 2, 4, 8
 OP_DTYPE = np.dtype([("kind", "<i4"), ("i", "<i4", (27,)), ("f", "<f4", (4,)), ("slot", "<i4", (OP_MAX_T,)),
                      ("off", "<i8", (OP_MAX_T,)), ("l", "<i8", (4,))], align=True)
 
@@ -97,6 +98,7 @@ class _Lib:
             "ctl_plan_run": [p, i32, p, i32, p],
             "ctl_prof_start": [C.c_char_p], "ctl_prof_stop": [p, C.c_size_t],
             "ctl_pack_weights_batched": [p, p, p, i32, i64, p], "ctl_wgrad_reduce_batched": [p, p, p, i32, i64, p],
+            "ctl_pack_weights_bf16_batched": [p, p, p, i32, i64, p],
         }
         for name, args in sig.items():
             getattr(lib, name).argtypes = args
@@ -123,7 +125,7 @@ EXPORTED = ["ctl_version", "ctl_last_error", "ctl_conv_wpack_floats", "ctl_conv_
             "ctl_sizeof_conv", "ctl_prof_start", "ctl_prof_stop", "ctl_pack_weights_batched",
             "ctl_wgrad_reduce_batched", "ctl_confusion_hist", "ctl_rescale_intensity_ws_floats", "ctl_rescale_intensity",
             "ctl_noise_clamp", "ctl_crop_or_pad", "ctl_step_tick", "ctl_dropout2d_ex", "ctl_uniform_dev", "ctl_adam_dev",
-            "ctl_latent_mask_fused_ws_floats", "ctl_latent_mask_fused", "ctl_accumulate"]
+            "ctl_latent_mask_fused_ws_floats", "ctl_latent_mask_fused", "ctl_accumulate", "ctl_pack_weights_bf16_batched"]
 
 
 def prof_start(kernel_filter: str = "") -> None:

@@ -20,58 +20,7 @@
 
 #include "ctl_common.h"
 
-template <int KS, int S, int MT, int TW>
-struct Geom {
-    static constexpr int MTILES = 4 * MT;            // 16-pixel M-tiles per 256-thread block
-    static constexpr int TH = MTILES * 16 / TW;      // output tile height
-    static constexpr int TP = TH * TW;               // output pixels per tile
-    static constexpr int IH = (TH - 1) * S + KS;     // input tile (virtual coordinates)
-    static constexpr int IW = (TW - 1) * S + KS;
-    static constexpr int IWH = (IW + 1) / 2;
-    static constexpr int IWP = (S == 2) ? 2 * IWH : IW;
-    static constexpr int XT_IMAGE = IH * IWP * 16;
-    static constexpr int XT_FLOATS = XT_IMAGE + 4;   // + one 16-byte dump slot for the staging units past the tile
-    static constexpr int PAD = (KS >= 3) ? 1 : 0;     // 3x3 and the 4x4 stride-2 form of a pooled 3x3 data gradient: pad 1
-    __device__ static __forceinline__ int ldscol(int c) { return (S == 2) ? ((c & 1) * IWH + (c >> 1)) : c; }
-};
-
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-// Byte offset that is out of range for every tensor (all are < 2 GiB, checked on the host): a buffer load from it returns 0
-// and a buffer store to it is dropped by the hardware bounds check -> zero padding / ragged edges cost no branch and no select.
-#define CTL_OOB ((int)0x80000000)
-// prologue coefficients (BatchNorm scale / shift per [group][cin]) are copied to LDS once per block: groups * cin <= CTL_PRO_MAX
-#define CTL_PRO_MAX 256
-
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t ctl_rsrc(const void* p, int64_t bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
-}
-__device__ __forceinline__ f32x4 ctl_bload4(__amdgpu_buffer_rsrc_t r, int voff) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0));
-}
-__device__ __forceinline__ float ctl_bload1(__amdgpu_buffer_rsrc_t r, int voff) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, 0, 0));
-}
-#ifndef CTL_STORE_AUX
-#define CTL_STORE_AUX 0      // cache-policy bits of the epilogue stores (experiment hook: sc0 = 1, nt = 2, sc1 = 16 on gfx94x/95x)
-#endif
-__device__ __forceinline__ void ctl_bstore4(__amdgpu_buffer_rsrc_t r, int voff, f32x4 v) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, 0, CTL_STORE_AUX);
-}
-__device__ __forceinline__ void ctl_bstore1(__amdgpu_buffer_rsrc_t r, int voff, float v) {
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), r, voff, 0, 0);
-}
-// Load with a wave-uniform byte offset in an SGPR: per-thread offsets stay loop-invariant VGPRs, the tile origin costs no VALU.
-// LOADS ONLY.  A buffer_store_dwordx4 with an SGPR soffset followed directly by a VALU write of its data VGPRs stores
-// garbage in the late-read lanes on gfx950 (measured: lanes 12-15 of every 16, second dword), and the compiler inserts the
-// required wait state only when soffset is NOT a register -> stores always carry the full offset in the VGPR.
-__device__ __forceinline__ f32x4 ctl_bload4s(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
-}
-// LeakyReLU for 0 <= slope <= 1 (checked on the host) as max(v, v*slope): two VALU ops, no compare+select
-__device__ __forceinline__ f32x4 ctl_leaky01(f32x4 v, float slope) {
-    const f32x4 m = v * slope;
-    return f32x4{fmaxf(v.x, m.x), fmaxf(v.y, m.y), fmaxf(v.z, m.z), fmaxf(v.w, m.w)};
-}
+#include "ctl_conv_common.h"
 
 // Staging of one 16-channel chunk of the (virtual) input tile into LDS, with the BN+LeakyReLU prologue.  Everything that
 // depends only on the thread (tile-relative coordinates, source byte offset, LDS offset) is computed ONCE (init); per tile a
@@ -193,25 +142,6 @@ struct XStage {
             // padding / channel-pad lanes hold hardware zeros and must stay zero; units past the tile go to the dump slot
             *reinterpret_cast<f32x4*>(xt + lds[i]) = ((vmask >> i) & 1u) ? t : zero;
         }
-    }
-};
-
-// Tile walker of a persistent block: tile index bid0, bid0+nblk, ... decoded incrementally (no per-tile divisions).
-struct TileWalk {
-    int n, th, tw;            // current tile coordinates
-    int dn, dth, dtw;         // decomposition of the stride nblk
-    int tiles_h, tiles_w;
-    __device__ __forceinline__ void init(int bid0, int nblk, int tiles_h_, int tiles_w_) {
-        tiles_h = tiles_h_; tiles_w = tiles_w_;
-        tw = bid0 % tiles_w; int b = bid0 / tiles_w; th = b % tiles_h; n = b / tiles_h;
-        dtw = nblk % tiles_w; b = nblk / tiles_w; dth = b % tiles_h; dn = b / tiles_h;
-    }
-    __device__ __forceinline__ void next() {
-        tw += dtw;
-        if (tw >= tiles_w) { tw -= tiles_w; ++th; }
-        th += dth;
-        if (th >= tiles_h) { th -= tiles_h; ++n; }
-        n += dn;
     }
 };
 
@@ -1130,7 +1060,7 @@ int ctl_conv_pick_cfg(const ctl_conv* d, ctl_conv_cfg* c, int for_wgrad) {
 // larger grid runs in rounds, pays the block setup again and ends in a thin tail; a smaller one leaves CUs with fewer blocks
 // than others (the dispatcher spreads blocks evenly over the CUs, tools/micro/dispatch_probe.hip).  With gridDim.y/z > 1 the
 // x extent is kept a multiple of 8 so that blockIdx.x % 8 stays the XCD of a block.
-static int conv_grid_x(int ntiles, int other, int occ) {
+int ctl_conv_grid_x(int ntiles, int other, int occ) {
     static int per_cu = -1;
     if (per_cu < 0) {
         const char* e = getenv("CTL_PERSIST");
@@ -1176,7 +1106,7 @@ static void conv_go(conv_call& a) {
     }
     const ctl_conv* d = a.d;
     const int ntiles = d->n * a.c.tiles_h * a.c.tiles_w;
-    a.grid_x = conv_grid_x(ntiles, (a.c.cot / NT) * d->nsub, occ);
+    a.grid_x = ctl_conv_grid_x(ntiles, (a.c.cot / NT) * d->nsub, occ);
     if (a.query) return;
     const dim3 grid((unsigned)a.grid_x, (unsigned)(a.c.cot / NT), (unsigned)d->nsub);
     conv_igemm_kernel<KS, S, MODE, MT, TW, NT, EPI><<<grid, dim3(256), 0, a.stream>>>(
@@ -1217,6 +1147,7 @@ static int conv_dispatch(conv_call& a) {
 }
 
 extern "C" int ctl_conv_stats_blocks(const ctl_conv* d) {
+    if (d->dt & CTL_DT_BF16) return ctl_conv_bf16_stats_blocks(d);
     conv_call a = {};
     a.d = d;
     if (ctl_conv_pick_cfg(d, &a.c, 0) != CTL_OK) return -1;
@@ -1234,6 +1165,7 @@ extern "C" int ctl_conv_forward(const ctl_conv* d, const float* x, const float* 
                                 const float* res_scale, const float* res_shift, float* y, float* stats_partial,
                                 ctl_stream stream) {
     CTL_REQUIRE(d && x && wpack && y, "conv_forward: null argument");
+    CTL_REQUIRE((d->dt & CTL_DT_BF16) || !(d->dt & (CTL_DT_X16 | CTL_DT_Y16 | CTL_DT_RES16)), "conv_forward: bf16-stored tensors need CTL_DT_BF16");
     conv_call a = {};
     a.d = d;
     int rc = ctl_conv_pick_cfg(d, &a.c, 0);
@@ -1253,6 +1185,12 @@ extern "C" int ctl_conv_forward(const ctl_conv* d, const float* x, const float* 
     CTL_REQUIRE((int64_t)d->n * d->hin * d->win * d->cin * 4 < (1ll << 31) &&
                 (int64_t)d->n * d->out_h * d->out_w * d->cout * 4 < (1ll << 31),
                 "conv_forward: tensors must stay below 2 GiB (32-bit buffer offsets)");
+    if (d->dt & CTL_DT_BF16) {
+        const int ptok16 = ctl_prof_begin("conv_igemm_bf16", d, &a.c, a.c.nt, (hipStream_t)stream);
+        rc = ctl_conv_forward_bf16(d, x, wpack, bias, pro_scale, pro_shift, res, res_scale, res_shift, y, stats_partial, stream);
+        ctl_prof_end(ptok16, (hipStream_t)stream);
+        return rc;
+    }
     a.x = x; a.wpack = wpack; a.bias = bias; a.pro_scale = pro_scale; a.pro_shift = pro_shift; a.res = res;
     a.res_scale = res_scale; a.res_shift = res_shift; a.y = y; a.stats_partial = stats_partial;
     a.stream = (hipStream_t)stream;
@@ -1335,6 +1273,10 @@ static int wgrad_pick(const ctl_conv* d, wgrad_cfg* w) {
     w->ntiles = d->n * w->c.tiles_h * w->c.tiles_w;
     w->cin_p = w->c.g * 16;
     w->cout_p = w->c.cot * 16;
+    if (d->dt & CTL_DT_BF16) {            // the bf16 kernels have their own occupancy, hence their own split count
+        w->splits = ctl_wgrad_bf16_splits(d);
+        return w->splits > 0 ? CTL_OK : CTL_EUNSUPPORTED;
+    }
     wgrad_call a = {};
     a.d = d; a.w = w; a.query = true;
     return wgrad_dispatch(a);
@@ -1367,6 +1309,12 @@ extern "C" int ctl_conv_wgrad(const ctl_conv* d, const float* x, const float* pr
     wgrad_cfg w;
     int rc = wgrad_pick(d, &w);
     if (rc != CTL_OK) return rc;
+    if (d->dt & CTL_DT_BF16) {
+        const int ptok16 = ctl_prof_begin("conv_wgrad_bf16", d, &w.c, w.ntw, (hipStream_t)stream);
+        rc = ctl_conv_wgrad_bf16(d, x, pro_scale, pro_shift, dy, w_partial, b_partial, stream);
+        ctl_prof_end(ptok16, (hipStream_t)stream);
+        return rc;
+    }
     wgrad_call a = {};
     a.d = d; a.w = &w; a.x = x; a.pro_scale = pro_scale; a.pro_shift = pro_shift; a.dy = dy; a.w_partial = w_partial;
     a.b_partial = b_partial; a.stream = (hipStream_t)stream;

@@ -1,0 +1,878 @@
+// bf16 implicit-GEMM convolution family for gfx950 (MI355X): BASELINE config 3 (bf16 activation storage, fp32 accumulate, fp32
+// BatchNorm statistics, fp32 master weights).  Same GEMM view, tile geometry, persistent XCD-aware tile walk and fused prologue /
+// epilogue as the fp32 family (ctl_conv.hip); what changes is the matrix instruction and everything that feeds it:
+//
+//   v_mfma_f32_16x16x32_bf16:  D^T[co][pixel] += W^T[co][k] * X^T[k][pixel],  K = 32 per instruction, 8 bf16 per lane and operand
+//     A (weights): lane l -> row co = l & 15, k-slots 8*(l>>4) .. +7        B (input): lane l -> k-slots 8*(l>>4) .. +7, col pixel = l & 15
+//   A 16-channel chunk of ONE tap fills only 16 of the 32 k-slots, so a fragment carries a PAIR of taps: lane groups 0,1 hold channels
+//   0-7 / 8-15 of tap 2f, groups 2,3 those of tap 2f+1 (a 3x3 conv: 5 fragments per 16-channel chunk instead of 36 fp32 MFMAs; the
+//   odd tap of the last fragment has zero weights).  One ds_read_b128 per lane (8 channels of "its" pixel, shifted by "its" tap) is one
+//   B operand; weights are pre-packed in exactly that order (pack_weights_bf16_batched_kernel), 16 bytes per lane and fragment.
+//
+// LDS input tile: [row][col][16 channels] bf16 = 32 B per pixel.  The input is staged from fp32 (network inputs) or bf16 (internal
+// activations) global memory; BatchNorm-apply + LeakyReLU of the producer runs in fp32 on the staged values, which are then rounded to
+// bf16 once (v_cvt_pk_bf16_f32, round-to-nearest-even) -- the rounding points of the path are: MFMA operands (activations after the
+// prologue, weights) and stored tensors; accumulation, bias, statistics, residual and activation arithmetic stay fp32.
+// With 14x fewer matrix cycles than fp32 these kernels are HBM-bound: what matters is bytes in flight, not VALU.
+#include <type_traits>
+
+#include "ctl_conv_common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2));
+}
+__device__ __forceinline__ u32x4 pack_bf16x8(f32x4 lo, f32x4 hi) {
+    return u32x4{pack_bf16x2(lo.x, lo.y), pack_bf16x2(lo.z, lo.w), pack_bf16x2(hi.x, hi.y), pack_bf16x2(hi.z, hi.w)};
+}
+__device__ __forceinline__ f32x4 unpack_bf16x4(unsigned a, unsigned b) {
+    return f32x4{__builtin_bit_cast(float, a << 16), __builtin_bit_cast(float, a & 0xffff0000u), __builtin_bit_cast(float, b << 16),
+                 __builtin_bit_cast(float, b & 0xffff0000u)};
+}
+__device__ __forceinline__ u32x4 ctl_bload4u(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+}
+__device__ __forceinline__ u32x2 ctl_bload2u(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+}
+
+// Staging of one 16-channel chunk of the (virtual) input tile: a unit = 8 channels of a pixel = 16 B of bf16 in LDS.
+template <int KS, int S, int MODE, int MT, int TW>
+struct XStage16 {
+    using G = Geom<KS, S, MT, TW>;
+    static constexpr int UNITS = G::IH * G::IW * 2;
+    static constexpr int NU = (UNITS + 255) / 256;
+    static constexpr int PADH = (G::PAD + 1) >> 1;
+    static constexpr int XT_BYTES = G::IH * G::IWP * 32;
+    int rel[NU];        // byte offset of the unit's first source element relative to the tile's source origin
+    int rc[NU];         // r | c << 16 (tile-relative virtual coordinates); 0x7fff7fff past the tile
+    int lds[NU];        // LDS byte offset; units past the tile write a dump slot behind the image
+    u32x4 v0[NU], v1[NU];     // source bf16: v0 = 8 channels; source fp32: v0 = channels 0-3, v1 = 4-7 of the unit
+    unsigned vmask;
+    int pad_h, pad_w;
+    bool all_in, x16;
+
+    __device__ __forceinline__ void init(const ctl_conv& d) {
+        const int tid = threadIdx.x, h = tid & 1;
+        x16 = (d.dt & CTL_DT_X16) != 0;
+        const int esz = x16 ? 2 : 4;
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            const int u = tid + i * 256;
+            const int pix = u >> 1;
+            const int r = pix / G::IW;
+            const int c = pix - r * G::IW;
+            const bool in = u < UNITS;
+            const int rr = (MODE == CTL_IN_PLAIN) ? r : (((r - G::PAD) >> 1) + PADH);
+            const int cc = (MODE == CTL_IN_PLAIN) ? c : (((c - G::PAD) >> 1) + PADH);
+            rel[i] = in ? ((rr * d.win + cc) * d.cin + h * 8) * esz : CTL_OOB;
+            rc[i] = in ? (r | (c << 16)) : 0x7fff7fff;
+            lds[i] = in ? ((r * G::IWP + G::ldscol(c)) * 32 + h * 16) : XT_BYTES;
+        }
+        vmask = 0;
+        all_in = false;
+        pad_h = pad_w = G::PAD;
+    }
+
+    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rx, const ctl_conv& d, int n, int ho0, int wo0, int g) {
+        const int vh0 = ho0 * S - pad_h, vw0 = wo0 * S - pad_w;
+        const unsigned hv = (MODE == CTL_IN_PLAIN) ? d.hin : 2 * d.hin;
+        const unsigned wv = (MODE == CTL_IN_PLAIN) ? d.win : 2 * d.win;
+        const int oh = (MODE == CTL_IN_PLAIN) ? vh0 : ((ho0 >> 1) - PADH);
+        const int ow = (MODE == CTL_IN_PLAIN) ? vw0 : ((wo0 >> 1) - PADH);
+        const int esz = x16 ? 2 : 4;
+        const int tb = (((n * d.hin + oh) * d.win + ow) * d.cin + g * 16) * esz;
+        all_in = MODE != CTL_IN_ZINS2 && vh0 >= 0 && vw0 >= 0 && vh0 + G::IH <= (int)hv && vw0 + G::IW <= (int)wv &&
+                 g * 16 + 16 <= d.cin;
+        if (all_in) {
+            if (x16) {
+#pragma unroll
+                for (int i = 0; i < NU; ++i) v0[i] = ctl_bload4u(rx, rel[i], tb);
+            } else {
+#pragma unroll
+                for (int i = 0; i < NU; ++i) { v0[i] = ctl_bload4u(rx, rel[i], tb); v1[i] = ctl_bload4u(rx, rel[i] + 16, tb); }
+            }
+            return;
+        }
+        const int cb = g * 16 + (threadIdx.x & 1) * 8;          // first channel of this thread's units
+        unsigned m = 0;
+        int vo[NU];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            const int vh = vh0 + (rc[i] & 0xffff), vw = vw0 + (rc[i] >> 16);
+            bool ok = cb < d.cin && (unsigned)vh < hv && (unsigned)vw < wv;
+            if (MODE == CTL_IN_ZINS2) ok = ok && (((vh | vw) & 1) == 0);
+            vo[i] = ok ? (tb + rel[i]) : CTL_OOB;
+            m |= ok ? (1u << i) : 0u;
+        }
+        vmask = m;
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        if (x16) {                                  // internal tensors: cin is a multiple of 16 (checked on the host)
+#pragma unroll
+            for (int i = 0; i < NU; ++i) v0[i] = ctl_bload4u(rx, vo[i], 0);
+        } else if (d.cin >= 4) {                    // fp32 source: quads of 4 channels, the second one may lie past cin (4 or 12 channels)
+            const bool q1 = cb + 4 < d.cin;
+#pragma unroll
+            for (int i = 0; i < NU; ++i) { v0[i] = ctl_bload4u(rx, vo[i], 0); v1[i] = q1 ? ctl_bload4u(rx, vo[i] + 16, 0) : z; }
+        } else {                                    // one input channel
+#pragma unroll
+            for (int i = 0; i < NU; ++i) {
+                v0[i] = u32x4{__builtin_amdgcn_raw_buffer_load_b32(rx, vo[i], 0, 0), 0u, 0u, 0u};
+                v1[i] = z;
+            }
+        }
+    }
+
+    __device__ __forceinline__ void store(unsigned char* __restrict__ xt, const ctl_conv& d, int g, const float* cf_scale,
+                                          const float* cf_shift, int goff) {
+        if (!d.pro_affine && x16) {                 // bf16 in, nothing to compute: out-of-range units were loaded as hardware zeros
+#pragma unroll
+            for (int i = 0; i < NU; ++i) *reinterpret_cast<u32x4*>(xt + lds[i]) = v0[i];
+            return;
+        }
+        const int cb = g * 16 + (threadIdx.x & 1) * 8;
+        f32x4 sc0 = {1.f, 1.f, 1.f, 1.f}, sh0 = {0.f, 0.f, 0.f, 0.f}, sc1 = sc0, sh1 = sh0;
+        if (d.pro_affine && cb < d.cin) {
+            if (d.cin >= 4) {
+                sc0 = *reinterpret_cast<const f32x4*>(cf_scale + goff + cb);
+                sh0 = *reinterpret_cast<const f32x4*>(cf_shift + goff + cb);
+                if (cb + 4 < d.cin) {
+                    sc1 = *reinterpret_cast<const f32x4*>(cf_scale + goff + cb + 4);
+                    sh1 = *reinterpret_cast<const f32x4*>(cf_shift + goff + cb + 4);
+                }
+            } else { sc0.x = cf_scale[goff]; sh0.x = cf_shift[goff]; }
+        }
+        const float slope = d.pro_slope;
+        const u32x4 zero = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            f32x4 lo, hi;
+            if (x16) { lo = unpack_bf16x4(v0[i].x, v0[i].y); hi = unpack_bf16x4(v0[i].z, v0[i].w); }
+            else { lo = __builtin_bit_cast(f32x4, v0[i]); hi = __builtin_bit_cast(f32x4, v1[i]); }
+            if (d.pro_affine) { lo = ctl_leaky01(lo * sc0 + sh0, slope); hi = ctl_leaky01(hi * sc1 + sh1, slope); }
+            u32x4 pk = pack_bf16x8(lo, hi);
+            // padding / channel-pad lanes hold hardware zeros and must stay zero under the affine prologue
+            if (d.pro_affine && !all_in && !((vmask >> i) & 1u)) pk = zero;
+            *reinterpret_cast<u32x4*>(xt + lds[i]) = pk;
+        }
+    }
+};
+
+#define NFRAG_OF(KS) (((KS) * (KS) + 1) / 2)
+
+template <int KS, int S, int MODE, int MT, int TW, int NT>
+__global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : 3) void conv_igemm_bf16_kernel(
+    const ctl_conv d, const void* __restrict__ x, const void* __restrict__ wpack, const float* __restrict__ bias,
+    const float* __restrict__ pro_scale, const float* __restrict__ pro_shift, const void* __restrict__ res,
+    const float* __restrict__ res_scale, const float* __restrict__ res_shift, void* __restrict__ y, float* __restrict__ stats_partial,
+    int tiles_h, int tiles_w, int G_chunks, int64_t wpack_sub_bytes, int ntiles) {
+    using G = Geom<KS, S, MT, TW>;
+    using XS = XStage16<KS, S, MODE, MT, TW>;
+    constexpr int TAPS = KS * KS;
+    constexpr int NFRAG = NFRAG_OF(KS);
+    constexpr int XT_ALLOC = XS::XT_BYTES + 16;            // + dump slot
+    constexpr int WT_BYTES = NFRAG * NT * 1024;
+    constexpr int RED_FLOATS = 4 * NT * 16 * 2;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[XT_ALLOC + WT_BYTES + (RED_FLOATS + 2 * CTL_PRO_MAX) * 4];
+    unsigned char* xt = smem;
+    unsigned char* wt = smem + XT_ALLOC;
+    float* sred = reinterpret_cast<float*>(wt + WT_BYTES);
+    float* cf_scale = sred + RED_FLOATS;
+    float* cf_shift = cf_scale + CTL_PRO_MAX;
+    constexpr int WU = NFRAG * NT * 64, NW = (WU + 255) / 256;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p = lane & 15, q = lane >> 4;
+    const int P = gridDim.x < 8 ? (int)gridDim.x : 8;
+    const int xcd = blockIdx.x % P, jblk = blockIdx.x / P;
+    const int nb = ((int)gridDim.x - xcd + P - 1) / P;
+    const int t_lo = (int)(((int64_t)ntiles * xcd) / P), t_hi = (int)(((int64_t)ntiles * (xcd + 1)) / P);
+    const int bid0 = t_lo + jblk;
+    const int z = blockIdx.z;
+    const int cot0 = blockIdx.y * NT;
+    const unsigned char* wp = reinterpret_cast<const unsigned char*>(wpack) + (int64_t)z * wpack_sub_bytes;
+    const int my_tiles = (bid0 < t_hi) ? (t_hi - bid0 + nb - 1) / nb : 0;
+    const int total_it = my_tiles * G_chunks;
+    const int flags = d.epi_flags;
+    const bool y16 = (d.dt & CTL_DT_Y16) != 0, r16 = (d.dt & CTL_DT_RES16) != 0;
+    const int yes = y16 ? 2 : 4, res_es = r16 ? 2 : 4;
+    const int ngroups = d.groups > 1 ? d.groups : 1;
+    const int group_n = d.n / ngroups;
+    const int oy0 = (z >> 1) * d.out_sub, ox0 = (z & 1) * d.out_sub;
+    const __amdgpu_buffer_rsrc_t rx = ctl_rsrc(x, (int64_t)d.n * d.hin * d.win * d.cin * ((d.dt & CTL_DT_X16) ? 2 : 4));
+    const int64_t ypix = (int64_t)d.n * d.out_h * d.out_w * d.cout;
+    const __amdgpu_buffer_rsrc_t ry = ctl_rsrc(y, ypix * yes);
+    const __amdgpu_buffer_rsrc_t rres = ctl_rsrc(res ? res : y, ypix * (res ? res_es : yes));
+
+    f32x4 ssum[NT], ssq[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) ssum[t] = ssq[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    constexpr int TWT = TW / 16;
+    static_assert(MT % TWT == 0, "a wave's M-tiles must cover whole tile rows");
+    const int wrow = wave * (MT / TWT);
+    int yrel[MT];                                       // element offset of this lane's 4 channels of M-tile m relative to the tile's output origin
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+        yrel[m] = ((wrow + m / TWT) * d.out_sy * d.out_w + ((m % TWT) * 16 + p) * d.out_sx) * d.cout + q * 4;
+    f32x4 bias4[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int co0 = (cot0 + t) * 16 + q * 4;
+        f32x4 b = {0.f, 0.f, 0.f, 0.f};
+        if (flags & CTL_EPI_BIAS) {
+            if (d.cout >= 4) b = *reinterpret_cast<const f32x4*>(bias + (co0 < d.cout ? co0 : 0));
+            else b.x = bias[0];
+        }
+        bias4[t] = b;
+        asm volatile("" ::"v"(bias4[t]));
+    }
+    // B-operand addresses: lane group q carries tap 2f + (q >> 1) (clamped to the last tap: its weights are zero there), channels
+    // 8*(q & 1) .. +7 of it; (fragment, M-tile) offsets: one VGPR per fragment + compile-time immediates per M-tile
+    int xoff[NFRAG];
+#pragma unroll
+    for (int f = 0; f < NFRAG; ++f) {
+        int tap = 2 * f + (q >> 1);
+        tap = tap < TAPS ? tap : TAPS - 1;
+        const int kh = tap / KS, kw = tap % KS;
+        const int kcol = (S == 2) ? ((kw & 1) * G::IWH + (kw >> 1)) : kw;
+        xoff[f] = (((wrow * S + kh) * G::IWP + p + kcol) * 32) + (q & 1) * 16;
+    }
+    const unsigned char* wrd = wt + lane * 16;
+
+    XS xs;
+    xs.init(d);
+    if (KS == 2 && S == 1) {
+        xs.pad_h = d.pad == 2 ? 1 - (z >> 1) : 0;
+        xs.pad_w = d.pad == 2 ? 1 - (z & 1) : 0;
+    }
+    // weight chunk g: [fragment][t][64 lanes][16 B]
+    const __amdgpu_buffer_rsrc_t rw = ctl_rsrc(wp, (int64_t)ctl_cdiv(d.cout, 16) * NFRAG * G_chunks * 1024);
+    u32x4 wv[NW];
+    int wrel[NW];
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        const int u = tid + i * 256;
+        const int tt = u >> 6, l = u & 63;
+        const int f = tt / NT, t = tt - f * NT;
+        wrel[i] = (u < WU) ? ((((cot0 + t) * NFRAG + f) * G_chunks) * 64 + l) * 16 : CTL_OOB;
+    }
+    auto wload = [&](int g) {
+#pragma unroll
+        for (int i = 0; i < NW; ++i) wv[i] = ctl_bload4u(rw, wrel[i], g * 1024);
+    };
+    auto wstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int u = tid + i * 256;
+            if (u < WU) *reinterpret_cast<u32x4*>(wt + u * 16) = wv[i];
+        }
+    };
+
+    TileWalk cur, nxt;
+    cur.init(bid0, nb, tiles_h, tiles_w);
+    nxt = cur;
+    if (total_it > 0) {
+        xs.load(rx, d, cur.n, cur.th * G::TH, cur.tw * TW, 0);
+        wload(0);
+    }
+    if (d.pro_affine) {
+        for (int i = tid; i < ngroups * d.cin; i += 256) { cf_scale[i] = pro_scale[i]; cf_shift[i] = pro_shift[i]; }
+        __syncthreads();
+    }
+    if (total_it > 0) {
+        xs.store(xt, d, 0, cf_scale, cf_shift, (cur.n / group_n) * d.cin);
+        wstore();
+    }
+    __syncthreads();
+
+    const int srows = gridDim.x * gridDim.z, srow = z * gridDim.x + blockIdx.x;
+    auto flush_stats = [&](int grp) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            float a[8] = {ssum[t].x, ssum[t].y, ssum[t].z, ssum[t].w, ssq[t].x, ssq[t].y, ssq[t].z, ssq[t].w};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float v = a[i];
+                v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+                a[i] = v;
+            }
+            if (p == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    sred[((wave * NT + t) * 16 + q * 4 + r) * 2 + 0] = a[r];
+                    sred[((wave * NT + t) * 16 + q * 4 + r) * 2 + 1] = a[4 + r];
+                }
+            }
+            ssum[t] = ssq[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        __syncthreads();
+        if (tid < NT * 16 * 2) {
+            const int stat = tid / (NT * 16), cl = tid % (NT * 16);
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) v += sred[((w * NT * 16) + cl) * 2 + stat];
+            const int co = cot0 * 16 + cl;
+            if (co < d.cout) stats_partial[(((int64_t)grp * srows + srow) * 2 + stat) * d.cout + co] = v;
+        }
+        __syncthreads();
+    };
+    int cur_grp = (my_tiles > 0) ? cur.n / group_n : 0;
+    if ((flags & CTL_EPI_STATS) && ngroups > 1 && tid < NT * 16 * 2) {
+        const int stat = tid / (NT * 16), co = cot0 * 16 + tid % (NT * 16);
+        if (co < d.cout)
+            for (int gi = 0; gi < ngroups; ++gi) stats_partial[(((int64_t)gi * srows + srow) * 2 + stat) * d.cout + co] = 0.f;
+    }
+
+    f32x4 acc[MT][NT];
+    for (int it = 0, g = 0; it < total_it; ++it) {
+        const int n = cur.n, ho0 = cur.th * G::TH, wo0 = cur.tw * TW;
+        const bool has_next = it + 1 < total_it;
+        const int g2 = (g + 1 == G_chunks) ? 0 : g + 1;
+        const bool new_w = has_next && G_chunks > 1;
+        if (g2 == 0) nxt.next();
+        if (has_next) {
+            xs.load(rx, d, nxt.n, nxt.th * G::TH, nxt.tw * TW, g2);
+            if (new_w) wload(g2);
+        }
+        if (g == 0) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[m][t] = bias4[t];
+        }
+#pragma unroll
+        for (int f = 0; f < NFRAG; ++f) {
+            bf16x8 wf[NT], xf[MT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) wf[t] = *reinterpret_cast<const bf16x8*>(wrd + (f * NT + t) * 1024);
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+                xf[m] = *reinterpret_cast<const bf16x8*>(xt + xoff[f] + (((m / TWT) * S) * G::IWP + (m % TWT) * 16) * 32);
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t], xf[m], acc[m][t], 0, 0, 0);
+        }
+        ctl_barrier_lds_reads_done();
+        if (has_next) {
+            xs.store(xt, d, g2, cf_scale, cf_shift, (nxt.n / group_n) * d.cin);
+            if (new_w) wstore();
+        }
+        ctl_barrier_lds_writes_done();
+
+        if (g == G_chunks - 1) {
+            const int grp = n / group_n;
+            if ((flags & CTL_EPI_STATS) && grp != cur_grp) {
+                flush_stats(cur_grp);
+                cur_grp = grp;
+            }
+            const int ybase = ((n * d.out_h + ho0 * d.out_sy + oy0) * d.out_w + wo0 * d.out_sx + ox0) * d.cout + cot0 * 16;      // elements
+            const bool full = ho0 + G::TH <= d.hout && wo0 + TW <= d.wout && (cot0 + NT) * 16 <= d.cout;
+            auto load4 = [&](__amdgpu_buffer_rsrc_t r, int eoff, bool b16) -> f32x4 {      // 4 channels at element offset eoff (or OOB)
+                if (eoff == CTL_OOB) return f32x4{0.f, 0.f, 0.f, 0.f};
+                if (b16) { const u32x2 u = ctl_bload2u(r, eoff * 2, 0); return unpack_bf16x4(u.x, u.y); }
+                return __builtin_bit_cast(f32x4, ctl_bload4u(r, eoff * 4, 0));
+            };
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int co0 = (cot0 + t) * 16 + q * 4;
+                const bool cok = full || co0 < d.cout;
+                const int cc = cok ? co0 : 0;
+                f32x4 rs = {0.f, 0.f, 0.f, 0.f}, rh = {0.f, 0.f, 0.f, 0.f};
+                if (flags & CTL_EPI_RES) {
+                    if (d.cout >= 4) {
+                        rs = *reinterpret_cast<const f32x4*>(res_scale + grp * d.cout + cc);
+                        rh = *reinterpret_cast<const f32x4*>(res_shift + grp * d.cout + cc);
+                    } else { rs.x = res_scale[grp]; rh.x = res_shift[grp]; }
+                }
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const bool pv = full || ((ho0 + wrow + m / TWT < d.hout) && (wo0 + (m % TWT) * 16 + p < d.wout));
+                    const int eo = (pv && cok) ? (ybase + yrel[m] + t * 16) : CTL_OOB;
+                    f32x4 v = acc[m][t];
+                    if (flags & CTL_EPI_RES) {
+                        f32x4 rv;
+                        if (d.cout >= 4) rv = load4(rres, eo, r16);
+                        else rv = f32x4{eo == CTL_OOB ? 0.f : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, eo * 4, 0, 0)), 0.f, 0.f, 0.f};
+                        v += rv * rs + rh;
+                    }
+                    if ((flags & CTL_EPI_STATS) && pv) { ssum[t] += v; ssq[t] += v * v; }
+                    if (d.epi_act == CTL_ACT_LEAKY) {
+                        v = ctl_leaky01(v, d.epi_slope);
+                    } else if (d.epi_act == CTL_ACT_SIGMOID) {
+                        v.x = 1.f / (1.f + expf(-v.x)); v.y = 1.f / (1.f + expf(-v.y));
+                        v.z = 1.f / (1.f + expf(-v.z)); v.w = 1.f / (1.f + expf(-v.w));
+                    }
+                    if (flags & CTL_EPI_ACCUM) {
+                        if (d.cout >= 4) v += load4(ry, eo, y16);
+                        else v.x += eo == CTL_OOB ? 0.f : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, eo * 4, 0, 0));
+                    }
+                    if (eo != CTL_OOB) {
+                        if (d.cout >= 4) {
+                            if (y16) __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)}, ry, eo * 2, 0, 0);
+                            else ctl_bstore4(ry, eo * 4, v);
+                        } else {
+                            ctl_bstore1(ry, eo * 4, v.x);             // cout == 1 (fp32 network output)
+                        }
+                    }
+                }
+            }
+        }
+        if (g2 == 0) cur = nxt;
+        g = g2;
+    }
+    if (flags & CTL_EPI_STATS) flush_stats(cur_grp);
+}
+
+// ------------------------------------------------------------------------------------------------ weight packing (bf16 fragments)
+// Same table records as pack_weights_batched_kernel (modes 0-3; mode 4 = K-packed taps is an fp32-only layout: the bf16 family runs the
+// <= 4-channel first layers through the plain path, the tile is HBM-bound either way).  One thread = one uint32 = two bf16 of
+// dst[cot][fragment][chunk g][lane][8]: lane (co = lane & 15, q = lane >> 4), element j -> tap 2f + (q >> 1), ci = 16 g + 8 (q & 1) + j.
+__device__ float ctl_pack_value(const float* __restrict__ src, const int64_t* __restrict__ r, int co, int ci, int kh, int kw) {
+    const int cout = (int)r[2], cin = (int)r[3], ks = (int)r[4], flip = (int)r[5];
+    if (co >= cout || ci >= cin) return 0.f;
+    float v = 0.f;
+    if (r[11] == 1) {
+        for (int a = 0; a < 2; ++a) {
+            const int sh = a + 2 - kh;
+            if (sh < 0 || sh > 2) continue;
+            for (int b = 0; b < 2; ++b) {
+                const int sw = b + 2 - kw;
+                if (sw < 0 || sw > 2) continue;
+                v += src[co * r[6] + ci * r[7] + sh * r[8] + sw * r[9]];
+            }
+        }
+    } else if (r[11] == 2) {
+        const int a = flip >> 1, b = flip & 1;
+        const int h0 = (kh == 0) ? 0 : (a ? 2 : 1), h1 = (kh == 0) ? (a ? 1 : 0) : 2;
+        const int w0 = (kw == 0) ? 0 : (b ? 2 : 1), w1 = (kw == 0) ? (b ? 1 : 0) : 2;
+        for (int sh = h0; sh <= h1; ++sh)
+            for (int sw = w0; sw <= w1; ++sw) v += src[co * r[6] + ci * r[7] + sh * r[8] + sw * r[9]];
+    } else if (r[11] == 3) {
+        const int a = flip >> 1, b = flip & 1;
+        const int sh = a ? (kh == 0 ? 2 : 0) : (kh == 0 ? 1 : -1);
+        const int sw = b ? (kw == 0 ? 2 : 0) : (kw == 0 ? 1 : -1);
+        if (sh >= 0 && sw >= 0) v = src[co * r[6] + ci * r[7] + sh * r[8] + sw * r[9]];
+    } else {
+        if (flip) { kh = ks - 1 - kh; kw = ks - 1 - kw; }
+        v = src[co * r[6] + ci * r[7] + kh * r[8] + kw * r[9]];
+    }
+    return v;
+}
+__global__ void pack_weights_bf16_batched_kernel(const float* __restrict__ params, float* __restrict__ wpack,
+                                                 const int64_t* __restrict__ table) {
+    const int64_t* r = table + (int64_t)blockIdx.y * 12;
+    const int cout = (int)r[2], cin = (int)r[3], ks = (int)r[4];
+    if (r[11] == 4) return;                                  // (not a bf16 layout)
+    const int g_chunks = (cin + 15) / 16, taps = ks * ks, nfrag = (taps + 1) / 2;
+    const int64_t total = (int64_t)((cout + 15) / 16) * nfrag * g_chunks * 64 * 4;      // uint32 words
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const float* src = params + r[0];
+    unsigned* dst = reinterpret_cast<unsigned*>(wpack + r[1]);
+    const int jp = idx & 3, lane = (idx >> 2) & 63;
+    int64_t rest = idx >> 8;
+    const int g = rest % g_chunks;
+    rest /= g_chunks;
+    const int f = rest % nfrag;
+    const int cot = rest / nfrag;
+    const int co = cot * 16 + (lane & 15), q = lane >> 4;
+    const int tap = 2 * f + (q >> 1);
+    float a = 0.f, b = 0.f;
+    if (tap < taps) {
+        const int ci = g * 16 + (q & 1) * 8 + jp * 2;
+        a = ctl_pack_value(src, r, co, ci, tap / ks, tap % ks);
+        b = ctl_pack_value(src, r, co, ci + 1, tap / ks, tap % ks);
+    }
+    dst[idx] = pack_bf16x2(a, b);
+}
+extern "C" int ctl_pack_weights_bf16_batched(const float* params, float* wpack, const int64_t* table, int32_t n_rec, int64_t max_total,
+                                             ctl_stream stream) {
+    CTL_REQUIRE(params && wpack && table && n_rec > 0 && max_total > 0, "pack_weights_bf16_batched: bad arguments");
+    // `max_total` is the fp32 layout's float count per record, an upper bound of the bf16 layout's uint32 count (5 of 9 taps)
+    pack_weights_bf16_batched_kernel<<<dim3((unsigned)ctl_cdiv64(max_total, 256), (unsigned)n_rec), dim3(256), 0, (hipStream_t)stream>>>(
+        params, wpack, table);
+    CTL_LAUNCH_CHECK("pack_weights_bf16_batched");
+    return CTL_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+struct conv16_call {
+    const ctl_conv* d; ctl_conv_cfg c;
+    const void *x, *wpack, *res; void* y;
+    const float *bias, *pro_scale, *pro_shift, *res_scale, *res_shift; float* stats_partial;
+    hipStream_t stream; bool query; int grid_x;
+};
+template <int KS, int S, int MODE, int MT, int TW, int NT>
+static void conv16_go(conv16_call& a) {
+    static int occ = 0;
+    if (!occ) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_igemm_bf16_kernel<KS, S, MODE, MT, TW, NT>, 256, 0) != hipSuccess || n < 1) {
+            (void)hipGetLastError();
+            n = 2;
+        }
+        occ = n;
+    }
+    const ctl_conv* d = a.d;
+    const int ntiles = d->n * a.c.tiles_h * a.c.tiles_w;
+    a.grid_x = ctl_conv_grid_x(ntiles, (a.c.cot / NT) * d->nsub, occ);
+    if (a.query) return;
+    const dim3 grid((unsigned)a.grid_x, (unsigned)(a.c.cot / NT), (unsigned)d->nsub);
+    conv_igemm_bf16_kernel<KS, S, MODE, MT, TW, NT><<<grid, dim3(256), 0, a.stream>>>(
+        *d, a.x, a.wpack, a.bias, a.pro_scale, a.pro_shift, a.res, a.res_scale, a.res_shift, a.y, a.stats_partial, a.c.tiles_h, a.c.tiles_w,
+        a.c.g, (int64_t)ctl_conv_wpack_floats(d->cin, d->cout, d->ks) * 4, ntiles);
+}
+template <int KS, int S, int MODE>
+static void conv16_go_tile(conv16_call& a) {
+    const bool big = S == 1 && a.c.mt == 4 && a.c.tw == 32;
+    if (a.c.nt == 2) {
+        if (big) conv16_go<KS, S, MODE, (S == 1 ? 4 : 2), (S == 1 ? 32 : 16), 2>(a);
+        else if (a.c.mt == 2) conv16_go<KS, S, MODE, 2, 16, 2>(a);
+        else conv16_go<KS, S, MODE, 1, 16, 2>(a);
+    } else {
+        if (big) conv16_go<KS, S, MODE, (S == 1 ? 4 : 2), (S == 1 ? 32 : 16), 1>(a);
+        else if (a.c.mt == 2) conv16_go<KS, S, MODE, 2, 16, 1>(a);
+        else conv16_go<KS, S, MODE, 1, 16, 1>(a);
+    }
+}
+static int conv16_dispatch(conv16_call& a) {
+    const int k = a.d->ks, s = a.d->stride, m = a.d->in_mode == CTL_IN_C4 ? CTL_IN_PLAIN : a.d->in_mode;
+    if (k == 3 && s == 1 && m == CTL_IN_PLAIN) conv16_go_tile<3, 1, CTL_IN_PLAIN>(a);
+    else if (k == 3 && s == 1 && m == CTL_IN_UP2) conv16_go_tile<3, 1, CTL_IN_UP2>(a);
+    else if (k == 3 && s == 1 && m == CTL_IN_ZINS2) conv16_go_tile<3, 1, CTL_IN_ZINS2>(a);
+    else if (k == 3 && s == 2) conv16_go_tile<3, 2, CTL_IN_PLAIN>(a);
+    else if (k == 1 && m == CTL_IN_PLAIN) conv16_go_tile<1, 1, CTL_IN_PLAIN>(a);
+    else if (k == 1 && m == CTL_IN_UP2) conv16_go_tile<1, 1, CTL_IN_UP2>(a);
+    else if (k == 2 && s == 2) conv16_go_tile<2, 2, CTL_IN_PLAIN>(a);
+    else if (k == 2 && s == 1) conv16_go_tile<2, 1, CTL_IN_PLAIN>(a);
+    else if (k == 4 && s == 2) {
+        if (a.c.mt == 2 && a.c.nt == 1) conv16_go<4, 2, CTL_IN_PLAIN, 2, 16, 1>(a);
+        else if (a.c.nt == 2) conv16_go<4, 2, CTL_IN_PLAIN, 1, 16, 2>(a);
+        else conv16_go<4, 2, CTL_IN_PLAIN, 1, 16, 1>(a);
+    } else CTL_FAIL(CTL_EUNSUPPORTED, "conv_forward(bf16): no kernel for this combination");
+    return CTL_OK;
+}
+
+int ctl_conv_bf16_stats_blocks(const ctl_conv* d) {
+    conv16_call a = {};
+    a.d = d;
+    if (ctl_conv_pick_cfg(d, &a.c, 0) != CTL_OK) return -1;
+    a.query = true;
+    if (conv16_dispatch(a) != CTL_OK) return -1;
+    return a.grid_x * d->nsub;
+}
+
+int ctl_conv_forward_bf16(const ctl_conv* d, const void* x, const void* wpack, const float* bias, const float* pro_scale,
+                          const float* pro_shift, const void* res, const float* res_scale, const float* res_shift, void* y,
+                          float* stats_partial, ctl_stream stream) {
+    CTL_REQUIRE(!(d->epi_flags & CTL_EPI_BNBWD), "conv_forward(bf16): CTL_EPI_BNBWD is an fp32-only epilogue");
+    CTL_REQUIRE(!(d->dt & CTL_DT_X16) || d->cin % 16 == 0, "conv_forward(bf16): bf16-stored inputs need cin %% 16 == 0 (got %d)", d->cin);
+    CTL_REQUIRE(!(d->dt & (CTL_DT_Y16 | CTL_DT_RES16)) || d->cout % 4 == 0, "conv_forward(bf16): bf16-stored outputs need cout %% 4 == 0");
+    conv16_call a = {};
+    a.d = d;
+    int rc = ctl_conv_pick_cfg(d, &a.c, 0);
+    if (rc != CTL_OK) return rc;
+    a.x = x; a.wpack = wpack; a.bias = bias; a.pro_scale = pro_scale; a.pro_shift = pro_shift; a.res = res; a.res_scale = res_scale;
+    a.res_shift = res_shift; a.y = y; a.stats_partial = stats_partial; a.stream = (hipStream_t)stream;
+    rc = conv16_dispatch(a);
+    if (rc != CTL_OK) return rc;
+    CTL_LAUNCH_CHECK("conv_forward(bf16)");
+    return CTL_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradient (bf16 operands)
+// dW[tap][ci][co] = sum_pixels x_virtual[pixel*S + tap - pad][ci] * dy[pixel][co]:  D[ci][co] += A[ci][k = pixel] B[pixel][co], K = 32 pixels.
+// Both operands want 8 PIXELS of one channel per lane, i.e. the transpose of the [pixel][16 channel] LDS tiles -- which is what
+// gfx950's ds_read_b64_tr_b16 delivers for free: per 16-lane group it reads 4 rows (pixels) x 16 columns (channels) of 16-bit elements and
+// hands lane i column i.  Lane 4q'+p' of a group supplies the address of row q', columns 4p'..4p'+3; every lane supplies its own row
+// address, so a tap shift is just another pixel address.  k-block kb of a tile = tile rows 2kb, 2kb+1 (TW = 16): lane group gk takes row
+// 2kb + (gk >> 1), columns 8(gk & 1) .. +7 (two transposed reads of 4 pixels each).  Wave w owns k-block w; the four waves are summed
+// through LDS at the end exactly like the fp32 kernel, same partial layout, same deterministic split reduction.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 tr_read8(const unsigned char* a0, const unsigned char* a1) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a1));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    return __builtin_bit_cast(bf16x8, s16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w});
+}
+
+template <int KS, int S, int MODE, int MT, int NTW>
+__global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const ctl_conv d, const void* __restrict__ x,
+                                                               const float* __restrict__ pro_scale, const float* __restrict__ pro_shift,
+                                                               const void* __restrict__ dy, float* __restrict__ w_partial,
+                                                               float* __restrict__ b_partial, int tiles_h, int tiles_w, int ntiles,
+                                                               int cin_p, int cout_p) {
+    constexpr int TW = 16;
+    using G = Geom<KS, S, MT, TW>;
+    using XS = XStage16<KS, S, MODE, MT, TW>;
+    constexpr int TAPS = KS * KS;
+    constexpr int KB = G::TP / 32;                       // k-blocks per tile: 4 (8x16 tile) or 2 (4x16)
+    constexpr int XT_ALLOC = XS::XT_BYTES + 16;
+    constexpr int DYT_BYTES = NTW * G::TP * 32;
+    constexpr int RED_BYTES = 4 * NTW * 256 * 4;
+    constexpr int MAIN_BYTES = (XT_ALLOC + DYT_BYTES > RED_BYTES) ? (XT_ALLOC + DYT_BYTES) : RED_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[MAIN_BYTES + 2 * CTL_PRO_MAX * 4];
+    unsigned char* xt = smem;
+    unsigned char* dyt = smem + XT_ALLOC;
+    float* cf_scale = reinterpret_cast<float*>(smem + MAIN_BYTES);
+    float* cf_shift = cf_scale + CTL_PRO_MAX;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p = lane & 15, q = lane >> 4;
+    const int g = blockIdx.y;
+    const int cot0 = blockIdx.z * NTW;
+    const int group_n = d.n / (d.groups > 1 ? d.groups : 1);
+    const bool dy16 = (d.dt & CTL_DT_Y16) != 0;
+    const int des = dy16 ? 2 : 4;
+
+    f32x4 acc[TAPS][NTW];
+#pragma unroll
+    for (int a = 0; a < TAPS; ++a)
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) acc[a][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) bsum[t] = 0.f;
+
+    const __amdgpu_buffer_rsrc_t rx = ctl_rsrc(x, (int64_t)d.n * d.hin * d.win * d.cin * ((d.dt & CTL_DT_X16) ? 2 : 4));
+    const __amdgpu_buffer_rsrc_t rdy = ctl_rsrc(dy, (int64_t)d.n * d.hout * d.wout * d.cout * des);
+    XS xs;
+    xs.init(d);
+    // dy tile [cout tile t][pixel][16 ch] bf16: units of 8 channels
+    constexpr int DU = G::TP * NTW * 2, ND = (DU + 255) / 256;
+    u32x4 dv0[ND], dv1[ND];
+    int drel[ND], drc[ND], dlds[ND];
+    bool dq1[ND];
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+        const int u = tid + i * 256;
+        const int pix = u / (NTW * 2), rest = u - pix * (NTW * 2);
+        const int t = rest >> 1, h = rest & 1;
+        const int pr = pix / TW, pc = pix % TW;
+        const int co = (cot0 + t) * 16 + h * 8;
+        const bool in = u < DU && co < d.cout;
+        drc[i] = in ? (pr | (pc << 16)) : 0x7fff7fff;
+        drel[i] = in ? ((pr * d.wout + pc) * d.cout + co) * des : CTL_OOB;
+        dlds[i] = (u < DU) ? ((t * G::TP + pix) * 32 + h * 16) : DYT_BYTES - 16;      // (units past the tile cannot exist: DU is a multiple of 256 or ND covers it)
+        dq1[i] = co + 4 < d.cout;
+    }
+    auto dyload = [&](int n, int ho0, int wo0) {
+        const int tb = ((n * d.hout + ho0) * d.wout + wo0) * d.cout * des;
+        const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const bool ok = (unsigned)(ho0 + (drc[i] & 0xffff)) < (unsigned)d.hout && (unsigned)(wo0 + (drc[i] >> 16)) < (unsigned)d.wout;
+            const int vo = ok ? (tb + drel[i]) : CTL_OOB;
+            if (dy16) dv0[i] = ctl_bload4u(rdy, vo, 0);
+            else if (d.cout >= 4) { dv0[i] = ctl_bload4u(rdy, vo, 0); dv1[i] = dq1[i] ? ctl_bload4u(rdy, vo + 16, 0) : z; }
+            else { dv0[i] = u32x4{__builtin_amdgcn_raw_buffer_load_b32(rdy, vo, 0, 0), 0u, 0u, 0u}; dv1[i] = z; }
+        }
+    };
+    auto dystore = [&]() {
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            if (tid + i * 256 < DU)
+                *reinterpret_cast<u32x4*>(dyt + dlds[i]) =
+                    dy16 ? dv0[i] : pack_bf16x8(__builtin_bit_cast(f32x4, dv0[i]), __builtin_bit_cast(f32x4, dv1[i]));
+        }
+    };
+    // transposed-read addresses of this lane: block row q' = (lane & 15) >> 2 (pixel), 8-byte column chunk p' = lane & 3
+    const int qp = (lane & 15) >> 2, pp = lane & 3;
+    const int krow = (q >> 1), kcol0 = 8 * (q & 1);     // tile row (within the k-block's two rows) and first column of this lane group
+    TileWalk cur;
+    cur.init(blockIdx.x, gridDim.x, tiles_h, tiles_w);
+    if ((int)blockIdx.x < ntiles) {
+        xs.load(rx, d, cur.n, cur.th * G::TH, cur.tw * TW, g);
+        dyload(cur.n, cur.th * G::TH, cur.tw * TW);
+    }
+    if (d.pro_affine) {
+        for (int i = tid; i < (d.groups > 1 ? d.groups : 1) * d.cin; i += 256) { cf_scale[i] = pro_scale[i]; cf_shift[i] = pro_shift[i]; }
+        __syncthreads();
+    }
+    if ((int)blockIdx.x < ntiles) {
+        xs.store(xt, d, g, cf_scale, cf_shift, (cur.n / group_n) * d.cin);
+        dystore();
+    }
+    __syncthreads();
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const bool has_next = tile + (int)gridDim.x < ntiles;
+        if (has_next) {
+            cur.next();
+            xs.load(rx, d, cur.n, cur.th * G::TH, cur.tw * TW, g);
+            dyload(cur.n, cur.th * G::TH, cur.tw * TW);
+        }
+        if (wave < KB) {                                 // (4x16 tiles: two k-blocks, waves 2 and 3 only stage)
+            const int tr = wave * 2 + krow;              // tile row of this lane group's 8 pixels
+            bf16x8 bf[NTW];
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) {
+                const unsigned char* b0 = dyt + ((t * G::TP + tr * TW + kcol0 + qp) * 32) + pp * 8;
+                bf[t] = tr_read8(b0, b0 + 4 * 32);
+                float s = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s += (float)bf[t][j];
+                bsum[t] += s;
+            }
+#pragma unroll
+            for (int tap = 0; tap < TAPS; ++tap) {
+                const int kh = tap / KS, kw = tap % KS;
+                const int c0 = G::ldscol((kcol0 + qp) * S + kw);          // consecutive output columns are consecutive LDS columns (stride 2: de-interleaved)
+                const unsigned char* a0 = xt + (((tr * S + kh) * G::IWP + c0) * 32) + pp * 8;
+                const bf16x8 af = tr_read8(a0, a0 + 4 * 32);
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) acc[tap][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf[t], acc[tap][t], 0, 0, 0);
+            }
+        }
+        ctl_barrier_lds_reads_done();
+        if (has_next) {
+            xs.store(xt, d, g, cf_scale, cf_shift, (cur.n / group_n) * d.cin);
+            dystore();
+        }
+        ctl_barrier_lds_writes_done();
+    }
+    __syncthreads();
+
+    // ---------------- sum the four waves through LDS and write this split's partial (layout of the fp32 kernel)
+    float* red = reinterpret_cast<float*>(smem);
+    constexpr int TAP_FLOATS = 4 * NTW * 256;
+    constexpr int TPR = (MAIN_BYTES / 4 / TAP_FLOATS) < TAPS ? (MAIN_BYTES / 4 / TAP_FLOATS) : TAPS;
+    static_assert(TPR >= 1, "reduction scratch");
+    const int64_t split_base = (int64_t)blockIdx.x * TAPS * cin_p * cout_p;
+#pragma unroll
+    for (int tap0 = 0; tap0 < TAPS; tap0 += TPR) {
+        if (tap0 > 0) ctl_barrier_lds_reads_done();
+#pragma unroll
+        for (int tp = 0; tp < TPR; ++tp) {
+            const int tap = tap0 + tp;
+            if (tap < TAPS) {
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) {
+                    float* r0 = red + tp * TAP_FLOATS + ((wave * NTW + t) * 4) * 64 + lane;
+                    r0[0] = acc[tap][t].x; r0[64] = acc[tap][t].y; r0[128] = acc[tap][t].z; r0[192] = acc[tap][t].w;
+                }
+            }
+        }
+        ctl_barrier_lds_writes_done();
+#pragma unroll
+        for (int tp = 0; tp < TPR; ++tp) {
+            const int tap = tap0 + tp;
+            if (tap < TAPS) {
+#pragma unroll
+                for (int e0 = 0; e0 < NTW * 256; e0 += 256) {
+                    const int e = e0 + tid;
+                    const int t = e >> 8, r = (e >> 6) & 3, l = e & 63;
+                    float v = 0.f;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) v += red[tp * TAP_FLOATS + ((w * NTW + t) * 4 + r) * 64 + l];
+                    const int co = (cot0 + t) * 16 + (l & 15);
+                    const int ci = g * 16 + (l >> 4) * 4 + r;
+                    if (co < cout_p) w_partial[split_base + ((int64_t)tap * cin_p + ci) * cout_p + co] = v;
+                }
+            }
+        }
+    }
+    if (g == 0 && b_partial != nullptr) {
+        ctl_barrier_lds_reads_done();
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            float v = bsum[t];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (q == 0) red[(wave * NTW + t) * 16 + p] = v;
+        }
+        ctl_barrier_lds_writes_done();
+        if (tid < NTW * 16) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) v += red[w * NTW * 16 + tid];
+            const int co = cot0 * 16 + tid;
+            if (co < cout_p) b_partial[(int64_t)blockIdx.x * cout_p + co] = v;
+        }
+    }
+}
+
+struct wgrad16_call {
+    const ctl_conv* d; ctl_conv_cfg c; int ntw, splits, ntiles, cin_p, cout_p;
+    const void *x, *dy; const float *pro_scale, *pro_shift; float *w_partial, *b_partial;
+    hipStream_t stream; bool query;
+};
+template <int KS, int S, int MODE, int MT, int NTW>
+static void wgrad16_go(wgrad16_call& a) {
+    static int occ = 0;
+    if (!occ) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_wgrad_bf16_kernel<KS, S, MODE, MT, NTW>, 256, 0) != hipSuccess || n < 1) {
+            (void)hipGetLastError();
+            n = 2;
+        }
+        occ = n;
+    }
+    const int par = a.c.g * (a.c.cot / NTW);
+    int splits = (256 * (occ < 4 ? occ : 4)) / par;
+    if (splits > 512) splits = 512;
+    if (splits > a.ntiles) splits = a.ntiles;
+    if (splits < 1) splits = 1;
+    a.splits = splits;
+    if (a.query) return;
+    const dim3 grid((unsigned)splits, (unsigned)a.c.g, (unsigned)(a.c.cot / NTW));
+    conv_wgrad_bf16_kernel<KS, S, MODE, MT, NTW><<<grid, dim3(256), 0, a.stream>>>(*a.d, a.x, a.pro_scale, a.pro_shift, a.dy, a.w_partial,
+                                                                                   a.b_partial, a.c.tiles_h, a.c.tiles_w, a.ntiles, a.cin_p, a.cout_p);
+}
+template <int KS, int S, int MODE>
+static void wgrad16_go_tile(wgrad16_call& a) {
+    if (a.c.mt == 2) { if (a.ntw == 2) wgrad16_go<KS, S, MODE, 2, 2>(a); else wgrad16_go<KS, S, MODE, 2, 1>(a); }
+    else { if (a.ntw == 2) wgrad16_go<KS, S, MODE, 1, 2>(a); else wgrad16_go<KS, S, MODE, 1, 1>(a); }
+}
+static int wgrad16_dispatch(wgrad16_call& a) {
+    const int k = a.d->ks, s = a.d->stride, m = a.d->in_mode == CTL_IN_C4 ? CTL_IN_PLAIN : a.d->in_mode;
+    if (k == 3 && s == 1 && m == CTL_IN_PLAIN) wgrad16_go_tile<3, 1, CTL_IN_PLAIN>(a);
+    else if (k == 3 && s == 1 && m == CTL_IN_UP2) wgrad16_go_tile<3, 1, CTL_IN_UP2>(a);
+    else if (k == 3 && s == 2) wgrad16_go_tile<3, 2, CTL_IN_PLAIN>(a);
+    else if (k == 1 && m == CTL_IN_PLAIN) wgrad16_go_tile<1, 1, CTL_IN_PLAIN>(a);
+    else if (k == 1 && m == CTL_IN_UP2) wgrad16_go_tile<1, 1, CTL_IN_UP2>(a);
+    else if (k == 2 && s == 2) wgrad16_go_tile<2, 2, CTL_IN_PLAIN>(a);
+    else CTL_FAIL(CTL_EUNSUPPORTED, "conv_wgrad(bf16): no kernel for this combination");
+    return CTL_OK;
+}
+static int wgrad16_pick(const ctl_conv* d, wgrad16_call* a) {
+    CTL_REQUIRE(d->nsub == 1 && d->in_mode != CTL_IN_ZINS2, "wgrad(bf16): nsub must be 1, no zero-insert input");
+    CTL_REQUIRE(!(d->dt & CTL_DT_X16) || d->cin % 16 == 0, "wgrad(bf16): bf16-stored x needs cin %% 16 == 0");
+    CTL_REQUIRE(!(d->dt & CTL_DT_Y16) || d->cout % 16 == 0, "wgrad(bf16): bf16-stored dy needs cout %% 16 == 0");
+    a->d = d;
+    int rc = ctl_conv_pick_cfg(d, &a->c, 1);
+    if (rc != CTL_OK) return rc;
+    a->ntw = (a->c.cot >= 2 && a->c.cot % 2 == 0) ? 2 : 1;
+    a->ntiles = d->n * a->c.tiles_h * a->c.tiles_w;
+    a->cin_p = a->c.g * 16;
+    a->cout_p = a->c.cot * 16;
+    a->query = true;
+    rc = wgrad16_dispatch(*a);
+    a->query = false;
+    return rc;
+}
+int ctl_wgrad_bf16_splits(const ctl_conv* d) {
+    wgrad16_call a = {};
+    return wgrad16_pick(d, &a) == CTL_OK ? a.splits : -1;
+}
+int ctl_conv_wgrad_bf16(const ctl_conv* d, const void* x, const float* pro_scale, const float* pro_shift, const void* dy,
+                        float* w_partial, float* b_partial, ctl_stream stream) {
+    wgrad16_call a = {};
+    int rc = wgrad16_pick(d, &a);
+    if (rc != CTL_OK) return rc;
+    a.x = x; a.dy = dy; a.pro_scale = pro_scale; a.pro_shift = pro_shift; a.w_partial = w_partial; a.b_partial = b_partial;
+    a.stream = (hipStream_t)stream;
+    rc = wgrad16_dispatch(a);
+    if (rc != CTL_OK) return rc;
+    CTL_LAUNCH_CHECK("conv_wgrad(bf16)");
+    return CTL_OK;
+}

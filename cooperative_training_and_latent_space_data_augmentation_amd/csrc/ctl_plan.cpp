@@ -4,7 +4,7 @@
 // Tensor slots per op kind (index into op.slot/op.off):
 //   CONV              0 x  1 wpack  2 bias  3 pro_scale  4 pro_shift  5 res  6 res_scale  7 res_shift  8 y  9 stats_partial
 //   WGRAD             0 x  1 pro_scale  2 pro_shift  3 dy  4 w_partial  5 b_partial
-//   WGRAD_REDUCE      0 w_partial  1 b_partial  2 dw  3 dbias            i[23]=accumulate  l[0..3]=s_co,s_ci,s_kh,s_kw
+//   WGRAD_REDUCE      0 w_partial  1 b_partial  2 dw  3 dbias            i[24]=accumulate  l[0..3]=s_co,s_ci,s_kh,s_kw
 //   PACK              0 src  1 dst                                       i[0..3]=cout,cin,ks,flip  l[0..3]=strides
 //   BN_FINALIZE       0 partial 1 gamma 2 beta 3 running_mean 4 running_var 5 nbt 6 scale 7 shift 8 save_mean 9 save_invstd
 //                                                                        i[0..2]=blocks,c,update_running l[0]=count f[0]=eps f[1]=momentum
@@ -18,7 +18,7 @@
 //   SIGMOID_BWD       0 dy 1 y 2 dx                                      l[0]=count
 //   ZERO              0 ptr                                              l[0]=bytes
 //   COPY              0 src 1 dst                                        l[0]=bytes
-//   PACK_BATCH        0 params 1 wpack 2 table                           i[0]=n_rec l[0]=max_total
+//   PACK_BATCH        0 params 1 wpack 2 table                           i[0]=n_rec i[1]=bf16 fragments l[0]=max_total
 //   WGRAD_REDUCE_BATCH 0 scratch 1 grad 2 table                          i[0]=n_rec l[0]=max_elems
 #include <stdarg.h>
 #include <stdlib.h>
@@ -57,9 +57,9 @@ int ctl_prof_begin(const char* kind, const ctl_conv* d, const ctl_conv_cfg* c, i
     if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return -1;
     const double pix = (double)d->n * d->hout * d->wout * d->nsub;
     r.flops = 2.0 * pix * d->cout * d->cin * d->ks * d->ks;
-    const double in_b = 4.0 * d->n * d->hin * d->win * d->cin, out_b = 4.0 * pix * d->cout;
+    const double in_b = ((d->dt & CTL_DT_X16) ? 2.0 : 4.0) * d->n * d->hin * d->win * d->cin, out_b = ((d->dt & CTL_DT_Y16) ? 2.0 : 4.0) * pix * d->cout;
     r.bytes = in_b + out_b;
-    if (d->epi_flags & CTL_EPI_RES) r.bytes += out_b;
+    if (d->epi_flags & CTL_EPI_RES) r.bytes += ((d->dt & CTL_DT_RES16) ? 2.0 : 4.0) * pix * d->cout;
     if (d->epi_flags & CTL_EPI_ACCUM) r.bytes += out_b;
     (void)hipEventRecord(r.a, stream);
     g_prof.push_back(r);
@@ -132,7 +132,7 @@ extern "C" const char* ctl_last_error(void) { return g_err; }
 extern "C" size_t ctl_sizeof_op(void) { return sizeof(ctl_op); }
 extern "C" size_t ctl_sizeof_conv(void) { return sizeof(ctl_conv); }
 
-static_assert(sizeof(ctl_conv) == 23 * 4, "ctl_conv must be 23 32-bit words (it is embedded in ctl_op.i[0..22]; i[23] and i[26] are taken)");
+static_assert(sizeof(ctl_conv) == 24 * 4, "ctl_conv must be 24 32-bit words (it is embedded in ctl_op.i[0..23]; i[24] and i[26] are taken)");
 
 // Side lane: ops with i[26] == 1 (weight gradients and their batched reduction: off the critical dgrad chain) run on a
 // library-owned second stream so that their launches fill the ramp-up / tail bubbles of the main chain.  Fork = event
@@ -201,7 +201,7 @@ extern "C" int ctl_plan_run(const ctl_op* ops, int32_t n_ops, void* const* bases
                 break;
             case CTL_OP_WGRAD_REDUCE:
                 memcpy(&d, op.i, sizeof(d));
-                rc = ctl_wgrad_reduce(&d, CF(0), CF(1), F(2), op.l[0], op.l[1], op.l[2], op.l[3], F(3), op.i[23], stream);
+                rc = ctl_wgrad_reduce(&d, CF(0), CF(1), F(2), op.l[0], op.l[1], op.l[2], op.l[3], F(3), op.i[24], stream);
                 break;
             case CTL_OP_PACK:
                 rc = ctl_pack_weights(CF(0), F(1), op.i[0], op.i[1], op.i[2], op.l[0], op.l[1], op.l[2], op.l[3], op.i[3], stream);
@@ -240,8 +240,9 @@ extern "C" int ctl_plan_run(const ctl_op* ops, int32_t n_ops, void* const* bases
                 if (e != hipSuccess) CTL_FAIL(CTL_ELAUNCH, "plan_run: memset: %s", hipGetErrorString(e));
                 break;
             }
-            case CTL_OP_PACK_BATCH:
-                rc = ctl_pack_weights_batched(CF(0), F(1), (const int64_t*)t[2], op.i[0], op.l[0], stream);
+            case CTL_OP_PACK_BATCH:       // i[1] = 1: bf16 fragments (CTL_DT_BF16 kernels)
+                rc = op.i[1] ? ctl_pack_weights_bf16_batched(CF(0), F(1), (const int64_t*)t[2], op.i[0], op.l[0], stream)
+                             : ctl_pack_weights_batched(CF(0), F(1), (const int64_t*)t[2], op.i[0], op.l[0], stream);
                 break;
             case CTL_OP_WGRAD_REDUCE_BATCH:
                 rc = ctl_wgrad_reduce_batched(CF(0), F(1), (const int64_t*)t[2], op.i[0], op.l[0], stream);

@@ -35,8 +35,15 @@ def as_nhwc(x: torch.Tensor) -> torch.Tensor:
     return x.float().contiguous(memory_format=torch.channels_last)
 
 
-def empty_nhwc(n: int, c: int, h: int, w: int, device) -> torch.Tensor:
-    return torch.empty((n, c, h, w), dtype=torch.float32, device=device, memory_format=torch.channels_last)
+def empty_nhwc(n: int, c: int, h: int, w: int, device, dtype=torch.float32) -> torch.Tensor:
+    return torch.empty((n, c, h, w), dtype=dtype, device=device, memory_format=torch.channels_last)
+
+
+def as_nhwc_any(x: torch.Tensor) -> torch.Tensor:
+    """NHWC memory, dtype kept (fp32 or bf16): the bf16 kernel family reads either (ctl_conv.dt)."""
+    if x.dim() != 4 or x.dtype not in (torch.float32, torch.bfloat16):
+        raise ValueError("expected a 4-D fp32 / bf16 NCHW tensor")
+    return x.contiguous(memory_format=torch.channels_last)
 
 
 # ---------------------------------------------------------------------------------------------- conv (unit-level API)
@@ -59,13 +66,40 @@ def pack_oihw_dgrad(w: torch.Tensor) -> torch.Tensor:
     return pack_weights(w.contiguous(), ci, co, ks, (ks * ks, ci * ks * ks, ks, 1), True)
 
 
+def pack_weights_bf16(w: torch.Tensor, cout: int, cin: int, ks: int, strides, flip=0, mode: int = 0) -> torch.Tensor:
+    """bf16 MFMA fragments (tap pairs x 16-channel chunks, see ctl_conv_bf16.hip) of one effective conv through the table-driven pack
+    kernel; `strides`/`flip`/`mode` as in ctl_pack_weights_batched records."""
+    require_gpu(w)
+    total = lib.ctl_conv_wpack_floats(cin, cout, ks)
+    table = torch.tensor([[0, 0, cout, cin, ks, int(flip), *[int(v) for v in strides], total, mode]], dtype=torch.int64, device=w.device)
+    dst = torch.zeros(total, dtype=torch.float32, device=w.device)
+    src = w.contiguous().float()
+    check(lib.ctl_pack_weights_bf16_batched(src.data_ptr(), dst.data_ptr(), table.data_ptr(), 1, total, stream_ptr()), "ctl_pack_weights_bf16_batched")
+    return dst
+
+
+def pack_oihw_fwd_bf16(w: torch.Tensor) -> torch.Tensor:
+    co, ci, ks, _ = w.shape
+    return pack_weights_bf16(w, co, ci, ks, (ci * ks * ks, ks * ks, ks, 1), 0)
+
+
+def pack_oihw_dgrad_bf16(w: torch.Tensor) -> torch.Tensor:
+    co, ci, ks, _ = w.shape
+    return pack_weights_bf16(w, ci, co, ks, (ks * ks, ci * ks * ks, ks, 1), 1)
+
+
 def conv_forward(d: np.ndarray, x, wpack, bias=None, pro_scale=None, pro_shift=None, res=None, res_scale=None,
                  res_shift=None, y=None, want_stats=False):
-    """Run one conv problem described by the ctl_conv record `d`.  Returns (y, stats_partial or None)."""
+    """Run one conv problem described by the ctl_conv record `d`.  Returns (y, stats_partial or None).  With d["dt"] & DT_BF16 the
+    storage dtypes of x / res / y must agree with the DT_X16 / DT_RES16 / DT_Y16 flags (y is allocated accordingly)."""
     require_gpu(x, wpack)
     n, cout, oh, ow = int(d["n"]), int(d["cout"]), int(d["out_h"]), int(d["out_w"])
+    dt = int(d["dt"])
+    for t, flag, what in ((x, _ffi.DT_X16, "x"), (res, _ffi.DT_RES16, "res"), (y, _ffi.DT_Y16, "y")):
+        if t is not None and (t.dtype == torch.bfloat16) != bool(dt & flag):
+            raise _ffi.CtlError(f"conv_forward: dtype of {what} ({t.dtype}) disagrees with ctl_conv.dt = {dt}")
     if y is None:
-        y = empty_nhwc(n, cout, oh, ow, x.device)
+        y = empty_nhwc(n, cout, oh, ow, x.device, torch.bfloat16 if dt & _ffi.DT_Y16 else torch.float32)
     stats = None
     if want_stats:
         stats = torch.empty(lib.ctl_conv_stats_floats(_ffi.desc_ptr(d)), dtype=torch.float32, device=x.device)
@@ -77,6 +111,9 @@ def conv_forward(d: np.ndarray, x, wpack, bias=None, pro_scale=None, pro_shift=N
 def conv_wgrad(d: np.ndarray, x, dy, dw: torch.Tensor, strides, dbias: Optional[torch.Tensor] = None, pro_scale=None,
                pro_shift=None, accumulate=False):
     require_gpu(x, dy, dw)
+    dt = int(d["dt"])
+    if (x.dtype == torch.bfloat16) != bool(dt & _ffi.DT_X16) or (dy.dtype == torch.bfloat16) != bool(dt & _ffi.DT_Y16):
+        raise _ffi.CtlError(f"conv_wgrad: dtypes of x / dy ({x.dtype}, {dy.dtype}) disagree with ctl_conv.dt = {dt}")
     dp = _ffi.desc_ptr(d)
     wpart = torch.empty(lib.ctl_wgrad_partial_floats(dp), dtype=torch.float32, device=x.device)
     bpart = torch.empty(lib.ctl_wgrad_bias_partial_floats(dp), dtype=torch.float32, device=x.device) if dbias is not None else None

@@ -7,7 +7,8 @@
  * "encdec.py" = medseg/models/ebm/encoder_decoder.py, "util.py" = medseg/models/model_util.py.
  *
  * Conventions
- *   - all tensors are fp32 NHWC ("channels_last") in device memory owned by the caller; labels are int64 NHW
+ *   - all tensors are fp32 NHWC ("channels_last") in device memory owned by the caller (bf16 where a ctl_conv.dt / op flag says so:
+ *     the `float*` in those signatures is then the base address of bf16 data); labels are int64 NHW
  *   - every call only enqueues work on `stream`; no allocation, no host sync, no retained pointers
  *   - return 0 on success, negative ctl_status on error; ctl_last_error() gives a thread-local message
  *   - scratch / partial-sum buffers are sized by the *_ws_* helpers and passed in by the caller
@@ -60,7 +61,13 @@ typedef struct ctl_conv {
     int32_t groups;                  /* BatchNorm groups along n (0/1 = one): images [g*n/groups, (g+1)*n/groups) use row g of
                                         pro_scale/pro_shift/res_scale/res_shift ([groups][c]) and get their own statistics
                                         partials -- several independent passes of one network batched into one launch   */
+    int32_t dt;                      /* CTL_DT_* : 0 = everything fp32 (BASELINE config 2).  CTL_DT_BF16 selects the bf16 kernel family
+                                        (v_mfma_f32_16x16x32_bf16: operands rounded to bf16 AFTER the fp32 prologue, fp32 accumulate,
+                                        fp32 bias / BatchNorm statistics / epilogue; weights packed as bf16 by the *_batched pack with
+                                        the same flag); CTL_DT_X16 / _Y16 / _RES16: that tensor is STORED as bf16 (activation storage
+                                        of BASELINE config 3) -- network inputs / outputs stay fp32                              */
 } ctl_conv;
+enum { CTL_DT_BF16 = 1, CTL_DT_X16 = 2, CTL_DT_Y16 = 4, CTL_DT_RES16 = 8 };
 
 /* number of floats of the packed weight buffer for one sub-problem, and of the statistics partial buffer */
 size_t ctl_conv_wpack_floats(int32_t cin, int32_t cout, int32_t ks);
@@ -104,6 +111,11 @@ int ctl_pack_weights_batched(const float* params, float* wpack, const int64_t* t
                              ctl_stream stream);
 int ctl_wgrad_reduce_batched(const float* scratch, float* grad, const int64_t* table, int32_t n_rec, int64_t max_blocks,
                              ctl_stream stream);
+/* bf16 MFMA fragments for the CTL_DT_BF16 kernels from the same pack records (modes 0-3): per 16-channel chunk a fragment carries a PAIR
+ * of taps (v_mfma_f32_16x16x32_bf16 has 32 k-slots), values rounded to bf16 (RNE) from the fp32 master weights; written at the same
+ * float offsets as the fp32 layout (it is smaller: 5 of 9 fragments for a 3x3 kernel).  max_total as for ctl_pack_weights_batched. */
+int ctl_pack_weights_bf16_batched(const float* params, float* wpack, const int64_t* table, int32_t n_rec, int64_t max_total,
+                                  ctl_stream stream);
 
 /* ------------------------------------------------------------------------------------------------ BatchNorm2d
  * encdec.py: every `norm(out_ch)`; three modes of SURVEY 8a row 4 (util.py:414-451).
@@ -258,7 +270,7 @@ enum ctl_op_kind {
 #define CTL_OP_MAX_T 12
 typedef struct ctl_op {
     int32_t kind;
-    int32_t i[27];                    /* CONV/WGRAD/WGRAD_REDUCE: i[0..22] = ctl_conv as int32 words, i[23] = accumulate; others: see
+    int32_t i[27];                    /* CONV/WGRAD/WGRAD_REDUCE: i[0..23] = ctl_conv as int32 words, i[24] = accumulate; others: see
                                          ctl_plan.cpp; i[26] = lane (0 main stream, 1 side stream: weight-gradient work) */
     float   f[4];
     int32_t slot[CTL_OP_MAX_T];       /* -1 = NULL */

@@ -1,0 +1,240 @@
+"""bf16 kernel family (BASELINE config 3: bf16 activation storage + v_mfma_f32_16x16x32_bf16, fp32 accumulate / statistics / master
+weights) against PyTorch with THE SAME ROUNDING POINTS: MFMA operands (activations after the fp32 BatchNorm + LeakyReLU prologue,
+weights) rounded to bf16 (RNE), accumulation in fp32 (the reference accumulates the rounded operands in fp64), stored outputs rounded to
+bf16 where the tensor is stored as bf16.  Tolerances: fp32 outputs 3e-4 of max|ref| (fp32 accumulation order over K <= 1152 products);
+bf16-stored outputs additionally one bf16 rounding of the result: 2^-8 relative per element; with the fused prologue 1e-3 (the kernel's
+fma and the reference's mul + add differ by an fp32 ulp, which now and then flips the bf16 rounding of one operand element)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from cooperative_training_and_latent_space_data_augmentation_amd import _ffi, ops  # noqa: E402
+from cooperative_training_and_latent_space_data_augmentation_amd._ffi import lib, check  # noqa: E402
+
+DEV = "cuda"
+BF = _ffi.DT_BF16
+
+
+def rb(t):
+    """round to bf16 (RNE), back to fp64 for the reference arithmetic"""
+    return t.float().to(torch.bfloat16).double()
+
+
+def dev(x, bf16=False):
+    x = x.to(DEV)
+    if bf16:
+        x = x.to(torch.bfloat16)
+    return x.contiguous(memory_format=torch.channels_last) if x.dim() == 4 else x.contiguous()
+
+
+def leaky(x, s):
+    return torch.where(x > 0, x, x * s)
+
+
+def close(a, b, rel, what, bf16_out=False):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    tol = rel * max(float(b.abs().max()), 1e-6) + 1e-7
+    err = (a - b).abs()
+    if bf16_out:
+        err = err - b.abs() * 2.0 ** -8                  # one bf16 rounding of the stored result
+    assert float(err.max()) <= tol, f"{what}: max err {float(err.max()):.3e} > tol {tol:.3e}"
+
+
+CASES = [(2, 16, 16, 32, 32), (4, 16, 16, 64, 64), (2, 32, 64, 16, 16), (2, 128, 128, 8, 8), (2, 64, 32, 24, 20), (1, 32, 32, 6, 6),
+         (2, 32, 32, 48, 48), (1, 64, 48, 40, 72), (3, 48, 16, 70, 70), (16, 16, 16, 128, 128)]
+
+
+@pytest.mark.parametrize("x16,y16", [(False, False), (True, True), (False, True), (True, False)])
+@pytest.mark.parametrize("n,cin,cout,h,w", CASES)
+def test_bf16_conv3x3_s1(n, cin, cout, h, w, x16, y16):
+    g = torch.Generator().manual_seed(n * 1000 + cin * 10 + cout + h)
+    x = torch.randn(n, cin, h, w, generator=g)
+    if x16:
+        x = x.to(torch.bfloat16).float()                 # the stored tensor IS bf16
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * 0.2
+    b = torch.randn(cout, generator=g)
+    sc, sh = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.3
+    wp = ops.pack_oihw_fwd_bf16(dev(wt))
+    dt = BF | (_ffi.DT_X16 if x16 else 0) | (_ffi.DT_Y16 if y16 else 0)
+    d = _ffi.conv_desc(n=n, hin=h, win=w, cin=cin, hout=h, wout=w, cout=cout, ks=3, epi_flags=_ffi.EPI_BIAS | _ffi.EPI_STATS, dt=dt)
+    y, stats = ops.conv_forward(d, dev(x, x16), wp, bias=dev(b), want_stats=True)
+    assert y.dtype == (torch.bfloat16 if y16 else torch.float32)
+    ref = F.conv2d(rb(x), rb(wt), b.double(), padding=1)
+    close(y, ref, 3e-4, "conv3x3 bf16", y16)
+    st = stats.view(-1, 2, cout).double().sum(0).cpu()   # statistics: from the fp32 accumulators, before the output rounding
+    close(st[0], ref.sum((0, 2, 3)), 2e-4, "stats sum")
+    close(st[1], (ref ** 2).sum((0, 2, 3)), 2e-4, "stats sumsq")
+    d2 = _ffi.conv_desc(n=n, hin=h, win=w, cin=cin, hout=h, wout=w, cout=cout, ks=3, epi_flags=_ffi.EPI_BIAS, pro_affine=1, pro_slope=0.2, dt=dt)
+    y2, _ = ops.conv_forward(d2, dev(x, x16), wp, bias=dev(b), pro_scale=dev(sc), pro_shift=dev(sh))
+    pro = leaky(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1), 0.2)      # fp32 prologue, THEN the operand rounding
+    close(y2, F.conv2d(rb(pro), rb(wt), b.double(), padding=1), 1e-3, "conv3x3 bf16 + prologue", y16)
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w", [(2, 1, 16, 32, 32), (2, 4, 16, 20, 12), (16, 1, 16, 64, 64), (2, 16, 4, 32, 32), (3, 16, 1, 16, 16),
+                                             (2, 128, 64, 3, 3)])
+def test_bf16_conv3x3_network_boundaries(n, cin, cout, h, w):
+    """fp32 network inputs with 1 / 4 channels (first layers) and fp32 outputs with 1 / 4 channels (last layers)."""
+    g = torch.Generator().manual_seed(cin * 7 + cout)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * 0.3
+    b = torch.randn(cout, generator=g)
+    y16 = cout % 4 == 0 and cout >= 16
+    d = _ffi.conv_desc(n=n, hin=h, win=w, cin=cin, hout=h, wout=w, cout=cout, ks=3, epi_flags=_ffi.EPI_BIAS | _ffi.EPI_STATS,
+                       dt=BF | (_ffi.DT_Y16 if y16 else 0))
+    y, stats = ops.conv_forward(d, dev(x), ops.pack_oihw_fwd_bf16(dev(wt)), bias=dev(b), want_stats=True)
+    ref = F.conv2d(rb(x), rb(wt), b.double(), padding=1)
+    close(y, ref, 3e-4, "boundary conv", y16)
+    close(stats.view(-1, 2, cout).double().sum(0).cpu()[0], ref.sum((0, 2, 3)), 2e-4, "stats sum")
+
+
+@pytest.mark.parametrize("n,c,cout,h,w", [(2, 16, 16, 32, 32), (2, 32, 64, 16, 24), (4, 64, 128, 8, 8), (16, 16, 32, 64, 64)])
+def test_bf16_residual_tail_1x1_up2_and_strided(n, c, cout, h, w):
+    g = torch.Generator().manual_seed(c + cout + h)
+    x = torch.randn(n, c, h, w, generator=g).to(torch.bfloat16).float()
+    w1 = torch.randn(cout, c, 1, 1, generator=g) * 0.3
+    b = torch.randn(cout, generator=g)
+    v = torch.randn(n, cout, 2 * h, 2 * w, generator=g).to(torch.bfloat16).float()
+    rs, rh = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.2
+    dt = BF | _ffi.DT_X16 | _ffi.DT_Y16 | _ffi.DT_RES16
+    # out = LReLU(conv1x1(up2(x)) + BN(v)): the residual tail of res_up_family (nearest-upsample input mode, bf16 residual operand)
+    d = _ffi.conv_desc(n=n, hin=h, win=w, cin=c, hout=2 * h, wout=2 * w, cout=cout, ks=1, in_mode=_ffi.IN_UP2,
+                       epi_flags=_ffi.EPI_BIAS | _ffi.EPI_RES, epi_act=_ffi.ACT_LEAKY, epi_slope=0.2, dt=dt)
+    y, _ = ops.conv_forward(d, dev(x, True), ops.pack_oihw_fwd_bf16(dev(w1)), bias=dev(b), res=dev(v, True), res_scale=dev(rs), res_shift=dev(rh))
+    up = F.interpolate(rb(x), scale_factor=2, mode="nearest")
+    ref = leaky(F.conv2d(up, rb(w1), b.double()) + v.double() * rs.double().view(1, -1, 1, 1) + rh.double().view(1, -1, 1, 1), 0.2)
+    close(y, ref, 3e-4, "1x1 + residual + leaky (up2)", True)
+    # 3x3 stride 2 (res_convdown.down) and 2x2 stride 2 (ConvTranspose2d data gradient)
+    w3 = torch.randn(cout, c, 3, 3, generator=g) * 0.2
+    x2 = torch.randn(n, c, 2 * h, 2 * w, generator=g).to(torch.bfloat16).float()
+    d3 = _ffi.conv_desc(n=n, hin=2 * h, win=2 * w, cin=c, hout=h, wout=w, cout=cout, ks=3, stride=2, epi_flags=_ffi.EPI_BIAS, dt=BF | _ffi.DT_X16 | _ffi.DT_Y16)
+    y3, _ = ops.conv_forward(d3, dev(x2, True), ops.pack_oihw_fwd_bf16(dev(w3)), bias=dev(b))
+    close(y3, F.conv2d(rb(x2), rb(w3), b.double(), stride=2, padding=1), 3e-4, "3x3 stride 2", True)
+    w2 = torch.randn(cout, c, 2, 2, generator=g) * 0.3
+    d2 = _ffi.conv_desc(n=n, hin=2 * h, win=2 * w, cin=c, hout=h, wout=w, cout=cout, ks=2, stride=2, pad=0, dt=BF | _ffi.DT_X16 | _ffi.DT_Y16)
+    y2, _ = ops.conv_forward(d2, dev(x2, True), ops.pack_oihw_fwd_bf16(dev(w2)))
+    close(y2, F.conv2d(rb(x2), rb(w2), stride=2), 3e-4, "2x2 stride 2", True)
+    # data gradient of the 3x3 conv: flipped / transposed weights, accumulate into an existing bf16 tensor
+    dy = torch.randn(n, cout, h, w, generator=g).to(torch.bfloat16).float()
+    w33 = torch.randn(cout, c, 3, 3, generator=g) * 0.2
+    acc0 = torch.randn(n, c, h, w, generator=g).to(torch.bfloat16)
+    dd = _ffi.conv_desc(n=n, hin=h, win=w, cin=cout, hout=h, wout=w, cout=c, ks=3, epi_flags=_ffi.EPI_ACCUM, dt=BF | _ffi.DT_X16 | _ffi.DT_Y16)
+    yacc = dev(acc0.float(), True).clone()
+    ops.conv_forward(dd, dev(dy, True), ops.pack_oihw_dgrad_bf16(dev(w33)), y=yacc)
+    close(yacc, F.conv_transpose2d(rb(dy), rb(w33), padding=1) + acc0.double(), 3e-4, "dgrad + accumulate", True)
+
+
+def _pack_phases_bf16(w, cout_eff, cin_eff, strides, mode):
+    sub = lib.ctl_conv_wpack_floats(cin_eff, cout_eff, 2)
+    table = np.asarray([[0, z * sub, cout_eff, cin_eff, 2, z, *strides, sub, mode] for z in range(4)], dtype=np.int64)
+    wd, td = w.to(DEV).contiguous(), torch.from_numpy(table).to(DEV)
+    out = torch.zeros(4 * sub, device=DEV)
+    check(lib.ctl_pack_weights_bf16_batched(wd.data_ptr(), out.data_ptr(), td.data_ptr(), 4, sub, ops.stream_ptr()))
+    return out
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w", [(2, 16, 16, 16, 16), (2, 128, 64, 4, 4), (3, 32, 16, 24, 20), (16, 16, 16, 64, 64)])
+def test_bf16_phase_convs_and_pooled_dgrad(n, cin, cout, h, w):
+    """The exact re-formulations around the resampling layers (pack modes 1-3): the COMBINED weights are formed in fp32 and rounded once."""
+    g = torch.Generator().manual_seed(cin + h)
+    x = torch.randn(n, cin, h, w, generator=g).to(torch.bfloat16).float()
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * 0.2
+    b = torch.randn(cout, generator=g)
+    dt = BF | _ffi.DT_X16 | _ffi.DT_Y16
+    d = _ffi.conv_desc(n=n, hin=h, win=w, cin=cin, hout=h, wout=w, cout=cout, ks=2, stride=1, pad=2, nsub=4, out_h=2 * h, out_w=2 * w,
+                       out_sy=2, out_sx=2, out_sub=1, epi_flags=_ffi.EPI_BIAS, dt=dt)
+    y = ops.empty_nhwc(n, cout, 2 * h, 2 * w, DEV, torch.bfloat16)
+    ops.conv_forward(d, dev(x, True), _pack_phases_bf16(wt, cout, cin, (cin * 9, 9, 3, 1), 2), bias=dev(b), y=y)
+    # reference with the phase weights combined in fp32 and rounded once (what the pack kernel does)
+    ref = torch.zeros(n, cout, 2 * h, 2 * w, dtype=torch.float64)
+    xp = F.pad(rb(x), (1, 1, 1, 1))
+    for a in range(2):
+        for bb in range(2):
+            k = torch.zeros(cout, cin, 2, 2)
+            for kh in range(3):
+                for kw in range(3):
+                    k[:, :, (a + kh + 1) // 2 - a, (bb + kw + 1) // 2 - bb] += wt[:, :, kh, kw]      # tap of phase (a, bb) that W[kh][kw] lands on
+            ref[:, :, a::2, bb::2] = F.conv2d(xp[:, :, a:a + h + 1, bb:bb + w + 1], rb(k)) + b.double().view(1, -1, 1, 1)
+    close(y, ref, 3e-4, "phase forward of conv3x3(up2(x))", True)
+    # 4x4 stride-2 form of sumpool2(conv3x3^T(dy)) (pack mode 1)
+    dy = torch.randn(n, cout, 2 * h, 2 * w, generator=g).to(torch.bfloat16).float()
+    total = lib.ctl_conv_wpack_floats(cout, cin, 4)
+    table = torch.tensor([[0, 0, cin, cout, 4, 0, 9, cin * 9, 3, 1, total, 1]], dtype=torch.int64, device=DEV)
+    wp4 = torch.zeros(total, device=DEV)
+    check(lib.ctl_pack_weights_bf16_batched(wt.to(DEV).contiguous().data_ptr(), wp4.data_ptr(), table.data_ptr(), 1, total, ops.stream_ptr()))
+    d4 = _ffi.conv_desc(n=n, hin=2 * h, win=2 * w, cin=cout, hout=h, wout=w, cout=cin, ks=4, stride=2, dt=dt)
+    y4, _ = ops.conv_forward(d4, dev(dy, True), wp4)
+    K = torch.zeros(cin, cout, 4, 4)
+    for a in range(2):
+        for bb in range(2):
+            for kh in range(3):
+                for kw in range(3):
+                    K[:, :, a + 2 - kh, bb + 2 - kw] += wt[:, :, kh, kw].transpose(0, 1)
+    close(y4, F.conv2d(rb(dy), rb(K), stride=2, padding=1), 3e-4, "pooled dgrad via 4x4 s2", True)
+
+
+WG = [(2, 16, 16, 32, 32), (16, 16, 16, 64, 64), (2, 32, 64, 16, 16), (2, 128, 128, 8, 8), (2, 64, 32, 24, 20), (2, 16, 32, 4, 4), (3, 48, 16, 40, 36)]
+
+
+@pytest.mark.parametrize("x16,dy16", [(True, True), (False, True), (True, False)])
+@pytest.mark.parametrize("n,cin,cout,h,w", WG)
+def test_bf16_wgrad_3x3(n, cin, cout, h, w, x16, dy16):
+    g = torch.Generator().manual_seed(n + cin + cout + h)
+    x = torch.randn(n, cin, h, w, generator=g)
+    dy = torch.randn(n, cout, h, w, generator=g)
+    if x16:
+        x = x.to(torch.bfloat16).float()
+    if dy16:
+        dy = dy.to(torch.bfloat16).float()
+    sc, sh = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.3
+    dt = BF | (_ffi.DT_X16 if x16 else 0) | (_ffi.DT_Y16 if dy16 else 0)
+    for pro in (False, True):
+        d = _ffi.conv_desc(n=n, hin=h, win=w, cin=cin, hout=h, wout=w, cout=cout, ks=3, pro_affine=int(pro), pro_slope=0.2, dt=dt)
+        dw, db = torch.zeros(cout, cin, 3, 3, device=DEV), torch.zeros(cout, device=DEV)
+        ops.conv_wgrad(d, dev(x, x16), dev(dy, dy16), dw, (cin * 9, 9, 3, 1), dbias=db, pro_scale=dev(sc) if pro else None,
+                       pro_shift=dev(sh) if pro else None)
+        xin = leaky(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1), 0.2) if pro else x
+        xr = rb(xin).requires_grad_(False)
+        wref = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+        F.conv2d(xr, wref, padding=1).backward(rb(dy))
+        close(dw, wref.grad, 1e-3 if pro else 3e-4, f"wgrad 3x3 (prologue {pro})")
+        close(db, rb(dy).sum((0, 2, 3)), 3e-4, "bias gradient")
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w", [(2, 16, 16, 16, 16), (2, 64, 32, 8, 12), (16, 16, 16, 32, 32)])
+def test_bf16_wgrad_other_forms(n, cin, cout, h, w):
+    g = torch.Generator().manual_seed(cin * 3 + h)
+    dt = BF | _ffi.DT_X16 | _ffi.DT_Y16
+    # 3x3 on a nearest-upsampled input
+    x = torch.randn(n, cin, h, w, generator=g).to(torch.bfloat16).float()
+    dy = torch.randn(n, cout, 2 * h, 2 * w, generator=g).to(torch.bfloat16).float()
+    d = _ffi.conv_desc(n=n, hin=h, win=w, cin=cin, hout=2 * h, wout=2 * w, cout=cout, ks=3, in_mode=_ffi.IN_UP2, dt=dt)
+    dw = torch.zeros(cout, cin, 3, 3, device=DEV)
+    ops.conv_wgrad(d, dev(x, True), dev(dy, True), dw, (cin * 9, 9, 3, 1))
+    wref = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(F.interpolate(rb(x), scale_factor=2, mode="nearest"), wref, padding=1).backward(rb(dy))
+    close(dw, wref.grad, 3e-4, "wgrad 3x3 on up2 input")
+    # 3x3 stride 2
+    x2 = torch.randn(n, cin, 2 * h, 2 * w, generator=g).to(torch.bfloat16).float()
+    dy2 = torch.randn(n, cout, h, w, generator=g).to(torch.bfloat16).float()
+    d2 = _ffi.conv_desc(n=n, hin=2 * h, win=2 * w, cin=cin, hout=h, wout=w, cout=cout, ks=3, stride=2, dt=dt)
+    dw2 = torch.zeros(cout, cin, 3, 3, device=DEV)
+    ops.conv_wgrad(d2, dev(x2, True), dev(dy2, True), dw2, (cin * 9, 9, 3, 1))
+    wref2 = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(rb(x2), wref2, stride=2, padding=1).backward(rb(dy2))
+    close(dw2, wref2.grad, 3e-4, "wgrad 3x3 stride 2")
+    # 1x1 and 2x2 stride 2
+    d1 = _ffi.conv_desc(n=n, hin=h, win=w, cin=cin, hout=h, wout=w, cout=cout, ks=1, dt=dt)
+    dy1 = torch.randn(n, cout, h, w, generator=g).to(torch.bfloat16).float()
+    dw1 = torch.zeros(cout, cin, 1, 1, device=DEV)
+    ops.conv_wgrad(d1, dev(x, True), dev(dy1, True), dw1, (cin, 1, 1, 1))
+    close(dw1.view(cout, cin), torch.einsum("nchw,nkhw->kc", rb(x), rb(dy1)), 3e-4, "wgrad 1x1")
+    d22 = _ffi.conv_desc(n=n, hin=2 * h, win=2 * w, cin=cin, hout=h, wout=w, cout=cout, ks=2, stride=2, pad=0, dt=dt)
+    dw22 = torch.zeros(cout, cin, 2, 2, device=DEV)
+    ops.conv_wgrad(d22, dev(x2, True), dev(dy2, True), dw22, (cin * 4, 4, 2, 1))
+    wref22 = torch.zeros(cout, cin, 2, 2, dtype=torch.float64, requires_grad=True)
+    F.conv2d(rb(x2), wref22, stride=2).backward(rb(dy2))
+    close(dw22, wref22.grad, 3e-4, "wgrad 2x2 stride 2")

@@ -28,7 +28,7 @@ def test_every_declared_symbol_is_exported():
 
 def test_struct_layouts_match():
     assert _ffi.lib.ctl_sizeof_op() == _ffi.OP_DTYPE.itemsize == 304
-    assert _ffi.lib.ctl_sizeof_conv() == _ffi.CONV_DTYPE.itemsize == 92
+    assert _ffi.lib.ctl_sizeof_conv() == _ffi.CONV_DTYPE.itemsize == 96
 
 
 def test_invalid_arguments_fail_loudly():
