@@ -22,11 +22,20 @@ sys.path.insert(0, ROOT)
 
 DROP_IMG = {"loss_name": "mse", "mask_type": "dropout", "max_threshold": 0.5, "random_threshold": True, "if_soft": True}
 DROP_SEG = {"loss_name": "ce", "mask_type": "dropout", "max_threshold": 0.5, "random_threshold": True, "if_soft": True}
+TGT_IMG = {"loss_name": "mse", "mask_type": "channel", "max_threshold": 0.5, "random_threshold": True, "if_soft": True}
+TGT_SEG = {"loss_name": "ce", "mask_type": "spatial", "max_threshold": 0.5, "random_threshold": True, "if_soft": True}
+RND_IMG = {"loss_name": "mse", "mask_type": "random", "max_threshold": 0.5, "random_threshold": True, "if_soft": True}
+RND_SEG = {"loss_name": "ce", "mask_type": "random", "max_threshold": 0.5, "random_threshold": True, "if_soft": True}
+MASKS = {"dropout": (DROP_IMG, DROP_SEG, "dropout latent masks"),                      # BASELINE configs[1]
+         "targeted": (TGT_IMG, TGT_SEG, "targeted channel-wise (image code) + spatial-wise (shape code) masks: extra dL/dz backward + top-k"),   # configs[2]
+         "random": (RND_IMG, RND_SEG, "all three masking schemes randomly sampled per step")}                                                  # configs[3]
 PEAK_MFMA_F32_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+PEAK_MFMA_BF16_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak
 PEAK_HBM_GBS = 8000.0
 # dominant kernel of this workload per profiles/ (rocprofv3 --kernel-trace --stats): the 3x3 stride-1 implicit-GEMM conv
 # at 8x32 tiles / 16 output channels, i.e. every 16->16 (and 1|4->16, 16->4) conv and dgrad at 256x256
 DOMINANT = "conv_igemm<ks3,s1,in0,mt4,tw32,nt1>"
+DOMINANT_BF16 = "conv_igemm_bf16<ks3,s1,in0,mt4,tw32,nt1>"
 
 
 def synthetic(n, h, w, seed, device):
@@ -88,7 +97,7 @@ def latent_mask_roofline(device):
     return out
 
 
-def cpu_baseline(host_batch, threads, steps=3):
+def cpu_baseline(host_batch, threads, steps=3, cfgs=(DROP_IMG, DROP_SEG), what="dropout masks"):
     """BASELINE.md section 3 procedure: the full bs16 batch, 1 warm-up step + `steps` timed steps, median (the oracle is the checker,
     timed here as the reported CPU baseline -- never on the product path)."""
     from oracle import ref_cpu as O
@@ -100,11 +109,11 @@ def cpu_baseline(host_batch, threads, steps=3):
     times = []
     for i in range(1 + steps):
         t0 = time.perf_counter()
-        s.cooperative_step(clean, label, noisy, DROP_IMG, DROP_SEG)
+        s.cooperative_step(clean, label, noisy, cfgs[0], cfgs[1])
         times.append(time.perf_counter() - t0)
     med = sorted(times[1:])[len(times[1:]) // 2]
     return {"value": clean.shape[0] / med, "unit": "slices/s", "cores": threads, "kind": "port",
-            "sample": f"full cooperative step (bs{clean.shape[0]}, {clean.shape[-1]}x{clean.shape[-1]}, dropout masks) of oracle/ref_cpu.py on {threads} torch "
+            "sample": f"full cooperative step (bs{clean.shape[0]}, {clean.shape[-1]}x{clean.shape[-1]}, {what}; fp32, the reference's arithmetic) of oracle/ref_cpu.py on {threads} torch "
                       f"threads: 1 warm-up ({times[0]:.1f} s) + {steps} timed steps, median {med:.1f} s (all: {[round(t, 1) for t in times[1:]]})"}
 
 
@@ -118,14 +127,24 @@ def main():
     ap.add_argument("--mode", default="auto", choices=["auto", "eager", "graph"],
                     help="eager: Python issues the ~1100 launches of a step on two HIP streams; graph: the whole step is one hipGraph replay "
                          "(host-insensitive); auto: both are timed for a few untimed steps after the warm-up and the faster one is measured")
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
+                    help="fp32: the reference's arithmetic (BASELINE configs[1], the headline); bf16: configs[2] -- network-internal "
+                         "activations / gradients stored as bf16, convolutions on v_mfma_f32_16x16x32_bf16, fp32 accumulate / BatchNorm "
+                         "statistics / master weights / losses")
+    ap.add_argument("--masks", default=None, choices=list(MASKS), help="latent masking scheme (default: dropout for fp32, targeted for bf16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
-    ap.add_argument("--prof-filter", default=DOMINANT)
+    ap.add_argument("--prof-filter", default=None)
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even for a world of 1")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo only for control-flow tests)")
     ap.add_argument("--all-on-device0", action="store_true", help="test aid: every rank uses GPU 0 (needs --backend gloo)")
     args = ap.parse_args()
 
+    if args.masks is None:
+        args.masks = "targeted" if args.dtype == "bf16" else "dropout"
+    if args.prof_filter is None:
+        args.prof_filter = DOMINANT_BF16 if args.dtype == "bf16" else DOMINANT
+    IMG_CFG, SEG_CFG, mask_text = MASKS[args.masks]
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -154,7 +173,7 @@ def main():
 
     torch.manual_seed(0)                                 # identical initial weights on every rank
     solver = AdvancedTripletReconSegmentationModel(network_type="FCN_16_standard", image_ch=1, num_classes=4,
-                                                   learning_rate=1e-4, use_gpu=True)
+                                                   learning_rate=1e-4, use_gpu=True, compute_dtype=args.dtype)
     dp = DataParallel(solver) if use_dist else None
     if use_dist:                                         # per-rank RNG streams (scheme / k / dropout / soft-noise draws), after the weight broadcast
         import random
@@ -166,7 +185,7 @@ def main():
     hook = dp.sync_gradients if dp else None
 
     def eager_step():
-        return solver.cooperative_step(clean, label, noisy, DROP_IMG, DROP_SEG, grad_hook=hook)
+        return solver.cooperative_step(clean, label, noisy, IMG_CFG, SEG_CFG, grad_hook=hook)
 
     step = eager_step
 
@@ -184,7 +203,7 @@ def main():
     calib, mode, gstep = {}, args.mode, None
     if mode in ("auto", "graph"):
         try:
-            gstep = CooperativeStepGraph(solver, DROP_IMG, DROP_SEG, grad_hook=hook)
+            gstep = CooperativeStepGraph(solver, IMG_CFG, SEG_CFG, grad_hook=hook)
             graph_step = lambda: gstep(clean, label, noisy)
             graph_step()                                  # capture + first replay
             fence()
@@ -275,10 +294,12 @@ def main():
         out = {
             "metric": "cooperative-training slices/sec (256x256, bs16 per GPU)", "value": world * args.batch * args.steps / dt,
             "unit": "slices/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.dtype == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": f"ACDC-shaped synthetic {args.size}x{args.size}x1, batch {args.batch}/GPU, full cooperative step "
-                                   "(FTN+STN standard + dropout latent masks + hard-example training + backward + 5x Adam), "
-                                   "reference-init weights", "global_batch": world * args.batch,
+                                   f"(FTN+STN standard + {mask_text} + hard-example training + backward + 5x Adam), "
+                                   "reference-init weights" + ("; bf16 storage of network-internal tensors + bf16 MFMA, fp32 accumulate / "
+                                   "statistics / master weights (BASELINE configs[2])" if args.dtype == "bf16" else ""),
+                       "global_batch": world * args.batch,
                        "parallelism": f"dp{world}" if world > 1 else "single GPU"},
             "final_losses": loss_vals, "mode": mode, "mode_calibration": calib,
             "step_ms": {"min": step_ms[0], "median": step_ms[len(step_ms) // 2], "max": step_ms[-1],
@@ -289,10 +310,11 @@ def main():
         def roofline_of(kid, rec, region_s=None):
             secs = rec["ms"] * 1e-3
             tf, gbs = rec["flops"] / secs / 1e12, rec["bytes"] / secs / 1e9
-            f_mfma, f_hbm = tf / PEAK_MFMA_F32_TFLOPS, gbs / PEAK_HBM_GBS
+            peak_mfma = PEAK_MFMA_BF16_TFLOPS if args.dtype == "bf16" else PEAK_MFMA_F32_TFLOPS
+            f_mfma, f_hbm = tf / peak_mfma, gbs / PEAK_HBM_GBS
             bound = "mfma" if f_mfma >= f_hbm else "hbm"
             r = {"bound": bound, "achieved": tf if bound == "mfma" else gbs,
-                 "peak": PEAK_MFMA_F32_TFLOPS if bound == "mfma" else PEAK_HBM_GBS,
+                 "peak": peak_mfma if bound == "mfma" else PEAK_HBM_GBS,
                  "unit": "TFLOP/s" if bound == "mfma" else "GB/s", "frac": max(f_mfma, f_hbm), "traffic": None,
                  "kernel": kid, "launches": int(rec["launches"]), "avg_us": 1e3 * rec["ms"] / rec["launches"],
                  "algorithmic_gflop_per_launch": rec["flops"] / rec["launches"] / 1e9,
@@ -326,7 +348,7 @@ def main():
         if world == 1:
             out["roofline_latent_mask"] = latent_mask_roofline(device)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(host_batch, args.cpu_threads or min(32, os.cpu_count()))
+            out["cpu_baseline"] = cpu_baseline(host_batch, args.cpu_threads or min(32, os.cpu_count()), cfgs=(IMG_CFG, SEG_CFG), what=mask_text)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()

@@ -125,7 +125,8 @@ EXPORTED = ["ctl_version", "ctl_last_error", "ctl_conv_wpack_floats", "ctl_conv_
             "ctl_sizeof_conv", "ctl_prof_start", "ctl_prof_stop", "ctl_pack_weights_batched",
             "ctl_wgrad_reduce_batched", "ctl_confusion_hist", "ctl_rescale_intensity_ws_floats", "ctl_rescale_intensity",
             "ctl_noise_clamp", "ctl_crop_or_pad", "ctl_step_tick", "ctl_dropout2d_ex", "ctl_uniform_dev", "ctl_adam_dev",
-            "ctl_latent_mask_fused_ws_floats", "ctl_latent_mask_fused", "ctl_accumulate", "ctl_pack_weights_bf16_batched"]
+            "ctl_latent_mask_fused_ws_floats", "ctl_latent_mask_fused", "ctl_accumulate", "ctl_pack_weights_bf16_batched",
+            "ctl_bn_act_dt", "ctl_bwd_reduce_dt", "ctl_bwd_apply_dt", "ctl_sumpool2_dt"]
 
 
 def prof_start(kernel_filter: str = "") -> None:

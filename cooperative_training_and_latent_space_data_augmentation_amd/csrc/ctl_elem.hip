@@ -27,6 +27,28 @@ __device__ __forceinline__ double block_sum_double(double v, double* sm) {
     return r;  // valid on thread 0
 }
 
+// Storage-type aware quad access for the kernels that touch network-internal tensors: with BASELINE config 3 those are stored as bf16
+// (`m` = bit mask over the kernel's tensor arguments, bit set = bf16 storage); arithmetic is fp32 either way, a store rounds once (RNE).
+typedef unsigned int u32x2e __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2e __attribute__((ext_vector_type(2)));
+typedef float f32x2e __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 ldq(const void* __restrict__ p, int64_t i, bool b16) {
+    if (b16) {
+        const u32x2e u = reinterpret_cast<const u32x2e*>(p)[i];
+        return f32x4{__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u),
+                     __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xffff0000u)};
+    }
+    return reinterpret_cast<const f32x4*>(p)[i];
+}
+__device__ __forceinline__ void stq(void* __restrict__ p, int64_t i, f32x4 v, bool b16) {
+    if (b16) {
+        reinterpret_cast<u32x2e*>(p)[i] = u32x2e{__builtin_bit_cast(unsigned, __builtin_convertvector(f32x2e{v.x, v.y}, bf16x2e)),
+                                                 __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2e{v.z, v.w}, bf16x2e))};
+    } else {
+        reinterpret_cast<f32x4*>(p)[i] = v;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ BatchNorm forward
 __global__ __launch_bounds__(EB) void bn_finalize_kernel(const float* __restrict__ partial, int blocks, int c,
                                                           double count, const float* __restrict__ gamma,
@@ -81,17 +103,17 @@ __global__ void bn_eval_kernel(int c, const float* gamma, const float* beta, con
     }
 }
 
-__global__ __launch_bounds__(EB) void bn_act_kernel(const f32x4* __restrict__ x, const f32x4* __restrict__ scale,
+__global__ __launch_bounds__(EB) void bn_act_kernel(const void* __restrict__ x, const f32x4* __restrict__ scale,
                                                      const f32x4* __restrict__ shift, float slope,
-                                                     f32x4* __restrict__ y, int64_t quads, int cq, int64_t group_quads) {
+                                                     void* __restrict__ y, int64_t quads, int cq, int64_t group_quads, unsigned m) {
     const int64_t stride = (int64_t)gridDim.x * EB;
     for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < quads; i += stride) {
         const int q = (int)(i % cq) + (int)(i / group_quads) * cq;
         const f32x4 sc = scale[q], sh = shift[q];
-        f32x4 v = x[i];
+        f32x4 v = ldq(x, i, m & 1);
         v.x = ctl_leaky(v.x * sc.x + sh.x, slope); v.y = ctl_leaky(v.y * sc.y + sh.y, slope);
         v.z = ctl_leaky(v.z * sc.z + sh.z, slope); v.w = ctl_leaky(v.w * sc.w + sh.w, slope);
-        y[i] = v;
+        stq(y, i, v, m & 2);
     }
 }
 
@@ -99,34 +121,31 @@ __global__ __launch_bounds__(EB) void bn_act_kernel(const f32x4* __restrict__ x,
 // grid = CTL_RED_BLOCKS x 256; the global stride (131072) is a multiple of every C/4 in use, so a thread always sees
 // the same channel quad and accumulates it in registers.
 template <int MODE>
-__global__ __launch_bounds__(EB) void bwd_reduce_kernel(const f32x4* __restrict__ dy, const f32x4* __restrict__ act_src,
-                                                         const f32x4* __restrict__ bn_src,
+__global__ __launch_bounds__(EB) void bwd_reduce_kernel(const void* __restrict__ dy_, const void* __restrict__ act_src_,
+                                                         const void* __restrict__ bn_src_,
                                                          const f32x4* __restrict__ scale,
                                                          const f32x4* __restrict__ shift, float slope, int64_t quads,
-                                                         int cq, float* __restrict__ partial) {
+                                                         int cq, float* __restrict__ partial, unsigned m) {      // m: bit 0 dy, 1 act_src, 2 bn_src
     // blockIdx.y = BatchNorm group: `quads` is the size of one group, its data start at blockIdx.y * quads
     __shared__ f32x4 sm[2][EB];
     const int64_t gtid = (int64_t)blockIdx.x * EB + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * EB;
     const int q = (int)(gtid % cq);
     const int64_t gbase = (int64_t)blockIdx.y * quads;
-    dy += gbase;
-    if (MODE == 0) act_src += gbase;
-    if (MODE != 2) bn_src += gbase;
     f32x4 sc = {1, 1, 1, 1}, sh = {0, 0, 0, 0};
     if (MODE == 1) { sc = scale[blockIdx.y * cq + q]; sh = shift[blockIdx.y * cq + q]; }
     f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
     for (int64_t i = gtid; i < quads; i += stride) {
-        f32x4 g = dy[i];
+        f32x4 g = ldq(dy_, gbase + i, m & 1);
         if (MODE == 0) {
-            const f32x4 o = act_src[i];
+            const f32x4 o = ldq(act_src_, gbase + i, m & 2);
             g.x *= ctl_leaky_grad(o.x, slope); g.y *= ctl_leaky_grad(o.y, slope);
             g.z *= ctl_leaky_grad(o.z, slope); g.w *= ctl_leaky_grad(o.w, slope);
         }
         if (MODE == 2) {
             s1.x += g.x; s1.y += g.y; s1.z += g.z; s1.w += g.w;
         } else {
-            const f32x4 u = bn_src[i];
+            const f32x4 u = ldq(bn_src_, gbase + i, m & 4);
             if (MODE == 1) {
                 g.x *= ctl_leaky_grad(u.x * sc.x + sh.x, slope); g.y *= ctl_leaky_grad(u.y * sc.y + sh.y, slope);
                 g.z *= ctl_leaky_grad(u.z * sc.z + sh.z, slope); g.w *= ctl_leaky_grad(u.w * sc.w + sh.w, slope);
@@ -187,23 +206,24 @@ __global__ __launch_bounds__(EB) void bn_bwd_finalize_kernel(const float* __rest
 }
 
 template <int MODE>
-__global__ __launch_bounds__(EB) void bwd_apply_kernel(const f32x4* __restrict__ dy, const f32x4* __restrict__ act_src,
-                                                        const f32x4* __restrict__ bn_src,
+__global__ __launch_bounds__(EB) void bwd_apply_kernel(const void* __restrict__ dy, const void* __restrict__ act_src,
+                                                        const void* __restrict__ bn_src,
                                                         const f32x4* __restrict__ scale,
                                                         const f32x4* __restrict__ shift, float slope,
                                                         const f32x4* __restrict__ coef, int64_t quads, int cq,
-                                                        f32x4* __restrict__ ds, f32x4* __restrict__ dx, int64_t group_quads) {
+                                                        void* __restrict__ ds, void* __restrict__ dx, int64_t group_quads,
+                                                        unsigned m) {      // m: bit 0 dy, 1 act_src, 2 bn_src, 3 ds, 4 dx
     const int64_t stride = (int64_t)gridDim.x * EB;
     for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < quads; i += stride) {
         const int q = (int)(i % cq);
         const int gi = (int)(i / group_quads);
-        f32x4 g = dy[i];
-        const f32x4 u = bn_src[i];
+        f32x4 g = ldq(dy, i, m & 1);
+        const f32x4 u = ldq(bn_src, i, m & 4);
         if (MODE == 0) {
-            const f32x4 o = act_src[i];
+            const f32x4 o = ldq(act_src, i, m & 2);
             g.x *= ctl_leaky_grad(o.x, slope); g.y *= ctl_leaky_grad(o.y, slope);
             g.z *= ctl_leaky_grad(o.z, slope); g.w *= ctl_leaky_grad(o.w, slope);
-            if (ds) ds[i] = g;
+            if (ds) stq(ds, i, g, m & 8);
         } else if (MODE == 1) {
             const f32x4 sc = scale[gi * cq + q], sh = shift[gi * cq + q];
             g.x *= ctl_leaky_grad(u.x * sc.x + sh.x, slope); g.y *= ctl_leaky_grad(u.y * sc.y + sh.y, slope);
@@ -213,7 +233,7 @@ __global__ __launch_bounds__(EB) void bwd_apply_kernel(const f32x4* __restrict__
         f32x4 r;
         r.x = A.x * g.x + B.x * u.x + C.x; r.y = A.y * g.y + B.y * u.y + C.y;
         r.z = A.z * g.z + B.z * u.z + C.z; r.w = A.w * g.w + B.w * u.w + C.w;
-        dx[i] = r;
+        stq(dx, i, r, m & 16);
     }
 }
 
@@ -227,8 +247,8 @@ __global__ __launch_bounds__(EB) void chan_sum_finalize_kernel(const float* __re
     if (threadIdx.x == 0) out[ch] = accumulate ? out[ch] + (float)s1 : (float)s1;
 }
 
-__global__ __launch_bounds__(EB) void sumpool2_kernel(const f32x4* __restrict__ dup, f32x4* __restrict__ dx, int n, int h,
-                                                       int w, int cq, int accumulate) {
+__global__ __launch_bounds__(EB) void sumpool2_kernel(const void* __restrict__ dup, void* __restrict__ dx, int n, int h,
+                                                       int w, int cq, int accumulate, unsigned m) {       // m: bit 0 dup, 1 dx
     const int64_t quads = (int64_t)n * h * w * cq;
     const int64_t stride = (int64_t)gridDim.x * EB;
     for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < quads; i += stride) {
@@ -240,17 +260,18 @@ __global__ __launch_bounds__(EB) void sumpool2_kernel(const f32x4* __restrict__ 
         const int64_t b = r / h;
         const int64_t row0 = ((b * 2 * h + 2 * y) * 2 * w + 2 * x) * cq + q;
         const int64_t row1 = row0 + (int64_t)2 * w * cq;
-        const f32x4 a0 = dup[row0], a1 = dup[row0 + cq], a2 = dup[row1], a3 = dup[row1 + cq];
+        const f32x4 a0 = ldq(dup, row0, m & 1), a1 = ldq(dup, row0 + cq, m & 1), a2 = ldq(dup, row1, m & 1), a3 = ldq(dup, row1 + cq, m & 1);
         f32x4 v;
         v.x = (a0.x + a1.x) + (a2.x + a3.x); v.y = (a0.y + a1.y) + (a2.y + a3.y);
         v.z = (a0.z + a1.z) + (a2.z + a3.z); v.w = (a0.w + a1.w) + (a2.w + a3.w);
-        if (accumulate) { const f32x4 o = dx[i]; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
-        dx[i] = v;
+        if (accumulate) { const f32x4 o = ldq(dx, i, m & 2); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+        stq(dx, i, v, m & 2);
     }
 }
 
 __global__ __launch_bounds__(EB) void sigmoid_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                           float* __restrict__ dx, int64_t count) {
+    // (dy and y are network outputs: fp32 in every configuration; dx is 1-channel and stays fp32 as well)
     const int64_t stride = (int64_t)gridDim.x * EB;
     for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < count; i += stride) {
         const float s = y[i];
@@ -489,41 +510,48 @@ extern "C" int ctl_bn_eval_coeffs(int32_t c, const float* gamma, const float* be
     CTL_LAUNCH_CHECK("bn_eval_coeffs");
     return CTL_OK;
 }
-extern "C" int ctl_bn_act(const float* x, const float* scale, const float* shift, float slope, float* y, int64_t pixels,
-                          int32_t c, int32_t groups, ctl_stream stream) {
+extern "C" int ctl_bn_act_dt(const float* x, const float* scale, const float* shift, float slope, float* y, int64_t pixels,
+                             int32_t c, int32_t groups, uint32_t bf16_mask, ctl_stream stream) {
     CTL_REQUIRE(x && y && scale && shift && c % 4 == 0 && pixels > 0 && groups >= 1 && pixels % groups == 0,
                 "bn_act: bad arguments (c must be a multiple of 4, pixels of groups)");
     const int64_t quads = pixels * (c / 4);
-    bn_act_kernel<<<dim3(stream_blocks(quads)), dim3(EB), 0, S_>>>((const f32x4*)x, (const f32x4*)scale,
-                                                                   (const f32x4*)shift, slope, (f32x4*)y, quads, c / 4, quads / groups);
+    bn_act_kernel<<<dim3(stream_blocks(quads)), dim3(EB), 0, S_>>>(x, (const f32x4*)scale, (const f32x4*)shift, slope, y, quads, c / 4,
+                                                                   quads / groups, bf16_mask);
     CTL_LAUNCH_CHECK("bn_act");
     return CTL_OK;
 }
+extern "C" int ctl_bn_act(const float* x, const float* scale, const float* shift, float slope, float* y, int64_t pixels,
+                          int32_t c, int32_t groups, ctl_stream stream) {
+    return ctl_bn_act_dt(x, scale, shift, slope, y, pixels, c, groups, 0, stream);
+}
 static bool red_c_ok(int c) { return c >= 4 && c % 4 == 0 && (EB % (c / 4)) == 0; }
 
-extern "C" int ctl_bwd_reduce(int32_t mode, const float* dy, const float* act_src, const float* bn_src,
-                              const float* scale, const float* shift, float slope, int64_t pixels, int32_t c,
-                              float* partial, int32_t groups, ctl_stream stream) {
+extern "C" int ctl_bwd_reduce_dt(int32_t mode, const float* dy, const float* act_src, const float* bn_src,
+                                 const float* scale, const float* shift, float slope, int64_t pixels, int32_t c,
+                                 float* partial, int32_t groups, uint32_t bf16_mask, ctl_stream stream) {
     CTL_REQUIRE(dy && partial && pixels > 0 && red_c_ok(c) && groups >= 1 && pixels % groups == 0, "bwd_reduce: bad arguments (c=%d)", c);
     const int64_t quads = (pixels / groups) * (c / 4);           // per group
     const dim3 grid(CTL_RED_BLOCKS, (unsigned)groups), blk(EB);
     if (mode == 0) {
         CTL_REQUIRE(act_src && bn_src, "bwd_reduce mode 0 needs act_src and bn_src");
-        bwd_reduce_kernel<0><<<grid, blk, 0, S_>>>((const f32x4*)dy, (const f32x4*)act_src, (const f32x4*)bn_src, nullptr,
-                                                  nullptr, slope, quads, c / 4, partial);
+        bwd_reduce_kernel<0><<<grid, blk, 0, S_>>>(dy, act_src, bn_src, nullptr, nullptr, slope, quads, c / 4, partial, bf16_mask);
     } else if (mode == 1) {
         CTL_REQUIRE(bn_src && scale && shift, "bwd_reduce mode 1 needs bn_src, scale, shift");
-        bwd_reduce_kernel<1><<<grid, blk, 0, S_>>>((const f32x4*)dy, nullptr, (const f32x4*)bn_src, (const f32x4*)scale,
-                                                  (const f32x4*)shift, slope, quads, c / 4, partial);
+        bwd_reduce_kernel<1><<<grid, blk, 0, S_>>>(dy, nullptr, bn_src, (const f32x4*)scale, (const f32x4*)shift, slope, quads, c / 4, partial,
+                                                  bf16_mask);
     } else if (mode == 2) {
         CTL_REQUIRE(groups == 1, "bwd_reduce mode 2 sums everything: groups must be 1");
-        bwd_reduce_kernel<2><<<grid, blk, 0, S_>>>((const f32x4*)dy, nullptr, nullptr, nullptr, nullptr, slope, quads,
-                                                  c / 4, partial);
+        bwd_reduce_kernel<2><<<grid, blk, 0, S_>>>(dy, nullptr, nullptr, nullptr, nullptr, slope, quads, c / 4, partial, bf16_mask);
     } else {
         CTL_FAIL(CTL_EINVAL, "bwd_reduce: mode %d", mode);
     }
     CTL_LAUNCH_CHECK("bwd_reduce");
     return CTL_OK;
+}
+extern "C" int ctl_bwd_reduce(int32_t mode, const float* dy, const float* act_src, const float* bn_src,
+                              const float* scale, const float* shift, float slope, int64_t pixels, int32_t c,
+                              float* partial, int32_t groups, ctl_stream stream) {
+    return ctl_bwd_reduce_dt(mode, dy, act_src, bn_src, scale, shift, slope, pixels, c, partial, groups, 0, stream);
 }
 extern "C" int ctl_bn_bwd_finalize(const float* partial, int32_t c, int64_t count, const float* gamma,
                                    const float* save_mean, const float* save_invstd, float* coef, float* dgamma,
@@ -534,29 +562,33 @@ extern "C" int ctl_bn_bwd_finalize(const float* partial, int32_t c, int64_t coun
     CTL_LAUNCH_CHECK("bn_bwd_finalize");
     return CTL_OK;
 }
-extern "C" int ctl_bwd_apply(int32_t mode, const float* dy, const float* act_src, const float* bn_src,
-                             const float* scale, const float* shift, float slope, const float* coef, int64_t pixels,
-                             int32_t c, float* ds, float* dx, int32_t groups, ctl_stream stream) {
+extern "C" int ctl_bwd_apply_dt(int32_t mode, const float* dy, const float* act_src, const float* bn_src,
+                                const float* scale, const float* shift, float slope, const float* coef, int64_t pixels,
+                                int32_t c, float* ds, float* dx, int32_t groups, uint32_t bf16_mask, ctl_stream stream) {
     CTL_REQUIRE(dy && bn_src && coef && dx && pixels > 0 && c % 4 == 0 && groups >= 1 && pixels % groups == 0, "bwd_apply: bad arguments");
     const int64_t quads = pixels * (c / 4);
     const dim3 grid(stream_blocks(quads)), blk(EB);
     if (mode == 0) {
         CTL_REQUIRE(act_src, "bwd_apply mode 0 needs act_src");
-        bwd_apply_kernel<0><<<grid, blk, 0, S_>>>((const f32x4*)dy, (const f32x4*)act_src, (const f32x4*)bn_src, nullptr,
-                                                 nullptr, slope, (const f32x4*)coef, quads, c / 4, (f32x4*)ds, (f32x4*)dx, quads / groups);
+        bwd_apply_kernel<0><<<grid, blk, 0, S_>>>(dy, act_src, bn_src, nullptr, nullptr, slope, (const f32x4*)coef, quads, c / 4, ds, dx,
+                                                 quads / groups, bf16_mask);
     } else if (mode == 1) {
         CTL_REQUIRE(scale && shift, "bwd_apply mode 1 needs scale and shift");
-        bwd_apply_kernel<1><<<grid, blk, 0, S_>>>((const f32x4*)dy, nullptr, (const f32x4*)bn_src, (const f32x4*)scale,
-                                                 (const f32x4*)shift, slope, (const f32x4*)coef, quads, c / 4, nullptr,
-                                                 (f32x4*)dx, quads / groups);
+        bwd_apply_kernel<1><<<grid, blk, 0, S_>>>(dy, nullptr, bn_src, (const f32x4*)scale, (const f32x4*)shift, slope, (const f32x4*)coef, quads,
+                                                 c / 4, nullptr, dx, quads / groups, bf16_mask);
     } else if (mode == 2) {
-        bwd_apply_kernel<2><<<grid, blk, 0, S_>>>((const f32x4*)dy, nullptr, (const f32x4*)bn_src, nullptr, nullptr, slope,
-                                                 (const f32x4*)coef, quads, c / 4, nullptr, (f32x4*)dx, quads / groups);
+        bwd_apply_kernel<2><<<grid, blk, 0, S_>>>(dy, nullptr, bn_src, nullptr, nullptr, slope, (const f32x4*)coef, quads, c / 4, nullptr, dx,
+                                                 quads / groups, bf16_mask);
     } else {
         CTL_FAIL(CTL_EINVAL, "bwd_apply: mode %d", mode);
     }
     CTL_LAUNCH_CHECK("bwd_apply");
     return CTL_OK;
+}
+extern "C" int ctl_bwd_apply(int32_t mode, const float* dy, const float* act_src, const float* bn_src,
+                             const float* scale, const float* shift, float slope, const float* coef, int64_t pixels,
+                             int32_t c, float* ds, float* dx, int32_t groups, ctl_stream stream) {
+    return ctl_bwd_apply_dt(mode, dy, act_src, bn_src, scale, shift, slope, coef, pixels, c, ds, dx, groups, 0, stream);
 }
 extern "C" int ctl_chan_sum_finalize(const float* partial, int32_t c, float* out, int32_t accumulate, ctl_stream stream) {
     CTL_REQUIRE(partial && out && c > 0, "chan_sum_finalize: bad arguments");
@@ -564,13 +596,17 @@ extern "C" int ctl_chan_sum_finalize(const float* partial, int32_t c, float* out
     CTL_LAUNCH_CHECK("chan_sum_finalize");
     return CTL_OK;
 }
-extern "C" int ctl_sumpool2(const float* dup, float* dx, int32_t n, int32_t h, int32_t w, int32_t c, int32_t accumulate,
-                            ctl_stream stream) {
+extern "C" int ctl_sumpool2_dt(const float* dup, float* dx, int32_t n, int32_t h, int32_t w, int32_t c, int32_t accumulate,
+                               uint32_t bf16_mask, ctl_stream stream) {
     CTL_REQUIRE(dup && dx && n > 0 && h > 0 && w > 0 && c % 4 == 0, "sumpool2: bad arguments");
     const int64_t quads = (int64_t)n * h * w * (c / 4);
-    sumpool2_kernel<<<dim3(stream_blocks(quads)), dim3(EB), 0, S_>>>((const f32x4*)dup, (f32x4*)dx, n, h, w, c / 4, accumulate);
+    sumpool2_kernel<<<dim3(stream_blocks(quads)), dim3(EB), 0, S_>>>(dup, dx, n, h, w, c / 4, accumulate, bf16_mask);
     CTL_LAUNCH_CHECK("sumpool2");
     return CTL_OK;
+}
+extern "C" int ctl_sumpool2(const float* dup, float* dx, int32_t n, int32_t h, int32_t w, int32_t c, int32_t accumulate,
+                            ctl_stream stream) {
+    return ctl_sumpool2_dt(dup, dx, n, h, w, c, accumulate, 0, stream);
 }
 extern "C" int ctl_sigmoid_bwd(const float* dy, const float* y, float* dx, int64_t count, ctl_stream stream) {
     CTL_REQUIRE(dy && y && dx && count > 0, "sigmoid_bwd: bad arguments");

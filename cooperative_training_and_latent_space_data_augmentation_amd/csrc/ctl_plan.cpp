@@ -214,22 +214,22 @@ extern "C" int ctl_plan_run(const ctl_op* ops, int32_t n_ops, void* const* bases
                 rc = ctl_bn_eval_coeffs(op.i[0], CF(0), CF(1), CF(2), CF(3), op.f[0], F(4), F(5), NG(op.i[1]), stream);
                 break;
             case CTL_OP_BN_ACT:
-                rc = ctl_bn_act(CF(0), CF(1), CF(2), op.f[0], F(3), op.l[0], op.i[0], NG(op.i[1]), stream);
+                rc = ctl_bn_act_dt(CF(0), CF(1), CF(2), op.f[0], F(3), op.l[0], op.i[0], NG(op.i[1]), (uint32_t)op.i[25], stream);
                 break;
             case CTL_OP_BWD_REDUCE:
-                rc = ctl_bwd_reduce(op.i[0], CF(0), CF(1), CF(2), CF(3), CF(4), op.f[0], op.l[0], op.i[1], F(5), NG(op.i[2]), stream);
+                rc = ctl_bwd_reduce_dt(op.i[0], CF(0), CF(1), CF(2), CF(3), CF(4), op.f[0], op.l[0], op.i[1], F(5), NG(op.i[2]), (uint32_t)op.i[25], stream);
                 break;
             case CTL_OP_BN_BWD_FINALIZE:
                 rc = ctl_bn_bwd_finalize(CF(0), op.i[0], op.l[0], CF(1), CF(2), CF(3), F(4), F(5), F(6), op.i[1], NG(op.i[2]), op.i[3], stream);
                 break;
             case CTL_OP_BWD_APPLY:
-                rc = ctl_bwd_apply(op.i[0], CF(0), CF(1), CF(2), CF(3), CF(4), op.f[0], CF(5), op.l[0], op.i[1], F(6), F(7), NG(op.i[2]), stream);
+                rc = ctl_bwd_apply_dt(op.i[0], CF(0), CF(1), CF(2), CF(3), CF(4), op.f[0], CF(5), op.l[0], op.i[1], F(6), F(7), NG(op.i[2]), (uint32_t)op.i[25], stream);
                 break;
             case CTL_OP_CHAN_SUM_FINALIZE:
                 rc = ctl_chan_sum_finalize(CF(0), op.i[0], F(1), op.i[1], stream);
                 break;
             case CTL_OP_SUMPOOL2:
-                rc = ctl_sumpool2(CF(0), F(1), op.i[0], op.i[1], op.i[2], op.i[3], op.i[4], stream);
+                rc = ctl_sumpool2_dt(CF(0), F(1), op.i[0], op.i[1], op.i[2], op.i[3], op.i[4], (uint32_t)op.i[25], stream);
                 break;
             case CTL_OP_SIGMOID_BWD:
                 rc = ctl_sigmoid_bwd(CF(0), CF(1), F(2), op.l[0], stream);

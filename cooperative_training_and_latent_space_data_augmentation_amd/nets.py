@@ -45,7 +45,7 @@ FUSE_BNBWD = os.environ.get("CTL_FUSE_BNBWD", "0") == "1"   # BN1-backward reduc
 CONV_WORDS = _ffi.CONV_DTYPE.itemsize // 4      # ctl_conv as int32 words at the head of ctl_op.i
 ALIGN_F = 64            # floats (256 B)
 
-T = namedtuple("T", "ref n h w c")     # tensor descriptor: ref = (slot, byte offset), NHWC dims
+T = namedtuple("T", "ref n h w c b16", defaults=(False,))     # tensor descriptor: ref = (slot, byte offset), NHWC dims, bf16 storage?
 
 
 def _rup(x: int, a: int) -> int:
@@ -85,16 +85,20 @@ class BNInfo:
 
 
 class Arena:
-    def __init__(self, slot):
-        self.slot, self.size = slot, 0
+    """Bump allocator of one plan workspace.  `b16`: the tensors living here are network-internal and stored as bf16 (BASELINE config 3);
+    network inputs / outputs (the external slots) are fp32 in every configuration."""
+
+    def __init__(self, slot, b16=False):
+        self.slot, self.size, self.b16 = slot, 0, b16
 
     def alloc(self, nbytes: int):
         off = self.size
         self.size += _rup(max(int(nbytes), 4), 256)
         return (self.slot, off)
 
-    def tensor(self, n, h, w, c) -> T:
-        return T(self.alloc(4 * n * h * w * c), n, h, w, c)
+    def tensor(self, n, h, w, c, *_, b16=None) -> T:
+        b16 = self.b16 if b16 is None else b16
+        return T(self.alloc((2 if b16 else 4) * n * h * w * c), n, h, w, c, b16)
 
 
 class _ArenaLease:
@@ -143,8 +147,9 @@ class PlanBuilder:
         # BatchNorm groups: independent passes batched along n (each keeps its own statistics), see ctl_conv.groups
         self.groups = int(getattr(net, "_cur_groups", 1))
         self.ops: List[np.ndarray] = []
-        self.act = Arena(S_ACT)
-        self.bscr = Arena(S_BSCR)
+        self.b16 = bool(getattr(net, "bf16", False))
+        self.act = Arena(S_ACT, self.b16)
+        self.bscr = Arena(S_BSCR, self.b16)
         self.scr_bytes = 0
         self.reduce_recs: List[list] = []     # batched wgrad reduction records (one launch at the end of the plan)
         self.table: Optional[np.ndarray] = None
@@ -181,10 +186,10 @@ class PlanBuilder:
         return (S_GRAD, 4 * off_floats)
 
     # -- conv family
-    def _conv_desc(self, x: T, cout, ks, stride, in_mode, hout, wout, pro, flags, act, slope, nsub=1, pad=None):
+    def _conv_desc(self, x: T, cout, ks, stride, in_mode, hout, wout, pro, flags, act, slope, nsub=1, pad=None, dt=0):
         d = _ffi.conv_desc(n=x.n, hin=x.h, win=x.w, cin=x.c, hout=hout, wout=wout, cout=cout, ks=ks, stride=stride,
                            pad=(1 if ks in (3, 4) else 0) if pad is None else pad, in_mode=in_mode, pro_affine=1 if pro else 0,
-                           pro_slope=pro[2] if pro else 0.0, epi_flags=flags, epi_act=act, epi_slope=slope)
+                           pro_slope=pro[2] if pro else 0.0, epi_flags=flags, epi_act=act, epi_slope=slope, dt=dt)
         if nsub == 4:
             d["out_h"], d["out_w"], d["out_sy"], d["out_sx"], d["nsub"], d["out_sub"] = 2 * hout, 2 * wout, 2, 2, 4, 1
         d["groups"] = self.groups
@@ -209,11 +214,15 @@ class PlanBuilder:
                 hout, wout = x.h, x.w
         flags = (_ffi.EPI_BIAS if bias_ref is not None else 0) | (_ffi.EPI_STATS if stats else 0) | \
                 ((_ffi.EPI_BNBWD if bnbwd is not None else _ffi.EPI_RES) if res is not None else 0) | (_ffi.EPI_ACCUM if accum else 0)
-        d = self._conv_desc(x, cout, ks, stride, in_mode, hout, wout, pro, flags, act, slope, nsub, pad)
         oh, ow = (2 * hout, 2 * wout) if nsub == 4 else (hout, wout)
         if out is None:
             out = (arena or self.act).tensor(x.n, oh, ow, cout)
         assert (out.n, out.h, out.w, out.c) == (x.n, oh, ow, cout), (out, x.n, oh, ow, cout)
+        dt = 0
+        if self.b16:        # bf16 MFMA family; which of x / y / res is STORED as bf16 follows from where the tensor lives
+            assert bnbwd is None, "CTL_EPI_BNBWD is an fp32-only epilogue"
+            dt = _ffi.DT_BF16 | (_ffi.DT_X16 if x.b16 else 0) | (_ffi.DT_Y16 if out.b16 else 0) | (_ffi.DT_RES16 if res is not None and res[0].b16 else 0)
+        d = self._conv_desc(x, cout, ks, stride, in_mode, hout, wout, pro, flags, act, slope, nsub, pad, dt)
         op = self.op(_ffi.OP_CONV)
         op["i"][:CONV_WORDS] = np.frombuffer(d.tobytes(), dtype="<i4")
         stats_ref, blocks = None, 0
@@ -230,7 +239,8 @@ class PlanBuilder:
 
     def wgrad(self, x: T, dy: T, ks, *, stride=1, in_mode=0, pro=None, dw_ref, strides, dbias_ref=None, accumulate=False):
         """CTL_OP_WGRAD + CTL_OP_WGRAD_REDUCE for the conv x -> dy."""
-        d = self._conv_desc(x, dy.c, ks, stride, in_mode, dy.h, dy.w, pro, 0, 0, 0.0)
+        dt = (_ffi.DT_BF16 | (_ffi.DT_X16 if x.b16 else 0) | (_ffi.DT_Y16 if dy.b16 else 0)) if self.b16 else 0
+        d = self._conv_desc(x, dy.c, ks, stride, in_mode, dy.h, dy.w, pro, 0, 0, 0.0, dt=dt)
         dp = _ffi.desc_ptr(d)
         wb, bb = 4 * lib.ctl_wgrad_partial_floats(dp), 4 * lib.ctl_wgrad_bias_partial_floats(dp)
         if wb == 0:
@@ -290,9 +300,15 @@ class PlanBuilder:
             self.set_t(op, idx, ref)
         return co
 
+    @staticmethod
+    def mask(*ts) -> int:
+        """bf16 storage mask over an element-wise op's tensor arguments (ctl_*_dt)."""
+        return sum(1 << k for k, t in enumerate(ts) if t is not None and t.b16)
+
     def bn_act(self, x: T, co, slope, out: T):
         op = self.op(_ffi.OP_BN_ACT)
         op["i"][0], op["i"][1] = x.c, self.groups
+        op["i"][25] = self.mask(x, out)
         op["l"][0] = x.n * x.h * x.w
         op["f"][0] = slope
         for idx, ref in enumerate([x.ref, co["scale"], co["shift"], out.ref]):
@@ -306,6 +322,7 @@ class PlanBuilder:
         coef = self.bscr.alloc(4 * 3 * c * G)
         op = self.op(_ffi.OP_BWD_REDUCE)
         op["i"][0], op["i"][1], op["i"][2] = mode_kind, c, G
+        op["i"][25] = self.mask(dy, act_src, bn_src)
         op["l"][0] = pixels
         op["f"][0] = slope
         for idx, ref in enumerate([dy.ref, act_src.ref if act_src else None, bn_src.ref, co["scale"], co["shift"], part]):
@@ -318,6 +335,7 @@ class PlanBuilder:
             self.set_t(op, idx, ref)
         op = self.op(_ffi.OP_BWD_APPLY)
         op["i"][0], op["i"][1], op["i"][2] = mode_kind, c, G
+        op["i"][25] = self.mask(dy, act_src, bn_src, ds, dx)
         op["l"][0] = pixels
         op["f"][0] = slope
         for idx, ref in enumerate([dy.ref, act_src.ref if act_src else None, bn_src.ref, co["scale"], co["shift"], coef,
@@ -326,6 +344,7 @@ class PlanBuilder:
 
     def bn_backward_from_stats(self, g: T, bn_src: T, bn: BNInfo, co, stats_ref, blocks, *, dx: T, affine_grad: bool):
         """BatchNorm backward whose reduction already happened in the producing conv (conv(..., bnbwd=...)): finalize + apply."""
+        assert not self.b16
         c, pixels, G = bn_src.c, bn_src.n * bn_src.h * bn_src.w, self.groups
         coef = self.bscr.alloc(4 * 3 * c * G)
         op = self.op(_ffi.OP_BN_BWD_FINALIZE)
@@ -345,6 +364,7 @@ class PlanBuilder:
         part, = self.scr(4 * _ffi.RED_BLOCKS * 2 * c)
         op = self.op(_ffi.OP_BWD_REDUCE)
         op["i"][0], op["i"][1] = 2, c
+        op["i"][25] = self.mask(dy)
         op["l"][0] = dy.n * dy.h * dy.w
         self.set_t(op, 0, dy.ref)
         self.set_t(op, 5, part)
@@ -356,10 +376,12 @@ class PlanBuilder:
     def sumpool2(self, dup: T, dx: T, accumulate=False):
         op = self.op(_ffi.OP_SUMPOOL2)
         op["i"][:5] = [dx.n, dx.h, dx.w, dx.c, 1 if accumulate else 0]
+        op["i"][25] = self.mask(dup, dx)
         self.set_t(op, 0, dup.ref)
         self.set_t(op, 1, dx.ref)
 
     def sigmoid_bwd(self, dy: T, y: T, dx: T):
+        assert not (dy.b16 or y.b16 or dx.b16), "sigmoid_bwd works on the fp32 network output"
         op = self.op(_ffi.OP_SIGMOID_BWD)
         op["l"][0] = y.n * y.h * y.w * y.c
         for idx, ref in enumerate([dy.ref, y.ref, dx.ref]):
@@ -393,10 +415,13 @@ class PlanBuilder:
 class CtlNet(nn.Module):
     """Flat-storage network whose compute is a compiled plan of HIP kernel launches."""
 
-    def __init__(self, spec, cin: int, device):
+    def __init__(self, spec, cin: int, device, bf16: bool = False):
         super().__init__()
         self._spec = spec
         self.cin = cin
+        # BASELINE config 3: network-internal activations and gradients stored as bf16, convolutions on v_mfma_f32_16x16x32_bf16 with
+        # fp32 accumulation; master weights, BatchNorm statistics / coefficients, parameter gradients and network inputs / outputs fp32
+        self.bf16 = bool(bf16)
         self._bn_track = True              # False inside `disable_tracking_bn_stats` (mode B)
         self._convs: Dict[str, ConvInfo] = {}
         self._bns: Dict[str, BNInfo] = {}
@@ -494,7 +519,7 @@ class CtlNet(nn.Module):
                     ci.wp_up, wp = wp, wp + lib.ctl_conv_wpack_floats(ci.cout, ci.cin, 4)
                 ci.wp_upf = ci.wp_s2d = ci.wp_c4 = -1
                 ci.wp_ph = 0
-                if SMALL_CIN and ci.ks == 3 and not ci.transposed and ci.cin <= 4:
+                if SMALL_CIN and not self.bf16 and ci.ks == 3 and not ci.transposed and ci.cin <= 4:
                     # first layer (image: 1 channel, STN input: 4): the 3x3 taps are K-packed, 3 fragments per cout tile
                     ci.wp_c4, wp = wp, wp + ((ci.cout + 15) // 16) * 3 * 256
                 if ci.wp_up >= 0 and PHASE_CONVS:
@@ -604,6 +629,7 @@ class CtlNet(nn.Module):
         pb.table = np.asarray(recs, dtype=np.int64)
         op = pb.op(_ffi.OP_PACK_BATCH)                 # ONE launch re-packs every conv of the network
         op["i"][0] = len(recs)
+        op["i"][1] = 1 if self.bf16 else 0             # bf16 MFMA fragments (tap pairs) instead of fp32 ones
         op["l"][0] = max(r[10] for r in recs)
         pb.set_t(op, 0, (S_P, 0))
         pb.set_t(op, 1, (S_WP, 0))
@@ -698,7 +724,7 @@ class CtlNet(nn.Module):
             pb.wgrad(u, dv, 3, pro=pro1, dw_ref=pb.G(c3.w_off), strides=(c3.cin * k9, k9, 3, 1), dbias_ref=pb.G(c3.b_off))
         # dgrad of conv.3; its epilogue already multiplies by leaky'(BN1(u)) and takes the BatchNorm-backward sums (no
         # separate reduction pass); the apply runs in place
-        if FUSE_BNBWD:
+        if FUSE_BNBWD and not pb.b16:
             g1, st, blk = pb.conv(dv, self._wp_ref(c3.wp_dgrad), c3.cin, 3, arena=A,
                                   bnbwd=(u, rec["co1"]["scale"], rec["co1"]["shift"], SLOPE))
             pb.bn_backward_from_stats(g1, u, B[prefix + ".conv.1"], rec["co1"], st, blk, dx=g1, affine_grad=need_w and affine)
@@ -840,12 +866,12 @@ class CtlNet(nn.Module):
 class MyEncoder(CtlNet):
     """MyEncoder(feature_reduce=4, norm=BatchNorm2d, act=ReLU): ladder 16-32-64-128-128, spatial /16."""
 
-    def __init__(self, input_channel: int, feature_reduce: int = 4, device="cuda", _spec=None, _prefix=""):
+    def __init__(self, input_channel: int, feature_reduce: int = 4, device="cuda", _spec=None, _prefix="", bf16: bool = False):
         self._px = _prefix
         self.chan = [64 // feature_reduce, 128 // feature_reduce, 256 // feature_reduce, 512 // feature_reduce,
                      512 // feature_reduce]
         super().__init__(_spec if _spec is not None else _init.encoder_spec("", input_channel, feature_reduce),
-                         input_channel, device)
+                         input_channel, device, bf16)
 
     # -- plan pieces shared with the dual encoder
     def _emit_encoder_fwd(self, pb: PlanBuilder, x: T, mode: str, z_out: T):
@@ -915,11 +941,11 @@ class Dual_Branch_Encoder(MyEncoder):
     """FTN encoder: z_i = general_encoder(x), z_s = code_decoupler(z_i)."""
 
     def __init__(self, input_channel: int, z_level_1_channel: int = 128, z_level_2_channel: int = 128, feature_reduce: int = 4,
-                 device="cuda"):
+                 device="cuda", bf16: bool = False):
         assert z_level_1_channel == z_level_2_channel == 512 // feature_reduce
         super().__init__(input_channel, feature_reduce, device,
                          _spec=_init.dual_encoder_spec(input_channel, z_level_1_channel, feature_reduce),
-                         _prefix="general_encoder.")
+                         _prefix="general_encoder.", bf16=bf16)
 
     def _compile_forward(self, n, h, w, mode) -> Plan:
         pb = PlanBuilder(self)
@@ -956,7 +982,7 @@ class Dual_Branch_Encoder(MyEncoder):
             pb.bn_backward(1, d, None, rec["ud"], bn, rec["cod0"], SLOPE, ds=None, dx=du, affine_grad=need_w and affine)
             if need_w:
                 pb.wgrad(z_i, du, 3, dw_ref=pb.G(ci.w_off), strides=(ci.cin * 9, 9, 3, 1), dbias_ref=pb.G(ci.b_off))
-            dzi = pb.bscr.tensor(*z_i[1:])
+            dzi = pb.bscr.tensor(*z_i[1:], b16=False)       # (sums the fp32 gradient arriving at z_i directly: fp32, it is 2 MiB)
             if dzi_in is not None:      # dz_i = (gradient arriving at z_i directly) + dgrad of code_decoupler.0
                 pb.copy(dzi_in.ref, dzi.ref, 4 * z_i.n * z_i.h * z_i.w * z_i.c)
             pb.conv(du, self._wp_ref(ci.wp_dgrad), ci.cin, 3, out=dzi, accum=dzi_in is not None)
@@ -1016,12 +1042,12 @@ class MyDecoder(CtlNet):
     """MyDecoder(up_type in {'NN','Conv2'}, norm=BatchNorm2d, last_act in {None, Sigmoid})."""
 
     def __init__(self, input_channel: int, output_channel: int, feature_reduce: int = 4, up_type: str = "NN",
-                 last_act: Optional[str] = None, device="cuda"):
+                 last_act: Optional[str] = None, device="cuda", bf16: bool = False):
         if up_type not in ("NN", "Conv2"):
             raise NotImplementedError(f"up_type {up_type!r} (the reference's FCN_16_standard uses 'NN' and 'Conv2')")
         self.up_type, self.out_ch = up_type, output_channel
         self.sigmoid = last_act in ("sigmoid", "Sigmoid") or isinstance(last_act, nn.Sigmoid)
-        super().__init__(_init.decoder_spec(input_channel, output_channel, up_type, feature_reduce), input_channel, device)
+        super().__init__(_init.decoder_spec(input_channel, output_channel, up_type, feature_reduce), input_channel, device, bf16)
 
     def _compile_forward(self, n, h, w, mode) -> Plan:
         pb = PlanBuilder(self)
@@ -1046,7 +1072,7 @@ class MyDecoder(CtlNet):
         out, x4, cf = rec["out"], rec["x4"], self._convs["final_conv"]
         dout = T((S_DOUT0, 0), *out[1:])
         if self.sigmoid:
-            dl = pb.bscr.tensor(*out[1:])
+            dl = pb.bscr.tensor(*out[1:], b16=False)
             pb.sigmoid_bwd(dout, out, dl)
             dout = dl
         if need_w:
@@ -1066,17 +1092,20 @@ class MyDecoder(CtlNet):
 
 
 def build_networks(image_ch: int = 1, num_classes: int = 4, reduce_factor: int = 4, device="cuda",
-                   state_dicts: Optional[dict] = None) -> Dict[str, CtlNet]:
+                   state_dicts: Optional[dict] = None, dtype: str = "fp32") -> Dict[str, CtlNet]:
     """`get_network('FCN_16_standard')` (model.py:76-149).  Without `state_dicts` the weights are drawn exactly like the
     reference does for the current torch seed (see init.py)."""
     z = 512 // reduce_factor
     sds = state_dicts if state_dicts is not None else _init.reference_init_state_dicts(image_ch, num_classes, reduce_factor)
+    if dtype not in ("fp32", "bf16"):
+        raise ValueError(f"dtype {dtype!r}: 'fp32' (the reference's arithmetic) or 'bf16' (bf16 storage + MFMA, fp32 accumulate)")
+    b = dtype == "bf16"
     nets = {
-        "image_encoder": Dual_Branch_Encoder(image_ch, z, z, reduce_factor, device=device),
-        "segmentation_decoder": MyDecoder(z, num_classes, reduce_factor, "NN", None, device=device),
-        "shape_encoder": MyEncoder(num_classes, reduce_factor, device=device),
-        "shape_decoder": MyDecoder(z, num_classes, reduce_factor, "NN", None, device=device),
-        "image_decoder": MyDecoder(z, image_ch, reduce_factor, "Conv2", "sigmoid", device=device),
+        "image_encoder": Dual_Branch_Encoder(image_ch, z, z, reduce_factor, device=device, bf16=b),
+        "segmentation_decoder": MyDecoder(z, num_classes, reduce_factor, "NN", None, device=device, bf16=b),
+        "shape_encoder": MyEncoder(num_classes, reduce_factor, device=device, bf16=b),
+        "shape_decoder": MyDecoder(z, num_classes, reduce_factor, "NN", None, device=device, bf16=b),
+        "image_decoder": MyDecoder(z, image_ch, reduce_factor, "Conv2", "sigmoid", device=device, bf16=b),
     }
     for k, net in nets.items():
         if k in sds and sds[k] is not None:

@@ -40,8 +40,12 @@ def basic_loss_fn(pred, target, loss_type="cross entropy"):
 
 class AdvancedTripletReconSegmentationModel(nn.Module):
     def __init__(self, network_type="FCN_16_standard", image_ch=1, learning_rate=1e-4, encoder_dropout=None,
-                 decoder_dropout=None, num_classes=4, n_iter=1, checkpoint_dir=None, use_gpu=True, debug=False):
+                 decoder_dropout=None, num_classes=4, n_iter=1, checkpoint_dir=None, use_gpu=True, debug=False, *, compute_dtype=None):
+        """`compute_dtype` (keyword-only, no upstream counterpart): "fp32" = the reference's arithmetic (default, BASELINE config 2);
+        "bf16" = BASELINE config 3: network-internal activations / gradients stored as bf16, convolutions on bf16 MFMA with fp32
+        accumulation, fp32 master weights / BatchNorm statistics / losses."""
         super().__init__()
+        self.compute_dtype = compute_dtype or os.environ.get("CTL_DTYPE", "fp32")
         if network_type not in ("FCN_16_standard", "FCN_16_standard_w_o_filter", "FCN_16_standard_share_code"):
             raise NotImplementedError(network_type)
         if encoder_dropout is not None or decoder_dropout is not None:
@@ -91,7 +95,7 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
     def get_network(self, checkpoint_dir=None):
         """model.py:76-149: fresh weights follow the reference's init for the current torch seed; with a checkpoint
         directory, `<name>.pth` state dicts are loaded (model.py:114-131,157-173)."""
-        model = build_networks(self.image_ch, self.num_classes, 4, device=self.device)
+        model = build_networks(self.image_ch, self.num_classes, 4, device=self.device, dtype=self.compute_dtype)
         if checkpoint_dir:
             for name, net in model.items():
                 self.init_model(net, resume_path=join(checkpoint_dir, name + ".pth"))

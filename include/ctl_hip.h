@@ -184,6 +184,20 @@ int ctl_mse_bwd(const float* a, const float* b, const float* gout, int64_t count
 /* pred.max(1)[1] (model.py:657): first maximal channel, uint8 out */
 int ctl_argmax_c(const float* logit, uint8_t* out, int64_t pixels, int32_t c, ctl_stream stream);
 
+/* Storage-type aware forms of the element-wise kernels that touch network-internal tensors (BASELINE config 3 stores those as bf16):
+ * `bf16_mask` bit k = tensor argument k (in the order x,y | dy,act_src,bn_src | dy,act_src,bn_src,ds,dx | dup,dx) is bf16; the
+ * arithmetic is fp32, a store rounds once (RNE).  mask 0 == the plain entry points above. */
+int ctl_bn_act_dt(const float* x, const float* scale, const float* shift, float slope, float* y, int64_t pixels, int32_t c,
+                  int32_t groups, uint32_t bf16_mask, ctl_stream stream);
+int ctl_bwd_reduce_dt(int32_t mode, const float* dy, const float* act_src, const float* bn_src, const float* scale,
+                      const float* shift, float slope, int64_t pixels, int32_t c, float* partial, int32_t groups,
+                      uint32_t bf16_mask, ctl_stream stream);
+int ctl_bwd_apply_dt(int32_t mode, const float* dy, const float* act_src, const float* bn_src, const float* scale,
+                     const float* shift, float slope, const float* coef, int64_t pixels, int32_t c, float* ds, float* dx,
+                     int32_t groups, uint32_t bf16_mask, ctl_stream stream);
+int ctl_sumpool2_dt(const float* dup, float* dx, int32_t n, int32_t h, int32_t w, int32_t c, int32_t accumulate,
+                    uint32_t bf16_mask, ctl_stream stream);
+
 /* ------------------------------------------------------------------------------------------------ latent masking
  * util.py:224-249 (channel) / 285-312 (spatial).  mode 0: score[n,c] = mean_hw grad; mode 1: score[n,hw] = mean_c grad.
  * `scratch` holds ctl_latent_score_ws_floats() floats (deterministic two-stage sum, no float atomics).

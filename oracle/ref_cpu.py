@@ -185,6 +185,76 @@ def build_networks(image_ch: int = 1, num_classes: int = 4, reduce_factor: int =
             "shape_encoder": shape_encoder, "shape_decoder": shape_decoder, "image_decoder": image_decoder}
 
 
+# --------------------------------------------------------------------------- bf16 rounding-point emulation (BASELINE config 3)
+def rb16(t: torch.Tensor) -> torch.Tensor:
+    """Round to bf16 (round-to-nearest-even), keep the dtype: what `v_cvt_pk_bf16_f32` does to an MFMA operand / a stored tensor."""
+    return t.to(torch.bfloat16).to(t.dtype)
+
+
+class bf16_rounding_points:
+    """Context manager: run the oracle networks with the ROUNDING POINTS of the engine's bf16 path (config 3) and fp32 arithmetic
+    everywhere else -- the checker for that path (tests/test_bf16_engine_gpu.py):
+      * every convolution's input and weights are rounded to bf16 (the MFMA operands; the input AFTER the fp32 BatchNorm + LeakyReLU of
+        its producer), products accumulate in fp32, bias / residual / activation in fp32;
+      * a BatchNorm takes its batch statistics from the UNROUNDED conv output (the kernels reduce the fp32 accumulators) but normalises
+        the tensor as STORED (bf16);
+      * `conv3x3(nearest_up(x))` of the 'NN' up blocks runs as the engine runs it: four 2x2 phase convs whose weights are sums of the
+        3x3 taps formed in fp32 and rounded ONCE;
+      * network inputs / outputs stay fp32.
+    Forward emulation (inference, losses); gradients flow through the roundings as identity."""
+
+    def __enter__(self):
+        self._saved = (nn.Conv2d.forward, nn.ConvTranspose2d.forward, nn.BatchNorm2d.forward, UpBlock.forward)
+        conv_fwd, convt_fwd, bn_fwd, _ = self._saved
+
+        def conv(m, x):
+            return m._conv_forward(rb16(x), rb16(m.weight), m.bias)
+
+        def convt(m, x):
+            return F.conv_transpose2d(rb16(x), rb16(m.weight), m.bias, m.stride, m.padding, m.output_padding, m.groups, m.dilation)
+
+        def bn(m, u):
+            if not (m.training or not m.track_running_stats):           # eval mode: running statistics
+                return F.batch_norm(rb16(u), m.running_mean, m.running_var, m.weight, m.bias, False, 0.0, m.eps)
+            mean = u.mean((0, 2, 3))
+            var = u.var((0, 2, 3), unbiased=False)
+            if m.track_running_stats and m.running_mean is not None:
+                with torch.no_grad():
+                    cnt = u.numel() / u.shape[1]
+                    m.running_mean.mul_(1 - m.momentum).add_(mean.detach() * m.momentum)
+                    m.running_var.mul_(1 - m.momentum).add_(var.detach() * cnt / max(cnt - 1, 1) * m.momentum)
+                    m.num_batches_tracked.add_(1)
+            scale = m.weight / torch.sqrt(var + m.eps)
+            return rb16(u) * scale.view(1, -1, 1, 1) + (m.bias - mean * scale).view(1, -1, 1, 1)
+
+        def up_forward(m, x):
+            if not isinstance(m.up, nn.Sequential):                      # 'Conv2' (ConvTranspose2d): no re-formulation
+                x = m.up(x)
+                return m.last_act(m.conv_input(x) + m.conv(x))
+            c0 = m.conv[0]
+            n, _, h, w = x.shape
+            xp = F.pad(rb16(x), (1, 1, 1, 1))
+            u = x.new_zeros(n, c0.out_channels, 2 * h, 2 * w)
+            for a in range(2):
+                for b in range(2):
+                    k = c0.weight.new_zeros(c0.out_channels, c0.in_channels, 2, 2)
+                    for kh in range(3):
+                        for kw in range(3):
+                            k[:, :, (a + kh + 1) // 2 - a, (b + kw + 1) // 2 - b] += c0.weight[:, :, kh, kw]
+                    u[:, :, a::2, b::2] = F.conv2d(xp[:, :, a:a + h + 1, b:b + w + 1], rb16(k), c0.bias)
+            main = u
+            for layer in list(m.conv)[1:]:
+                main = layer(main)
+            return m.last_act(m.conv_input(m.up(x)) + main)
+
+        nn.Conv2d.forward, nn.ConvTranspose2d.forward, nn.BatchNorm2d.forward, UpBlock.forward = conv, convt, bn, up_forward
+        return self
+
+    def __exit__(self, *exc):
+        nn.Conv2d.forward, nn.ConvTranspose2d.forward, nn.BatchNorm2d.forward, UpBlock.forward = self._saved
+        return False
+
+
 # --------------------------------------------------------------------------- small functions
 def set_grad(module: nn.Module, requires_grad: bool) -> None:
     """model_util.py:163-165 / basic_operations.py:82-84."""

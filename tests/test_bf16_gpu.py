@@ -176,7 +176,7 @@ def test_bf16_phase_convs_and_pooled_dgrad(n, cin, cout, h, w):
     close(y4, F.conv2d(rb(dy), rb(K), stride=2, padding=1), 3e-4, "pooled dgrad via 4x4 s2", True)
 
 
-WG = [(2, 16, 16, 32, 32), (16, 16, 16, 64, 64), (2, 32, 64, 16, 16), (2, 128, 128, 8, 8), (2, 64, 32, 24, 20), (2, 16, 32, 4, 4), (3, 48, 16, 40, 36)]
+WG = [(2, 1, 16, 32, 32), (16, 4, 16, 64, 64), (2, 16, 4, 32, 32), (2, 16, 16, 32, 32), (16, 16, 16, 64, 64), (2, 32, 64, 16, 16), (2, 128, 128, 8, 8), (2, 64, 32, 24, 20), (2, 16, 32, 4, 4), (3, 48, 16, 40, 36)]
 
 
 @pytest.mark.parametrize("x16,dy16", [(True, True), (False, True), (True, False)])
@@ -191,6 +191,8 @@ def test_bf16_wgrad_3x3(n, cin, cout, h, w, x16, dy16):
         dy = dy.to(torch.bfloat16).float()
     sc, sh = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.3
     dt = BF | (_ffi.DT_X16 if x16 else 0) | (_ffi.DT_Y16 if dy16 else 0)
+    if (x16 and cin % 16) or (dy16 and cout % 16):
+        pytest.skip("bf16-stored tensors have multiples of 16 channels (network inputs / outputs are fp32)")
     for pro in (False, True):
         d = _ffi.conv_desc(n=n, hin=h, win=w, cin=cin, hout=h, wout=w, cout=cout, ks=3, pro_affine=int(pro), pro_slope=0.2, dt=dt)
         dw, db = torch.zeros(cout, cin, 3, 3, device=DEV), torch.zeros(cout, device=DEV)
