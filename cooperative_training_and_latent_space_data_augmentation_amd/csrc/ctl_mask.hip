@@ -87,7 +87,8 @@ __global__ __launch_bounds__(MB) void mask_apply_kernel(const f32x4* __restrict_
     float* srow = sm;            // [L] scores
     float* mval = sm + L;        // [c] (channel) or [slab_pix] (spatial) mask values
     const int n = blockIdx.y;
-    const int k = k_dev ? k_dev[0] : k_host;
+    int k = k_dev ? k_dev[0] : k_host;
+    k = k < 0 ? 0 : (k > L - 1 ? L - 1 : k);      // a device-side k is not range-checked on the host
     const int p0 = blockIdx.x * slab_pix;
     const int p1 = min(hw, p0 + slab_pix);
     for (int i = threadIdx.x; i < L; i += MB) srow[i] = score[(int64_t)n * L + i];
@@ -126,7 +127,8 @@ __global__ __launch_bounds__(MB) void latent_threshold_kernel(const float* __res
                                                                const int* __restrict__ k_dev, float* __restrict__ thr) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int n = blockIdx.x;
-    const int k = k_dev ? k_dev[0] : k_host;
+    int k = k_dev ? k_dev[0] : k_host;
+    k = k < 0 ? 0 : (k > L - 1 ? L - 1 : k);      // a device-side k is not range-checked on the host (sm[] holds Lp2 >= L entries)
     for (int i = threadIdx.x; i < Lp2; i += MB) sm[i] = (i < L) ? score[(int64_t)n * L + i] : -INFINITY;
     __syncthreads();
     for (int size = 2; size <= Lp2; size <<= 1) {
