@@ -15,6 +15,8 @@ IN_PLAIN, IN_UP2, IN_ZINS2, IN_C4 = 0, 1, 2, 3
 ACT_NONE, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2
 EPI_BIAS, EPI_ACCUM, EPI_RES, EPI_STATS, EPI_BNBWD = 1, 2, 4, 8, 16
 RED_BLOCKS = 512
+FIN_REC_BYTES, FIN_MAX_RECS = 128 + 4 * 9 * 128, 85      # ctl_hip.h: CTL_FIN_*
+FIN_HEADER_BYTES = FIN_REC_BYTES * FIN_MAX_RECS
 (OP_CONV, OP_WGRAD, OP_WGRAD_REDUCE, OP_PACK, OP_BN_FINALIZE, OP_BN_EVAL, OP_BN_ACT, OP_BWD_REDUCE, OP_BN_BWD_FINALIZE,
  OP_BWD_APPLY, OP_CHAN_SUM_FINALIZE, OP_SUMPOOL2, OP_SIGMOID_BWD, OP_ZERO, OP_COPY, OP_PACK_BATCH, OP_WGRAD_REDUCE_BATCH) = range(1, 18)
 OP_MAX_T = 12
@@ -31,6 +33,21 @@ OP_DTYPE = np.dtype([("kind", "<i4"), ("i", "<i4", (27,)), ("f", "<f4", (4,)), (
 
 class CtlError(RuntimeError):
     pass
+
+
+class BnFin(C.Structure):
+    """ctl_bn_fin (ctl_hip.h): arguments of a BatchNorm finalize fused into the producing convolution"""
+    _fields_ = [("gamma", C.c_void_p), ("beta", C.c_void_p), ("running_mean", C.c_void_p), ("running_var", C.c_void_p),
+                ("num_batches_tracked", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p), ("save_mean", C.c_void_p),
+                ("save_invstd", C.c_void_p), ("count", C.c_int64), ("eps", C.c_float), ("momentum", C.c_float),
+                ("update_running", C.c_int32), ("reserved", C.c_int32)]
+
+
+class BnbFin(C.Structure):
+    """ctl_bnb_fin (ctl_hip.h): arguments of a BatchNorm-backward finalize fused into ctl_bwd_reduce_fin"""
+    _fields_ = [("gamma", C.c_void_p), ("save_mean", C.c_void_p), ("save_invstd", C.c_void_p), ("coef", C.c_void_p),
+                ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("counter", C.c_void_p), ("count", C.c_int64),
+                ("accumulate", C.c_int32), ("reserved", C.c_int32)]
 
 
 class _Lib:
@@ -99,6 +116,14 @@ class _Lib:
             "ctl_prof_start": [C.c_char_p], "ctl_prof_stop": [p, C.c_size_t],
             "ctl_pack_weights_batched": [p, p, p, i32, i64, p], "ctl_wgrad_reduce_batched": [p, p, p, i32, i64, p],
             "ctl_pack_weights_bf16_batched": [p, p, p, i32, i64, p],
+            "ctl_conv_forward_fin": [p] * 13,
+            "ctl_bn_fin_table_write": [p, p, i32, p],
+            "ctl_bwd_reduce_rows": [i32, i64, i32],
+            "ctl_bwd_reduce_fin": [i32, p, p, p, p, p, f32, i64, i32, p, i32, C.c_uint32, p, p],
+            "ctl_bn_act_dt": [p, p, p, f32, p, i64, i32, i32, C.c_uint32, p],
+            "ctl_bwd_reduce_dt": [i32, p, p, p, p, p, f32, i64, i32, p, i32, C.c_uint32, p],
+            "ctl_bwd_apply_dt": [i32, p, p, p, p, p, f32, p, i64, i32, p, p, i32, C.c_uint32, p],
+            "ctl_sumpool2_dt": [p, p, i32, i32, i32, i32, i32, C.c_uint32, p],
         }
         for name, args in sig.items():
             getattr(lib, name).argtypes = args
@@ -126,7 +151,8 @@ EXPORTED = ["ctl_version", "ctl_last_error", "ctl_conv_wpack_floats", "ctl_conv_
             "ctl_wgrad_reduce_batched", "ctl_confusion_hist", "ctl_rescale_intensity_ws_floats", "ctl_rescale_intensity",
             "ctl_noise_clamp", "ctl_crop_or_pad", "ctl_step_tick", "ctl_dropout2d_ex", "ctl_uniform_dev", "ctl_adam_dev",
             "ctl_latent_mask_fused_ws_floats", "ctl_latent_mask_fused", "ctl_accumulate", "ctl_pack_weights_bf16_batched",
-            "ctl_bn_act_dt", "ctl_bwd_reduce_dt", "ctl_bwd_apply_dt", "ctl_sumpool2_dt"]
+            "ctl_bn_act_dt", "ctl_bwd_reduce_dt", "ctl_bwd_apply_dt", "ctl_sumpool2_dt", "ctl_conv_forward_fin", "ctl_bn_fin_table_write",
+            "ctl_bwd_reduce_fin", "ctl_bwd_reduce_rows"]
 
 
 def prof_start(kernel_filter: str = "") -> None:

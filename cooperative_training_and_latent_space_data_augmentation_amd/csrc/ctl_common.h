@@ -43,6 +43,122 @@ __device__ __forceinline__ float ctl_leaky_grad(float out, float slope) { return
 __device__ __forceinline__ void ctl_barrier_lds_reads_done() { asm volatile("s_barrier" ::: "memory"); }
 __device__ __forceinline__ void ctl_barrier_lds_writes_done() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// Hand-off of per-block partial rows to the block that arrives last at a device-scope counter (it finalises them in the same
+// launch: no separate finalize kernel, no kernel boundary).  MI355X: the 8 XCD L2s are not coherent with each other, so the rows are
+// stored write-through (agent-scope relaxed atomic store = global_store sc1), every storing wave drains its stores (vmcnt(0)) before
+// the workgroup barrier in front of the arrival add, and the last block takes an agent-scope acquire before it reads the rows with
+// agent-scope loads (global_load sc1).  The counter is left at zero for the next launch.
+__device__ __forceinline__ void ctl_store_wt(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ctl_load_wt(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// Arrival counters are SHARDED: `base` points at CTL_ARRIVE_LINES 128-byte lines -- line 0 the top counter, lines 1..8 one shard
+// each (block L arrives at shard L % 8; the last arriver of a shard arrives at the top).  Hundreds of adds to ONE address serialise at
+// ~12 ns each on this part (768 blocks: 9 us per launch, measured); 8 shards on lines of their own run side by side.
+#define CTL_ARRIVE_SHARDS 8
+#define CTL_ARRIVE_LINES (CTL_ARRIVE_SHARDS + 1)
+#define CTL_ARRIVE_STRIDE 32      /* uint32 per line */
+__device__ __forceinline__ bool ctl_arrive_last(unsigned* base, unsigned block_linear, unsigned nblocks, int* flag_lds) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's partial-row stores have been acknowledged
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned shard = block_linear % CTL_ARRIVE_SHARDS;
+        const unsigned in_shard = (nblocks - shard + CTL_ARRIVE_SHARDS - 1) / CTL_ARRIVE_SHARDS;
+        const unsigned nshards = nblocks < CTL_ARRIVE_SHARDS ? nblocks : CTL_ARRIVE_SHARDS;
+        unsigned* sc = base + (1 + shard) * CTL_ARRIVE_STRIDE;
+        int last = 0;
+        if (__hip_atomic_fetch_add(sc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_shard - 1) {
+            __hip_atomic_store(sc, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__hip_atomic_fetch_add(base, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nshards - 1) {
+                __hip_atomic_store(base, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last = 1;
+            }
+        }
+        *flag_lds = last;
+    }
+    __syncthreads();
+    if (!*flag_lds) return false;
+    if (threadIdx.x < 64) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    return true;
+}
+__device__ __forceinline__ double wave_sum_double(double v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// BatchNorm forward finalize of one channel from its two sums over `count` pixels (bn_finalize_kernel and the fused tail of the
+// convolution kernels): biased variance for the normalisation, unbiased for running_var, momentum update in place.
+struct ctl_bn_fin_dev {
+    const float* gamma; const float* beta; float* running_mean; float* running_var; int64_t* nbt;
+    float* scale; float* shift; float* save_mean; float* save_invstd;
+    double count; float eps, momentum; int update_running;
+};
+struct ctl_bn_chan { float gamma, beta, rm, rv; };       // a channel's parameters, requested BEFORE the reduction whose result they meet
+__device__ __forceinline__ ctl_bn_chan ctl_bn_chan_load(int ch, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        int update_running, const float* __restrict__ running_mean,
+                                                        const float* __restrict__ running_var) {
+    ctl_bn_chan p;
+    p.gamma = gamma[ch]; p.beta = beta[ch];
+    p.rm = update_running ? running_mean[ch] : 0.f;
+    p.rv = update_running ? running_var[ch] : 0.f;
+    return p;
+}
+// p.rm / p.rv are carried from group to group (the running statistics see the groups in order) and stored every time
+__device__ __forceinline__ void ctl_bn_coefs(double s1, double s2, double count, int c, int g, int ch, ctl_bn_chan& p, float eps,
+                                             float momentum, int update_running, float* __restrict__ running_mean,
+                                             float* __restrict__ running_var, float* __restrict__ scale, float* __restrict__ shift,
+                                             float* __restrict__ save_mean, float* __restrict__ save_invstd) {
+    const double mean = s1 / count;
+    double var = s2 / count - mean * mean;   // biased variance, as F.batch_norm normalises with
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = p.gamma * invstd;
+    scale[g * c + ch] = sc;
+    shift[g * c + ch] = p.beta - (float)mean * sc;
+    if (save_mean) save_mean[g * c + ch] = (float)mean;
+    if (save_invstd) save_invstd[g * c + ch] = invstd;
+    if (update_running) {   // nn.BatchNorm2d: momentum 0.1, running_var uses the unbiased estimate
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        p.rm = (1.f - momentum) * p.rm + momentum * (float)mean;
+        p.rv = (1.f - momentum) * p.rv + momentum * (float)unbiased;
+        running_mean[ch] = p.rm;
+        running_var[ch] = p.rv;
+    }
+}
+// Device-resident record of one fused finalize (written by ctl_bn_fin_table_write before the producing kernel runs): the finalize
+// arguments and the arrival counters (one sharded set per block row of output-channel tiles; zero between launches).  The convolution kernels
+// take ONE pointer to it: passing the fields as kernel arguments cost the tuned kernels 50-60 spilled SGPRs.
+struct alignas(128) ctl_bn_rec {
+    ctl_bn_fin_dev f;                                                      // (first line)
+    unsigned counters[CTL_FIN_MAX_Y][CTL_ARRIVE_LINES][CTL_ARRIVE_STRIDE];  // per block row of output-channel tiles: sharded arrival counters
+};
+static_assert(sizeof(ctl_bn_rec) == CTL_FIN_REC_BYTES, "ctl_bn_rec is one table slot");
+__device__ __forceinline__ void ctl_bn_finalize_tail(ctl_bn_rec* __restrict__ rec, const float* __restrict__ partial, int rows, int groups,
+                                                     int cout, int co_first, int nco, unsigned nblocks, int* flag_lds) {
+    if (!ctl_arrive_last(&rec->counters[blockIdx.y][0][0], blockIdx.z * gridDim.x + blockIdx.x, nblocks, flag_lds)) return;
+    const ctl_bn_fin_dev f = rec->f;
+    const int lane = threadIdx.x & 63;
+    for (int cl = threadIdx.x >> 6; cl < nco; cl += (int)(blockDim.x >> 6)) {
+        const int ch = co_first + cl;
+        if (ch >= cout) continue;
+        ctl_bn_chan p = ctl_bn_chan_load(ch, f.gamma, f.beta, f.update_running, f.running_mean, f.running_var);
+        for (int g = 0; g < groups; ++g) {      // the running statistics see the groups in order, as consecutive forward calls would
+            double s1 = 0.0, s2 = 0.0;
+#pragma unroll 4
+            for (int b = lane; b < rows; b += 64) {
+                s1 += (double)ctl_load_wt(partial + (((int64_t)g * rows + b) * 2 + 0) * cout + ch);
+                s2 += (double)ctl_load_wt(partial + (((int64_t)g * rows + b) * 2 + 1) * cout + ch);
+            }
+            s1 = wave_sum_double(s1);
+            s2 = wave_sum_double(s2);
+            if (lane == 0)
+                ctl_bn_coefs(s1, s2, f.count, cout, g, ch, p, f.eps, f.momentum, f.update_running, f.running_mean, f.running_var, f.scale,
+                             f.shift, f.save_mean, f.save_invstd);
+        }
+    }
+    if (f.update_running && f.nbt && co_first == 0 && threadIdx.x == 0) f.nbt[0] += groups;
+}
+
 // conv descriptors shared between ctl_conv.hip and ctl_plan.cpp
 struct ctl_conv_cfg {
     int mt, tw, nt;      // M-tiles per wave, tile width in pixels, cout tiles (of 16) per block
@@ -57,7 +173,7 @@ int ctl_conv_grid_x(int ntiles, int other, int occ);      // persistent grid: th
 // bf16 kernel family (ctl_conv_bf16.hip), reached through the public entry points when ctl_conv.dt has CTL_DT_BF16
 int ctl_conv_forward_bf16(const ctl_conv* d, const void* x, const void* wpack, const float* bias, const float* pro_scale,
                           const float* pro_shift, const void* res, const float* res_scale, const float* res_shift, void* y,
-                          float* stats_partial, ctl_stream stream);
+                          float* stats_partial, ctl_bn_rec* rec, ctl_stream stream);
 int ctl_conv_bf16_stats_blocks(const ctl_conv* d);
 int ctl_wgrad_bf16_splits(const ctl_conv* d);
 int ctl_conv_wgrad_bf16(const ctl_conv* d, const void* x, const float* pro_scale, const float* pro_shift, const void* dy,

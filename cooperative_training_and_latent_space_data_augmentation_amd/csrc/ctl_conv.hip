@@ -200,7 +200,8 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : ((MT * NT >= 4
                                                           const float* __restrict__ res_scale,
                                                           const float* __restrict__ res_shift, float* __restrict__ y,
                                                           float* __restrict__ stats_partial, int tiles_h, int tiles_w,
-                                                          int G_chunks, int64_t wpack_sub_stride, int ntiles) {
+                                                          int G_chunks, int64_t wpack_sub_stride, int ntiles,
+                                                          ctl_bn_rec* __restrict__ rec) {
     using G = Geom<KS, S, MT, TW>;
     constexpr int TAPS = KS * KS;
     // C4: input with <= 4 channels.  The four lane groups of an MFMA (its k index) carry four different TAPS (channels 0-3 each)
@@ -362,7 +363,8 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : ((MT * NT >= 4
 #pragma unroll
             for (int w = 0; w < 4; ++w) v += sred[((w * NT * 16) + cl) * 2 + stat];
             const int co = cot0 * 16 + cl;
-            if (co < d.cout) stats_partial[(((int64_t)grp * srows + srow) * 2 + stat) * d.cout + co] = v;
+            // write-through: the rows may be read by another block of this launch (fused finalize, ctl_bn_finalize_tail)
+            if (co < d.cout) ctl_store_wt(stats_partial + (((int64_t)grp * srows + srow) * 2 + stat) * d.cout + co, v);
         }
         __syncthreads();
     };
@@ -370,7 +372,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : ((MT * NT >= 4
     if ((flags & CTL_EPI_STATS) && ngroups > 1 && tid < NT * 16 * 2) {      // groups this block never visits contribute zeros
         const int stat = tid / (NT * 16), co = cot0 * 16 + tid % (NT * 16);
         if (co < d.cout)
-            for (int gi = 0; gi < ngroups; ++gi) stats_partial[(((int64_t)gi * srows + srow) * 2 + stat) * d.cout + co] = 0.f;
+            for (int gi = 0; gi < ngroups; ++gi) ctl_store_wt(stats_partial + (((int64_t)gi * srows + srow) * 2 + stat) * d.cout + co, 0.f);
     }
 
     TM(7)
@@ -569,7 +571,13 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : ((MT * NT >= 4
     TM_FLUSH
 #endif
 
-    if (flags & CTL_EPI_STATS) flush_stats(cur_grp);
+    if (flags & CTL_EPI_STATS) {
+        flush_stats(cur_grp);
+        // fused BatchNorm finalize: the last of the blocks that share this block's output channels turns the rows into coefficients
+        if (rec != nullptr)
+            ctl_bn_finalize_tail(rec, stats_partial, srows, ngroups, d.cout, cot0 * 16, NT * 16, gridDim.x * gridDim.z,
+                                 reinterpret_cast<int*>(sred));
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ weight gradient
@@ -1091,6 +1099,7 @@ struct conv_call {
     hipStream_t stream;
     bool query;      // only report the grid (ctl_conv_stats_blocks), launch nothing
     int grid_x;
+    ctl_bn_rec* rec;
 };
 
 template <int KS, int S, int MODE, int MT, int TW, int NT, int EPI>
@@ -1111,7 +1120,7 @@ static void conv_go(conv_call& a) {
     const dim3 grid((unsigned)a.grid_x, (unsigned)(a.c.cot / NT), (unsigned)d->nsub);
     conv_igemm_kernel<KS, S, MODE, MT, TW, NT, EPI><<<grid, dim3(256), 0, a.stream>>>(
         *d, a.x, a.wpack, a.bias, a.pro_scale, a.pro_shift, a.res, a.res_scale, a.res_shift, a.y, a.stats_partial, a.c.tiles_h,
-        a.c.tiles_w, a.c.g, (int64_t)ctl_conv_wpack_floats(d->cin, d->cout, d->ks), ntiles);
+        a.c.tiles_w, a.c.g, (int64_t)ctl_conv_wpack_floats(d->cin, d->cout, d->ks), ntiles, a.rec);
 }
 template <int KS, int S, int MODE, int MT, int TW>
 static void conv_go_nt(conv_call& a) {
@@ -1160,16 +1169,51 @@ extern "C" size_t ctl_conv_stats_floats(const ctl_conv* d) {
     return b < 0 ? 0 : (size_t)(d->groups > 1 ? d->groups : 1) * b * 2 * d->cout;
 }
 
+// ---- fused-finalize records: host structs -> device table slots (the counters of a slot are never written from here)
+struct ctl_fin_batch { ctl_bn_fin_dev f[16]; };
+__global__ void fin_table_write_kernel(ctl_bn_rec* table, int first, int n, const ctl_fin_batch batch) {
+    if ((int)threadIdx.x < n) table[first + threadIdx.x].f = batch.f[threadIdx.x];
+}
+extern "C" int ctl_bn_fin_table_write(void* table, const ctl_bn_fin* recs, int32_t n, ctl_stream stream) {
+    CTL_REQUIRE(table && recs && n > 0 && ((uintptr_t)table & 127) == 0, "bn_fin_table_write: bad arguments");
+    for (int first = 0; first < n; first += 16) {
+        ctl_fin_batch b = {};
+        const int m = n - first < 16 ? n - first : 16;
+        for (int i = 0; i < m; ++i) {
+            const ctl_bn_fin& r = recs[first + i];
+            CTL_REQUIRE(r.gamma && r.beta && r.scale && r.shift && r.count > 0, "bn_fin_table_write: record %d needs gamma, beta, scale, shift, count", first + i);
+            CTL_REQUIRE(!r.update_running || (r.running_mean && r.running_var), "bn_fin_table_write: record %d: update_running without buffers", first + i);
+            ctl_bn_fin_dev& f = b.f[i];
+            f.gamma = r.gamma; f.beta = r.beta; f.running_mean = r.running_mean; f.running_var = r.running_var; f.nbt = r.num_batches_tracked;
+            f.scale = r.scale; f.shift = r.shift; f.save_mean = r.save_mean; f.save_invstd = r.save_invstd; f.count = (double)r.count;
+            f.eps = r.eps; f.momentum = r.momentum; f.update_running = r.update_running;
+        }
+        fin_table_write_kernel<<<dim3(1), dim3(64), 0, (hipStream_t)stream>>>(reinterpret_cast<ctl_bn_rec*>(table), first, m, b);
+    }
+    CTL_LAUNCH_CHECK("bn_fin_table_write");
+    return CTL_OK;
+}
 extern "C" int ctl_conv_forward(const ctl_conv* d, const float* x, const float* wpack, const float* bias,
                                 const float* pro_scale, const float* pro_shift, const float* res,
                                 const float* res_scale, const float* res_shift, float* y, float* stats_partial,
                                 ctl_stream stream) {
+    return ctl_conv_forward_fin(d, x, wpack, bias, pro_scale, pro_shift, res, res_scale, res_shift, y, stats_partial, nullptr, stream);
+}
+extern "C" int ctl_conv_forward_fin(const ctl_conv* d, const float* x, const float* wpack, const float* bias,
+                                    const float* pro_scale, const float* pro_shift, const float* res,
+                                    const float* res_scale, const float* res_shift, float* y, float* stats_partial,
+                                    void* fin_rec, ctl_stream stream) {
     CTL_REQUIRE(d && x && wpack && y, "conv_forward: null argument");
     CTL_REQUIRE((d->dt & CTL_DT_BF16) || !(d->dt & (CTL_DT_X16 | CTL_DT_Y16 | CTL_DT_RES16)), "conv_forward: bf16-stored tensors need CTL_DT_BF16");
     conv_call a = {};
     a.d = d;
     int rc = ctl_conv_pick_cfg(d, &a.c, 0);
     if (rc != CTL_OK) return rc;
+    if (fin_rec) {
+        CTL_REQUIRE((d->epi_flags & CTL_EPI_STATS) && !(d->epi_flags & CTL_EPI_BNBWD) && stats_partial, "conv_forward: a fused BatchNorm finalize needs CTL_EPI_STATS (and no CTL_EPI_BNBWD)");
+        CTL_REQUIRE(ctl_cdiv(ctl_cdiv(d->cout, 16), a.c.nt) <= CTL_FIN_MAX_Y && ((uintptr_t)fin_rec & 127) == 0, "conv_forward: fused finalize: at most %d block rows of output-channel tiles, 128-byte aligned record", CTL_FIN_MAX_Y);
+    }
+    a.rec = reinterpret_cast<ctl_bn_rec*>(fin_rec);
     CTL_REQUIRE(!(d->epi_flags & CTL_EPI_BIAS) || bias, "conv_forward: CTL_EPI_BIAS without bias");
     CTL_REQUIRE(!(d->epi_flags & CTL_EPI_RES) || (res && res_scale && res_shift), "conv_forward: CTL_EPI_RES without res");
     CTL_REQUIRE(!(d->epi_flags & CTL_EPI_STATS) || stats_partial, "conv_forward: CTL_EPI_STATS without a partial buffer");
@@ -1187,7 +1231,7 @@ extern "C" int ctl_conv_forward(const ctl_conv* d, const float* x, const float* 
                 "conv_forward: tensors must stay below 2 GiB (32-bit buffer offsets)");
     if (d->dt & CTL_DT_BF16) {
         const int ptok16 = ctl_prof_begin("conv_igemm_bf16", d, &a.c, a.c.nt, (hipStream_t)stream);
-        rc = ctl_conv_forward_bf16(d, x, wpack, bias, pro_scale, pro_shift, res, res_scale, res_shift, y, stats_partial, stream);
+        rc = ctl_conv_forward_bf16(d, x, wpack, bias, pro_scale, pro_shift, res, res_scale, res_shift, y, stats_partial, a.rec, stream);
         ctl_prof_end(ptok16, (hipStream_t)stream);
         return rc;
     }

@@ -164,12 +164,19 @@ struct XStage16 {
 
 #define NFRAG_OF(KS) (((KS) * (KS) + 1) / 2)
 
+// resident blocks per CU the register allocation aims for (HBM-bound kernels: tiles in flight per CU is what hides the latency)
+#ifndef CTL16_OCC_BIG
+#define CTL16_OCC_BIG 2
+#endif
+#ifndef CTL16_OCC
+#define CTL16_OCC 3
+#endif
 template <int KS, int S, int MODE, int MT, int TW, int NT>
-__global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : 3) void conv_igemm_bf16_kernel(
+__global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? CTL16_OCC_BIG : CTL16_OCC) void conv_igemm_bf16_kernel(
     const ctl_conv d, const void* __restrict__ x, const void* __restrict__ wpack, const float* __restrict__ bias,
     const float* __restrict__ pro_scale, const float* __restrict__ pro_shift, const void* __restrict__ res,
     const float* __restrict__ res_scale, const float* __restrict__ res_shift, void* __restrict__ y, float* __restrict__ stats_partial,
-    int tiles_h, int tiles_w, int G_chunks, int64_t wpack_sub_bytes, int ntiles) {
+    int tiles_h, int tiles_w, int G_chunks, int64_t wpack_sub_bytes, int ntiles, ctl_bn_rec* __restrict__ rec) {
     using G = Geom<KS, S, MT, TW>;
     using XS = XStage16<KS, S, MODE, MT, TW>;
     constexpr int TAPS = KS * KS;
@@ -319,7 +326,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : 3) void conv_i
 #pragma unroll
             for (int w = 0; w < 4; ++w) v += sred[((w * NT * 16) + cl) * 2 + stat];
             const int co = cot0 * 16 + cl;
-            if (co < d.cout) stats_partial[(((int64_t)grp * srows + srow) * 2 + stat) * d.cout + co] = v;
+            if (co < d.cout) ctl_store_wt(stats_partial + (((int64_t)grp * srows + srow) * 2 + stat) * d.cout + co, v);      // (write-through: fused finalize)
         }
         __syncthreads();
     };
@@ -327,7 +334,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : 3) void conv_i
     if ((flags & CTL_EPI_STATS) && ngroups > 1 && tid < NT * 16 * 2) {
         const int stat = tid / (NT * 16), co = cot0 * 16 + tid % (NT * 16);
         if (co < d.cout)
-            for (int gi = 0; gi < ngroups; ++gi) stats_partial[(((int64_t)gi * srows + srow) * 2 + stat) * d.cout + co] = 0.f;
+            for (int gi = 0; gi < ngroups; ++gi) ctl_store_wt(stats_partial + (((int64_t)gi * srows + srow) * 2 + stat) * d.cout + co, 0.f);
     }
 
     f32x4 acc[MT][NT];
@@ -416,7 +423,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : 3) void conv_i
                     }
                     if (eo != CTL_OOB) {
                         if (d.cout >= 4) {
-                            if (y16) __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)}, ry, eo * 2, 0, 0);
+                            if (y16) __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)}, ry, eo * 2, 0, CTL_STORE_AUX);
                             else ctl_bstore4(ry, eo * 4, v);
                         } else {
                             ctl_bstore1(ry, eo * 4, v.x);             // cout == 1 (fp32 network output)
@@ -428,7 +435,12 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : 3) void conv_i
         if (g2 == 0) cur = nxt;
         g = g2;
     }
-    if (flags & CTL_EPI_STATS) flush_stats(cur_grp);
+    if (flags & CTL_EPI_STATS) {
+        flush_stats(cur_grp);
+        if (rec != nullptr)               // fused BatchNorm finalize by the last-arriving block of this output-channel range
+            ctl_bn_finalize_tail(rec, stats_partial, srows, ngroups, d.cout, cot0 * 16, NT * 16, gridDim.x * gridDim.z,
+                                 reinterpret_cast<int*>(sred));
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ weight packing (bf16 fragments)
@@ -509,6 +521,7 @@ struct conv16_call {
     const void *x, *wpack, *res; void* y;
     const float *bias, *pro_scale, *pro_shift, *res_scale, *res_shift; float* stats_partial;
     hipStream_t stream; bool query; int grid_x;
+    ctl_bn_rec* rec;
 };
 template <int KS, int S, int MODE, int MT, int TW, int NT>
 static void conv16_go(conv16_call& a) {
@@ -528,7 +541,7 @@ static void conv16_go(conv16_call& a) {
     const dim3 grid((unsigned)a.grid_x, (unsigned)(a.c.cot / NT), (unsigned)d->nsub);
     conv_igemm_bf16_kernel<KS, S, MODE, MT, TW, NT><<<grid, dim3(256), 0, a.stream>>>(
         *d, a.x, a.wpack, a.bias, a.pro_scale, a.pro_shift, a.res, a.res_scale, a.res_shift, a.y, a.stats_partial, a.c.tiles_h, a.c.tiles_w,
-        a.c.g, (int64_t)ctl_conv_wpack_floats(d->cin, d->cout, d->ks) * 4, ntiles);
+        a.c.g, (int64_t)ctl_conv_wpack_floats(d->cin, d->cout, d->ks) * 4, ntiles, a.rec);
 }
 template <int KS, int S, int MODE>
 static void conv16_go_tile(conv16_call& a) {
@@ -572,7 +585,7 @@ int ctl_conv_bf16_stats_blocks(const ctl_conv* d) {
 
 int ctl_conv_forward_bf16(const ctl_conv* d, const void* x, const void* wpack, const float* bias, const float* pro_scale,
                           const float* pro_shift, const void* res, const float* res_scale, const float* res_shift, void* y,
-                          float* stats_partial, ctl_stream stream) {
+                          float* stats_partial, ctl_bn_rec* rec, ctl_stream stream) {
     CTL_REQUIRE(!(d->epi_flags & CTL_EPI_BNBWD), "conv_forward(bf16): CTL_EPI_BNBWD is an fp32-only epilogue");
     CTL_REQUIRE(!(d->dt & CTL_DT_X16) || d->cin % 16 == 0, "conv_forward(bf16): bf16-stored inputs need cin %% 16 == 0 (got %d)", d->cin);
     CTL_REQUIRE(!(d->dt & (CTL_DT_Y16 | CTL_DT_RES16)) || d->cout % 4 == 0, "conv_forward(bf16): bf16-stored outputs need cout %% 4 == 0");
@@ -582,6 +595,7 @@ int ctl_conv_forward_bf16(const ctl_conv* d, const void* x, const void* wpack, c
     if (rc != CTL_OK) return rc;
     a.x = x; a.wpack = wpack; a.bias = bias; a.pro_scale = pro_scale; a.pro_shift = pro_shift; a.res = res; a.res_scale = res_scale;
     a.res_shift = res_shift; a.y = y; a.stats_partial = stats_partial; a.stream = (hipStream_t)stream;
+    a.rec = rec;
     rc = conv16_dispatch(a);
     if (rc != CTL_OK) return rc;
     CTL_LAUNCH_CHECK("conv_forward(bf16)");

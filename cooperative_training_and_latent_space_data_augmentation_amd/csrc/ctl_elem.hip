@@ -14,6 +14,34 @@ static inline unsigned stream_blocks(int64_t work_items) {
     return (unsigned)b;
 }
 
+// sums two values over the block at once: thread 0 gets both (one LDS round instead of two)
+__device__ __forceinline__ void block_sum_double2(double& a, double& b, double* sm) {
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sm[w] = a; sm[8 + w] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a = b = 0.0;
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) { a += sm[i]; b += sm[8 + i]; }
+    }
+    __syncthreads();
+}
+// the rows a thread owns (b = tid, tid + 256, ...; at most 4 * 256 rows) requested back to back: ONE memory round trip instead of one per
+// 256 rows -- these kernels are pure latency (a few KB of partial sums), and there are ~220 of them in a training step
+__device__ __forceinline__ void sum_rows2(const float* __restrict__ partial, int64_t row0, int blocks, int c, int ch, double& s1, double& s2) {
+    for (int b0 = threadIdx.x; b0 < blocks; b0 += 4 * EB) {
+        float v1[4], v2[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int b = b0 + u * EB;
+            const bool ok = b < blocks;
+            v1[u] = ok ? partial[((row0 + b) * 2 + 0) * c + ch] : 0.f;
+            v2[u] = ok ? partial[((row0 + b) * 2 + 1) * c + ch] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { s1 += (double)v1[u]; s2 += (double)v2[u]; }
+    }
+}
 __device__ __forceinline__ double block_sum_double(double v, double* sm) {
     // 256 threads: wave shuffle then LDS
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -40,12 +68,16 @@ __device__ __forceinline__ f32x4 ldq(const void* __restrict__ p, int64_t i, bool
     }
     return reinterpret_cast<const f32x4*>(p)[i];
 }
+#ifndef CTL_ELEM_NT
+#define CTL_ELEM_NT 0        // experiment hook: 1 = non-temporal stores of the element-wise kernels' output tensors
+#endif
 __device__ __forceinline__ void stq(void* __restrict__ p, int64_t i, f32x4 v, bool b16) {
     if (b16) {
-        reinterpret_cast<u32x2e*>(p)[i] = u32x2e{__builtin_bit_cast(unsigned, __builtin_convertvector(f32x2e{v.x, v.y}, bf16x2e)),
-                                                 __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2e{v.z, v.w}, bf16x2e))};
+        const u32x2e pk = u32x2e{__builtin_bit_cast(unsigned, __builtin_convertvector(f32x2e{v.x, v.y}, bf16x2e)),
+                                 __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2e{v.z, v.w}, bf16x2e))};
+        if (CTL_ELEM_NT) __builtin_nontemporal_store(pk, reinterpret_cast<u32x2e*>(p) + i); else reinterpret_cast<u32x2e*>(p)[i] = pk;
     } else {
-        reinterpret_cast<f32x4*>(p)[i] = v;
+        if (CTL_ELEM_NT) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p) + i); else reinterpret_cast<f32x4*>(p)[i] = v;
     }
 }
 
@@ -58,37 +90,20 @@ __global__ __launch_bounds__(EB) void bn_finalize_kernel(const float* __restrict
                                                           int64_t* __restrict__ nbt, float* __restrict__ scale,
                                                           float* __restrict__ shift, float* __restrict__ save_mean,
                                                           float* __restrict__ save_invstd, int groups) {
-    __shared__ double sm[8];
+    __shared__ double sm[16];
     const int ch = blockIdx.x;
+    ctl_bn_chan p = {};
+    if (threadIdx.x == 0) p = ctl_bn_chan_load(ch, gamma, beta, update_running, running_mean, running_var);
     // groups = independent passes batched along n: one set of coefficients each; the running statistics see them in order,
     // exactly as consecutive forward calls would
     for (int g = 0; g < groups; ++g) {
         double s1 = 0.0, s2 = 0.0;
-        for (int b = threadIdx.x; b < blocks; b += EB) {
-            s1 += (double)partial[(((int64_t)g * blocks + b) * 2 + 0) * c + ch];
-            s2 += (double)partial[(((int64_t)g * blocks + b) * 2 + 1) * c + ch];
-        }
-        s1 = block_sum_double(s1, sm);
-        __syncthreads();
-        s2 = block_sum_double(s2, sm + 4);
-        __syncthreads();
+        sum_rows2(partial, (int64_t)g * blocks, blocks, c, ch, s1, s2);
+        block_sum_double2(s1, s2, sm);
         if (threadIdx.x == 0) {
-            const double mean = s1 / count;
-            double var = s2 / count - mean * mean;   // biased variance, as F.batch_norm normalises with
-            if (var < 0.0) var = 0.0;
-            const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-            const float gm = gamma[ch], bt = beta[ch];
-            const float sc = gm * invstd;
-            scale[g * c + ch] = sc;
-            shift[g * c + ch] = bt - (float)mean * sc;
-            if (save_mean) save_mean[g * c + ch] = (float)mean;
-            if (save_invstd) save_invstd[g * c + ch] = invstd;
-            if (update_running) {   // nn.BatchNorm2d: momentum 0.1, running_var uses the unbiased estimate
-                const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-                running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * (float)mean;
-                running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * (float)unbiased;
-                if (ch == 0 && nbt) nbt[0] += 1;
-            }
+            ctl_bn_coefs(s1, s2, count, c, g, ch, p, eps, momentum, update_running, running_mean, running_var, scale, shift, save_mean,
+                         save_invstd);
+            if (update_running && ch == 0 && nbt) nbt[0] += 1;
         }
     }
 }
@@ -118,14 +133,58 @@ __global__ __launch_bounds__(EB) void bn_act_kernel(const void* __restrict__ x, 
 }
 
 // ------------------------------------------------------------------------------------------------ backward reductions
-// grid = CTL_RED_BLOCKS x 256; the global stride (131072) is a multiple of every C/4 in use, so a thread always sees
-// the same channel quad and accumulates it in registers.
+// rows of partial sums per group: enough blocks to stream a large tensor, few for the low-resolution layers (whose old fixed 512
+// rows cost more to write and re-read than the tensor itself)
+static inline int ctl_red_blocks(int64_t quads_per_group) {
+    int64_t b = ctl_cdiv64(quads_per_group, (int64_t)EB * 8);
+    if (b > CTL_RED_BLOCKS) b = CTL_RED_BLOCKS;
+    if (b < 16) b = 16;
+    return (int)b;
+}
+
+// BatchNorm backward coefficients of one (group, channel) from its two sums (shared by the finalize kernel and the fused tail)
+struct ctl_bnb_fin_dev {
+    const float* gamma; const float* save_mean; const float* save_invstd; float* coef; float* dgamma; float* dbeta;
+    unsigned* counter; double count; int accumulate;
+};
+struct ctl_bnb_chan { float gamma, dgamma, dbeta; };      // requested before the reduction (dgamma / dbeta carried over the groups)
+__device__ __forceinline__ ctl_bnb_chan bnb_chan_load(int ch, const float* __restrict__ gamma, const float* __restrict__ dgamma,
+                                                      const float* __restrict__ dbeta, int accumulate) {
+    ctl_bnb_chan p;
+    p.gamma = gamma[ch];
+    p.dgamma = (dgamma && accumulate) ? dgamma[ch] : 0.f;
+    p.dbeta = (dbeta && accumulate) ? dbeta[ch] : 0.f;
+    return p;
+}
+__device__ __forceinline__ void bn_bwd_coefs(double s1, double s2, double count, int c, int gi, int ch, ctl_bnb_chan& p, float mean,
+                                             float invstd, float* __restrict__ coef, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const double mu = mean, is = invstd, g = p.gamma;
+    const double sum_g = s1;
+    const double sum_gxhat = is * (s2 - mu * s1);
+    const double m1 = sum_g / count, m2 = sum_gxhat / count;
+    // dx = gamma*is*(g - m1 - xhat*m2),  xhat = (x-mu)*is   ==>  dx = A*g + B*x + C
+    const double A = g * is;
+    const double B = -g * is * is * m2;
+    const double C = -g * is * m1 + g * is * is * m2 * mu;
+    coef[(gi * 3 + 0) * c + ch] = (float)A;
+    coef[(gi * 3 + 1) * c + ch] = (float)B;
+    coef[(gi * 3 + 2) * c + ch] = (float)C;
+    // (first group without `accumulate`: p.dgamma = p.dbeta = 0 and 0 + x == x exactly)
+    p.dgamma += (float)sum_gxhat;
+    p.dbeta += (float)sum_g;
+    if (dgamma) dgamma[ch] = p.dgamma;
+    if (dbeta) dbeta[ch] = p.dbeta;
+}
+
+// grid = (rows, groups) x 256; the global stride (rows * 256) is a multiple of every C/4 in use, so a thread always sees
+// the same channel quad and accumulates it in registers.  fin.counter != NULL: the last block also finalises (bn_bwd_finalize).
 template <int MODE>
 __global__ __launch_bounds__(EB) void bwd_reduce_kernel(const void* __restrict__ dy_, const void* __restrict__ act_src_,
                                                          const void* __restrict__ bn_src_,
                                                          const f32x4* __restrict__ scale,
                                                          const f32x4* __restrict__ shift, float slope, int64_t quads,
-                                                         int cq, float* __restrict__ partial, unsigned m) {      // m: bit 0 dy, 1 act_src, 2 bn_src
+                                                         int cq, float* __restrict__ partial, unsigned m,      // m: bit 0 dy, 1 act_src, 2 bn_src
+                                                         const ctl_bnb_fin_dev fin) {
     // blockIdx.y = BatchNorm group: `quads` is the size of one group, its data start at blockIdx.y * quads
     __shared__ f32x4 sm[2][EB];
     const int64_t gtid = (int64_t)blockIdx.x * EB + threadIdx.x;
@@ -164,7 +223,28 @@ __global__ __launch_bounds__(EB) void bwd_reduce_kernel(const void* __restrict__
         float v = 0.f;
         // threads with (tid % cq) == qq hold this quad (EB % cq == 0 for every cq in use)
         for (int k = qq; k < EB; k += cq) v += sm[stat][k][comp];
-        partial[(((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 + stat) * c + ch] = v;
+        ctl_store_wt(partial + (((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 + stat) * c + ch, v);
+    }
+    if (MODE == 2 || fin.counter == nullptr) return;
+    // ---- fused finalize: the block that arrives last turns the rows into A, B, C (+ dgamma, dbeta); one wave per channel, rows
+    // spread over its lanes in a fixed order (deterministic), fp64 like the stand-alone kernel
+    __shared__ int last_flag;
+    if (!ctl_arrive_last(fin.counter, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, &last_flag)) return;
+    const int rows = gridDim.x, groups = gridDim.y, lane = threadIdx.x & 63;
+    for (int ch = threadIdx.x >> 6; ch < c; ch += EB / 64) {
+        ctl_bnb_chan p = bnb_chan_load(ch, fin.gamma, fin.dgamma, fin.dbeta, fin.accumulate);
+        for (int gi = 0; gi < groups; ++gi) {
+            const float mu = fin.save_mean[gi * c + ch], is = fin.save_invstd[gi * c + ch];
+            double s1 = 0.0, s2 = 0.0;
+#pragma unroll 4
+            for (int b = lane; b < rows; b += 64) {
+                s1 += (double)ctl_load_wt(partial + (((int64_t)gi * rows + b) * 2 + 0) * c + ch);
+                s2 += (double)ctl_load_wt(partial + (((int64_t)gi * rows + b) * 2 + 1) * c + ch);
+            }
+            s1 = wave_sum_double(s1);
+            s2 = wave_sum_double(s2);
+            if (lane == 0) bn_bwd_coefs(s1, s2, fin.count, c, gi, ch, p, mu, is, fin.coef, fin.dgamma, fin.dbeta);
+        }
     }
 }
 
@@ -174,34 +254,17 @@ __global__ __launch_bounds__(EB) void bn_bwd_finalize_kernel(const float* __rest
                                                               const float* __restrict__ save_invstd,
                                                               float* __restrict__ coef, float* __restrict__ dgamma,
                                                               float* __restrict__ dbeta, int accumulate, int groups) {
-    __shared__ double sm[8];
+    __shared__ double sm[16];
     const int ch = blockIdx.x;
+    ctl_bnb_chan p = {};
+    if (threadIdx.x == 0) p = bnb_chan_load(ch, gamma, dgamma, dbeta, accumulate);
     for (int gi = 0; gi < groups; ++gi) {       // coef[group][3][c]; dgamma/dbeta sum the groups in order
+        float mu = 0.f, is = 0.f;
+        if (threadIdx.x == 0) { mu = save_mean[gi * c + ch]; is = save_invstd[gi * c + ch]; }
         double s1 = 0.0, s2 = 0.0;
-        for (int b = threadIdx.x; b < blocks; b += EB) {
-            s1 += (double)partial[(((int64_t)gi * blocks + b) * 2 + 0) * c + ch];
-            s2 += (double)partial[(((int64_t)gi * blocks + b) * 2 + 1) * c + ch];
-        }
-        s1 = block_sum_double(s1, sm);
-        __syncthreads();
-        s2 = block_sum_double(s2, sm + 4);
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const double mu = save_mean[gi * c + ch], is = save_invstd[gi * c + ch], g = gamma[ch];
-            const double sum_g = s1;
-            const double sum_gxhat = is * (s2 - mu * s1);
-            const double m1 = sum_g / count, m2 = sum_gxhat / count;
-            // dx = gamma*is*(g - m1 - xhat*m2),  xhat = (x-mu)*is   ==>  dx = A*g + B*x + C
-            const double A = g * is;
-            const double B = -g * is * is * m2;
-            const double C = -g * is * m1 + g * is * is * m2 * mu;
-            coef[(gi * 3 + 0) * c + ch] = (float)A;
-            coef[(gi * 3 + 1) * c + ch] = (float)B;
-            coef[(gi * 3 + 2) * c + ch] = (float)C;
-            const bool acc = accumulate || gi > 0;
-            if (dgamma) dgamma[ch] = acc ? dgamma[ch] + (float)sum_gxhat : (float)sum_gxhat;
-            if (dbeta) dbeta[ch] = acc ? dbeta[ch] + (float)sum_g : (float)sum_g;
-        }
+        sum_rows2(partial, (int64_t)gi * blocks, blocks, c, ch, s1, s2);
+        block_sum_double2(s1, s2, sm);
+        if (threadIdx.x == 0) bn_bwd_coefs(s1, s2, count, c, gi, ch, p, mu, is, coef, dgamma, dbeta);
     }
 }
 
@@ -526,27 +589,43 @@ extern "C" int ctl_bn_act(const float* x, const float* scale, const float* shift
 }
 static bool red_c_ok(int c) { return c >= 4 && c % 4 == 0 && (EB % (c / 4)) == 0; }
 
-extern "C" int ctl_bwd_reduce_dt(int32_t mode, const float* dy, const float* act_src, const float* bn_src,
-                                 const float* scale, const float* shift, float slope, int64_t pixels, int32_t c,
-                                 float* partial, int32_t groups, uint32_t bf16_mask, ctl_stream stream) {
+extern "C" int ctl_bwd_reduce_rows(int32_t mode, int64_t pixels_per_group, int32_t c) {
+    return mode == 2 ? CTL_RED_BLOCKS : ctl_red_blocks(pixels_per_group * (c / 4));
+}
+extern "C" int ctl_bwd_reduce_fin(int32_t mode, const float* dy, const float* act_src, const float* bn_src,
+                                  const float* scale, const float* shift, float slope, int64_t pixels, int32_t c,
+                                  float* partial, int32_t groups, uint32_t bf16_mask, const ctl_bnb_fin* fin, ctl_stream stream) {
     CTL_REQUIRE(dy && partial && pixels > 0 && red_c_ok(c) && groups >= 1 && pixels % groups == 0, "bwd_reduce: bad arguments (c=%d)", c);
     const int64_t quads = (pixels / groups) * (c / 4);           // per group
-    const dim3 grid(CTL_RED_BLOCKS, (unsigned)groups), blk(EB);
+    // modes 0 / 1 feed ctl_bn_bwd_finalize, which derives the same row count from (count, c); mode 2 feeds ctl_chan_sum_finalize (fixed rows)
+    const dim3 grid((unsigned)(mode == 2 ? CTL_RED_BLOCKS : ctl_red_blocks(quads)), (unsigned)groups), blk(EB);
+    ctl_bnb_fin_dev f = {};
+    if (fin) {
+        CTL_REQUIRE(mode != 2 && fin->gamma && fin->save_mean && fin->save_invstd && fin->coef && fin->counter && fin->count > 0,
+                    "bwd_reduce: fused finalize needs modes 0/1, gamma, save_mean, save_invstd, coef, counter and count");
+        f.gamma = fin->gamma; f.save_mean = fin->save_mean; f.save_invstd = fin->save_invstd; f.coef = fin->coef; f.dgamma = fin->dgamma;
+        f.dbeta = fin->dbeta; f.counter = fin->counter; f.count = (double)fin->count; f.accumulate = fin->accumulate;
+    }
     if (mode == 0) {
         CTL_REQUIRE(act_src && bn_src, "bwd_reduce mode 0 needs act_src and bn_src");
-        bwd_reduce_kernel<0><<<grid, blk, 0, S_>>>(dy, act_src, bn_src, nullptr, nullptr, slope, quads, c / 4, partial, bf16_mask);
+        bwd_reduce_kernel<0><<<grid, blk, 0, S_>>>(dy, act_src, bn_src, nullptr, nullptr, slope, quads, c / 4, partial, bf16_mask, f);
     } else if (mode == 1) {
         CTL_REQUIRE(bn_src && scale && shift, "bwd_reduce mode 1 needs bn_src, scale, shift");
         bwd_reduce_kernel<1><<<grid, blk, 0, S_>>>(dy, nullptr, bn_src, (const f32x4*)scale, (const f32x4*)shift, slope, quads, c / 4, partial,
-                                                  bf16_mask);
+                                                  bf16_mask, f);
     } else if (mode == 2) {
         CTL_REQUIRE(groups == 1, "bwd_reduce mode 2 sums everything: groups must be 1");
-        bwd_reduce_kernel<2><<<grid, blk, 0, S_>>>(dy, nullptr, nullptr, nullptr, nullptr, slope, quads, c / 4, partial, bf16_mask);
+        bwd_reduce_kernel<2><<<grid, blk, 0, S_>>>(dy, nullptr, nullptr, nullptr, nullptr, slope, quads, c / 4, partial, bf16_mask, f);
     } else {
         CTL_FAIL(CTL_EINVAL, "bwd_reduce: mode %d", mode);
     }
     CTL_LAUNCH_CHECK("bwd_reduce");
     return CTL_OK;
+}
+extern "C" int ctl_bwd_reduce_dt(int32_t mode, const float* dy, const float* act_src, const float* bn_src,
+                                 const float* scale, const float* shift, float slope, int64_t pixels, int32_t c,
+                                 float* partial, int32_t groups, uint32_t bf16_mask, ctl_stream stream) {
+    return ctl_bwd_reduce_fin(mode, dy, act_src, bn_src, scale, shift, slope, pixels, c, partial, groups, bf16_mask, nullptr, stream);
 }
 extern "C" int ctl_bwd_reduce(int32_t mode, const float* dy, const float* act_src, const float* bn_src,
                               const float* scale, const float* shift, float slope, int64_t pixels, int32_t c,
@@ -557,7 +636,8 @@ extern "C" int ctl_bn_bwd_finalize(const float* partial, int32_t c, int64_t coun
                                    const float* save_mean, const float* save_invstd, float* coef, float* dgamma,
                                    float* dbeta, int32_t accumulate, int32_t groups, int32_t blocks, ctl_stream stream) {
     CTL_REQUIRE(partial && gamma && save_mean && save_invstd && coef && c > 0 && count > 0 && groups >= 1 && blocks >= 0, "bn_bwd_finalize: bad arguments");
-    bn_bwd_finalize_kernel<<<dim3(c), dim3(EB), 0, S_>>>(partial, blocks > 0 ? blocks : CTL_RED_BLOCKS, c, (double)count, gamma, save_mean,
+    // blocks == 0: rows as written by ctl_bwd_reduce for a group of `count` pixels
+    bn_bwd_finalize_kernel<<<dim3(c), dim3(EB), 0, S_>>>(partial, blocks > 0 ? blocks : ctl_red_blocks(count * (c / 4)), c, (double)count, gamma, save_mean,
                                                           save_invstd, coef, dgamma, dbeta, accumulate, groups);
     CTL_LAUNCH_CHECK("bn_bwd_finalize");
     return CTL_OK;

@@ -9,14 +9,29 @@
 // HBM traffic = read grad + read code + write masked = 3*N*C*H*W*4 bytes (+ the tiny score/mask vectors): the kernels
 // are pure streams, 16 B per lane, coalesced NHWC.  At the configured size (16x128x16x16 = 2 MiB per tensor) everything
 // sits in L2/Infinity Cache and the pair is launch-latency bound; bench.py sweeps sizes to show the HBM-bound regime.
+#include <stdlib.h>
+
 #include "ctl_common.h"
 
 #define MB 256
+// once-written / once-read streams of the HBM-sized problems: non-temporal policy (tuning: -DCTL_MASK_NT=0 none, 1 stores, 2 + loads)
+#ifndef CTL_MASK_NT
+#define CTL_MASK_NT 1      // measured (64x128x64x64): 86.5 us with plain stores, 67.2 with non-temporal stores, 70.0 with loads too
+#endif
+__device__ __forceinline__ void stream_store(f32x4* p, f32x4 v) {
+    if (CTL_MASK_NT >= 1) __builtin_nontemporal_store(v, p); else *p = v;
+}
+__device__ __forceinline__ f32x4 stream_load(const f32x4* p) {
+    if (CTL_MASK_NT >= 2) return __builtin_nontemporal_load(p);
+    return *p;
+}
 // pixels per block in the channel-mode score pass: 64 keeps the tiny configured problem (hw = 256) spread over 64 blocks;
 // large problems use 512-pixel slabs (more bytes in flight per block, 8x fewer partial rows)
 // (the split fixes the summation order of the channel scores: the three-launch path and the fused kernel share it, so their scores are
 // bit-identical; >= ~1024 partial sums in flight where the problem allows)
 static inline int score_split_pix(int n, int hw) {
+    static const int forced = [] { const char* e = getenv("CTL_MASK_SPLIT"); return e ? atoi(e) : 0; }();     // tuning hook
+    if (forced > 0) return forced;
     int sp = 512;
     while (sp > 64 && (int64_t)n * ctl_cdiv(hw, sp) < 1024) sp >>= 1;
     return sp;
@@ -34,9 +49,17 @@ __global__ __launch_bounds__(MB) void score_channel_partial_kernel(const f32x4* 
     const int p0 = sp * split_pix;
     const int p1 = min(hw, p0 + split_pix);
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    for (int pix = p0 + prow; pix < p1; pix += ppb) {
-        const f32x4 v = grad[((int64_t)n * hw + pix) * cq + q];
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    // 8 loads in flight per thread (a one-load-per-iteration loop keeps 4 KiB per block in flight: latency-bound at ~4 TB/s); the
+    // adds keep the order of the rolled loop, and the +0 of a lane past the split leaves a sum unchanged bit for bit
+    for (int pix = p0 + prow; pix < p1; pix += 8 * ppb) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int pp = pix + u * ppb;
+            v[u] = pp < p1 ? stream_load(grad + ((int64_t)n * hw + pp) * cq + q) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
     }
     sm[threadIdx.x] = s;
     __syncthreads();
@@ -63,21 +86,33 @@ __global__ __launch_bounds__(MB) void score_spatial_kernel(const f32x4* __restri
     const int q = threadIdx.x % cq, prow = threadIdx.x / cq;
     const int64_t stride = (int64_t)gridDim.x * ppb;
     const int64_t npad = ctl_cdiv64(pixels, stride) * stride;      // keep whole waves converged for the shuffles
-    for (int64_t pix = (int64_t)blockIdx.x * ppb + prow; pix < npad; pix += stride) {
-        float s = 0.f;
-        if (pix < pixels) {
-            const f32x4 v = grad[pix * cq + q];
-            s = (v.x + v.y) + (v.z + v.w);
+    for (int64_t pix0 = (int64_t)blockIdx.x * ppb + prow; pix0 < npad; pix0 += 4 * stride) {
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {                      // 4 loads in flight per thread
+            const int64_t pix = pix0 + u * stride;
+            v[u] = pix < pixels ? grad[pix * cq + q] : f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        for (int o = cq >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        if (q == 0 && pix < pixels) score[pix] = s * inv_count;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t pix = pix0 + u * stride;
+            float s = (v[u].x + v[u].y) + (v[u].z + v[u].w);
+            for (int o = cq >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            if (q == 0 && pix < pixels) score[pix] = s * inv_count;
+        }
     }
 }
 
 // ---- select + apply
-// grid (slabs, n).  LDS holds the image's whole score row (L <= 8192 floats).
+// grid (slabs, n).  LDS holds the image's whole score row (L <= 8192 floats).  The block's first 8 code quads per thread are requested
+// before anything else, so the score row, the ranking and k's load run under their latency.  `partial` (channel mode, optional):
+// the split sums of score_channel_partial_kernel -- the block then finalises the score row itself, in the order of
+// score_channel_finalize_kernel (bit-identical scores, one launch fewer); block 0 of an image publishes the row to `score_out`.
+#define APF 8
 template <int MODE>
 __global__ __launch_bounds__(MB) void mask_apply_kernel(const f32x4* __restrict__ code, const float* __restrict__ score,
+                                                         const float* __restrict__ partial, int splits, float inv_count,
+                                                         float* __restrict__ score_out,
                                                          const float* __restrict__ soft_noise, int k_host,
                                                          const int* __restrict__ k_dev, f32x4* __restrict__ masked,
                                                          float* __restrict__ mask_out, int hw, int cq, int slab_pix) {
@@ -87,37 +122,76 @@ __global__ __launch_bounds__(MB) void mask_apply_kernel(const f32x4* __restrict_
     float* srow = sm;            // [L] scores
     float* mval = sm + L;        // [c] (channel) or [slab_pix] (spatial) mask values
     const int n = blockIdx.y;
-    int k = k_dev ? k_dev[0] : k_host;
-    k = k < 0 ? 0 : (k > L - 1 ? L - 1 : k);      // a device-side k is not range-checked on the host
     const int p0 = blockIdx.x * slab_pix;
     const int p1 = min(hw, p0 + slab_pix);
-    for (int i = threadIdx.x; i < L; i += MB) srow[i] = score[(int64_t)n * L + i];
-    __syncthreads();
-    const int first = (MODE == 0) ? 0 : p0;
-    const int count = (MODE == 0) ? c : (p1 - p0);
-    for (int e = threadIdx.x; e < count; e += MB) {
-        const int i = first + e;
-        const float si = srow[i];
-        int ge = 0;
-        for (int j = 0; j < L; ++j) ge += (srow[j] >= si) ? 1 : 0;
-        float mv = 1.f;
-        if (ge <= k) mv = soft_noise ? 0.5f * soft_noise[(int64_t)n * L + i] : 0.f;
-        mval[e] = mv;
-        if (MODE == 1 || blockIdx.x == 0) mask_out[(int64_t)n * L + i] = mv;
-    }
-    __syncthreads();
     const int64_t base = ((int64_t)n * hw + p0) * cq;
     const int quads = (p1 - p0) * cq;
-    for (int e = threadIdx.x; e < quads; e += MB) {
-        f32x4 v = code[base + e];
+    f32x4 v[APF];
+#pragma unroll
+    for (int u = 0; u < APF; ++u) {
+        const int e = threadIdx.x + u * MB;
+        v[u] = e < quads ? stream_load(code + base + e) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    int k = k_dev ? k_dev[0] : k_host;
+    if (MODE == 0 && partial) {
+        for (int i = threadIdx.x; i < L; i += MB) {
+            float a = 0.f;
+            for (int sp = 0; sp < splits; ++sp) a += partial[((int64_t)n * splits + sp) * c + i];
+            a *= inv_count;
+            srow[i] = a;
+            if (score_out && blockIdx.x == 0) score_out[(int64_t)n * L + i] = a;
+        }
+    } else {
+        for (int i = threadIdx.x; i < L; i += MB) srow[i] = score[(int64_t)n * L + i];
+    }
+    __syncthreads();
+    k = k < 0 ? 0 : (k > L - 1 ? L - 1 : k);      // a device-side k is not range-checked on the host
+    const int first = (MODE == 0) ? 0 : p0;
+    const int count = (MODE == 0) ? c : (p1 - p0);
+    constexpr int RK = 4;                                     // lanes per ranked entry (interleaved scan + shuffle sum)
+    for (int e0 = 0; e0 < count; e0 += MB / RK) {
+        const int e = e0 + threadIdx.x / RK, sub = threadIdx.x % RK;
+        const bool ok = e < count;
+        const int i = first + (ok ? e : 0);
+        const float si = srow[i];
+        int ge = 0;
+#pragma unroll 8
+        for (int j = sub; j < L; j += RK) ge += (srow[j] >= si) ? 1 : 0;
+        ge += __shfl_xor(ge, 1); ge += __shfl_xor(ge, 2);
+        if (ok && sub == 0) {
+            float mv = 1.f;
+            if (ge <= k) mv = soft_noise ? 0.5f * soft_noise[(int64_t)n * L + i] : 0.f;
+            mval[e] = mv;
+            if (MODE == 1 || blockIdx.x == 0) mask_out[(int64_t)n * L + i] = mv;
+        }
+    }
+    __syncthreads();
+    auto apply = [&](f32x4 t, int e) -> f32x4 {
         if (MODE == 0) {
             const f32x4 m = reinterpret_cast<const f32x4*>(mval)[e % cq];
-            v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
+            t.x *= m.x; t.y *= m.y; t.z *= m.z; t.w *= m.w;
         } else {
             const float m = mval[e / cq];
-            v.x *= m; v.y *= m; v.z *= m; v.w *= m;
+            t.x *= m; t.y *= m; t.z *= m; t.w *= m;
         }
-        masked[base + e] = v;
+        return t;
+    };
+#pragma unroll
+    for (int u = 0; u < APF; ++u) {
+        const int e = threadIdx.x + u * MB;
+        if (e < quads) stream_store(masked + base + e, apply(v[u], e));
+    }
+    for (int e0 = APF * MB; e0 < quads; e0 += APF * MB) {       // slabs beyond 8 quads per thread: same 8-deep batches
+#pragma unroll
+        for (int u = 0; u < APF; ++u) {
+            const int e = e0 + threadIdx.x + u * MB;
+            v[u] = e < quads ? stream_load(code + base + e) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < APF; ++u) {
+            const int e = e0 + threadIdx.x + u * MB;
+            if (e < quads) stream_store(masked + base + e, apply(v[u], e));
+        }
     }
 }
 
@@ -167,16 +241,27 @@ __global__ __launch_bounds__(MB) void mask_apply_thr_kernel(const f32x4* __restr
     __syncthreads();
     const int64_t base = ((int64_t)n * hw + p0) * cq;
     const int quads = (p1 - p0) * cq;
-    for (int e = threadIdx.x; e < quads; e += MB) {
-        f32x4 v = code[base + e];
-        if (MODE == 0) {
-            const f32x4 m = reinterpret_cast<const f32x4*>(mval)[e % cq];
-            v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
-        } else {
-            const float m = mval[e / cq];
-            v.x *= m; v.y *= m; v.z *= m; v.w *= m;
+    for (int e0 = 0; e0 < quads; e0 += APF * MB) {              // 8 loads in flight per thread
+        f32x4 v[APF];
+#pragma unroll
+        for (int u = 0; u < APF; ++u) {
+            const int e = e0 + threadIdx.x + u * MB;
+            v[u] = e < quads ? code[base + e] : f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        masked[base + e] = v;
+#pragma unroll
+        for (int u = 0; u < APF; ++u) {
+            const int e = e0 + threadIdx.x + u * MB;
+            if (e >= quads) continue;
+            f32x4 t = v[u];
+            if (MODE == 0) {
+                const f32x4 m = reinterpret_cast<const f32x4*>(mval)[e % cq];
+                t.x *= m.x; t.y *= m.y; t.z *= m.z; t.w *= m.w;
+            } else {
+                const float m = mval[e / cq];
+                t.x *= m; t.y *= m; t.z *= m; t.w *= m;
+            }
+            masked[base + e] = t;
+        }
     }
 }
 
@@ -192,7 +277,7 @@ __global__ __launch_bounds__(MB) void mask_apply_thr_kernel(const f32x4* __restr
 // the HBM-streaming three-launch path (72 % of 8 TB/s at 128 MiB), both behind ctl_latent_mask_fused.
 #define IB 1024
 #define IPF 16      // quads of grad / code a thread holds: 1024 * 16 * 4 = 64 Ki elements per image
-template <int MODE>
+template <int MODE, int CPF, int GPF>      // quads of code / of grad a thread holds at once (the host picks the smallest instantiation that fits)
 __global__ __launch_bounds__(IB) void latent_mask_image_kernel(const f32x4* __restrict__ grad, const f32x4* __restrict__ code,
                                                                 const float* __restrict__ soft_noise, int k_host,
                                                                 const int* __restrict__ k_dev, f32x4* __restrict__ masked,
@@ -210,20 +295,41 @@ __global__ __launch_bounds__(IB) void latent_mask_image_kernel(const f32x4* __re
     const int64_t base = (int64_t)img * hw * cq;
     const int px0 = sl * slab_pix, px1 = min(hw, px0 + slab_pix);
     const int quads = max(px1 - px0, 0) * cq, qoff = px0 * cq;          // this block's slab of the image
-    f32x4 cv[IPF];
+    f32x4 cv[CPF];
 #pragma unroll
-    for (int j = 0; j < IPF; ++j) {                                     // code: consumed last, requested first
+    for (int j = 0; j < CPF; ++j) {                                     // code: consumed last, requested first
         const int e = tid + j * IB;
         cv[j] = e < quads ? code[base + qoff + e] : f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    // k and this thread's first soft-noise value: requested now, consumed after the score row exists (no dependent round trips later)
+    int k = k_dev ? k_dev[0] : k_host;
+    const int i0 = (MODE == 0) ? 0 : px0, i1 = (MODE == 0) ? c : px1;   // entries this block ranks: every channel / the pixels of its slab
+    // ranking: RK lanes share one entry (each scans every RK-th score, conflict-free LDS reads, shuffle sum): a one-lane scan of
+    // L = 128 scores is 128 dependent LDS round trips and was most of this kernel's time
+    constexpr int RK = 8;
+    float noise0 = 0.f;
+    if (soft_noise && i0 + tid / RK < i1) noise0 = soft_noise[(int64_t)img * L + i0 + tid / RK];
     if (MODE == 0) {
         // virtual block vb reduces splits vb, vb + 4, ...: thread lt of it sums pixels p0 + prow, p0 + prow + ppb, ... (in that order)
         const int vb = tid >> 8, lt = tid & 255;
         const int q = lt % cq, prow = lt / cq, ppb = 256 / cq;
+        const int iters = (split_pix + ppb - 1) / ppb;                  // loads per thread and split
         for (int sp0 = 0; sp0 < splits; sp0 += 4) {
             const int sp = sp0 + vb;
             f32x4 s = {0.f, 0.f, 0.f, 0.f};
-            if (sp < splits) {
+            if (iters <= GPF) {
+                // every load of the split in flight at once, then the adds in the order of the rolled loop (adding the +0 of a lane
+                // past the split leaves a sum unchanged bit for bit: the sums start from +0 and can never become -0)
+                f32x4 gv[GPF];
+#pragma unroll
+                for (int j = 0; j < GPF; ++j) {
+                    const int pix = sp * split_pix + prow + j * ppb;
+                    const bool ok = sp < splits && j < iters && pix < min(hw, (sp + 1) * split_pix);
+                    gv[j] = ok ? grad[base + (int64_t)pix * cq + q] : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int j = 0; j < GPF; ++j) { s.x += gv[j].x; s.y += gv[j].y; s.z += gv[j].z; s.w += gv[j].w; }
+            } else if (sp < splits) {
                 const int p0 = sp * split_pix, p1 = min(hw, p0 + split_pix);
                 for (int pix = p0 + prow; pix < p1; pix += ppb) {
                     const f32x4 v = grad[base + (int64_t)pix * cq + q];
@@ -250,14 +356,14 @@ __global__ __launch_bounds__(IB) void latent_mask_image_kernel(const f32x4* __re
         // (quad tid + j*IB of the image = channel quad tid % cq of pixel tid / cq + j * IB / cq: all of a thread's loads go out at once)
         const int q = tid % cq, prow = tid / cq, ppb = IB / cq;
         const int allq = hw * cq;
-        f32x4 gv[IPF];
+        f32x4 gv[GPF];
 #pragma unroll
-        for (int j = 0; j < IPF; ++j) {
+        for (int j = 0; j < GPF; ++j) {
             const int e = tid + j * IB;
             gv[j] = e < allq ? grad[base + e] : f32x4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
-        for (int j = 0; j < IPF; ++j) {
+        for (int j = 0; j < GPF; ++j) {
             const int pix = prow + j * ppb;
             float sc = (gv[j].x + gv[j].y) + (gv[j].z + gv[j].w);
             for (int o = cq >> 1; o > 0; o >>= 1) sc += __shfl_xor(sc, o);
@@ -265,24 +371,29 @@ __global__ __launch_bounds__(IB) void latent_mask_image_kernel(const f32x4* __re
         }
     }
     __syncthreads();
-    int k = k_dev ? k_dev[0] : k_host;
     k = k < 0 ? 0 : (k > L - 1 ? L - 1 : k);
-    // entries this block needs: every channel (channel mode) / the pixels of its slab (spatial mode)
-    const int i0 = (MODE == 0) ? 0 : px0, i1 = (MODE == 0) ? c : px1;
-    for (int i = i0 + tid; i < i1; i += IB) {
+    for (int e0 = 0; e0 < i1 - i0; e0 += IB / RK) {         // (uniform trip count: every lane takes part in the shuffles)
+        const int e = e0 + tid / RK, sub = tid % RK;
+        const bool ok = i0 + e < i1;
+        const int i = ok ? i0 + e : i0;
         const float si = srow[i];
         int ge = 0;
-        for (int j = 0; j < L; ++j) ge += (srow[j] >= si) ? 1 : 0;
-        const float mv = (ge <= k) ? (soft_noise ? 0.5f * soft_noise[(int64_t)img * L + i] : 0.f) : 1.f;
-        mval[i] = mv;
-        if (MODE == 1 || sl == 0) {
-            mask_out[(int64_t)img * L + i] = mv;
-            if (score_out) score_out[(int64_t)img * L + i] = si;
+#pragma unroll 8
+        for (int j = sub; j < L; j += RK) ge += (srow[j] >= si) ? 1 : 0;
+        ge += __shfl_xor(ge, 1); ge += __shfl_xor(ge, 2); ge += __shfl_xor(ge, 4);
+        if (ok && sub == 0) {
+            const float nz = (e0 == 0) ? noise0 : (soft_noise ? soft_noise[(int64_t)img * L + i] : 0.f);
+            const float mv = (ge <= k) ? (soft_noise ? 0.5f * nz : 0.f) : 1.f;
+            mval[i] = mv;
+            if (MODE == 1 || sl == 0) {
+                mask_out[(int64_t)img * L + i] = mv;
+                if (score_out) score_out[(int64_t)img * L + i] = si;
+            }
         }
     }
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < IPF; ++j) {
+    for (int j = 0; j < CPF; ++j) {
         const int e = tid + j * IB;
         if (e < quads) {
             f32x4 v = cv[j];
@@ -350,8 +461,9 @@ __global__ __launch_bounds__(MB) void uniform_kernel(float* __restrict__ out, in
 // ------------------------------------------------------------------------------------------------ launchers
 static bool cq_ok(int c) { return c >= 4 && c % 4 == 0 && (c / 4) <= 64 && (64 % (c / 4)) == 0; }
 static int slab_pixels(int n, int hw, int c) {
-    // ~16 KiB of code per block, but at least ~1024 blocks when the problem is large enough
-    int sp = (16 * 1024) / (c * 4);
+    // ~32 KiB of code per block (8 quads per thread in flight), but at least ~512 blocks when the problem is large enough
+    static const int forced_kb = [] { const char* e = getenv("CTL_MASK_SLAB_KB"); return e ? atoi(e) : 0; }();   // tuning hook
+    int sp = ((forced_kb > 0 ? forced_kb : 32) * 1024) / (c * 4);
     if (sp < 1) sp = 1;
     while (sp > 1 && (int64_t)n * ctl_cdiv(hw, sp) < 512) sp >>= 1;
     return sp;
@@ -413,11 +525,11 @@ extern "C" int ctl_latent_mask_apply(int32_t mode, const float* code, const floa
     }
     if (mode == 0) {
         const size_t lds = (size_t)(L + c) * sizeof(float);
-        mask_apply_kernel<0><<<grid, dim3(MB), lds, s>>>((const f32x4*)code, score, soft_noise, k_host, k_dev,
+        mask_apply_kernel<0><<<grid, dim3(MB), lds, s>>>((const f32x4*)code, score, nullptr, 0, 0.f, nullptr, soft_noise, k_host, k_dev,
                                                         (f32x4*)masked, mask_out, hw, c / 4, sp);
     } else if (mode == 1) {
         const size_t lds = (size_t)(L + sp) * sizeof(float);
-        mask_apply_kernel<1><<<grid, dim3(MB), lds, s>>>((const f32x4*)code, score, soft_noise, k_host, k_dev,
+        mask_apply_kernel<1><<<grid, dim3(MB), lds, s>>>((const f32x4*)code, score, nullptr, 0, 0.f, nullptr, soft_noise, k_host, k_dev,
                                                         (f32x4*)masked, mask_out, hw, c / 4, sp);
     } else {
         CTL_FAIL(CTL_EINVAL, "latent_mask_apply: mode %d", mode);
@@ -452,20 +564,37 @@ extern "C" int ctl_latent_mask_fused(int32_t mode, const float* grad, const floa
         int S = 1;                                    // blocks per image: at least ~64 blocks in flight when the batch is small
         while (S < 8 && n * S < 64 && hw / (2 * S) >= 8) S *= 2;
         const int slab_pix = ctl_cdiv(hw, S);
-        if (mode == 0)
-            latent_mask_image_kernel<0><<<dim3(n * S), dim3(IB), lds, s>>>((const f32x4*)grad, (const f32x4*)code, soft_noise, k_host, k_dev,
-                                                                          (f32x4*)masked, mask_out, score_out, hw, c / 4, split_pix, splits, S, slab_pix);
-        else
-            latent_mask_image_kernel<1><<<dim3(n * S), dim3(IB), lds, s>>>((const f32x4*)grad, (const f32x4*)code, soft_noise, k_host, k_dev,
-                                                                          (f32x4*)masked, mask_out, score_out, hw, c / 4, split_pix, splits, S, slab_pix);
+        // registers: the slab's code quads (CPF) and the grad quads in flight (GPF: channel mode = loads per thread and split,
+        // spatial mode = the whole image spread over the block); the rolled loop of the channel mode takes whatever exceeds GPF
+        const int cpf = ctl_cdiv(slab_pix * (c / 4), IB);
+        const int gpf = mode == 0 ? ctl_cdiv(split_pix, 256 / (c / 4)) : ctl_cdiv(hw * (c / 4), IB);
+        const bool small = cpf <= 4 && gpf <= 8;
+#define CTL_IMG_LAUNCH(M, CP, GP)                                                                                                  \
+        latent_mask_image_kernel<M, CP, GP><<<dim3(n * S), dim3(IB), lds, s>>>((const f32x4*)grad, (const f32x4*)code, soft_noise, k_host, \
+                                                                               k_dev, (f32x4*)masked, mask_out, score_out, hw, c / 4,  \
+                                                                               split_pix, splits, S, slab_pix)
+        if (mode == 0) { if (small) CTL_IMG_LAUNCH(0, 4, 8); else CTL_IMG_LAUNCH(0, IPF, 8); }      // (more than 8 loads per split: rolled loop)
+        else { if (small) CTL_IMG_LAUNCH(1, 4, 8); else CTL_IMG_LAUNCH(1, IPF, IPF); }
+#undef CTL_IMG_LAUNCH
         CTL_LAUNCH_CHECK("latent_mask_fused");
         return CTL_OK;
     }
-    // HBM-streaming sizes: the score pass, the (long-row) threshold and the apply pass as separate launches
+    // HBM-streaming sizes.  Channel mode: split sums of grad, then ONE apply launch whose blocks finalise the score row from the
+    // split sums themselves (2 launches).  Spatial mode: score pass, (long rows) threshold, apply.
     CTL_REQUIRE(workspace, "latent_mask_fused: this size needs ctl_latent_mask_fused_ws_floats() floats of workspace");
     float* score = workspace;
     float* ws_score = score + (size_t)n * L;
     float* ws_apply = ws_score + ctl_latent_score_ws_floats(mode, n, hw, c);
+    if (mode == 0 && L <= 1024) {
+        const int cq = c / 4, sp_pix = score_split_pix(n, hw), splits = ctl_cdiv(hw, sp_pix);
+        score_channel_partial_kernel<<<dim3(splits, n), dim3(MB), 0, s>>>((const f32x4*)grad, ws_score, hw, cq, splits, sp_pix);
+        const int sp = slab_pixels(n, hw, c);
+        mask_apply_kernel<0><<<dim3(ctl_cdiv(hw, sp), n), dim3(MB), (size_t)(L + c) * sizeof(float), s>>>(
+            (const f32x4*)code, nullptr, ws_score, splits, 1.f / (float)hw, score_out, soft_noise, k_host, k_dev, (f32x4*)masked, mask_out,
+            hw, cq, sp);
+        CTL_LAUNCH_CHECK("latent_mask_fused(stream)");
+        return CTL_OK;
+    }
     int rc = ctl_latent_score(mode, grad, score, ws_score, n, hw, c, stream);
     if (rc != CTL_OK) return rc;
     rc = ctl_latent_mask_apply(mode, code, score, soft_noise, k_host, k_dev, masked, mask_out, ws_apply, n, hw, c, stream);

@@ -162,7 +162,66 @@ extern "C" int ctl_plan_run(const ctl_op* ops, int32_t n_ops, void* const* bases
     }
     size_t forks = 0;
     bool side_used = false;
+    // ---- fused finalizes (opt-in per op: BN_FINALIZE / BN_BWD_FINALIZE with i[4] == 1 directly behind the kernel that writes their
+    // partial rows; the buffer of the partial slot starts with CTL_FIN_HEADER_BYTES of zero-initialised header = the record table).
+    // The finalize op is folded into its producer: rec_of[k] = table slot used by op k, skip[k + 1] drops the stand-alone launch.
+    // MEASURED on MI355X (profiles/README.md, round 2): OFF by default.  The arrival + agent-scope acquire + re-read of the rows by the
+    // last block costs ~10 us per fused launch (fp32 step 18.3 -> 21.6 ms) -- more than the ~7 us of a stand-alone finalize kernel and
+    // its boundary; cross-block hand-offs inside a launch are as expensive as a kernel boundary on this part.  CTL_FUSE_FINALIZE=1 opts in.
+    static const bool fuse_enabled = [] { const char* e = getenv("CTL_FUSE_FINALIZE"); return e && atoi(e) != 0; }();
+    thread_local std::vector<int> rec_of;
+    thread_local std::vector<char> skip;
+    rec_of.assign((size_t)n_ops, -1);
+    skip.assign((size_t)n_ops + 1, 0);
+    ctl_bn_fin recs[CTL_FIN_MAX_RECS];
+    int n_rec = 0;
+    char* table = nullptr;
+    auto resolve = [&](const ctl_op& o, int a) -> void* {
+        const int sl = o.slot[a];
+        return (sl < 0 || sl >= n_bases || !bases[sl]) ? nullptr : (void*)((char*)bases[sl] + o.off[a]);
+    };
+    for (int32_t k = 0; fuse_enabled && k + 1 < n_ops && n_rec < CTL_FIN_MAX_RECS; ++k) {
+        const ctl_op& a = ops[k];
+        const ctl_op& b = ops[k + 1];
+        if (b.i[4] != 1) continue;
+        int pslot = -1;
+        if (a.kind == CTL_OP_CONV && b.kind == CTL_OP_BN_FINALIZE && a.slot[9] >= 0 && a.slot[9] == b.slot[0] && a.off[9] == b.off[0]) {
+            ctl_conv dd;
+            memcpy(&dd, a.i, sizeof(dd));
+            ctl_conv_cfg cc;
+            if (!(dd.epi_flags & CTL_EPI_STATS) || (dd.epi_flags & CTL_EPI_BNBWD) || ctl_conv_pick_cfg(&dd, &cc, 0) != CTL_OK ||
+                cc.cot / cc.nt > CTL_FIN_MAX_Y)
+                continue;                                   // (more block rows of output-channel tiles than a record has counter sets)
+            ctl_bn_fin& r = recs[n_rec];
+            memset(&r, 0, sizeof(r));
+            r.gamma = (const float*)resolve(b, 1); r.beta = (const float*)resolve(b, 2);
+            r.running_mean = (float*)resolve(b, 3); r.running_var = (float*)resolve(b, 4);
+            r.num_batches_tracked = (int64_t*)resolve(b, 5);
+            r.scale = (float*)resolve(b, 6); r.shift = (float*)resolve(b, 7); r.save_mean = (float*)resolve(b, 8); r.save_invstd = (float*)resolve(b, 9);
+            r.count = b.l[0]; r.eps = b.f[0]; r.momentum = b.f[1]; r.update_running = b.i[2];
+            pslot = a.slot[9];
+        } else if (a.kind == CTL_OP_BWD_REDUCE && b.kind == CTL_OP_BN_BWD_FINALIZE && a.i[0] != 2 && b.i[3] == 0 && a.slot[5] >= 0 &&
+                   a.slot[5] == b.slot[0] && a.off[5] == b.off[0]) {
+            memset(&recs[n_rec], 0, sizeof(recs[n_rec]));          // (backward: arguments go by value, only the slot's counter is used)
+            recs[n_rec].gamma = recs[n_rec].beta = (const float*)resolve(b, 1);
+            recs[n_rec].scale = recs[n_rec].shift = (float*)resolve(b, 4);
+            recs[n_rec].count = 1;
+            pslot = a.slot[5];
+        } else {
+            continue;
+        }
+        CTL_REQUIRE(pslot < n_bases && bases[pslot], "plan_run: op %d: empty partial slot", k);
+        CTL_REQUIRE(table == nullptr || table == (char*)bases[pslot], "plan_run: fused finalizes must share one partial slot");
+        table = (char*)bases[pslot];
+        rec_of[k] = n_rec++;
+        skip[k + 1] = 1;
+    }
+    if (n_rec > 0) {
+        int rc0 = ctl_bn_fin_table_write(table, recs, n_rec, stream_);
+        if (rc0 != CTL_OK) return rc0;
+    }
     for (int32_t k = 0; k < n_ops; ++k) {
+        if (skip[k]) continue;
         const ctl_op& op = ops[k];
         ctl_stream stream = stream_;
         if (g_side_enabled && op.i[26] == 1) {
@@ -193,7 +252,8 @@ extern "C" int ctl_plan_run(const ctl_op* ops, int32_t n_ops, void* const* bases
         switch (op.kind) {
             case CTL_OP_CONV:
                 memcpy(&d, op.i, sizeof(d));
-                rc = ctl_conv_forward(&d, CF(0), CF(1), CF(2), CF(3), CF(4), CF(5), CF(6), CF(7), F(8), F(9), stream);
+                rc = ctl_conv_forward_fin(&d, CF(0), CF(1), CF(2), CF(3), CF(4), CF(5), CF(6), CF(7), F(8), F(9),
+                                          rec_of[k] >= 0 ? (void*)(table + (size_t)rec_of[k] * CTL_FIN_REC_BYTES) : nullptr, stream);
                 break;
             case CTL_OP_WGRAD:
                 memcpy(&d, op.i, sizeof(d));
@@ -217,7 +277,18 @@ extern "C" int ctl_plan_run(const ctl_op* ops, int32_t n_ops, void* const* bases
                 rc = ctl_bn_act_dt(CF(0), CF(1), CF(2), op.f[0], F(3), op.l[0], op.i[0], NG(op.i[1]), (uint32_t)op.i[25], stream);
                 break;
             case CTL_OP_BWD_REDUCE:
-                rc = ctl_bwd_reduce_dt(op.i[0], CF(0), CF(1), CF(2), CF(3), CF(4), op.f[0], op.l[0], op.i[1], F(5), NG(op.i[2]), (uint32_t)op.i[25], stream);
+                if (rec_of[k] >= 0) {       // + the BN_BWD_FINALIZE op behind it (its arguments by value, the slot's first counter)
+                    const ctl_op& fo = ops[k + 1];
+                    ctl_bnb_fin bf;
+                    memset(&bf, 0, sizeof(bf));
+                    bf.gamma = (const float*)resolve(fo, 1); bf.save_mean = (const float*)resolve(fo, 2); bf.save_invstd = (const float*)resolve(fo, 3);
+                    bf.coef = (float*)resolve(fo, 4); bf.dgamma = (float*)resolve(fo, 5); bf.dbeta = (float*)resolve(fo, 6);
+                    bf.counter = (uint32_t*)(table + (size_t)rec_of[k] * CTL_FIN_REC_BYTES + 128);      // the slot's first counter set
+                    bf.count = fo.l[0]; bf.accumulate = fo.i[1];
+                    rc = ctl_bwd_reduce_fin(op.i[0], CF(0), CF(1), CF(2), CF(3), CF(4), op.f[0], op.l[0], op.i[1], F(5), NG(op.i[2]), (uint32_t)op.i[25], &bf, stream);
+                } else {
+                    rc = ctl_bwd_reduce_dt(op.i[0], CF(0), CF(1), CF(2), CF(3), CF(4), op.f[0], op.l[0], op.i[1], F(5), NG(op.i[2]), (uint32_t)op.i[25], stream);
+                }
                 break;
             case CTL_OP_BN_BWD_FINALIZE:
                 rc = ctl_bn_bwd_finalize(CF(0), op.i[0], op.l[0], CF(1), CF(2), CF(3), F(4), F(5), F(6), op.i[1], NG(op.i[2]), op.i[3], stream);

@@ -44,6 +44,7 @@ PHASE_CONVS = os.environ.get("CTL_PHASE_CONVS", "1") != "0"     # 2x2 phase form
 FUSE_BNBWD = os.environ.get("CTL_FUSE_BNBWD", "0") == "1"   # BN1-backward reduction inside the dgrad conv epilogue (measured: no gain)
 CONV_WORDS = _ffi.CONV_DTYPE.itemsize // 4      # ctl_conv as int32 words at the head of ctl_op.i
 ALIGN_F = 64            # floats (256 B)
+FIN_HEADER = _ffi.FIN_HEADER_BYTES      # head of every plan scratch buffer: fused-finalize record table (ctl_hip.h)
 
 T = namedtuple("T", "ref n h w c b16", defaults=(False,))     # tensor descriptor: ref = (slot, byte offset), NHWC dims, bf16 storage?
 
@@ -169,8 +170,9 @@ class PlanBuilder:
             op["off"][idx] = ref[1]
 
     def scr(self, *nbytes):
-        """Transient scratch (valid until the next op that asks for scratch)."""
-        refs, off = [], 0
+        """Transient scratch (valid until the next op that asks for scratch).  The first FIN_HEADER bytes of the scratch buffer are the
+        fused-finalize record table (arrival counters + arguments, ctl_hip.h): zero at allocation, never handed out."""
+        refs, off = [], FIN_HEADER
         for nb in nbytes:
             refs.append((S_SCR, off))
             off += _rup(int(nb), 256)
@@ -292,6 +294,7 @@ class PlanBuilder:
             return co
         op = self.op(_ffi.OP_BN_FINALIZE)
         op["i"][0], op["i"][1], op["i"][2], op["i"][3] = blocks, c, 1 if mode == "A" else 0, G
+        op["i"][4] = 1                 # may be folded into the conv that wrote `stats_ref` (the op directly in front), see ctl_plan.cpp
         op["l"][0] = count
         op["f"][0], op["f"][1] = EPS, MOMENTUM
         for idx, ref in enumerate([stats_ref, self.P(bn.g_off), self.P(bn.b_off), (S_B, 4 * bn.rm_off),
@@ -329,6 +332,7 @@ class PlanBuilder:
             self.set_t(op, idx, ref)
         op = self.op(_ffi.OP_BN_BWD_FINALIZE)
         op["i"][0], op["i"][1], op["i"][2] = c, 0, G
+        op["i"][4] = 1                 # may be folded into the reduction in front of it
         op["l"][0] = pixels // G
         for idx, ref in enumerate([part, self.P(bn.g_off), co["mean"], co["invstd"], coef,
                                    self.G(bn.g_off) if affine_grad else None, self.G(bn.b_off) if affine_grad else None]):
@@ -652,8 +656,8 @@ class CtlNet(nn.Module):
             if self._scr is None:
                 self._scr = {}
             scr = self._scr.get(stream.cuda_stream)
-            if scr is None or scr.numel() < plan.scr_bytes:
-                scr = self._scr[stream.cuda_stream] = torch.empty(plan.scr_bytes, dtype=torch.uint8, device=self.device)
+            if scr is None or scr.numel() < plan.scr_bytes:      # zeros: the head of the buffer holds the fused-finalize arrival counters
+                scr = self._scr[stream.cuda_stream] = torch.zeros(plan.scr_bytes, dtype=torch.uint8, device=self.device)
             tensors = dict(tensors)
             tensors[S_SCR] = scr
         if plan.table_np is not None:

@@ -136,7 +136,44 @@ int ctl_bn_eval_coeffs(int32_t c, const float* gamma, const float* beta, const f
 int ctl_bn_act(const float* x, const float* scale, const float* shift, float slope, float* y, int64_t pixels,
                int32_t c, int32_t groups, ctl_stream stream);
 
-/* backward helpers; `partial` buffers are [CTL_RED_BLOCKS][2][c] floats */
+/* Fused finalize: the block of the PRODUCING kernel that arrives last at a device-scope counter turns the statistics partials
+ * into the BatchNorm coefficients in the same launch (what ctl_bn_finalize / ctl_bn_bwd_finalize do in a launch of their own: one
+ * kernel and one kernel boundary less per BatchNorm layer and direction).
+ * Forward: the arguments live in a DEVICE table of CTL_FIN_REC_BYTES-byte slots (one 128-byte line of arguments + the arrival
+ * counters: per block row of output-channel tiles 9 lines -- a top counter and 8 shards, each on a line of its own) so that the
+ * convolution kernels take a single pointer.  The table memory must be zero before its first use; ctl_bn_fin_table_write (one tiny
+ * launch for up to 16 records) fills the argument part of slots [0, n) and never touches the counters, every convolution launch
+ * leaves its counters zero.  ctl_conv_forward_fin(..., fin_rec = table + i * CTL_FIN_REC_BYTES, ...); supported while the launch has
+ * at most CTL_FIN_MAX_Y block rows of output-channel tiles (cout <= 64 always qualifies). */
+#define CTL_FIN_MAX_Y 4
+#define CTL_FIN_REC_BYTES (128 + CTL_FIN_MAX_Y * 9 * 128)
+#define CTL_FIN_MAX_RECS 85                              /* per plan */
+#define CTL_FIN_HEADER_BYTES (CTL_FIN_MAX_RECS * CTL_FIN_REC_BYTES)      /* head of the scratch buffer of a plan (402,560 bytes) */
+typedef struct ctl_bn_fin {
+    const float *gamma, *beta;
+    float *running_mean, *running_var;
+    int64_t* num_batches_tracked;
+    float *scale, *shift, *save_mean, *save_invstd;      /* [groups][c] each */
+    int64_t count;                                       /* pixels of ONE group */
+    float eps, momentum;
+    int32_t update_running, reserved;
+} ctl_bn_fin;
+int ctl_bn_fin_table_write(void* table, const ctl_bn_fin* recs, int32_t n, ctl_stream stream);
+/* ctl_conv_forward with CTL_EPI_STATS + the BatchNorm finalize of its output (fin_rec == NULL: plain ctl_conv_forward) */
+int ctl_conv_forward_fin(const ctl_conv* d, const float* x, const float* wpack, const float* bias,
+                         const float* pro_scale, const float* pro_shift, const float* res,
+                         const float* res_scale, const float* res_shift, float* y, float* stats_partial,
+                         void* fin_rec, ctl_stream stream);
+/* Backward: arguments by value; `counter`: 9 zero 128-byte lines of device memory (sharded arrival counters, left zero by the launch). */
+typedef struct ctl_bnb_fin {
+    const float *gamma, *save_mean, *save_invstd;
+    float *coef, *dgamma, *dbeta;                        /* coef [groups][3][c]; dgamma / dbeta may be NULL */
+    uint32_t* counter;
+    int64_t count;                                       /* pixels of ONE group */
+    int32_t accumulate, reserved;
+} ctl_bnb_fin;
+
+/* backward helpers; `partial` buffers are [groups][rows][2][c] floats, rows = ctl_bwd_reduce_rows() <= CTL_RED_BLOCKS */
 #define CTL_RED_BLOCKS 512
 /* mode 0 (residual tail, encdec.py:64,344): g = dout * leaky'(out);        sums: sum g, sum g*v
  * mode 1 (BN->act tail):                    g = da * leaky'(u*scale+shift); sums: sum g, sum g*u
@@ -144,6 +181,13 @@ int ctl_bn_act(const float* x, const float* scale, const float* shift, float slo
 int ctl_bwd_reduce(int32_t mode, const float* dy, const float* act_src, const float* bn_src, const float* scale,
                    const float* shift, float slope, int64_t pixels, int32_t c, float* partial, int32_t groups,
                    ctl_stream stream);
+/* the same with per-tensor storage flags (bf16_mask bit k: k-th tensor argument is stored as bf16) and, with `fin`, the fused
+ * ctl_bn_bwd_finalize (modes 0 / 1).  Rows of `partial` per group: min(CTL_RED_BLOCKS, max(16, ceil(quads per group / 2048))). */
+/* rows per group that ctl_bwd_reduce* writes for this problem (<= CTL_RED_BLOCKS) */
+int ctl_bwd_reduce_rows(int32_t mode, int64_t pixels_per_group, int32_t c);
+int ctl_bwd_reduce_fin(int32_t mode, const float* dy, const float* act_src, const float* bn_src, const float* scale,
+                       const float* shift, float slope, int64_t pixels, int32_t c, float* partial, int32_t groups,
+                       uint32_t bf16_mask, const ctl_bnb_fin* fin, ctl_stream stream);
 /* partial -> coefficients A,B,C with dx = A*g + B*bn_src + C (training-mode BN backward), and, if dgamma/dbeta
  * are non-NULL, dgamma += sum g*xhat, dbeta += sum g (accumulate ? += : =). */
 /* `blocks` = rows per group of `partial` (0 = CTL_RED_BLOCKS, i.e. written by ctl_bwd_reduce; a conv with CTL_EPI_BNBWD
@@ -273,6 +317,8 @@ int ctl_adam_dev(float* p, const float* g, float* m, float* v, int64_t count, fl
                  float eps, const int64_t* state, float grad_scale, ctl_stream stream);
 
 /* ------------------------------------------------------------------------------------------------ plans
+ * (Fused finalizes in plans: a BN_FINALIZE / BN_BWD_FINALIZE op with i[4] == 1 that directly follows the op writing its partial rows is
+ * folded into that producer; the buffer behind the partial slot must then begin with CTL_FIN_HEADER_BYTES of header, zero at first use.)
  * A plan is an array of ctl_op executed in order on one stream: one C call per network pass (the Python host builds
  * it once per (network, shape, mode)).  Tensor arguments are (slot, byte offset) pairs resolved against `bases`. */
 enum ctl_op_kind {

@@ -1,12 +1,23 @@
 #!/bin/bash
-# usage: tools/build_variant.sh NAME "-DCTL_LB_MID=2 ..."   -> csrc/variants/libctl_NAME.so (A/B builds; load with CTL_HIP_LIB)
+# usage: tools/build_variant.sh NAME "-DCTL_LB_MID=2 ..." [file.hip ...]   -> csrc/variants/libctl_NAME.so (A/B builds; load with CTL_HIP_LIB)
+# With a file list only those sources are recompiled with the flags; the other objects come from the default build (csrc/build/).
 set -e
 cd "$(dirname "$0")/../cooperative_training_and_latent_space_data_augmentation_amd/csrc"
-mkdir -p variants/obj_$1
-F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-gpu-rdc -Wall -Wno-unused-function -I../../include -I. $2"
-for s in ctl_conv.hip ctl_elem.hip ctl_mask.hip ctl_io.hip; do /opt/rocm/bin/hipcc $F -c $s -o variants/obj_$1/$s.o & done
-/opt/rocm/bin/hipcc $F -x hip -c ctl_plan.cpp -o variants/obj_$1/ctl_plan.o &
+name=$1; flags=$2; shift; shift
+all="ctl_conv.hip ctl_conv_bf16.hip ctl_elem.hip ctl_mask.hip ctl_io.hip ctl_plan.cpp"
+files=${*:-$all}
+mkdir -p variants/obj_$name
+F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-gpu-rdc -Wall -Wno-unused-function -I../../include -I. $flags"
+objs=""
+for s in $all; do
+  if echo " $files " | grep -q " $s "; then
+    /opt/rocm/bin/hipcc $F -x hip -c $s -o variants/obj_$name/$s.o 2> variants/obj_$name/$s.log &
+    objs="$objs variants/obj_$name/$s.o"
+  else
+    objs="$objs build/$s.o"
+  fi
+done
 wait
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o variants/libctl_$1.so variants/obj_$1/*.o
-rm -rf variants/obj_$1
-echo built variants/libctl_$1.so
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o variants/libctl_$name.so $objs
+rm -rf variants/obj_$name
+echo built variants/libctl_$name.so
