@@ -41,13 +41,19 @@ __device__ __forceinline__ u32x2 ctl_bload2u(__amdgpu_buffer_rsrc_t r, int voff,
 }
 
 // Staging of one 16-channel chunk of the (virtual) input tile: a unit = 8 channels of a pixel = 16 B of bf16 in LDS.
-template <int KS, int S, int MODE, int MT, int TW>
+// PLANAR: the LDS image is two planes [channels 0-7 | channels 8-15] of [row][col][8 ch] = 16 B per pixel and plane.  A B-operand
+// read (16 lanes = 16 consecutive pixels x 16 B) then covers 256 contiguous bytes = every bank once; in the interleaved [pixel][16 ch]
+// image the same read strides 32 B and hits half the banks twice (2-way conflict on every operand read: measured ~10 of the 17.5 us of
+// the 16->16 layer at 256^2).  The second plane starts 128 B past a multiple of 256 B so that a staging write (8 pixels x 2 planes per
+// 16 lanes) is conflict-free too.  The weight-gradient kernel keeps the interleaved image (its transposed reads want pixel rows).
+template <int KS, int S, int MODE, int MT, int TW, bool X16C = false, bool PLANAR = false>      // X16C: the source is known to be stored as bf16
 struct XStage16 {
     using G = Geom<KS, S, MT, TW>;
     static constexpr int UNITS = G::IH * G::IW * 2;
     static constexpr int NU = (UNITS + 255) / 256;
     static constexpr int PADH = (G::PAD + 1) >> 1;
-    static constexpr int XT_BYTES = G::IH * G::IWP * 32;
+    static constexpr int PLANE = ((G::IH * G::IWP * 16 + 255) / 256) * 256 + 128;
+    static constexpr int XT_BYTES = PLANAR ? 2 * PLANE : G::IH * G::IWP * 32;
     int rel[NU];        // byte offset of the unit's first source element relative to the tile's source origin
     int rc[NU];         // r | c << 16 (tile-relative virtual coordinates); 0x7fff7fff past the tile
     int lds[NU];        // LDS byte offset; units past the tile write a dump slot behind the image
@@ -58,7 +64,7 @@ struct XStage16 {
 
     __device__ __forceinline__ void init(const ctl_conv& d) {
         const int tid = threadIdx.x, h = tid & 1;
-        x16 = (d.dt & CTL_DT_X16) != 0;
+        x16 = X16C || (d.dt & CTL_DT_X16) != 0;
         const int esz = x16 ? 2 : 4;
 #pragma unroll
         for (int i = 0; i < NU; ++i) {
@@ -71,7 +77,7 @@ struct XStage16 {
             const int cc = (MODE == CTL_IN_PLAIN) ? c : (((c - G::PAD) >> 1) + PADH);
             rel[i] = in ? ((rr * d.win + cc) * d.cin + h * 8) * esz : CTL_OOB;
             rc[i] = in ? (r | (c << 16)) : 0x7fff7fff;
-            lds[i] = in ? ((r * G::IWP + G::ldscol(c)) * 32 + h * 16) : XT_BYTES;
+            lds[i] = in ? (PLANAR ? (h * PLANE + (r * G::IWP + G::ldscol(c)) * 16) : ((r * G::IWP + G::ldscol(c)) * 32 + h * 16)) : XT_BYTES;
         }
         vmask = 0;
         all_in = false;
@@ -164,6 +170,38 @@ struct XStage16 {
 
 #define NFRAG_OF(KS) (((KS) * (KS) + 1) / 2)
 
+// Phase timers (variant builds only: tools/build_variant.sh tm16 "-DCTL_TIMING16" ctl_conv_bf16.hip; read with ctl_debug_timing16):
+// s_memtime deltas summed over every wave: [0] prefetch issue, [1] MFMA loop, [2] barrier after the reads, [3] staging (vmcnt wait +
+// prologue + ds_write), [4] barrier after the writes, [5] epilogue, [6] steps, [7] setup, [8] wave span, [9] realtime span (100 MHz)
+#ifdef CTL_TIMING16
+#define CTL_TM_WAVES 65536
+__device__ unsigned long long ctl_tm16[CTL_TM_WAVES][10];
+#define TM_DECL unsigned long long tm_prev = __builtin_amdgcn_s_memtime(), tm_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; \
+                const unsigned long long tm_t0 = tm_prev, tm_r0 = __builtin_amdgcn_s_memrealtime();
+#define TM(i) { const unsigned long long tm_now = __builtin_amdgcn_s_memtime(); tm_acc[i] += tm_now - tm_prev; tm_prev = tm_now; }
+#define TM_COUNT(i) { tm_acc[i] += 1; }
+#define TM_FLUSH { const unsigned w_ = ((blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 4 + (threadIdx.x >> 6)) % CTL_TM_WAVES; \
+                   tm_acc[8] = __builtin_amdgcn_s_memtime() - tm_t0; tm_acc[9] = __builtin_amdgcn_s_memrealtime() - tm_r0; \
+                   if ((threadIdx.x & 63) == 0) { _Pragma("unroll") for (int i_ = 0; i_ < 10; ++i_) ctl_tm16[w_][i_] += tm_acc[i_]; } }
+extern "C" int ctl_debug_timing16(unsigned long long* out12) {
+    static unsigned long long host[CTL_TM_WAVES][10];
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(ctl_tm16), sizeof(host)) != hipSuccess) return -1;
+    for (int i = 0; i < 12; ++i) out12[i] = 0;       // [10] max span over waves, [11] number of waves that ran
+    for (int w = 0; w < CTL_TM_WAVES; ++w) {
+        for (int i = 0; i < 10; ++i) out12[i] += host[w][i];
+        if (host[w][8] > out12[10]) out12[10] = host[w][8];
+        if (host[w][8]) out12[11] += 1;
+    }
+    for (int w = 0; w < CTL_TM_WAVES; ++w) for (int i = 0; i < 10; ++i) host[w][i] = 0;
+    return hipMemcpyToSymbol(HIP_SYMBOL(ctl_tm16), host, sizeof(host)) == hipSuccess ? 0 : -1;
+}
+#else
+#define TM_DECL
+#define TM(i)
+#define TM_COUNT(i)
+#define TM_FLUSH
+#endif
+
 // resident blocks per CU the register allocation aims for (HBM-bound kernels: tiles in flight per CU is what hides the latency)
 #ifndef CTL16_OCC_BIG
 #define CTL16_OCC_BIG 2
@@ -171,14 +209,19 @@ struct XStage16 {
 #ifndef CTL16_OCC
 #define CTL16_OCC 3
 #endif
-template <int KS, int S, int MODE, int MT, int TW, int NT>
+// FAST: the instantiation for the layers that carry the step -- bf16 in, bf16 out, whole 16-channel tiles on both sides, no residual /
+// accumulate operand, no activation (every 3x3 / 2x2 / 4x4 forward conv with statistics and every plain data gradient).  With those known
+// at compile time the epilogue is straight-line code (the generic one decides per fragment between fp32 / bf16 / 1-channel forms of
+// three optional operands: ~3700 cycles per tile and wave of scalar branches, measured with the phase timers) and the staging loses
+// the fp32-source half of its registers.
+template <int KS, int S, int MODE, int MT, int TW, int NT, bool FAST>
 __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? CTL16_OCC_BIG : CTL16_OCC) void conv_igemm_bf16_kernel(
     const ctl_conv d, const void* __restrict__ x, const void* __restrict__ wpack, const float* __restrict__ bias,
     const float* __restrict__ pro_scale, const float* __restrict__ pro_shift, const void* __restrict__ res,
     const float* __restrict__ res_scale, const float* __restrict__ res_shift, void* __restrict__ y, float* __restrict__ stats_partial,
     int tiles_h, int tiles_w, int G_chunks, int64_t wpack_sub_bytes, int ntiles, ctl_bn_rec* __restrict__ rec) {
     using G = Geom<KS, S, MT, TW>;
-    using XS = XStage16<KS, S, MODE, MT, TW>;
+    using XS = XStage16<KS, S, MODE, MT, TW, FAST, true>;
     constexpr int TAPS = KS * KS;
     constexpr int NFRAG = NFRAG_OF(KS);
     constexpr int XT_ALLOC = XS::XT_BYTES + 16;            // + dump slot
@@ -206,13 +249,13 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? CTL16_OCC_BIG : CT
     const unsigned char* wp = reinterpret_cast<const unsigned char*>(wpack) + (int64_t)z * wpack_sub_bytes;
     const int my_tiles = (bid0 < t_hi) ? (t_hi - bid0 + nb - 1) / nb : 0;
     const int total_it = my_tiles * G_chunks;
-    const int flags = d.epi_flags;
-    const bool y16 = (d.dt & CTL_DT_Y16) != 0, r16 = (d.dt & CTL_DT_RES16) != 0;
+    const int flags = FAST ? (d.epi_flags & (CTL_EPI_BIAS | CTL_EPI_STATS)) : d.epi_flags;
+    const bool y16 = FAST || (d.dt & CTL_DT_Y16) != 0, r16 = (d.dt & CTL_DT_RES16) != 0;
     const int yes = y16 ? 2 : 4, res_es = r16 ? 2 : 4;
     const int ngroups = d.groups > 1 ? d.groups : 1;
     const int group_n = d.n / ngroups;
     const int oy0 = (z >> 1) * d.out_sub, ox0 = (z & 1) * d.out_sub;
-    const __amdgpu_buffer_rsrc_t rx = ctl_rsrc(x, (int64_t)d.n * d.hin * d.win * d.cin * ((d.dt & CTL_DT_X16) ? 2 : 4));
+    const __amdgpu_buffer_rsrc_t rx = ctl_rsrc(x, (int64_t)d.n * d.hin * d.win * d.cin * ((FAST || (d.dt & CTL_DT_X16)) ? 2 : 4));
     const int64_t ypix = (int64_t)d.n * d.out_h * d.out_w * d.cout;
     const __amdgpu_buffer_rsrc_t ry = ctl_rsrc(y, ypix * yes);
     const __amdgpu_buffer_rsrc_t rres = ctl_rsrc(res ? res : y, ypix * (res ? res_es : yes));
@@ -249,7 +292,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? CTL16_OCC_BIG : CT
         tap = tap < TAPS ? tap : TAPS - 1;
         const int kh = tap / KS, kw = tap % KS;
         const int kcol = (S == 2) ? ((kw & 1) * G::IWH + (kw >> 1)) : kw;
-        xoff[f] = (((wrow * S + kh) * G::IWP + p + kcol) * 32) + (q & 1) * 16;
+        xoff[f] = (((wrow * S + kh) * G::IWP + p + kcol) * 16) + (q & 1) * XS::PLANE;
     }
     const unsigned char* wrd = wt + lane * 16;
 
@@ -285,6 +328,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? CTL16_OCC_BIG : CT
     TileWalk cur, nxt;
     cur.init(bid0, nb, tiles_h, tiles_w);
     nxt = cur;
+    TM_DECL
     if (total_it > 0) {
         xs.load(rx, d, cur.n, cur.th * G::TH, cur.tw * TW, 0);
         wload(0);
@@ -299,6 +343,17 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? CTL16_OCC_BIG : CT
     }
     __syncthreads();
 
+    // One 16-channel chunk (cin <= 16): the block's weight fragments never change -> read them from LDS ONCE into registers
+    // (5 fragments x 4 VGPRs per cout tile for a 3x3 kernel) instead of once per tile.
+    constexpr bool WREG = (NFRAG * NT <= 10);
+    const bool wreg_on = WREG && G_chunks == 1;
+    bf16x8 wreg[WREG ? NFRAG : 1][WREG ? NT : 1];
+    if (wreg_on) {
+#pragma unroll
+        for (int f = 0; f < (WREG ? NFRAG : 1); ++f)
+#pragma unroll
+            for (int t = 0; t < (WREG ? NT : 1); ++t) wreg[f][t] = *reinterpret_cast<const bf16x8*>(wrd + (f * NT + t) * 1024);
+    }
     const int srows = gridDim.x * gridDim.z, srow = z * gridDim.x + blockIdx.x;
     auto flush_stats = [&](int grp) {
 #pragma unroll
@@ -337,8 +392,10 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? CTL16_OCC_BIG : CT
             for (int gi = 0; gi < ngroups; ++gi) ctl_store_wt(stats_partial + (((int64_t)gi * srows + srow) * 2 + stat) * d.cout + co, 0.f);
     }
 
+    TM(7)
     f32x4 acc[MT][NT];
     for (int it = 0, g = 0; it < total_it; ++it) {
+        TM_COUNT(6)
         const int n = cur.n, ho0 = cur.th * G::TH, wo0 = cur.tw * TW;
         const bool has_next = it + 1 < total_it;
         const int g2 = (g + 1 == G_chunks) ? 0 : g + 1;
@@ -348,31 +405,74 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? CTL16_OCC_BIG : CT
             xs.load(rx, d, nxt.n, nxt.th * G::TH, nxt.tw * TW, g2);
             if (new_w) wload(g2);
         }
+        TM(0)
         if (g == 0) {
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int t = 0; t < NT; ++t) acc[m][t] = bias4[t];
         }
+        // operands of fragment f+1 are requested before the MFMAs of fragment f; two instances of the phase: weights from the
+        // block's registers (single-chunk problems) or from LDS -- a branch once per tile, not a select per operand
+        auto mfma_phase = [&](auto wreg_tag) {
+            constexpr bool WR = decltype(wreg_tag)::value;
+            // PF fragments of B operands are requested ahead of the MFMAs that consume them: with 16-cycle bf16 MFMAs one fragment of
+            // work (MT x NT x 16 cycles) is shorter than an LDS round trip, so a read-ahead of one (the fp32 kernels' scheme) leaves
+            // the latency exposed at every fragment (phase timers: 1430 cycles for 20 MFMAs = 320 cycles of matrix pipe)
+            // (the scheduler sinks every read back to its use -- ds_read, s_waitcnt lgkmcnt(0), v_mfma, 20 times over, seen in the ISA --
+            // unless scheduling barriers pin the read-ahead)
+#ifndef CTL16_PF
+#define CTL16_PF 2
+#endif
+            constexpr int PF = (CTL16_PF > NFRAG) ? NFRAG : CTL16_PF;
+            constexpr bool PIN = S == 1 && KS != 4 && (NT == 1 || MT == 1);      // (the other instantiations have no registers to spare: 30-110 spills)
+            bf16x8 wf[PF][NT], xf[PF][MT];
+            auto lds_operands = [&](int f) {
+                const int b = f % PF;
+                if constexpr (!WR) {
 #pragma unroll
-        for (int f = 0; f < NFRAG; ++f) {
-            bf16x8 wf[NT], xf[MT];
+                    for (int t = 0; t < NT; ++t) wf[b][t] = *reinterpret_cast<const bf16x8*>(wrd + (f * NT + t) * 1024);
+                }
 #pragma unroll
-            for (int t = 0; t < NT; ++t) wf[t] = *reinterpret_cast<const bf16x8*>(wrd + (f * NT + t) * 1024);
+                for (int m = 0; m < MT; ++m)
+                    xf[b][m] = *reinterpret_cast<const bf16x8*>(xt + xoff[f] + (((m / TWT) * S) * G::IWP + (m % TWT) * 16) * 16);
+            };
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
-                xf[m] = *reinterpret_cast<const bf16x8*>(xt + xoff[f] + (((m / TWT) * S) * G::IWP + (m % TWT) * 16) * 32);
+            for (int f = 0; f < PF - 1 && f < NFRAG; ++f) lds_operands(f);
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
+            for (int f = 0; f < NFRAG; ++f) {
+                const int b = f % PF;
+                if (f + PF - 1 < NFRAG) lds_operands(f + PF - 1);
+                // pin: the wait for fragment f's operands comes AFTER the requests above (left alone, the scheduler sinks every read to
+                // its use: ds_read, s_waitcnt lgkmcnt(0), v_mfma, 20 times per tile = 1430 cycles for 320 cycles of matrix work).  The
+                // empty asm "rewrites" the operands, so the MFMAs depend on it, and its memory clobber keeps the reads above it.
 #pragma unroll
-                for (int t = 0; t < NT; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t], xf[m], acc[m][t], 0, 0, 0);
+                for (int m = 0; m < MT; ++m) { if constexpr (PIN) asm volatile("" : "+v"(xf[b][m]) : : "memory"); }
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        if constexpr (WR) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[WREG ? f : 0][WREG ? t : 0], xf[b][m], acc[m][t], 0, 0, 0);
+                        else acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[b][t], xf[b][m], acc[m][t], 0, 0, 0);
+                    }
+            }
+        };
+        if constexpr (WREG) {
+            if (wreg_on) mfma_phase(std::true_type{});
+            else mfma_phase(std::false_type{});
+        } else {
+            mfma_phase(std::false_type{});
         }
+        TM(1)
         ctl_barrier_lds_reads_done();
+        TM(2)
         if (has_next) {
             xs.store(xt, d, g2, cf_scale, cf_shift, (nxt.n / group_n) * d.cin);
             if (new_w) wstore();
         }
+        TM(3)
         ctl_barrier_lds_writes_done();
+        TM(4)
 
         if (g == G_chunks - 1) {
             const int grp = n / group_n;
@@ -382,6 +482,38 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? CTL16_OCC_BIG : CT
             }
             const int ybase = ((n * d.out_h + ho0 * d.out_sy + oy0) * d.out_w + wo0 * d.out_sx + ox0) * d.cout + cot0 * 16;      // elements
             const bool full = ho0 + G::TH <= d.hout && wo0 + TW <= d.wout && (cot0 + NT) * 16 <= d.cout;
+            if constexpr (FAST) {
+                // lane (p, q) holds channels 4q .. 4q+3 of pixel p of each M-tile: 8 bytes of bf16 per fragment; nothing is read back,
+                // nothing branches per fragment; ragged tiles send the dropped lanes to CTL_OOB (hardware bounds check)
+                if (full) {
+                    if (flags & CTL_EPI_STATS) {
+                        asm volatile("" ::: "memory");                  // keeps the branch (not a select per element)
+#pragma unroll
+                        for (int t = 0; t < NT; ++t)
+#pragma unroll
+                            for (int m = 0; m < MT; ++m) { ssum[t] += acc[m][t]; ssq[t] += acc[m][t] * acc[m][t]; }
+                    }
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int m = 0; m < MT; ++m)
+                            __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack_bf16x2(acc[m][t].x, acc[m][t].y), pack_bf16x2(acc[m][t].z, acc[m][t].w)},
+                                                                  ry, (ybase + yrel[m] + t * 16) * 2, 0, CTL_STORE_AUX);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const bool cok = (cot0 + t) * 16 + q * 4 < d.cout;
+#pragma unroll
+                        for (int m = 0; m < MT; ++m) {
+                            const bool pv = (ho0 + wrow + m / TWT < d.hout) && (wo0 + (m % TWT) * 16 + p < d.wout);
+                            const f32x4 v = acc[m][t];
+                            if ((flags & CTL_EPI_STATS) && pv) { ssum[t] += v; ssq[t] += v * v; }
+                            const int bo = (pv && cok) ? (ybase + yrel[m] + t * 16) * 2 : CTL_OOB;
+                            __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)}, ry, bo, 0, CTL_STORE_AUX);
+                        }
+                    }
+                }
+            } else {
             auto load4 = [&](__amdgpu_buffer_rsrc_t r, int eoff, bool b16) -> f32x4 {      // 4 channels at element offset eoff (or OOB)
                 if (eoff == CTL_OOB) return f32x4{0.f, 0.f, 0.f, 0.f};
                 if (b16) { const u32x2 u = ctl_bload2u(r, eoff * 2, 0); return unpack_bf16x4(u.x, u.y); }
@@ -431,10 +563,13 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? CTL16_OCC_BIG : CT
                     }
                 }
             }
+            }      // generic epilogue
         }
+        TM(5)
         if (g2 == 0) cur = nxt;
         g = g2;
     }
+    TM_FLUSH
     if (flags & CTL_EPI_STATS) {
         flush_stats(cur_grp);
         if (rec != nullptr)               // fused BatchNorm finalize by the last-arriving block of this output-channel range
@@ -523,12 +658,12 @@ struct conv16_call {
     hipStream_t stream; bool query; int grid_x;
     ctl_bn_rec* rec;
 };
-template <int KS, int S, int MODE, int MT, int TW, int NT>
-static void conv16_go(conv16_call& a) {
+template <int KS, int S, int MODE, int MT, int TW, int NT, bool FAST>
+static void conv16_go_f(conv16_call& a) {
     static int occ = 0;
     if (!occ) {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_igemm_bf16_kernel<KS, S, MODE, MT, TW, NT>, 256, 0) != hipSuccess || n < 1) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_igemm_bf16_kernel<KS, S, MODE, MT, TW, NT, FAST>, 256, 0) != hipSuccess || n < 1) {
             (void)hipGetLastError();
             n = 2;
         }
@@ -539,9 +674,18 @@ static void conv16_go(conv16_call& a) {
     a.grid_x = ctl_conv_grid_x(ntiles, (a.c.cot / NT) * d->nsub, occ);
     if (a.query) return;
     const dim3 grid((unsigned)a.grid_x, (unsigned)(a.c.cot / NT), (unsigned)d->nsub);
-    conv_igemm_bf16_kernel<KS, S, MODE, MT, TW, NT><<<grid, dim3(256), 0, a.stream>>>(
+    conv_igemm_bf16_kernel<KS, S, MODE, MT, TW, NT, FAST><<<grid, dim3(256), 0, a.stream>>>(
         *d, a.x, a.wpack, a.bias, a.pro_scale, a.pro_shift, a.res, a.res_scale, a.res_shift, a.y, a.stats_partial, a.c.tiles_h, a.c.tiles_w,
         a.c.g, (int64_t)ctl_conv_wpack_floats(d->cin, d->cout, d->ks) * 4, ntiles, a.rec);
+}
+template <int KS, int S, int MODE, int MT, int TW, int NT>
+static void conv16_go(conv16_call& a) {
+    const ctl_conv* d = a.d;
+    // the FAST instantiation (see the kernel): bf16 on both sides, whole channel tiles, nothing but bias / statistics in the epilogue
+    const bool fast = (d->dt & CTL_DT_X16) && (d->dt & CTL_DT_Y16) && d->cin % 16 == 0 && d->cout % 16 == 0 && d->epi_act == CTL_ACT_NONE &&
+                      !(d->epi_flags & (CTL_EPI_RES | CTL_EPI_ACCUM | CTL_EPI_BNBWD));
+    if (fast) conv16_go_f<KS, S, MODE, MT, TW, NT, true>(a);
+    else conv16_go_f<KS, S, MODE, MT, TW, NT, false>(a);
 }
 template <int KS, int S, int MODE>
 static void conv16_go_tile(conv16_call& a) {

@@ -52,9 +52,27 @@ def main():
         run = lambda: check(lib.ctl_conv_forward(dp, x.data_ptr(), wp.data_ptr(), b.data_ptr(), sc.data_ptr() if pro else None,
                                                  sh.data_ptr() if pro else None, None, None, None, y.data_ptr(),
                                                  st.data_ptr() if stats else None, ops.stream_ptr()))
+        has_tm = hasattr(lib, "ctl_debug_timing16")           # -DCTL_TIMING16 variant build
+        import ctypes as C
+        tm = (C.c_ulonglong * 12)()
+        if has_tm:
+            for _ in range(3):
+                run()
+            torch.cuda.synchronize()
+            lib.ctl_debug_timing16(tm)                         # reset
         us = timed(run)
         nbytes = 2.0 * (x.numel() + y.numel())
         res[name] = {"us": round(us, 1), "GBs": round(nbytes / us / 1e3), "hbm_frac": round(nbytes / us / 1e3 / 8000, 3)}
+        if has_tm:
+            lib.ctl_debug_timing16(tm)
+            steps = max(tm[6], 1)
+            names = ["issue", "mfma", "bar_rd", "stage", "bar_wr", "epi"]
+            res[name]["phase_cycles_per_step"] = {k: round(tm[i] / steps) for i, k in enumerate(names)}
+            res[name]["setup_per_step"] = round(tm[7] / steps)
+            res[name]["steps_per_wave"] = round(steps / max(tm[11], 1), 2)
+            mhz = 100.0 * tm[8] / max(tm[9], 1)
+            res[name]["memtime_MHz"] = round(mhz, 1)
+            res[name]["wave_span_us"] = {"mean": round(tm[9] / max(tm[11], 1) / 30 / 100.0, 1), "max": round(tm[10] / 30 / mhz, 1)}
     # the BatchNorm-backward element-wise passes on bf16 tensors (16 ch, 256^2): reduce (2 reads), apply (2 reads + 1 write)
     c, hw = 16, 256 * 256
     dy = torch.randn(N, c, 256, 256, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
@@ -72,7 +90,7 @@ def main():
     nb = 2.0 * 3 * dy.numel()
     res["bwd_apply<1> 16ch@256"] = {"us": round(us, 1), "GBs": round(nb / us / 1e3), "hbm_frac": round(nb / us / 1e3 / 8000, 3)}
     for k, v in res.items():
-        print(f"  {k:28s} {v['us']:8.1f} us  {v['GBs']:6d} GB/s  {v['hbm_frac']:.3f}")
+        print(f"  {k:28s} {v['us']:8.1f} us  {v['GBs']:6d} GB/s  {v['hbm_frac']:.3f}", v.get("phase_cycles_per_step", ""), v.get("setup_per_step", ""), v.get("steps_per_wave", ""), v.get("memtime_MHz", ""), v.get("wave_span_us", ""))
     print("RESULT " + json.dumps(res))
 
 
