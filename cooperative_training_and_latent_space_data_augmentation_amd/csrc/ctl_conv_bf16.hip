@@ -14,6 +14,8 @@
 // bf16 once (v_cvt_pk_bf16_f32, round-to-nearest-even) -- the rounding points of the path are: MFMA operands (activations after the
 // prologue, weights) and stored tensors; accumulation, bias, statistics, residual and activation arithmetic stay fp32.
 // With 14x fewer matrix cycles than fp32 these kernels are HBM-bound: what matters is bytes in flight, not VALU.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "ctl_conv_common.h"
@@ -214,14 +216,14 @@ extern "C" int ctl_debug_timing16(unsigned long long* out12) {
 // at compile time the epilogue is straight-line code (the generic one decides per fragment between fp32 / bf16 / 1-channel forms of
 // three optional operands: ~3700 cycles per tile and wave of scalar branches, measured with the phase timers) and the staging loses
 // the fp32-source half of its registers.
-template <int KS, int S, int MODE, int MT, int TW, int NT, bool FAST>
+template <int KS, int S, int MODE, int MT, int TW, int NT, int FAST>      // 0 generic; 1 plain; 2 + bf16 residual * scale + shift (+ LeakyReLU); 3 accumulate into y
 __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? CTL16_OCC_BIG : CTL16_OCC) void conv_igemm_bf16_kernel(
     const ctl_conv d, const void* __restrict__ x, const void* __restrict__ wpack, const float* __restrict__ bias,
     const float* __restrict__ pro_scale, const float* __restrict__ pro_shift, const void* __restrict__ res,
     const float* __restrict__ res_scale, const float* __restrict__ res_shift, void* __restrict__ y, float* __restrict__ stats_partial,
     int tiles_h, int tiles_w, int G_chunks, int64_t wpack_sub_bytes, int ntiles, ctl_bn_rec* __restrict__ rec) {
     using G = Geom<KS, S, MT, TW>;
-    using XS = XStage16<KS, S, MODE, MT, TW, FAST, true>;
+    using XS = XStage16<KS, S, MODE, MT, TW, FAST != 0, true>;
     constexpr int TAPS = KS * KS;
     constexpr int NFRAG = NFRAG_OF(KS);
     constexpr int XT_ALLOC = XS::XT_BYTES + 16;            // + dump slot
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? CTL16_OCC_BIG : CT
     const unsigned char* wp = reinterpret_cast<const unsigned char*>(wpack) + (int64_t)z * wpack_sub_bytes;
     const int my_tiles = (bid0 < t_hi) ? (t_hi - bid0 + nb - 1) / nb : 0;
     const int total_it = my_tiles * G_chunks;
-    const int flags = FAST ? (d.epi_flags & (CTL_EPI_BIAS | CTL_EPI_STATS)) : d.epi_flags;
+    const int flags = FAST == 1 ? (d.epi_flags & (CTL_EPI_BIAS | CTL_EPI_STATS)) : (FAST ? (d.epi_flags & CTL_EPI_BIAS) : d.epi_flags);
     const bool y16 = FAST || (d.dt & CTL_DT_Y16) != 0, r16 = (d.dt & CTL_DT_RES16) != 0;
     const int yes = y16 ? 2 : 4, res_es = r16 ? 2 : 4;
     const int ngroups = d.groups > 1 ? d.groups : 1;
@@ -482,7 +484,44 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? CTL16_OCC_BIG : CT
             }
             const int ybase = ((n * d.out_h + ho0 * d.out_sy + oy0) * d.out_w + wo0 * d.out_sx + ox0) * d.cout + cot0 * 16;      // elements
             const bool full = ho0 + G::TH <= d.hout && wo0 + TW <= d.wout && (cot0 + NT) * 16 <= d.cout;
-            if constexpr (FAST) {
+            if constexpr (FAST >= 2) {
+                // the residual tail  out = LeakyReLU(conv + v * scale + shift)  (FAST 2) and  y += conv  (FAST 3) on bf16 operands: the
+                // operand loads of every fragment go out first, then the arithmetic; ragged tiles use CTL_OOB offsets (loads return 0,
+                // stores are dropped)
+                f32x4 rs[NT], rh[NT];
+                if constexpr (FAST == 2) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const int co0 = (cot0 + t) * 16 + q * 4;
+                        rs[t] = *reinterpret_cast<const f32x4*>(res_scale + grp * d.cout + co0);
+                        rh[t] = *reinterpret_cast<const f32x4*>(res_shift + grp * d.cout + co0);
+                    }
+                }
+                int bo[MT];
+                u32x2 rq[MT][NT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const bool pv = full || ((ho0 + wrow + m / TWT < d.hout) && (wo0 + (m % TWT) * 16 + p < d.wout));
+                    bo[m] = pv ? (ybase + yrel[m]) * 2 : CTL_OOB;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) rq[m][t] = ctl_bload2u(FAST == 2 ? rres : ry, bo[m] == CTL_OOB ? CTL_OOB : bo[m] + t * 32, 0);
+                }
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        f32x4 v = acc[m][t];
+                        const f32x4 r = unpack_bf16x4(rq[m][t].x, rq[m][t].y);
+                        if constexpr (FAST == 2) {
+                            v += r * rs[t] + rh[t];
+                            if (d.epi_act == CTL_ACT_LEAKY) v = ctl_leaky01(v, d.epi_slope);
+                        } else {
+                            v += r;
+                        }
+                        __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)}, ry,
+                                                              bo[m] == CTL_OOB ? CTL_OOB : bo[m] + t * 32, 0, CTL_STORE_AUX);
+                    }
+            } else if constexpr (FAST == 1) {
                 // lane (p, q) holds channels 4q .. 4q+3 of pixel p of each M-tile: 8 bytes of bf16 per fragment; nothing is read back,
                 // nothing branches per fragment; ragged tiles send the dropped lanes to CTL_OOB (hardware bounds check)
                 if (full) {
@@ -658,7 +697,7 @@ struct conv16_call {
     hipStream_t stream; bool query; int grid_x;
     ctl_bn_rec* rec;
 };
-template <int KS, int S, int MODE, int MT, int TW, int NT, bool FAST>
+template <int KS, int S, int MODE, int MT, int TW, int NT, int FAST>
 static void conv16_go_f(conv16_call& a) {
     static int occ = 0;
     if (!occ) {
@@ -681,11 +720,15 @@ static void conv16_go_f(conv16_call& a) {
 template <int KS, int S, int MODE, int MT, int TW, int NT>
 static void conv16_go(conv16_call& a) {
     const ctl_conv* d = a.d;
-    // the FAST instantiation (see the kernel): bf16 on both sides, whole channel tiles, nothing but bias / statistics in the epilogue
-    const bool fast = (d->dt & CTL_DT_X16) && (d->dt & CTL_DT_Y16) && d->cin % 16 == 0 && d->cout % 16 == 0 && d->epi_act == CTL_ACT_NONE &&
-                      !(d->epi_flags & (CTL_EPI_RES | CTL_EPI_ACCUM | CTL_EPI_BNBWD));
-    if (fast) conv16_go_f<KS, S, MODE, MT, TW, NT, true>(a);
-    else conv16_go_f<KS, S, MODE, MT, TW, NT, false>(a);
+    // the FAST instantiations (see the kernel): bf16 on both sides, whole channel tiles; 1 = bias / statistics only, 2 = bf16 residual
+    // with affine (+ LeakyReLU): the tail of every residual block, 3 = accumulate into the bf16 output (the 1x1 data gradients)
+    const bool io16 = (d->dt & CTL_DT_X16) && (d->dt & CTL_DT_Y16) && d->cin % 16 == 0 && d->cout % 16 == 0;
+    const int e = d->epi_flags & (CTL_EPI_RES | CTL_EPI_ACCUM | CTL_EPI_BNBWD | CTL_EPI_STATS);
+    if (io16 && !(e & ~CTL_EPI_STATS) && d->epi_act == CTL_ACT_NONE) conv16_go_f<KS, S, MODE, MT, TW, NT, 1>(a);
+    else if (io16 && e == CTL_EPI_RES && (d->dt & CTL_DT_RES16) && (d->epi_act == CTL_ACT_NONE || d->epi_act == CTL_ACT_LEAKY))
+        conv16_go_f<KS, S, MODE, MT, TW, NT, 2>(a);
+    else if (io16 && e == CTL_EPI_ACCUM && d->epi_act == CTL_ACT_NONE) conv16_go_f<KS, S, MODE, MT, TW, NT, 3>(a);
+    else conv16_go_f<KS, S, MODE, MT, TW, NT, 0>(a);
 }
 template <int KS, int S, int MODE>
 static void conv16_go_tile(conv16_call& a) {
@@ -869,8 +912,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const ctl_conv d, 
             xs.load(rx, d, cur.n, cur.th * G::TH, cur.tw * TW, g);
             dyload(cur.n, cur.th * G::TH, cur.tw * TW);
         }
-        if (wave < KB) {                                 // (4x16 tiles: two k-blocks, waves 2 and 3 only stage)
-            const int tr = wave * 2 + krow;              // tile row of this lane group's 8 pixels
+        for (int kb = wave; kb < KB; kb += 4) {          // (4x16 tiles: two k-blocks, waves 2 and 3 only stage; 16x16 tiles: two k-blocks per wave)
+            const int tr = kb * 2 + krow;                // tile row of this lane group's 8 pixels
             bf16x8 bf[NTW];
 #pragma unroll
             for (int t = 0; t < NTW; ++t) {
@@ -881,14 +924,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const ctl_conv d, 
                 for (int j = 0; j < 8; ++j) s += (float)bf[t][j];
                 bsum[t] += s;
             }
-#pragma unroll
-            for (int tap = 0; tap < TAPS; ++tap) {
+            // the A operand of tap+1 is requested before the MFMAs of tap; the empty asm pins that order (the scheduler otherwise sinks
+            // every transposed read to its use: read, wait, MFMA, nine times per tile -- see the forward kernel)
+            auto a_operand = [&](int tap) -> bf16x8 {
                 const int kh = tap / KS, kw = tap % KS;
                 const int c0 = G::ldscol((kcol0 + qp) * S + kw);          // consecutive output columns are consecutive LDS columns (stride 2: de-interleaved)
                 const unsigned char* a0 = xt + (((tr * S + kh) * G::IWP + c0) * 32) + pp * 8;
-                const bf16x8 af = tr_read8(a0, a0 + 4 * 32);
+                return tr_read8(a0, a0 + 4 * 32);
+            };
+            bf16x8 af[2];
+            af[0] = a_operand(0);
 #pragma unroll
-                for (int t = 0; t < NTW; ++t) acc[tap][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf[t], acc[tap][t], 0, 0, 0);
+            for (int tap = 0; tap < TAPS; ++tap) {
+                if (tap + 1 < TAPS) af[(tap + 1) & 1] = a_operand(tap + 1);
+                asm volatile("" : "+v"(af[tap & 1]) : : "memory");
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) acc[tap][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tap & 1], bf[t], acc[tap][t], 0, 0, 0);
             }
         }
         ctl_barrier_lds_reads_done();
@@ -976,8 +1027,9 @@ static void wgrad16_go(wgrad16_call& a) {
         occ = n;
     }
     const int par = a.c.g * (a.c.cot / NTW);
+    static const int cap = [] { const char* e = getenv("CTL16_WGRAD_SPLITS"); return e ? atoi(e) : 1024; }();      // tuning hook (measured: 512 -> 768/1024 splits = 28.7 -> 24.5 us on the 16->16 3x3 layer at 256^2)
     int splits = (256 * (occ < 4 ? occ : 4)) / par;
-    if (splits > 512) splits = 512;
+    if (splits > cap) splits = cap;
     if (splits > a.ntiles) splits = a.ntiles;
     if (splits < 1) splits = 1;
     a.splits = splits;
@@ -988,6 +1040,9 @@ static void wgrad16_go(wgrad16_call& a) {
 }
 template <int KS, int S, int MODE>
 static void wgrad16_go_tile(wgrad16_call& a) {
+    if constexpr (S == 1 && (KS == 3 || KS == 1)) {
+        if (a.c.mt == 4) { if (a.ntw == 2) wgrad16_go<KS, S, MODE, 4, 2>(a); else wgrad16_go<KS, S, MODE, 4, 1>(a); return; }
+    }
     if (a.c.mt == 2) { if (a.ntw == 2) wgrad16_go<KS, S, MODE, 2, 2>(a); else wgrad16_go<KS, S, MODE, 2, 1>(a); }
     else { if (a.ntw == 2) wgrad16_go<KS, S, MODE, 1, 2>(a); else wgrad16_go<KS, S, MODE, 1, 1>(a); }
 }
@@ -1009,6 +1064,14 @@ static int wgrad16_pick(const ctl_conv* d, wgrad16_call* a) {
     a->d = d;
     int rc = ctl_conv_pick_cfg(d, &a->c, 1);
     if (rc != CTL_OK) return rc;
+    // With 16-cycle bf16 MFMAs a tile's matrix work (9 per wave for a 3x3 kernel) is far shorter than the load latency of the next tile,
+    // which the single-buffered loop then exposes every time: the large layers take 16x16-pixel tiles (twice the bytes in flight per
+    // block, half the barriers per byte).  Measured 16->16 at 256^2: 41.9 us with 8x16 tiles.
+    static const int big_ok = [] { const char* e = getenv("CTL16_WGRAD_MT4"); return e ? atoi(e) : 1; }();
+    if (big_ok && d->stride == 1 && d->ks == 3 && d->hout >= 64 && d->wout >= 16) {      // (1x1: 8x16 tiles measured faster)
+        a->c.mt = 4; a->c.th = 16;
+        a->c.tiles_h = ctl_cdiv(d->hout, 16);
+    }
     a->ntw = (a->c.cot >= 2 && a->c.cot % 2 == 0) ? 2 : 1;
     a->ntiles = d->n * a->c.tiles_h * a->c.tiles_w;
     a->cin_p = a->c.g * 16;

@@ -300,6 +300,154 @@ __global__ __launch_bounds__(EB) void bwd_apply_kernel(const void* __restrict__ 
     }
 }
 
+// ---- all-bf16 forms of the two BatchNorm-backward passes: 8 channels = 16 bytes per lane (the 4-channel forms above move 8 bytes per
+// lane when the tensors are bf16 -- half the bytes per memory instruction, 0.54-0.70x the 16-byte rate on this part), two octets in
+// flight per thread and tensor.  Arithmetic, rounding points and the partial-row layout are those of the quad forms.
+typedef unsigned int u32x4e __attribute__((ext_vector_type(4)));
+struct f32x8 { float v[8]; };
+__device__ __forceinline__ f32x8 unpack8(u32x4e u) {
+    f32x8 r;
+    r.v[0] = __builtin_bit_cast(float, u.x << 16); r.v[1] = __builtin_bit_cast(float, u.x & 0xffff0000u);
+    r.v[2] = __builtin_bit_cast(float, u.y << 16); r.v[3] = __builtin_bit_cast(float, u.y & 0xffff0000u);
+    r.v[4] = __builtin_bit_cast(float, u.z << 16); r.v[5] = __builtin_bit_cast(float, u.z & 0xffff0000u);
+    r.v[6] = __builtin_bit_cast(float, u.w << 16); r.v[7] = __builtin_bit_cast(float, u.w & 0xffff0000u);
+    return r;
+}
+__device__ __forceinline__ u32x4e pack8(const f32x8& a) {
+    u32x4e r;
+    r.x = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2e{a.v[0], a.v[1]}, bf16x2e));
+    r.y = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2e{a.v[2], a.v[3]}, bf16x2e));
+    r.z = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2e{a.v[4], a.v[5]}, bf16x2e));
+    r.w = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2e{a.v[6], a.v[7]}, bf16x2e));
+    return r;
+}
+__device__ __forceinline__ f32x8 load8f(const float* __restrict__ p) {      // 8 consecutive fp32 coefficients (32-byte aligned)
+    const f32x4 a = reinterpret_cast<const f32x4*>(p)[0], b = reinterpret_cast<const f32x4*>(p)[1];
+    return f32x8{{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}};
+}
+
+template <int MODE>
+__global__ __launch_bounds__(EB) void bwd_reduce16_kernel(const u32x4e* __restrict__ dy, const u32x4e* __restrict__ act_src,
+                                                           const u32x4e* __restrict__ bn_src, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, float slope, int64_t octs, int co,
+                                                           float* __restrict__ partial, const ctl_bnb_fin_dev fin) {
+    // blockIdx.y = BatchNorm group: `octs` is the size of one group; a thread always sees the same channel octet (256 % co == 0)
+    __shared__ float sm[2][8][EB];
+    const int64_t gtid = (int64_t)blockIdx.x * EB + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * EB;
+    const int o = (int)(gtid % co), c = co * 8;
+    const int64_t gbase = (int64_t)blockIdx.y * octs;
+    f32x8 sc, sh;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { sc.v[k] = 1.f; sh.v[k] = 0.f; }
+    if (MODE == 1) { sc = load8f(scale + blockIdx.y * c + o * 8); sh = load8f(shift + blockIdx.y * c + o * 8); }
+    float s1[8], s2[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s1[k] = s2[k] = 0.f;
+    for (int64_t i0 = gtid; i0 < octs; i0 += 2 * stride) {
+        u32x4e gq[2], uq[2], oq[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int64_t i = i0 + u * stride;
+            const bool ok = i < octs;
+            const u32x4e z = {0u, 0u, 0u, 0u};
+            gq[u] = ok ? dy[gbase + i] : z;
+            uq[u] = ok ? bn_src[gbase + i] : z;
+            if (MODE == 0) oq[u] = ok ? act_src[gbase + i] : z;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            f32x8 g = unpack8(gq[u]);
+            const f32x8 x = unpack8(uq[u]);
+            if (MODE == 0) {
+                const f32x8 a = unpack8(oq[u]);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) g.v[k] *= ctl_leaky_grad(a.v[k], slope);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) g.v[k] *= ctl_leaky_grad(x.v[k] * sc.v[k] + sh.v[k], slope);
+            }
+            // (a lane past the end contributes g = 0 * leaky'(..) = 0 and 0 * u = 0: nothing)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { s1[k] += g.v[k]; s2[k] += g.v[k] * x.v[k]; }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { sm[0][k][threadIdx.x] = s1[k]; sm[1][k][threadIdx.x] = s2[k]; }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 2 * c; t += EB) {   // one (stat, channel) per thread: threads with (tid % co) == channel / 8 hold it
+        const int stat = t / c, ch = t % c;
+        const int oo = ch >> 3, comp = ch & 7;
+        float v = 0.f;
+        for (int k = oo; k < EB; k += co) v += sm[stat][comp][k];
+        ctl_store_wt(partial + (((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 + stat) * c + ch, v);
+    }
+    if (fin.counter == nullptr) return;
+    __shared__ int last_flag;
+    if (!ctl_arrive_last(fin.counter, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, &last_flag)) return;
+    const int rows = gridDim.x, groups = gridDim.y, lane = threadIdx.x & 63;
+    for (int ch = threadIdx.x >> 6; ch < c; ch += EB / 64) {
+        ctl_bnb_chan p = bnb_chan_load(ch, fin.gamma, fin.dgamma, fin.dbeta, fin.accumulate);
+        for (int gi = 0; gi < groups; ++gi) {
+            const float mu = fin.save_mean[gi * c + ch], is = fin.save_invstd[gi * c + ch];
+            double a1 = 0.0, a2 = 0.0;
+#pragma unroll 4
+            for (int b = lane; b < rows; b += 64) {
+                a1 += (double)ctl_load_wt(partial + (((int64_t)gi * rows + b) * 2 + 0) * c + ch);
+                a2 += (double)ctl_load_wt(partial + (((int64_t)gi * rows + b) * 2 + 1) * c + ch);
+            }
+            a1 = wave_sum_double(a1);
+            a2 = wave_sum_double(a2);
+            if (lane == 0) bn_bwd_coefs(a1, a2, fin.count, c, gi, ch, p, mu, is, fin.coef, fin.dgamma, fin.dbeta);
+        }
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(EB) void bwd_apply16_kernel(const u32x4e* __restrict__ dy, const u32x4e* __restrict__ act_src,
+                                                          const u32x4e* __restrict__ bn_src, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, float slope, const float* __restrict__ coef,
+                                                          int64_t octs, int co, u32x4e* __restrict__ ds, u32x4e* __restrict__ dx,
+                                                          int64_t group_octs) {
+    const int64_t stride = (int64_t)gridDim.x * EB;
+    const int c = co * 8;
+    for (int64_t i0 = (int64_t)blockIdx.x * EB + threadIdx.x; i0 < octs; i0 += 2 * stride) {
+        u32x4e gq[2], uq[2], oq[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int64_t i = i0 + u * stride;
+            const bool ok = i < octs;
+            const u32x4e z = {0u, 0u, 0u, 0u};
+            gq[u] = ok ? dy[i] : z;
+            uq[u] = ok ? bn_src[i] : z;
+            if (MODE == 0) oq[u] = ok ? act_src[i] : z;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int64_t i = i0 + u * stride;
+            if (i >= octs) continue;
+            const int o = (int)(i % co), gi = (int)(i / group_octs);
+            f32x8 g = unpack8(gq[u]);
+            const f32x8 x = unpack8(uq[u]);
+            if (MODE == 0) {
+                const f32x8 a = unpack8(oq[u]);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) g.v[k] *= ctl_leaky_grad(a.v[k], slope);
+                if (ds) ds[i] = pack8(g);
+            } else if (MODE == 1) {
+                const f32x8 sc = load8f(scale + gi * c + o * 8), sh = load8f(shift + gi * c + o * 8);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) g.v[k] *= ctl_leaky_grad(x.v[k] * sc.v[k] + sh.v[k], slope);
+            }
+            const f32x8 A = load8f(coef + (gi * 3 + 0) * c + o * 8), B = load8f(coef + (gi * 3 + 1) * c + o * 8), C = load8f(coef + (gi * 3 + 2) * c + o * 8);
+            f32x8 r;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) r.v[k] = A.v[k] * g.v[k] + B.v[k] * x.v[k] + C.v[k];
+            dx[i] = pack8(r);
+        }
+    }
+}
+
 __global__ __launch_bounds__(EB) void chan_sum_finalize_kernel(const float* __restrict__ partial, int blocks, int c,
                                                                 float* __restrict__ out, int accumulate) {
     __shared__ double sm[8];
@@ -606,13 +754,24 @@ extern "C" int ctl_bwd_reduce_fin(int32_t mode, const float* dy, const float* ac
         f.gamma = fin->gamma; f.save_mean = fin->save_mean; f.save_invstd = fin->save_invstd; f.coef = fin->coef; f.dgamma = fin->dgamma;
         f.dbeta = fin->dbeta; f.counter = fin->counter; f.count = (double)fin->count; f.accumulate = fin->accumulate;
     }
+    // every tensor stored as bf16 and whole channel octets: 16 bytes per lane
+    const bool oct = c % 8 == 0 && (EB % (c / 8)) == 0 && (pixels / groups) * (int64_t)(c / 8) >= 1 &&
+                     ((mode == 0 && (bf16_mask & 7u) == 7u) || (mode == 1 && (bf16_mask & 5u) == 5u));
     if (mode == 0) {
         CTL_REQUIRE(act_src && bn_src, "bwd_reduce mode 0 needs act_src and bn_src");
-        bwd_reduce_kernel<0><<<grid, blk, 0, S_>>>(dy, act_src, bn_src, nullptr, nullptr, slope, quads, c / 4, partial, bf16_mask, f);
+        if (oct)
+            bwd_reduce16_kernel<0><<<grid, blk, 0, S_>>>((const u32x4e*)dy, (const u32x4e*)act_src, (const u32x4e*)bn_src, nullptr, nullptr, slope,
+                                                        quads / 2, c / 8, partial, f);
+        else
+            bwd_reduce_kernel<0><<<grid, blk, 0, S_>>>(dy, act_src, bn_src, nullptr, nullptr, slope, quads, c / 4, partial, bf16_mask, f);
     } else if (mode == 1) {
         CTL_REQUIRE(bn_src && scale && shift, "bwd_reduce mode 1 needs bn_src, scale, shift");
-        bwd_reduce_kernel<1><<<grid, blk, 0, S_>>>(dy, nullptr, bn_src, (const f32x4*)scale, (const f32x4*)shift, slope, quads, c / 4, partial,
-                                                  bf16_mask, f);
+        if (oct)
+            bwd_reduce16_kernel<1><<<grid, blk, 0, S_>>>((const u32x4e*)dy, nullptr, (const u32x4e*)bn_src, scale, shift, slope, quads / 2, c / 8,
+                                                        partial, f);
+        else
+            bwd_reduce_kernel<1><<<grid, blk, 0, S_>>>(dy, nullptr, bn_src, (const f32x4*)scale, (const f32x4*)shift, slope, quads, c / 4, partial,
+                                                      bf16_mask, f);
     } else if (mode == 2) {
         CTL_REQUIRE(groups == 1, "bwd_reduce mode 2 sums everything: groups must be 1");
         bwd_reduce_kernel<2><<<grid, blk, 0, S_>>>(dy, nullptr, nullptr, nullptr, nullptr, slope, quads, c / 4, partial, bf16_mask, f);
@@ -648,14 +807,26 @@ extern "C" int ctl_bwd_apply_dt(int32_t mode, const float* dy, const float* act_
     CTL_REQUIRE(dy && bn_src && coef && dx && pixels > 0 && c % 4 == 0 && groups >= 1 && pixels % groups == 0, "bwd_apply: bad arguments");
     const int64_t quads = pixels * (c / 4);
     const dim3 grid(stream_blocks(quads)), blk(EB);
+    // every tensor stored as bf16 and whole channel octets: 16 bytes per lane (mask bits: 0 dy, 1 act_src, 2 bn_src, 3 ds, 4 dx)
+    const unsigned need = mode == 0 ? (1u | 2u | 4u | 16u | (ds ? 8u : 0u)) : (1u | 4u | 16u);
+    const bool oct = c % 8 == 0 && mode != 2 && (bf16_mask & need) == need;
+    const dim3 grid8(stream_blocks(quads / 4));      // two octets per thread and trip
     if (mode == 0) {
         CTL_REQUIRE(act_src, "bwd_apply mode 0 needs act_src");
-        bwd_apply_kernel<0><<<grid, blk, 0, S_>>>(dy, act_src, bn_src, nullptr, nullptr, slope, (const f32x4*)coef, quads, c / 4, ds, dx,
-                                                 quads / groups, bf16_mask);
+        if (oct)
+            bwd_apply16_kernel<0><<<grid8, blk, 0, S_>>>((const u32x4e*)dy, (const u32x4e*)act_src, (const u32x4e*)bn_src, nullptr, nullptr, slope,
+                                                        coef, quads / 2, c / 8, (u32x4e*)ds, (u32x4e*)dx, quads / 2 / groups);
+        else
+            bwd_apply_kernel<0><<<grid, blk, 0, S_>>>(dy, act_src, bn_src, nullptr, nullptr, slope, (const f32x4*)coef, quads, c / 4, ds, dx,
+                                                     quads / groups, bf16_mask);
     } else if (mode == 1) {
         CTL_REQUIRE(scale && shift, "bwd_apply mode 1 needs scale and shift");
-        bwd_apply_kernel<1><<<grid, blk, 0, S_>>>(dy, nullptr, bn_src, (const f32x4*)scale, (const f32x4*)shift, slope, (const f32x4*)coef, quads,
-                                                 c / 4, nullptr, dx, quads / groups, bf16_mask);
+        if (oct)
+            bwd_apply16_kernel<1><<<grid8, blk, 0, S_>>>((const u32x4e*)dy, nullptr, (const u32x4e*)bn_src, scale, shift, slope, coef, quads / 2,
+                                                        c / 8, nullptr, (u32x4e*)dx, quads / 2 / groups);
+        else
+            bwd_apply_kernel<1><<<grid, blk, 0, S_>>>(dy, nullptr, bn_src, (const f32x4*)scale, (const f32x4*)shift, slope, (const f32x4*)coef, quads,
+                                                     c / 4, nullptr, dx, quads / groups, bf16_mask);
     } else if (mode == 2) {
         bwd_apply_kernel<2><<<grid, blk, 0, S_>>>(dy, nullptr, bn_src, nullptr, nullptr, slope, (const f32x4*)coef, quads, c / 4, nullptr, dx,
                                                  quads / groups, bf16_mask);

@@ -89,8 +89,19 @@ def main():
                                                   N * hw, c, None, dx.data_ptr(), 1, 1 | 4 | 16, ops.stream_ptr())))
     nb = 2.0 * 3 * dy.numel()
     res["bwd_apply<1> 16ch@256"] = {"us": round(us, 1), "GBs": round(nb / us / 1e3), "hbm_frac": round(nb / us / 1e3 / 8000, 3)}
+    # weight gradients (bf16 x and dy): the kernel alone, without the split reduction
+    for name, cin, cout, h, ks in (("wgrad 3x3 16-16@256", 16, 16, 256, 3), ("wgrad 3x3 32-32@128", 32, 32, 128, 3), ("wgrad 1x1 16-16@256", 16, 16, 256, 1)):
+        x = torch.randn(N, cin, h, h, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        dyw = torch.randn(N, cout, h, h, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        d = _ffi.conv_desc(n=N, hin=h, win=h, cin=cin, hout=h, wout=h, cout=cout, ks=ks, dt=BF)
+        dp = _ffi.desc_ptr(d)
+        wpart = torch.empty(lib.ctl_wgrad_partial_floats(dp), device="cuda")
+        bpart = torch.empty(lib.ctl_wgrad_bias_partial_floats(dp), device="cuda")
+        us = timed(lambda: check(lib.ctl_conv_wgrad(dp, x.data_ptr(), None, None, dyw.data_ptr(), wpart.data_ptr(), bpart.data_ptr(), ops.stream_ptr())))
+        nb = 2.0 * (x.numel() + dyw.numel())
+        res[name] = {"us": round(us, 1), "GBs": round(nb / us / 1e3), "hbm_frac": round(nb / us / 1e3 / 8000, 3), "splits": lib.ctl_wgrad_splits(dp)}
     for k, v in res.items():
-        print(f"  {k:28s} {v['us']:8.1f} us  {v['GBs']:6d} GB/s  {v['hbm_frac']:.3f}", v.get("phase_cycles_per_step", ""), v.get("setup_per_step", ""), v.get("steps_per_wave", ""), v.get("memtime_MHz", ""), v.get("wave_span_us", ""))
+        print(f"  {k:28s} {v['us']:8.1f} us  {v['GBs']:6d} GB/s  {v['hbm_frac']:.3f}", v.get("phase_cycles_per_step", ""), v.get("setup_per_step", ""), v.get("steps_per_wave", ""), v.get("memtime_MHz", ""), v.get("wave_span_us", ""), v.get("splits", ""))
     print("RESULT " + json.dumps(res))
 
 
