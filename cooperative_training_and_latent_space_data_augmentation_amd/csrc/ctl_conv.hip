@@ -961,7 +961,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(const float* 
         tap = idx / ((int64_t)cout * cin);
         const int64_t stride = (int64_t)taps * cin_p * cout_p;
         const float* src = scratch + r[0] + ((int64_t)tap * cin_p + ci) * cout_p + co;
-        for (int s = sl; s < splits; s += SLN) v += src[s * stride];
+        // 8 split rows in flight per thread (one per trip leaves this launch, the serial tail of every backward plan, latency-bound);
+        // the adds keep the order of the rolled loop
+        for (int s0 = sl; s0 < splits; s0 += 8 * SLN) {
+            float t8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int s = s0 + u * SLN; t8[u] = s < splits ? src[s * stride] : 0.f; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v += t8[u];
+        }
     } else if (is_b) {
         co = idx - total;
         const float* src = scratch + r[1] + co;
