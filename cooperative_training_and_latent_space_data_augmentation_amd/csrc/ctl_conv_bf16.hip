@@ -216,14 +216,16 @@ extern "C" int ctl_debug_timing16(unsigned long long* out12) {
 // at compile time the epilogue is straight-line code (the generic one decides per fragment between fp32 / bf16 / 1-channel forms of
 // three optional operands: ~3700 cycles per tile and wave of scalar branches, measured with the phase timers) and the staging loses
 // the fp32-source half of its registers.
-template <int KS, int S, int MODE, int MT, int TW, int NT, int FAST>      // 0 generic; 1 plain; 2 + bf16 residual * scale + shift (+ LeakyReLU); 3 accumulate into y
+// XB: the input is stored as bf16 with whole 16-channel chunks (compile-time staging); the network-boundary layers (fp32 input with 1 or 4
+// channels) take the FAST epilogues with the generic staging.
+template <int KS, int S, int MODE, int MT, int TW, int NT, int FAST, bool XB>      // FAST: 0 generic; 1 plain; 2 + bf16 residual * scale + shift (+ LeakyReLU); 3 accumulate into y
 __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? CTL16_OCC_BIG : CTL16_OCC) void conv_igemm_bf16_kernel(
     const ctl_conv d, const void* __restrict__ x, const void* __restrict__ wpack, const float* __restrict__ bias,
     const float* __restrict__ pro_scale, const float* __restrict__ pro_shift, const void* __restrict__ res,
     const float* __restrict__ res_scale, const float* __restrict__ res_shift, void* __restrict__ y, float* __restrict__ stats_partial,
     int tiles_h, int tiles_w, int G_chunks, int64_t wpack_sub_bytes, int ntiles, ctl_bn_rec* __restrict__ rec) {
     using G = Geom<KS, S, MT, TW>;
-    using XS = XStage16<KS, S, MODE, MT, TW, FAST != 0, true>;
+    using XS = XStage16<KS, S, MODE, MT, TW, XB, true>;
     constexpr int TAPS = KS * KS;
     constexpr int NFRAG = NFRAG_OF(KS);
     constexpr int XT_ALLOC = XS::XT_BYTES + 16;            // + dump slot
@@ -257,7 +259,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? CTL16_OCC_BIG : CT
     const int ngroups = d.groups > 1 ? d.groups : 1;
     const int group_n = d.n / ngroups;
     const int oy0 = (z >> 1) * d.out_sub, ox0 = (z & 1) * d.out_sub;
-    const __amdgpu_buffer_rsrc_t rx = ctl_rsrc(x, (int64_t)d.n * d.hin * d.win * d.cin * ((FAST || (d.dt & CTL_DT_X16)) ? 2 : 4));
+    const __amdgpu_buffer_rsrc_t rx = ctl_rsrc(x, (int64_t)d.n * d.hin * d.win * d.cin * ((XB || (d.dt & CTL_DT_X16)) ? 2 : 4));
     const int64_t ypix = (int64_t)d.n * d.out_h * d.out_w * d.cout;
     const __amdgpu_buffer_rsrc_t ry = ctl_rsrc(y, ypix * yes);
     const __amdgpu_buffer_rsrc_t rres = ctl_rsrc(res ? res : y, ypix * (res ? res_es : yes));
@@ -697,12 +699,12 @@ struct conv16_call {
     hipStream_t stream; bool query; int grid_x;
     ctl_bn_rec* rec;
 };
-template <int KS, int S, int MODE, int MT, int TW, int NT, int FAST>
+template <int KS, int S, int MODE, int MT, int TW, int NT, int FAST, bool XB>
 static void conv16_go_f(conv16_call& a) {
     static int occ = 0;
     if (!occ) {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_igemm_bf16_kernel<KS, S, MODE, MT, TW, NT, FAST>, 256, 0) != hipSuccess || n < 1) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_igemm_bf16_kernel<KS, S, MODE, MT, TW, NT, FAST, XB>, 256, 0) != hipSuccess || n < 1) {
             (void)hipGetLastError();
             n = 2;
         }
@@ -713,7 +715,7 @@ static void conv16_go_f(conv16_call& a) {
     a.grid_x = ctl_conv_grid_x(ntiles, (a.c.cot / NT) * d->nsub, occ);
     if (a.query) return;
     const dim3 grid((unsigned)a.grid_x, (unsigned)(a.c.cot / NT), (unsigned)d->nsub);
-    conv_igemm_bf16_kernel<KS, S, MODE, MT, TW, NT, FAST><<<grid, dim3(256), 0, a.stream>>>(
+    conv_igemm_bf16_kernel<KS, S, MODE, MT, TW, NT, FAST, XB><<<grid, dim3(256), 0, a.stream>>>(
         *d, a.x, a.wpack, a.bias, a.pro_scale, a.pro_shift, a.res, a.res_scale, a.res_shift, a.y, a.stats_partial, a.c.tiles_h, a.c.tiles_w,
         a.c.g, (int64_t)ctl_conv_wpack_floats(d->cin, d->cout, d->ks) * 4, ntiles, a.rec);
 }
@@ -722,13 +724,23 @@ static void conv16_go(conv16_call& a) {
     const ctl_conv* d = a.d;
     // the FAST instantiations (see the kernel): bf16 on both sides, whole channel tiles; 1 = bias / statistics only, 2 = bf16 residual
     // with affine (+ LeakyReLU): the tail of every residual block, 3 = accumulate into the bf16 output (the 1x1 data gradients)
-    const bool io16 = (d->dt & CTL_DT_X16) && (d->dt & CTL_DT_Y16) && d->cin % 16 == 0 && d->cout % 16 == 0;
+    const bool xb = (d->dt & CTL_DT_X16) && d->cin % 16 == 0;
+    const bool o16 = (d->dt & CTL_DT_Y16) && d->cout % 16 == 0;
     const int e = d->epi_flags & (CTL_EPI_RES | CTL_EPI_ACCUM | CTL_EPI_BNBWD | CTL_EPI_STATS);
-    if (io16 && !(e & ~CTL_EPI_STATS) && d->epi_act == CTL_ACT_NONE) conv16_go_f<KS, S, MODE, MT, TW, NT, 1>(a);
-    else if (io16 && e == CTL_EPI_RES && (d->dt & CTL_DT_RES16) && (d->epi_act == CTL_ACT_NONE || d->epi_act == CTL_ACT_LEAKY))
-        conv16_go_f<KS, S, MODE, MT, TW, NT, 2>(a);
-    else if (io16 && e == CTL_EPI_ACCUM && d->epi_act == CTL_ACT_NONE) conv16_go_f<KS, S, MODE, MT, TW, NT, 3>(a);
-    else conv16_go_f<KS, S, MODE, MT, TW, NT, 0>(a);
+    int fast = 0;
+    if (o16 && !(e & ~CTL_EPI_STATS) && d->epi_act == CTL_ACT_NONE) fast = 1;
+    else if (o16 && e == CTL_EPI_RES && (d->dt & CTL_DT_RES16) && (d->epi_act == CTL_ACT_NONE || d->epi_act == CTL_ACT_LEAKY)) fast = 2;
+    else if (o16 && e == CTL_EPI_ACCUM && d->epi_act == CTL_ACT_NONE) fast = 3;
+    if (xb) {
+        if (fast == 1) conv16_go_f<KS, S, MODE, MT, TW, NT, 1, true>(a);
+        else if (fast == 2) conv16_go_f<KS, S, MODE, MT, TW, NT, 2, true>(a);
+        else if (fast == 3) conv16_go_f<KS, S, MODE, MT, TW, NT, 3, true>(a);
+        else conv16_go_f<KS, S, MODE, MT, TW, NT, 0, false>(a);
+    } else {          // fp32 (or partial-chunk) input: first layers of the encoders
+        if (fast == 1) conv16_go_f<KS, S, MODE, MT, TW, NT, 1, false>(a);
+        else if (fast == 2) conv16_go_f<KS, S, MODE, MT, TW, NT, 2, false>(a);
+        else conv16_go_f<KS, S, MODE, MT, TW, NT, 0, false>(a);
+    }
 }
 template <int KS, int S, int MODE>
 static void conv16_go_tile(conv16_call& a) {
