@@ -1282,12 +1282,16 @@ static void wgrad_go(wgrad_call& a) {
     wgrad_cfg& w = *a.w;
     static int per_cu = -1;
     if (per_cu < 0) {
-        const char* e = getenv("CTL_PERSIST");
-        per_cu = e ? atoi(e) : 4;
+        // ONE block per CU: the weight gradients co-run with the other launch chain, and every block costs a partial tensor that the
+        // reduction at the end of the plan reads back (measured, whole step: 256 blocks 18.23 ms, 512-768 (occupancy) 18.40, 768 19.05,
+        // 128 20.98).  CTL_WGRAD_PERSIST / CTL_WGRAD_SLOTS are the tuning hooks.
+        const char* e = getenv("CTL_WGRAD_PERSIST");
+        per_cu = e ? atoi(e) : 1;
         if (per_cu < 1) per_cu = 1;
     }
     const int par = w.c.g * (w.c.cot / NTW);
-    int splits = (256 * (occ < per_cu ? occ : per_cu)) / par;
+    static const int slots = [] { const char* e = getenv("CTL_WGRAD_SLOTS"); return e ? atoi(e) : 0; }();      // tuning hook: total blocks
+    int splits = (slots > 0 ? slots : 256 * (occ < per_cu ? occ : per_cu)) / par;
     if (splits > 512) splits = 512;
     if (splits > w.ntiles) splits = w.ntiles;
     if (splits < 1) splits = 1;
