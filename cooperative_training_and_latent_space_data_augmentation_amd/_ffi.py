@@ -119,7 +119,7 @@ class _Lib:
             "ctl_conv_forward_fin": [p] * 13,
             "ctl_bn_fin_table_write": [p, p, i32, p],
             "ctl_bwd_reduce_rows": [i32, i64, i32],
-            "ctl_bwd_reduce_fin": [i32, p, p, p, p, p, f32, i64, i32, p, i32, C.c_uint32, p, p],
+            "ctl_bwd_reduce_fin": [i32, p, p, p, p, p, f32, i64, i32, p, i32, C.c_uint32, p, p, p],
             "ctl_bn_act_dt": [p, p, p, f32, p, i64, i32, i32, C.c_uint32, p],
             "ctl_bwd_reduce_dt": [i32, p, p, p, p, p, f32, i64, i32, p, i32, C.c_uint32, p],
             "ctl_bwd_apply_dt": [i32, p, p, p, p, p, f32, p, i64, i32, p, p, i32, C.c_uint32, p],

@@ -183,8 +183,8 @@ __global__ __launch_bounds__(EB) void bwd_reduce_kernel(const void* __restrict__
                                                          const void* __restrict__ bn_src_,
                                                          const f32x4* __restrict__ scale,
                                                          const f32x4* __restrict__ shift, float slope, int64_t quads,
-                                                         int cq, float* __restrict__ partial, unsigned m,      // m: bit 0 dy, 1 act_src, 2 bn_src
-                                                         const ctl_bnb_fin_dev fin) {
+                                                         int cq, float* __restrict__ partial, unsigned m,      // m: bit 0 dy, 1 act_src, 2 bn_src, 3 ds
+                                                         const ctl_bnb_fin_dev fin, void* __restrict__ ds_) {
     // blockIdx.y = BatchNorm group: `quads` is the size of one group, its data start at blockIdx.y * quads
     __shared__ f32x4 sm[2][EB];
     const int64_t gtid = (int64_t)blockIdx.x * EB + threadIdx.x;
@@ -200,6 +200,9 @@ __global__ __launch_bounds__(EB) void bwd_reduce_kernel(const void* __restrict__
             const f32x4 o = ldq(act_src_, gbase + i, m & 2);
             g.x *= ctl_leaky_grad(o.x, slope); g.y *= ctl_leaky_grad(o.y, slope);
             g.z *= ctl_leaky_grad(o.z, slope); g.w *= ctl_leaky_grad(o.w, slope);
+            // the activation-gradient product does not depend on the sums: written here, the apply pass reads it back instead of
+            // recomputing it from dout and out (one tensor read less per residual tail)
+            if (ds_) stq(ds_, gbase + i, g, m & 8);
         }
         if (MODE == 2) {
             s1.x += g.x; s1.y += g.y; s1.z += g.z; s1.w += g.w;
@@ -742,7 +745,8 @@ extern "C" int ctl_bwd_reduce_rows(int32_t mode, int64_t pixels_per_group, int32
 }
 extern "C" int ctl_bwd_reduce_fin(int32_t mode, const float* dy, const float* act_src, const float* bn_src,
                                   const float* scale, const float* shift, float slope, int64_t pixels, int32_t c,
-                                  float* partial, int32_t groups, uint32_t bf16_mask, const ctl_bnb_fin* fin, ctl_stream stream) {
+                                  float* partial, int32_t groups, uint32_t bf16_mask, const ctl_bnb_fin* fin, float* ds, ctl_stream stream) {
+    CTL_REQUIRE(!ds || mode == 0, "bwd_reduce: ds (= dy * leaky'(act_src)) is an output of mode 0 only");
     CTL_REQUIRE(dy && partial && pixels > 0 && red_c_ok(c) && groups >= 1 && pixels % groups == 0, "bwd_reduce: bad arguments (c=%d)", c);
     const int64_t quads = (pixels / groups) * (c / 4);           // per group
     // modes 0 / 1 feed ctl_bn_bwd_finalize, which derives the same row count from (count, c); mode 2 feeds ctl_chan_sum_finalize (fixed rows)
@@ -755,7 +759,7 @@ extern "C" int ctl_bwd_reduce_fin(int32_t mode, const float* dy, const float* ac
         f.dbeta = fin->dbeta; f.counter = fin->counter; f.count = (double)fin->count; f.accumulate = fin->accumulate;
     }
     // every tensor stored as bf16 and whole channel octets: 16 bytes per lane
-    const bool oct = c % 8 == 0 && (EB % (c / 8)) == 0 && (pixels / groups) * (int64_t)(c / 8) >= 1 &&
+    const bool oct = c % 8 == 0 && (EB % (c / 8)) == 0 && (pixels / groups) * (int64_t)(c / 8) >= 1 && !ds &&
                      ((mode == 0 && (bf16_mask & 7u) == 7u) || (mode == 1 && (bf16_mask & 5u) == 5u));
     if (mode == 0) {
         CTL_REQUIRE(act_src && bn_src, "bwd_reduce mode 0 needs act_src and bn_src");
@@ -763,7 +767,7 @@ extern "C" int ctl_bwd_reduce_fin(int32_t mode, const float* dy, const float* ac
             bwd_reduce16_kernel<0><<<grid, blk, 0, S_>>>((const u32x4e*)dy, (const u32x4e*)act_src, (const u32x4e*)bn_src, nullptr, nullptr, slope,
                                                         quads / 2, c / 8, partial, f);
         else
-            bwd_reduce_kernel<0><<<grid, blk, 0, S_>>>(dy, act_src, bn_src, nullptr, nullptr, slope, quads, c / 4, partial, bf16_mask, f);
+            bwd_reduce_kernel<0><<<grid, blk, 0, S_>>>(dy, act_src, bn_src, nullptr, nullptr, slope, quads, c / 4, partial, bf16_mask, f, ds);
     } else if (mode == 1) {
         CTL_REQUIRE(bn_src && scale && shift, "bwd_reduce mode 1 needs bn_src, scale, shift");
         if (oct)
@@ -771,10 +775,10 @@ extern "C" int ctl_bwd_reduce_fin(int32_t mode, const float* dy, const float* ac
                                                         partial, f);
         else
             bwd_reduce_kernel<1><<<grid, blk, 0, S_>>>(dy, nullptr, bn_src, (const f32x4*)scale, (const f32x4*)shift, slope, quads, c / 4, partial,
-                                                      bf16_mask, f);
+                                                      bf16_mask, f, nullptr);
     } else if (mode == 2) {
         CTL_REQUIRE(groups == 1, "bwd_reduce mode 2 sums everything: groups must be 1");
-        bwd_reduce_kernel<2><<<grid, blk, 0, S_>>>(dy, nullptr, nullptr, nullptr, nullptr, slope, quads, c / 4, partial, bf16_mask, f);
+        bwd_reduce_kernel<2><<<grid, blk, 0, S_>>>(dy, nullptr, nullptr, nullptr, nullptr, slope, quads, c / 4, partial, bf16_mask, f, nullptr);
     } else {
         CTL_FAIL(CTL_EINVAL, "bwd_reduce: mode %d", mode);
     }
@@ -784,7 +788,7 @@ extern "C" int ctl_bwd_reduce_fin(int32_t mode, const float* dy, const float* ac
 extern "C" int ctl_bwd_reduce_dt(int32_t mode, const float* dy, const float* act_src, const float* bn_src,
                                  const float* scale, const float* shift, float slope, int64_t pixels, int32_t c,
                                  float* partial, int32_t groups, uint32_t bf16_mask, ctl_stream stream) {
-    return ctl_bwd_reduce_fin(mode, dy, act_src, bn_src, scale, shift, slope, pixels, c, partial, groups, bf16_mask, nullptr, stream);
+    return ctl_bwd_reduce_fin(mode, dy, act_src, bn_src, scale, shift, slope, pixels, c, partial, groups, bf16_mask, nullptr, nullptr, stream);
 }
 extern "C" int ctl_bwd_reduce(int32_t mode, const float* dy, const float* act_src, const float* bn_src,
                               const float* scale, const float* shift, float slope, int64_t pixels, int32_t c,

@@ -10,7 +10,7 @@
 //                                                                        i[0..2]=blocks,c,update_running l[0]=count f[0]=eps f[1]=momentum
 //   BN_EVAL           0 gamma 1 beta 2 running_mean 3 running_var 4 scale 5 shift      i[0]=c f[0]=eps
 //   BN_ACT            0 x 1 scale 2 shift 3 y                            i[0]=c l[0]=pixels f[0]=slope
-//   BWD_REDUCE        0 dy 1 act_src 2 bn_src 3 scale 4 shift 5 partial  i[0]=mode i[1]=c l[0]=pixels f[0]=slope
+//   BWD_REDUCE        0 dy 1 act_src 2 bn_src 3 scale 4 shift 5 partial 6 ds (mode 0, optional)  i[0]=mode i[1]=c l[0]=pixels f[0]=slope
 //   BN_BWD_FINALIZE   0 partial 1 gamma 2 save_mean 3 save_invstd 4 coef 5 dgamma 6 dbeta   i[0]=c i[1]=accumulate l[0]=count
 //   BWD_APPLY         0 dy 1 act_src 2 bn_src 3 scale 4 shift 5 coef 6 ds 7 dx   i[0]=mode i[1]=c l[0]=pixels f[0]=slope
 //   CHAN_SUM_FINALIZE 0 partial 1 out                                    i[0]=c i[1]=accumulate
@@ -285,9 +285,9 @@ extern "C" int ctl_plan_run(const ctl_op* ops, int32_t n_ops, void* const* bases
                     bf.coef = (float*)resolve(fo, 4); bf.dgamma = (float*)resolve(fo, 5); bf.dbeta = (float*)resolve(fo, 6);
                     bf.counter = (uint32_t*)(table + (size_t)rec_of[k] * CTL_FIN_REC_BYTES + 128);      // the slot's first counter set
                     bf.count = fo.l[0]; bf.accumulate = fo.i[1];
-                    rc = ctl_bwd_reduce_fin(op.i[0], CF(0), CF(1), CF(2), CF(3), CF(4), op.f[0], op.l[0], op.i[1], F(5), NG(op.i[2]), (uint32_t)op.i[25], &bf, stream);
+                    rc = ctl_bwd_reduce_fin(op.i[0], CF(0), CF(1), CF(2), CF(3), CF(4), op.f[0], op.l[0], op.i[1], F(5), NG(op.i[2]), (uint32_t)op.i[25], &bf, F(6), stream);
                 } else {
-                    rc = ctl_bwd_reduce_dt(op.i[0], CF(0), CF(1), CF(2), CF(3), CF(4), op.f[0], op.l[0], op.i[1], F(5), NG(op.i[2]), (uint32_t)op.i[25], stream);
+                    rc = ctl_bwd_reduce_fin(op.i[0], CF(0), CF(1), CF(2), CF(3), CF(4), op.f[0], op.l[0], op.i[1], F(5), NG(op.i[2]), (uint32_t)op.i[25], nullptr, F(6), stream);
                 }
                 break;
             case CTL_OP_BN_BWD_FINALIZE:

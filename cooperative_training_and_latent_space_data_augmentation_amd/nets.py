@@ -323,12 +323,17 @@ class PlanBuilder:
         c, pixels, G = bn_src.c, bn_src.n * bn_src.h * bn_src.w, self.groups
         part, = self.scr(4 * G * _ffi.RED_BLOCKS * 2 * c)
         coef = self.bscr.alloc(4 * 3 * c * G)
+        # residual tail (mode 0), fp32: the reduction also writes ds = dy * leaky'(act_src) (it has it in registers), and the apply pass
+        # then runs in mode 2 on ds -- same arithmetic bit for bit, one tensor read less.  (bf16 keeps the two-operand apply: reading a
+        # ROUNDED ds back would add a rounding point.)
+        ds_early = mode_kind == 0 and ds is not None and not self.b16
         op = self.op(_ffi.OP_BWD_REDUCE)
         op["i"][0], op["i"][1], op["i"][2] = mode_kind, c, G
         op["i"][25] = self.mask(dy, act_src, bn_src)
         op["l"][0] = pixels
         op["f"][0] = slope
-        for idx, ref in enumerate([dy.ref, act_src.ref if act_src else None, bn_src.ref, co["scale"], co["shift"], part]):
+        for idx, ref in enumerate([dy.ref, act_src.ref if act_src else None, bn_src.ref, co["scale"], co["shift"], part,
+                                   ds.ref if ds_early else None]):
             self.set_t(op, idx, ref)
         op = self.op(_ffi.OP_BN_BWD_FINALIZE)
         op["i"][0], op["i"][1], op["i"][2] = c, 0, G
@@ -338,6 +343,12 @@ class PlanBuilder:
                                    self.G(bn.g_off) if affine_grad else None, self.G(bn.b_off) if affine_grad else None]):
             self.set_t(op, idx, ref)
         op = self.op(_ffi.OP_BWD_APPLY)
+        if ds_early:
+            op["i"][0], op["i"][1], op["i"][2] = 2, c, G
+            op["l"][0] = pixels
+            for idx, ref in enumerate([ds.ref, None, bn_src.ref, None, None, coef, None, dx.ref]):
+                self.set_t(op, idx, ref)
+            return
         op["i"][0], op["i"][1], op["i"][2] = mode_kind, c, G
         op["i"][25] = self.mask(dy, act_src, bn_src, ds, dx)
         op["l"][0] = pixels

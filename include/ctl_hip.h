@@ -187,7 +187,9 @@ int ctl_bwd_reduce(int32_t mode, const float* dy, const float* act_src, const fl
 int ctl_bwd_reduce_rows(int32_t mode, int64_t pixels_per_group, int32_t c);
 int ctl_bwd_reduce_fin(int32_t mode, const float* dy, const float* act_src, const float* bn_src, const float* scale,
                        const float* shift, float slope, int64_t pixels, int32_t c, float* partial, int32_t groups,
-                       uint32_t bf16_mask, const ctl_bnb_fin* fin, ctl_stream stream);
+                       uint32_t bf16_mask, const ctl_bnb_fin* fin, float* ds, ctl_stream stream);
+/* (ds, mode 0 only, may be NULL: also writes ds = dy * leaky'(act_src) (bf16_mask bit 3 = its storage), so that the apply pass can run in
+ * mode 2 on ds instead of recomputing it from dy and act_src) */
 /* partial -> coefficients A,B,C with dx = A*g + B*bn_src + C (training-mode BN backward), and, if dgamma/dbeta
  * are non-NULL, dgamma += sum g*xhat, dbeta += sum g (accumulate ? += : =). */
 /* `blocks` = rows per group of `partial` (0 = CTL_RED_BLOCKS, i.e. written by ctl_bwd_reduce; a conv with CTL_EPI_BNBWD

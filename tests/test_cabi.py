@@ -63,6 +63,6 @@ def test_host_side_sizing_helpers():
     blocks = _ffi.lib.ctl_conv_stats_blocks(_ffi.desc_ptr(d))
     assert blocks in (512, 768, 1024)
     assert _ffi.lib.ctl_conv_stats_floats(_ffi.desc_ptr(d)) == blocks * 2 * 16
-    assert _ffi.lib.ctl_wgrad_splits(_ffi.desc_ptr(d)) == 512
-    assert _ffi.lib.ctl_wgrad_partial_floats(_ffi.desc_ptr(d)) == 512 * 9 * 16 * 16
+    assert _ffi.lib.ctl_wgrad_splits(_ffi.desc_ptr(d)) == 256          # one block per CU (round 2: the weight gradients co-run with the other chain)
+    assert _ffi.lib.ctl_wgrad_partial_floats(_ffi.desc_ptr(d)) == 256 * 9 * 16 * 16
     assert _ffi.lib.ctl_latent_score_ws_floats(0, 16, 256, 128) == 16 * 4 * 128

@@ -685,7 +685,7 @@ def test_bwd_reduce_fused_finalize_matches_separate_launch(mode, n, c, h, w, gro
     fin = _ffi.BnbFin(gamma.data_ptr(), mean.data_ptr(), invstd.data_ptr(), coef_b.data_ptr(), dg_b.data_ptr(), db_b.data_ptr(), counter.data_ptr(),
                       M // groups, 1, 0)
     part2 = torch.empty_like(part)
-    check(lib.ctl_bwd_reduce_fin(*args, part2.data_ptr(), groups, 0, ctypes.byref(fin), ops.stream_ptr()))
+    check(lib.ctl_bwd_reduce_fin(*args, part2.data_ptr(), groups, 0, ctypes.byref(fin), None, ops.stream_ptr()))
     torch.cuda.synchronize()
     assert torch.equal(part, part2)
     close(coef_b, coef_a, rel=2e-6, what="fused bwd finalize coef")
