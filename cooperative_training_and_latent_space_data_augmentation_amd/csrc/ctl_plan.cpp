@@ -162,6 +162,11 @@ extern "C" int ctl_plan_run(const ctl_op* ops, int32_t n_ops, void* const* bases
     }
     size_t forks = 0;
     bool side_used = false;
+    bool side_ok = g_side_enabled == 1;
+    if (side_ok) {      // the library-owned side stream cannot join a stream capture (hipGraph mode): the plan then stays on one stream
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing((hipStream_t)stream_, &st) != hipSuccess || st != hipStreamCaptureStatusNone) side_ok = false;
+    }
     // ---- fused finalizes (opt-in per op: BN_FINALIZE / BN_BWD_FINALIZE with i[4] == 1 directly behind the kernel that writes their
     // partial rows; the buffer of the partial slot starts with CTL_FIN_HEADER_BYTES of zero-initialised header = the record table).
     // The finalize op is folded into its producer: rec_of[k] = table slot used by op k, skip[k + 1] drops the stand-alone launch.
@@ -224,7 +229,7 @@ extern "C" int ctl_plan_run(const ctl_op* ops, int32_t n_ops, void* const* bases
         if (skip[k]) continue;
         const ctl_op& op = ops[k];
         ctl_stream stream = stream_;
-        if (g_side_enabled && op.i[26] == 1) {
+        if (side_ok && op.i[26] == 1) {
             if (!g_side) {
                 CTL_REQUIRE(hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking) == hipSuccess &&
                             hipEventCreateWithFlags(&g_join_event, hipEventDisableTiming) == hipSuccess,
