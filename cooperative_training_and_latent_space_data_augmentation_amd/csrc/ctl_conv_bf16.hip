@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? CTL16_OCC_BIG : CT
     const unsigned char* wp = reinterpret_cast<const unsigned char*>(wpack) + (int64_t)z * wpack_sub_bytes;
     const int my_tiles = (bid0 < t_hi) ? (t_hi - bid0 + nb - 1) / nb : 0;
     const int total_it = my_tiles * G_chunks;
-    const int flags = FAST == 1 ? (d.epi_flags & (CTL_EPI_BIAS | CTL_EPI_STATS)) : (FAST ? (d.epi_flags & CTL_EPI_BIAS) : d.epi_flags);
+    const int flags = FAST == 1 ? (d.epi_flags & (CTL_EPI_BIAS | CTL_EPI_STATS)) : (FAST == 4 ? CTL_EPI_STATS : (FAST ? (d.epi_flags & CTL_EPI_BIAS) : d.epi_flags));
     const bool y16 = FAST || (d.dt & CTL_DT_Y16) != 0, r16 = (d.dt & CTL_DT_RES16) != 0;
     const int yes = y16 ? 2 : 4, res_es = r16 ? 2 : 4;
     const int ngroups = d.groups > 1 ? d.groups : 1;
@@ -486,7 +486,41 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? CTL16_OCC_BIG : CT
             }
             const int ybase = ((n * d.out_h + ho0 * d.out_sy + oy0) * d.out_w + wo0 * d.out_sx + ox0) * d.cout + cot0 * 16;      // elements
             const bool full = ho0 + G::TH <= d.hout && wo0 + TW <= d.wout && (cot0 + NT) * 16 <= d.cout;
-            if constexpr (FAST >= 2) {
+            if constexpr (FAST == 4) {
+                // CTL_EPI_BNBWD on bf16 tensors: this conv produced dL/da of a = leaky(BN(u)).  Write g = dL/da * leaky'(BN(u)) and take the
+                // two BatchNorm-backward sums (sum g, sum g*u) here -- the separate reduction pass over da and u disappears (its launch
+                // and one of its two tensor reads; the fp32 family has the same epilogue, where it only broke even: MFMA-bound there)
+                f32x4 rs[NT], rh[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int co0 = (cot0 + t) * 16 + q * 4;
+                    rs[t] = *reinterpret_cast<const f32x4*>(res_scale + grp * d.cout + co0);
+                    rh[t] = *reinterpret_cast<const f32x4*>(res_shift + grp * d.cout + co0);
+                }
+                int bo[MT];
+                u32x2 uq[MT][NT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const bool pv = full || ((ho0 + wrow + m / TWT < d.hout) && (wo0 + (m % TWT) * 16 + p < d.wout));
+                    bo[m] = pv ? (ybase + yrel[m]) * 2 : CTL_OOB;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) uq[m][t] = ctl_bload2u(rres, bo[m] == CTL_OOB ? CTL_OOB : bo[m] + t * 32, 0);
+                }
+                const float sl = d.epi_slope;
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        f32x4 v = acc[m][t];
+                        const f32x4 u = unpack_bf16x4(uq[m][t].x, uq[m][t].y);
+                        const f32x4 sa = u * rs[t] + rh[t];
+                        v.x *= sa.x > 0.f ? 1.f : sl; v.y *= sa.y > 0.f ? 1.f : sl;
+                        v.z *= sa.z > 0.f ? 1.f : sl; v.w *= sa.w > 0.f ? 1.f : sl;
+                        if (bo[m] != CTL_OOB) { ssum[t] += v; ssq[t] += v * u; }
+                        __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)}, ry,
+                                                              bo[m] == CTL_OOB ? CTL_OOB : bo[m] + t * 32, 0, CTL_STORE_AUX);
+                    }
+            } else if constexpr (FAST >= 2) {
                 // the residual tail  out = LeakyReLU(conv + v * scale + shift)  (FAST 2) and  y += conv  (FAST 3) on bf16 operands: the
                 // operand loads of every fragment go out first, then the arithmetic; ragged tiles use CTL_OOB offsets (loads return 0,
                 // stores are dropped)
@@ -731,6 +765,7 @@ static void conv16_go(conv16_call& a) {
     if (o16 && !(e & ~CTL_EPI_STATS) && d->epi_act == CTL_ACT_NONE) fast = 1;
     else if (o16 && e == CTL_EPI_RES && (d->dt & CTL_DT_RES16) && (d->epi_act == CTL_ACT_NONE || d->epi_act == CTL_ACT_LEAKY)) fast = 2;
     else if (o16 && e == CTL_EPI_ACCUM && d->epi_act == CTL_ACT_NONE) fast = 3;
+    if (d->epi_flags & CTL_EPI_BNBWD) { conv16_go_f<KS, S, MODE, MT, TW, NT, 4, true>(a); return; }      // (checked in ctl_conv_forward_bf16)
     if (xb) {
         if (fast == 1) conv16_go_f<KS, S, MODE, MT, TW, NT, 1, true>(a);
         else if (fast == 2) conv16_go_f<KS, S, MODE, MT, TW, NT, 2, true>(a);
@@ -785,7 +820,8 @@ int ctl_conv_bf16_stats_blocks(const ctl_conv* d) {
 int ctl_conv_forward_bf16(const ctl_conv* d, const void* x, const void* wpack, const float* bias, const float* pro_scale,
                           const float* pro_shift, const void* res, const float* res_scale, const float* res_shift, void* y,
                           float* stats_partial, ctl_bn_rec* rec, ctl_stream stream) {
-    CTL_REQUIRE(!(d->epi_flags & CTL_EPI_BNBWD), "conv_forward(bf16): CTL_EPI_BNBWD is an fp32-only epilogue");
+    CTL_REQUIRE(!(d->epi_flags & CTL_EPI_BNBWD) || ((d->dt & CTL_DT_X16) && (d->dt & CTL_DT_Y16) && (d->dt & CTL_DT_RES16) && d->cin % 16 == 0 && d->cout % 16 == 0),
+                "conv_forward(bf16): CTL_EPI_BNBWD needs bf16-stored x, y and u with whole 16-channel tiles");
     CTL_REQUIRE(!(d->dt & CTL_DT_X16) || d->cin % 16 == 0, "conv_forward(bf16): bf16-stored inputs need cin %% 16 == 0 (got %d)", d->cin);
     CTL_REQUIRE(!(d->dt & (CTL_DT_Y16 | CTL_DT_RES16)) || d->cout % 4 == 0, "conv_forward(bf16): bf16-stored outputs need cout %% 4 == 0");
     conv16_call a = {};

@@ -437,7 +437,7 @@ __global__ __launch_bounds__(EB) void bwd_apply16_kernel(const u32x4e* __restric
 #pragma unroll
                 for (int k = 0; k < 8; ++k) g.v[k] *= ctl_leaky_grad(a.v[k], slope);
                 if (ds) ds[i] = pack8(g);
-            } else if (MODE == 1) {
+            } else if (MODE == 1) {      // (MODE 2: dy is g already)
                 const f32x8 sc = load8f(scale + gi * c + o * 8), sh = load8f(shift + gi * c + o * 8);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) g.v[k] *= ctl_leaky_grad(x.v[k] * sc.v[k] + sh.v[k], slope);
@@ -813,7 +813,7 @@ extern "C" int ctl_bwd_apply_dt(int32_t mode, const float* dy, const float* act_
     const dim3 grid(stream_blocks(quads)), blk(EB);
     // every tensor stored as bf16 and whole channel octets: 16 bytes per lane (mask bits: 0 dy, 1 act_src, 2 bn_src, 3 ds, 4 dx)
     const unsigned need = mode == 0 ? (1u | 2u | 4u | 16u | (ds ? 8u : 0u)) : (1u | 4u | 16u);
-    const bool oct = c % 8 == 0 && mode != 2 && (bf16_mask & need) == need;
+    const bool oct = c % 8 == 0 && (bf16_mask & need) == need;
     const dim3 grid8(stream_blocks(quads / 4));      // two octets per thread and trip
     if (mode == 0) {
         CTL_REQUIRE(act_src, "bwd_apply mode 0 needs act_src");
@@ -832,8 +832,12 @@ extern "C" int ctl_bwd_apply_dt(int32_t mode, const float* dy, const float* act_
             bwd_apply_kernel<1><<<grid, blk, 0, S_>>>(dy, nullptr, bn_src, (const f32x4*)scale, (const f32x4*)shift, slope, (const f32x4*)coef, quads,
                                                      c / 4, nullptr, dx, quads / groups, bf16_mask);
     } else if (mode == 2) {
-        bwd_apply_kernel<2><<<grid, blk, 0, S_>>>(dy, nullptr, bn_src, nullptr, nullptr, slope, (const f32x4*)coef, quads, c / 4, nullptr, dx,
-                                                 quads / groups, bf16_mask);
+        if (oct)
+            bwd_apply16_kernel<2><<<grid8, blk, 0, S_>>>((const u32x4e*)dy, nullptr, (const u32x4e*)bn_src, nullptr, nullptr, slope, coef, quads / 2,
+                                                        c / 8, nullptr, (u32x4e*)dx, quads / 2 / groups);
+        else
+            bwd_apply_kernel<2><<<grid, blk, 0, S_>>>(dy, nullptr, bn_src, nullptr, nullptr, slope, (const f32x4*)coef, quads, c / 4, nullptr, dx,
+                                                     quads / groups, bf16_mask);
     } else {
         CTL_FAIL(CTL_EINVAL, "bwd_apply: mode %d", mode);
     }

@@ -41,7 +41,8 @@ EPS = 1e-5
 MOMENTUM = 0.1
 SMALL_CIN = os.environ.get("CTL_SMALL_CIN", "1") != "0"          # K-packed taps for the Cin <= 4 first layers
 PHASE_CONVS = os.environ.get("CTL_PHASE_CONVS", "1") != "0"     # 2x2 phase forms of the up-sampled forward / stride-2 data gradient
-FUSE_BNBWD = os.environ.get("CTL_FUSE_BNBWD", "0") == "1"   # BN1-backward reduction inside the dgrad conv epilogue (measured: no gain)
+FUSE_BNBWD = os.environ.get("CTL_FUSE_BNBWD", "0") == "1"   # BN1-backward reduction inside the dgrad conv epilogue (fp32, measured: no gain)
+FUSE_BNBWD16 = os.environ.get("CTL_FUSE_BNBWD16", "1") == "1"   # the same in the bf16 family, where the data gradient is not matrix-bound
 CONV_WORDS = _ffi.CONV_DTYPE.itemsize // 4      # ctl_conv as int32 words at the head of ctl_op.i
 ALIGN_F = 64            # floats (256 B)
 FIN_HEADER = _ffi.FIN_HEADER_BYTES      # head of every plan scratch buffer: fused-finalize record table (ctl_hip.h)
@@ -222,7 +223,7 @@ class PlanBuilder:
         assert (out.n, out.h, out.w, out.c) == (x.n, oh, ow, cout), (out, x.n, oh, ow, cout)
         dt = 0
         if self.b16:        # bf16 MFMA family; which of x / y / res is STORED as bf16 follows from where the tensor lives
-            assert bnbwd is None, "CTL_EPI_BNBWD is an fp32-only epilogue"
+            assert bnbwd is None or (x.b16 and out.b16 and bnbwd[0].b16), "CTL_EPI_BNBWD (bf16): x, y and u must be bf16-stored"
             dt = _ffi.DT_BF16 | (_ffi.DT_X16 if x.b16 else 0) | (_ffi.DT_Y16 if out.b16 else 0) | (_ffi.DT_RES16 if res is not None and res[0].b16 else 0)
         d = self._conv_desc(x, cout, ks, stride, in_mode, hout, wout, pro, flags, act, slope, nsub, pad, dt)
         op = self.op(_ffi.OP_CONV)
@@ -359,7 +360,6 @@ class PlanBuilder:
 
     def bn_backward_from_stats(self, g: T, bn_src: T, bn: BNInfo, co, stats_ref, blocks, *, dx: T, affine_grad: bool):
         """BatchNorm backward whose reduction already happened in the producing conv (conv(..., bnbwd=...)): finalize + apply."""
-        assert not self.b16
         c, pixels, G = bn_src.c, bn_src.n * bn_src.h * bn_src.w, self.groups
         coef = self.bscr.alloc(4 * 3 * c * G)
         op = self.op(_ffi.OP_BN_BWD_FINALIZE)
@@ -370,6 +370,7 @@ class PlanBuilder:
             self.set_t(op, idx, ref)
         op = self.op(_ffi.OP_BWD_APPLY)
         op["i"][0], op["i"][1], op["i"][2] = 2, c, G
+        op["i"][25] = self.mask(g, None, bn_src, None, dx)
         op["l"][0] = pixels
         for idx, ref in enumerate([g.ref, None, bn_src.ref, None, None, coef, None, dx.ref]):
             self.set_t(op, idx, ref)
@@ -739,7 +740,7 @@ class CtlNet(nn.Module):
             pb.wgrad(u, dv, 3, pro=pro1, dw_ref=pb.G(c3.w_off), strides=(c3.cin * k9, k9, 3, 1), dbias_ref=pb.G(c3.b_off))
         # dgrad of conv.3; its epilogue already multiplies by leaky'(BN1(u)) and takes the BatchNorm-backward sums (no
         # separate reduction pass); the apply runs in place
-        if FUSE_BNBWD and not pb.b16:
+        if (FUSE_BNBWD and not pb.b16) or (FUSE_BNBWD16 and pb.b16 and dv.b16 and u.b16):
             g1, st, blk = pb.conv(dv, self._wp_ref(c3.wp_dgrad), c3.cin, 3, arena=A,
                                   bnbwd=(u, rec["co1"]["scale"], rec["co1"]["shift"], SLOPE))
             pb.bn_backward_from_stats(g1, u, B[prefix + ".conv.1"], rec["co1"], st, blk, dx=g1, affine_grad=need_w and affine)
