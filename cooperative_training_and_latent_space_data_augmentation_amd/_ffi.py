@@ -18,7 +18,7 @@ RED_BLOCKS = 512
 FIN_REC_BYTES, FIN_MAX_RECS = 128 + 4 * 9 * 128, 85      # ctl_hip.h: CTL_FIN_*
 FIN_HEADER_BYTES = FIN_REC_BYTES * FIN_MAX_RECS
 (OP_CONV, OP_WGRAD, OP_WGRAD_REDUCE, OP_PACK, OP_BN_FINALIZE, OP_BN_EVAL, OP_BN_ACT, OP_BWD_REDUCE, OP_BN_BWD_FINALIZE,
- OP_BWD_APPLY, OP_CHAN_SUM_FINALIZE, OP_SUMPOOL2, OP_SIGMOID_BWD, OP_ZERO, OP_COPY, OP_PACK_BATCH, OP_WGRAD_REDUCE_BATCH) = range(1, 18)
+ OP_BWD_APPLY, OP_CHAN_SUM_FINALIZE, OP_SUMPOOL2, OP_SIGMOID_BWD, OP_ZERO, OP_COPY, OP_PACK_BATCH, OP_WGRAD_REDUCE_BATCH, OP_DROPOUT2D) = range(1, 19)
 OP_MAX_T = 12
 
 CONV_DTYPE = np.dtype([

@@ -20,6 +20,8 @@
 //   COPY              0 src 1 dst                                        l[0]=bytes
 //   PACK_BATCH        0 params 1 wpack 2 table                           i[0]=n_rec i[1]=bf16 fragments l[0]=max_total
 //   WGRAD_REDUCE_BATCH 0 scratch 1 grad 2 table                          i[0]=n_rec l[0]=max_elems
+//   DROPOUT2D         0 z 1 keep (given pattern, optional) 2 state (device RNG state, optional) 3 out 4 keep_out (optional)
+//                                                                        i[0..2]=n,hw,c f[0]=p l[0]=seed (no state) | call-site salt (state)
 #include <stdarg.h>
 #include <stdlib.h>
 #include <string.h>
@@ -322,6 +324,9 @@ extern "C" int ctl_plan_run(const ctl_op* ops, int32_t n_ops, void* const* bases
                 break;
             case CTL_OP_WGRAD_REDUCE_BATCH:
                 rc = ctl_wgrad_reduce_batched(CF(0), F(1), (const int64_t*)t[2], op.i[0], op.l[0], stream);
+                break;
+            case CTL_OP_DROPOUT2D:      // nn.Dropout2d behind a residual block (encoder_decoder.py:58-66); backward = the same op on dy with the saved pattern
+                rc = ctl_dropout2d_ex(CF(0), CF(1), (uint64_t)op.l[0], (const int64_t*)t[2], op.f[0], F(3), F(4), nullptr, op.i[0], op.i[1], op.i[2], stream);
                 break;
             case CTL_OP_COPY: {
                 CTL_REQUIRE(t[0] && t[1] && op.l[0] > 0, "plan_run: op %d COPY needs two pointers and a size", k);

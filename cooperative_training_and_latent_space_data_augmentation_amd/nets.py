@@ -34,8 +34,8 @@ import torch.nn as nn
 from . import _ffi, init as _init
 from ._ffi import lib, check, OP_DTYPE
 
-(S_X, S_P, S_B, S_NBT, S_WP, S_ACT, S_SCR, S_OUT0, S_OUT1, S_DOUT0, S_DOUT1, S_GRAD, S_DX, S_BSCR, S_TAB) = range(15)
-N_SLOTS = 15
+(S_X, S_P, S_B, S_NBT, S_WP, S_ACT, S_SCR, S_OUT0, S_OUT1, S_DOUT0, S_DOUT1, S_GRAD, S_DX, S_BSCR, S_TAB, S_STATE, S_KEEP) = range(17)
+N_SLOTS = 17
 SLOPE = 0.2
 EPS = 1e-5
 MOMENTUM = 0.1
@@ -403,6 +403,18 @@ class PlanBuilder:
         for idx, ref in enumerate([dy.ref, y.ref, dx.ref]):
             self.set_t(op, idx, ref)
 
+    def dropout(self, z: T, out: T, p: float, *, keep_in=None, keep_out=None, salt: int = 0):
+        """nn.Dropout2d (whole channels per sample, scaled by 1/(1-p)).  keep_in = ref of a given [n][c] pattern (backward pass, injected
+        patterns); otherwise the pattern is drawn on the device from the network's RNG state (S_STATE) and this call site's salt and
+        written to keep_out."""
+        assert not (z.b16 or out.b16), "Dropout2d inside the networks runs on fp32 tensors"
+        op = self.op(_ffi.OP_DROPOUT2D)
+        op["i"][0], op["i"][1], op["i"][2] = z.n, z.h * z.w, z.c
+        op["f"][0] = p
+        op["l"][0] = salt
+        for idx, ref in enumerate([z.ref, keep_in, None if keep_in is not None else (S_STATE, 0), out.ref, keep_out]):
+            self.set_t(op, idx, ref)
+
     def zero(self, ref, nbytes):
         op = self.op(_ffi.OP_ZERO)
         op["l"][0] = nbytes
@@ -451,6 +463,10 @@ class CtlNet(nn.Module):
         self._pass_seq = 0
         self._scr: Optional[dict] = None          # stream handle -> scratch tensor
         self._arenas = ArenaPool()
+        # nn.Dropout2d behind every residual block (encoder_decoder.py:58-66; `encoder_dropout` / `decoder_dropout`, None upstream's default)
+        self.drop_p: Optional[float] = None
+        self._drop_state: Optional[torch.Tensor] = None      # device int64[3]: seed, pass counter (advanced by ctl_step_tick), unused
+        self._drop_keep: Optional[torch.Tensor] = None       # injected patterns (tests): the blocks' [n][c] rows concatenated
         self._build_tree()
         self._finalize_storage(torch.device(device))
 
@@ -683,6 +699,20 @@ class CtlNet(nn.Module):
         check(lib.ctl_plan_run(plan.ops.ctypes.data, plan.n_ops, bases, N_SLOTS, stream.cuda_stream),
               f"{type(self).__name__} plan")
 
+    def set_dropout(self, p: Optional[float]):
+        """nn.Dropout2d(p) behind every residual block in training mode (None: off, upstream's default)."""
+        if p is not None:
+            if not (0.0 <= float(p) < 1.0):
+                raise ValueError(f"dropout probability {p!r} must be in [0, 1)")
+            if self.bf16:
+                raise NotImplementedError("encoder/decoder Dropout2d is only offered with compute_dtype='fp32'")
+        self.drop_p = None if p is None else float(p)
+
+    def set_dropout_keep(self, patterns):
+        """Test hook: inject the keep patterns of one forward pass ([n, c] tensors of 0/1, one per residual block in forward order;
+        None: draw on the device again)."""
+        self._drop_keep = None if patterns is None else torch.cat([t.reshape(-1).float() for t in patterns]).to(self.device).contiguous()
+
     def bn_mode(self) -> str:
         if not self.training:
             return "C"
@@ -721,6 +751,20 @@ class CtlNet(nn.Module):
         out, _, _ = pb.conv(src, self._wp_ref(c1.wp_fwd), c1.cout, 1, in_mode=src_mode, bias_ref=pb.P(c1.b_off),
                             res=(v, co2["scale"], co2["shift"]), act=_ffi.ACT_LEAKY, slope=SLOPE)
         rec.update(src=src, src_mode=src_mode, u=u, v=v, out=out, co1=co1, co2=co2)
+        if self.drop_p is not None and train:
+            # res_x = self.drop(res_x): the block hands on the dropped tensor, keeps `out` (the LeakyReLU derivative needs its sign)
+            # and the [n][c] pattern for the backward pass
+            keep = pb.act.alloc(4 * out.n * out.c)
+            dropped = pb.act.tensor(out.n, out.h, out.w, out.c)
+            idx = getattr(pb, "_n_drop", 0)
+            pb._n_drop = idx + 1
+            keep_in = None
+            if self._drop_keep is not None:
+                keep_in = (S_KEEP, 4 * getattr(pb, "_keep_off", 0))
+                pb._keep_off = getattr(pb, "_keep_off", 0) + out.n * out.c
+            pb.dropout(out, dropped, float(self.drop_p), keep_in=keep_in, keep_out=keep, salt=0x5D0 + idx)
+            rec["drop"] = (keep, float(self.drop_p))
+            return dropped, rec
         return out, rec
 
     def _emit_block_bwd(self, pb: PlanBuilder, rec: dict, d_out: T, d_in: Optional[T], need_w: bool, affine: bool) -> T:
@@ -731,6 +775,10 @@ class CtlNet(nn.Module):
         src, src_mode, u, v, out, xin = rec["src"], rec["src_mode"], rec["u"], rec["v"], rec["out"], rec["xin"]
         c0, c3, c1 = C[prefix + ".conv.0"], C[prefix + ".conv.3"], C[prefix + ".conv_input"]
         A = pb.bscr
+        if rec.get("drop") is not None:      # Dropout2d backward: the gradient times the saved pattern (and 1/(1-p))
+            d_pre = A.tensor(out.n, out.h, out.w, out.c)
+            pb.dropout(d_out, d_pre, rec["drop"][1], keep_in=rec["drop"][0])
+            d_out = d_pre
         # residual tail: dS (to conv_input) and dV (to conv.3)
         ds, dv = A.tensor(out.n, out.h, out.w, out.c), A.tensor(out.n, out.h, out.w, out.c)
         pb.bn_backward(0, d_out, out, v, B[prefix + ".conv.4"], rec["co2"], SLOPE, ds=ds, dx=dv, affine_grad=need_w and affine)
@@ -827,7 +875,7 @@ class CtlNet(nn.Module):
             raise ValueError(f"{type(self).__name__}: expected {self.cin} input channels, got {c}")
         if groups < 1 or n % groups:
             raise ValueError(f"{type(self).__name__}: batch {n} cannot be split into {groups} groups")
-        key = ("f", n, h, w, mode, groups)
+        key = ("f", n, h, w, mode, groups, self.drop_p, self._drop_keep is not None)
         plan = self._plans.get(key)
         if plan is None:
             self._cur_groups = groups
@@ -841,6 +889,15 @@ class CtlNet(nn.Module):
         tensors = {S_X: x, S_P: self._flat_data, S_B: self._bflat, S_NBT: self._nbt, S_WP: self._wp, S_ACT: act.t, S_OUT0: outs[0]}
         if len(outs) > 1:
             tensors[S_OUT1] = outs[1]
+        if self.drop_p is not None and mode != "C":
+            if self._drop_keep is not None:
+                tensors[S_KEEP] = self._drop_keep
+            else:
+                if self._drop_state is None:      # (drawn at first use: the construction-time RNG order of the weight init stays upstream's)
+                    from .model_util import _draw_seed
+                    self._drop_state = torch.tensor([_draw_seed() & (2 ** 62 - 1), 0, 0], dtype=torch.int64, device=self.device)
+                check(lib.ctl_step_tick(self._drop_state.data_ptr(), torch.cuda.current_stream().cuda_stream), "ctl_step_tick")
+                tensors[S_STATE] = self._drop_state
         self._run(plan, tensors)
         return tuple(outs), act, plan
 
@@ -848,7 +905,7 @@ class CtlNet(nn.Module):
         """Returns (dx or None, flat parameter gradient or None)."""
         n, c, h, w = x.shape
         mask = tuple(d is not None for d in douts)
-        key = ("b", n, h, w, mode, mask, need_dx, need_w, affine, fwd_plan.groups)
+        key = ("b", n, h, w, mode, mask, need_dx, need_w, affine, fwd_plan.groups, id(fwd_plan))
         plan = self._plans.get(key)
         if plan is None:
             self._cur_groups = fwd_plan.groups
@@ -1108,7 +1165,8 @@ class MyDecoder(CtlNet):
 
 
 def build_networks(image_ch: int = 1, num_classes: int = 4, reduce_factor: int = 4, device="cuda",
-                   state_dicts: Optional[dict] = None, dtype: str = "fp32") -> Dict[str, CtlNet]:
+                   state_dicts: Optional[dict] = None, dtype: str = "fp32", encoder_dropout: Optional[float] = None,
+                   decoder_dropout: Optional[float] = None) -> Dict[str, CtlNet]:
     """`get_network('FCN_16_standard')` (model.py:76-149).  Without `state_dicts` the weights are drawn exactly like the
     reference does for the current torch seed (see init.py)."""
     z = 512 // reduce_factor
@@ -1126,4 +1184,6 @@ def build_networks(image_ch: int = 1, num_classes: int = 4, reduce_factor: int =
     for k, net in nets.items():
         if k in sds and sds[k] is not None:
             net.load_state_dict(sds[k])
+        # model.py:92-106: encoder_dropout -> image_encoder, shape_encoder; decoder_dropout -> the three decoders
+        net.set_dropout(encoder_dropout if k.endswith("encoder") else decoder_dropout)
     return nets

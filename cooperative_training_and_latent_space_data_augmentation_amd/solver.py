@@ -48,8 +48,8 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
         self.compute_dtype = compute_dtype or os.environ.get("CTL_DTYPE", "fp32")
         if network_type not in ("FCN_16_standard", "FCN_16_standard_w_o_filter", "FCN_16_standard_share_code"):
             raise NotImplementedError(network_type)
-        if encoder_dropout is not None or decoder_dropout is not None:
-            raise NotImplementedError("encoder/decoder Dropout2d is unused by the reference configs (dropout=None)")
+        if (encoder_dropout is not None or decoder_dropout is not None) and self.compute_dtype == "bf16":
+            raise NotImplementedError("encoder/decoder Dropout2d is only offered with compute_dtype='fp32'")
         if not use_gpu:
             raise RuntimeError("this engine runs on MI355X only (use_gpu=True); the CPU path is the oracle under oracle/")
         self.network_type, self.image_ch, self.checkpoint_dir = network_type, image_ch, checkpoint_dir
@@ -95,7 +95,8 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
     def get_network(self, checkpoint_dir=None):
         """model.py:76-149: fresh weights follow the reference's init for the current torch seed; with a checkpoint
         directory, `<name>.pth` state dicts are loaded (model.py:114-131,157-173)."""
-        model = build_networks(self.image_ch, self.num_classes, 4, device=self.device, dtype=self.compute_dtype)
+        model = build_networks(self.image_ch, self.num_classes, 4, device=self.device, dtype=self.compute_dtype,
+                               encoder_dropout=self.encoder_dropout, decoder_dropout=self.decoder_dropout)
         if checkpoint_dir:
             for name, net in model.items():
                 self.init_model(net, resume_path=join(checkpoint_dir, name + ".pth"))

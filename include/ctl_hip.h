@@ -327,7 +327,7 @@ enum ctl_op_kind {
     CTL_OP_CONV = 1, CTL_OP_WGRAD = 2, CTL_OP_WGRAD_REDUCE = 3, CTL_OP_PACK = 4, CTL_OP_BN_FINALIZE = 5,
     CTL_OP_BN_EVAL = 6, CTL_OP_BN_ACT = 7, CTL_OP_BWD_REDUCE = 8, CTL_OP_BN_BWD_FINALIZE = 9, CTL_OP_BWD_APPLY = 10,
     CTL_OP_CHAN_SUM_FINALIZE = 11, CTL_OP_SUMPOOL2 = 12, CTL_OP_SIGMOID_BWD = 13, CTL_OP_ZERO = 14, CTL_OP_COPY = 15, CTL_OP_PACK_BATCH = 16,
-    CTL_OP_WGRAD_REDUCE_BATCH = 17
+    CTL_OP_WGRAD_REDUCE_BATCH = 17, CTL_OP_DROPOUT2D = 18
 };
 #define CTL_OP_MAX_T 12
 typedef struct ctl_op {

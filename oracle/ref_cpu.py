@@ -57,6 +57,19 @@ def _init_direct_conv_children(mod: nn.Module) -> None:
             child.bias.data.zero_()
 
 
+def _block_dropout(mod: nn.Module, res_x: torch.Tensor) -> torch.Tensor:
+    """`res_x = self.drop(res_x)` (encoder_decoder.py:58-66, 338-347): nn.Dropout2d in training mode.  `mod.keep` (a [n, c] tensor of 0/1,
+    test hook) replaces the Bernoulli draw so that two implementations can be compared on the same pattern."""
+    p = getattr(mod, "drop_p", None)
+    if p is None or not mod.training:
+        return res_x
+    keep = getattr(mod, "keep", None)
+    if keep is None:
+        keep = (torch.rand(res_x.shape[0], res_x.shape[1]) >= p).to(res_x.dtype)
+    mod.last_keep = keep
+    return res_x * keep.to(res_x.dtype)[:, :, None, None] * (1.0 / (1.0 - p))
+
+
 class DownBlock(nn.Module):
     """`res_convdown` (encoder_decoder.py:19-68): x'=conv3x3 s2; out=LReLU(conv1x1(x') + dconv(x'))."""
 
@@ -69,7 +82,7 @@ class DownBlock(nn.Module):
 
     def forward(self, x):
         x = self.down(x)
-        return self.last_act(self.conv_input(x) + self.conv(x))
+        return _block_dropout(self, self.last_act(self.conv_input(x) + self.conv(x)))
 
 
 class UpBlock(nn.Module):
@@ -89,7 +102,7 @@ class UpBlock(nn.Module):
 
     def forward(self, x):
         x = self.up(x)
-        return self.last_act(self.conv_input(x) + self.conv(x))
+        return _block_dropout(self, self.last_act(self.conv_input(x) + self.conv(x)))
 
 
 class Encoder(nn.Module):
@@ -151,6 +164,15 @@ class Decoder(nn.Module):
     def forward(self, x):
         x = self.final_conv(self.up4(self.up3(self.up2(self.up1(x)))))
         return x if self.last_act is None else self.last_act(x)
+
+
+def set_dropout(net: nn.Module, p: Optional[float], patterns=None) -> None:
+    """`encoder_dropout` / `decoder_dropout` of model.py:92-106 on one network: Dropout2d(p) behind every residual block; `patterns`
+    (list of [n, c] tensors in forward order) injects the keep patterns."""
+    blocks = [m for m in net.modules() if isinstance(m, (DownBlock, UpBlock))]
+    for i, m in enumerate(blocks):
+        m.drop_p = p
+        m.keep = None if patterns is None else patterns[i]
 
 
 def kaiming_init_(net: nn.Module) -> None:

@@ -257,3 +257,32 @@ def test_surface_distance_scores_vs_reference(io_cases):
         M.hd(empty[0], full[0])
     with pytest.raises(ValueError):
         M.runningMySegmentationScore(3, metrics_list=["HD"]).update("x", np.ones((2, 8, 8), np.uint8), np.ones((2, 8, 8), np.int64))
+
+
+def test_oracle_block_dropout_is_dropout2d():
+    """`_block_dropout` == nn.Dropout2d's arithmetic (whole (sample, channel) planes, survivors scaled by 1/(1-p)), identity in eval mode;
+    an injected pattern replaces the draw.  (The reference draws from torch's Bernoulli stream inside nn.Dropout2d, encoder_decoder.py:58-66;
+    that stream is not reproducible on the device, hence the injection hook -- the ARITHMETIC is what the engine test compares.)"""
+    import torch.nn.functional as F
+    nets_ = O.build_networks(init=True)
+    dec = nets_["shape_decoder"]
+    blocks = [m for m in dec.modules() if isinstance(m, O.UpBlock)]
+    x = torch.relu(torch.randn(2, 128, 4, 4, generator=torch.Generator().manual_seed(0)))
+    keep = (torch.rand(2, blocks[0].conv_input.out_channels, generator=torch.Generator().manual_seed(1)) >= 0.4).float()
+    dec.train()
+    with O.bn_no_track(dec):
+        ref = blocks[0](x)                                   # dropout off
+        O.set_dropout(dec, 0.4, [keep, None, None, None])
+        got = blocks[0](x)
+    assert torch.allclose(got, ref * keep[:, :, None, None] / 0.6)
+    # the same planes nn.Dropout2d would zero, the same scale
+    torch.manual_seed(3)
+    d2 = F.dropout2d(ref, 0.4, training=True)
+    kept = (d2.abs().sum((2, 3)) > 0).float()
+    assert torch.allclose(d2, ref * kept[:, :, None, None] / 0.6)
+    dec.eval()
+    with torch.no_grad():
+        O.set_dropout(dec, None)
+        e0 = dec(x)
+        O.set_dropout(dec, 0.4)
+        assert torch.equal(dec(x), e0)
