@@ -236,6 +236,12 @@ def main():
         for _ in range(3):
             eager_step()
         fence()
+    # launches of one step: the library's own census over one eager step (untimed; the graph replays the same launches as nodes) +
+    # what ATen adds (fills / copies / cats: counted by the profiler once in tools/aten_ops_in_step.py, ~45 per step, not re-counted here)
+    n0 = _ffi.lib.ctl_launch_count()
+    eager_step()
+    fence()
+    launches_per_step = int(_ffi.lib.ctl_launch_count() - n0)
     phase_tm = None
     if rank == 0 and os.environ.get("CTL_HIP_LIB") and hasattr(_ffi.lib, "ctl_debug_timing"):
         import ctypes                                     # -DCTL_TIMING variant build: per-phase cycle counters of the conv kernel
@@ -306,6 +312,8 @@ def main():
                         "note": "GPU time between consecutive per-step events on the launch stream (rank 0)"},
             "cpu_issue_ms": {"median": 1e3 * sorted(issue_s)[len(issue_s) // 2], "max": 1e3 * max(issue_s)},
             "device_allocs_in_timed_region": int(allocs_in_region),
+            "launches_per_step": {"library": launches_per_step, "note": "kernels + stream memsets / copies enqueued by libctl_hip.so in one step "
+                                  "(ctl_launch_count); PyTorch adds ~45 fills / copies per step (tools/aten_ops_in_step.py)"},
         }
         def roofline_of(kid, rec, region_s=None):
             secs = rec["ms"] * 1e-3

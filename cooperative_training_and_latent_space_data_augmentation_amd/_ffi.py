@@ -63,6 +63,7 @@ class _Lib:
         lib = C.CDLL(LIB_PATH)
         lib.ctl_last_error.restype = C.c_char_p
         lib.ctl_version.restype = C.c_int
+        lib.ctl_launch_count.restype = C.c_ulonglong
         for name in ("ctl_conv_wpack_floats", "ctl_conv_stats_floats", "ctl_wgrad_partial_floats",
                      "ctl_wgrad_bias_partial_floats", "ctl_latent_score_ws_floats", "ctl_latent_mask_apply_ws_floats",
                      "ctl_rescale_intensity_ws_floats", "ctl_sizeof_op", "ctl_sizeof_conv", "ctl_latent_mask_fused_ws_floats"):
@@ -152,7 +153,7 @@ EXPORTED = ["ctl_version", "ctl_last_error", "ctl_conv_wpack_floats", "ctl_conv_
             "ctl_noise_clamp", "ctl_crop_or_pad", "ctl_step_tick", "ctl_dropout2d_ex", "ctl_uniform_dev", "ctl_adam_dev",
             "ctl_latent_mask_fused_ws_floats", "ctl_latent_mask_fused", "ctl_accumulate", "ctl_pack_weights_bf16_batched",
             "ctl_bn_act_dt", "ctl_bwd_reduce_dt", "ctl_bwd_apply_dt", "ctl_sumpool2_dt", "ctl_conv_forward_fin", "ctl_bn_fin_table_write",
-            "ctl_bwd_reduce_fin", "ctl_bwd_reduce_rows"]
+            "ctl_bwd_reduce_fin", "ctl_bwd_reduce_rows", "ctl_launch_count"]
 
 
 def prof_start(kernel_filter: str = "") -> None:

@@ -19,8 +19,10 @@ void ctl_set_error(const char* fmt, ...);
     } while (0)
 
 // every launcher ends with this: catches bad launch configurations without synchronising
+void ctl_count_launches(int n);      // launch census (ctl_launch_count): every launcher counts ONE here, multi-kernel launchers add the rest
 #define CTL_LAUNCH_CHECK(name)                                                         \
     do {                                                                               \
+        ctl_count_launches(1);                                                         \
         hipError_t e__ = hipGetLastError();                                            \
         if (e__ != hipSuccess) CTL_FAIL(CTL_ELAUNCH, "%s: %s", name, hipGetErrorString(e__)); \
     } while (0)

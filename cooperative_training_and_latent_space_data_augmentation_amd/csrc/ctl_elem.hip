@@ -897,6 +897,7 @@ extern "C" int ctl_ce2d_fwd(const float* logit, const int64_t* label, int64_t pi
     CTL_REQUIRE(logit && label && partial && loss && pixels > 0 && c > 0 && c <= MAXC, "ce2d_fwd: bad arguments");
     CTL_ROW_DISPATCH(ce2d_partial_kernel, rows_vec4(c, logit), dim3(CTL_RED_BLOCKS), logit, label, pixels, c, partial);
     scalar_finalize_kernel<<<dim3(1), dim3(EB), 0, S_>>>(partial, CTL_RED_BLOCKS, 1.0 / (double)pixels, loss);
+    ctl_count_launches(1);      // partial + finalize
     CTL_LAUNCH_CHECK("ce2d_fwd");
     return CTL_OK;
 }
@@ -912,6 +913,7 @@ extern "C" int ctl_mse_fwd(const float* a, const float* b, int64_t count, float 
     CTL_REQUIRE(a && b && partial && loss && count > 0, "mse_fwd: bad arguments");
     mse_partial_kernel<<<dim3(CTL_RED_BLOCKS), dim3(EB), 0, S_>>>(a, b, count, partial);
     scalar_finalize_kernel<<<dim3(1), dim3(EB), 0, S_>>>(partial, CTL_RED_BLOCKS, (double)scale / (double)count, loss);
+    ctl_count_launches(1);      // partial + finalize
     CTL_LAUNCH_CHECK("mse_fwd");
     return CTL_OK;
 }

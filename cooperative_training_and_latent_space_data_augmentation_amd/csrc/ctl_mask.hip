@@ -484,6 +484,7 @@ extern "C" int ctl_latent_score(int32_t mode, const float* grad, float* score, f
         const int splits = ctl_cdiv(hw, sp_pix);
         score_channel_partial_kernel<<<dim3(splits, n), dim3(MB), 0, s>>>((const f32x4*)grad, scratch, hw, cq, splits, sp_pix);
         score_channel_finalize_kernel<<<dim3(ctl_cdiv(c, 64), n), dim3(64), 0, s>>>(scratch, score, c, splits, 1.f / (float)hw);
+        ctl_count_launches(1);
     } else if (mode == 1) {
         const int64_t pixels = (int64_t)n * hw;
         const int ppb = MB / cq;
@@ -520,6 +521,7 @@ extern "C" int ctl_latent_mask_apply(int32_t mode, const float* code, const floa
         latent_threshold_kernel<<<dim3(n), dim3(MB), (size_t)lp2 * sizeof(float), s>>>(score, L, lp2, k_host, k_dev, scratch);
         mask_apply_thr_kernel<1><<<grid, dim3(MB), (size_t)sp * sizeof(float), s>>>((const f32x4*)code, score, soft_noise, scratch,
                                                                                    (f32x4*)masked, mask_out, hw, c / 4, sp);
+        ctl_count_launches(1);      // threshold + apply
         CTL_LAUNCH_CHECK("latent_mask_apply(thr)");
         return CTL_OK;
     }
@@ -592,6 +594,7 @@ extern "C" int ctl_latent_mask_fused(int32_t mode, const float* grad, const floa
         mask_apply_kernel<0><<<dim3(ctl_cdiv(hw, sp), n), dim3(MB), (size_t)(L + c) * sizeof(float), s>>>(
             (const f32x4*)code, nullptr, ws_score, splits, 1.f / (float)hw, score_out, soft_noise, k_host, k_dev, (f32x4*)masked, mask_out,
             hw, cq, sp);
+        ctl_count_launches(1);      // split sums + apply
         CTL_LAUNCH_CHECK("latent_mask_fused(stream)");
         return CTL_OK;
     }

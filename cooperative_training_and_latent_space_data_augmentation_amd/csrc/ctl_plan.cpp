@@ -38,6 +38,7 @@ void ctl_set_error(const char* fmt, ...) {
 }
 
 // ------------------------------------------------------------------------------------------------ profiling
+#include <atomic>
 #include <map>
 #include <string>
 #include <vector>
@@ -129,6 +130,9 @@ extern "C" int ctl_prof_stop(char* out, size_t cap) {
     return CTL_OK;
 }
 
+static std::atomic<unsigned long long> g_launches{0};
+void ctl_count_launches(int n) { g_launches.fetch_add((unsigned long long)n, std::memory_order_relaxed); }
+extern "C" unsigned long long ctl_launch_count(void) { return g_launches.load(std::memory_order_relaxed); }
 extern "C" int ctl_version(void) { return 1; }
 extern "C" const char* ctl_last_error(void) { return g_err; }
 extern "C" size_t ctl_sizeof_op(void) { return sizeof(ctl_op); }
@@ -314,6 +318,7 @@ extern "C" int ctl_plan_run(const ctl_op* ops, int32_t n_ops, void* const* bases
                 break;
             case CTL_OP_ZERO: {
                 CTL_REQUIRE(t[0] && op.l[0] > 0, "plan_run: op %d ZERO needs a pointer and a size", k);
+                ctl_count_launches(1);
                 hipError_t e = hipMemsetAsync(t[0], 0, (size_t)op.l[0], (hipStream_t)stream);
                 if (e != hipSuccess) CTL_FAIL(CTL_ELAUNCH, "plan_run: memset: %s", hipGetErrorString(e));
                 break;
@@ -330,6 +335,7 @@ extern "C" int ctl_plan_run(const ctl_op* ops, int32_t n_ops, void* const* bases
                 break;
             case CTL_OP_COPY: {
                 CTL_REQUIRE(t[0] && t[1] && op.l[0] > 0, "plan_run: op %d COPY needs two pointers and a size", k);
+                ctl_count_launches(1);
                 hipError_t e = hipMemcpyAsync(t[1], t[0], (size_t)op.l[0], hipMemcpyDeviceToDevice, (hipStream_t)stream);
                 if (e != hipSuccess) CTL_FAIL(CTL_ELAUNCH, "plan_run: memcpy: %s", hipGetErrorString(e));
                 break;

@@ -350,6 +350,8 @@ int ctl_plan_run(const ctl_op* ops, int32_t n_ops, void* const* bases, int32_t n
  *   "<id> launches=<n> ms=<total> flops=<sum> bytes=<sum>\n".  Not for use under graph capture. */
 int ctl_prof_start(const char* filter);
 int ctl_prof_stop(char* out, size_t cap);
+/* launch census: kernels / stream memsets / copies enqueued by this library since it was loaded (bench.py reports launches per step) */
+unsigned long long ctl_launch_count(void);
 size_t ctl_sizeof_op(void);
 size_t ctl_sizeof_conv(void);
 

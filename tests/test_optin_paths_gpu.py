@@ -1,0 +1,65 @@
+"""Opt-in execution paths that are OFF by default (measured slower or neutral on MI355X, kept for the record and for other parts):
+they must stay correct.  Each runs in a subprocess because the switches are read once per process.
+  CTL_FUSE_FINALIZE=1   BatchNorm finalize folded into the producing conv / reduction by the plan executor (ctl_plan.cpp)
+  CTL_FUSE_BNBWD=1      fp32 BatchNorm-backward reduction inside the data-gradient epilogue
+  CTL_SIDE_STREAM=1     weight gradients on a library-owned side stream (eager mode)"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SCRIPT = r"""
+import json, sys, torch
+sys.path.insert(0, %r)
+from cooperative_training_and_latent_space_data_augmentation_amd.solver import AdvancedTripletReconSegmentationModel
+from cooperative_training_and_latent_space_data_augmentation_amd import _ffi
+torch.manual_seed(0)
+s = AdvancedTripletReconSegmentationModel(use_gpu=True)
+g = torch.Generator().manual_seed(7)
+clean = torch.rand(4, 1, 96, 80, generator=g).cuda().contiguous(memory_format=torch.channels_last)
+label = torch.randint(0, 4, (4, 96, 80), generator=g).cuda()
+ci = {"loss_name": "mse", "mask_type": "channel", "max_threshold": 0.5, "random_threshold": False, "if_soft": False}
+cs = {"loss_name": "ce", "mask_type": "spatial", "max_threshold": 0.5, "random_threshold": False, "if_soft": False}
+out = []
+n0 = _ffi.lib.ctl_launch_count()
+for _ in range(2):
+    out.append([float(v) for v in s.cooperative_step(clean, label, clean, ci, cs)])
+torch.cuda.synchronize()
+launches = int(_ffi.lib.ctl_launch_count() - n0) // 2
+sums = {k: float(m._flat_data.double().sum()) for k, m in s.model.items()}
+bufs = {k: float(m._bflat.double().sum()) for k, m in s.model.items()}
+print("RESULT " + json.dumps({"losses": out, "sums": sums, "bufs": bufs, "launches": launches}))
+""" % ROOT
+
+
+def run(env_extra):
+    env = dict(os.environ, **env_extra)
+    r = subprocess.run([sys.executable, "-c", SCRIPT], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
+    assert line, r.stderr[-2000:]
+    return json.loads(line[0][7:])
+
+
+@pytest.fixture(scope="module")
+def default_run():
+    return run({})
+
+
+@pytest.mark.parametrize("env", [{"CTL_FUSE_FINALIZE": "1"}, {"CTL_FUSE_BNBWD": "1"}, {"CTL_SIDE_STREAM": "1"}])
+def test_optin_path_matches_default(env, default_run):
+    got = run(env)
+    for a, b in zip(got["losses"], default_run["losses"]):
+        for x, y in zip(a, b):
+            assert abs(x - y) <= 2e-5 * max(1.0, abs(y)), (env, a, b)
+    for k in default_run["sums"]:
+        # two Adam steps move every weight by ~+-lr = 1e-4: a gradient that is rounding noise around 0 (the order of the fp32 sums differs
+        # between the paths) may flip its sign and move the SUM of a network's ~1e6 weights by 2e-4 per flipped element
+        assert abs(got["sums"][k] - default_run["sums"][k]) <= 5e-2, (env, k, got["sums"][k], default_run["sums"][k])
+        assert abs(got["bufs"][k] - default_run["bufs"][k]) <= 1e-3 + 1e-4 * abs(default_run["bufs"][k]), (env, k)
+    if "CTL_FUSE_FINALIZE" in env:          # the stand-alone finalize launches are gone (one table-write launch per plan instead)
+        assert got["launches"] < default_run["launches"] - 100, (got["launches"], default_run["launches"])
