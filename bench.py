@@ -348,7 +348,7 @@ def main():
             out["roofline"]["note"] = ("timed region = hipGraph replays (no per-launch events possible): HIP events around every launch of this "
                                        "kernel in 5 eager single-stream steps run right after the timed region, same process, same inputs; "
                                        "rocprofv3 --kernel-trace agrees with this duration")
-        tfile = os.path.join(ROOT, "profiles", "dominant_kernel_traffic.json")      # committed rocprofv3 --pmc measurement
+        tfile = os.path.join(ROOT, "profiles", "dominant_kernel_traffic_bf16.json" if args.dtype == "bf16" else "dominant_kernel_traffic.json")      # committed rocprofv3 --pmc measurement
         if "roofline" in out and os.path.exists(tfile):
             t = json.load(open(tfile))
             if t.get("kernel") == out["roofline"]["kernel"]:

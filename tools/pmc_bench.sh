@@ -1,10 +1,12 @@
 #!/bin/bash
 # HBM traffic (FETCH_SIZE / WRITE_SIZE, separate passes) of every kernel of the bench workload; run via gpurun.
+#   tools/pmc_bench.sh [TAG [bench args...]]   ->  gpurun_out/pmc_bench_TAG/traffic_by_kernel.json
+tag=${1:-fp32}; shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-out=gpurun_out/pmc_bench; mkdir -p $out
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $out/fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $out/write.log 2>&1
-python - <<PY
+out=gpurun_out/pmc_bench_$tag; rm -rf $out; mkdir -p $out
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --mode eager "$@" > $out/fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --mode eager "$@" > $out/write.log 2>&1
+python3 - <<PY
 import csv, glob, collections, json
 def load(d, name):
     acc = collections.defaultdict(list)
@@ -21,5 +23,6 @@ for k in fe:
 rows.sort(reverse=True)
 res = {k: {"launches": n, "fetch_bytes_per_launch": f, "write_bytes_per_launch": w, "hbm_bytes_per_launch": f + w} for n, k, f, w in rows}
 json.dump(res, open("$out/traffic_by_kernel.json", "w"), indent=1)
-for n, k, f, w in rows[:12]: print(f"{k[:70]:70s} launches {n:5d}  fetch {f/1e6:8.1f} MB  write {w/1e6:8.1f} MB")
+for n, k, f, w in rows[:14]: print(f"{k[:70]:70s} launches {n:5d}  fetch {f/1e6:8.1f} MB  write {w/1e6:8.1f} MB")
 PY
+rm -rf $out/fetch $out/write
