@@ -346,6 +346,17 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? CTL16_OCC_BIG : CT
         wstore();
     }
     __syncthreads();
+    // Pipeline (two steps deep): while step `it` computes out of LDS, the registers hold step it+1 (requested one step earlier, staged
+    // after the MFMA phase) and step it+2 is requested right behind that staging -- BEFORE the epilogue's stores.  (Requested at the top
+    // of the loop, the loads waited ~800 cycles per tile for the previous epilogue's stores: same registers, in-order vmcnt.)
+    TileWalk nn = cur;                 // walker of the step whose loads are in flight next
+    int gn = 0;                        // its chunk
+    auto advance_nn = [&]() { gn = (gn + 1 == G_chunks) ? 0 : gn + 1; if (gn == 0) nn.next(); };
+    if (total_it > 1) {
+        advance_nn();
+        xs.load(rx, d, nn.n, nn.th * G::TH, nn.tw * TW, gn);
+        if (G_chunks > 1) wload(gn);
+    }
 
     // One 16-channel chunk (cin <= 16): the block's weight fragments never change -> read them from LDS ONCE into registers
     // (5 fragments x 4 VGPRs per cout tile for a 3x3 kernel) instead of once per tile.
@@ -405,10 +416,6 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? CTL16_OCC_BIG : CT
         const int g2 = (g + 1 == G_chunks) ? 0 : g + 1;
         const bool new_w = has_next && G_chunks > 1;
         if (g2 == 0) nxt.next();
-        if (has_next) {
-            xs.load(rx, d, nxt.n, nxt.th * G::TH, nxt.tw * TW, g2);
-            if (new_w) wload(g2);
-        }
         TM(0)
         if (g == 0) {
 #pragma unroll
@@ -477,6 +484,11 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? CTL16_OCC_BIG : CT
         TM(3)
         ctl_barrier_lds_writes_done();
         TM(4)
+        if (it + 2 < total_it) {       // step it+2: its loads have the whole next step to land
+            advance_nn();
+            xs.load(rx, d, nn.n, nn.th * G::TH, nn.tw * TW, gn);
+            if (G_chunks > 1) wload(gn);
+        }
 
         if (g == G_chunks - 1) {
             const int grp = n / group_n;

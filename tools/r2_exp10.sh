@@ -5,7 +5,7 @@ V=$PWD/cooperative_training_and_latent_space_data_augmentation_amd/csrc/variants
 timeout 900 python3 -m pytest tests/test_bf16_gpu.py tests/test_bf16_engine_gpu.py -x -q > $out/pytest_bf16.log 2>&1; tail -3 $out/pytest_bf16.log
 echo "== default build"; timeout 300 python3 tools/bench_conv16.py 2>&1 | grep -v RESULT | tee $out/conv16.txt
 echo "== phase timers"; CTL_HIP_LIB=$V/libctl_tm16.so timeout 300 python3 tools/bench_conv16.py 2>&1 | grep -v RESULT | tee $out/tm16.txt
-echo "== pf3"; CTL_HIP_LIB=$V/libctl_pf3.so timeout 300 python3 tools/bench_conv16.py 2>&1 | grep -v RESULT | head -4
+
 timeout 600 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --dtype bf16 > $out/bench_bf16.json 2> $out/bench_bf16.err
 python3 - <<PY
 import json
