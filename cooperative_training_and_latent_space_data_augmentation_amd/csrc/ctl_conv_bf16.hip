@@ -211,6 +211,9 @@ extern "C" int ctl_debug_timing16(unsigned long long* out12) {
 #ifndef CTL16_OCC
 #define CTL16_OCC 3
 #endif
+#ifndef CTL16_STORE16
+#define CTL16_STORE16 0      // 1: 16-byte epilogue stores through v_permlane16_swap (parity-green; measured: 18.0 vs 18.1 us on the 16->16 layer, +24 spilled VGPRs in the 32-channel instantiation -> off)
+#endif
 // FAST: the instantiation for the layers that carry the step -- bf16 in, bf16 out, whole 16-channel tiles on both sides, no residual /
 // accumulate operand, no activation (every 3x3 / 2x2 / 4x4 forward conv with statistics and every plain data gradient).  With those known
 // at compile time the epilogue is straight-line code (the generic one decides per fragment between fp32 / bf16 / 1-channel forms of
@@ -275,6 +278,14 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? CTL16_OCC_BIG : CT
 #pragma unroll
     for (int m = 0; m < MT; ++m)
         yrel[m] = ((wrow + m / TWT) * d.out_sy * d.out_w + ((m % TWT) * 16 + p) * d.out_sx) * d.cout + q * 4;
+    // 16-byte stores of bf16 results (FAST 1, whole tiles): lane rows q and q^1 exchange halves of two M-tiles (v_permlane16_swap), after
+    // which lane (p, q) holds 8 consecutive channels 8*(q>>1).. of pixel p of M-tile 2j + (q & 1): one b128 store instead of two b64
+    int yrel2[(MT + 1) / 2];
+#pragma unroll
+    for (int j = 0; j < (MT + 1) / 2; ++j) {
+        const int mt2 = 2 * j + (q & 1);
+        yrel2[j] = ((wrow + mt2 / TWT) * d.out_sy * d.out_w + ((mt2 % TWT) * 16 + p) * d.out_sx) * d.cout + (q >> 1) * 8;
+    }
     f32x4 bias4[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -580,12 +591,24 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? CTL16_OCC_BIG : CT
 #pragma unroll
                             for (int m = 0; m < MT; ++m) { ssum[t] += acc[m][t]; ssq[t] += acc[m][t] * acc[m][t]; }
                     }
+                    if constexpr (MT % 2 == 0 && CTL16_STORE16) {
 #pragma unroll
-                    for (int t = 0; t < NT; ++t)
+                        for (int t = 0; t < NT; ++t)
 #pragma unroll
-                        for (int m = 0; m < MT; ++m)
-                            __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack_bf16x2(acc[m][t].x, acc[m][t].y), pack_bf16x2(acc[m][t].z, acc[m][t].w)},
-                                                                  ry, (ybase + yrel[m] + t * 16) * 2, 0, CTL_STORE_AUX);
+                            for (int j = 0; j < MT / 2; ++j) {
+                                const f32x4 a = acc[2 * j][t], b = acc[2 * j + 1][t];
+                                const u32x2 r0 = __builtin_amdgcn_permlane16_swap(pack_bf16x2(a.x, a.y), pack_bf16x2(b.x, b.y), false, false);
+                                const u32x2 r1 = __builtin_amdgcn_permlane16_swap(pack_bf16x2(a.z, a.w), pack_bf16x2(b.z, b.w), false, false);
+                                __builtin_amdgcn_raw_buffer_store_b128(u32x4{r0.x, r1.x, r0.y, r1.y}, ry, (ybase + yrel2[j] + t * 16) * 2, 0, CTL_STORE_AUX);
+                            }
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < NT; ++t)
+#pragma unroll
+                            for (int m = 0; m < MT; ++m)
+                                __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack_bf16x2(acc[m][t].x, acc[m][t].y), pack_bf16x2(acc[m][t].z, acc[m][t].w)},
+                                                                      ry, (ybase + yrel[m] + t * 16) * 2, 0, CTL_STORE_AUX);
+                    }
                 } else {
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
