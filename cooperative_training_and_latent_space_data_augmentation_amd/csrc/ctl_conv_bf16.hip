@@ -211,6 +211,11 @@ extern "C" int ctl_debug_timing16(unsigned long long* out12) {
 #ifndef CTL16_OCC
 #define CTL16_OCC 3
 #endif
+// timing ablations (variant builds only, WRONG results): which resource bounds the kernel?  1 = no epilogue stores, 2 = no global loads
+// in the loop, 4 = no MFMA phase (bit mask)
+#ifndef CTL16_ABLATE
+#define CTL16_ABLATE 0
+#endif
 #ifndef CTL16_STORE16
 #define CTL16_STORE16 0      // 1: 16-byte epilogue stores through v_permlane16_swap (parity-green; measured: 18.0 vs 18.1 us on the 16->16 layer, +24 spilled VGPRs in the 32-channel instantiation -> off)
 #endif
@@ -479,11 +484,13 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? CTL16_OCC_BIG : CT
                     }
             }
         };
+        if (!(CTL16_ABLATE & 4)) {
         if constexpr (WREG) {
             if (wreg_on) mfma_phase(std::true_type{});
             else mfma_phase(std::false_type{});
         } else {
             mfma_phase(std::false_type{});
+        }
         }
         TM(1)
         ctl_barrier_lds_reads_done();
@@ -497,7 +504,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? CTL16_OCC_BIG : CT
         TM(4)
         if (it + 2 < total_it) {       // step it+2: its loads have the whole next step to land
             advance_nn();
-            xs.load(rx, d, nn.n, nn.th * G::TH, nn.tw * TW, gn);
+            if (!(CTL16_ABLATE & 2)) xs.load(rx, d, nn.n, nn.th * G::TH, nn.tw * TW, gn);
             if (G_chunks > 1) wload(gn);
         }
 
@@ -591,7 +598,12 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? CTL16_OCC_BIG : CT
 #pragma unroll
                             for (int m = 0; m < MT; ++m) { ssum[t] += acc[m][t]; ssq[t] += acc[m][t] * acc[m][t]; }
                     }
-                    if constexpr (MT % 2 == 0 && CTL16_STORE16) {
+                    if constexpr ((CTL16_ABLATE & 1) != 0) {
+#pragma unroll
+                        for (int t = 0; t < NT; ++t)
+#pragma unroll
+                            for (int m = 0; m < MT; ++m) ssum[t] += acc[m][t];
+                    } else if constexpr (MT % 2 == 0 && CTL16_STORE16) {
 #pragma unroll
                         for (int t = 0; t < NT; ++t)
 #pragma unroll
