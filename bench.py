@@ -212,14 +212,18 @@ def main():
                 raise
             calib["graph_error"], gstep = f"{type(exc).__name__}: {str(exc)[:160]}", None
     if mode == "auto":
-        def time_steps(fn, n=6):
+        def time_steps(fn, n=8):
             fence()
             t = time.perf_counter()
             for _ in range(n):
                 fn()
             fence()
             return 1e3 * (time.perf_counter() - t) / n
+        if rank == 0:                                     # as in the timed region: eager steps carry the per-launch events of the
+            _ffi.prof_start(args.prof_filter)             # dominant kernel (the roofline figure), graph replays cannot
         calib["eager_ms"] = time_steps(eager_step)
+        if rank == 0:
+            _ffi.prof_stop()
         if gstep is not None:
             calib["graph_ms"] = time_steps(graph_step)
         pick = torch.tensor([1.0 if (gstep is not None and calib["graph_ms"] < calib["eager_ms"]) else 0.0], device=device)

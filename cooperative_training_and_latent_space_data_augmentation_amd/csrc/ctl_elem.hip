@@ -55,31 +55,7 @@ __device__ __forceinline__ double block_sum_double(double v, double* sm) {
     return r;  // valid on thread 0
 }
 
-// Storage-type aware quad access for the kernels that touch network-internal tensors: with BASELINE config 3 those are stored as bf16
-// (`m` = bit mask over the kernel's tensor arguments, bit set = bf16 storage); arithmetic is fp32 either way, a store rounds once (RNE).
-typedef unsigned int u32x2e __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2e __attribute__((ext_vector_type(2)));
-typedef float f32x2e __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x4 ldq(const void* __restrict__ p, int64_t i, bool b16) {
-    if (b16) {
-        const u32x2e u = reinterpret_cast<const u32x2e*>(p)[i];
-        return f32x4{__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u),
-                     __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xffff0000u)};
-    }
-    return reinterpret_cast<const f32x4*>(p)[i];
-}
-#ifndef CTL_ELEM_NT
-#define CTL_ELEM_NT 0        // experiment hook: 1 = non-temporal stores of the element-wise kernels' output tensors
-#endif
-__device__ __forceinline__ void stq(void* __restrict__ p, int64_t i, f32x4 v, bool b16) {
-    if (b16) {
-        const u32x2e pk = u32x2e{__builtin_bit_cast(unsigned, __builtin_convertvector(f32x2e{v.x, v.y}, bf16x2e)),
-                                 __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2e{v.z, v.w}, bf16x2e))};
-        if (CTL_ELEM_NT) __builtin_nontemporal_store(pk, reinterpret_cast<u32x2e*>(p) + i); else reinterpret_cast<u32x2e*>(p)[i] = pk;
-    } else {
-        if (CTL_ELEM_NT) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p) + i); else reinterpret_cast<f32x4*>(p)[i] = v;
-    }
-}
+// (ldq / stq, the storage-type aware quad accessors, live in ctl_common.h)
 
 // ------------------------------------------------------------------------------------------------ BatchNorm forward
 __global__ __launch_bounds__(EB) void bn_finalize_kernel(const float* __restrict__ partial, int blocks, int c,

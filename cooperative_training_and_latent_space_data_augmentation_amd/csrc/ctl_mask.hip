@@ -424,10 +424,12 @@ __device__ __forceinline__ uint64_t state_seed(const int64_t* __restrict__ state
     z = (z ^ (z >> 32)) * 0xBF58476D1CE4E5B9ull;
     return z ^ (z >> 29);
 }
-__global__ __launch_bounds__(MB) void dropout2d_kernel(const f32x4* __restrict__ z, const float* __restrict__ keep,
+// `m`: storage of z (bit 0) / out (bit 1): set = bf16 (network-internal tensors of BASELINE config 3); the product is formed in fp32 and
+// rounded once by the store.  mask_full is fp32 (latent-code form only).
+__global__ __launch_bounds__(MB) void dropout2d_kernel(const void* __restrict__ z, const float* __restrict__ keep,
                                                         uint64_t seed, const int64_t* __restrict__ state, float p,
-                                                        f32x4* __restrict__ out, float* __restrict__ keep_out,
-                                                        f32x4* __restrict__ mask_full, int hw, int cq, int slab_pix) {
+                                                        void* __restrict__ out, float* __restrict__ keep_out,
+                                                        f32x4* __restrict__ mask_full, int hw, int cq, int slab_pix, unsigned m) {
     extern __shared__ __attribute__((aligned(16))) float sm[];     // [c] multipliers
     const int c = cq * 4, n = blockIdx.y;
     const float inv = 1.f / (1.f - p);
@@ -442,11 +444,11 @@ __global__ __launch_bounds__(MB) void dropout2d_kernel(const f32x4* __restrict__
     const int64_t base = ((int64_t)n * hw + p0) * cq;
     const int quads = (p1 - p0) * cq;
     for (int e = threadIdx.x; e < quads; e += MB) {
-        f32x4 v = z[base + e];
-        const f32x4 m = reinterpret_cast<const f32x4*>(sm)[e % cq];
+        f32x4 v = ldq(z, base + e, m & 1);
+        const f32x4 k4 = reinterpret_cast<const f32x4*>(sm)[e % cq];
         const f32x4 in = v;
-        v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
-        out[base + e] = v;
+        v.x *= k4.x; v.y *= k4.y; v.z *= k4.z; v.w *= k4.w;
+        stq(out, base + e, v, m & 2);
         // upstream's `mask` (model.py:334-336): 1 where the dropped-out tensor EQUALS the input, else 0
         if (mask_full) mask_full[base + e] = f32x4{v.x == in.x ? 1.f : 0.f, v.y == in.y ? 1.f : 0.f, v.z == in.z ? 1.f : 0.f, v.w == in.w ? 1.f : 0.f};
     }
@@ -609,23 +611,28 @@ extern "C" int ctl_latent_mask_fused(int32_t mode, const float* grad, const floa
     return CTL_OK;
 }
 
-static int dropout2d_launch(const float* z, const float* keep, uint64_t seed, const int64_t* state, float p, float* out,
-                            float* keep_out, float* mask_full, int32_t n, int32_t hw, int32_t c, ctl_stream stream) {
+static int dropout2d_launch(const void* z, const float* keep, uint64_t seed, const int64_t* state, float p, void* out,
+                            float* keep_out, float* mask_full, int32_t n, int32_t hw, int32_t c, uint32_t bf16_mask, ctl_stream stream) {
     CTL_REQUIRE(z && out && n > 0 && hw > 0 && cq_ok(c) && p >= 0.f && p < 1.f, "dropout2d: bad arguments");
+    CTL_REQUIRE(!mask_full || !(bf16_mask & 3), "dropout2d: the full-size mask goes with fp32 tensors");
     const int sp = slab_pixels(n, hw, c);
     dropout2d_kernel<<<dim3(ctl_cdiv(hw, sp), n), dim3(MB), (size_t)c * sizeof(float), (hipStream_t)stream>>>(
-        (const f32x4*)z, keep, seed, state, p, (f32x4*)out, keep_out, (f32x4*)mask_full, hw, c / 4, sp);
+        z, keep, seed, state, p, out, keep_out, (f32x4*)mask_full, hw, c / 4, sp, bf16_mask);
     CTL_LAUNCH_CHECK("dropout2d");
     return CTL_OK;
 }
 extern "C" int ctl_dropout2d(const float* z, const float* keep, uint64_t seed, float p, float* out, float* keep_out,
                              int32_t n, int32_t hw, int32_t c, ctl_stream stream) {
-    return dropout2d_launch(z, keep, seed, nullptr, p, out, keep_out, nullptr, n, hw, c, stream);
+    return dropout2d_launch(z, keep, seed, nullptr, p, out, keep_out, nullptr, n, hw, c, 0, stream);
 }
 extern "C" int ctl_dropout2d_ex(const float* z, const float* keep, uint64_t seed_or_salt, const int64_t* state, float p,
                                 float* out, float* keep_out, float* mask_full, int32_t n, int32_t hw, int32_t c,
                                 ctl_stream stream) {
-    return dropout2d_launch(z, keep, seed_or_salt, state, p, out, keep_out, mask_full, n, hw, c, stream);
+    return dropout2d_launch(z, keep, seed_or_salt, state, p, out, keep_out, mask_full, n, hw, c, 0, stream);
+}
+extern "C" int ctl_dropout2d_dt(const void* z, const float* keep, uint64_t seed_or_salt, const int64_t* state, float p, void* out,
+                                float* keep_out, int32_t n, int32_t hw, int32_t c, uint32_t bf16_mask, ctl_stream stream) {
+    return dropout2d_launch(z, keep, seed_or_salt, state, p, out, keep_out, nullptr, n, hw, c, bf16_mask, stream);
 }
 
 static int uniform_launch(float* out, int64_t count, uint64_t seed, const int64_t* state, ctl_stream stream) {

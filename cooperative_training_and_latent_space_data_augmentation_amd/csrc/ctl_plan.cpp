@@ -143,35 +143,61 @@ static_assert(sizeof(ctl_conv) == 24 * 4, "ctl_conv must be 24 32-bit words (it 
 // Side lane: ops with i[26] == 1 (weight gradients and their batched reduction: off the critical dgrad chain) run on a
 // library-owned second stream so that their launches fill the ramp-up / tail bubbles of the main chain.  Fork = event
 // recorded on the main stream right before the side op (it then sees everything the main stream produced so far);
-// join = the main stream waits for the side stream once, at the end of the plan.  Opt-in: CTL_SIDE_STREAM=1.
+// join = the main stream waits for the side stream once, at the end of the plan.  CTL_SIDE_STREAM=0 switches it off.
+// Every main stream has its own side stream (the two launch chains of a training step do not serialise each other's side work).
+// Under stream capture (hipGraph mode) the fork / join events become graph dependencies; nothing may be CREATED while a capture is
+// running, so a lane is only used there if an eager plan on the same stream created it (and enough fork events) before -- the graph
+// module's eager warm-up step does -- and the op runs inline otherwise.
 namespace {
-hipStream_t g_side = nullptr;
-std::vector<hipEvent_t> g_fork_events;
-hipEvent_t g_join_event = nullptr;
+struct side_lane {
+    hipStream_t side = nullptr;
+    hipEvent_t join = nullptr;
+    std::vector<hipEvent_t> forks;
+};
+std::map<hipStream_t, side_lane> g_lanes;
 int g_side_enabled = -1;
 }  // namespace
 
-static hipEvent_t fork_event(size_t k) {
-    while (g_fork_events.size() <= k) {
+static side_lane* lane_of(hipStream_t main, bool may_create) {
+    auto it = g_lanes.find(main);
+    if (it != g_lanes.end()) return &it->second;
+    if (!may_create) return nullptr;
+    side_lane l;
+    if (hipStreamCreateWithFlags(&l.side, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&l.join, hipEventDisableTiming) != hipSuccess) return nullptr;
+    return &(g_lanes[main] = l);
+}
+static hipEvent_t fork_event(side_lane* l, size_t k, bool may_create) {
+    while (l->forks.size() <= k) {
         hipEvent_t e = nullptr;
-        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
-        g_fork_events.push_back(e);
+        if (!may_create || hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+        l->forks.push_back(e);
     }
-    return g_fork_events[k];
+    return l->forks[k];
 }
 
 extern "C" int ctl_plan_run(const ctl_op* ops, int32_t n_ops, void* const* bases, int32_t n_bases, ctl_stream stream_) {
     CTL_REQUIRE(ops && bases && n_ops >= 0, "plan_run: null arguments");
     if (g_side_enabled < 0) {
+        // 0 = off; 1 (default) = eager plans only: fp32 step 20.67 -> 20.44 ms, bf16 14.67 -> 13.90 ms (profiles/README.md, round 2);
+        // 2 = also inside a stream capture: correct, but the replayed graph is SLOWER with the ~165 extra cross-stream edges per step
+        // (fp32 17.9 -> 22.3 ms, bf16 12.6 -> 15.8 ms), so a captured step keeps its two chains and nothing else.
         const char* e = getenv("CTL_SIDE_STREAM");
-        g_side_enabled = (e && atoi(e) == 1) ? 1 : 0;      // measured neutral on MI355X (the chain has no fillable bubbles): off by default
+        g_side_enabled = e ? atoi(e) : 1;
+        if (g_side_enabled < 0 || g_side_enabled > 2) g_side_enabled = 0;
     }
     size_t forks = 0;
     bool side_used = false;
-    bool side_ok = g_side_enabled == 1;
-    if (side_ok) {      // the library-owned side stream cannot join a stream capture (hipGraph mode): the plan then stays on one stream
+    bool side_ok = g_side_enabled >= 1;
+    bool capturing = false;
+    side_lane* lane = nullptr;
+    if (side_ok) {
         hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing((hipStream_t)stream_, &st) != hipSuccess || st != hipStreamCaptureStatusNone) side_ok = false;
+        if (hipStreamIsCapturing((hipStream_t)stream_, &st) != hipSuccess) side_ok = false;
+        capturing = st != hipStreamCaptureStatusNone;
+        if (capturing && g_side_enabled < 2) side_ok = false;
+        if (side_ok) lane = lane_of((hipStream_t)stream_, !capturing);
+        if (!lane) side_ok = false;
     }
     // ---- fused finalizes (opt-in per op: BN_FINALIZE / BN_BWD_FINALIZE with i[4] == 1 directly behind the kernel that writes their
     // partial rows; the buffer of the partial slot starts with CTL_FIN_HEADER_BYTES of zero-initialised header = the record table).
@@ -236,16 +262,14 @@ extern "C" int ctl_plan_run(const ctl_op* ops, int32_t n_ops, void* const* bases
         const ctl_op& op = ops[k];
         ctl_stream stream = stream_;
         if (side_ok && op.i[26] == 1) {
-            if (!g_side) {
-                CTL_REQUIRE(hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking) == hipSuccess &&
-                            hipEventCreateWithFlags(&g_join_event, hipEventDisableTiming) == hipSuccess,
-                            "plan_run: cannot create the side stream");
+            hipEvent_t ev = fork_event(lane, forks, !capturing);
+            if (ev) {                                    // (no event left under capture: the op stays on the main stream)
+                ++forks;
+                CTL_REQUIRE(hipEventRecord(ev, (hipStream_t)stream_) == hipSuccess &&
+                            hipStreamWaitEvent(lane->side, ev, 0) == hipSuccess, "plan_run: fork failed");
+                stream = (ctl_stream)lane->side;
+                side_used = true;
             }
-            hipEvent_t ev = fork_event(forks++);
-            CTL_REQUIRE(ev && hipEventRecord(ev, (hipStream_t)stream_) == hipSuccess &&
-                        hipStreamWaitEvent(g_side, ev, 0) == hipSuccess, "plan_run: fork failed");
-            stream = (ctl_stream)g_side;
-            side_used = true;
         }
         void* t[CTL_OP_MAX_T];
         for (int a = 0; a < CTL_OP_MAX_T; ++a) {
@@ -331,7 +355,7 @@ extern "C" int ctl_plan_run(const ctl_op* ops, int32_t n_ops, void* const* bases
                 rc = ctl_wgrad_reduce_batched(CF(0), F(1), (const int64_t*)t[2], op.i[0], op.l[0], stream);
                 break;
             case CTL_OP_DROPOUT2D:      // nn.Dropout2d behind a residual block (encoder_decoder.py:58-66); backward = the same op on dy with the saved pattern
-                rc = ctl_dropout2d_ex(CF(0), CF(1), (uint64_t)op.l[0], (const int64_t*)t[2], op.f[0], F(3), F(4), nullptr, op.i[0], op.i[1], op.i[2], stream);
+                rc = ctl_dropout2d_dt(t[0], CF(1), (uint64_t)op.l[0], (const int64_t*)t[2], op.f[0], t[3], F(4), op.i[0], op.i[1], op.i[2], (uint32_t)op.i[25], stream);
                 break;
             case CTL_OP_COPY: {
                 CTL_REQUIRE(t[0] && t[1] && op.l[0] > 0, "plan_run: op %d COPY needs two pointers and a size", k);
@@ -354,9 +378,24 @@ extern "C" int ctl_plan_run(const ctl_op* ops, int32_t n_ops, void* const* bases
             return rc;
         }
     }
-    if (side_used) {
-        CTL_REQUIRE(hipEventRecord(g_join_event, g_side) == hipSuccess &&
-                    hipStreamWaitEvent((hipStream_t)stream_, g_join_event, 0) == hipSuccess, "plan_run: join failed");
+    if (side_used && !capturing) {
+        CTL_REQUIRE(hipEventRecord(lane->join, lane->side) == hipSuccess &&
+                    hipStreamWaitEvent((hipStream_t)stream_, lane->join, 0) == hipSuccess, "plan_run: join failed");
+    } else if (side_used) {
+        // Under capture the join is an explicit graph dependency (the side lane's last nodes become predecessors of the main stream's
+        // next node), NOT an event wait: a non-origin stream that waits on an event of a stream it forked is entered into that
+        // stream's list of parallel capture streams as well, and the runtime's EndCapture then recurses A -> side -> A -> ... until the
+        // stack ends (ROCm 7.0, hip::Stream::EndCapture; found with rocgdb).
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        unsigned long long id = 0;
+        hipGraph_t graph = nullptr;
+        const hipGraphNode_t* deps = nullptr;
+        size_t ndeps = 0;
+        CTL_REQUIRE(hipStreamGetCaptureInfo_v2(lane->side, &st, &id, &graph, &deps, &ndeps) == hipSuccess &&
+                    st == hipStreamCaptureStatusActive, "plan_run: the side lane left the capture");
+        if (ndeps > 0)
+            CTL_REQUIRE(hipStreamUpdateCaptureDependencies((hipStream_t)stream_, const_cast<hipGraphNode_t*>(deps), ndeps,
+                                                           hipStreamAddCaptureDependencies) == hipSuccess, "plan_run: join (capture) failed");
     }
     return CTL_OK;
 }

@@ -407,8 +407,8 @@ class PlanBuilder:
         """nn.Dropout2d (whole channels per sample, scaled by 1/(1-p)).  keep_in = ref of a given [n][c] pattern (backward pass, injected
         patterns); otherwise the pattern is drawn on the device from the network's RNG state (S_STATE) and this call site's salt and
         written to keep_out."""
-        assert not (z.b16 or out.b16), "Dropout2d inside the networks runs on fp32 tensors"
         op = self.op(_ffi.OP_DROPOUT2D)
+        op["i"][25] = self.mask(z, out)
         op["i"][0], op["i"][1], op["i"][2] = z.n, z.h * z.w, z.c
         op["f"][0] = p
         op["l"][0] = salt
@@ -704,8 +704,6 @@ class CtlNet(nn.Module):
         if p is not None:
             if not (0.0 <= float(p) < 1.0):
                 raise ValueError(f"dropout probability {p!r} must be in [0, 1)")
-            if self.bf16:
-                raise NotImplementedError("encoder/decoder Dropout2d is only offered with compute_dtype='fp32'")
         self.drop_p = None if p is None else float(p)
 
     def set_dropout_keep(self, patterns):

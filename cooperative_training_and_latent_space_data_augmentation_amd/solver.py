@@ -48,8 +48,6 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
         self.compute_dtype = compute_dtype or os.environ.get("CTL_DTYPE", "fp32")
         if network_type not in ("FCN_16_standard", "FCN_16_standard_w_o_filter", "FCN_16_standard_share_code"):
             raise NotImplementedError(network_type)
-        if (encoder_dropout is not None or decoder_dropout is not None) and self.compute_dtype == "bf16":
-            raise NotImplementedError("encoder/decoder Dropout2d is only offered with compute_dtype='fp32'")
         if not use_gpu:
             raise RuntimeError("this engine runs on MI355X only (use_gpu=True); the CPU path is the oracle under oracle/")
         self.network_type, self.image_ch, self.checkpoint_dir = network_type, image_ch, checkpoint_dir

@@ -283,6 +283,11 @@ int ctl_step_tick(int64_t* state, ctl_stream stream);
 int ctl_dropout2d_ex(const float* z, const float* keep, uint64_t seed_or_salt, const int64_t* state, float p, float* out,
                      float* keep_out, float* mask_full, int32_t n, int32_t hw, int32_t c, ctl_stream stream);
 int ctl_uniform_dev(float* out, int64_t count, uint64_t salt, const int64_t* state, ctl_stream stream);
+/* nn.Dropout2d behind every residual block (encoder_dropout / decoder_dropout, model.py:27-28, 92-106; encoder_decoder.py:58-66, 338-347):
+ * ctl_dropout2d_ex on network-internal tensors, which BASELINE config 3 stores as bf16.  bf16_mask: bit 0 = z, bit 1 = out are bf16
+ * ([n,hw,c] either way); the product z * keep / (1-p) is formed in fp32 and rounded once by the store. */
+int ctl_dropout2d_dt(const void* z, const float* keep, uint64_t seed_or_salt, const int64_t* state, float p, void* out,
+                     float* keep_out, int32_t n, int32_t hw, int32_t c, uint32_t bf16_mask, ctl_stream stream);
 
 /* ------------------------------------------------------------------------------------------------ SURVEY 8(f) rows 1, 3
  * Validation metrics and the input pipeline on device (no host round trip per batch).

@@ -222,6 +222,8 @@ class bf16_rounding_points:
         the tensor as STORED (bf16);
       * `conv3x3(nearest_up(x))` of the 'NN' up blocks runs as the engine runs it: four 2x2 phase convs whose weights are sums of the
         3x3 taps formed in fp32 and rounded ONCE;
+      * Dropout2d behind a block (encoder_dropout / decoder_dropout) reads the block's output as stored (bf16), scales in fp32 and stores
+        bf16 again (the second rounding happens at the next convolution's operand rounding);
       * network inputs / outputs stay fp32.
     Forward emulation (inference, losses); gradients flow through the roundings as identity."""
 
@@ -252,7 +254,7 @@ class bf16_rounding_points:
         def up_forward(m, x):
             if not isinstance(m.up, nn.Sequential):                      # 'Conv2' (ConvTranspose2d): no re-formulation
                 x = m.up(x)
-                return m.last_act(m.conv_input(x) + m.conv(x))
+                return _block_dropout(m, m.last_act(m.conv_input(x) + m.conv(x)))
             c0 = m.conv[0]
             n, _, h, w = x.shape
             xp = F.pad(rb16(x), (1, 1, 1, 1))
@@ -267,13 +269,22 @@ class bf16_rounding_points:
             main = u
             for layer in list(m.conv)[1:]:
                 main = layer(main)
-            return m.last_act(m.conv_input(m.up(x)) + main)
+            return _block_dropout(m, m.last_act(m.conv_input(m.up(x)) + main))
+
+        def block_dropout(mod, res_x):
+            if getattr(mod, "drop_p", None) is None or not mod.training:
+                return res_x
+            return plain_dropout(mod, rb16(res_x))       # the block's output is STORED (rounded) before the Dropout2d launch reads it
 
         nn.Conv2d.forward, nn.ConvTranspose2d.forward, nn.BatchNorm2d.forward, UpBlock.forward = conv, convt, bn, up_forward
+        g = globals()
+        plain_dropout = self._saved_dropout = g["_block_dropout"]
+        g["_block_dropout"] = block_dropout
         return self
 
     def __exit__(self, *exc):
         nn.Conv2d.forward, nn.ConvTranspose2d.forward, nn.BatchNorm2d.forward, UpBlock.forward = self._saved
+        globals()["_block_dropout"] = self._saved_dropout
         return False
 
 

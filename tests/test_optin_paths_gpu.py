@@ -2,7 +2,8 @@
 they must stay correct.  Each runs in a subprocess because the switches are read once per process.
   CTL_FUSE_FINALIZE=1   BatchNorm finalize folded into the producing conv / reduction by the plan executor (ctl_plan.cpp)
   CTL_FUSE_BNBWD=1      fp32 BatchNorm-backward reduction inside the data-gradient epilogue
-  CTL_SIDE_STREAM=1     weight gradients on a library-owned side stream (eager mode)"""
+  CTL_SIDE_STREAM=0     weight gradients back on the main chain (the side lane is ON by default in eager plans: the comparison is against it)
+  CTL_SIDE_STREAM=2     side lanes also inside a captured step (correct; the replay is slower with the extra cross-stream edges)"""
 import json
 import os
 import subprocess
@@ -27,8 +28,14 @@ ci = {"loss_name": "mse", "mask_type": "channel", "max_threshold": 0.5, "random_
 cs = {"loss_name": "ce", "mask_type": "spatial", "max_threshold": 0.5, "random_threshold": False, "if_soft": False}
 out = []
 n0 = _ffi.lib.ctl_launch_count()
-for _ in range(2):
-    out.append([float(v) for v in s.cooperative_step(clean, label, clean, ci, cs)])
+if GRAPH:
+    from cooperative_training_and_latent_space_data_augmentation_amd.graph import CooperativeStepGraph
+    step = CooperativeStepGraph(s, ci, cs)
+    for _ in range(3):
+        out.append([float(v) for v in step(clean, label, clean)])
+else:
+    for _ in range(2):
+        out.append([float(v) for v in s.cooperative_step(clean, label, clean, ci, cs)])
 torch.cuda.synchronize()
 launches = int(_ffi.lib.ctl_launch_count() - n0) // 2
 sums = {k: float(m._flat_data.double().sum()) for k, m in s.model.items()}
@@ -37,9 +44,9 @@ print("RESULT " + json.dumps({"losses": out, "sums": sums, "bufs": bufs, "launch
 """ % ROOT
 
 
-def run(env_extra):
+def run(env_extra, graph=False):
     env = dict(os.environ, **env_extra)
-    r = subprocess.run([sys.executable, "-c", SCRIPT], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    r = subprocess.run([sys.executable, "-c", f"GRAPH = {graph}\n" + SCRIPT], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
     assert line, r.stderr[-2000:]
     return json.loads(line[0][7:])
@@ -50,7 +57,7 @@ def default_run():
     return run({})
 
 
-@pytest.mark.parametrize("env", [{"CTL_FUSE_FINALIZE": "1"}, {"CTL_FUSE_BNBWD": "1"}, {"CTL_SIDE_STREAM": "1"}])
+@pytest.mark.parametrize("env", [{"CTL_FUSE_FINALIZE": "1"}, {"CTL_FUSE_BNBWD": "1"}, {"CTL_SIDE_STREAM": "0"}])
 def test_optin_path_matches_default(env, default_run):
     got = run(env)
     for a, b in zip(got["losses"], default_run["losses"]):
@@ -63,3 +70,13 @@ def test_optin_path_matches_default(env, default_run):
         assert abs(got["bufs"][k] - default_run["bufs"][k]) <= 1e-3 + 1e-4 * abs(default_run["bufs"][k]), (env, k)
     if "CTL_FUSE_FINALIZE" in env:          # the stand-alone finalize launches are gone (one table-write launch per plan instead)
         assert got["launches"] < default_run["launches"] - 100, (got["launches"], default_run["launches"])
+
+
+def test_side_stream_inside_a_captured_step():
+    """hipGraph mode with CTL_SIDE_STREAM=2: the fork / join events of the side lanes become graph dependencies (the lanes are created by
+    the eager warm-up step in front of the capture).  Same kernels on the same data: the replays' losses and the weights after three
+    steps equal the default graph run bit for bit."""
+    ref = run({}, graph=True)
+    got = run({"CTL_SIDE_STREAM": "2"}, graph=True)
+    assert got["losses"] == ref["losses"], (got["losses"], ref["losses"])
+    assert got["sums"] == ref["sums"] and got["bufs"] == ref["bufs"]
