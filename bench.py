@@ -276,6 +276,7 @@ def main():
     prof_single = {}
     if getattr(solver, "two_streams", False):          # EVERY rank replays (step() contains the gradient all-reduce); rank 0 profiles
         solver.two_streams = False
+        lanes = _ffi.lib.ctl_plan_side_lanes(0)        # ... and the weight gradients stay on the one stream as well
         for _ in range(2):
             eager_step()
         torch.cuda.synchronize()
@@ -287,6 +288,7 @@ def main():
         if rank == 0:
             prof_single = _ffi.prof_stop()
         solver.two_streams = True
+        _ffi.lib.ctl_plan_side_lanes(lanes)
     if phase_tm is not None:
         _ffi.lib.ctl_debug_timing(phase_tm)
         steps = max(phase_tm[6], 1)

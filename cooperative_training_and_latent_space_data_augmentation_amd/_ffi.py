@@ -40,7 +40,7 @@ class BnFin(C.Structure):
     _fields_ = [("gamma", C.c_void_p), ("beta", C.c_void_p), ("running_mean", C.c_void_p), ("running_var", C.c_void_p),
                 ("num_batches_tracked", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p), ("save_mean", C.c_void_p),
                 ("save_invstd", C.c_void_p), ("count", C.c_int64), ("eps", C.c_float), ("momentum", C.c_float),
-                ("update_running", C.c_int32), ("reserved", C.c_int32)]
+                ("update_running", C.c_int32), ("role", C.c_int32), ("partial", C.c_void_p), ("rows", C.c_int32), ("reserved", C.c_int32)]
 
 
 class BnbFin(C.Structure):
@@ -64,6 +64,7 @@ class _Lib:
         lib.ctl_last_error.restype = C.c_char_p
         lib.ctl_version.restype = C.c_int
         lib.ctl_launch_count.restype = C.c_ulonglong
+        lib.ctl_plan_side_lanes.argtypes = [C.c_int32]
         for name in ("ctl_conv_wpack_floats", "ctl_conv_stats_floats", "ctl_wgrad_partial_floats",
                      "ctl_wgrad_bias_partial_floats", "ctl_latent_score_ws_floats", "ctl_latent_mask_apply_ws_floats",
                      "ctl_rescale_intensity_ws_floats", "ctl_sizeof_op", "ctl_sizeof_conv", "ctl_latent_mask_fused_ws_floats"):
@@ -118,7 +119,7 @@ class _Lib:
             "ctl_prof_start": [C.c_char_p], "ctl_prof_stop": [p, C.c_size_t],
             "ctl_pack_weights_batched": [p, p, p, i32, i64, p], "ctl_wgrad_reduce_batched": [p, p, p, i32, i64, p],
             "ctl_pack_weights_bf16_batched": [p, p, p, i32, i64, p],
-            "ctl_conv_forward_fin": [p] * 13,
+            "ctl_conv_forward_fin": [p] * 12 + [i32, p],
             "ctl_bn_fin_table_write": [p, p, i32, p],
             "ctl_bwd_reduce_rows": [i32, i64, i32],
             "ctl_bwd_reduce_fin": [i32, p, p, p, p, p, f32, i64, i32, p, i32, C.c_uint32, p, p, p],
@@ -154,7 +155,7 @@ EXPORTED = ["ctl_version", "ctl_last_error", "ctl_conv_wpack_floats", "ctl_conv_
             "ctl_noise_clamp", "ctl_crop_or_pad", "ctl_step_tick", "ctl_dropout2d_ex", "ctl_dropout2d_dt", "ctl_uniform_dev", "ctl_adam_dev",
             "ctl_latent_mask_fused_ws_floats", "ctl_latent_mask_fused", "ctl_accumulate", "ctl_pack_weights_bf16_batched",
             "ctl_bn_act_dt", "ctl_bwd_reduce_dt", "ctl_bwd_apply_dt", "ctl_sumpool2_dt", "ctl_conv_forward_fin", "ctl_bn_fin_table_write",
-            "ctl_bwd_reduce_fin", "ctl_bwd_reduce_rows", "ctl_launch_count"]
+            "ctl_bwd_reduce_fin", "ctl_bwd_reduce_rows", "ctl_launch_count", "ctl_plan_side_lanes"]
 
 
 def prof_start(kernel_filter: str = "") -> None:

@@ -120,6 +120,10 @@ struct ctl_bn_fin_dev {
     const float* gamma; const float* beta; float* running_mean; float* running_var; int64_t* nbt;
     float* scale; float* shift; float* save_mean; float* save_invstd;
     double count; float eps, momentum; int update_running;
+    // role 0: the producer's last block finalises (ctl_bn_finalize_tail).  role 1 / 2: CONSUMER-side finalize -- the kernel that first
+    // uses the coefficients (1: as its prologue, 2: as its residual affine) computes them in its first few blocks from the producer's
+    // statistics rows `partial` ([groups][rows][2][c]) while the other blocks wait at the record's counter (ctl_bn_consume)
+    int role; int rows; const float* partial;
 };
 struct ctl_bn_chan { float gamma, beta, rm, rv; };       // a channel's parameters, requested BEFORE the reduction whose result they meet
 __device__ __forceinline__ ctl_bn_chan ctl_bn_chan_load(int ch, const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -153,16 +157,101 @@ __device__ __forceinline__ void ctl_bn_coefs(double s1, double s2, double count,
         running_var[ch] = p.rv;
     }
 }
+// Consumer-side finalize (role 1 / 2).  The first min(nblocks, c) blocks of the launch are the writers: a block per channel sums the
+// producer's rows with all 256 threads (one round trip, double), writes scale / shift (write-through: the other XCDs' blocks read them
+// in this launch), mean / invstd, the running statistics, and arrives at the record's counter; the LAST writer raises the go flags.
+// Every block then waits for a go flag and reads the coefficients with agent-scope loads.  The writers are the first blocks of the grid and wait for
+// nobody: no deadlock whatever is resident.  The wait overlaps the waiting blocks' first-tile loads (requested before the call); the
+// stand-alone finalize launch and its kernel boundary disappear.  Polling: ~1000 blocks polling ONE line starve the writers' arrival
+// adds (measured: +24 us per launch), so there are CTL_GO_LINES flag lines (block L polls line L % CTL_GO_LINES, with a sleep between
+// polls).  `lines` = the record's counter lines: line 0 the arrival counter, lines 1.. the go flags; all zero at launch
+// (ctl_bn_fin_table_write zeroes them every plan run).  `sm`: LDS scratch, 16 doubles, free at the call.
+#define CTL_GO_LINES 32
+__device__ __forceinline__ void ctl_bn_consume(const ctl_bn_fin_dev& f, unsigned* lines, int groups, int c, unsigned lin_block, unsigned nblocks,
+                                               double* sm) {
+    const unsigned nwr = nblocks < (unsigned)c ? nblocks : (unsigned)c;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (lin_block < nwr) {
+        for (int ch = (int)lin_block; ch < c; ch += (int)nwr) {
+            ctl_bn_chan p = {};
+            if (tid == 0) p = ctl_bn_chan_load(ch, f.gamma, f.beta, f.update_running, f.running_mean, f.running_var);
+            for (int g = 0; g < groups; ++g) {
+                const float* base = f.partial + ((int64_t)g * f.rows * 2) * c + ch;
+                double s1 = 0.0, s2 = 0.0;
+                for (int r0 = tid; r0 < f.rows; r0 += 256 * 4) {
+                    float v1[4], v2[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int r = r0 + u * 256;
+                        const bool ok = r < f.rows;
+                        v1[u] = ok ? base[(int64_t)r * 2 * c] : 0.f;
+                        v2[u] = ok ? base[((int64_t)r * 2 + 1) * c] : 0.f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { s1 += (double)v1[u]; s2 += (double)v2[u]; }
+                }
+                s1 = wave_sum_double(s1);
+                s2 = wave_sum_double(s2);
+                if (lane == 0) { sm[wave] = s1; sm[4 + wave] = s2; }
+                __syncthreads();
+                if (tid == 0) {
+                    s1 = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+                    s2 = (sm[4] + sm[5]) + (sm[6] + sm[7]);
+                    const double mean = s1 / f.count;
+                    double var = s2 / f.count - mean * mean;
+                    if (var < 0.0) var = 0.0;
+                    const float invstd = (float)(1.0 / sqrt(var + (double)f.eps));
+                    const float sc = p.gamma * invstd;
+                    ctl_store_wt(f.scale + g * c + ch, sc);
+                    ctl_store_wt(f.shift + g * c + ch, p.beta - (float)mean * sc);
+                    if (f.save_mean) f.save_mean[g * c + ch] = (float)mean;
+                    if (f.save_invstd) f.save_invstd[g * c + ch] = invstd;
+                    if (f.update_running) {
+                        const double unbiased = f.count > 1.0 ? var * f.count / (f.count - 1.0) : var;
+                        p.rm = (1.f - f.momentum) * p.rm + f.momentum * (float)mean;
+                        p.rv = (1.f - f.momentum) * p.rv + f.momentum * (float)unbiased;
+                        f.running_mean[ch] = p.rm;
+                        f.running_var[ch] = p.rv;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        if (lin_block == 0 && tid == 0 && f.update_running && f.nbt) f.nbt[0] += groups;
+        if (tid < 64) {       // (only thread 0 stored: its wave drains, releases and arrives; the last writer raises the flags)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            int last = 0;
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                last = __hip_atomic_fetch_add(lines, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nwr - 1;
+            }
+            last = __shfl(last, 0);
+            if (last && tid < CTL_GO_LINES) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+                __hip_atomic_store(lines + (1 + tid) * CTL_ARRIVE_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+    if (tid == 0) {
+        const unsigned* flag = lines + (1 + lin_block % CTL_GO_LINES) * CTL_ARRIVE_STRIDE;
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(16);
+    }
+    __syncthreads();
+    // NO acquire fence here: an agent-scope acquire invalidates the XCD's L2 for every block of the launch (measured: +20 us per launch).
+    // The callers read the coefficients with agent-scope loads (ctl_load_wt) into LDS instead.
+}
+
 // Device-resident record of one fused finalize (written by ctl_bn_fin_table_write before the producing kernel runs): the finalize
 // arguments and the arrival counters (one sharded set per block row of output-channel tiles; zero between launches).  The convolution kernels
 // take ONE pointer to it: passing the fields as kernel arguments cost the tuned kernels 50-60 spilled SGPRs.
 struct alignas(128) ctl_bn_rec {
     ctl_bn_fin_dev f;                                                      // (first line)
-    unsigned counters[CTL_FIN_MAX_Y][CTL_ARRIVE_LINES][CTL_ARRIVE_STRIDE];  // per block row of output-channel tiles: sharded arrival counters
+    alignas(128) unsigned counters[CTL_FIN_MAX_Y][CTL_ARRIVE_LINES][CTL_ARRIVE_STRIDE];  // per block row of output-channel tiles: sharded arrival counters
 };
 static_assert(sizeof(ctl_bn_rec) == CTL_FIN_REC_BYTES, "ctl_bn_rec is one table slot");
 __device__ __forceinline__ void ctl_bn_finalize_tail(ctl_bn_rec* __restrict__ rec, const float* __restrict__ partial, int rows, int groups,
                                                      int cout, int co_first, int nco, unsigned nblocks, int* flag_lds) {
+    if (rec->f.role != 0) return;             // (a consumer-side record: nothing to do behind the tiles)
     if (!ctl_arrive_last(&rec->counters[blockIdx.y][0][0], blockIdx.z * gridDim.x + blockIdx.x, nblocks, flag_lds)) return;
     const ctl_bn_fin_dev f = rec->f;
     const int lane = threadIdx.x & 63;

@@ -324,8 +324,22 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : ((MT * NT >= 4
         xs.load(rx, d, cur.n, cur.th * G::TH, cur.tw * TW, 0);
         wload(0);
     }
+    // consumer-side BatchNorm finalize (rec->f.role 1: this kernel's prologue coefficients, 2: its residual affine): the first blocks
+    // compute them, everybody waits for them -- behind the first tile's loads
+    if (rec && rec->f.role != 0)
+        ctl_bn_consume(rec->f, &rec->counters[0][0][0], ngroups, rec->f.role == 1 ? d.cin : d.cout,
+                       (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, gridDim.x * gridDim.y * gridDim.z,
+                       reinterpret_cast<double*>(xt));
+    const bool res_lds = rec && rec->f.role == 2;      // the residual affine was computed in this launch: read into LDS with agent-scope loads
     if (d.pro_affine) {      // behind the first tile's loads, in front of their use
-        for (int i = tid; i < ngroups * d.cin; i += 256) { cf_scale[i] = pro_scale[i]; cf_shift[i] = pro_shift[i]; }
+        if (rec && rec->f.role == 1) {        // computed in this launch by other blocks: agent-scope loads
+            for (int i = tid; i < ngroups * d.cin; i += 256) { cf_scale[i] = ctl_load_wt(pro_scale + i); cf_shift[i] = ctl_load_wt(pro_shift + i); }
+        } else {
+            for (int i = tid; i < ngroups * d.cin; i += 256) { cf_scale[i] = pro_scale[i]; cf_shift[i] = pro_shift[i]; }
+        }
+        __syncthreads();
+    } else if (res_lds) {
+        for (int i = tid; i < ngroups * d.cout; i += 256) { cf_scale[i] = ctl_load_wt(res_scale + i); cf_shift[i] = ctl_load_wt(res_shift + i); }
         __syncthreads();
     }
     if (total_it > 0) {
@@ -517,7 +531,10 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : ((MT * NT >= 4
                     const int cc = cok ? co0 : 0;
                     f32x4 rs = {0.f, 0.f, 0.f, 0.f}, rh = {0.f, 0.f, 0.f, 0.f};
                     if (EPI && (flags & (CTL_EPI_RES | CTL_EPI_BNBWD))) {
-                        if (d.cout >= 4) {
+                        if (res_lds) {
+                            rs = *reinterpret_cast<const f32x4*>(cf_scale + grp * d.cout + cc);
+                            rh = *reinterpret_cast<const f32x4*>(cf_shift + grp * d.cout + cc);
+                        } else if (d.cout >= 4) {
                             rs = *reinterpret_cast<const f32x4*>(res_scale + grp * d.cout + cc);
                             rh = *reinterpret_cast<const f32x4*>(res_shift + grp * d.cout + cc);
                         } else { rs.x = res_scale[grp]; rh.x = res_shift[grp]; }
@@ -1180,7 +1197,11 @@ extern "C" size_t ctl_conv_stats_floats(const ctl_conv* d) {
 // ---- fused-finalize records: host structs -> device table slots (the counters of a slot are never written from here)
 struct ctl_fin_batch { ctl_bn_fin_dev f[16]; };
 __global__ void fin_table_write_kernel(ctl_bn_rec* table, int first, int n, const ctl_fin_batch batch) {
-    if ((int)threadIdx.x < n) table[first + threadIdx.x].f = batch.f[threadIdx.x];
+    if ((int)threadIdx.x < n) {
+        table[first + threadIdx.x].f = batch.f[threadIdx.x];
+        if (batch.f[threadIdx.x].role != 0)          // consumer side: the writers' arrival counter and the go flags (lines 0 .. CTL_GO_LINES)
+            for (int l = 0; l <= CTL_GO_LINES; ++l) (&table[first + threadIdx.x].counters[0][0][0])[l * CTL_ARRIVE_STRIDE] = 0;
+    }
 }
 extern "C" int ctl_bn_fin_table_write(void* table, const ctl_bn_fin* recs, int32_t n, ctl_stream stream) {
     CTL_REQUIRE(table && recs && n > 0 && ((uintptr_t)table & 127) == 0, "bn_fin_table_write: bad arguments");
@@ -1195,6 +1216,8 @@ extern "C" int ctl_bn_fin_table_write(void* table, const ctl_bn_fin* recs, int32
             f.gamma = r.gamma; f.beta = r.beta; f.running_mean = r.running_mean; f.running_var = r.running_var; f.nbt = r.num_batches_tracked;
             f.scale = r.scale; f.shift = r.shift; f.save_mean = r.save_mean; f.save_invstd = r.save_invstd; f.count = (double)r.count;
             f.eps = r.eps; f.momentum = r.momentum; f.update_running = r.update_running;
+            f.role = r.role; f.rows = r.rows; f.partial = r.partial;
+            CTL_REQUIRE(r.role >= 0 && r.role <= 2 && (r.role == 0 || (r.partial && r.rows > 0)), "bn_fin_table_write: record %d: role %d needs the producer's rows", first + i, r.role);
         }
         fin_table_write_kernel<<<dim3(1), dim3(64), 0, (hipStream_t)stream>>>(reinterpret_cast<ctl_bn_rec*>(table), first, m, b);
     }
@@ -1205,12 +1228,12 @@ extern "C" int ctl_conv_forward(const ctl_conv* d, const float* x, const float* 
                                 const float* pro_scale, const float* pro_shift, const float* res,
                                 const float* res_scale, const float* res_shift, float* y, float* stats_partial,
                                 ctl_stream stream) {
-    return ctl_conv_forward_fin(d, x, wpack, bias, pro_scale, pro_shift, res, res_scale, res_shift, y, stats_partial, nullptr, stream);
+    return ctl_conv_forward_fin(d, x, wpack, bias, pro_scale, pro_shift, res, res_scale, res_shift, y, stats_partial, nullptr, 0, stream);
 }
 extern "C" int ctl_conv_forward_fin(const ctl_conv* d, const float* x, const float* wpack, const float* bias,
                                     const float* pro_scale, const float* pro_shift, const float* res,
                                     const float* res_scale, const float* res_shift, float* y, float* stats_partial,
-                                    void* fin_rec, ctl_stream stream) {
+                                    void* fin_rec, int32_t fin_role, ctl_stream stream) {
     CTL_REQUIRE(d && x && wpack && y, "conv_forward: null argument");
     CTL_REQUIRE((d->dt & CTL_DT_BF16) || !(d->dt & (CTL_DT_X16 | CTL_DT_Y16 | CTL_DT_RES16)), "conv_forward: bf16-stored tensors need CTL_DT_BF16");
     conv_call a = {};
@@ -1218,8 +1241,17 @@ extern "C" int ctl_conv_forward_fin(const ctl_conv* d, const float* x, const flo
     int rc = ctl_conv_pick_cfg(d, &a.c, 0);
     if (rc != CTL_OK) return rc;
     if (fin_rec) {
-        CTL_REQUIRE((d->epi_flags & CTL_EPI_STATS) && !(d->epi_flags & CTL_EPI_BNBWD) && stats_partial, "conv_forward: a fused BatchNorm finalize needs CTL_EPI_STATS (and no CTL_EPI_BNBWD)");
-        CTL_REQUIRE(ctl_cdiv(ctl_cdiv(d->cout, 16), a.c.nt) <= CTL_FIN_MAX_Y && ((uintptr_t)fin_rec & 127) == 0, "conv_forward: fused finalize: at most %d block rows of output-channel tiles, 128-byte aligned record", CTL_FIN_MAX_Y);
+        CTL_REQUIRE(((uintptr_t)fin_rec & 127) == 0 && fin_role >= 0 && fin_role <= 2, "conv_forward: fused finalize: 128-byte aligned record, role 0..2");
+        if (fin_role == 0) {
+            CTL_REQUIRE((d->epi_flags & CTL_EPI_STATS) && !(d->epi_flags & CTL_EPI_BNBWD) && stats_partial, "conv_forward: a producer-side BatchNorm finalize needs CTL_EPI_STATS (and no CTL_EPI_BNBWD)");
+            CTL_REQUIRE(ctl_cdiv(ctl_cdiv(d->cout, 16), a.c.nt) <= CTL_FIN_MAX_Y, "conv_forward: fused finalize: at most %d block rows of output-channel tiles", CTL_FIN_MAX_Y);
+        } else if (fin_role == 1) {
+            CTL_REQUIRE(d->pro_affine && pro_scale && pro_shift, "conv_forward: consumer-side finalize (role 1) computes the prologue coefficients: pro_affine needed");
+        } else {
+            CTL_REQUIRE((d->epi_flags & CTL_EPI_RES) && res_scale && res_shift && !d->pro_affine && d->cout >= 4 &&
+                        (d->groups > 1 ? d->groups : 1) * d->cout <= CTL_PRO_MAX,
+                        "conv_forward: consumer-side finalize (role 2) computes the residual affine: CTL_EPI_RES, no prologue, 4 <= groups * cout <= %d", CTL_PRO_MAX);
+        }
     }
     a.rec = reinterpret_cast<ctl_bn_rec*>(fin_rec);
     CTL_REQUIRE(!(d->epi_flags & CTL_EPI_BIAS) || bias, "conv_forward: CTL_EPI_BIAS without bias");

@@ -353,8 +353,21 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? CTL16_OCC_BIG : CT
         xs.load(rx, d, cur.n, cur.th * G::TH, cur.tw * TW, 0);
         wload(0);
     }
+    // consumer-side BatchNorm finalize (ctl_bn_consume; see the fp32 kernel)
+    if (rec && rec->f.role != 0)
+        ctl_bn_consume(rec->f, &rec->counters[0][0][0], ngroups, rec->f.role == 1 ? d.cin : d.cout,
+                       (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, gridDim.x * gridDim.y * gridDim.z,
+                       reinterpret_cast<double*>(xt));
+    const bool res_lds = rec && rec->f.role == 2;
     if (d.pro_affine) {
-        for (int i = tid; i < ngroups * d.cin; i += 256) { cf_scale[i] = pro_scale[i]; cf_shift[i] = pro_shift[i]; }
+        if (rec && rec->f.role == 1) {        // computed in this launch by other blocks: agent-scope loads
+            for (int i = tid; i < ngroups * d.cin; i += 256) { cf_scale[i] = ctl_load_wt(pro_scale + i); cf_shift[i] = ctl_load_wt(pro_shift + i); }
+        } else {
+            for (int i = tid; i < ngroups * d.cin; i += 256) { cf_scale[i] = pro_scale[i]; cf_shift[i] = pro_shift[i]; }
+        }
+        __syncthreads();
+    } else if (res_lds) {
+        for (int i = tid; i < ngroups * d.cout; i += 256) { cf_scale[i] = ctl_load_wt(res_scale + i); cf_shift[i] = ctl_load_wt(res_shift + i); }
         __syncthreads();
     }
     if (total_it > 0) {
@@ -559,8 +572,8 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? CTL16_OCC_BIG : CT
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
                         const int co0 = (cot0 + t) * 16 + q * 4;
-                        rs[t] = *reinterpret_cast<const f32x4*>(res_scale + grp * d.cout + co0);
-                        rh[t] = *reinterpret_cast<const f32x4*>(res_shift + grp * d.cout + co0);
+                        rs[t] = *reinterpret_cast<const f32x4*>((res_lds ? cf_scale : res_scale) + grp * d.cout + co0);
+                        rh[t] = *reinterpret_cast<const f32x4*>((res_lds ? cf_shift : res_shift) + grp * d.cout + co0);
                     }
                 }
                 int bo[MT];
@@ -648,7 +661,10 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? CTL16_OCC_BIG : CT
                 const int cc = cok ? co0 : 0;
                 f32x4 rs = {0.f, 0.f, 0.f, 0.f}, rh = {0.f, 0.f, 0.f, 0.f};
                 if (flags & CTL_EPI_RES) {
-                    if (d.cout >= 4) {
+                    if (res_lds) {
+                        rs = *reinterpret_cast<const f32x4*>(cf_scale + grp * d.cout + cc);
+                        rh = *reinterpret_cast<const f32x4*>(cf_shift + grp * d.cout + cc);
+                    } else if (d.cout >= 4) {
                         rs = *reinterpret_cast<const f32x4*>(res_scale + grp * d.cout + cc);
                         rh = *reinterpret_cast<const f32x4*>(res_shift + grp * d.cout + cc);
                     } else { rs.x = res_scale[grp]; rh.x = res_shift[grp]; }

@@ -176,16 +176,25 @@ static hipEvent_t fork_event(side_lane* l, size_t k, bool may_create) {
     return l->forks[k];
 }
 
+static void side_mode_init() {
+    if (g_side_enabled >= 0) return;
+    // 0 = off; 1 (default) = eager plans only: fp32 step 20.67 -> 20.44 ms, bf16 14.67 -> 13.90 ms (profiles/README.md, round 2);
+    // 2 = also inside a stream capture: correct, but the replayed graph is SLOWER with the ~165 extra cross-stream edges per step
+    // (fp32 17.9 -> 22.3 ms, bf16 12.6 -> 15.8 ms), so a captured step keeps its two chains and nothing else.
+    const char* e = getenv("CTL_SIDE_STREAM");
+    g_side_enabled = e ? atoi(e) : 1;
+    if (g_side_enabled < 0 || g_side_enabled > 2) g_side_enabled = 0;
+}
+extern "C" int ctl_plan_side_lanes(int32_t mode) {
+    side_mode_init();
+    const int prev = g_side_enabled;
+    if (mode >= 0 && mode <= 2) g_side_enabled = mode;
+    return prev;
+}
+
 extern "C" int ctl_plan_run(const ctl_op* ops, int32_t n_ops, void* const* bases, int32_t n_bases, ctl_stream stream_) {
     CTL_REQUIRE(ops && bases && n_ops >= 0, "plan_run: null arguments");
-    if (g_side_enabled < 0) {
-        // 0 = off; 1 (default) = eager plans only: fp32 step 20.67 -> 20.44 ms, bf16 14.67 -> 13.90 ms (profiles/README.md, round 2);
-        // 2 = also inside a stream capture: correct, but the replayed graph is SLOWER with the ~165 extra cross-stream edges per step
-        // (fp32 17.9 -> 22.3 ms, bf16 12.6 -> 15.8 ms), so a captured step keeps its two chains and nothing else.
-        const char* e = getenv("CTL_SIDE_STREAM");
-        g_side_enabled = e ? atoi(e) : 1;
-        if (g_side_enabled < 0 || g_side_enabled > 2) g_side_enabled = 0;
-    }
+    side_mode_init();
     size_t forks = 0;
     bool side_used = false;
     bool side_ok = g_side_enabled >= 1;
@@ -206,10 +215,19 @@ extern "C" int ctl_plan_run(const ctl_op* ops, int32_t n_ops, void* const* bases
     // last block costs ~10 us per fused launch (fp32 step 18.3 -> 21.6 ms) -- more than the ~7 us of a stand-alone finalize kernel and
     // its boundary; cross-block hand-offs inside a launch are as expensive as a kernel boundary on this part.  CTL_FUSE_FINALIZE=1 opts in.
     static const bool fuse_enabled = [] { const char* e = getenv("CTL_FUSE_FINALIZE"); return e && atoi(e) != 0; }();
+    // CONSUMER-side variant (CTL_FUSE_CONSUMER, see ctl_bn_consume in ctl_common.h): conv k (statistics) -> BN_FINALIZE k+1 -> conv k+2
+    // whose prologue (role 1) or residual affine (role 2) are exactly that finalize's scale / shift: the finalize moves into the first
+    // blocks of conv k+2.  No hand-off behind the producer's tiles; the wait sits where conv k+2's blocks wait for their first loads anyway.
+    // MEASURED on MI355X (round 2): OFF by default.  With an agent-scope acquire fence in every waiting block the step lost 2 ms (the fence
+    // invalidates the XCD's L2: +20 us per launch); with agent-scope LOADS of the coefficients instead it is 94 launches fewer per step
+    // and still 0.2-0.35 ms slower (fp32 18.3 -> 18.5 ms, bf16 12.0 -> 12.3 ms): the serial writer -> flag -> poll -> load chain at the head
+    // of the consumer costs what the stand-alone launch and its boundary cost.  CTL_FUSE_CONSUMER=1 opts in.
+    static const bool consumer_enabled = [] { const char* e = getenv("CTL_FUSE_CONSUMER"); return e && atoi(e) != 0; }();
     thread_local std::vector<int> rec_of;
-    thread_local std::vector<char> skip;
+    thread_local std::vector<char> skip, role_of;
     rec_of.assign((size_t)n_ops, -1);
     skip.assign((size_t)n_ops + 1, 0);
+    role_of.assign((size_t)n_ops, 0);
     ctl_bn_fin recs[CTL_FIN_MAX_RECS];
     int n_rec = 0;
     char* table = nullptr;
@@ -217,10 +235,40 @@ extern "C" int ctl_plan_run(const ctl_op* ops, int32_t n_ops, void* const* bases
         const int sl = o.slot[a];
         return (sl < 0 || sl >= n_bases || !bases[sl]) ? nullptr : (void*)((char*)bases[sl] + o.off[a]);
     };
+    auto same = [](const ctl_op& x, int ax, const ctl_op& y, int ay) { return x.slot[ax] >= 0 && x.slot[ax] == y.slot[ay] && x.off[ax] == y.off[ay]; };
+    for (int32_t k = 0; consumer_enabled && k + 2 < n_ops && n_rec < CTL_FIN_MAX_RECS; ++k) {
+        const ctl_op& a = ops[k];
+        const ctl_op& b = ops[k + 1];
+        const ctl_op& c = ops[k + 2];
+        if (a.kind != CTL_OP_CONV || b.kind != CTL_OP_BN_FINALIZE || c.kind != CTL_OP_CONV || b.i[4] != 1 || !same(a, 9, b, 0)) continue;
+        ctl_conv dc;
+        memcpy(&dc, c.i, sizeof(dc));
+        if (dc.epi_flags & CTL_EPI_BNBWD) continue;
+        int role = 0;
+        if (dc.pro_affine && same(c, 3, b, 6) && same(c, 4, b, 7) && dc.cin == b.i[1]) role = 1;
+        else if ((dc.epi_flags & CTL_EPI_RES) && !dc.pro_affine && same(c, 6, b, 6) && same(c, 7, b, 7) && dc.cout == b.i[1] && dc.cout >= 4 &&
+                 (dc.groups > 1 ? dc.groups : 1) * dc.cout <= 256 /* CTL_PRO_MAX */) role = 2;
+        if (!role || (dc.groups > 1 ? dc.groups : 1) != (b.i[3] > 0 ? b.i[3] : 1)) continue;
+        ctl_bn_fin& r = recs[n_rec];
+        memset(&r, 0, sizeof(r));
+        r.gamma = (const float*)resolve(b, 1); r.beta = (const float*)resolve(b, 2);
+        r.running_mean = (float*)resolve(b, 3); r.running_var = (float*)resolve(b, 4);
+        r.num_batches_tracked = (int64_t*)resolve(b, 5);
+        r.scale = (float*)resolve(b, 6); r.shift = (float*)resolve(b, 7); r.save_mean = (float*)resolve(b, 8); r.save_invstd = (float*)resolve(b, 9);
+        r.count = b.l[0]; r.eps = b.f[0]; r.momentum = b.f[1]; r.update_running = b.i[2];
+        r.role = role; r.rows = b.i[0]; r.partial = (const float*)resolve(b, 0);
+        const int pslot = a.slot[9];
+        CTL_REQUIRE(pslot < n_bases && bases[pslot], "plan_run: op %d: empty partial slot", k);
+        CTL_REQUIRE(table == nullptr || table == (char*)bases[pslot], "plan_run: fused finalizes must share one partial slot");
+        table = (char*)bases[pslot];
+        rec_of[k + 2] = n_rec++;
+        role_of[k + 2] = (char)role;
+        skip[k + 1] = 1;
+    }
     for (int32_t k = 0; fuse_enabled && k + 1 < n_ops && n_rec < CTL_FIN_MAX_RECS; ++k) {
         const ctl_op& a = ops[k];
         const ctl_op& b = ops[k + 1];
-        if (b.i[4] != 1) continue;
+        if (b.i[4] != 1 || skip[k + 1] || rec_of[k] >= 0) continue;
         int pslot = -1;
         if (a.kind == CTL_OP_CONV && b.kind == CTL_OP_BN_FINALIZE && a.slot[9] >= 0 && a.slot[9] == b.slot[0] && a.off[9] == b.off[0]) {
             ctl_conv dd;
@@ -288,7 +336,7 @@ extern "C" int ctl_plan_run(const ctl_op* ops, int32_t n_ops, void* const* bases
             case CTL_OP_CONV:
                 memcpy(&d, op.i, sizeof(d));
                 rc = ctl_conv_forward_fin(&d, CF(0), CF(1), CF(2), CF(3), CF(4), CF(5), CF(6), CF(7), F(8), F(9),
-                                          rec_of[k] >= 0 ? (void*)(table + (size_t)rec_of[k] * CTL_FIN_REC_BYTES) : nullptr, stream);
+                                          rec_of[k] >= 0 ? (void*)(table + (size_t)rec_of[k] * CTL_FIN_REC_BYTES) : nullptr, role_of[k], stream);
                 break;
             case CTL_OP_WGRAD:
                 memcpy(&d, op.i, sizeof(d));

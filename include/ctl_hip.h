@@ -156,14 +156,18 @@ typedef struct ctl_bn_fin {
     float *scale, *shift, *save_mean, *save_invstd;      /* [groups][c] each */
     int64_t count;                                       /* pixels of ONE group */
     float eps, momentum;
-    int32_t update_running, reserved;
+    int32_t update_running;
+    int32_t role;                                        /* 0: finalised by the PRODUCER's last block (below); 1 / 2: by the first blocks of the
+                                                            CONSUMER launch (1: the coefficients are its prologue, 2: its residual affine) */
+    const float* partial;                                /* roles 1 / 2: the producer's statistics rows [groups][rows][2][c] ... */
+    int32_t rows, reserved;                              /* ... and their number per group (ctl_conv_stats_blocks of the producer) */
 } ctl_bn_fin;
 int ctl_bn_fin_table_write(void* table, const ctl_bn_fin* recs, int32_t n, ctl_stream stream);
 /* ctl_conv_forward with CTL_EPI_STATS + the BatchNorm finalize of its output (fin_rec == NULL: plain ctl_conv_forward) */
 int ctl_conv_forward_fin(const ctl_conv* d, const float* x, const float* wpack, const float* bias,
                          const float* pro_scale, const float* pro_shift, const float* res,
                          const float* res_scale, const float* res_shift, float* y, float* stats_partial,
-                         void* fin_rec, ctl_stream stream);
+                         void* fin_rec, int32_t fin_role, ctl_stream stream);
 /* Backward: arguments by value; `counter`: 9 zero 128-byte lines of device memory (sharded arrival counters, left zero by the launch). */
 typedef struct ctl_bnb_fin {
     const float *gamma, *save_mean, *save_invstd;
@@ -357,6 +361,10 @@ int ctl_prof_start(const char* filter);
 int ctl_prof_stop(char* out, size_t cap);
 /* launch census: kernels / stream memsets / copies enqueued by this library since it was loaded (bench.py reports launches per step) */
 unsigned long long ctl_launch_count(void);
+/* Side lanes of ctl_plan_run (weight gradients of a backward plan on a second, library-owned stream per launch stream): 0 off, 1 eager
+ * plans only (default; environment CTL_SIDE_STREAM), 2 also inside a stream capture.  mode < 0 only queries.  Returns the previous mode.
+ * (bench.py switches them off for the single-stream replay that times the dominant kernel alone.) */
+int ctl_plan_side_lanes(int32_t mode);
 size_t ctl_sizeof_op(void);
 size_t ctl_sizeof_conv(void);
 

@@ -650,7 +650,7 @@ def test_conv_fused_bn_finalize_matches_separate_launch(n, cin, cout, h, w, grou
         y = torch.empty_like(y_ref)
         st = torch.empty_like(stats)
         check(lib.ctl_conv_forward_fin(_ffi.desc_ptr(d), x.data_ptr(), wp.data_ptr(), b.data_ptr(), None, None, None, None, None, y.data_ptr(),
-                                       st.data_ptr(), table.data_ptr(), ops.stream_ptr()))
+                                       st.data_ptr(), table.data_ptr(), 0, ops.stream_ptr()))
         torch.cuda.synchronize()
         assert torch.equal(y, y_ref)
         for got, want, what in zip((sc, sh, mu, isd, rm_b, rv_b), (*ref, rm_a, rv_a), ("scale", "shift", "mean", "invstd", "running_mean", "running_var")):
@@ -692,3 +692,69 @@ def test_bwd_reduce_fused_finalize_matches_separate_launch(mode, n, c, h, w, gro
     close(dg_b, dg_a, rel=2e-6, what="fused bwd finalize dgamma")
     close(db_b, db_a, rel=2e-6, what="fused bwd finalize dbeta")
     assert int(counter.view(torch.int32).abs().sum().item()) == 0
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+@pytest.mark.parametrize("role", [1, 2])
+@pytest.mark.parametrize("n,c1,c2,h,w,groups", [(2, 16, 16, 32, 32, 1), (16, 16, 16, 128, 128, 1), (4, 32, 64, 24, 40, 2), (2, 128, 128, 16, 16, 1), (6, 64, 32, 9, 13, 2)])
+def test_conv_consumer_side_bn_finalize(n, c1, c2, h, w, groups, role, bf16):
+    """ctl_conv_forward_fin with a consumer-side record (ctl_bn_consume): the launch that first USES a BatchNorm's coefficients -- as its
+    prologue (role 1) or as the affine of its residual operand (role 2) -- computes them in its first blocks from the producer's
+    statistics rows while the other blocks wait.  Against ctl_bn_finalize + the plain launch: coefficients, saved and running statistics
+    2e-6 relative (different fixed summation order), outputs 2e-5 of max (+ one bf16 rounding for bf16 storage); two launches agree bitwise."""
+    import ctypes
+    g = torch.Generator().manual_seed(c1 + c2 + h + role)
+    tdt = torch.bfloat16 if bf16 else torch.float32
+    BF = (_ffi.DT_BF16 | _ffi.DT_X16 | _ffi.DT_Y16) if bf16 else 0
+    pack = ops.pack_oihw_fwd_bf16 if bf16 else ops.pack_oihw_fwd
+    x = dev(torch.randn(n, c1, h, w, generator=g)).to(tdt)
+    w1 = dev(torch.randn(c1, c1, 3, 3, generator=g) * 0.2)
+    b1 = dev(torch.randn(c1, generator=g))
+    gamma, beta = dev(torch.rand(c1, generator=g) + 0.5), dev(torch.randn(c1, generator=g) * 0.2)
+    rm0, rv0 = torch.randn(c1, generator=g) * 0.1, torch.rand(c1, generator=g) + 0.5
+    d1 = _ffi.conv_desc(n=n, hin=h, win=w, cin=c1, hout=h, wout=w, cout=c1, ks=3, epi_flags=_ffi.EPI_BIAS | _ffi.EPI_STATS, dt=BF)
+    d1["groups"] = groups
+    count = n * h * w // groups
+    u, stats = ops.conv_forward(d1, x, pack(w1), bias=b1, want_stats=True)           # the producer: u and its statistics rows
+    rows = lib.ctl_conv_stats_blocks(_ffi.desc_ptr(d1))
+    rm_a, rv_a, nbt_a = dev(rm0), dev(rv0), torch.zeros(1, dtype=torch.int64, device=DEV)
+    ref = ops.bn_finalize(stats, c1, count, gamma, beta, running_mean=rm_a, running_var=rv_a, nbt=nbt_a, groups=groups)
+    if role == 1:       # consumer: 3x3 conv c1 -> c2 with the BatchNorm + LeakyReLU prologue
+        w2 = dev(torch.randn(c2, c1, 3, 3, generator=g) * 0.2)
+        b2 = dev(torch.randn(c2, generator=g))
+        d2 = _ffi.conv_desc(n=n, hin=h, win=w, cin=c1, hout=h, wout=w, cout=c2, ks=3, epi_flags=_ffi.EPI_BIAS, pro_affine=1, pro_slope=0.2, dt=BF)
+        d2["groups"] = groups
+        xin, wp2, res = u, pack(w2), None
+        y_ref, _ = ops.conv_forward(d2, xin, wp2, bias=b2, pro_scale=ref[0], pro_shift=ref[1])
+    else:               # consumer: 1x1 conv c2 -> c1 whose residual operand is BN(u): out = LReLU(conv1x1(x2) + scale * u + shift)
+        x2 = dev(torch.randn(n, c2, h, w, generator=g)).to(tdt)
+        w2 = dev(torch.randn(c1, c2, 1, 1, generator=g) * 0.2)
+        b2 = dev(torch.randn(c1, generator=g))
+        d2 = _ffi.conv_desc(n=n, hin=h, win=w, cin=c2, hout=h, wout=w, cout=c1, ks=1, epi_flags=_ffi.EPI_BIAS | _ffi.EPI_RES, epi_act=_ffi.ACT_LEAKY,
+                            epi_slope=0.2, dt=BF | (_ffi.DT_RES16 if bf16 else 0))
+        d2["groups"] = groups
+        xin, wp2, res = x2, pack(w2), u
+        y_ref, _ = ops.conv_forward(d2, xin, wp2, bias=b2, res=res, res_scale=ref[0], res_shift=ref[1])
+    table = torch.zeros(_ffi.FIN_REC_BYTES, dtype=torch.uint8, device=DEV)
+    outs = []
+    for rep in range(2):
+        rm_b, rv_b, nbt_b = dev(rm0), dev(rv0), torch.zeros(1, dtype=torch.int64, device=DEV)
+        sc, sh, mu, isd = (torch.full((groups * c1,), float("nan"), device=DEV) for _ in range(4))
+        fin = _ffi.BnFin(gamma.data_ptr(), beta.data_ptr(), rm_b.data_ptr(), rv_b.data_ptr(), nbt_b.data_ptr(), sc.data_ptr(), sh.data_ptr(),
+                         mu.data_ptr(), isd.data_ptr(), count, 1e-5, 0.1, 1, role, stats.data_ptr(), rows, 0)
+        check(lib.ctl_bn_fin_table_write(table.data_ptr(), ctypes.byref(fin), 1, ops.stream_ptr()))
+        y = torch.empty_like(y_ref)
+        check(lib.ctl_conv_forward_fin(_ffi.desc_ptr(d2), xin.data_ptr(), wp2.data_ptr(), b2.data_ptr(), sc.data_ptr() if role == 1 else None,
+                                       sh.data_ptr() if role == 1 else None, res.data_ptr() if role == 2 else None,
+                                       sc.data_ptr() if role == 2 else None, sh.data_ptr() if role == 2 else None, y.data_ptr(), None,
+                                       table.data_ptr(), role, ops.stream_ptr()))
+        torch.cuda.synchronize()
+        for got, want, what in zip((sc, sh, mu, isd, rm_b, rv_b), (*ref, rm_a, rv_a), ("scale", "shift", "mean", "invstd", "running_mean", "running_var")):
+            close(got, want, rel=2e-6, what=f"consumer-side finalize {what}")
+        assert int(nbt_b.item()) == int(nbt_a.item()) == groups
+        ymax = float(y_ref.float().abs().max())
+        tol = 2e-5 * ymax + (2.0 ** -7 * ymax if bf16 else 0.0)
+        assert float((y.float() - y_ref.float()).abs().max()) <= tol, (role, bf16, float((y.float() - y_ref.float()).abs().max()), tol)
+        outs.append((sc.clone(), sh.clone(), rm_b.clone(), y.clone()))
+    for a_, b_ in zip(*outs):
+        assert torch.equal(a_, b_), "the consumer-side finalize must be deterministic"
