@@ -155,7 +155,7 @@ EXPORTED = ["ctl_version", "ctl_last_error", "ctl_conv_wpack_floats", "ctl_conv_
             "ctl_noise_clamp", "ctl_crop_or_pad", "ctl_step_tick", "ctl_dropout2d_ex", "ctl_dropout2d_dt", "ctl_uniform_dev", "ctl_adam_dev",
             "ctl_latent_mask_fused_ws_floats", "ctl_latent_mask_fused", "ctl_accumulate", "ctl_pack_weights_bf16_batched",
             "ctl_bn_act_dt", "ctl_bwd_reduce_dt", "ctl_bwd_apply_dt", "ctl_sumpool2_dt", "ctl_conv_forward_fin", "ctl_bn_fin_table_write",
-            "ctl_bwd_reduce_fin", "ctl_bwd_reduce_rows", "ctl_launch_count", "ctl_plan_side_lanes"]
+            "ctl_bwd_reduce_fin", "ctl_bwd_reduce_rows", "ctl_launch_count", "ctl_plan_side_lanes", "ctl_consumer_finalize_built"]
 
 
 def prof_start(kernel_filter: str = "") -> None:

@@ -166,6 +166,12 @@ __device__ __forceinline__ void ctl_bn_coefs(double s1, double s2, double count,
 // adds (measured: +24 us per launch), so there are CTL_GO_LINES flag lines (block L polls line L % CTL_GO_LINES, with a sleep between
 // polls).  `lines` = the record's counter lines: line 0 the arrival counter, lines 1.. the go flags; all zero at launch
 // (ctl_bn_fin_table_write zeroes them every plan run).  `sm`: LDS scratch, 16 doubles, free at the call.
+// The kernel side of this path is compiled in with -DCTL_CONSUMER_FINALIZE=1 only (tools/build_variant.sh): its mere presence in the
+// convolution kernels cost the DEFAULT path 1.9 % of the fp32 step (same-box A/B against the commit before it, 18.00 -> 18.34 ms:
+// a few more spilled SGPRs and a longer prologue in every instantiation), for a variant that measured slower anyway.
+#ifndef CTL_CONSUMER_FINALIZE
+#define CTL_CONSUMER_FINALIZE 0
+#endif
 #define CTL_GO_LINES 32
 __device__ __forceinline__ void ctl_bn_consume(const ctl_bn_fin_dev& f, unsigned* lines, int groups, int c, unsigned lin_block, unsigned nblocks,
                                                double* sm) {
@@ -251,7 +257,9 @@ struct alignas(128) ctl_bn_rec {
 static_assert(sizeof(ctl_bn_rec) == CTL_FIN_REC_BYTES, "ctl_bn_rec is one table slot");
 __device__ __forceinline__ void ctl_bn_finalize_tail(ctl_bn_rec* __restrict__ rec, const float* __restrict__ partial, int rows, int groups,
                                                      int cout, int co_first, int nco, unsigned nblocks, int* flag_lds) {
+#if CTL_CONSUMER_FINALIZE
     if (rec->f.role != 0) return;             // (a consumer-side record: nothing to do behind the tiles)
+#endif
     if (!ctl_arrive_last(&rec->counters[blockIdx.y][0][0], blockIdx.z * gridDim.x + blockIdx.x, nblocks, flag_lds)) return;
     const ctl_bn_fin_dev f = rec->f;
     const int lane = threadIdx.x & 63;

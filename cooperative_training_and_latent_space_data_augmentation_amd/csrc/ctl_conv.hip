@@ -326,6 +326,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : ((MT * NT >= 4
     }
     // consumer-side BatchNorm finalize (rec->f.role 1: this kernel's prologue coefficients, 2: its residual affine): the first blocks
     // compute them, everybody waits for them -- behind the first tile's loads
+#if CTL_CONSUMER_FINALIZE
     if (rec && rec->f.role != 0)
         ctl_bn_consume(rec->f, &rec->counters[0][0][0], ngroups, rec->f.role == 1 ? d.cin : d.cout,
                        (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, gridDim.x * gridDim.y * gridDim.z,
@@ -342,6 +343,13 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : ((MT * NT >= 4
         for (int i = tid; i < ngroups * d.cout; i += 256) { cf_scale[i] = ctl_load_wt(res_scale + i); cf_shift[i] = ctl_load_wt(res_shift + i); }
         __syncthreads();
     }
+#else
+    constexpr bool res_lds = false;
+    if (d.pro_affine) {      // behind the first tile's loads, in front of their use
+        for (int i = tid; i < ngroups * d.cin; i += 256) { cf_scale[i] = pro_scale[i]; cf_shift[i] = pro_shift[i]; }
+        __syncthreads();
+    }
+#endif
     if (total_it > 0) {
         xs.store(xt, d, 0, cf_scale, cf_shift, (cur.n / group_n) * d.cin);
         wstore();
@@ -1203,6 +1211,7 @@ __global__ void fin_table_write_kernel(ctl_bn_rec* table, int first, int n, cons
             for (int l = 0; l <= CTL_GO_LINES; ++l) (&table[first + threadIdx.x].counters[0][0][0])[l * CTL_ARRIVE_STRIDE] = 0;
     }
 }
+extern "C" int ctl_consumer_finalize_built(void) { return CTL_CONSUMER_FINALIZE; }
 extern "C" int ctl_bn_fin_table_write(void* table, const ctl_bn_fin* recs, int32_t n, ctl_stream stream) {
     CTL_REQUIRE(table && recs && n > 0 && ((uintptr_t)table & 127) == 0, "bn_fin_table_write: bad arguments");
     for (int first = 0; first < n; first += 16) {
@@ -1242,6 +1251,7 @@ extern "C" int ctl_conv_forward_fin(const ctl_conv* d, const float* x, const flo
     if (rc != CTL_OK) return rc;
     if (fin_rec) {
         CTL_REQUIRE(((uintptr_t)fin_rec & 127) == 0 && fin_role >= 0 && fin_role <= 2, "conv_forward: fused finalize: 128-byte aligned record, role 0..2");
+        CTL_REQUIRE(fin_role == 0 || CTL_CONSUMER_FINALIZE, "conv_forward: consumer-side finalize records need a -DCTL_CONSUMER_FINALIZE=1 build of the kernels");
         if (fin_role == 0) {
             CTL_REQUIRE((d->epi_flags & CTL_EPI_STATS) && !(d->epi_flags & CTL_EPI_BNBWD) && stats_partial, "conv_forward: a producer-side BatchNorm finalize needs CTL_EPI_STATS (and no CTL_EPI_BNBWD)");
             CTL_REQUIRE(ctl_cdiv(ctl_cdiv(d->cout, 16), a.c.nt) <= CTL_FIN_MAX_Y, "conv_forward: fused finalize: at most %d block rows of output-channel tiles", CTL_FIN_MAX_Y);

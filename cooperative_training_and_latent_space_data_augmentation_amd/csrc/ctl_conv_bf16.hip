@@ -354,6 +354,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? CTL16_OCC_BIG : CT
         wload(0);
     }
     // consumer-side BatchNorm finalize (ctl_bn_consume; see the fp32 kernel)
+#if CTL_CONSUMER_FINALIZE
     if (rec && rec->f.role != 0)
         ctl_bn_consume(rec->f, &rec->counters[0][0][0], ngroups, rec->f.role == 1 ? d.cin : d.cout,
                        (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, gridDim.x * gridDim.y * gridDim.z,
@@ -370,6 +371,13 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? CTL16_OCC_BIG : CT
         for (int i = tid; i < ngroups * d.cout; i += 256) { cf_scale[i] = ctl_load_wt(res_scale + i); cf_shift[i] = ctl_load_wt(res_shift + i); }
         __syncthreads();
     }
+#else
+    constexpr bool res_lds = false;
+    if (d.pro_affine) {
+        for (int i = tid; i < ngroups * d.cin; i += 256) { cf_scale[i] = pro_scale[i]; cf_shift[i] = pro_shift[i]; }
+        __syncthreads();
+    }
+#endif
     if (total_it > 0) {
         xs.store(xt, d, 0, cf_scale, cf_shift, (cur.n / group_n) * d.cin);
         wstore();

@@ -143,7 +143,7 @@ static_assert(sizeof(ctl_conv) == 24 * 4, "ctl_conv must be 24 32-bit words (it 
 // Side lane: ops with i[26] == 1 (weight gradients and their batched reduction: off the critical dgrad chain) run on a
 // library-owned second stream so that their launches fill the ramp-up / tail bubbles of the main chain.  Fork = event
 // recorded on the main stream right before the side op (it then sees everything the main stream produced so far);
-// join = the main stream waits for the side stream once, at the end of the plan.  CTL_SIDE_STREAM=0 switches it off.
+// join = the main stream waits for the side stream once, at the end of the plan.  Opt-in: CTL_SIDE_STREAM=1 (eager) / 2 (+ captured).
 // Every main stream has its own side stream (the two launch chains of a training step do not serialise each other's side work).
 // Under stream capture (hipGraph mode) the fork / join events become graph dependencies; nothing may be CREATED while a capture is
 // running, so a lane is only used there if an eager plan on the same stream created it (and enough fork events) before -- the graph
@@ -178,11 +178,13 @@ static hipEvent_t fork_event(side_lane* l, size_t k, bool may_create) {
 
 static void side_mode_init() {
     if (g_side_enabled >= 0) return;
-    // 0 = off; 1 (default) = eager plans only: fp32 step 20.67 -> 20.44 ms, bf16 14.67 -> 13.90 ms (profiles/README.md, round 2);
-    // 2 = also inside a stream capture: correct, but the replayed graph is SLOWER with the ~165 extra cross-stream edges per step
-    // (fp32 17.9 -> 22.3 ms, bf16 12.6 -> 15.8 ms), so a captured step keeps its two chains and nothing else.
+    // 0 (default) = off; 1 = eager plans; 2 = also inside a stream capture.  Round-2 measurements (profiles/README.md): in eager mode the
+    // lanes were worth +1-5 % on some boxes and -1-4 % on others, and merely HAVING the two extra streams alive cost the hipGraph replays
+    // of the same process 1.5 % (fp32 18.08 -> 18.35 ms): streams share a few hardware queues, and which streams share one decides how
+    // well the two launch chains overlap (GPU_MAX_HW_QUEUES=8 without lanes put both chains of the replay on ONE queue: 31.6 ms).
+    // Captured lanes are correct but slow (~165 extra cross-stream edges per replay: fp32 17.9 -> 22.3 ms).
     const char* e = getenv("CTL_SIDE_STREAM");
-    g_side_enabled = e ? atoi(e) : 1;
+    g_side_enabled = e ? atoi(e) : 0;
     if (g_side_enabled < 0 || g_side_enabled > 2) g_side_enabled = 0;
 }
 extern "C" int ctl_plan_side_lanes(int32_t mode) {
@@ -222,7 +224,7 @@ extern "C" int ctl_plan_run(const ctl_op* ops, int32_t n_ops, void* const* bases
     // invalidates the XCD's L2: +20 us per launch); with agent-scope LOADS of the coefficients instead it is 94 launches fewer per step
     // and still 0.2-0.35 ms slower (fp32 18.3 -> 18.5 ms, bf16 12.0 -> 12.3 ms): the serial writer -> flag -> poll -> load chain at the head
     // of the consumer costs what the stand-alone launch and its boundary cost.  CTL_FUSE_CONSUMER=1 opts in.
-    static const bool consumer_enabled = [] { const char* e = getenv("CTL_FUSE_CONSUMER"); return e && atoi(e) != 0; }();
+    static const bool consumer_enabled = [] { const char* e = getenv("CTL_FUSE_CONSUMER"); return CTL_CONSUMER_FINALIZE && e && atoi(e) != 0; }();
     thread_local std::vector<int> rec_of;
     thread_local std::vector<char> skip, role_of;
     rec_of.assign((size_t)n_ops, -1);

@@ -74,7 +74,8 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
         self.two_streams = os.environ.get("CTL_TWO_STREAMS", "1") != "0"
         # parameter gradients of the passes of a step are parked and added with one launch per network after backward (nets.py)
         self.defer_param_grads = os.environ.get("CTL_DEFER_GRADS", "1") != "0"
-        self._side = torch.cuda.Stream(device=self.device) if self.two_streams else None
+        # (tuning hook CTL_CHAIN_PRIORITY: priority of the second chain's stream; streams of different priority never share a hardware queue)
+        self._side = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("CTL_CHAIN_PRIORITY", "0"))) if self.two_streams else None
         if self.two_streams and hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
             # the flat-parameter leaves live on the main stream while part of their gradient is produced on the second one: intended
             torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)

@@ -163,6 +163,9 @@ typedef struct ctl_bn_fin {
     int32_t rows, reserved;                              /* ... and their number per group (ctl_conv_stats_blocks of the producer) */
 } ctl_bn_fin;
 int ctl_bn_fin_table_write(void* table, const ctl_bn_fin* recs, int32_t n, ctl_stream stream);
+/* 1 if the convolution kernels were built with -DCTL_CONSUMER_FINALIZE=1 (records with role 1 / 2 are refused otherwise: the default
+ * build leaves the consumer-side path out of the kernels, see ctl_common.h) */
+int ctl_consumer_finalize_built(void);
 /* ctl_conv_forward with CTL_EPI_STATS + the BatchNorm finalize of its output (fin_rec == NULL: plain ctl_conv_forward) */
 int ctl_conv_forward_fin(const ctl_conv* d, const float* x, const float* wpack, const float* bias,
                          const float* pro_scale, const float* pro_shift, const float* res,
@@ -361,8 +364,8 @@ int ctl_prof_start(const char* filter);
 int ctl_prof_stop(char* out, size_t cap);
 /* launch census: kernels / stream memsets / copies enqueued by this library since it was loaded (bench.py reports launches per step) */
 unsigned long long ctl_launch_count(void);
-/* Side lanes of ctl_plan_run (weight gradients of a backward plan on a second, library-owned stream per launch stream): 0 off, 1 eager
- * plans only (default; environment CTL_SIDE_STREAM), 2 also inside a stream capture.  mode < 0 only queries.  Returns the previous mode.
+/* Side lanes of ctl_plan_run (weight gradients of a backward plan on a second, library-owned stream per launch stream): 0 off (default),
+ * 1 eager plans (environment CTL_SIDE_STREAM), 2 also inside a stream capture.  mode < 0 only queries.  Returns the previous mode.
  * (bench.py switches them off for the single-stream replay that times the dominant kernel alone.) */
 int ctl_plan_side_lanes(int32_t mode);
 size_t ctl_sizeof_op(void);
