@@ -117,6 +117,17 @@ def cpu_baseline(host_batch, threads, steps=3, cfgs=(DROP_IMG, DROP_SEG), what="
                       f"threads: 1 warm-up ({times[0]:.1f} s) + {steps} timed steps, median {med:.1f} s (all: {[round(t, 1) for t in times[1:]]})"}
 
 
+def flush_c_stdio():
+    """RCCL writes its version banner to C stdout while the first communicator is built; redirected to a file that buffer is only
+    written at process exit -- BEHIND the JSON line.  Flushing it early keeps the JSON line the last line of the job's stdout."""
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -175,6 +186,8 @@ def main():
     solver = AdvancedTripletReconSegmentationModel(network_type="FCN_16_standard", image_ch=1, num_classes=4,
                                                    learning_rate=1e-4, use_gpu=True, compute_dtype=args.dtype)
     dp = DataParallel(solver) if use_dist else None
+    if use_dist:
+        flush_c_stdio()                                   # (the weight broadcast built the communicator: its banner goes out now)
     if use_dist:                                         # per-rank RNG streams (scheme / k / dropout / soft-noise draws), after the weight broadcast
         import random
         import numpy as np
@@ -183,6 +196,8 @@ def main():
         random.seed(1234 + rank)
     clean, label, noisy, host_batch = synthetic(args.batch, args.size, args.size, 1000 + rank, device)
     hook = dp.sync_gradients if dp else None
+    if os.environ.get("CTL_BENCH_NO_HOOK"):              # diagnosis only: RCCL initialised, no gradient exchange
+        hook = None
 
     def eager_step():
         return solver.cooperative_step(clean, label, noisy, IMG_CFG, SEG_CFG, grad_hook=hook)
@@ -237,7 +252,7 @@ def main():
         import gc
         gc.collect()
         torch.cuda.empty_cache()
-        for _ in range(3):
+        for _ in range(8):                                # (3 were not enough: 14 device allocations fell into the timed region)
             eager_step()
         fence()
     # launches of one step: the library's own census over one eager step (untimed; the graph replays the same launches as nodes) +
@@ -318,6 +333,7 @@ def main():
                         "note": "GPU time between consecutive per-step events on the launch stream (rank 0)"},
             "cpu_issue_ms": {"median": 1e3 * sorted(issue_s)[len(issue_s) // 2], "max": 1e3 * max(issue_s)},
             "device_allocs_in_timed_region": int(allocs_in_region),
+            "chain_overlap": getattr(solver, "chain_overlap", None),
             "launches_per_step": {"library": launches_per_step, "note": "kernels + stream memsets / copies enqueued by libctl_hip.so in one step "
                                   "(ctl_launch_count); PyTorch adds ~45 fills / copies per step (tools/aten_ops_in_step.py)"},
         }
@@ -363,9 +379,11 @@ def main():
             out["roofline_latent_mask"] = latent_mask_roofline(device)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(host_batch, args.cpu_threads or min(32, os.cpu_count()), cfgs=(IMG_CFG, SEG_CFG), what=mask_text)
-        print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()
+    flush_c_stdio()
+    if rank == 0:                                         # the JSON line is the LAST thing this job writes to stdout
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -109,6 +109,7 @@ class _Lib:
             "ctl_dropout2d": [p, p, u64, f32, p, p, i32, i32, i32, p],
             "ctl_uniform": [p, i64, u64, p],
             "ctl_step_tick": [p, p],
+            "ctl_spin": [i32, p],
             "ctl_dropout2d_ex": [p, p, u64, p, f32, p, p, p, i32, i32, i32, p],
             "ctl_dropout2d_dt": [p, p, u64, p, f32, p, p, i32, i32, i32, C.c_uint32, p],
             "ctl_uniform_dev": [p, i64, u64, p, p],
@@ -152,7 +153,7 @@ EXPORTED = ["ctl_version", "ctl_last_error", "ctl_conv_wpack_floats", "ctl_conv_
             "ctl_latent_mask_apply", "ctl_latent_mask_apply_ws_floats", "ctl_dropout2d", "ctl_uniform", "ctl_adam", "ctl_plan_run", "ctl_sizeof_op",
             "ctl_sizeof_conv", "ctl_prof_start", "ctl_prof_stop", "ctl_pack_weights_batched",
             "ctl_wgrad_reduce_batched", "ctl_confusion_hist", "ctl_rescale_intensity_ws_floats", "ctl_rescale_intensity",
-            "ctl_noise_clamp", "ctl_crop_or_pad", "ctl_step_tick", "ctl_dropout2d_ex", "ctl_dropout2d_dt", "ctl_uniform_dev", "ctl_adam_dev",
+            "ctl_noise_clamp", "ctl_crop_or_pad", "ctl_step_tick", "ctl_spin", "ctl_dropout2d_ex", "ctl_dropout2d_dt", "ctl_uniform_dev", "ctl_adam_dev",
             "ctl_latent_mask_fused_ws_floats", "ctl_latent_mask_fused", "ctl_accumulate", "ctl_pack_weights_bf16_batched",
             "ctl_bn_act_dt", "ctl_bwd_reduce_dt", "ctl_bwd_apply_dt", "ctl_sumpool2_dt", "ctl_conv_forward_fin", "ctl_bn_fin_table_write",
             "ctl_bwd_reduce_fin", "ctl_bwd_reduce_rows", "ctl_launch_count", "ctl_plan_side_lanes", "ctl_consumer_finalize_built"]

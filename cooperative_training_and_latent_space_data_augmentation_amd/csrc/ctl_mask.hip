@@ -656,6 +656,18 @@ extern "C" int ctl_uniform_dev(float* out, int64_t count, uint64_t salt, const i
 __global__ void step_tick_kernel(int64_t* state) {
     if (threadIdx.x == 0 && blockIdx.x == 0) { state[1] += 1; state[2] += 1; }
 }
+// A kernel that does nothing for `microseconds` (one wave; 100 MHz constant clock): the probe with which the host checks that two
+// streams really run side by side.  HIP streams share a handful of hardware queues, and two streams on ONE queue execute in order.
+__global__ void spin_kernel(unsigned long long ticks) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+extern "C" int ctl_spin(int32_t microseconds, ctl_stream stream) {
+    CTL_REQUIRE(microseconds >= 0 && microseconds <= 100000, "spin: 0..100000 us");
+    spin_kernel<<<dim3(1), dim3(64), 0, (hipStream_t)stream>>>((unsigned long long)microseconds * 100ull);
+    CTL_LAUNCH_CHECK("spin");
+    return CTL_OK;
+}
 extern "C" int ctl_step_tick(int64_t* state, ctl_stream stream) {
     CTL_REQUIRE(state, "step_tick: null state");
     step_tick_kernel<<<dim3(1), dim3(64), 0, (hipStream_t)stream>>>(state);

@@ -80,6 +80,7 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
             # the flat-parameter leaves live on the main stream while part of their gradient is produced on the second one: intended
             torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
         self._side_pending = False
+        self._queue_checked, self.chain_overlap = None, None
         self._chain_events = None        # list collecting per-step stream events (tools/chain_timing.py)
         self._in_side = False            # True while the hard-example branch of cooperative_step is being issued on the side stream
         # HIP-graph capture (graph.py): while set, nothing that changes from step to step may be a launch argument -- RNG seeds and the
@@ -224,6 +225,42 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
 
     def decode_image(self, latent_code, disable_track_bn_stats=False):
         return self._call(self.model["image_decoder"], latent_code, disable_track_bn_stats)
+
+    # ------------------------------------------------------------------ the two launch chains need two HARDWARE queues
+    @staticmethod
+    def _overlap_probe(a, b, us=300) -> float:
+        """Two idle 300-us kernels, one per stream, between two events: ~1.0 = they ran side by side, ~2.0 = one behind the other."""
+        from ._ffi import lib, check
+        for st in (a, b):
+            check(lib.ctl_spin(1, st.cuda_stream), "ctl_spin")
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        b.wait_stream(a)
+        e0.record(a)
+        for st in (a, b):
+            check(lib.ctl_spin(us, st.cuda_stream), "ctl_spin")
+        a.wait_stream(b)
+        e1.record(a)
+        e1.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / us
+
+    def _ensure_chains_overlap(self):
+        """HIP streams share a few hardware queues (4 by default) in creation order, and two streams on one queue run IN ORDER: the
+        second chain then overlaps nothing (measured: 18.2 -> 22.5 ms per step once RCCL's streams had shifted the assignment,
+        profiles/README.md round 2).  Before the first two-chain step on a stream the pair is probed with two idle kernels; on a
+        collision the second chain moves to the next stream of torch's pool (the next queue) until the probe shows overlap."""
+        if torch.cuda.is_current_stream_capturing():
+            return
+        cur = torch.cuda.current_stream()
+        if self._queue_checked == cur.cuda_stream:
+            return
+        self._queue_checked = cur.cuda_stream
+        prio = int(os.environ.get("CTL_CHAIN_PRIORITY", "0"))
+        ratio, attempts = self._overlap_probe(cur, self._side), 1
+        while ratio > 1.5 and attempts < 8:
+            self._side = torch.cuda.Stream(device=self.device, priority=prio)
+            ratio, attempts = self._overlap_probe(cur, self._side), attempts + 1
+        self.chain_overlap = {"probe_ratio": round(ratio, 2), "streams_tried": attempts, "overlap": ratio <= 1.5}
 
     def _fork_side(self, fn, *inputs):
         """Run fn() on the side stream (after everything issued so far on the current stream) when two_streams is on; the result
@@ -661,6 +698,7 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
     def _cooperative_step(self, clean_image_l, label_l, image_l, img_cfg, seg_cfg, latent_DA, separate_training, image_override,
                           seg_override, do_optim, grad_hook):
         if self.two_streams and latent_DA:
+            self._ensure_chains_overlap()
             std, hard = self._two_chain_forward(clean_image_l, label_l, image_l, img_cfg, seg_cfg, separate_training, image_override,
                                                 seg_override)
             # (two backward() calls, one per chain, were measured: 682 vs 751 slices/s -- every call ends by joining the streams)

@@ -287,6 +287,9 @@ int ctl_uniform(float* out, int64_t count, uint64_t seed, ctl_stream stream);
  * integer argument is a per-call-site salt.  ctl_dropout2d_ex additionally writes (mask_full != NULL) upstream's dropout `mask`
  * (model.py:334-336: 1 where the dropped-out tensor equals the input element, else 0; [n,hw,c] like out). */
 int ctl_step_tick(int64_t* state, ctl_stream stream);
+/* One idle wave for `microseconds` on `stream`: the host-side probe for "do these two streams overlap?" (streams share a few hardware
+ * queues; the two launch chains of a training step must not sit on the same one, see solver.py) */
+int ctl_spin(int32_t microseconds, ctl_stream stream);
 int ctl_dropout2d_ex(const float* z, const float* keep, uint64_t seed_or_salt, const int64_t* state, float p, float* out,
                      float* keep_out, float* mask_full, int32_t n, int32_t hw, int32_t c, ctl_stream stream);
 int ctl_uniform_dev(float* out, int64_t count, uint64_t salt, const int64_t* state, ctl_stream stream);

@@ -41,7 +41,7 @@ torch.cuda.synchronize()
 launches = int(_ffi.lib.ctl_launch_count() - n0) // 2
 sums = {k: float(m._flat_data.double().sum()) for k, m in s.model.items()}
 bufs = {k: float(m._bflat.double().sum()) for k, m in s.model.items()}
-print("RESULT " + json.dumps({"losses": out, "sums": sums, "bufs": bufs, "launches": launches}))
+print("RESULT " + json.dumps({"losses": out, "sums": sums, "bufs": bufs, "launches": launches, "chain_overlap": s.chain_overlap}))
 """ % ROOT
 
 
@@ -86,3 +86,16 @@ def test_side_stream_inside_a_captured_step():
     got = run({"CTL_SIDE_STREAM": "2"}, graph=True)
     assert got["losses"] == ref["losses"], (got["losses"], ref["losses"])
     assert got["sums"] == ref["sums"] and got["bufs"] == ref["bufs"]
+
+
+def test_two_chains_sit_on_two_hardware_queues(default_run):
+    """solver._ensure_chains_overlap: before the first two-chain step the pair of streams is probed with two idle kernels (ctl_spin) and
+    the second chain is moved to another stream until they run side by side.  With ONE hardware queue for the whole process
+    (GPU_MAX_HW_QUEUES=1) no stream can overlap the main one: the probe reports it after 8 streams and the step is still the same step."""
+    ov = default_run["chain_overlap"]
+    assert ov is not None and ov["overlap"] and ov["probe_ratio"] < 1.5, ov
+    one = run({"GPU_MAX_HW_QUEUES": "1"})
+    assert one["chain_overlap"]["overlap"] is False and one["chain_overlap"]["streams_tried"] == 8, one["chain_overlap"]
+    for a, b in zip(one["losses"], default_run["losses"]):
+        for x, y in zip(a, b):
+            assert abs(x - y) <= 2e-5 * max(1.0, abs(y)), (a, b)
