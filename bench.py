@@ -252,7 +252,10 @@ def main():
         import gc
         gc.collect()
         torch.cuda.empty_cache()
-        for _ in range(8):                                # (3 were not enough: 14 device allocations fell into the timed region)
+        # as many un-synchronised steps as the timed region has: the host runs several steps ahead of the GPU there, blocks that carry
+        # a record_stream() mark are reused late, and the pool only stops growing once it has seen that depth (3 steps: 14 device
+        # allocations and one 13.5-ms step inside the timed region)
+        for _ in range(max(8, args.steps)):
             eager_step()
         fence()
     # launches of one step: the library's own census over one eager step (untimed; the graph replays the same launches as nodes) +
@@ -273,6 +276,7 @@ def main():
     step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     issue_s = []
     alloc0 = torch.cuda.memory_stats().get("num_device_alloc", 0)
+    alloc_at = []
     t0 = time.perf_counter()
     step_ev[0].record()
     for i in range(args.steps):
@@ -280,6 +284,7 @@ def main():
         losses = step()
         issue_s.append(time.perf_counter() - ti)
         step_ev[i + 1].record()
+        alloc_at.append(torch.cuda.memory_stats().get("num_device_alloc", 0))
     fence()
     dt = time.perf_counter() - t0
     step_ms = sorted(step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(args.steps))
@@ -333,6 +338,7 @@ def main():
                         "note": "GPU time between consecutive per-step events on the launch stream (rank 0)"},
             "cpu_issue_ms": {"median": 1e3 * sorted(issue_s)[len(issue_s) // 2], "max": 1e3 * max(issue_s)},
             "device_allocs_in_timed_region": int(allocs_in_region),
+            "device_allocs_by_step": [int(b - a) for a, b in zip([alloc0] + alloc_at[:-1], alloc_at)],
             "chain_overlap": getattr(solver, "chain_overlap", None),
             "launches_per_step": {"library": launches_per_step, "note": "kernels + stream memsets / copies enqueued by libctl_hip.so in one step "
                                   "(ctl_launch_count); PyTorch adds ~45 fills / copies per step (tools/aten_ops_in_step.py)"},

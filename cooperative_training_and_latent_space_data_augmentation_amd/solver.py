@@ -709,7 +709,7 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
                 grad_hook(self)
             if do_optim:
                 self.optimize_all_params()
-            return tuple(std) + tuple(hard)
+            return self._loss_record(std, hard)
         std = self.standard_training(clean_image_l, label_l, perturbed_image=image_l, separate_training=separate_training)
         loss = std[0] + std[1] + std[3] + std[2]
         zero = torch.zeros((), device=clean_image_l.device)
@@ -728,4 +728,11 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
             grad_hook(self)          # data-parallel gradient all-reduce goes here
         if do_optim:
             self.optimize_all_params()
-        return tuple(std) + tuple(hard)
+        return self._loss_record(std, hard)
+
+    @staticmethod
+    def _loss_record(std, hard):
+        """The 8 losses as DETACHED device scalars: backward has run, and a caller that keeps the tuple until the next step (any training
+        loop does) would otherwise keep the whole autograd graph of this step alive through their grad_fn -- and with it the activation
+        arenas of every pass, so that the next step needs a second set (seen as 8 device allocations in bench.py's second timed step)."""
+        return tuple(v.detach() for v in tuple(std) + tuple(hard))
