@@ -55,6 +55,9 @@ __device__ __forceinline__ float ctl_load_wt(const float* p) { return __hip_atom
 // Arrival counters are SHARDED: `base` points at CTL_ARRIVE_LINES 128-byte lines -- line 0 the top counter, lines 1..8 one shard
 // each (block L arrives at shard L % 8; the last arriver of a shard arrives at the top).  Hundreds of adds to ONE address serialise at
 // ~12 ns each on this part (768 blocks: 9 us per launch, measured); 8 shards on lines of their own run side by side.
+#ifndef CTL_ARRIVE_ACQUIRE
+#define CTL_ARRIVE_ACQUIRE 1      /* experiment hook: 0 = no agent-scope acquire (L2 invalidate) in the last block; it reads the rows with agent-scope loads anyway */
+#endif
 #define CTL_ARRIVE_SHARDS 8
 #define CTL_ARRIVE_LINES (CTL_ARRIVE_SHARDS + 1)
 #define CTL_ARRIVE_STRIDE 32      /* uint32 per line */
@@ -78,7 +81,9 @@ __device__ __forceinline__ bool ctl_arrive_last(unsigned* base, unsigned block_l
     }
     __syncthreads();
     if (!*flag_lds) return false;
+#if CTL_ARRIVE_ACQUIRE
     if (threadIdx.x < 64) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     return true;
