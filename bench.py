@@ -34,6 +34,8 @@ PEAK_MFMA_BF16_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak
 PEAK_HBM_GBS = 8000.0
 # dominant kernel of this workload per profiles/ (rocprofv3 --kernel-trace --stats): the 3x3 stride-1 implicit-GEMM conv
 # at 8x32 tiles / 16 output channels, i.e. every 16->16 (and 1|4->16, 16->4) conv and dgrad at 256x256
+PROF_EVERY = 4                   # inside the timed region the dominant kernel's launches are sampled (two event records per launch cost
+                                 # a launch-bound step ~1.5 %); the single-stream replay behind it brackets every launch
 DOMINANT = "conv_igemm<ks3,s1,in0,mt4,tw32,nt1>"
 DOMINANT_BF16 = "conv_igemm_bf16<ks3,s1,in0,mt4,tw32,nt1>"
 
@@ -235,7 +237,7 @@ def main():
             fence()
             return 1e3 * (time.perf_counter() - t) / n
         if rank == 0:                                     # as in the timed region: eager steps carry the per-launch events of the
-            _ffi.prof_start(args.prof_filter)             # dominant kernel (the roofline figure), graph replays cannot
+            _ffi.prof_start(args.prof_filter, PROF_EVERY) # dominant kernel (the roofline figure), graph replays cannot
         calib["eager_ms"] = time_steps(eager_step)
         if rank == 0:
             _ffi.prof_stop()
@@ -270,7 +272,7 @@ def main():
         phase_tm = (ctypes.c_ulonglong * 12)()
         _ffi.lib.ctl_debug_timing(phase_tm)               # reset
     if rank == 0 and mode == "eager":                     # per-launch HIP events cannot be recorded inside a graph replay
-        _ffi.prof_start(args.prof_filter)
+        _ffi.prof_start(args.prof_filter, PROF_EVERY)     # (every 4th launch of the dominant kernel: ~250 samples in 20 steps)
     # per-step record: one event per step on the launch stream (no sync inside the timed region), the host's
     # issue time per step, and the caching allocator's device-allocation counter (a hipMalloc inside the region = a one-off stall)
     step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]

@@ -117,7 +117,7 @@ class _Lib:
             "ctl_adam": [p, p, p, p, i64, f32, f32, f32, f32, i32, f32, p],
             "ctl_accumulate": [p, p, i32, i64, p],
             "ctl_plan_run": [p, i32, p, i32, p],
-            "ctl_prof_start": [C.c_char_p], "ctl_prof_stop": [p, C.c_size_t],
+            "ctl_prof_start": [C.c_char_p], "ctl_prof_start_sampled": [C.c_char_p, i32], "ctl_prof_stop": [p, C.c_size_t],
             "ctl_pack_weights_batched": [p, p, p, i32, i64, p], "ctl_wgrad_reduce_batched": [p, p, p, i32, i64, p],
             "ctl_pack_weights_bf16_batched": [p, p, p, i32, i64, p],
             "ctl_conv_forward_fin": [p] * 12 + [i32, p],
@@ -151,7 +151,7 @@ EXPORTED = ["ctl_version", "ctl_last_error", "ctl_conv_wpack_floats", "ctl_conv_
             "ctl_sigmoid_bwd", "ctl_softmax_t_fwd", "ctl_softmax_t_bwd", "ctl_onehot", "ctl_ce2d_fwd", "ctl_ce2d_bwd",
             "ctl_mse_fwd", "ctl_mse_bwd", "ctl_argmax_c", "ctl_latent_score_ws_floats", "ctl_latent_score",
             "ctl_latent_mask_apply", "ctl_latent_mask_apply_ws_floats", "ctl_dropout2d", "ctl_uniform", "ctl_adam", "ctl_plan_run", "ctl_sizeof_op",
-            "ctl_sizeof_conv", "ctl_prof_start", "ctl_prof_stop", "ctl_pack_weights_batched",
+            "ctl_sizeof_conv", "ctl_prof_start", "ctl_prof_start_sampled", "ctl_prof_stop", "ctl_pack_weights_batched",
             "ctl_wgrad_reduce_batched", "ctl_confusion_hist", "ctl_rescale_intensity_ws_floats", "ctl_rescale_intensity",
             "ctl_noise_clamp", "ctl_crop_or_pad", "ctl_step_tick", "ctl_spin", "ctl_dropout2d_ex", "ctl_dropout2d_dt", "ctl_uniform_dev", "ctl_adam_dev",
             "ctl_latent_mask_fused_ws_floats", "ctl_latent_mask_fused", "ctl_accumulate", "ctl_pack_weights_bf16_batched",
@@ -159,8 +159,9 @@ EXPORTED = ["ctl_version", "ctl_last_error", "ctl_conv_wpack_floats", "ctl_conv_
             "ctl_bwd_reduce_fin", "ctl_bwd_reduce_rows", "ctl_launch_count", "ctl_plan_side_lanes", "ctl_consumer_finalize_built"]
 
 
-def prof_start(kernel_filter: str = "") -> None:
-    check(lib.ctl_prof_start(kernel_filter.encode()), "ctl_prof_start")
+def prof_start(kernel_filter: str = "", every: int = 1) -> None:
+    """Bracket the launches whose id contains `kernel_filter` with HIP events on their own stream (every `every`-th one)."""
+    check(lib.ctl_prof_start_sampled(kernel_filter.encode(), int(every)), "ctl_prof_start_sampled")
 
 
 def prof_stop() -> dict:

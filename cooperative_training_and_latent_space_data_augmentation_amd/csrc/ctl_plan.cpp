@@ -47,6 +47,14 @@ struct ProfRec { std::string id; hipEvent_t a, b; double flops, bytes; void* str
 bool g_prof_on = false;
 std::string g_prof_filter;
 std::vector<ProfRec> g_prof;
+std::vector<hipEvent_t> g_prof_pool;      // events are recycled: two hipEventCreate per bracketed launch were most of the profiler's cost
+int g_prof_every = 1;                     // bracket every n-th matching launch (sampling: the timed region of bench.py)
+long g_prof_seen = 0;
+hipEvent_t prof_event() {
+    if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    return hipEventCreate(&e) == hipSuccess ? e : nullptr;
+}
 }  // namespace
 
 int ctl_prof_begin(const char* kind, const ctl_conv* d, const ctl_conv_cfg* c, int nt, hipStream_t stream) {
@@ -54,10 +62,13 @@ int ctl_prof_begin(const char* kind, const ctl_conv* d, const ctl_conv_cfg* c, i
     char id[128];
     snprintf(id, sizeof(id), "%s<ks%d,s%d,in%d,mt%d,tw%d,nt%d>", kind, d->ks, d->stride, d->in_mode, c->mt, c->tw, nt);
     if (!g_prof_filter.empty() && std::string(id).find(g_prof_filter) == std::string::npos) return -1;
+    if (g_prof_every > 1 && (g_prof_seen++ % g_prof_every) != 0) return -1;
     ProfRec r;
     r.id = id;
     r.stream = (void*)stream;
-    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return -1;
+    r.a = prof_event();
+    r.b = prof_event();
+    if (!r.a || !r.b) return -1;
     const double pix = (double)d->n * d->hout * d->wout * d->nsub;
     r.flops = 2.0 * pix * d->cout * d->cin * d->ks * d->ks;
     const double in_b = ((d->dt & CTL_DT_X16) ? 2.0 : 4.0) * d->n * d->hin * d->win * d->cin, out_b = ((d->dt & CTL_DT_Y16) ? 2.0 : 4.0) * pix * d->cout;
@@ -78,7 +89,9 @@ static int prof_begin_op(int kind, hipStream_t stream) {
     r.id = id;
     r.stream = (void*)stream;
     r.flops = r.bytes = 0.0;
-    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return -1;
+    r.a = prof_event();
+    r.b = prof_event();
+    if (!r.a || !r.b) return -1;
     (void)hipEventRecord(r.a, stream);
     g_prof.push_back(r);
     return (int)g_prof.size() - 1;
@@ -86,13 +99,16 @@ static int prof_begin_op(int kind, hipStream_t stream) {
 void ctl_prof_end(int token, hipStream_t stream) {
     if (token >= 0 && token < (int)g_prof.size()) (void)hipEventRecord(g_prof[token].b, stream);
 }
-extern "C" int ctl_prof_start(const char* filter) {
-    for (auto& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+extern "C" int ctl_prof_start_sampled(const char* filter, int32_t every) {
+    for (auto& r : g_prof) { g_prof_pool.push_back(r.a); g_prof_pool.push_back(r.b); }
     g_prof.clear();
     g_prof_filter = filter ? filter : "";
+    g_prof_every = every > 1 ? every : 1;
+    g_prof_seen = 0;
     g_prof_on = true;
     return CTL_OK;
 }
+extern "C" int ctl_prof_start(const char* filter) { return ctl_prof_start_sampled(filter, 1); }
 extern "C" int ctl_prof_stop(char* out, size_t cap) {
     g_prof_on = false;
     struct Agg { long n = 0; double ms = 0, flops = 0, bytes = 0; };
@@ -113,7 +129,7 @@ extern "C" int ctl_prof_stop(char* out, size_t cap) {
             a.n++; a.ms += ms; a.flops += r.flops; a.bytes += r.bytes;
         }
     }
-    for (auto& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (auto& r : g_prof) { g_prof_pool.push_back(r.a); g_prof_pool.push_back(r.b); }
     g_prof.clear();
     if (tl) fclose(tl);
     std::string text;

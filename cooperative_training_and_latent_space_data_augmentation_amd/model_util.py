@@ -18,7 +18,8 @@ from .autograd import cross_entropy_2D as _ce2d, scaled_mse as _mse
 
 
 def set_grad(module, requires_grad=False):
-    for p in module.parameters():
+    plist = module.param_list() if hasattr(module, "param_list") else module.parameters()      # (cached list of the engine's networks)
+    for p in plist:
         p.requires_grad = requires_grad
 
 
@@ -49,7 +50,9 @@ def cross_entropy_2D(input, target, weight=None, size_average=True):
 def _disable_tracking_bn_stats(model):
     """BatchNorm 'mode B': batch statistics, no running-stat update, gamma/beta frozen for this pass."""
     old = model._bn_track
-    bn_params = [p for m in model.modules() if type(m).__name__ == "_BNP" for p in (m.weight, m.bias)]
+    bn_params = model.__dict__.get("_bn_plist")           # (cached: the module tree is fixed; the walk cost 0.3 ms of host time per step)
+    if bn_params is None:
+        bn_params = model.__dict__["_bn_plist"] = [p for m in model.modules() if type(m).__name__ == "_BNP" for p in (m.weight, m.bias)]
     model._bn_track = False
     for p in bn_params:
         p.requires_grad_(False)

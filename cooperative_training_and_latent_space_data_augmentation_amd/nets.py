@@ -628,8 +628,25 @@ class CtlNet(nn.Module):
         """Call after modifying parameters in place by other means than the engine's optimizer / load_state_dict."""
         self._packed_ok = False
 
+    def param_list(self):
+        """The network's parameters as a cached list (the module tree is fixed after construction): `Module.parameters()` walks ~100
+        sub-modules on every call, and the training loop asks several hundred times per step (set_grad, wants_param_grad) -- 2 ms of
+        host time per step before this cache (tools/debug/host_profile.py)."""
+        pl = self.__dict__.get("_plist")
+        if pl is None:
+            pl = self.__dict__["_plist"] = list(self.parameters())
+        return pl
+
     def wants_param_grad(self) -> bool:
-        return any(p.requires_grad for p in self.parameters())
+        return any(p.requires_grad for p in self.param_list())
+
+    def train(self, mode: bool = True):
+        """nn.Module.train, without the walk over the module tree when the whole tree is already in that mode (it is flipped only here)."""
+        if self.__dict__.get("_mode_synced") is mode and self.training is mode:
+            return self
+        super().train(mode)
+        self.__dict__["_mode_synced"] = mode
+        return self
 
     # ---------------------------------------------------------------- weight packing
     def _build_pack_plan(self) -> Plan:

@@ -364,6 +364,9 @@ int ctl_plan_run(const ctl_op* ops, int32_t n_ops, void* const* bases, int32_t n
  * ctl_prof_stop synchronises the recorded events and writes one text line per kernel id:
  *   "<id> launches=<n> ms=<total> flops=<sum> bytes=<sum>\n".  Not for use under graph capture. */
 int ctl_prof_start(const char* filter);
+/* the same, bracketing only every `every`-th matching launch (bench.py samples inside its timed region: two event records per launch
+ * are not free on a launch-bound step) */
+int ctl_prof_start_sampled(const char* filter, int32_t every);
 int ctl_prof_stop(char* out, size_t cap);
 /* launch census: kernels / stream memsets / copies enqueued by this library since it was loaded (bench.py reports launches per step) */
 unsigned long long ctl_launch_count(void);
