@@ -570,3 +570,51 @@ def test_adam_skips_a_network_without_gradient(golden_cases, golden_sd):
         assert torch.equal(s.model[k]._flat_data, before[k]) and s.optimizers[k].step_count == 1, k
     for k in ("shape_encoder", "shape_decoder"):
         assert not torch.equal(s.model[k]._flat_data, before[k]) and s.optimizers[k].step_count == 2, k
+
+
+def test_host_side_caches_keep_module_semantics(golden_sd):
+    """CtlNet.param_list / train() fast path / the cached BatchNorm parameter list (host time, not results): requires_grad and training
+    flags still behave like nn.Module's."""
+    from cooperative_training_and_latent_space_data_augmentation_amd.model_util import set_grad
+    net = nets.build_networks(device=DEV, state_dicts={"shape_decoder": golden_sd["shape_decoder"]})["shape_decoder"]
+    assert [id(p) for p in net.param_list()] == [id(p) for p in net.parameters()] and net.param_list() is net.param_list()
+    set_grad(net, False)
+    assert not net.wants_param_grad() and not any(p.requires_grad for p in net.parameters())
+    next(iter(net.parameters())).requires_grad = True               # a single parameter flipped by hand is seen
+    assert net.wants_param_grad()
+    set_grad(net, True)
+    assert all(p.requires_grad for p in net.parameters())
+    net.eval()
+    assert not net.training and not any(m.training for m in net.modules())
+    net.train()
+    assert net.training and all(m.training for m in net.modules())
+    next(net.children()).eval()                                     # a child flipped by hand: the next train() repairs the tree
+    net.train(False)
+    net.train(True)
+    assert all(m.training for m in net.modules())
+    with _disable_tracking_bn_stats(net):
+        assert net._bn_track is False and not any(p.requires_grad for p in net.__dict__["_bn_plist"])
+    assert all(p.requires_grad for p in net.__dict__["_bn_plist"])
+
+
+def test_spin_kernel_and_sampled_profiler():
+    """ctl_spin (the idle kernel of the stream-pair probe) waits about as long as asked; the in-process profiler brackets every n-th launch."""
+    from cooperative_training_and_latent_space_data_augmentation_amd._ffi import lib, check
+    st = torch.cuda.current_stream().cuda_stream
+    check(lib.ctl_spin(1, st), "ctl_spin")
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    check(lib.ctl_spin(500, st), "ctl_spin")
+    e1.record()
+    e1.synchronize()
+    assert 450.0 <= e0.elapsed_time(e1) * 1e3 <= 900.0, e0.elapsed_time(e1)
+    x = dev(torch.randn(2, 16, 32, 32))
+    w = ops.pack_oihw_fwd(dev(torch.randn(16, 16, 3, 3) * 0.1))
+    d = _ffi.conv_desc(n=2, hin=32, win=32, cin=16, hout=32, wout=32, cout=16, ks=3)
+    for every, want in ((1, 10), (4, 3)):
+        _ffi.prof_start("conv_igemm", every)
+        for _ in range(10):
+            ops.conv_forward(d, x, w)
+        rec = _ffi.prof_stop()
+        assert len(rec) == 1 and int(next(iter(rec.values()))["launches"]) == want, (every, rec)
