@@ -60,6 +60,10 @@ class _Lib:
         if not os.path.exists(LIB_PATH):
             raise CtlError(f"HIP extension not built: {LIB_PATH} is missing. Run `python -c 'import __graft_entry__ as g; "
                            "g.build()'` (or `make -C <package>/csrc`). There is no fallback path.")
+        # PyTorch first: its wheel carries its own libamdhip64.so, and the extension must bind to THAT runtime (the one that owns the
+        # device, the streams and the memory).  Loaded before torch, the extension pulled in /opt/rocm's copy instead and every launch
+        # failed with "no ROCm-capable device is detected" (build() followed by smoke() in one process).
+        import torch  # noqa: F401
         lib = C.CDLL(LIB_PATH)
         lib.ctl_last_error.restype = C.c_char_p
         lib.ctl_version.restype = C.c_int

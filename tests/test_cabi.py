@@ -66,3 +66,21 @@ def test_host_side_sizing_helpers():
     assert _ffi.lib.ctl_wgrad_splits(_ffi.desc_ptr(d)) == 256          # one block per CU (round 2: the weight gradients co-run with the other chain)
     assert _ffi.lib.ctl_wgrad_partial_floats(_ffi.desc_ptr(d)) == 256 * 9 * 16 * 16
     assert _ffi.lib.ctl_latent_score_ws_floats(0, 16, 256, 128) == 16 * 4 * 128
+
+
+def test_extension_binds_to_torchs_hip_runtime():
+    """Loading the extension imports torch first (one HIP runtime per process: the wheel's libamdhip64.so, not /opt/rocm's): checked in
+    a fresh interpreter that touches the extension before anything else -- build() followed by smoke() in one process."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from cooperative_training_and_latent_space_data_augmentation_amd import _ffi\n"
+            "assert 'torch' not in sys.modules\n"
+            "assert _ffi.lib.ctl_version() >= 1\n"
+            "assert 'torch' in sys.modules\n"
+            "maps = open('/proc/self/maps').read()\n"
+            "hips = sorted({l.split()[-1] for l in maps.splitlines() if 'libamdhip64' in l})\n"
+            "assert len(hips) == 1 and '/torch/lib/' in hips[0], hips\n"
+            "print('OK', hips[0])\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
