@@ -4,7 +4,9 @@ K extra streams are touched before the first capture ("before") or one by one wi
 on 8 different LAUNCH streams.  Round-2 findings (profiles/r2_hw_queue_sharing.txt): with 8 queues the replay takes 27-31 ms on launch
 streams 0-2 and 18.2 ms on streams 3-7; extra streams in front of the FIRST instantiation move the assignment, re-capturing does not (the
 runtime's branch streams are created once); a two-branch probe graph of idle kernels does not predict the real graph; timing the real
-replay on several launch streams inside the product segfaulted in the runtime with the default 4 queues -- not shipped."""
+replay on several launch streams inside the product segfaulted in the runtime with the default 4 queues -- not shipped (this script
+dies the same way behind the 3rd-4th launch stream when GPU_MAX_HW_QUEUES is left at its default).  CTL_DTYPE=bf16 PROBE_MASKS=targeted:
+config 3, whose replay takes 12.5-12.65 ms on every launch stream (the eager step: 11.8)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
@@ -15,10 +17,11 @@ from cooperative_training_and_latent_space_data_augmentation_amd.graph import Co
 k = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 when = sys.argv[2] if len(sys.argv) > 2 else "before"
 torch.manual_seed(0)
-s = AdvancedTripletReconSegmentationModel(use_gpu=True)
+s = AdvancedTripletReconSegmentationModel(use_gpu=True)            # CTL_DTYPE=bf16 PROBE_MASKS=targeted: config 3
+CFG = (bench.TGT_IMG, bench.TGT_SEG) if os.environ.get("PROBE_MASKS") == "targeted" else (bench.DROP_IMG, bench.DROP_SEG)
 clean, label, noisy, _ = bench.synthetic(16, 256, 256, 1000, torch.device("cuda"))
 for _ in range(3):
-    s.cooperative_step(clean, label, noisy, bench.DROP_IMG, bench.DROP_SEG)
+    s.cooperative_step(clean, label, noisy, *CFG)
 torch.cuda.synchronize()
 extra = []
 def make(n):
@@ -29,7 +32,7 @@ def make(n):
     torch.cuda.synchronize()
 if when == "before":
     make(k)
-g = CooperativeStepGraph(s, bench.DROP_IMG, bench.DROP_SEG)
+g = CooperativeStepGraph(s, *CFG)
 g(clean, label, noisy)
 torch.cuda.synchronize()
 def timeit(n=6):
