@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("CTL_HIP_LIB") or os.path.join(_HERE, "csrc", "libctl_
 IN_PLAIN, IN_UP2, IN_ZINS2, IN_C4 = 0, 1, 2, 3
 ACT_NONE, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2
 EPI_BIAS, EPI_ACCUM, EPI_RES, EPI_STATS, EPI_BNBWD = 1, 2, 4, 8, 16
-RED_BLOCKS = 512
+RED_BLOCKS = int(os.environ.get("CTL_RED_BLOCKS", "512"))      # = CTL_RED_BLOCKS of ctl_hip.h (the environment override goes with a variant build)
 FIN_REC_BYTES, FIN_MAX_RECS = 128 + 4 * 9 * 128, 85      # ctl_hip.h: CTL_FIN_*
 FIN_HEADER_BYTES = FIN_REC_BYTES * FIN_MAX_RECS
 (OP_CONV, OP_WGRAD, OP_WGRAD_REDUCE, OP_PACK, OP_BN_FINALIZE, OP_BN_EVAL, OP_BN_ACT, OP_BWD_REDUCE, OP_BN_BWD_FINALIZE,

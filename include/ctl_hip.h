@@ -181,7 +181,9 @@ typedef struct ctl_bnb_fin {
 } ctl_bnb_fin;
 
 /* backward helpers; `partial` buffers are [groups][rows][2][c] floats, rows = ctl_bwd_reduce_rows() <= CTL_RED_BLOCKS */
+#ifndef CTL_RED_BLOCKS
 #define CTL_RED_BLOCKS 512
+#endif
 /* mode 0 (residual tail, encdec.py:64,344): g = dout * leaky'(out);        sums: sum g, sum g*v
  * mode 1 (BN->act tail):                    g = da * leaky'(u*scale+shift); sums: sum g, sum g*u
  * mode 2 (plain):                           g = da;                         sums: sum g, (unused)          */
