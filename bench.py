@@ -7,11 +7,15 @@ codes) + hard_example_training + backward + 5x Adam, fp32, one process per GPU.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0.  `roofline` is measured live: HIP events bracket every launch of the dominant kernel
-(inside the timed region, on the launch stream).  `cpu_baseline` times the CPU oracle (oracle/ref_cpu.py, a port of the
-reference's PyTorch-CPU path) on one step of the same workload on the host cores (N=1 only)."""
+(on the launch stream).  `cpu_baseline` times the CPU oracle (oracle/ref_cpu.py, a port of the reference's PyTorch-CPU
+path) on one step of the same workload on the host cores (N=1 only).  At N=1 the line also carries `roofline_families`
+(weight gradients, BatchNorm-backward passes, ... of the same step) and two sub-records measured by child processes
+running this same script: `config3_bf16` (BASELINE configs[2]: targeted masks, bf16) and `config5_inference`
+(configs[4]: 192x192 volume inference); the headline keys are configs[1] and nothing else."""
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -36,6 +40,7 @@ PEAK_HBM_GBS = 8000.0
 # at 8x32 tiles / 16 output channels, i.e. every 16->16 (and 1|4->16, 16->4) conv and dgrad at 256x256
 PROF_EVERY = 4                   # inside the timed region the dominant kernel's launches are sampled (two event records per launch cost
                                  # a launch-bound step ~1.5 %); the single-stream replay behind it brackets every launch
+SINGLE_STREAM_STEPS = 5
 DOMINANT = "conv_igemm<ks3,s1,in0,mt4,tw32,nt1>"
 DOMINANT_BF16 = "conv_igemm_bf16<ks3,s1,in0,mt4,tw32,nt1>"
 
@@ -119,6 +124,117 @@ def cpu_baseline(host_batch, threads, steps=3, cfgs=(DROP_IMG, DROP_SEG), what="
                       f"threads: 1 warm-up ({times[0]:.1f} s) + {steps} timed steps, median {med:.1f} s (all: {[round(t, 1) for t in times[1:]]})"}
 
 
+FAMILIES = (("conv_fwd_dgrad", ("conv_igemm",)), ("weight_gradients", ("conv_wgrad",)),
+            ("batchnorm_backward", ("bwd_reduce<0>", "bwd_reduce<1>", "bwd_apply")), ("other_hbm_passes", ("bn_act", "sumpool2", "bwd_reduce<2>")))
+
+
+def family_rooflines(prof, dtype, steps):
+    """Per-family and per-kernel rooflines of ONE step from the single-stream replay (every launch bracketed with HIP events on its
+    launch stream): conv families against the MFMA peak of the arithmetic type or HBM, whichever bounds them; the element-wise passes
+    against HBM.  `ms_per_step` is serialised kernel time (the timed region overlaps two launch chains)."""
+    peak_mfma = PEAK_MFMA_BF16_TFLOPS if dtype == "bf16" else PEAK_MFMA_F32_TFLOPS
+    out = {}
+    for fam, keys in FAMILIES:
+        ids = {k: v for k, v in prof.items() if any(k.startswith(p) for p in keys)}
+        if not ids:
+            continue
+        ms = sum(v["ms"] for v in ids.values())
+        fl, by, n = sum(v["flops"] for v in ids.values()), sum(v["bytes"] for v in ids.values()), sum(v["launches"] for v in ids.values())
+        tf, gbs = fl / ms / 1e9, by / ms / 1e6
+        f_m, f_h = tf / peak_mfma, gbs / PEAK_HBM_GBS
+        rec = {"bound": "mfma" if f_m >= f_h else "hbm", "frac": max(f_m, f_h), "tflops": tf, "hbm_gbs": gbs, "mfma_frac": f_m, "hbm_frac": f_h,
+               "launches_per_step": n / steps, "ms_per_step": ms / steps, "algorithmic_gflop_per_step": fl / steps / 1e9,
+               "algorithmic_gb_per_step": by / steps / 1e9, "kernels": {}}
+        for k, v in sorted(ids.items(), key=lambda kv: -kv[1]["ms"])[:6]:
+            ktf, kgb = v["flops"] / v["ms"] / 1e9, v["bytes"] / v["ms"] / 1e6
+            rec["kernels"][k] = {"launches_per_step": v["launches"] / steps, "avg_us": 1e3 * v["ms"] / v["launches"], "tflops": ktf, "hbm_gbs": kgb,
+                                 "frac": max(ktf / peak_mfma, kgb / PEAK_HBM_GBS), "bound": "mfma" if ktf / peak_mfma >= kgb / PEAK_HBM_GBS else "hbm"}
+        out[fam] = rec
+    return out
+
+
+def sub_record(argv, keep):
+    """Run this script in a child process (never an exec of this one: it holds the GPU) and return its JSON line, cut down to `keep`."""
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__)] + argv, capture_output=True, text=True, timeout=900, cwd=ROOT)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return {"error": f"rc={r.returncode}: {r.stderr[-300:]}"}
+        rec = json.loads(lines[-1])
+        return rec if keep is None else {k: rec[k] for k in keep if k in rec}
+    except Exception as exc:
+        return {"error": f"{type(exc).__name__}: {str(exc)[:200]}"}
+
+
+def inference_main(args, device):
+    """BASELINE configs[4]: 3-D volume inference, 192x192xN stacks, FTN+STN forward only (model.py:375-394 through
+    test_basic_segmentation_solver.py:85-114), eval-mode BatchNorm, argmax to a uint8 label volume.  Two forms of the same computation:
+    the reference's chunks of <= 10 slices, and the whole volume in one pass (exact under eval-mode BatchNorm: slices are independent)."""
+    from cooperative_training_and_latent_space_data_augmentation_amd import _ffi, ops
+    from cooperative_training_and_latent_space_data_augmentation_amd.solver import AdvancedTripletReconSegmentationModel
+    from cooperative_training_and_latent_space_data_augmentation_amd.tester import predict_volume
+    torch.manual_seed(0)
+    solver = AdvancedTripletReconSegmentationModel(network_type="FCN_16_standard", image_ch=1, num_classes=4, use_gpu=True)
+    solver.eval()
+    slices, size, n_iter = 40, 192, 2
+    g = torch.Generator().manual_seed(5)
+    vol = torch.rand(slices, 1, size, size, generator=g)
+    dvol = vol.to(device)
+    gflop_per_slice = 4.14 * (size / 192.0) ** 2          # SURVEY 8(d): n_iter=2 with the redundant second STN pass removed (6.18 as the reference runs it)
+    out = {"metric": "volume-inference slices/sec (192x192, n_iter=2, eval BatchNorm, argmax)", "unit": "slices/s", "n_gpus": 1, "dtype": "f32",
+           "data": "synthetic", "higher_is_better": True,
+           "config": {"workload": f"BASELINE configs[4]: {slices}-slice 192x192 volume, FTN + STN refinement (n_iter={n_iter}), uint8 label volume out; "
+                                  "reference-init weights, non-trivial running statistics are not needed for timing"}}
+    recs = {}
+    for tag, chunk in (("chunk10_as_reference", 10), ("whole_volume", slices)):
+        fn = lambda: predict_volume(solver, dvol, n_iter=n_iter, chunk=chunk)
+        for _ in range(max(2, args.warmup)):
+            lab = fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            lab = fn()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.steps
+        _ffi.prof_start("")
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        prof = _ffi.prof_stop()
+        fl = sum(v["flops"] for v in prof.values()) / 3
+        kms = sum(v["ms"] for v in prof.values()) / 3
+        recs[tag] = {"value": slices / dt, "ms_per_volume": 1e3 * dt, "chunk": chunk,
+                     "roofline": {"bound": "mfma", "achieved": fl / dt / 1e12, "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": fl / dt / 1e12 / PEAK_MFMA_F32_TFLOPS, "traffic": None,
+                                  "executed_conv_gflop_per_slice": fl / slices / 1e9, "reference_gflop_per_slice": gflop_per_slice,
+                                  "note": "whole-path figure: conv flops the engine executes per volume / wall time per volume; "
+                                          f"serialised conv kernel time {kms:.3f} ms of {1e3 * dt:.3f} ms"}}
+        assert lab.dtype == torch.uint8 and tuple(lab.shape) == (slices, size, size)
+    out.update({"value": recs["whole_volume"]["value"], "ms_per_step": recs["whole_volume"]["ms_per_volume"], "steps": args.steps, "warmup": args.warmup,
+                "roofline": recs["whole_volume"]["roofline"], "forms": recs})
+    if not args.no_cpu_baseline:
+        from oracle import ref_cpu as O
+        from cooperative_training_and_latent_space_data_augmentation_amd.init import reference_init_state_dicts
+        threads = args.cpu_threads or min(32, os.cpu_count())
+        torch.set_num_threads(threads)
+        torch.manual_seed(0)
+        o = O.OracleSolver(state_dicts=reference_init_state_dicts())
+        o.eval()
+        ts = []
+        with torch.no_grad():
+            for _ in range(4):
+                t0 = time.perf_counter()
+                for c0 in range(0, slices, 10):
+                    o.predict(vol[c0:c0 + 10], n_iter=n_iter).argmax(1)
+                ts.append(time.perf_counter() - t0)
+        med = sorted(ts[1:])[1]
+        out["cpu_baseline"] = {"value": slices / med, "unit": "slices/s", "cores": threads, "kind": "port",
+                               "sample": f"the same {slices}-slice volume in chunks of 10 through oracle/ref_cpu.py predict(n_iter={n_iter}) + argmax on {threads} "
+                                         f"torch threads: 1 warm-up + 3 volumes, median {med:.2f} s"}
+    flush_c_stdio()
+    print(json.dumps(out), flush=True)
+
+
 def flush_c_stdio():
     """RCCL writes its version banner to C stdout while the first communicator is built; redirected to a file that buffer is only
     written at process exit -- BEHIND the JSON line.  Flushing it early keeps the JSON line the last line of the job's stdout."""
@@ -145,6 +261,12 @@ def main():
                          "activations / gradients stored as bf16, convolutions on v_mfma_f32_16x16x32_bf16, fp32 accumulate / BatchNorm "
                          "statistics / master weights / losses")
     ap.add_argument("--masks", default=None, choices=list(MASKS), help="latent masking scheme (default: dropout for fp32, targeted for bf16)")
+    ap.add_argument("--workload", default="step", choices=["step", "inference"],
+                    help="step: the cooperative-training iteration (headline); inference: BASELINE configs[4], 192x192 volume inference")
+    ap.add_argument("--no-sub-records", action="store_true", help="headline only (the sub-records are measured by child processes)")
+    ap.add_argument("--lib", default=None, help="A/B aid: path of another build of libctl_hip.so (tools/ab.sh)")
+    ap.add_argument("--set", action="append", default=[], metavar="MODULE.ATTR=VALUE",
+                    help="A/B aid: set a plan-compiler switch before the solver is built, e.g. nets.FUSE_BNBWD=True")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--prof-filter", default=None)
@@ -181,6 +303,15 @@ def main():
             dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
 
     from cooperative_training_and_latent_space_data_augmentation_amd import _ffi
+    if args.lib:
+        _ffi.LIB_PATH = os.path.abspath(args.lib)
+    import importlib
+    for kv in args.set:
+        target, val = kv.split("=", 1)
+        modname, attr = target.rsplit(".", 1)
+        setattr(importlib.import_module("cooperative_training_and_latent_space_data_augmentation_amd." + modname), attr, eval(val))
+    if args.workload == "inference":
+        return inference_main(args, device)
     from cooperative_training_and_latent_space_data_augmentation_amd.solver import AdvancedTripletReconSegmentationModel
     from cooperative_training_and_latent_space_data_augmentation_amd.dist import DataParallel
 
@@ -267,7 +398,7 @@ def main():
     fence()
     launches_per_step = int(_ffi.lib.ctl_launch_count() - n0)
     phase_tm = None
-    if rank == 0 and os.environ.get("CTL_HIP_LIB") and hasattr(_ffi.lib, "ctl_debug_timing"):
+    if rank == 0 and args.lib and hasattr(_ffi.lib, "ctl_debug_timing"):
         import ctypes                                     # -DCTL_TIMING variant build: per-phase cycle counters of the conv kernel
         phase_tm = (ctypes.c_ulonglong * 12)()
         _ffi.lib.ctl_debug_timing(phase_tm)               # reset
@@ -295,22 +426,21 @@ def main():
     # In the timed region two launch chains share the GPU (solver.two_streams), so a kernel's event-timed duration includes
     # the time it shares the CUs with the other chain.  For the kernel-quality figure the same step is replayed on ONE stream
     # afterwards (outside the timed region): that is also what rocprofv3 --kernel-trace shows, because it serialises dispatches.
-    prof_single = {}
+    prof_single, prof_all = {}, {}
     if getattr(solver, "two_streams", False):          # EVERY rank replays (step() contains the gradient all-reduce); rank 0 profiles
         solver.two_streams = False
-        lanes = _ffi.lib.ctl_plan_side_lanes(0)        # ... and the weight gradients stay on the one stream as well
         for _ in range(2):
             eager_step()
         torch.cuda.synchronize()
         if rank == 0:
-            _ffi.prof_start(args.prof_filter)
-        for _ in range(5):
+            _ffi.prof_start("")                        # every conv-family launch and every HBM-bound plan op, each with its algorithmic work
+        for _ in range(SINGLE_STREAM_STEPS):
             eager_step()
         torch.cuda.synchronize()
         if rank == 0:
-            prof_single = _ffi.prof_stop()
+            prof_all = _ffi.prof_stop()
+            prof_single = {k: v for k, v in prof_all.items() if args.prof_filter in k}
         solver.two_streams = True
-        _ffi.lib.ctl_plan_side_lanes(lanes)
     if phase_tm is not None:
         _ffi.lib.ctl_debug_timing(phase_tm)
         steps = max(phase_tm[6], 1)
@@ -345,7 +475,7 @@ def main():
             "launches_per_step": {"library": launches_per_step, "note": "kernels + stream memsets / copies enqueued by libctl_hip.so in one step "
                                   "(ctl_launch_count); PyTorch adds ~45 fills / copies per step (tools/aten_ops_in_step.py)"},
         }
-        def roofline_of(kid, rec, region_s=None):
+        def roofline_of(kid, rec, region_s=None, sampled_every=1):
             secs = rec["ms"] * 1e-3
             tf, gbs = rec["flops"] / secs / 1e12, rec["bytes"] / secs / 1e9
             peak_mfma = PEAK_MFMA_BF16_TFLOPS if args.dtype == "bf16" else PEAK_MFMA_F32_TFLOPS
@@ -357,13 +487,16 @@ def main():
                  "kernel": kid, "launches": int(rec["launches"]), "avg_us": 1e3 * rec["ms"] / rec["launches"],
                  "algorithmic_gflop_per_launch": rec["flops"] / rec["launches"] / 1e9,
                  "algorithmic_mb_per_launch": rec["bytes"] / rec["launches"] / 1e6, "hbm_gbs": gbs, "hbm_frac": f_hbm}
-            if region_s:
+            if sampled_every > 1:                          # (the sampled count is not the launch count)
+                r["sampled_every"] = sampled_every
+                r["launches_note"] = f"every {sampled_every}-th launch was bracketed: `launches` counts the samples"
+            elif region_s:
                 r["share_of_step_time"] = secs / region_s
             return r
 
         if prof:                                          # eager mode: HIP events around every launch of the kernel INSIDE the timed region
             kid, rec = max(prof.items(), key=lambda kv: kv[1]["ms"])
-            out["roofline"] = roofline_of(kid, rec, dt)
+            out["roofline"] = roofline_of(kid, rec, dt, PROF_EVERY)
             out["roofline"]["note"] = ("timed region: two launch chains share the GPU, so this kernel's event-timed duration includes the time it "
                                        "shares the CUs with the other chain; kernel quality = single_stream below")
             if kid in prof_single:
@@ -383,10 +516,22 @@ def main():
             t = json.load(open(tfile))
             if t.get("kernel") == out["roofline"]["kernel"]:
                 out["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
+        if prof_all:
+            out["roofline_families"] = family_rooflines(prof_all, args.dtype, SINGLE_STREAM_STEPS)
         if world == 1:
             out["roofline_latent_mask"] = latent_mask_roofline(device)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(host_batch, args.cpu_threads or min(32, os.cpu_count()), cfgs=(IMG_CFG, SEG_CFG), what=mask_text)
+        if world == 1 and not args.no_sub_records and args.dtype == "fp32" and args.masks == "dropout":
+            # BASELINE configs[2] and configs[4], each measured by a child process running this script (a fresh process: its own
+            # streams, pools and graphs; this process is idle meanwhile).  The headline keys above are untouched.
+            common = ["--steps", str(args.steps), "--warmup", str(args.warmup), "--no-sub-records"] + (["--no-cpu-baseline"] if args.no_cpu_baseline else []) + \
+                     (["--lib", args.lib] if args.lib else []) + [x for kv in args.set for x in ("--set", kv)]
+            out["config3_bf16"] = sub_record(["--dtype", "bf16", "--masks", "targeted"] + common,
+                                             ("metric", "value", "unit", "ms_per_step", "dtype", "mode", "mode_calibration", "step_ms", "cpu_issue_ms",
+                                              "device_allocs_in_timed_region", "launches_per_step", "roofline", "roofline_families", "cpu_baseline",
+                                              "final_losses", "config"))
+            out["config5_inference"] = sub_record(["--workload", "inference"] + common, None)
     if use_dist:
         dist.destroy_process_group()
     flush_c_stdio()

@@ -8,15 +8,14 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("CTL_HIP_LIB") or os.path.join(_HERE, "csrc", "libctl_hip.so")   # override: A/B builds of the kernels
+LIB_PATH = os.path.join(_HERE, "csrc", "libctl_hip.so")
+ABI_VERSION = 3                      # CTL_ABI_VERSION of include/ctl_hip.h this binding was written against
+RED_BLOCKS = 512                     # CTL_RED_BLOCKS of ctl_hip.h; checked against the library's compiled value (ctl_red_blocks) at load
 
 # enums of ctl_hip.h
 IN_PLAIN, IN_UP2, IN_ZINS2, IN_C4 = 0, 1, 2, 3
 ACT_NONE, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2
 EPI_BIAS, EPI_ACCUM, EPI_RES, EPI_STATS, EPI_BNBWD = 1, 2, 4, 8, 16
-RED_BLOCKS = int(os.environ.get("CTL_RED_BLOCKS", "512"))      # = CTL_RED_BLOCKS of ctl_hip.h (the environment override goes with a variant build)
-FIN_REC_BYTES, FIN_MAX_RECS = 128 + 4 * 9 * 128, 85      # ctl_hip.h: CTL_FIN_*
-FIN_HEADER_BYTES = FIN_REC_BYTES * FIN_MAX_RECS
 (OP_CONV, OP_WGRAD, OP_WGRAD_REDUCE, OP_PACK, OP_BN_FINALIZE, OP_BN_EVAL, OP_BN_ACT, OP_BWD_REDUCE, OP_BN_BWD_FINALIZE,
  OP_BWD_APPLY, OP_CHAN_SUM_FINALIZE, OP_SUMPOOL2, OP_SIGMOID_BWD, OP_ZERO, OP_COPY, OP_PACK_BATCH, OP_WGRAD_REDUCE_BATCH, OP_DROPOUT2D) = range(1, 19)
 OP_MAX_T = 12
@@ -33,21 +32,6 @@ OP_DTYPE = np.dtype([("kind", "<i4"), ("i", "<i4", (27,)), ("f", "<f4", (4,)), (
 
 class CtlError(RuntimeError):
     pass
-
-
-class BnFin(C.Structure):
-    """ctl_bn_fin (ctl_hip.h): arguments of a BatchNorm finalize fused into the producing convolution"""
-    _fields_ = [("gamma", C.c_void_p), ("beta", C.c_void_p), ("running_mean", C.c_void_p), ("running_var", C.c_void_p),
-                ("num_batches_tracked", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p), ("save_mean", C.c_void_p),
-                ("save_invstd", C.c_void_p), ("count", C.c_int64), ("eps", C.c_float), ("momentum", C.c_float),
-                ("update_running", C.c_int32), ("role", C.c_int32), ("partial", C.c_void_p), ("rows", C.c_int32), ("reserved", C.c_int32)]
-
-
-class BnbFin(C.Structure):
-    """ctl_bnb_fin (ctl_hip.h): arguments of a BatchNorm-backward finalize fused into ctl_bwd_reduce_fin"""
-    _fields_ = [("gamma", C.c_void_p), ("save_mean", C.c_void_p), ("save_invstd", C.c_void_p), ("coef", C.c_void_p),
-                ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("counter", C.c_void_p), ("count", C.c_int64),
-                ("accumulate", C.c_int32), ("reserved", C.c_int32)]
 
 
 class _Lib:
@@ -68,7 +52,6 @@ class _Lib:
         lib.ctl_last_error.restype = C.c_char_p
         lib.ctl_version.restype = C.c_int
         lib.ctl_launch_count.restype = C.c_ulonglong
-        lib.ctl_plan_side_lanes.argtypes = [C.c_int32]
         for name in ("ctl_conv_wpack_floats", "ctl_conv_stats_floats", "ctl_wgrad_partial_floats",
                      "ctl_wgrad_bias_partial_floats", "ctl_latent_score_ws_floats", "ctl_latent_mask_apply_ws_floats",
                      "ctl_rescale_intensity_ws_floats", "ctl_sizeof_op", "ctl_sizeof_conv", "ctl_latent_mask_fused_ws_floats"):
@@ -90,7 +73,7 @@ class _Lib:
             "ctl_bn_finalize": [p, i32, i32, i64, p, p, f32, f32, i32, p, p, p, p, p, p, p, i32, p],
             "ctl_bn_eval_coeffs": [i32, p, p, p, p, f32, p, p, i32, p],
             "ctl_bn_act": [p, p, p, f32, p, i64, i32, i32, p],
-            "ctl_bwd_reduce": [i32, p, p, p, p, p, f32, i64, i32, p, i32, p],
+            "ctl_bwd_reduce": [i32, p, p, p, p, p, f32, i64, i32, p, i32, p], "ctl_red_blocks": [],
             "ctl_bn_bwd_finalize": [p, i32, i64, p, p, p, p, p, p, i32, i32, i32, p],
             "ctl_bwd_apply": [i32, p, p, p, p, p, f32, p, i64, i32, p, p, i32, p],
             "ctl_chan_sum_finalize": [p, i32, p, i32, p],
@@ -124,20 +107,19 @@ class _Lib:
             "ctl_prof_start": [C.c_char_p], "ctl_prof_start_sampled": [C.c_char_p, i32], "ctl_prof_stop": [p, C.c_size_t],
             "ctl_pack_weights_batched": [p, p, p, i32, i64, p], "ctl_wgrad_reduce_batched": [p, p, p, i32, i64, p],
             "ctl_pack_weights_bf16_batched": [p, p, p, i32, i64, p],
-            "ctl_conv_forward_fin": [p] * 12 + [i32, p],
-            "ctl_bn_fin_table_write": [p, p, i32, p],
             "ctl_bwd_reduce_rows": [i32, i64, i32],
-            "ctl_bwd_reduce_fin": [i32, p, p, p, p, p, f32, i64, i32, p, i32, C.c_uint32, p, p, p],
             "ctl_bn_act_dt": [p, p, p, f32, p, i64, i32, i32, C.c_uint32, p],
-            "ctl_bwd_reduce_dt": [i32, p, p, p, p, p, f32, i64, i32, p, i32, C.c_uint32, p],
+            "ctl_bwd_reduce_dt": [i32, p, p, p, p, p, f32, i64, i32, p, i32, C.c_uint32, p, p],
             "ctl_bwd_apply_dt": [i32, p, p, p, p, p, f32, p, i64, i32, p, p, i32, C.c_uint32, p],
             "ctl_sumpool2_dt": [p, p, i32, i32, i32, i32, i32, C.c_uint32, p],
         }
         for name, args in sig.items():
             getattr(lib, name).argtypes = args
-        if lib.ctl_sizeof_op() != OP_DTYPE.itemsize or lib.ctl_sizeof_conv() != CONV_DTYPE.itemsize:
-            raise CtlError(f"ABI mismatch: sizeof(ctl_op)={lib.ctl_sizeof_op()} vs {OP_DTYPE.itemsize}, "
-                           f"sizeof(ctl_conv)={lib.ctl_sizeof_conv()} vs {CONV_DTYPE.itemsize}")
+        if lib.ctl_version() != ABI_VERSION or lib.ctl_sizeof_op() != OP_DTYPE.itemsize or lib.ctl_sizeof_conv() != CONV_DTYPE.itemsize:
+            raise CtlError(f"ABI mismatch: library version {lib.ctl_version()} vs binding {ABI_VERSION}, sizeof(ctl_op)={lib.ctl_sizeof_op()} "
+                           f"vs {OP_DTYPE.itemsize}, sizeof(ctl_conv)={lib.ctl_sizeof_conv()} vs {CONV_DTYPE.itemsize}")
+        if lib.ctl_red_blocks() != RED_BLOCKS:
+            raise CtlError(f"ABI mismatch: the library was built with CTL_RED_BLOCKS={lib.ctl_red_blocks()}, this binding sizes scratch for {RED_BLOCKS}")
         self._lib = lib
         return lib
 
@@ -159,8 +141,8 @@ EXPORTED = ["ctl_version", "ctl_last_error", "ctl_conv_wpack_floats", "ctl_conv_
             "ctl_wgrad_reduce_batched", "ctl_confusion_hist", "ctl_rescale_intensity_ws_floats", "ctl_rescale_intensity",
             "ctl_noise_clamp", "ctl_crop_or_pad", "ctl_step_tick", "ctl_spin", "ctl_dropout2d_ex", "ctl_dropout2d_dt", "ctl_uniform_dev", "ctl_adam_dev",
             "ctl_latent_mask_fused_ws_floats", "ctl_latent_mask_fused", "ctl_accumulate", "ctl_pack_weights_bf16_batched",
-            "ctl_bn_act_dt", "ctl_bwd_reduce_dt", "ctl_bwd_apply_dt", "ctl_sumpool2_dt", "ctl_conv_forward_fin", "ctl_bn_fin_table_write",
-            "ctl_bwd_reduce_fin", "ctl_bwd_reduce_rows", "ctl_launch_count", "ctl_plan_side_lanes", "ctl_consumer_finalize_built"]
+            "ctl_bn_act_dt", "ctl_bwd_reduce_dt", "ctl_bwd_apply_dt", "ctl_sumpool2_dt", "ctl_bwd_reduce_rows", "ctl_red_blocks",
+            "ctl_launch_count"]
 
 
 def prof_start(kernel_filter: str = "", every: int = 1) -> None:

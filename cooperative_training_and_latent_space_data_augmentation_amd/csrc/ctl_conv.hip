@@ -200,8 +200,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : ((MT * NT >= 4
                                                           const float* __restrict__ res_scale,
                                                           const float* __restrict__ res_shift, float* __restrict__ y,
                                                           float* __restrict__ stats_partial, int tiles_h, int tiles_w,
-                                                          int G_chunks, int64_t wpack_sub_stride, int ntiles,
-                                                          ctl_bn_rec* __restrict__ rec) {
+                                                          int G_chunks, int64_t wpack_sub_stride, int ntiles) {
     using G = Geom<KS, S, MT, TW>;
     constexpr int TAPS = KS * KS;
     // C4: input with <= 4 channels.  The four lane groups of an MFMA (its k index) carry four different TAPS (channels 0-3 each)
@@ -324,32 +323,10 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : ((MT * NT >= 4
         xs.load(rx, d, cur.n, cur.th * G::TH, cur.tw * TW, 0);
         wload(0);
     }
-    // consumer-side BatchNorm finalize (rec->f.role 1: this kernel's prologue coefficients, 2: its residual affine): the first blocks
-    // compute them, everybody waits for them -- behind the first tile's loads
-#if CTL_CONSUMER_FINALIZE
-    if (rec && rec->f.role != 0)
-        ctl_bn_consume(rec->f, &rec->counters[0][0][0], ngroups, rec->f.role == 1 ? d.cin : d.cout,
-                       (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, gridDim.x * gridDim.y * gridDim.z,
-                       reinterpret_cast<double*>(xt));
-    const bool res_lds = rec && rec->f.role == 2;      // the residual affine was computed in this launch: read into LDS with agent-scope loads
-    if (d.pro_affine) {      // behind the first tile's loads, in front of their use
-        if (rec && rec->f.role == 1) {        // computed in this launch by other blocks: agent-scope loads
-            for (int i = tid; i < ngroups * d.cin; i += 256) { cf_scale[i] = ctl_load_wt(pro_scale + i); cf_shift[i] = ctl_load_wt(pro_shift + i); }
-        } else {
-            for (int i = tid; i < ngroups * d.cin; i += 256) { cf_scale[i] = pro_scale[i]; cf_shift[i] = pro_shift[i]; }
-        }
-        __syncthreads();
-    } else if (res_lds) {
-        for (int i = tid; i < ngroups * d.cout; i += 256) { cf_scale[i] = ctl_load_wt(res_scale + i); cf_shift[i] = ctl_load_wt(res_shift + i); }
-        __syncthreads();
-    }
-#else
-    constexpr bool res_lds = false;
     if (d.pro_affine) {      // behind the first tile's loads, in front of their use
         for (int i = tid; i < ngroups * d.cin; i += 256) { cf_scale[i] = pro_scale[i]; cf_shift[i] = pro_shift[i]; }
         __syncthreads();
     }
-#endif
     if (total_it > 0) {
         xs.store(xt, d, 0, cf_scale, cf_shift, (cur.n / group_n) * d.cin);
         wstore();
@@ -385,8 +362,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : ((MT * NT >= 4
 #pragma unroll
             for (int w = 0; w < 4; ++w) v += sred[((w * NT * 16) + cl) * 2 + stat];
             const int co = cot0 * 16 + cl;
-            // write-through: the rows may be read by another block of this launch (fused finalize, ctl_bn_finalize_tail)
-            if (co < d.cout) ctl_store_wt(stats_partial + (((int64_t)grp * srows + srow) * 2 + stat) * d.cout + co, v);
+            if (co < d.cout) stats_partial[(((int64_t)grp * srows + srow) * 2 + stat) * d.cout + co] = v;
         }
         __syncthreads();
     };
@@ -394,7 +370,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : ((MT * NT >= 4
     if ((flags & CTL_EPI_STATS) && ngroups > 1 && tid < NT * 16 * 2) {      // groups this block never visits contribute zeros
         const int stat = tid / (NT * 16), co = cot0 * 16 + tid % (NT * 16);
         if (co < d.cout)
-            for (int gi = 0; gi < ngroups; ++gi) ctl_store_wt(stats_partial + (((int64_t)gi * srows + srow) * 2 + stat) * d.cout + co, 0.f);
+            for (int gi = 0; gi < ngroups; ++gi) stats_partial[(((int64_t)gi * srows + srow) * 2 + stat) * d.cout + co] = 0.f;
     }
 
     TM(7)
@@ -539,10 +515,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : ((MT * NT >= 4
                     const int cc = cok ? co0 : 0;
                     f32x4 rs = {0.f, 0.f, 0.f, 0.f}, rh = {0.f, 0.f, 0.f, 0.f};
                     if (EPI && (flags & (CTL_EPI_RES | CTL_EPI_BNBWD))) {
-                        if (res_lds) {
-                            rs = *reinterpret_cast<const f32x4*>(cf_scale + grp * d.cout + cc);
-                            rh = *reinterpret_cast<const f32x4*>(cf_shift + grp * d.cout + cc);
-                        } else if (d.cout >= 4) {
+                        if (d.cout >= 4) {
                             rs = *reinterpret_cast<const f32x4*>(res_scale + grp * d.cout + cc);
                             rh = *reinterpret_cast<const f32x4*>(res_shift + grp * d.cout + cc);
                         } else { rs.x = res_scale[grp]; rh.x = res_shift[grp]; }
@@ -596,13 +569,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : ((MT * NT >= 4
     TM_FLUSH
 #endif
 
-    if (flags & CTL_EPI_STATS) {
-        flush_stats(cur_grp);
-        // fused BatchNorm finalize: the last of the blocks that share this block's output channels turns the rows into coefficients
-        if (rec != nullptr)
-            ctl_bn_finalize_tail(rec, stats_partial, srows, ngroups, d.cout, cot0 * 16, NT * 16, gridDim.x * gridDim.z,
-                                 reinterpret_cast<int*>(sred));
-    }
+    if (flags & CTL_EPI_STATS) flush_stats(cur_grp);
 }
 
 // ------------------------------------------------------------------------------------------------ weight gradient
@@ -1081,7 +1048,7 @@ int ctl_conv_pick_cfg(const ctl_conv* d, ctl_conv_cfg* c, int for_wgrad) {
     {   // tuning hook (tools/bench_conv.py): CTL_FORCE_CFG="mt,tw,nt" overrides the heuristic when the combination is valid
         static int fm = 0, ft = 0, fn = 0;                 // read ONCE per process (this runs on every conv launch)
         static const bool forced = [] {
-            const char* f = getenv("CTL_FORCE_CFG");
+            const char* f = ctl_tune_str("CTL_FORCE_CFG");
             return f && sscanf(f, "%d,%d,%d", &fm, &ft, &fn) == 3;
         }();
         if (forced) {
@@ -1104,8 +1071,7 @@ int ctl_conv_pick_cfg(const ctl_conv* d, ctl_conv_cfg* c, int for_wgrad) {
 int ctl_conv_grid_x(int ntiles, int other, int occ) {
     static int per_cu = -1;
     if (per_cu < 0) {
-        const char* e = getenv("CTL_PERSIST");
-        per_cu = e ? atoi(e) : 4;
+        per_cu = ctl_tune_int("CTL_PERSIST", 4);
         if (per_cu < 1) per_cu = 1;
     }
     const int resident = occ < per_cu ? occ : per_cu;
@@ -1132,7 +1098,6 @@ struct conv_call {
     hipStream_t stream;
     bool query;      // only report the grid (ctl_conv_stats_blocks), launch nothing
     int grid_x;
-    ctl_bn_rec* rec;
 };
 
 template <int KS, int S, int MODE, int MT, int TW, int NT, int EPI>
@@ -1153,7 +1118,7 @@ static void conv_go(conv_call& a) {
     const dim3 grid((unsigned)a.grid_x, (unsigned)(a.c.cot / NT), (unsigned)d->nsub);
     conv_igemm_kernel<KS, S, MODE, MT, TW, NT, EPI><<<grid, dim3(256), 0, a.stream>>>(
         *d, a.x, a.wpack, a.bias, a.pro_scale, a.pro_shift, a.res, a.res_scale, a.res_shift, a.y, a.stats_partial, a.c.tiles_h,
-        a.c.tiles_w, a.c.g, (int64_t)ctl_conv_wpack_floats(d->cin, d->cout, d->ks), ntiles, a.rec);
+        a.c.tiles_w, a.c.g, (int64_t)ctl_conv_wpack_floats(d->cin, d->cout, d->ks), ntiles);
 }
 template <int KS, int S, int MODE, int MT, int TW>
 static void conv_go_nt(conv_call& a) {
@@ -1202,68 +1167,16 @@ extern "C" size_t ctl_conv_stats_floats(const ctl_conv* d) {
     return b < 0 ? 0 : (size_t)(d->groups > 1 ? d->groups : 1) * b * 2 * d->cout;
 }
 
-// ---- fused-finalize records: host structs -> device table slots (the counters of a slot are never written from here)
-struct ctl_fin_batch { ctl_bn_fin_dev f[16]; };
-__global__ void fin_table_write_kernel(ctl_bn_rec* table, int first, int n, const ctl_fin_batch batch) {
-    if ((int)threadIdx.x < n) {
-        table[first + threadIdx.x].f = batch.f[threadIdx.x];
-        if (batch.f[threadIdx.x].role != 0)          // consumer side: the writers' arrival counter and the go flags (lines 0 .. CTL_GO_LINES)
-            for (int l = 0; l <= CTL_GO_LINES; ++l) (&table[first + threadIdx.x].counters[0][0][0])[l * CTL_ARRIVE_STRIDE] = 0;
-    }
-}
-extern "C" int ctl_consumer_finalize_built(void) { return CTL_CONSUMER_FINALIZE; }
-extern "C" int ctl_bn_fin_table_write(void* table, const ctl_bn_fin* recs, int32_t n, ctl_stream stream) {
-    CTL_REQUIRE(table && recs && n > 0 && ((uintptr_t)table & 127) == 0, "bn_fin_table_write: bad arguments");
-    for (int first = 0; first < n; first += 16) {
-        ctl_fin_batch b = {};
-        const int m = n - first < 16 ? n - first : 16;
-        for (int i = 0; i < m; ++i) {
-            const ctl_bn_fin& r = recs[first + i];
-            CTL_REQUIRE(r.gamma && r.beta && r.scale && r.shift && r.count > 0, "bn_fin_table_write: record %d needs gamma, beta, scale, shift, count", first + i);
-            CTL_REQUIRE(!r.update_running || (r.running_mean && r.running_var), "bn_fin_table_write: record %d: update_running without buffers", first + i);
-            ctl_bn_fin_dev& f = b.f[i];
-            f.gamma = r.gamma; f.beta = r.beta; f.running_mean = r.running_mean; f.running_var = r.running_var; f.nbt = r.num_batches_tracked;
-            f.scale = r.scale; f.shift = r.shift; f.save_mean = r.save_mean; f.save_invstd = r.save_invstd; f.count = (double)r.count;
-            f.eps = r.eps; f.momentum = r.momentum; f.update_running = r.update_running;
-            f.role = r.role; f.rows = r.rows; f.partial = r.partial;
-            CTL_REQUIRE(r.role >= 0 && r.role <= 2 && (r.role == 0 || (r.partial && r.rows > 0)), "bn_fin_table_write: record %d: role %d needs the producer's rows", first + i, r.role);
-        }
-        fin_table_write_kernel<<<dim3(1), dim3(64), 0, (hipStream_t)stream>>>(reinterpret_cast<ctl_bn_rec*>(table), first, m, b);
-    }
-    CTL_LAUNCH_CHECK("bn_fin_table_write");
-    return CTL_OK;
-}
 extern "C" int ctl_conv_forward(const ctl_conv* d, const float* x, const float* wpack, const float* bias,
                                 const float* pro_scale, const float* pro_shift, const float* res,
                                 const float* res_scale, const float* res_shift, float* y, float* stats_partial,
                                 ctl_stream stream) {
-    return ctl_conv_forward_fin(d, x, wpack, bias, pro_scale, pro_shift, res, res_scale, res_shift, y, stats_partial, nullptr, 0, stream);
-}
-extern "C" int ctl_conv_forward_fin(const ctl_conv* d, const float* x, const float* wpack, const float* bias,
-                                    const float* pro_scale, const float* pro_shift, const float* res,
-                                    const float* res_scale, const float* res_shift, float* y, float* stats_partial,
-                                    void* fin_rec, int32_t fin_role, ctl_stream stream) {
     CTL_REQUIRE(d && x && wpack && y, "conv_forward: null argument");
     CTL_REQUIRE((d->dt & CTL_DT_BF16) || !(d->dt & (CTL_DT_X16 | CTL_DT_Y16 | CTL_DT_RES16)), "conv_forward: bf16-stored tensors need CTL_DT_BF16");
     conv_call a = {};
     a.d = d;
     int rc = ctl_conv_pick_cfg(d, &a.c, 0);
     if (rc != CTL_OK) return rc;
-    if (fin_rec) {
-        CTL_REQUIRE(((uintptr_t)fin_rec & 127) == 0 && fin_role >= 0 && fin_role <= 2, "conv_forward: fused finalize: 128-byte aligned record, role 0..2");
-        CTL_REQUIRE(fin_role == 0 || CTL_CONSUMER_FINALIZE, "conv_forward: consumer-side finalize records need a -DCTL_CONSUMER_FINALIZE=1 build of the kernels");
-        if (fin_role == 0) {
-            CTL_REQUIRE((d->epi_flags & CTL_EPI_STATS) && !(d->epi_flags & CTL_EPI_BNBWD) && stats_partial, "conv_forward: a producer-side BatchNorm finalize needs CTL_EPI_STATS (and no CTL_EPI_BNBWD)");
-            CTL_REQUIRE(ctl_cdiv(ctl_cdiv(d->cout, 16), a.c.nt) <= CTL_FIN_MAX_Y, "conv_forward: fused finalize: at most %d block rows of output-channel tiles", CTL_FIN_MAX_Y);
-        } else if (fin_role == 1) {
-            CTL_REQUIRE(d->pro_affine && pro_scale && pro_shift, "conv_forward: consumer-side finalize (role 1) computes the prologue coefficients: pro_affine needed");
-        } else {
-            CTL_REQUIRE((d->epi_flags & CTL_EPI_RES) && res_scale && res_shift && !d->pro_affine && d->cout >= 4 &&
-                        (d->groups > 1 ? d->groups : 1) * d->cout <= CTL_PRO_MAX,
-                        "conv_forward: consumer-side finalize (role 2) computes the residual affine: CTL_EPI_RES, no prologue, 4 <= groups * cout <= %d", CTL_PRO_MAX);
-        }
-    }
-    a.rec = reinterpret_cast<ctl_bn_rec*>(fin_rec);
     CTL_REQUIRE(!(d->epi_flags & CTL_EPI_BIAS) || bias, "conv_forward: CTL_EPI_BIAS without bias");
     CTL_REQUIRE(!(d->epi_flags & CTL_EPI_RES) || (res && res_scale && res_shift), "conv_forward: CTL_EPI_RES without res");
     CTL_REQUIRE(!(d->epi_flags & CTL_EPI_STATS) || stats_partial, "conv_forward: CTL_EPI_STATS without a partial buffer");
@@ -1281,7 +1194,7 @@ extern "C" int ctl_conv_forward_fin(const ctl_conv* d, const float* x, const flo
                 "conv_forward: tensors must stay below 2 GiB (32-bit buffer offsets)");
     if (d->dt & CTL_DT_BF16) {
         const int ptok16 = ctl_prof_begin("conv_igemm_bf16", d, &a.c, a.c.nt, (hipStream_t)stream);
-        rc = ctl_conv_forward_bf16(d, x, wpack, bias, pro_scale, pro_shift, res, res_scale, res_shift, y, stats_partial, a.rec, stream);
+        rc = ctl_conv_forward_bf16(d, x, wpack, bias, pro_scale, pro_shift, res, res_scale, res_shift, y, stats_partial, stream);
         ctl_prof_end(ptok16, (hipStream_t)stream);
         return rc;
     }
@@ -1327,12 +1240,11 @@ static void wgrad_go(wgrad_call& a) {
         // ONE block per CU: the weight gradients co-run with the other launch chain, and every block costs a partial tensor that the
         // reduction at the end of the plan reads back (measured, whole step: 256 blocks 18.23 ms, 512-768 (occupancy) 18.40, 768 19.05,
         // 128 20.98).  CTL_WGRAD_PERSIST / CTL_WGRAD_SLOTS are the tuning hooks.
-        const char* e = getenv("CTL_WGRAD_PERSIST");
-        per_cu = e ? atoi(e) : 1;
+        per_cu = ctl_tune_int("CTL_WGRAD_PERSIST", 1);
         if (per_cu < 1) per_cu = 1;
     }
     const int par = w.c.g * (w.c.cot / NTW);
-    static const int slots = [] { const char* e = getenv("CTL_WGRAD_SLOTS"); return e ? atoi(e) : 0; }();      // tuning hook: total blocks
+    static const int slots = ctl_tune_int("CTL_WGRAD_SLOTS", 0);      // tuning hook: total blocks
     int splits = (slots > 0 ? slots : 256 * (occ < per_cu ? occ : per_cu)) / par;
     if (splits > 512) splits = 512;
     if (splits > w.ntiles) splits = w.ntiles;

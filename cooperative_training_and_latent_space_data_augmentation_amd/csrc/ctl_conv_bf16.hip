@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? CTL16_OCC_BIG : CT
     const ctl_conv d, const void* __restrict__ x, const void* __restrict__ wpack, const float* __restrict__ bias,
     const float* __restrict__ pro_scale, const float* __restrict__ pro_shift, const void* __restrict__ res,
     const float* __restrict__ res_scale, const float* __restrict__ res_shift, void* __restrict__ y, float* __restrict__ stats_partial,
-    int tiles_h, int tiles_w, int G_chunks, int64_t wpack_sub_bytes, int ntiles, ctl_bn_rec* __restrict__ rec) {
+    int tiles_h, int tiles_w, int G_chunks, int64_t wpack_sub_bytes, int ntiles) {
     using G = Geom<KS, S, MT, TW>;
     using XS = XStage16<KS, S, MODE, MT, TW, XB, true>;
     constexpr int TAPS = KS * KS;
@@ -353,31 +353,10 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? CTL16_OCC_BIG : CT
         xs.load(rx, d, cur.n, cur.th * G::TH, cur.tw * TW, 0);
         wload(0);
     }
-    // consumer-side BatchNorm finalize (ctl_bn_consume; see the fp32 kernel)
-#if CTL_CONSUMER_FINALIZE
-    if (rec && rec->f.role != 0)
-        ctl_bn_consume(rec->f, &rec->counters[0][0][0], ngroups, rec->f.role == 1 ? d.cin : d.cout,
-                       (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, gridDim.x * gridDim.y * gridDim.z,
-                       reinterpret_cast<double*>(xt));
-    const bool res_lds = rec && rec->f.role == 2;
-    if (d.pro_affine) {
-        if (rec && rec->f.role == 1) {        // computed in this launch by other blocks: agent-scope loads
-            for (int i = tid; i < ngroups * d.cin; i += 256) { cf_scale[i] = ctl_load_wt(pro_scale + i); cf_shift[i] = ctl_load_wt(pro_shift + i); }
-        } else {
-            for (int i = tid; i < ngroups * d.cin; i += 256) { cf_scale[i] = pro_scale[i]; cf_shift[i] = pro_shift[i]; }
-        }
-        __syncthreads();
-    } else if (res_lds) {
-        for (int i = tid; i < ngroups * d.cout; i += 256) { cf_scale[i] = ctl_load_wt(res_scale + i); cf_shift[i] = ctl_load_wt(res_shift + i); }
-        __syncthreads();
-    }
-#else
-    constexpr bool res_lds = false;
     if (d.pro_affine) {
         for (int i = tid; i < ngroups * d.cin; i += 256) { cf_scale[i] = pro_scale[i]; cf_shift[i] = pro_shift[i]; }
         __syncthreads();
     }
-#endif
     if (total_it > 0) {
         xs.store(xt, d, 0, cf_scale, cf_shift, (cur.n / group_n) * d.cin);
         wstore();
@@ -433,7 +412,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? CTL16_OCC_BIG : CT
 #pragma unroll
             for (int w = 0; w < 4; ++w) v += sred[((w * NT * 16) + cl) * 2 + stat];
             const int co = cot0 * 16 + cl;
-            if (co < d.cout) ctl_store_wt(stats_partial + (((int64_t)grp * srows + srow) * 2 + stat) * d.cout + co, v);      // (write-through: fused finalize)
+            if (co < d.cout) stats_partial[(((int64_t)grp * srows + srow) * 2 + stat) * d.cout + co] = v;
         }
         __syncthreads();
     };
@@ -441,7 +420,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? CTL16_OCC_BIG : CT
     if ((flags & CTL_EPI_STATS) && ngroups > 1 && tid < NT * 16 * 2) {
         const int stat = tid / (NT * 16), co = cot0 * 16 + tid % (NT * 16);
         if (co < d.cout)
-            for (int gi = 0; gi < ngroups; ++gi) ctl_store_wt(stats_partial + (((int64_t)gi * srows + srow) * 2 + stat) * d.cout + co, 0.f);
+            for (int gi = 0; gi < ngroups; ++gi) stats_partial[(((int64_t)gi * srows + srow) * 2 + stat) * d.cout + co] = 0.f;
     }
 
     TM(7)
@@ -580,8 +559,8 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? CTL16_OCC_BIG : CT
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
                         const int co0 = (cot0 + t) * 16 + q * 4;
-                        rs[t] = *reinterpret_cast<const f32x4*>((res_lds ? cf_scale : res_scale) + grp * d.cout + co0);
-                        rh[t] = *reinterpret_cast<const f32x4*>((res_lds ? cf_shift : res_shift) + grp * d.cout + co0);
+                        rs[t] = *reinterpret_cast<const f32x4*>(res_scale + grp * d.cout + co0);
+                        rh[t] = *reinterpret_cast<const f32x4*>(res_shift + grp * d.cout + co0);
                     }
                 }
                 int bo[MT];
@@ -669,10 +648,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? CTL16_OCC_BIG : CT
                 const int cc = cok ? co0 : 0;
                 f32x4 rs = {0.f, 0.f, 0.f, 0.f}, rh = {0.f, 0.f, 0.f, 0.f};
                 if (flags & CTL_EPI_RES) {
-                    if (res_lds) {
-                        rs = *reinterpret_cast<const f32x4*>(cf_scale + grp * d.cout + cc);
-                        rh = *reinterpret_cast<const f32x4*>(cf_shift + grp * d.cout + cc);
-                    } else if (d.cout >= 4) {
+                    if (d.cout >= 4) {
                         rs = *reinterpret_cast<const f32x4*>(res_scale + grp * d.cout + cc);
                         rh = *reinterpret_cast<const f32x4*>(res_shift + grp * d.cout + cc);
                     } else { rs.x = res_scale[grp]; rh.x = res_shift[grp]; }
@@ -716,12 +692,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? CTL16_OCC_BIG : CT
         g = g2;
     }
     TM_FLUSH
-    if (flags & CTL_EPI_STATS) {
-        flush_stats(cur_grp);
-        if (rec != nullptr)               // fused BatchNorm finalize by the last-arriving block of this output-channel range
-            ctl_bn_finalize_tail(rec, stats_partial, srows, ngroups, d.cout, cot0 * 16, NT * 16, gridDim.x * gridDim.z,
-                                 reinterpret_cast<int*>(sred));
-    }
+    if (flags & CTL_EPI_STATS) flush_stats(cur_grp);
 }
 
 // ------------------------------------------------------------------------------------------------ weight packing (bf16 fragments)
@@ -802,7 +773,6 @@ struct conv16_call {
     const void *x, *wpack, *res; void* y;
     const float *bias, *pro_scale, *pro_shift, *res_scale, *res_shift; float* stats_partial;
     hipStream_t stream; bool query; int grid_x;
-    ctl_bn_rec* rec;
 };
 template <int KS, int S, int MODE, int MT, int TW, int NT, int FAST, bool XB>
 static void conv16_go_f(conv16_call& a) {
@@ -822,7 +792,7 @@ static void conv16_go_f(conv16_call& a) {
     const dim3 grid((unsigned)a.grid_x, (unsigned)(a.c.cot / NT), (unsigned)d->nsub);
     conv_igemm_bf16_kernel<KS, S, MODE, MT, TW, NT, FAST, XB><<<grid, dim3(256), 0, a.stream>>>(
         *d, a.x, a.wpack, a.bias, a.pro_scale, a.pro_shift, a.res, a.res_scale, a.res_shift, a.y, a.stats_partial, a.c.tiles_h, a.c.tiles_w,
-        a.c.g, (int64_t)ctl_conv_wpack_floats(d->cin, d->cout, d->ks) * 4, ntiles, a.rec);
+        a.c.g, (int64_t)ctl_conv_wpack_floats(d->cin, d->cout, d->ks) * 4, ntiles);
 }
 template <int KS, int S, int MODE, int MT, int TW, int NT>
 static void conv16_go(conv16_call& a) {
@@ -890,7 +860,7 @@ int ctl_conv_bf16_stats_blocks(const ctl_conv* d) {
 
 int ctl_conv_forward_bf16(const ctl_conv* d, const void* x, const void* wpack, const float* bias, const float* pro_scale,
                           const float* pro_shift, const void* res, const float* res_scale, const float* res_shift, void* y,
-                          float* stats_partial, ctl_bn_rec* rec, ctl_stream stream) {
+                          float* stats_partial, ctl_stream stream) {
     CTL_REQUIRE(!(d->epi_flags & CTL_EPI_BNBWD) || ((d->dt & CTL_DT_X16) && (d->dt & CTL_DT_Y16) && (d->dt & CTL_DT_RES16) && d->cin % 16 == 0 && d->cout % 16 == 0),
                 "conv_forward(bf16): CTL_EPI_BNBWD needs bf16-stored x, y and u with whole 16-channel tiles");
     CTL_REQUIRE(!(d->dt & CTL_DT_X16) || d->cin % 16 == 0, "conv_forward(bf16): bf16-stored inputs need cin %% 16 == 0 (got %d)", d->cin);
@@ -901,7 +871,6 @@ int ctl_conv_forward_bf16(const ctl_conv* d, const void* x, const void* wpack, c
     if (rc != CTL_OK) return rc;
     a.x = x; a.wpack = wpack; a.bias = bias; a.pro_scale = pro_scale; a.pro_shift = pro_shift; a.res = res; a.res_scale = res_scale;
     a.res_shift = res_shift; a.y = y; a.stats_partial = stats_partial; a.stream = (hipStream_t)stream;
-    a.rec = rec;
     rc = conv16_dispatch(a);
     if (rc != CTL_OK) return rc;
     CTL_LAUNCH_CHECK("conv_forward(bf16)");
@@ -1146,7 +1115,7 @@ static void wgrad16_go(wgrad16_call& a) {
         occ = n;
     }
     const int par = a.c.g * (a.c.cot / NTW);
-    static const int cap = [] { const char* e = getenv("CTL16_WGRAD_SPLITS"); return e ? atoi(e) : 1024; }();      // tuning hook (measured: 512 -> 768/1024 splits = 28.7 -> 24.5 us on the 16->16 3x3 layer at 256^2)
+    static const int cap = ctl_tune_int("CTL16_WGRAD_SPLITS", 1024);      // tuning hook (measured: 512 -> 768/1024 splits = 28.7 -> 24.5 us on the 16->16 3x3 layer at 256^2)
     int splits = (256 * (occ < 4 ? occ : 4)) / par;
     if (splits > cap) splits = cap;
     if (splits > a.ntiles) splits = a.ntiles;
@@ -1186,7 +1155,7 @@ static int wgrad16_pick(const ctl_conv* d, wgrad16_call* a) {
     // With 16-cycle bf16 MFMAs a tile's matrix work (9 per wave for a 3x3 kernel) is far shorter than the load latency of the next tile,
     // which the single-buffered loop then exposes every time: the large layers take 16x16-pixel tiles (twice the bytes in flight per
     // block, half the barriers per byte).  Measured 16->16 at 256^2: 41.9 us with 8x16 tiles.
-    static const int big_ok = [] { const char* e = getenv("CTL16_WGRAD_MT4"); return e ? atoi(e) : 1; }();
+    static const int big_ok = ctl_tune_int("CTL16_WGRAD_MT4", 1);
     if (big_ok && d->stride == 1 && d->ks == 3 && d->hout >= 64 && d->wout >= 16) {      // (1x1: 8x16 tiles measured faster)
         a->c.mt = 4; a->c.th = 16;
         a->c.tiles_h = ctl_cdiv(d->hout, 16);

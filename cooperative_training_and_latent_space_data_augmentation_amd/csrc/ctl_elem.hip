@@ -111,18 +111,14 @@ __global__ __launch_bounds__(EB) void bn_act_kernel(const void* __restrict__ x, 
 // ------------------------------------------------------------------------------------------------ backward reductions
 // rows of partial sums per group: enough blocks to stream a large tensor, few for the low-resolution layers (whose old fixed 512
 // rows cost more to write and re-read than the tensor itself)
-static inline int ctl_red_blocks(int64_t quads_per_group) {
+static inline int red_rows_for(int64_t quads_per_group) {
     int64_t b = ctl_cdiv64(quads_per_group, (int64_t)EB * 8);
     if (b > CTL_RED_BLOCKS) b = CTL_RED_BLOCKS;
     if (b < 16) b = 16;
     return (int)b;
 }
 
-// BatchNorm backward coefficients of one (group, channel) from its two sums (shared by the finalize kernel and the fused tail)
-struct ctl_bnb_fin_dev {
-    const float* gamma; const float* save_mean; const float* save_invstd; float* coef; float* dgamma; float* dbeta;
-    unsigned* counter; double count; int accumulate;
-};
+// BatchNorm backward coefficients of one (group, channel) from its two sums
 struct ctl_bnb_chan { float gamma, dgamma, dbeta; };      // requested before the reduction (dgamma / dbeta carried over the groups)
 __device__ __forceinline__ ctl_bnb_chan bnb_chan_load(int ch, const float* __restrict__ gamma, const float* __restrict__ dgamma,
                                                       const float* __restrict__ dbeta, int accumulate) {
@@ -153,14 +149,14 @@ __device__ __forceinline__ void bn_bwd_coefs(double s1, double s2, double count,
 }
 
 // grid = (rows, groups) x 256; the global stride (rows * 256) is a multiple of every C/4 in use, so a thread always sees
-// the same channel quad and accumulates it in registers.  fin.counter != NULL: the last block also finalises (bn_bwd_finalize).
+// the same channel quad and accumulates it in registers.
 template <int MODE>
 __global__ __launch_bounds__(EB) void bwd_reduce_kernel(const void* __restrict__ dy_, const void* __restrict__ act_src_,
                                                          const void* __restrict__ bn_src_,
                                                          const f32x4* __restrict__ scale,
                                                          const f32x4* __restrict__ shift, float slope, int64_t quads,
                                                          int cq, float* __restrict__ partial, unsigned m,      // m: bit 0 dy, 1 act_src, 2 bn_src, 3 ds
-                                                         const ctl_bnb_fin_dev fin, void* __restrict__ ds_) {
+                                                         void* __restrict__ ds_) {
     // blockIdx.y = BatchNorm group: `quads` is the size of one group, its data start at blockIdx.y * quads
     __shared__ f32x4 sm[2][EB];
     const int64_t gtid = (int64_t)blockIdx.x * EB + threadIdx.x;
@@ -202,28 +198,7 @@ __global__ __launch_bounds__(EB) void bwd_reduce_kernel(const void* __restrict__
         float v = 0.f;
         // threads with (tid % cq) == qq hold this quad (EB % cq == 0 for every cq in use)
         for (int k = qq; k < EB; k += cq) v += sm[stat][k][comp];
-        ctl_store_wt(partial + (((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 + stat) * c + ch, v);
-    }
-    if (MODE == 2 || fin.counter == nullptr) return;
-    // ---- fused finalize: the block that arrives last turns the rows into A, B, C (+ dgamma, dbeta); one wave per channel, rows
-    // spread over its lanes in a fixed order (deterministic), fp64 like the stand-alone kernel
-    __shared__ int last_flag;
-    if (!ctl_arrive_last(fin.counter, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, &last_flag)) return;
-    const int rows = gridDim.x, groups = gridDim.y, lane = threadIdx.x & 63;
-    for (int ch = threadIdx.x >> 6; ch < c; ch += EB / 64) {
-        ctl_bnb_chan p = bnb_chan_load(ch, fin.gamma, fin.dgamma, fin.dbeta, fin.accumulate);
-        for (int gi = 0; gi < groups; ++gi) {
-            const float mu = fin.save_mean[gi * c + ch], is = fin.save_invstd[gi * c + ch];
-            double s1 = 0.0, s2 = 0.0;
-#pragma unroll 4
-            for (int b = lane; b < rows; b += 64) {
-                s1 += (double)ctl_load_wt(partial + (((int64_t)gi * rows + b) * 2 + 0) * c + ch);
-                s2 += (double)ctl_load_wt(partial + (((int64_t)gi * rows + b) * 2 + 1) * c + ch);
-            }
-            s1 = wave_sum_double(s1);
-            s2 = wave_sum_double(s2);
-            if (lane == 0) bn_bwd_coefs(s1, s2, fin.count, c, gi, ch, p, mu, is, fin.coef, fin.dgamma, fin.dbeta);
-        }
+        partial[(((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 + stat) * c + ch] = v;
     }
 }
 
@@ -309,7 +284,7 @@ template <int MODE>
 __global__ __launch_bounds__(EB) void bwd_reduce16_kernel(const u32x4e* __restrict__ dy, const u32x4e* __restrict__ act_src,
                                                            const u32x4e* __restrict__ bn_src, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, float slope, int64_t octs, int co,
-                                                           float* __restrict__ partial, const ctl_bnb_fin_dev fin) {
+                                                           float* __restrict__ partial) {
     // blockIdx.y = BatchNorm group: `octs` is the size of one group; a thread always sees the same channel octet (256 % co == 0)
     __shared__ float sm[2][8][EB];
     const int64_t gtid = (int64_t)blockIdx.x * EB + threadIdx.x;
@@ -359,26 +334,7 @@ __global__ __launch_bounds__(EB) void bwd_reduce16_kernel(const u32x4e* __restri
         const int oo = ch >> 3, comp = ch & 7;
         float v = 0.f;
         for (int k = oo; k < EB; k += co) v += sm[stat][comp][k];
-        ctl_store_wt(partial + (((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 + stat) * c + ch, v);
-    }
-    if (fin.counter == nullptr) return;
-    __shared__ int last_flag;
-    if (!ctl_arrive_last(fin.counter, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, &last_flag)) return;
-    const int rows = gridDim.x, groups = gridDim.y, lane = threadIdx.x & 63;
-    for (int ch = threadIdx.x >> 6; ch < c; ch += EB / 64) {
-        ctl_bnb_chan p = bnb_chan_load(ch, fin.gamma, fin.dgamma, fin.dbeta, fin.accumulate);
-        for (int gi = 0; gi < groups; ++gi) {
-            const float mu = fin.save_mean[gi * c + ch], is = fin.save_invstd[gi * c + ch];
-            double a1 = 0.0, a2 = 0.0;
-#pragma unroll 4
-            for (int b = lane; b < rows; b += 64) {
-                a1 += (double)ctl_load_wt(partial + (((int64_t)gi * rows + b) * 2 + 0) * c + ch);
-                a2 += (double)ctl_load_wt(partial + (((int64_t)gi * rows + b) * 2 + 1) * c + ch);
-            }
-            a1 = wave_sum_double(a1);
-            a2 = wave_sum_double(a2);
-            if (lane == 0) bn_bwd_coefs(a1, a2, fin.count, c, gi, ch, p, mu, is, fin.coef, fin.dgamma, fin.dbeta);
-        }
+        partial[(((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 + stat) * c + ch] = v;
     }
 }
 
@@ -716,24 +672,18 @@ extern "C" int ctl_bn_act(const float* x, const float* scale, const float* shift
 }
 static bool red_c_ok(int c) { return c >= 4 && c % 4 == 0 && (EB % (c / 4)) == 0; }
 
+extern "C" int ctl_red_blocks(void) { return CTL_RED_BLOCKS; }
 extern "C" int ctl_bwd_reduce_rows(int32_t mode, int64_t pixels_per_group, int32_t c) {
-    return mode == 2 ? CTL_RED_BLOCKS : ctl_red_blocks(pixels_per_group * (c / 4));
+    return mode == 2 ? CTL_RED_BLOCKS : red_rows_for(pixels_per_group * (c / 4));
 }
-extern "C" int ctl_bwd_reduce_fin(int32_t mode, const float* dy, const float* act_src, const float* bn_src,
-                                  const float* scale, const float* shift, float slope, int64_t pixels, int32_t c,
-                                  float* partial, int32_t groups, uint32_t bf16_mask, const ctl_bnb_fin* fin, float* ds, ctl_stream stream) {
+extern "C" int ctl_bwd_reduce_dt(int32_t mode, const float* dy, const float* act_src, const float* bn_src,
+                                 const float* scale, const float* shift, float slope, int64_t pixels, int32_t c,
+                                 float* partial, int32_t groups, uint32_t bf16_mask, float* ds, ctl_stream stream) {
     CTL_REQUIRE(!ds || mode == 0, "bwd_reduce: ds (= dy * leaky'(act_src)) is an output of mode 0 only");
     CTL_REQUIRE(dy && partial && pixels > 0 && red_c_ok(c) && groups >= 1 && pixels % groups == 0, "bwd_reduce: bad arguments (c=%d)", c);
     const int64_t quads = (pixels / groups) * (c / 4);           // per group
     // modes 0 / 1 feed ctl_bn_bwd_finalize, which derives the same row count from (count, c); mode 2 feeds ctl_chan_sum_finalize (fixed rows)
-    const dim3 grid((unsigned)(mode == 2 ? CTL_RED_BLOCKS : ctl_red_blocks(quads)), (unsigned)groups), blk(EB);
-    ctl_bnb_fin_dev f = {};
-    if (fin) {
-        CTL_REQUIRE(mode != 2 && fin->gamma && fin->save_mean && fin->save_invstd && fin->coef && fin->counter && fin->count > 0,
-                    "bwd_reduce: fused finalize needs modes 0/1, gamma, save_mean, save_invstd, coef, counter and count");
-        f.gamma = fin->gamma; f.save_mean = fin->save_mean; f.save_invstd = fin->save_invstd; f.coef = fin->coef; f.dgamma = fin->dgamma;
-        f.dbeta = fin->dbeta; f.counter = fin->counter; f.count = (double)fin->count; f.accumulate = fin->accumulate;
-    }
+    const dim3 grid((unsigned)(mode == 2 ? CTL_RED_BLOCKS : red_rows_for(quads)), (unsigned)groups), blk(EB);
     // every tensor stored as bf16 and whole channel octets: 16 bytes per lane
     const bool oct = c % 8 == 0 && (EB % (c / 8)) == 0 && (pixels / groups) * (int64_t)(c / 8) >= 1 && !ds &&
                      ((mode == 0 && (bf16_mask & 7u) == 7u) || (mode == 1 && (bf16_mask & 5u) == 5u));
@@ -741,42 +691,37 @@ extern "C" int ctl_bwd_reduce_fin(int32_t mode, const float* dy, const float* ac
         CTL_REQUIRE(act_src && bn_src, "bwd_reduce mode 0 needs act_src and bn_src");
         if (oct)
             bwd_reduce16_kernel<0><<<grid, blk, 0, S_>>>((const u32x4e*)dy, (const u32x4e*)act_src, (const u32x4e*)bn_src, nullptr, nullptr, slope,
-                                                        quads / 2, c / 8, partial, f);
+                                                        quads / 2, c / 8, partial);
         else
-            bwd_reduce_kernel<0><<<grid, blk, 0, S_>>>(dy, act_src, bn_src, nullptr, nullptr, slope, quads, c / 4, partial, bf16_mask, f, ds);
+            bwd_reduce_kernel<0><<<grid, blk, 0, S_>>>(dy, act_src, bn_src, nullptr, nullptr, slope, quads, c / 4, partial, bf16_mask, ds);
     } else if (mode == 1) {
         CTL_REQUIRE(bn_src && scale && shift, "bwd_reduce mode 1 needs bn_src, scale, shift");
         if (oct)
             bwd_reduce16_kernel<1><<<grid, blk, 0, S_>>>((const u32x4e*)dy, nullptr, (const u32x4e*)bn_src, scale, shift, slope, quads / 2, c / 8,
-                                                        partial, f);
+                                                        partial);
         else
             bwd_reduce_kernel<1><<<grid, blk, 0, S_>>>(dy, nullptr, bn_src, (const f32x4*)scale, (const f32x4*)shift, slope, quads, c / 4, partial,
-                                                      bf16_mask, f, nullptr);
+                                                      bf16_mask, nullptr);
     } else if (mode == 2) {
         CTL_REQUIRE(groups == 1, "bwd_reduce mode 2 sums everything: groups must be 1");
-        bwd_reduce_kernel<2><<<grid, blk, 0, S_>>>(dy, nullptr, nullptr, nullptr, nullptr, slope, quads, c / 4, partial, bf16_mask, f, nullptr);
+        bwd_reduce_kernel<2><<<grid, blk, 0, S_>>>(dy, nullptr, nullptr, nullptr, nullptr, slope, quads, c / 4, partial, bf16_mask, nullptr);
     } else {
         CTL_FAIL(CTL_EINVAL, "bwd_reduce: mode %d", mode);
     }
     CTL_LAUNCH_CHECK("bwd_reduce");
     return CTL_OK;
 }
-extern "C" int ctl_bwd_reduce_dt(int32_t mode, const float* dy, const float* act_src, const float* bn_src,
-                                 const float* scale, const float* shift, float slope, int64_t pixels, int32_t c,
-                                 float* partial, int32_t groups, uint32_t bf16_mask, ctl_stream stream) {
-    return ctl_bwd_reduce_fin(mode, dy, act_src, bn_src, scale, shift, slope, pixels, c, partial, groups, bf16_mask, nullptr, nullptr, stream);
-}
 extern "C" int ctl_bwd_reduce(int32_t mode, const float* dy, const float* act_src, const float* bn_src,
                               const float* scale, const float* shift, float slope, int64_t pixels, int32_t c,
                               float* partial, int32_t groups, ctl_stream stream) {
-    return ctl_bwd_reduce_dt(mode, dy, act_src, bn_src, scale, shift, slope, pixels, c, partial, groups, 0, stream);
+    return ctl_bwd_reduce_dt(mode, dy, act_src, bn_src, scale, shift, slope, pixels, c, partial, groups, 0, nullptr, stream);
 }
 extern "C" int ctl_bn_bwd_finalize(const float* partial, int32_t c, int64_t count, const float* gamma,
                                    const float* save_mean, const float* save_invstd, float* coef, float* dgamma,
                                    float* dbeta, int32_t accumulate, int32_t groups, int32_t blocks, ctl_stream stream) {
     CTL_REQUIRE(partial && gamma && save_mean && save_invstd && coef && c > 0 && count > 0 && groups >= 1 && blocks >= 0, "bn_bwd_finalize: bad arguments");
     // blocks == 0: rows as written by ctl_bwd_reduce for a group of `count` pixels
-    bn_bwd_finalize_kernel<<<dim3(c), dim3(EB), 0, S_>>>(partial, blocks > 0 ? blocks : ctl_red_blocks(count * (c / 4)), c, (double)count, gamma, save_mean,
+    bn_bwd_finalize_kernel<<<dim3(c), dim3(EB), 0, S_>>>(partial, blocks > 0 ? blocks : red_rows_for(count * (c / 4)), c, (double)count, gamma, save_mean,
                                                           save_invstd, coef, dgamma, dbeta, accumulate, groups);
     CTL_LAUNCH_CHECK("bn_bwd_finalize");
     return CTL_OK;

@@ -30,7 +30,7 @@ __device__ __forceinline__ f32x4 stream_load(const f32x4* p) {
 // (the split fixes the summation order of the channel scores: the three-launch path and the fused kernel share it, so their scores are
 // bit-identical; >= ~1024 partial sums in flight where the problem allows)
 static inline int score_split_pix(int n, int hw) {
-    static const int forced = [] { const char* e = getenv("CTL_MASK_SPLIT"); return e ? atoi(e) : 0; }();     // tuning hook
+    static const int forced = ctl_tune_int("CTL_MASK_SPLIT", 0);     // tuning hook
     if (forced > 0) return forced;
     int sp = 512;
     while (sp > 64 && (int64_t)n * ctl_cdiv(hw, sp) < 1024) sp >>= 1;
@@ -464,7 +464,7 @@ __global__ __launch_bounds__(MB) void uniform_kernel(float* __restrict__ out, in
 static bool cq_ok(int c) { return c >= 4 && c % 4 == 0 && (c / 4) <= 64 && (64 % (c / 4)) == 0; }
 static int slab_pixels(int n, int hw, int c) {
     // ~32 KiB of code per block (8 quads per thread in flight), but at least ~512 blocks when the problem is large enough
-    static const int forced_kb = [] { const char* e = getenv("CTL_MASK_SLAB_KB"); return e ? atoi(e) : 0; }();   // tuning hook
+    static const int forced_kb = ctl_tune_int("CTL_MASK_SLAB_KB", 0);   // tuning hook
     int sp = ((forced_kb > 0 ? forced_kb : 32) * 1024) / (c * 4);
     if (sp < 1) sp = 1;
     while (sp > 1 && (int64_t)n * ctl_cdiv(hw, sp) < 512) sp >>= 1;

@@ -50,8 +50,9 @@ class CooperativeStepGraph:
         self.state = torch.zeros(3, dtype=torch.int64, device=dev)
         self.state[0] = _draw_seed() & (2 ** 62 - 1)                   # respects torch.manual_seed
         self.k_dev = {1: torch.zeros(1, dtype=torch.int32, device=dev), 2: torch.zeros(1, dtype=torch.int32, device=dev)}
-        self.k_host = {i: torch.zeros(1, dtype=torch.int32).pin_memory() for i in (1, 2)}
         self.replays = 0
+        self.k_log = []                # the k values handed to the replays, in draw order (tests compare them with the eager sequence)
+        self._dev_adam_count = None    # what state[2] holds on the device after the launches issued so far
 
     # ------------------------------------------------------------------ host draws, in the reference's order
     def _draw_schemes(self):
@@ -77,8 +78,12 @@ class CooperativeStepGraph:
             slot += 1
             if sc in ("channel", "spatial") and cfg["random_threshold"]:
                 L = c if sc == "channel" else h * w
-                self.k_host[slot][0] = int(L * (np.random.rand() * cfg["max_threshold"]))
-                self.k_dev[slot].copy_(self.k_host[slot], non_blocking=True)
+                # the value travels as a LAUNCH ARGUMENT of a fill kernel (captured at issue time).  A non-blocking copy from one
+                # reused pinned word is read when the copy executes: the host runs several replays ahead of the GPU, so later draws
+                # overwrote the word before earlier copies had run and consecutive steps saw the same k
+                k = int(L * (np.random.rand() * cfg["max_threshold"]))
+                self.k_dev[slot].fill_(k)
+                self.k_log.append(k)
 
     # ------------------------------------------------------------------ capture
     def _adam_step_counts(self):
@@ -162,12 +167,21 @@ class CooperativeStepGraph:
         zs = e.z[0].shape if e.z[0] is not None else None
         if zs is not None:
             self._draw_ks(schemes, zs)
+        # the Adam step count lives on the device (state[2], advanced by the replay itself).  Anything that stepped the optimizers
+        # outside this object since the last replay (an eager cooperative_step for a tail batch of another shape, load_state_dict,
+        # bench.py's launch census) moved the host counts but not the device word: re-seed it, as a launch argument, before replaying
+        counts = self._adam_step_counts()
+        if len(set(counts)) != 1:
+            raise CtlError("CooperativeStepGraph: the five optimizers must be at the same step count (one device-side counter)")
+        if counts[0] != self._dev_adam_count:
+            self.state[2:3].fill_(counts[0])
         e.graph.replay()
         if e.adam_graph is not None:
             self.grad_hook(s)
             e.adam_graph.replay()
         for o in s.optimizers.values():        # host mirrors of what the replay did on the device
             o.step_count += 1
+        self._dev_adam_count = counts[0] + 1
         for m in s.model.values():
             m.weights_changed()
         s.z_i, s.z_s = e.z

@@ -21,8 +21,6 @@ without gamma/beta gradients, "C" eval (running statistics).
 """
 from __future__ import annotations
 
-import os
-
 import ctypes
 from collections import namedtuple
 from typing import Dict, List, Optional, Tuple
@@ -39,13 +37,13 @@ N_SLOTS = 17
 SLOPE = 0.2
 EPS = 1e-5
 MOMENTUM = 0.1
-SMALL_CIN = os.environ.get("CTL_SMALL_CIN", "1") != "0"          # K-packed taps for the Cin <= 4 first layers
-PHASE_CONVS = os.environ.get("CTL_PHASE_CONVS", "1") != "0"     # 2x2 phase forms of the up-sampled forward / stride-2 data gradient
-FUSE_BNBWD = os.environ.get("CTL_FUSE_BNBWD", "0") == "1"   # BN1-backward reduction inside the dgrad conv epilogue (fp32, measured: no gain)
-FUSE_BNBWD16 = os.environ.get("CTL_FUSE_BNBWD16", "1") == "1"   # the same in the bf16 family, where the data gradient is not matrix-bound
+# Plan-compiler switches (module attributes, no environment reads; tools/ab.py flips them for A/B runs)
+SMALL_CIN = True         # K-packed taps for the Cin <= 4 first layers
+PHASE_CONVS = True       # 2x2 phase forms of the up-sampled forward / stride-2 data gradient
+FUSE_BNBWD = False       # BN1-backward reduction inside the dgrad conv epilogue (fp32: matrix-bound kernel, measured no gain)
+FUSE_BNBWD16 = True      # the same in the bf16 family, where the data gradient is not matrix-bound
 CONV_WORDS = _ffi.CONV_DTYPE.itemsize // 4      # ctl_conv as int32 words at the head of ctl_op.i
 ALIGN_F = 64            # floats (256 B)
-FIN_HEADER = _ffi.FIN_HEADER_BYTES      # head of every plan scratch buffer: fused-finalize record table (ctl_hip.h)
 
 T = namedtuple("T", "ref n h w c b16", defaults=(False,))     # tensor descriptor: ref = (slot, byte offset), NHWC dims, bf16 storage?
 
@@ -171,9 +169,8 @@ class PlanBuilder:
             op["off"][idx] = ref[1]
 
     def scr(self, *nbytes):
-        """Transient scratch (valid until the next op that asks for scratch).  The first FIN_HEADER bytes of the scratch buffer are the
-        fused-finalize record table (arrival counters + arguments, ctl_hip.h): zero at allocation, never handed out."""
-        refs, off = [], FIN_HEADER
+        """Transient scratch (valid until the next op that asks for scratch)."""
+        refs, off = [], 0
         for nb in nbytes:
             refs.append((S_SCR, off))
             off += _rup(int(nb), 256)
@@ -254,7 +251,6 @@ class PlanBuilder:
         words = np.frombuffer(d.tobytes(), dtype="<i4")
         op = self.op(_ffi.OP_WGRAD)
         op["i"][:CONV_WORDS] = words
-        op["i"][26] = 1                    # side lane: off the critical dgrad chain (see ctl_plan.cpp)
         for idx, ref in enumerate([x.ref, pro[0] if pro else None, pro[1] if pro else None, dy.ref, wref, bref]):
             self.set_t(op, idx, ref)
         assert dw_ref[0] == S_GRAD and (dbias_ref is None or dbias_ref[0] == S_GRAD)
@@ -270,7 +266,6 @@ class PlanBuilder:
         assert self.table is None
         self.table = np.asarray(self.reduce_recs, dtype=np.int64)
         op = self.op(_ffi.OP_WGRAD_REDUCE_BATCH)
-        op["i"][26] = 1
         op["i"][0] = len(self.reduce_recs)
         op["l"][0] = max(-(-((r[5] & 0xff) * r[6] * r[7] + r[7]) // (64 if r[4] <= 64 else 8)) for r in self.reduce_recs)
         self.set_t(op, 0, (S_BSCR, 0))
@@ -295,7 +290,6 @@ class PlanBuilder:
             return co
         op = self.op(_ffi.OP_BN_FINALIZE)
         op["i"][0], op["i"][1], op["i"][2], op["i"][3] = blocks, c, 1 if mode == "A" else 0, G
-        op["i"][4] = 1                 # may be folded into the conv that wrote `stats_ref` (the op directly in front), see ctl_plan.cpp
         op["l"][0] = count
         op["f"][0], op["f"][1] = EPS, MOMENTUM
         for idx, ref in enumerate([stats_ref, self.P(bn.g_off), self.P(bn.b_off), (S_B, 4 * bn.rm_off),
@@ -338,7 +332,6 @@ class PlanBuilder:
             self.set_t(op, idx, ref)
         op = self.op(_ffi.OP_BN_BWD_FINALIZE)
         op["i"][0], op["i"][1], op["i"][2] = c, 0, G
-        op["i"][4] = 1                 # may be folded into the reduction in front of it
         op["l"][0] = pixels // G
         for idx, ref in enumerate([part, self.P(bn.g_off), co["mean"], co["invstd"], coef,
                                    self.G(bn.g_off) if affine_grad else None, self.G(bn.b_off) if affine_grad else None]):
@@ -701,7 +694,7 @@ class CtlNet(nn.Module):
             if self._scr is None:
                 self._scr = {}
             scr = self._scr.get(stream.cuda_stream)
-            if scr is None or scr.numel() < plan.scr_bytes:      # zeros: the head of the buffer holds the fused-finalize arrival counters
+            if scr is None or scr.numel() < plan.scr_bytes:
                 scr = self._scr[stream.cuda_stream] = torch.zeros(plan.scr_bytes, dtype=torch.uint8, device=self.device)
             tensors = dict(tensors)
             tensors[S_SCR] = scr

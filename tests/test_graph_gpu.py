@@ -165,3 +165,47 @@ def test_dropout_mask_has_the_reference_semantics(golden_sd):
     assert torch.equal(masked.cpu(), ref_masked) and torch.equal(mask.cpu(), ref_mask) and mask.shape == z.shape
     out, kp, m2 = ops.dropout2d(dev(z), 0.5, seed=9, want_mask=True)
     assert torch.equal(m2.cpu(), (out.cpu() == z).float())
+
+
+def test_unsynchronised_replays_see_their_own_k(golden_sd):
+    """the host runs several replays ahead of the GPU; every replay must still mask with ITS k (the reference's np.random
+    sequence, model_util.py:229-230), not with a later draw.  No host sync between the replays; the per-step masks are cloned
+    stream-ordered and counted afterwards."""
+    clean, label, noisy = (dev(t) for t in O.synthetic_batch(4, 64, 64, seed=5))
+    s = _solver(golden_sd)
+    g = CooperativeStepGraph(s, CH_MSE_RT, SP_CE_RT)
+    g(clean, label, noisy)                               # capture + first replay
+    torch.cuda.synchronize()
+    np.random.seed(11)
+    expect = []
+    rs = np.random.RandomState(11)
+    for _ in range(12):
+        expect.append((int(128 * (rs.rand() * 0.5)), int(16 * (rs.rand() * 0.5))))      # z is 128 x 4 x 4 at 64^2: L = 128 / 16
+    del g.k_log[:]
+    masks = []
+    for _ in range(12):
+        g(clean, label, noisy)
+        masks.append((s.last_masks["image"].clone(), s.last_masks["seg"].clone()))   # stream-ordered copies, no host sync
+    torch.cuda.synchronize()
+    assert g.k_log == [k for pair in expect for k in pair]
+    assert len(set(expect)) > 6                             # the draws do differ from step to step
+    for (mi, ms), (ki, ks) in zip(masks, expect):
+        assert ((mi == 0).flatten(1).sum(1) == ki).all(), (ki, (mi == 0).flatten(1).sum(1))
+        assert ((ms == 0).flatten(1).sum(1) == ks).all(), (ks, (ms == 0).flatten(1).sum(1))
+
+
+def test_eager_steps_between_replays_keep_the_adam_count(golden_sd):
+    """graph, eager, graph == three eager steps, bit for bit (the device-side Adam step counter is re-seeded when the
+    optimizers were stepped outside the graph object)."""
+    clean, label, noisy = (dev(t) for t in O.synthetic_batch(2, 64, 64, seed=6))
+    ref = _solver(golden_sd)
+    for _ in range(4):
+        ref.cooperative_step(clean, label, noisy, CH_MSE, SP_CE)
+    s = _solver(golden_sd)
+    g = CooperativeStepGraph(s, CH_MSE, SP_CE)
+    g(clean, label, noisy)
+    s.cooperative_step(clean, label, noisy, CH_MSE, SP_CE)
+    g(clean, label, noisy)
+    g(clean, label, noisy)
+    assert int(g.state[2]) == 4
+    _same(_state(ref), _state(s))

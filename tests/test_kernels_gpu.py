@@ -617,146 +617,3 @@ def test_surface_scores_from_device_volumes():
         for k, ((pr, gt), row) in enumerate(zip(r["volumes"], r["rows"])):
             got = ms.update("s%d" % k, pr.cuda(), gt.cuda(), voxel_spacing=r["spacing"])
             assert np.allclose(got[1:], row[1:], rtol=0, atol=1e-12)
-
-
-# ------------------------------------------------------------------------------------------------ fused finalizes (round 2)
-@pytest.mark.parametrize("n,cin,cout,h,w,groups", [(2, 16, 16, 32, 32, 1), (4, 16, 32, 24, 40, 2), (16, 16, 16, 128, 128, 1), (2, 64, 128, 16, 16, 1),
-                                                  (6, 32, 64, 9, 13, 2), (16, 128, 128, 16, 16, 2)])
-def test_conv_fused_bn_finalize_matches_separate_launch(n, cin, cout, h, w, groups):
-    """ctl_conv_forward_fin (the last-arriving block finalises the statistics) == ctl_conv_forward + ctl_bn_finalize: coefficients,
-    saved statistics, running statistics and the batch counter; the arrival counters are back at zero; repeated launches agree bitwise."""
-    g = torch.Generator().manual_seed(cout + h)
-    x = dev(torch.randn(n, cin, h, w, generator=g))
-    wt = dev(torch.randn(cout, cin, 3, 3, generator=g) * 0.2)
-    b = dev(torch.randn(cout, generator=g))
-    gamma, beta = dev(torch.rand(cout, generator=g) + 0.5), dev(torch.randn(cout, generator=g) * 0.2)
-    rm0, rv0 = torch.randn(cout, generator=g) * 0.1, torch.rand(cout, generator=g) + 0.5
-    wp = ops.pack_oihw_fwd(wt)
-    d = _ffi.conv_desc(n=n, hin=h, win=w, cin=cin, hout=h, wout=w, cout=cout, ks=3, epi_flags=_ffi.EPI_BIAS | _ffi.EPI_STATS)
-    d["groups"] = groups
-    count = n * h * w // groups
-    y_ref, stats = ops.conv_forward(d, x, wp, bias=b, want_stats=True)
-    rm_a, rv_a, nbt_a = dev(rm0), dev(rv0), torch.zeros(1, dtype=torch.int64, device=DEV)
-    ref = ops.bn_finalize(stats, cout, count, gamma, beta, running_mean=rm_a, running_var=rv_a, nbt=nbt_a, groups=groups)
-    table = torch.zeros(_ffi.FIN_REC_BYTES, dtype=torch.uint8, device=DEV)
-    outs = []
-    for rep in range(2):
-        rm_b, rv_b, nbt_b = dev(rm0), dev(rv0), torch.zeros(1, dtype=torch.int64, device=DEV)
-        sc, sh, mu, isd = (torch.empty(groups * cout, device=DEV) for _ in range(4))
-        fin = _ffi.BnFin(gamma.data_ptr(), beta.data_ptr(), rm_b.data_ptr(), rv_b.data_ptr(), nbt_b.data_ptr(), sc.data_ptr(), sh.data_ptr(),
-                         mu.data_ptr(), isd.data_ptr(), count, 1e-5, 0.1, 1, 0)
-        import ctypes
-        check(lib.ctl_bn_fin_table_write(table.data_ptr(), ctypes.byref(fin), 1, ops.stream_ptr()))
-        y = torch.empty_like(y_ref)
-        st = torch.empty_like(stats)
-        check(lib.ctl_conv_forward_fin(_ffi.desc_ptr(d), x.data_ptr(), wp.data_ptr(), b.data_ptr(), None, None, None, None, None, y.data_ptr(),
-                                       st.data_ptr(), table.data_ptr(), 0, ops.stream_ptr()))
-        torch.cuda.synchronize()
-        assert torch.equal(y, y_ref)
-        for got, want, what in zip((sc, sh, mu, isd, rm_b, rv_b), (*ref, rm_a, rv_a), ("scale", "shift", "mean", "invstd", "running_mean", "running_var")):
-            close(got, want, rel=2e-6, what=f"fused finalize {what}")
-        assert int(nbt_b.item()) == int(nbt_a.item()) == groups
-        assert int(table[128:].view(torch.int32).abs().sum().item()) == 0, "arrival counters must return to zero"
-        outs.append((sc.clone(), sh.clone(), rm_b.clone(), rv_b.clone()))
-    for a_, b_ in zip(*outs):
-        assert torch.equal(a_, b_), "the fused finalize must be deterministic"
-
-
-@pytest.mark.parametrize("mode", [0, 1])
-@pytest.mark.parametrize("n,c,h,w,groups", [(2, 16, 32, 32, 1), (16, 16, 128, 128, 1), (4, 128, 8, 8, 2), (6, 32, 20, 12, 2)])
-def test_bwd_reduce_fused_finalize_matches_separate_launch(mode, n, c, h, w, groups):
-    g = torch.Generator().manual_seed(c + h + mode)
-    dy, u, act = (dev(torch.randn(n, c, h, w, generator=g)) for _ in range(3))
-    sc, sh = dev(torch.rand(groups * c, generator=g) + 0.5), dev(torch.randn(groups * c, generator=g) * 0.2)
-    gamma = dev(torch.rand(c, generator=g) + 0.5)
-    mean, invstd = dev(torch.randn(groups * c, generator=g) * 0.3), dev(torch.rand(groups * c, generator=g) + 0.5)
-    M = n * h * w
-    rows = lib.ctl_bwd_reduce_rows(mode, M // groups, c)
-    part = torch.empty(groups * rows * 2 * c, device=DEV)
-    args = (mode, dy.data_ptr(), act.data_ptr() if mode == 0 else None, u.data_ptr(), sc.data_ptr() if mode == 1 else None,
-            sh.data_ptr() if mode == 1 else None, 0.2, M, c)
-    check(lib.ctl_bwd_reduce(*args, part.data_ptr(), groups, ops.stream_ptr()))
-    coef_a, dg_a, db_a = torch.empty(groups * 3 * c, device=DEV), torch.full((c,), 0.25, device=DEV), torch.full((c,), -0.5, device=DEV)
-    check(lib.ctl_bn_bwd_finalize(part.data_ptr(), c, M // groups, gamma.data_ptr(), mean.data_ptr(), invstd.data_ptr(), coef_a.data_ptr(),
-                                  dg_a.data_ptr(), db_a.data_ptr(), 1, groups, 0, ops.stream_ptr()))
-    counter = torch.zeros(9 * 128, dtype=torch.uint8, device=DEV)
-    coef_b, dg_b, db_b = torch.empty(groups * 3 * c, device=DEV), torch.full((c,), 0.25, device=DEV), torch.full((c,), -0.5, device=DEV)
-    import ctypes
-    fin = _ffi.BnbFin(gamma.data_ptr(), mean.data_ptr(), invstd.data_ptr(), coef_b.data_ptr(), dg_b.data_ptr(), db_b.data_ptr(), counter.data_ptr(),
-                      M // groups, 1, 0)
-    part2 = torch.empty_like(part)
-    check(lib.ctl_bwd_reduce_fin(*args, part2.data_ptr(), groups, 0, ctypes.byref(fin), None, ops.stream_ptr()))
-    torch.cuda.synchronize()
-    assert torch.equal(part, part2)
-    close(coef_b, coef_a, rel=2e-6, what="fused bwd finalize coef")
-    close(dg_b, dg_a, rel=2e-6, what="fused bwd finalize dgamma")
-    close(db_b, db_a, rel=2e-6, what="fused bwd finalize dbeta")
-    assert int(counter.view(torch.int32).abs().sum().item()) == 0
-
-
-@pytest.mark.parametrize("bf16", [False, True])
-@pytest.mark.parametrize("role", [1, 2])
-@pytest.mark.parametrize("n,c1,c2,h,w,groups", [(2, 16, 16, 32, 32, 1), (16, 16, 16, 128, 128, 1), (4, 32, 64, 24, 40, 2), (2, 128, 128, 16, 16, 1), (6, 64, 32, 9, 13, 2)])
-def test_conv_consumer_side_bn_finalize(n, c1, c2, h, w, groups, role, bf16):
-    """ctl_conv_forward_fin with a consumer-side record (ctl_bn_consume): the launch that first USES a BatchNorm's coefficients -- as its
-    prologue (role 1) or as the affine of its residual operand (role 2) -- computes them in its first blocks from the producer's
-    statistics rows while the other blocks wait.  Against ctl_bn_finalize + the plain launch: coefficients, saved and running statistics
-    2e-6 relative (different fixed summation order), outputs 2e-5 of max (+ one bf16 rounding for bf16 storage); two launches agree bitwise."""
-    import ctypes
-    if not lib.ctl_consumer_finalize_built():
-        pytest.skip("the default build leaves the consumer-side path out of the kernels (-DCTL_CONSUMER_FINALIZE=1 variant only)")
-    g = torch.Generator().manual_seed(c1 + c2 + h + role)
-    tdt = torch.bfloat16 if bf16 else torch.float32
-    BF = (_ffi.DT_BF16 | _ffi.DT_X16 | _ffi.DT_Y16) if bf16 else 0
-    pack = ops.pack_oihw_fwd_bf16 if bf16 else ops.pack_oihw_fwd
-    x = dev(torch.randn(n, c1, h, w, generator=g)).to(tdt)
-    w1 = dev(torch.randn(c1, c1, 3, 3, generator=g) * 0.2)
-    b1 = dev(torch.randn(c1, generator=g))
-    gamma, beta = dev(torch.rand(c1, generator=g) + 0.5), dev(torch.randn(c1, generator=g) * 0.2)
-    rm0, rv0 = torch.randn(c1, generator=g) * 0.1, torch.rand(c1, generator=g) + 0.5
-    d1 = _ffi.conv_desc(n=n, hin=h, win=w, cin=c1, hout=h, wout=w, cout=c1, ks=3, epi_flags=_ffi.EPI_BIAS | _ffi.EPI_STATS, dt=BF)
-    d1["groups"] = groups
-    count = n * h * w // groups
-    u, stats = ops.conv_forward(d1, x, pack(w1), bias=b1, want_stats=True)           # the producer: u and its statistics rows
-    rows = lib.ctl_conv_stats_blocks(_ffi.desc_ptr(d1))
-    rm_a, rv_a, nbt_a = dev(rm0), dev(rv0), torch.zeros(1, dtype=torch.int64, device=DEV)
-    ref = ops.bn_finalize(stats, c1, count, gamma, beta, running_mean=rm_a, running_var=rv_a, nbt=nbt_a, groups=groups)
-    if role == 1:       # consumer: 3x3 conv c1 -> c2 with the BatchNorm + LeakyReLU prologue
-        w2 = dev(torch.randn(c2, c1, 3, 3, generator=g) * 0.2)
-        b2 = dev(torch.randn(c2, generator=g))
-        d2 = _ffi.conv_desc(n=n, hin=h, win=w, cin=c1, hout=h, wout=w, cout=c2, ks=3, epi_flags=_ffi.EPI_BIAS, pro_affine=1, pro_slope=0.2, dt=BF)
-        d2["groups"] = groups
-        xin, wp2, res = u, pack(w2), None
-        y_ref, _ = ops.conv_forward(d2, xin, wp2, bias=b2, pro_scale=ref[0], pro_shift=ref[1])
-    else:               # consumer: 1x1 conv c2 -> c1 whose residual operand is BN(u): out = LReLU(conv1x1(x2) + scale * u + shift)
-        x2 = dev(torch.randn(n, c2, h, w, generator=g)).to(tdt)
-        w2 = dev(torch.randn(c1, c2, 1, 1, generator=g) * 0.2)
-        b2 = dev(torch.randn(c1, generator=g))
-        d2 = _ffi.conv_desc(n=n, hin=h, win=w, cin=c2, hout=h, wout=w, cout=c1, ks=1, epi_flags=_ffi.EPI_BIAS | _ffi.EPI_RES, epi_act=_ffi.ACT_LEAKY,
-                            epi_slope=0.2, dt=BF | (_ffi.DT_RES16 if bf16 else 0))
-        d2["groups"] = groups
-        xin, wp2, res = x2, pack(w2), u
-        y_ref, _ = ops.conv_forward(d2, xin, wp2, bias=b2, res=res, res_scale=ref[0], res_shift=ref[1])
-    table = torch.zeros(_ffi.FIN_REC_BYTES, dtype=torch.uint8, device=DEV)
-    outs = []
-    for rep in range(2):
-        rm_b, rv_b, nbt_b = dev(rm0), dev(rv0), torch.zeros(1, dtype=torch.int64, device=DEV)
-        sc, sh, mu, isd = (torch.full((groups * c1,), float("nan"), device=DEV) for _ in range(4))
-        fin = _ffi.BnFin(gamma.data_ptr(), beta.data_ptr(), rm_b.data_ptr(), rv_b.data_ptr(), nbt_b.data_ptr(), sc.data_ptr(), sh.data_ptr(),
-                         mu.data_ptr(), isd.data_ptr(), count, 1e-5, 0.1, 1, role, stats.data_ptr(), rows, 0)
-        check(lib.ctl_bn_fin_table_write(table.data_ptr(), ctypes.byref(fin), 1, ops.stream_ptr()))
-        y = torch.empty_like(y_ref)
-        check(lib.ctl_conv_forward_fin(_ffi.desc_ptr(d2), xin.data_ptr(), wp2.data_ptr(), b2.data_ptr(), sc.data_ptr() if role == 1 else None,
-                                       sh.data_ptr() if role == 1 else None, res.data_ptr() if role == 2 else None,
-                                       sc.data_ptr() if role == 2 else None, sh.data_ptr() if role == 2 else None, y.data_ptr(), None,
-                                       table.data_ptr(), role, ops.stream_ptr()))
-        torch.cuda.synchronize()
-        for got, want, what in zip((sc, sh, mu, isd, rm_b, rv_b), (*ref, rm_a, rv_a), ("scale", "shift", "mean", "invstd", "running_mean", "running_var")):
-            close(got, want, rel=2e-6, what=f"consumer-side finalize {what}")
-        assert int(nbt_b.item()) == int(nbt_a.item()) == groups
-        ymax = float(y_ref.float().abs().max())
-        tol = 2e-5 * ymax + (2.0 ** -7 * ymax if bf16 else 0.0)
-        assert float((y.float() - y_ref.float()).abs().max()) <= tol, (role, bf16, float((y.float() - y_ref.float()).abs().max()), tol)
-        outs.append((sc.clone(), sh.clone(), rm_b.clone(), y.clone()))
-    for a_, b_ in zip(*outs):
-        assert torch.equal(a_, b_), "the consumer-side finalize must be deterministic"

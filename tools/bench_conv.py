@@ -13,7 +13,10 @@ CFGS = ["4,32,1", "2,16,1", "1,16,1", "4,32,2", "2,16,2", "1,16,2", "4,32,4", "2
 
 def child(kind):
     import torch
-    from cooperative_training_and_latent_space_data_augmentation_amd import _ffi, ops
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _variant import use_variant
+    _ffi = use_variant()                # CTL_TOOL_LIB=tuning: the per-config sweep below needs the CTL_FORCE_CFG hook of a -DCTL_TUNING build
+    from cooperative_training_and_latent_space_data_augmentation_amd import ops
     from cooperative_training_and_latent_space_data_augmentation_amd._ffi import lib, check
     res = {}
     for name, cin, cout, h, ks, stride, mode in LAYERS:

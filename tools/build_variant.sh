@@ -1,5 +1,8 @@
 #!/bin/bash
-# usage: tools/build_variant.sh NAME "-DCTL_LB_MID=2 ..." [file.hip ...]   -> csrc/variants/libctl_NAME.so (A/B builds; load with CTL_HIP_LIB)
+# usage: tools/build_variant.sh NAME "-DCTL_LB_MID=2 ..." [file.hip ...]   -> csrc/variants/libctl_NAME.so
+#   A/B builds: bench.py --lib <path>, tools with CTL_TOOL_LIB=NAME (tools/_variant.py).  `tools/build_variant.sh tuning -DCTL_TUNING` gives the
+#   library whose tuning hooks (CTL_FORCE_CFG, CTL_PERSIST, CTL_WGRAD_SLOTS, CTL_MASK_SPLIT, CTL_PROF_TIMELINE, ...) read the environment;
+#   the shipped build has none (tests/test_cabi.py).
 # With a file list only those sources are recompiled with the flags; the other objects come from the default build (csrc/build/).
 set -e
 cd "$(dirname "$0")/../cooperative_training_and_latent_space_data_augmentation_amd/csrc"

@@ -1,4 +1,4 @@
-"""Race check for the two-stream step: N training steps with and without CTL_TWO_STREAMS from the same seed must give the
+"""Race check for the two-stream step: N training steps with and without `solver.two_streams` from the same seed must give the
 same losses and the same weights (bitwise: every kernel is deterministic), several times in a row."""
 import os, sys, subprocess, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -8,6 +8,7 @@ def child():
     import bench
     torch.manual_seed(0)
     s = AdvancedTripletReconSegmentationModel(use_gpu=True)
+    s.two_streams = os.environ.get("CHECK_TWO_STREAMS", "1") != "0"
     g = torch.Generator(device="cuda").manual_seed(1)
     clean = torch.rand(16, 1, 256, 256, device="cuda", generator=g); noisy = (clean + 0.1 * torch.randn(clean.shape, device="cuda", generator=g)).clamp(0, 1)
     label = torch.randint(0, 4, (16, 256, 256), device="cuda", generator=g)
@@ -30,7 +31,7 @@ if __name__ == "__main__":
     if len(sys.argv) > 1: child(); sys.exit(0)
     res = []
     for mode in ("0", "1", "1", "1", "1", "1", "0"):
-        env = dict(os.environ, CTL_TWO_STREAMS=mode)
+        env = dict(os.environ, CHECK_TWO_STREAMS=mode)
         out = subprocess.run([sys.executable, __file__, "child"], env=env, capture_output=True, text=True)
         line = [l for l in out.stdout.splitlines() if l.startswith("RESULT ")]
         if not line: print(out.stderr[-2000:]); sys.exit(1)

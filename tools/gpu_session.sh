@@ -1,0 +1,29 @@
+#!/bin/bash
+# One GPU session (run via gpurun): tools/gpu_session.sh TAG [tests|notests] [pmc]
+#   -m gpu suite, the driver's bench command (headline + sub-records), rocprofv3 kernel stats of the fp32 and bf16 steps, optionally the
+#   PMC traffic passes.  Everything lands in gpurun_out/$TAG/ ; copy what is to be judged into profiles/.
+tag=${1:-s}; tests=${2:-tests}; pmc=${3:-}
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+out=gpurun_out/$tag; mkdir -p $out
+if [ "$tests" = "tests" ]; then
+  timeout 3000 python3 -m pytest tests -m gpu -x -q > $out/pytest_gpu.log 2>&1; echo "pytest exit $?" | tee -a $out/pytest_gpu.log
+  tail -5 $out/pytest_gpu.log
+fi
+timeout 1200 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench.json 2> $out/bench.err; echo "bench exit $?"
+python3 - $out/bench.json <<'PY'
+import json, sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print("fp32: %.1f slices/s %.3f ms mode %s launches %s roofline %.3f" % (d["value"], d["ms_per_step"], d["mode"], d["launches_per_step"]["library"], d["roofline"]["frac"]))
+for k, v in d.get("roofline_families", {}).items(): print("   family %-20s %6.2f ms/step %6.1f launches  frac %.3f (%s)" % (k, v["ms_per_step"], v["launches_per_step"], v["frac"], v["bound"]))
+c3 = d.get("config3_bf16", {}); c5 = d.get("config5_inference", {})
+print("config3_bf16:", {k: c3.get(k) for k in ("value", "ms_per_step", "mode", "error")}, "roofline", c3.get("roofline", {}).get("frac"))
+print("config5:", {k: c5.get(k) for k in ("value", "ms_per_step", "error")}, {k: round(v["value"]) for k, v in c5.get("forms", {}).items()})
+print("cpu:", d.get("cpu_baseline", {}).get("value"))
+PY
+timeout 600 bash tools/prof_bench.sh ${tag}_fp32 > $out/prof_fp32.txt 2>&1; cp gpurun_out/prof_${tag}_fp32/stats.csv $out/kernel_stats_fp32.csv
+timeout 600 bash tools/prof_bench.sh ${tag}_bf16 --dtype bf16 > $out/prof_bf16.txt 2>&1; cp gpurun_out/prof_${tag}_bf16/stats.csv $out/kernel_stats_bf16.csv
+head -24 $out/prof_fp32.txt
+if [ "$pmc" = "pmc" ]; then
+  timeout 900 bash tools/pmc_bench.sh ${tag}_fp32 > $out/pmc_fp32.txt 2>&1; cp gpurun_out/pmc_bench_${tag}_fp32/traffic_by_kernel.json $out/pmc_traffic_by_kernel_fp32.json
+  tail -16 $out/pmc_fp32.txt
+fi

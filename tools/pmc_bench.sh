@@ -4,8 +4,8 @@
 tag=${1:-fp32}; shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/pmc_bench_$tag; rm -rf $out; mkdir -p $out
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --mode eager "$@" > $out/fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --mode eager "$@" > $out/write.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-sub-records --mode eager "$@" > $out/fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-sub-records --mode eager "$@" > $out/write.log 2>&1
 python3 - <<PY
 import csv, glob, collections, json
 def load(d, name):

@@ -3,7 +3,7 @@
 tag=${1:-x}; shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/prof_$tag; rm -rf $out; mkdir -p $out
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/raw -- python3 bench.py --steps 7 --warmup 3 --no-cpu-baseline --mode eager "$@" > $out/bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/raw -- python3 bench.py --steps 7 --warmup 3 --no-cpu-baseline --no-sub-records --mode eager "$@" > $out/bench.log 2>&1
 cp $out/raw/*/*kernel_stats.csv $out/stats.csv 2>/dev/null
 rm -rf $out/raw
 tail -1 $out/bench.log | cut -c1-200

@@ -2,13 +2,14 @@
 serialises dispatches and cannot show this).  Prints per 1-ms bucket how busy each stream is and the phase boundaries."""
 import os, sys, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["CTL_PROF_TIMELINE"] = "/tmp/ctl_timeline.txt"
+os.environ["CTL_PROF_TIMELINE"] = "/tmp/ctl_timeline.txt"      # read by a -DCTL_TUNING build only: CTL_TOOL_LIB=tuning python tools/timeline.py
 import torch
-from cooperative_training_and_latent_space_data_augmentation_amd import _ffi
+from _variant import use_variant
+_ffi = use_variant(os.environ.get("CTL_TOOL_LIB", "tuning"))
 from cooperative_training_and_latent_space_data_augmentation_amd.solver import AdvancedTripletReconSegmentationModel
 import bench
 torch.manual_seed(0)
-s = AdvancedTripletReconSegmentationModel(use_gpu=True)          # CTL_DTYPE=bf16 for the bf16 engine; TIMELINE_MASKS=targeted for config 3
+s = AdvancedTripletReconSegmentationModel(use_gpu=True, compute_dtype=os.environ.get("TIMELINE_DTYPE", "fp32"))    # TIMELINE_MASKS=targeted for config 3
 CFG = (bench.TGT_IMG, bench.TGT_SEG) if os.environ.get("TIMELINE_MASKS") == "targeted" else (bench.DROP_IMG, bench.DROP_SEG)
 clean = torch.rand(16, 1, 256, 256, device="cuda"); noisy = (clean + 0.1 * torch.randn_like(clean)).clamp(0, 1)
 label = torch.randint(0, 4, (16, 256, 256), device="cuda")
