@@ -225,9 +225,20 @@ class bf16_rounding_points:
       * Dropout2d behind a block (encoder_dropout / decoder_dropout) reads the block's output as stored (bf16), scales in fp32 and stores
         bf16 again (the second rounding happens at the next convolution's operand rounding);
       * network inputs / outputs stay fp32.
-    Forward emulation (inference, losses); gradients flow through the roundings as identity."""
+    Forward emulation (inference, losses) by default.  `backward=True`: every network pass -- forward AND backward -- runs through the
+    explicit plan emulation of oracle/bf16_plan.py instead (the same forward rounding points, plus the rounding points of the engine's
+    backward plans: stored gradient tensors, dgrad / wgrad operands, BatchNorm-backward sums); that is the checker for bf16 gradients."""
+
+    def __init__(self, backward: bool = False):
+        self.backward = backward
 
     def __enter__(self):
+        if self.backward:
+            from . import bf16_plan
+            self._saved_nets = (Encoder.forward, DualEncoder.forward, Decoder.forward)
+            fwd = lambda m, x: bf16_plan.net_apply(m, x)
+            Encoder.forward = DualEncoder.forward = Decoder.forward = fwd
+            return self
         self._saved = (nn.Conv2d.forward, nn.ConvTranspose2d.forward, nn.BatchNorm2d.forward, UpBlock.forward)
         conv_fwd, convt_fwd, bn_fwd, _ = self._saved
 
@@ -283,6 +294,9 @@ class bf16_rounding_points:
         return self
 
     def __exit__(self, *exc):
+        if self.backward:
+            Encoder.forward, DualEncoder.forward, Decoder.forward = self._saved_nets
+            return False
         nn.Conv2d.forward, nn.ConvTranspose2d.forward, nn.BatchNorm2d.forward, UpBlock.forward = self._saved
         globals()["_block_dropout"] = self._saved_dropout
         return False
@@ -465,6 +479,7 @@ class OracleSolver:
         self.optimizers = {k: torch.optim.Adam(m.parameters(), lr=learning_rate) for k, m in self.model.items()}
         self.z_i = self.z_s = None
         self.last_masks = {}
+        self.last_scores = []
         self.dtype = torch.float32
         self.train()
 
@@ -541,9 +556,10 @@ class OracleSolver:
             out, mask = dropout2d_with_keep(z, threshold, ov.get("keep"))
         else:
             fn = mask_latent_code_spatial_wise if scheme == "spatial" else mask_latent_code_channel_wise
-            out, mask = fn(z, decoder, label_y, num_classes=self.num_classes, percentile=threshold,
-                           random=random_threshold, loss_type=loss_type, if_detach=True, if_soft=if_soft,
-                           k=ov.get("k"), soft_noise=ov.get("soft_noise"))
+            out, mask, aux = fn(z, decoder, label_y, num_classes=self.num_classes, percentile=threshold,
+                                random=random_threshold, loss_type=loss_type, if_detach=True, if_soft=if_soft,
+                                k=ov.get("k"), soft_noise=ov.get("soft_noise"), return_aux=True)
+            self.last_scores.append({"scheme": scheme, "score": aux["score"].detach().clone(), "k": aux["k"]})      # (tests: near-tie margins of the ranking)
         if ov.get("mask") is not None:          # a selection made elsewhere (the fp64 yardstick re-uses the fp32 run's masks: a near-tie
             mask = ov["mask"].to(z.dtype)       # in the ranking must not make the two runs train on different hard examples)
             out = z * mask
