@@ -982,17 +982,22 @@ class MyEncoder(CtlNet):
 
     def _emit_encoder_bwd(self, pb: PlanBuilder, rec, dz: T, need_dx: bool, need_w: bool, affine: bool):
         px = self._px
+        dbg = {"dz": dz}                 # where the intermediate gradients live (tests read them through CtlNet._dbg_last)
         d = self._emit_conv_bn_pair_bwd(pb, px + "final_conv.0", px + "final_conv.1", rec["x4"], None, rec["uf"], rec["cof"], 0.0,
                                         dz, None, need_w, affine)
-        for brec in reversed(rec["blocks"]):
+        dbg["d_down5"] = d               # gradient w.r.t. the output of down4
+        for i, brec in reversed(list(enumerate(rec["blocks"]))):
             d = self._emit_block_bwd(pb, brec, d, None, need_w, affine)
+            dbg[f"d_down{i + 1}"] = d    # gradient w.r.t. the input of block down{i+1}
         # d = gradient w.r.t. x1 = LReLU(BN(v0))
         pro0 = (rec["co0"]["scale"], rec["co0"]["shift"], SLOPE)
         d = self._emit_conv_bn_pair_bwd(pb, px + "inc.3", px + "inc.4", rec["u0"], pro0, rec["v0"], rec["co1"], SLOPE, d, None,
                                         need_w, affine)
+        dbg["d_inc3"] = d
         dx = T((S_DX, 0), *rec["x"][1:]) if need_dx else None
         self._emit_conv_bn_pair_bwd(pb, px + "inc.0", px + "inc.1", rec["x"], None, rec["u0"], rec["co0"], SLOPE, d, dx,
                                     need_w, affine, need_dx=need_dx)
+        return dbg
 
     def _zdims(self, n, h, w):
         for _ in range(4):
@@ -1010,8 +1015,8 @@ class MyEncoder(CtlNet):
         if need_w:
             pb.zero((S_GRAD, 0), 4 * self._pcount)
         z = fwd.rec["z"]
-        self._emit_encoder_bwd(pb, fwd.rec, T((S_DOUT0, 0), *z[1:]), need_dx, need_w, affine)
-        return pb.finish()
+        dbg = self._emit_encoder_bwd(pb, fwd.rec, T((S_DOUT0, 0), *z[1:]), need_dx, need_w, affine)
+        return pb.finish(dbg)
 
     def forward(self, x):
         from .autograd import net_apply
@@ -1052,6 +1057,7 @@ class Dual_Branch_Encoder(MyEncoder):
             pb.zero((S_GRAD, 0), 4 * self._pcount)
         z_i = rec["z"]
         dzi_in = T((S_DOUT0, 0), *z_i[1:]) if mask[0] else None
+        extra = {}
         if mask[1]:
             dzs = T((S_DOUT1, 0), *z_i[1:])
             pro = (rec["cod0"]["scale"], rec["cod0"]["shift"], SLOPE)
@@ -1067,12 +1073,14 @@ class Dual_Branch_Encoder(MyEncoder):
             if dzi_in is not None:      # dz_i = (gradient arriving at z_i directly) + dgrad of code_decoupler.0
                 pb.copy(dzi_in.ref, dzi.ref, 4 * z_i.n * z_i.h * z_i.w * z_i.c)
             pb.conv(du, self._wp_ref(ci.wp_dgrad), ci.cin, 3, out=dzi, accum=dzi_in is not None)
+            extra = {"d_cd3": d, "du_cd0": du}
         else:
             dzi = dzi_in
         if dzi is None:
             raise _ffi.CtlError("Dual_Branch_Encoder backward called without any output gradient")
-        self._emit_encoder_bwd(pb, rec, dzi, need_dx, need_w, affine)
-        return pb.finish()
+        dbg = self._emit_encoder_bwd(pb, rec, dzi, need_dx, need_w, affine)
+        dbg.update(extra)
+        return pb.finish(dbg)
 
     def forward(self, x):
         from .autograd import net_apply

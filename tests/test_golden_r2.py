@@ -53,8 +53,9 @@ def projections(g, key):
 # projections estimates the L2 error of the whole tensor (within ~2x) -- and unlike sum / L2 / max it is NOT invariant under permutations
 # inside the tensor: a transposed tap, a swapped channel pair or a mis-strided weight block moves it by O(||g||).  Judged like the
 # element-wise check of the 16 picked tensors, against the fp64 evaluation: HIP error <= max(PROJ_FACTOR x the reference's own fp32 error,
-# PROJ_FLOOR x ||g64||).  Measured (tools/debug/proj_calibration.py, both records): reference 0.1-1.2 %, HIP 0.1-1.9 % of ||g64||.
-PROJ_FACTOR, PROJ_FLOOR = 5.0, 3e-2
+# PROJ_FLOOR x ||g64||).  Measured on both records: worst tensor 2.5 % of ||g64|| for the HIP step (the rms of four projections scatters
+# around the tensor's 0.3-1.6 % L2 error by up to ~1.6x), update-sign agreement 0.9996.
+PROJ_FACTOR, PROJ_FLOOR = 5.0, 4e-2
 
 
 def check_grad_projections(named_grads, rec3, what, factor=PROJ_FACTOR, floor=PROJ_FLOOR, against="fp64"):
