@@ -9,13 +9,13 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libctl_hip.so")
-ABI_VERSION = 3                      # CTL_ABI_VERSION of include/ctl_hip.h this binding was written against
+ABI_VERSION = 4                      # CTL_ABI_VERSION of include/ctl_hip.h this binding was written against
 RED_BLOCKS = 512                     # CTL_RED_BLOCKS of ctl_hip.h; checked against the library's compiled value (ctl_red_blocks) at load
 
 # enums of ctl_hip.h
 IN_PLAIN, IN_UP2, IN_ZINS2, IN_C4 = 0, 1, 2, 3
 ACT_NONE, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2
-EPI_BIAS, EPI_ACCUM, EPI_RES, EPI_STATS, EPI_BNBWD = 1, 2, 4, 8, 16
+EPI_BIAS, EPI_ACCUM, EPI_RES, EPI_STATS, EPI_BNBWD, EPI_TAILBWD = 1, 2, 4, 8, 16, 32
 (OP_CONV, OP_WGRAD, OP_WGRAD_REDUCE, OP_PACK, OP_BN_FINALIZE, OP_BN_EVAL, OP_BN_ACT, OP_BWD_REDUCE, OP_BN_BWD_FINALIZE,
  OP_BWD_APPLY, OP_CHAN_SUM_FINALIZE, OP_SUMPOOL2, OP_SIGMOID_BWD, OP_ZERO, OP_COPY, OP_PACK_BATCH, OP_WGRAD_REDUCE_BATCH, OP_DROPOUT2D) = range(1, 19)
 OP_MAX_T = 12
@@ -62,7 +62,7 @@ class _Lib:
             "ctl_conv_stats_floats": [p], "ctl_conv_stats_blocks": [p],
             "ctl_wgrad_splits": [p], "ctl_wgrad_partial_floats": [p], "ctl_wgrad_bias_partial_floats": [p],
             "ctl_pack_weights": [p, p, i32, i32, i32, i64, i64, i64, i64, i32, p],
-            "ctl_conv_forward": [p] * 12,
+            "ctl_conv_forward": [p] * 12, "ctl_conv_forward_ex": [p] * 13,
             "ctl_conv_wgrad": [p] * 8,
             "ctl_wgrad_reduce": [p, p, p, p, i64, i64, i64, i64, p, i32, p],
             "ctl_confusion_hist": [p, p, i64, i32, p, p],
@@ -131,7 +131,7 @@ lib = _Lib()
 
 # every symbol include/ctl_hip.h declares (checked by tests/test_cabi.py without a GPU)
 EXPORTED = ["ctl_version", "ctl_last_error", "ctl_conv_wpack_floats", "ctl_conv_stats_floats", "ctl_conv_stats_blocks",
-            "ctl_pack_weights", "ctl_conv_forward", "ctl_wgrad_splits", "ctl_wgrad_partial_floats",
+            "ctl_pack_weights", "ctl_conv_forward", "ctl_conv_forward_ex", "ctl_wgrad_splits", "ctl_wgrad_partial_floats",
             "ctl_wgrad_bias_partial_floats", "ctl_conv_wgrad", "ctl_wgrad_reduce", "ctl_bn_finalize", "ctl_bn_eval_coeffs",
             "ctl_bn_act", "ctl_bwd_reduce", "ctl_bn_bwd_finalize", "ctl_bwd_apply", "ctl_chan_sum_finalize", "ctl_sumpool2",
             "ctl_sigmoid_bwd", "ctl_softmax_t_fwd", "ctl_softmax_t_bwd", "ctl_onehot", "ctl_ce2d_fwd", "ctl_ce2d_bwd",
@@ -152,7 +152,7 @@ def prof_start(kernel_filter: str = "", every: int = 1) -> None:
 
 def prof_stop() -> dict:
     """{kernel id: dict(launches, ms, flops, bytes)} for the launches bracketed since prof_start."""
-    buf = C.create_string_buffer(1 << 16)
+    buf = C.create_string_buffer(1 << 18)
     check(lib.ctl_prof_stop(buf, len(buf)), "ctl_prof_stop")
     out = {}
     for line in buf.value.decode().splitlines():

@@ -200,7 +200,8 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : ((MT * NT >= 4
                                                           const float* __restrict__ res_scale,
                                                           const float* __restrict__ res_shift, float* __restrict__ y,
                                                           float* __restrict__ stats_partial, int tiles_h, int tiles_w,
-                                                          int G_chunks, int64_t wpack_sub_stride, int ntiles) {
+                                                          int G_chunks, int64_t wpack_sub_stride, int ntiles,
+                                                          const float* __restrict__ res2) {
     using G = Geom<KS, S, MT, TW>;
     constexpr int TAPS = KS * KS;
     // C4: input with <= 4 channels.  The four lane groups of an MFMA (its k index) carry four different TAPS (channels 0-3 each)
@@ -245,6 +246,11 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : ((MT * NT >= 4
     const int64_t ybytes = (int64_t)d.n * d.out_h * d.out_w * d.cout * 4;
     const __amdgpu_buffer_rsrc_t ry = ctl_rsrc(y, ybytes);
     const __amdgpu_buffer_rsrc_t rres = ctl_rsrc(EPI ? (const void*)res : (const void*)y, ybytes);
+    // EPI == 2 (CTL_EPI_TAILBWD): this launch produces dL/dOut of a residual block; the epilogue turns it into g = dOut * leaky'(out)
+    // (res = the block's stored output), stores g and takes the BatchNorm-backward sums (sum g, sum g*v; res2 = v, the BatchNorm input of the
+    // tail) -- the stand-alone reduction pass over dOut, out and v (ctl_bwd_reduce mode 0) and the dOut tensor itself disappear
+    constexpr bool TAIL = (EPI == 2);
+    const __amdgpu_buffer_rsrc_t rres2 = ctl_rsrc(TAIL ? (const void*)res2 : (const void*)y, ybytes);
 
     f32x4 ssum[NT], ssq[NT];
 #pragma unroll
@@ -488,7 +494,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : ((MT * NT >= 4
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
                     pv[m] = FULL || ((ho0 + wrow + m / TWT < d.hout) && (wo0 + (m % TWT) * 16 + p < d.wout));
-                f32x4 rv[EPI ? MT : 1][EPI ? NT : 1], ov[EPI ? MT : 1][EPI ? NT : 1];
+                f32x4 rv[EPI ? MT : 1][EPI ? NT : 1], ov[EPI ? MT : 1][EPI ? NT : 1], r2[TAIL ? MT : 1][TAIL ? NT : 1];
                 if (EPI) {
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
@@ -498,7 +504,11 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : ((MT * NT >= 4
                             const int vo = FULL ? (yrel[m] + t * 64) : ((pv[m] && cok) ? (ybase + yrel[m] + t * 64) : CTL_OOB);
                             const int so = FULL ? ybase : 0;
                             rv[m][t] = ov[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                            if (d.cout >= 4) {
+                            if constexpr (TAIL) {           // (cout is a multiple of 16 here, checked on the host)
+                                rv[m][t] = ctl_bload4s(rres, vo, so);
+                                r2[m][t] = ctl_bload4s(rres2, vo, so);
+                                if (flags & CTL_EPI_ACCUM) ov[m][t] = ctl_bload4s(ry, vo, so);
+                            } else if (d.cout >= 4) {
                                 if (flags & (CTL_EPI_RES | CTL_EPI_BNBWD)) rv[m][t] = ctl_bload4s(rres, vo, so);
                                 if (flags & CTL_EPI_ACCUM) ov[m][t] = ctl_bload4s(ry, vo, so);
                             } else {
@@ -514,7 +524,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : ((MT * NT >= 4
                     const bool cok = FULL || co0 < d.cout;
                     const int cc = cok ? co0 : 0;
                     f32x4 rs = {0.f, 0.f, 0.f, 0.f}, rh = {0.f, 0.f, 0.f, 0.f};
-                    if (EPI && (flags & (CTL_EPI_RES | CTL_EPI_BNBWD))) {
+                    if (EPI && !TAIL && (flags & (CTL_EPI_RES | CTL_EPI_BNBWD))) {
                         if (d.cout >= 4) {
                             rs = *reinterpret_cast<const f32x4*>(res_scale + grp * d.cout + cc);
                             rh = *reinterpret_cast<const f32x4*>(res_shift + grp * d.cout + cc);
@@ -523,6 +533,17 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : ((MT * NT >= 4
 #pragma unroll
                     for (int m = 0; m < MT; ++m) {
                         f32x4 v = acc[m][t];
+                        if constexpr (TAIL) {
+                            v += ov[m][t];                                   // (CTL_EPI_ACCUM: the other half of dOut, already in y)
+                            const f32x4 o = rv[m][t];
+                            const float sl = d.epi_slope;
+                            v.x *= o.x > 0.f ? 1.f : sl; v.y *= o.y > 0.f ? 1.f : sl;
+                            v.z *= o.z > 0.f ? 1.f : sl; v.w *= o.w > 0.f ? 1.f : sl;
+                            if (FULL || pv[m]) { ssum[t] += v; ssq[t] += v * r2[m][t]; }
+                            if (FULL) ctl_bstore4(ry, ybase + yrel[m] + t * 64, v);
+                            else ctl_bstore4(ry, (pv[m] && cok) ? (ybase + yrel[m] + t * 64) : CTL_OOB, v);
+                            continue;
+                        }
                         if (EPI && (flags & CTL_EPI_BNBWD)) {
                             // this conv produced dL/da of a = leaky(BN(u)): turn it into g = dL/da * leaky'(BN(u)) and take the two
                             // sums of the BatchNorm backward (sum g, sum g*u) here instead of in a separate pass over da and u
@@ -1093,7 +1114,7 @@ extern "C" int ctl_pack_weights(const float* src, float* dst, int32_t cout, int3
 
 struct conv_call {
     const ctl_conv* d; ctl_conv_cfg c;
-    const float *x, *wpack, *bias, *pro_scale, *pro_shift, *res, *res_scale, *res_shift;
+    const float *x, *wpack, *bias, *pro_scale, *pro_shift, *res, *res_scale, *res_shift, *res2;
     float *y, *stats_partial;
     hipStream_t stream;
     bool query;      // only report the grid (ctl_conv_stats_blocks), launch nothing
@@ -1118,11 +1139,21 @@ static void conv_go(conv_call& a) {
     const dim3 grid((unsigned)a.grid_x, (unsigned)(a.c.cot / NT), (unsigned)d->nsub);
     conv_igemm_kernel<KS, S, MODE, MT, TW, NT, EPI><<<grid, dim3(256), 0, a.stream>>>(
         *d, a.x, a.wpack, a.bias, a.pro_scale, a.pro_shift, a.res, a.res_scale, a.res_shift, a.y, a.stats_partial, a.c.tiles_h,
-        a.c.tiles_w, a.c.g, (int64_t)ctl_conv_wpack_floats(d->cin, d->cout, d->ks), ntiles);
+        a.c.tiles_w, a.c.g, (int64_t)ctl_conv_wpack_floats(d->cin, d->cout, d->ks), ntiles, a.res2);
 }
+// the launches that write dL/dOut of a residual block (and can carry CTL_EPI_TAILBWD): the 1x1 data gradients, the 2x2 stride-2 conv
+// behind a ConvTranspose2d, the four phase problems / the zero-insert form of a stride-2 3x3 data gradient
+template <int KS, int S, int MODE>
+constexpr bool conv_tail_ok() { return (KS == 1 && MODE == CTL_IN_PLAIN) || KS == 2 || (KS == 3 && S == 1 && MODE == CTL_IN_ZINS2); }
 template <int KS, int S, int MODE, int MT, int TW>
 static void conv_go_nt(conv_call& a) {
     const bool epi = (a.d->epi_flags & (CTL_EPI_RES | CTL_EPI_ACCUM | CTL_EPI_BNBWD)) != 0;
+    if constexpr (conv_tail_ok<KS, S, MODE>()) {
+        if (a.d->epi_flags & CTL_EPI_TAILBWD) {
+            if (a.c.nt == 2) conv_go<KS, S, MODE, MT, TW, 2, 2>(a); else conv_go<KS, S, MODE, MT, TW, 1, 2>(a);
+            return;
+        }
+    }
     if (a.c.nt == 2) { if (epi) conv_go<KS, S, MODE, MT, TW, 2, 1>(a); else conv_go<KS, S, MODE, MT, TW, 2, 0>(a); }
     else { if (epi) conv_go<KS, S, MODE, MT, TW, 1, 1>(a); else conv_go<KS, S, MODE, MT, TW, 1, 0>(a); }
 }
@@ -1171,6 +1202,12 @@ extern "C" int ctl_conv_forward(const ctl_conv* d, const float* x, const float* 
                                 const float* pro_scale, const float* pro_shift, const float* res,
                                 const float* res_scale, const float* res_shift, float* y, float* stats_partial,
                                 ctl_stream stream) {
+    return ctl_conv_forward_ex(d, x, wpack, bias, pro_scale, pro_shift, res, res_scale, res_shift, nullptr, y, stats_partial, stream);
+}
+extern "C" int ctl_conv_forward_ex(const ctl_conv* d, const float* x, const float* wpack, const float* bias,
+                                   const float* pro_scale, const float* pro_shift, const float* res,
+                                   const float* res_scale, const float* res_shift, const float* res2, float* y,
+                                   float* stats_partial, ctl_stream stream) {
     CTL_REQUIRE(d && x && wpack && y, "conv_forward: null argument");
     CTL_REQUIRE((d->dt & CTL_DT_BF16) || !(d->dt & (CTL_DT_X16 | CTL_DT_Y16 | CTL_DT_RES16)), "conv_forward: bf16-stored tensors need CTL_DT_BF16");
     conv_call a = {};
@@ -1183,6 +1220,15 @@ extern "C" int ctl_conv_forward(const ctl_conv* d, const float* x, const float* 
     CTL_REQUIRE(!(d->epi_flags & CTL_EPI_BNBWD) || ((d->epi_flags & CTL_EPI_STATS) && res && res_scale && res_shift &&
                                                     !(d->epi_flags & (CTL_EPI_RES | CTL_EPI_ACCUM | CTL_EPI_BIAS)) && d->epi_act == CTL_ACT_NONE),
                 "conv_forward: CTL_EPI_BNBWD needs CTL_EPI_STATS + res (= u) + res_scale/res_shift (BatchNorm coefficients) and nothing else");
+    if (d->epi_flags & CTL_EPI_TAILBWD) {
+        const int k = d->ks, s = d->stride, m = d->in_mode;
+        CTL_REQUIRE((d->epi_flags & CTL_EPI_STATS) && res && res2 && !(d->epi_flags & (CTL_EPI_RES | CTL_EPI_BNBWD | CTL_EPI_BIAS)) &&
+                    d->epi_act == CTL_ACT_NONE && d->cout % 16 == 0 && !(d->dt & CTL_DT_BF16),
+                    "conv_forward: CTL_EPI_TAILBWD needs CTL_EPI_STATS + res (= the block output) + res2 (= the BatchNorm input), cout %% 16 == 0, fp32, nothing else but CTL_EPI_ACCUM");
+        CTL_REQUIRE((k == 1 && m == CTL_IN_PLAIN) || k == 2 || (k == 3 && s == 1 && m == CTL_IN_ZINS2),
+                    "conv_forward: CTL_EPI_TAILBWD is built for the launches that write a block's output gradient (1x1, 2x2, zero-insert 3x3)");
+        CTL_REQUIRE(d->epi_slope >= 0.f && d->epi_slope <= 1.f, "conv_forward: LeakyReLU slope must be in [0, 1]");
+    }
     CTL_REQUIRE(!d->pro_affine || (pro_scale && pro_shift), "conv_forward: prologue without scale/shift");
     CTL_REQUIRE(!d->pro_affine || (d->groups > 1 ? d->groups : 1) * d->cin <= CTL_PRO_MAX, "conv_forward: groups * cin = %d prologue coefficients exceed %d", (d->groups > 1 ? d->groups : 1) * d->cin, CTL_PRO_MAX);
     CTL_REQUIRE(!d->pro_affine || (d->pro_slope >= 0.f && d->pro_slope <= 1.f), "conv_forward: prologue slope must be in [0, 1]");
@@ -1199,7 +1245,7 @@ extern "C" int ctl_conv_forward(const ctl_conv* d, const float* x, const float* 
         return rc;
     }
     a.x = x; a.wpack = wpack; a.bias = bias; a.pro_scale = pro_scale; a.pro_shift = pro_shift; a.res = res;
-    a.res_scale = res_scale; a.res_shift = res_shift; a.y = y; a.stats_partial = stats_partial;
+    a.res_scale = res_scale; a.res_shift = res_shift; a.res2 = res2; a.y = y; a.stats_partial = stats_partial;
     a.stream = (hipStream_t)stream;
     const int ptok = ctl_prof_begin("conv_igemm", d, &a.c, a.c.nt, a.stream);
     rc = conv_dispatch(a);

@@ -2,7 +2,7 @@
 // version / error plumbing.  No allocation, no synchronisation: safe under hipStreamBeginCapture.
 //
 // Tensor slots per op kind (index into op.slot/op.off):
-//   CONV              0 x  1 wpack  2 bias  3 pro_scale  4 pro_shift  5 res  6 res_scale  7 res_shift  8 y  9 stats_partial
+//   CONV              0 x  1 wpack  2 bias  3 pro_scale  4 pro_shift  5 res  6 res_scale  7 res_shift  8 y  9 stats_partial  10 res2 (CTL_EPI_TAILBWD)
 //   WGRAD             0 x  1 pro_scale  2 pro_shift  3 dy  4 w_partial  5 b_partial
 //   WGRAD_REDUCE      0 w_partial  1 b_partial  2 dw  3 dbias            i[24]=accumulate  l[0..3]=s_co,s_ci,s_kh,s_kw
 //   PACK              0 src  1 dst                                       i[0..3]=cout,cin,ks,flip  l[0..3]=strides
@@ -59,8 +59,13 @@ hipEvent_t prof_event() {
 
 int ctl_prof_begin(const char* kind, const ctl_conv* d, const ctl_conv_cfg* c, int nt, hipStream_t stream) {
     if (!g_prof_on) return -1;
-    char id[128];
-    snprintf(id, sizeof(id), "%s<ks%d,s%d,in%d,mt%d,tw%d,nt%d>", kind, d->ks, d->stride, d->in_mode, c->mt, c->tw, nt);
+    char id[160];
+    static const bool shapes = ctl_tune_str("CTL_PROF_SHAPES") != nullptr;      // (-DCTL_TUNING builds: one id per layer shape)
+    if (shapes)
+        snprintf(id, sizeof(id), "%s<ks%d,s%d,in%d,mt%d,tw%d,nt%d>[n%d,h%d,ci%d,co%d,e%d]", kind, d->ks, d->stride, d->in_mode, c->mt, c->tw, nt, d->n, d->hout,
+                 d->cin, d->cout, d->epi_flags);
+    else
+        snprintf(id, sizeof(id), "%s<ks%d,s%d,in%d,mt%d,tw%d,nt%d>", kind, d->ks, d->stride, d->in_mode, c->mt, c->tw, nt);
     if (!g_prof_filter.empty() && std::string(id).find(g_prof_filter) == std::string::npos) return -1;
     if (g_prof_every > 1 && (g_prof_seen++ % g_prof_every) != 0) return -1;
     ProfRec r;
@@ -73,7 +78,8 @@ int ctl_prof_begin(const char* kind, const ctl_conv* d, const ctl_conv_cfg* c, i
     r.flops = 2.0 * pix * d->cout * d->cin * d->ks * d->ks;
     const double in_b = ((d->dt & CTL_DT_X16) ? 2.0 : 4.0) * d->n * d->hin * d->win * d->cin, out_b = ((d->dt & CTL_DT_Y16) ? 2.0 : 4.0) * pix * d->cout;
     r.bytes = in_b + out_b;
-    if (d->epi_flags & CTL_EPI_RES) r.bytes += ((d->dt & CTL_DT_RES16) ? 2.0 : 4.0) * pix * d->cout;
+    if (d->epi_flags & (CTL_EPI_RES | CTL_EPI_BNBWD)) r.bytes += ((d->dt & CTL_DT_RES16) ? 2.0 : 4.0) * pix * d->cout;
+    if (d->epi_flags & CTL_EPI_TAILBWD) r.bytes += 2.0 * 4.0 * pix * d->cout;            // the block output and the BatchNorm input of the tail
     if (d->epi_flags & CTL_EPI_ACCUM) r.bytes += out_b;
     (void)hipEventRecord(r.a, stream);
     g_prof.push_back(r);
@@ -84,7 +90,7 @@ int ctl_prof_begin(const char* kind, const ctl_conv* d, const ctl_conv_cfg* c, i
 static int prof_begin_op(const ctl_op& op, hipStream_t stream) {
     if (!g_prof_on) return -1;
     static const bool timeline = ctl_tune_str("CTL_PROF_TIMELINE") != nullptr;
-    char id[48];
+    char id[96];
     double bytes = 0.0;
     const unsigned m = (unsigned)op.i[25];
     auto w = [&](int bit) { return (m >> bit) & 1u ? 2.0 : 4.0; };
@@ -194,8 +200,18 @@ static_assert(sizeof(ctl_conv) == 24 * 4, "ctl_conv must be 24 32-bit words (it 
 extern "C" int ctl_plan_run(const ctl_op* ops, int32_t n_ops, void* const* bases, int32_t n_bases, ctl_stream stream_) {
     CTL_REQUIRE(ops && bases && n_ops >= 0, "plan_run: null arguments");
     const ctl_stream stream = stream_;
+#ifdef CTL_TUNING
+    // ceiling probes (wrong numbers, right launch structure): what would the step cost without these launches?
+    static const int skip_mask = ctl_tune_int("CTL_SKIP_OPS", 0);      // bit 0: BN_FINALIZE, 1: BN_BWD_FINALIZE, 2: BWD_REDUCE mode 0, 3: BWD_REDUCE mode 1, 4: BWD_APPLY
+#endif
     for (int32_t k = 0; k < n_ops; ++k) {
         const ctl_op& op = ops[k];
+#ifdef CTL_TUNING
+        if (((skip_mask & 1) && op.kind == CTL_OP_BN_FINALIZE) || ((skip_mask & 2) && op.kind == CTL_OP_BN_BWD_FINALIZE) ||
+            ((skip_mask & 4) && op.kind == CTL_OP_BWD_REDUCE && op.i[0] == 0) || ((skip_mask & 8) && op.kind == CTL_OP_BWD_REDUCE && op.i[0] == 1) ||
+            ((skip_mask & 16) && op.kind == CTL_OP_BWD_APPLY))
+            continue;
+#endif
         void* t[CTL_OP_MAX_T];
         for (int a = 0; a < CTL_OP_MAX_T; ++a) {
             const int s = op.slot[a];
@@ -212,7 +228,7 @@ extern "C" int ctl_plan_run(const ctl_op* ops, int32_t n_ops, void* const* bases
         switch (op.kind) {
             case CTL_OP_CONV:
                 memcpy(&d, op.i, sizeof(d));
-                rc = ctl_conv_forward(&d, CF(0), CF(1), CF(2), CF(3), CF(4), CF(5), CF(6), CF(7), F(8), F(9), stream);
+                rc = ctl_conv_forward_ex(&d, CF(0), CF(1), CF(2), CF(3), CF(4), CF(5), CF(6), CF(7), CF(10), F(8), F(9), stream);
                 break;
             case CTL_OP_WGRAD:
                 memcpy(&d, op.i, sizeof(d));

@@ -42,6 +42,8 @@ SMALL_CIN = True         # K-packed taps for the Cin <= 4 first layers
 PHASE_CONVS = True       # 2x2 phase forms of the up-sampled forward / stride-2 data gradient
 FUSE_BNBWD = False       # BN1-backward reduction inside the dgrad conv epilogue (fp32: matrix-bound kernel, measured no gain)
 FUSE_BNBWD16 = True      # the same in the bf16 family, where the data gradient is not matrix-bound
+FUSE_TAIL = True         # fp32: the residual tail's BatchNorm-backward reduction inside the launch that writes dOut (CTL_EPI_TAILBWD): dOut is
+                         # never materialised, the stand-alone reduction launch (read dOut, out, v; write dS) disappears
 CONV_WORDS = _ffi.CONV_DTYPE.itemsize // 4      # ctl_conv as int32 words at the head of ctl_op.i
 ALIGN_F = 64            # floats (256 B)
 
@@ -197,11 +199,17 @@ class PlanBuilder:
 
     def conv(self, x: T, wp_ref, cout, ks, *, stride=1, in_mode=0, pro=None, bias_ref=None, stats=False, act=0,
              slope=0.0, res=None, accum=False, out: Optional[T] = None, arena: Optional[Arena] = None, nsub=1,
-             hout=None, wout=None, bnbwd=None, pad=None):
+             hout=None, wout=None, bnbwd=None, pad=None, tail=None):
         """Emit one CTL_OP_CONV.  pro = (scale_ref, shift_ref, slope); res = (T v, scale_ref, shift_ref).
         bnbwd = (T u, scale_ref, shift_ref, slope): data-gradient conv whose result is dL/d leaky(BN(u)); the epilogue writes
         g = result * leaky'(BN(u)) and the BatchNorm-backward sums go to the statistics partials (CTL_EPI_BNBWD).
+        tail = (T block_out, T v, slope): this conv writes dL/dOut of a residual block; the epilogue stores g = dOut * leaky'(block_out)
+        instead and takes the BatchNorm-backward sums of the tail (sum g, sum g*v) into the statistics partials (CTL_EPI_TAILBWD).
         Returns (T y, stats_ref or None, stats_blocks)."""
+        res2 = None
+        if tail is not None:
+            assert res is None and bnbwd is None and bias_ref is None and act == 0 and not self.b16
+            stats, res2, slope = True, tail[1], tail[2]
         if bnbwd is not None:
             assert res is None and not accum and bias_ref is None and act == 0
             stats, res, slope = True, (bnbwd[0], bnbwd[1], bnbwd[2]), bnbwd[3]
@@ -213,7 +221,8 @@ class PlanBuilder:
             else:
                 hout, wout = x.h, x.w
         flags = (_ffi.EPI_BIAS if bias_ref is not None else 0) | (_ffi.EPI_STATS if stats else 0) | \
-                ((_ffi.EPI_BNBWD if bnbwd is not None else _ffi.EPI_RES) if res is not None else 0) | (_ffi.EPI_ACCUM if accum else 0)
+                ((_ffi.EPI_BNBWD if bnbwd is not None else _ffi.EPI_RES) if res is not None else 0) | (_ffi.EPI_ACCUM if accum else 0) | \
+                (_ffi.EPI_TAILBWD if tail is not None else 0)
         oh, ow = (2 * hout, 2 * wout) if nsub == 4 else (hout, wout)
         if out is None:
             out = (arena or self.act).tensor(x.n, oh, ow, cout)
@@ -232,8 +241,8 @@ class PlanBuilder:
                 raise _ffi.CtlError("conv plan: " + lib.ctl_last_error().decode())
             stats_ref, = self.scr(4 * self.groups * blocks * 2 * cout)
         for idx, ref in enumerate([x.ref, wp_ref, bias_ref, pro[0] if pro else None, pro[1] if pro else None,
-                                   res[0].ref if res else None, res[1] if res else None, res[2] if res else None,
-                                   out.ref, stats_ref]):
+                                   (tail[0].ref if tail is not None else (res[0].ref if res else None)), res[1] if res else None, res[2] if res else None,
+                                   out.ref, stats_ref, res2.ref if res2 is not None else None]):
             self.set_t(op, idx, ref)
         return out, stats_ref, blocks
 
@@ -775,9 +784,19 @@ class CtlNet(nn.Module):
             return dropped, rec
         return out, rec
 
-    def _emit_block_bwd(self, pb: PlanBuilder, rec: dict, d_out: T, d_in: Optional[T], need_w: bool, affine: bool) -> T:
+    def _tail_of(self, pb: PlanBuilder, rec: Optional[dict]):
+        """(T out, T v, slope) of the block whose output gradient the next launch writes, if its tail reduction can ride in that launch."""
+        if rec is None or not FUSE_TAIL or pb.b16 or rec.get("drop") is not None:
+            return None
+        return (rec["out"], rec["v"], SLOPE)
+
+    def _emit_block_bwd(self, pb: PlanBuilder, rec: dict, d_out: T, d_in: Optional[T], need_w: bool, affine: bool, *, pre_tail=None,
+                        tail_next=None):
         """Backward of one residual block.  Returns the gradient w.r.t. the block input `xin` (post-activation tensor
-        the block consumed; if rec['xin_pro'] is set it is the gradient w.r.t. the *activated* virtual tensor)."""
+        the block consumed; if rec['xin_pro'] is set it is the gradient w.r.t. the *activated* virtual tensor).
+        pre_tail = (stats_ref, blocks): `d_out` is already g = dOut * leaky'(out) and the tail's BatchNorm-backward sums are in the
+        statistics partials (the launch that wrote it carried CTL_EPI_TAILBWD).  tail_next = `_tail_of` the block that consumes THIS
+        block's input gradient: the last launch writing it carries the flag; then returns (d_in, stats_ref, blocks)."""
         C, B = self._convs, self._bns
         prefix, pre = rec["prefix"], rec["pre"]
         src, src_mode, u, v, out, xin = rec["src"], rec["src_mode"], rec["u"], rec["v"], rec["out"], rec["xin"]
@@ -788,8 +807,13 @@ class CtlNet(nn.Module):
             pb.dropout(d_out, d_pre, rec["drop"][1], keep_in=rec["drop"][0])
             d_out = d_pre
         # residual tail: dS (to conv_input) and dV (to conv.3)
-        ds, dv = A.tensor(out.n, out.h, out.w, out.c), A.tensor(out.n, out.h, out.w, out.c)
-        pb.bn_backward(0, d_out, out, v, B[prefix + ".conv.4"], rec["co2"], SLOPE, ds=ds, dx=dv, affine_grad=need_w and affine)
+        if pre_tail is not None:
+            assert rec.get("drop") is None
+            ds, dv = d_out, A.tensor(out.n, out.h, out.w, out.c)
+            pb.bn_backward_from_stats(ds, v, B[prefix + ".conv.4"], rec["co2"], pre_tail[0], pre_tail[1], dx=dv, affine_grad=need_w and affine)
+        else:
+            ds, dv = A.tensor(out.n, out.h, out.w, out.c), A.tensor(out.n, out.h, out.w, out.c)
+            pb.bn_backward(0, d_out, out, v, B[prefix + ".conv.4"], rec["co2"], SLOPE, ds=ds, dx=dv, affine_grad=need_w and affine)
         pro1 = (rec["co1"]["scale"], rec["co1"]["shift"], SLOPE)
         k9 = 9
         if need_w:
@@ -825,11 +849,12 @@ class CtlNet(nn.Module):
             dsrc_shape = (src.n, 2 * src.h, 2 * src.w, src.c)
         if d_in is None:
             d_in = A.tensor(xin.n, xin.h, xin.w, xin.c)
+        fin = lambda st, blk: d_in if tail_next is None else (d_in, st, blk)
         if pre == "nn":
             # sumpool2(conv3x3^T(dU)) as one 4x4 stride-2 conv (no full-resolution gradient tensor at all), then the 1x1 part
             pb.conv(du, self._wp_ref(c0.wp_up), c0.cin, 4, stride=2, out=d_in)
-            pb.conv(ds_low, self._wp_ref(c1.wp_dgrad), c1.cin, 1, out=d_in, accum=True)
-            return d_in
+            _, st, blk = pb.conv(ds_low, self._wp_ref(c1.wp_dgrad), c1.cin, 1, out=d_in, accum=True, tail=tail_next)
+            return fin(st, blk)
         dsrc = A.tensor(*dsrc_shape)
         pb.conv(du, self._wp_ref(c0.wp_dgrad), c0.cin, 3, out=dsrc)
         pb.conv(ds, self._wp_ref(c1.wp_dgrad), c1.cin, 1, out=dsrc, accum=True)
@@ -839,20 +864,20 @@ class CtlNet(nn.Module):
                 pb.chan_sum(dsrc, pb.G(ci.b_off))
                 # role swap: "input" = dsrc (full res), "output gradient" = xin  ->  Wt[ci][co][a][b]
                 pb.wgrad(dsrc, xin, 2, stride=2, dw_ref=pb.G(ci.w_off), strides=(ci.cout * 4, 4, 2, 1))
-            pb.conv(dsrc, self._wp_ref(ci.wp_dgrad), ci.cin, 2, stride=2, out=d_in)
+            _, st, blk = pb.conv(dsrc, self._wp_ref(ci.wp_dgrad), ci.cin, 2, stride=2, out=d_in, tail=tail_next)
         else:  # down: stride-2 conv
             ci = C[prefix + ".down"]
             if need_w:
                 pb.wgrad(xin, dsrc, 3, stride=2, pro=rec["xin_pro"], dw_ref=pb.G(ci.w_off), strides=(ci.cin * k9, k9, 3, 1),
                          dbias_ref=pb.G(ci.b_off))
             if ci.wp_s2d >= 0 and xin.h == 2 * dsrc.h and xin.w == 2 * dsrc.w:
-                pb.conv(dsrc, self._wp_ref(ci.wp_s2d), ci.cin, 2, nsub=4, pad=0, hout=dsrc.h, wout=dsrc.w, out=d_in)
+                _, st, blk = pb.conv(dsrc, self._wp_ref(ci.wp_s2d), ci.cin, 2, nsub=4, pad=0, hout=dsrc.h, wout=dsrc.w, out=d_in, tail=tail_next)
             else:       # odd sizes: 3x3 conv over the zero-inserted gradient
-                pb.conv(dsrc, self._wp_ref(ci.wp_dgrad), ci.cin, 3, in_mode=_ffi.IN_ZINS2, out=d_in, hout=xin.h, wout=xin.w)
-        return d_in
+                _, st, blk = pb.conv(dsrc, self._wp_ref(ci.wp_dgrad), ci.cin, 3, in_mode=_ffi.IN_ZINS2, out=d_in, hout=xin.h, wout=xin.w, tail=tail_next)
+        return fin(st, blk)
 
     def _emit_conv_bn_pair_bwd(self, pb, conv_key, bn_key, x: T, x_pro, u: T, co, slope, d_act: T, d_x: Optional[T], need_w, affine,
-                               need_dx=True) -> Optional[T]:
+                               need_dx=True, tail_next=None):
         """Backward of  a = act(BN(conv3x3/1x1(x)))  given d_act (gradient w.r.t. a).  Returns gradient w.r.t. x
         (w.r.t. the activated virtual tensor if x_pro is set)."""
         ci, bn = self._convs[conv_key], self._bns[bn_key]
@@ -867,8 +892,8 @@ class CtlNet(nn.Module):
             return None
         if d_x is None:
             d_x = A.tensor(x.n, x.h, x.w, x.c)
-        pb.conv(du, self._wp_ref(ci.wp_dgrad), ci.cin, ci.ks, out=d_x)
-        return d_x
+        _, st, blk = pb.conv(du, self._wp_ref(ci.wp_dgrad), ci.cin, ci.ks, out=d_x, tail=tail_next)
+        return d_x if tail_next is None else (d_x, st, blk)
 
     # ---------------------------------------------------------------- public compute entry points
     def _alloc_out(self, shape):
@@ -983,11 +1008,20 @@ class MyEncoder(CtlNet):
     def _emit_encoder_bwd(self, pb: PlanBuilder, rec, dz: T, need_dx: bool, need_w: bool, affine: bool):
         px = self._px
         dbg = {"dz": dz}                 # where the intermediate gradients live (tests read them through CtlNet._dbg_last)
+        blocks = rec["blocks"]
+        tail = self._tail_of(pb, blocks[-1])
         d = self._emit_conv_bn_pair_bwd(pb, px + "final_conv.0", px + "final_conv.1", rec["x4"], None, rec["uf"], rec["cof"], 0.0,
-                                        dz, None, need_w, affine)
-        dbg["d_down5"] = d               # gradient w.r.t. the output of down4
-        for i, brec in reversed(list(enumerate(rec["blocks"]))):
-            d = self._emit_block_bwd(pb, brec, d, None, need_w, affine)
+                                        dz, None, need_w, affine, tail_next=tail)
+        pre = None
+        if tail is not None:
+            d, pre = d[0], d[1:]
+        dbg["d_down5"] = d               # gradient w.r.t. the output of down4 (with FUSE_TAIL: already times leaky'(out), i.e. dS of down4)
+        for i, brec in reversed(list(enumerate(blocks))):
+            tail = self._tail_of(pb, blocks[i - 1]) if i >= 1 else None
+            d = self._emit_block_bwd(pb, brec, d, None, need_w, affine, pre_tail=pre, tail_next=tail)
+            pre = None
+            if tail is not None:
+                d, pre = d[0], d[1:]
             dbg[f"d_down{i + 1}"] = d    # gradient w.r.t. the input of block down{i+1}
         # d = gradient w.r.t. x1 = LReLU(BN(v0))
         pro0 = (rec["co0"]["scale"], rec["co0"]["shift"], SLOPE)
@@ -1166,12 +1200,18 @@ class MyDecoder(CtlNet):
             dout = dl
         if need_w:
             pb.wgrad(x4, dout, 1, dw_ref=pb.G(cf.w_off), strides=(cf.cin, 1, 1, 1), dbias_ref=pb.G(cf.b_off))
-        d, _, _ = pb.conv(dout, self._wp_ref(cf.wp_dgrad), cf.cin, 1, arena=pb.bscr)
         blocks = rec["blocks"]
+        tail = self._tail_of(pb, blocks[3])
+        d, st, blk = pb.conv(dout, self._wp_ref(cf.wp_dgrad), cf.cin, 1, arena=pb.bscr, tail=tail)
+        pre = (st, blk) if tail is not None else None
         dbg = {"d_out4": d}
         for i in range(3, -1, -1):
             d_in = T((S_DX, 0), *rec["x"][1:]) if (i == 0 and need_dx) else None
-            d = self._emit_block_bwd(pb, blocks[i], d, d_in, need_w, affine)
+            tail = self._tail_of(pb, blocks[i - 1]) if i >= 1 else None
+            d = self._emit_block_bwd(pb, blocks[i], d, d_in, need_w, affine, pre_tail=pre, tail_next=tail)
+            pre = None
+            if tail is not None:
+                d, pre = d[0], d[1:]
             dbg[f"d_out{i}"] = d
         return pb.finish(dbg)
 

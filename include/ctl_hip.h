@@ -30,8 +30,8 @@ enum ctl_status { CTL_OK = 0, CTL_EINVAL = -1, CTL_EUNSUPPORTED = -2, CTL_ELAUNC
 /* ABI version: bumped whenever a struct layout, an argument list or a plan-op slot assignment changes.  Bindings must compare
  * ctl_version() with the CTL_ABI_VERSION they were written against (and ctl_sizeof_conv / ctl_sizeof_op with their struct sizes)
  * at load time and refuse to run on a mismatch.  3 = round 3: fused-finalize entry points and side lanes removed, `ds` argument of
- * ctl_bwd_reduce_dt, ctl_red_blocks(). */
-#define CTL_ABI_VERSION 3
+ * ctl_bwd_reduce_dt, ctl_red_blocks().  4 = CTL_EPI_TAILBWD / ctl_conv_forward_ex (plan op CONV slot 10). */
+#define CTL_ABI_VERSION 4
 int         ctl_version(void);
 const char* ctl_last_error(void);
 
@@ -47,7 +47,7 @@ const char* ctl_last_error(void);
 enum { CTL_IN_PLAIN = 0, CTL_IN_UP2 = 1, CTL_IN_ZINS2 = 2, CTL_IN_C4 = 3 /* plain input with <= 4 channels, 3x3 stride 1: the taps are
        K-packed (weights from ctl_pack_weights_batched mode 4); 12 MFMAs per pixel tile instead of 36 */ };
 enum { CTL_ACT_NONE = 0, CTL_ACT_LEAKY = 1, CTL_ACT_SIGMOID = 2 };
-enum { CTL_EPI_BIAS = 1, CTL_EPI_ACCUM = 2, CTL_EPI_RES = 4, CTL_EPI_STATS = 8, CTL_EPI_BNBWD = 16 };
+enum { CTL_EPI_BIAS = 1, CTL_EPI_ACCUM = 2, CTL_EPI_RES = 4, CTL_EPI_STATS = 8, CTL_EPI_BNBWD = 16, CTL_EPI_TAILBWD = 32 };
 
 typedef struct ctl_conv {
     int32_t n, hin, win, cin;        /* stored input tensor [n,hin,win,cin]                                   */
@@ -94,6 +94,15 @@ int ctl_conv_forward(const ctl_conv* d, const float* x, const float* wpack, cons
                      const float* pro_scale, const float* pro_shift,
                      const float* res, const float* res_scale, const float* res_shift,
                      float* y, float* stats_partial, ctl_stream stream);
+/* ... with a second epilogue tensor.  CTL_EPI_TAILBWD (with CTL_EPI_STATS, optionally CTL_EPI_ACCUM; fp32, cout % 16 == 0; the 1x1 / 2x2 /
+ * zero-insert 3x3 launches that write the output gradient of a residual block, encdec.py:64,344): the conv result (+ y with
+ * CTL_EPI_ACCUM) is dL/dOut of out = leaky(S + BN(v), epi_slope); res = out, res2 = v.  y receives g = dOut * leaky'(out) and
+ * stats_partial (sum g, sum g*v) per BatchNorm group: the reduction pass of the residual tail (ctl_bwd_reduce mode 0) folded into the
+ * producer of dOut, which is then never materialised.  res2 == NULL: plain ctl_conv_forward. */
+int ctl_conv_forward_ex(const ctl_conv* d, const float* x, const float* wpack, const float* bias,
+                        const float* pro_scale, const float* pro_shift,
+                        const float* res, const float* res_scale, const float* res_shift, const float* res2,
+                        float* y, float* stats_partial, ctl_stream stream);
 
 /* Weight gradient of the conv described by d (x [n,hin,win,cin] -> dy [n,hout,wout,cout], nsub must be 1):
  * partial[split][tap][cin16][cout16] (+ bias partial[split][cout16]); then ctl_wgrad_reduce sums the splits and
