@@ -328,9 +328,11 @@ def main():
         np.random.seed(1234 + rank)
         random.seed(1234 + rank)
     clean, label, noisy, host_batch = synthetic(args.batch, args.size, args.size, 1000 + rank, device)
-    hook = dp.sync_gradients if dp else None
-    if os.environ.get("CTL_BENCH_NO_HOOK"):              # diagnosis only: RCCL initialised, no gradient exchange
-        hook = None
+    # eager steps: every network's range of the gradient bucket is all-reduced from inside the backward sweep as soon as that network's
+    # last backward pass has been issued, and its Adam launch waits for that range only (dist.py); graph mode: the five exchanges run
+    # between the forward/backward graph and the Adam graph
+    hook = dp.launch_remaining if dp else None
+    hook_graph = dp.sync_gradients if dp else None
 
     def eager_step():
         return solver.cooperative_step(clean, label, noisy, IMG_CFG, SEG_CFG, grad_hook=hook)
@@ -351,7 +353,7 @@ def main():
     calib, mode, gstep = {}, args.mode, None
     if mode in ("auto", "graph"):
         try:
-            gstep = CooperativeStepGraph(solver, IMG_CFG, SEG_CFG, grad_hook=hook)
+            gstep = CooperativeStepGraph(solver, IMG_CFG, SEG_CFG, grad_hook=hook_graph)
             graph_step = lambda: gstep(clean, label, noisy)
             graph_step()                                  # capture + first replay
             fence()

@@ -19,6 +19,9 @@ class _NetFn(torch.autograd.Function):
     def forward(ctx, net, mode, affine, groups, x, flat):
         outs, act, plan = net.run_forward(x, mode, groups)
         net._pass_seq += 1
+        ctx.counted = bool(flat.requires_grad)            # this pass owes the network a parameter gradient
+        if ctx.counted:
+            net._pending_bwd += 1
         ctx.net, ctx.mode, ctx.affine, ctx.act, ctx.plan, ctx.seq = net, mode, affine, act, plan, net._pass_seq
         ctx.save_for_backward(x, *outs)
         ctx.set_materialize_grads(False)
@@ -42,6 +45,14 @@ class _NetFn(torch.autograd.Function):
             ev.record()
             ctx.net._deferred.append((ctx.seq, gflat, ev))
             gflat = None
+        if ctx.counted and need_w:
+            net = ctx.net
+            net._pending_bwd -= 1
+            if net._pending_bwd == 0 and net._on_grads_complete is not None and net._defer_grads:
+                # the last backward pass of this network in this step: its gradient range is complete once the parked per-pass
+                # gradients are added -- done here, on this pass' stream, and the exchange of the range starts behind it (dist.py)
+                net.collect_deferred_grads()
+                net._on_grads_complete()
         return None, None, None, None, dx, gflat
 
 

@@ -463,6 +463,10 @@ class CtlNet(nn.Module):
         self._defer_grads = False
         self._deferred: list = []
         self._pass_seq = 0
+        # data parallelism (dist.py): backward passes of this step that still owe a parameter gradient, and what to call when the last
+        # one has been issued (the network's range of the gradient bucket is complete: its all-reduce can start)
+        self._pending_bwd = 0
+        self._on_grads_complete = None
         self._scr: Optional[dict] = None          # stream handle -> scratch tensor
         self._arenas = ArenaPool()
         # nn.Dropout2d behind every residual block (encoder_decoder.py:58-66; `encoder_dropout` / `decoder_dropout`, None upstream's default)

@@ -66,6 +66,7 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
         self.z_i = self.z_s = None
         self.last_masks = {}
         self.grad_scale = 1.0          # set to 1/world_size by the data-parallel wrapper
+        self._dp = None                # dist.DataParallel: per-network gradient exchange, waited for in front of each Adam launch
         # independent STN passes of one step that share the BatchNorm mode run as one grouped pass (recon_shape_pair); off = one
         # pass per reference call
         self.group_stn_passes = True
@@ -181,10 +182,14 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
         return self.optimizers if model_name is None else self.optimizers[model_name]
 
     def optimize_all_params(self):
-        for o in self.optimizers.values():
+        for name, o in self.optimizers.items():
+            if self._dp is not None:
+                self._dp.wait(name)              # this network's range of the gradient bucket (no-op if the exchange was already waited for)
             o.step(grad_scale=self.grad_scale, state=self._gstate)
 
     def optimize_params(self, model_name):
+        if self._dp is not None:
+            self._dp.wait(model_name)
         self.optimizers[model_name].step(grad_scale=self.grad_scale, state=self._gstate)
 
     def reset_optimizer(self, model_name):
@@ -680,7 +685,9 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
             ops.step_tick(self._gstate)           # (graph capture) RNG counter and Adam step advance on the device
         self.reset_all_optimizers()
         for net in self.model.values():
-            net._defer_grads, net._deferred = self.defer_param_grads, []
+            net._defer_grads, net._deferred, net._pending_bwd = self.defer_param_grads, [], 0
+        if self._dp is not None:
+            self._dp.launched_in_backward = []
         try:
             return self._cooperative_step(clean_image_l, label_l, image_l, img_cfg, seg_cfg, latent_DA, separate_training, image_override,
                                           seg_override, do_optim, grad_hook)

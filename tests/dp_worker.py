@@ -48,15 +48,17 @@ def main():
     rec = {}
 
     def hook(solver):
-        dp.sync_gradients(solver)
+        dp.sync_gradients(solver)                # launches what backward has not launched yet, then waits for all five ranges
         rec["bucket_sum"] = dp.bucket.buf.detach().cpu().clone()
+        rec["launched_in_backward"] = list(dp.launched_in_backward)
 
     losses = s.cooperative_step(clean, label, noisy, CH_MSE, SP_CE, grad_hook=hook)
     torch.cuda.synchronize()
     rec["losses"] = torch.stack([v.detach().float() for v in losses]).cpu()
     rec["weights"] = {k: m._flat_data.detach().cpu().clone() for k, m in s.model.items()}
     rec["buffers"] = {k: (m._bflat.detach().cpu().clone(), m._nbt.detach().cpu().clone()) for k, m in s.model.items()}
-    s.cooperative_step(clean, label, noisy, DROP_MSE, DROP_CE, grad_hook=dp.sync_gradients)     # per-rank dropout patterns
+    s.cooperative_step(clean, label, noisy, DROP_MSE, DROP_CE, grad_hook=dp.launch_remaining)   # per-rank dropout patterns; every Adam launch
+    rec["launched_in_backward2"] = list(dp.launched_in_backward)                                # waits for its own range (optimize_all_params)
     rec["drop_masks"] = {k: v.detach().cpu().clone() for k, v in s.last_masks.items()}
     rec["weights2"] = {k: m._flat_data.detach().cpu().clone() for k, m in s.model.items()}
     torch.cuda.synchronize()

@@ -45,6 +45,12 @@ def test_two_rank_step_equals_mean_of_single_rank_gradients(golden_sd, tmp_path)
         for k in order:                                                           # BatchNorm statistics stay rank-local (no SyncBN upstream)
             assert torch.equal(ranks[r]["buffers"][k][0], singles[r][2][k][0]) and torch.equal(ranks[r]["buffers"][k][1], singles[r][2][k][1])
     assert any(not torch.equal(ranks[0]["buffers"][k][0], ranks[1]["buffers"][k][0]) for k in order)
+    # round 3: the five per-network ranges were exchanged from INSIDE the backward sweep (each as soon as its network's last backward pass
+    # had been issued: the decoders and the STN first, the FTN encoder -- the tail of the sweep -- last), in the same order on every rank
+    for r in range(2):
+        assert sorted(ranks[r]["launched_in_backward"]) == sorted(order), ranks[r]["launched_in_backward"]
+        assert ranks[r]["launched_in_backward"][-1] == "image_encoder" and ranks[r]["launched_in_backward"] == ranks[0]["launched_in_backward"]
+        assert sorted(ranks[r]["launched_in_backward2"]) == sorted(order)
     # the update: Adam on the MEAN gradient (1/world folded into the kernel), identical on both ranks
     s = AdvancedTripletReconSegmentationModel(use_gpu=True)
     for k, m in s.model.items():
