@@ -18,6 +18,7 @@ class _NetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, net, mode, affine, groups, x, flat):
         outs, act, plan = net.run_forward(x, mode, groups)
+        net.remember_pass(x, act, outs, plan, mode, groups)
         net._pass_seq += 1
         ctx.counted = bool(flat.requires_grad)            # this pass owes the network a parameter gradient
         if ctx.counted:
@@ -50,8 +51,7 @@ class _NetFn(torch.autograd.Function):
             net._pending_bwd -= 1
             if net._pending_bwd == 0 and net._on_grads_complete is not None and net._defer_grads:
                 # the last backward pass of this network in this step: its gradient range is complete once the parked per-pass
-                # gradients are added -- done here, on this pass' stream, and the exchange of the range starts behind it (dist.py)
-                net.collect_deferred_grads()
+                # gradients are added; dist.DataParallel does that here, on this pass' stream, and starts the exchange of the range behind it
                 net._on_grads_complete()
         return None, None, None, None, dx, gflat
 

@@ -103,7 +103,8 @@ __device__ __forceinline__ ctl_bn_chan ctl_bn_chan_load(int ch, const float* __r
 __device__ __forceinline__ void ctl_bn_coefs(double s1, double s2, double count, int c, int g, int ch, ctl_bn_chan& p, float eps,
                                              float momentum, int update_running, float* __restrict__ running_mean,
                                              float* __restrict__ running_var, float* __restrict__ scale, float* __restrict__ shift,
-                                             float* __restrict__ save_mean, float* __restrict__ save_invstd) {
+                                             float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                             float* __restrict__ save_uvar = nullptr) {
     const double mean = s1 / count;
     double var = s2 / count - mean * mean;   // biased variance, as F.batch_norm normalises with
     if (var < 0.0) var = 0.0;
@@ -115,6 +116,7 @@ __device__ __forceinline__ void ctl_bn_coefs(double s1, double s2, double count,
     if (save_invstd) save_invstd[g * c + ch] = invstd;
     if (update_running) {   // nn.BatchNorm2d: momentum 0.1, running_var uses the unbiased estimate
         const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        if (save_uvar) save_uvar[g * c + ch] = (float)unbiased;      // (with save_mean: the two floats of the running update, for ctl_bn_replay_running)
         p.rm = (1.f - momentum) * p.rm + momentum * (float)mean;
         p.rv = (1.f - momentum) * p.rv + momentum * (float)unbiased;
         running_mean[ch] = p.rm;

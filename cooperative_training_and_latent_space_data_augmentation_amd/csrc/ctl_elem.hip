@@ -65,7 +65,7 @@ __global__ __launch_bounds__(EB) void bn_finalize_kernel(const float* __restrict
                                                           float* __restrict__ running_var,
                                                           int64_t* __restrict__ nbt, float* __restrict__ scale,
                                                           float* __restrict__ shift, float* __restrict__ save_mean,
-                                                          float* __restrict__ save_invstd, int groups) {
+                                                          float* __restrict__ save_invstd, int groups, float* __restrict__ save_uvar) {
     __shared__ double sm[16];
     const int ch = blockIdx.x;
     ctl_bn_chan p = {};
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(EB) void bn_finalize_kernel(const float* __restrict
         block_sum_double2(s1, s2, sm);
         if (threadIdx.x == 0) {
             ctl_bn_coefs(s1, s2, count, c, g, ch, p, eps, momentum, update_running, running_mean, running_var, scale, shift, save_mean,
-                         save_invstd);
+                         save_invstd, save_uvar);
             if (update_running && ch == 0 && nbt) nbt[0] += 1;
         }
     }
@@ -637,15 +637,49 @@ extern "C" int ctl_accumulate(float* dst, const float* const* srcs, int32_t k, i
     return CTL_OK;
 }
 
+// Running-statistics update of BatchNorm layers REPLAYED from saved batch statistics: a second forward pass of a network over the same
+// input in training mode (the saliency pass of the targeted latent masks, model_util.py:214: `decoder_function(code)` on the code the
+// standard pass has just decoded) computes the same batch statistics and moves the running statistics once more by the same two
+// floats.  The engine re-uses the first pass' activations and replays only this update.  table: n_rec records of 6 int64
+// {mean byte offset in `act`, uvar byte offset in `act`, running_mean float offset in `buffers`, running_var float offset, nbt index, c}.
+__global__ void bn_replay_running_kernel(const char* __restrict__ act, float* __restrict__ buffers, int64_t* __restrict__ nbt,
+                                         const int64_t* __restrict__ table, float momentum) {
+    const int64_t* r = table + (int64_t)blockIdx.x * 6;
+    const float* mean = reinterpret_cast<const float*>(act + r[0]);
+    const float* uvar = reinterpret_cast<const float*>(act + r[1]);
+    float* rm = buffers + r[2];
+    float* rv = buffers + r[3];
+    const int c = (int)r[5];
+    for (int ch = threadIdx.x; ch < c; ch += blockDim.x) {
+        rm[ch] = (1.f - momentum) * rm[ch] + momentum * mean[ch];
+        rv[ch] = (1.f - momentum) * rv[ch] + momentum * uvar[ch];
+    }
+    if (threadIdx.x == 0) nbt[r[4]] += 1;
+}
+extern "C" int ctl_bn_replay_running(const void* act, float* buffers, int64_t* nbt, const int64_t* table, int32_t n_rec, float momentum,
+                                     ctl_stream stream) {
+    CTL_REQUIRE(act && buffers && nbt && table && n_rec > 0, "bn_replay_running: bad arguments");
+    bn_replay_running_kernel<<<dim3((unsigned)n_rec), dim3(128), 0, (hipStream_t)stream>>>((const char*)act, buffers, nbt, table, momentum);
+    CTL_LAUNCH_CHECK("bn_replay_running");
+    return CTL_OK;
+}
+
 extern "C" int ctl_bn_finalize(const float* partial, int32_t blocks, int32_t c, int64_t count, const float* gamma,
                                const float* beta, float eps, float momentum, int32_t update_running,
                                float* running_mean, float* running_var, int64_t* nbt, float* scale, float* shift,
                                float* save_mean, float* save_invstd, int32_t groups, ctl_stream stream) {
+    return ctl_bn_finalize_ex(partial, blocks, c, count, gamma, beta, eps, momentum, update_running, running_mean, running_var, nbt, scale, shift,
+                              save_mean, save_invstd, nullptr, groups, stream);
+}
+extern "C" int ctl_bn_finalize_ex(const float* partial, int32_t blocks, int32_t c, int64_t count, const float* gamma,
+                                  const float* beta, float eps, float momentum, int32_t update_running,
+                                  float* running_mean, float* running_var, int64_t* nbt, float* scale, float* shift,
+                                  float* save_mean, float* save_invstd, float* save_uvar, int32_t groups, ctl_stream stream) {
     CTL_REQUIRE(partial && gamma && beta && scale && shift && blocks > 0 && c > 0 && count > 0 && groups >= 1, "bn_finalize: bad arguments");
     CTL_REQUIRE(!update_running || (running_mean && running_var), "bn_finalize: update_running without buffers");
     bn_finalize_kernel<<<dim3(c), dim3(EB), 0, S_>>>(partial, blocks, c, (double)count, gamma, beta, eps, momentum,
                                                       update_running, running_mean, running_var, nbt, scale, shift,
-                                                      save_mean, save_invstd, groups);
+                                                      save_mean, save_invstd, groups, save_uvar);
     CTL_LAUNCH_CHECK("bn_finalize");
     return CTL_OK;
 }

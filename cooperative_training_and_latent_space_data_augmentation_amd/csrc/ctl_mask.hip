@@ -567,6 +567,8 @@ extern "C" int ctl_latent_mask_fused(int32_t mode, const float* grad, const floa
         const size_t lds = ((size_t)2 * L + (mode == 0 ? (size_t)splits * c : 0)) * sizeof(float) + (size_t)IB * sizeof(f32x4);
         int S = 1;                                    // blocks per image: at least ~64 blocks in flight when the batch is small
         while (S < 8 && n * S < 64 && hw / (2 * S) >= 8) S *= 2;
+        static const int forced_s = ctl_tune_int("CTL_MASK_S", 0);      // tuning hook
+        if (forced_s > 0) S = forced_s;
         const int slab_pix = ctl_cdiv(hw, S);
         // registers: the slab's code quads (CPF) and the grad quads in flight (GPF: channel mode = loads per thread and split,
         // spatial mode = the whole image spread over the block); the rolled loop of the channel mode takes whatever exceeds GPF

@@ -6,7 +6,8 @@
 //   WGRAD             0 x  1 pro_scale  2 pro_shift  3 dy  4 w_partial  5 b_partial
 //   WGRAD_REDUCE      0 w_partial  1 b_partial  2 dw  3 dbias            i[24]=accumulate  l[0..3]=s_co,s_ci,s_kh,s_kw
 //   PACK              0 src  1 dst                                       i[0..3]=cout,cin,ks,flip  l[0..3]=strides
-//   BN_FINALIZE       0 partial 1 gamma 2 beta 3 running_mean 4 running_var 5 nbt 6 scale 7 shift 8 save_mean 9 save_invstd
+//   BN_FINALIZE       0 partial 1 gamma 2 beta 3 running_mean 4 running_var 5 nbt 6 scale 7 shift 8 save_mean 9 save_invstd 10 save_uvar
+//   BN_REPLAY         0 act arena 1 buffers 2 nbt 3 table                i[0]=n_rec f[0]=momentum
 //                                                                        i[0..2]=blocks,c,update_running l[0]=count f[0]=eps f[1]=momentum
 //   BN_EVAL           0 gamma 1 beta 2 running_mean 3 running_var 4 scale 5 shift      i[0]=c f[0]=eps
 //   BN_ACT            0 x 1 scale 2 shift 3 y                            i[0]=c l[0]=pixels f[0]=slope
@@ -242,8 +243,11 @@ extern "C" int ctl_plan_run(const ctl_op* ops, int32_t n_ops, void* const* bases
                 rc = ctl_pack_weights(CF(0), F(1), op.i[0], op.i[1], op.i[2], op.l[0], op.l[1], op.l[2], op.l[3], op.i[3], stream);
                 break;
             case CTL_OP_BN_FINALIZE:
-                rc = ctl_bn_finalize(CF(0), op.i[0], op.i[1], op.l[0], CF(1), CF(2), op.f[0], op.f[1], op.i[2], F(3), F(4),
-                                     (int64_t*)t[5], F(6), F(7), F(8), F(9), NG(op.i[3]), stream);
+                rc = ctl_bn_finalize_ex(CF(0), op.i[0], op.i[1], op.l[0], CF(1), CF(2), op.f[0], op.f[1], op.i[2], F(3), F(4),
+                                        (int64_t*)t[5], F(6), F(7), F(8), F(9), F(10), NG(op.i[3]), stream);
+                break;
+            case CTL_OP_BN_REPLAY:
+                rc = ctl_bn_replay_running(t[0], F(1), (int64_t*)t[2], (const int64_t*)t[3], op.i[0], op.f[0], stream);
                 break;
             case CTL_OP_BN_EVAL:
                 rc = ctl_bn_eval_coeffs(op.i[0], CF(0), CF(1), CF(2), CF(3), op.f[0], F(4), F(5), NG(op.i[1]), stream);

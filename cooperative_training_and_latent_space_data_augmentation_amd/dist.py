@@ -51,6 +51,7 @@ class DataParallel:
         self.bucket = GradBucket(solver.model)
         self._works: Dict[str, object] = {}
         self.launched_in_backward = []          # (diagnostics / tests) names, in launch order, of the last step
+        self.suspended = False                  # graph capture / its warm-up step: no exchange from inside backward
         solver.grad_scale = 1.0 / self.world
         solver._dp = self
         self.overlap = overlap
@@ -73,8 +74,9 @@ class DataParallel:
             self._works[name] = dist.all_reduce(self.bucket.ranges[name], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
 
     def _from_backward(self, name: str):
-        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        if self.suspended or (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()):
             return                                # (graph mode: the exchange runs eagerly between the two graphs)
+        self.solver.model[name].collect_deferred_grads()      # the parked per-pass gradients of this network -> its range of the bucket
         self.launched_in_backward.append(name)
         self._launch(name)
 

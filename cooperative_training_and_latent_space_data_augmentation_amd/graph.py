@@ -114,6 +114,9 @@ class CooperativeStepGraph:
         cur = torch.cuda.current_stream()
         self.stream.wait_stream(cur)
         s._gstate, s._gk = self.state, self.k_dev
+        dp = getattr(s, "_dp", None)
+        if dp is not None:                    # (data parallel: nothing may start a collective from inside the warm-up step or the capture)
+            dp.suspended = True
         try:
             with torch.cuda.stream(self.stream):
                 self._run_step(schemes, do_optim=False, hook=None)      # warm-up: plan compilation, lazy tables, per-stream scratch
@@ -141,6 +144,8 @@ class CooperativeStepGraph:
             e.masks, e.z = dict(s.last_masks), (s.z_i, s.z_s)
         finally:
             s._gstate = s._gk = None
+            if dp is not None:
+                dp.suspended = False
             for o, c0 in zip(s.optimizers.values(), counts):           # capturing executed nothing: undo the host-side mirror
                 o.step_count = c0
             random.setstate(rng[0])

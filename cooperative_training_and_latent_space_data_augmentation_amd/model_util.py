@@ -68,8 +68,31 @@ def _draw_seed() -> int:
     return int(torch.randint(0, 2 ** 62, (1,)).item())        # host RNG: respects torch.manual_seed, no device sync
 
 
+REUSE_SALIENCY_FORWARD = True     # see _saliency_grad
+
+
 def _saliency_grad(code, decoder_function, label, num_classes, loss_type):
-    """dL/dz through the (frozen) decoder: forward + dgrad-only backward (model_util.py:202-223)."""
+    """dL/dz through the (frozen) decoder: forward + dgrad-only backward (model_util.py:202-223).
+
+    Upstream's saliency pass runs `decoder_function(code)` in training mode on the very tensor the standard pass has just decoded
+    (model.py:436-447 store z_i / z_s, model.py:491-501 hands them to perturb_latent_code): same input, same weights, same mode -- the same
+    activations, the same batch statistics.  If the decoder still remembers that pass (CtlNet.reuse_pass) its activations are re-used:
+    the loss gradient w.r.t. the output is formed from the remembered output, the data-gradient-only backward runs on the remembered
+    activations, and the second running-statistics update of every BatchNorm is replayed from the saved batch statistics -- bit for
+    bit the numbers of running the pass again (tests/test_engine_gpu.py::test_saliency_forward_reuse_is_bitwise), one decoder forward less."""
+    reuse = decoder_function.reuse_pass(ops.as_nhwc(code.detach())) if (REUSE_SALIENCY_FORWARD and hasattr(decoder_function, "reuse_pass")) else None
+    if reuse is not None and loss_type in ("ce", "mse", "corr"):
+        outs, backward, handle = reuse
+        out = outs[0]
+        one = torch.ones((), device=out.device)
+        if loss_type == "ce":
+            dout = ops.ce2d_bwd(out, label.long().contiguous(), one)
+        else:
+            gt = ops.as_nhwc(ops.onehot(label, num_classes) if label.dim() < code.dim() else label)
+            dout = ops.mse_bwd(out, gt, one, 1.0) if loss_type == "mse" else gt / float(out.numel())
+        grad = backward((dout,))
+        decoder_function.replay_running_stats(handle)
+        return ops.as_nhwc(code.detach()), grad
     code = ops.as_nhwc(code.detach()).requires_grad_(True)
     with torch.enable_grad():
         out = decoder_function(code)

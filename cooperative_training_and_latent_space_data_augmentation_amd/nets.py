@@ -140,7 +140,8 @@ class ArenaPool:
 
 
 class Plan:
-    __slots__ = ("ops", "n_ops", "act_bytes", "scr_bytes", "bscr_bytes", "rec", "out_shapes", "table_np", "table_dev", "groups")
+    __slots__ = ("ops", "n_ops", "act_bytes", "scr_bytes", "bscr_bytes", "rec", "out_shapes", "table_np", "table_dev", "groups", "bn_log",
+                 "replay")
 
 
 class PlanBuilder:
@@ -155,6 +156,7 @@ class PlanBuilder:
         self.scr_bytes = 0
         self.reduce_recs: List[list] = []     # batched wgrad reduction records (one launch at the end of the plan)
         self.table: Optional[np.ndarray] = None
+        self.bn_log: List[tuple] = []         # (BNInfo, coefficient refs) of every training-mode BatchNorm of a forward plan, in order
 
     # -- low level
     def op(self, kind: int) -> np.ndarray:
@@ -288,7 +290,7 @@ class PlanBuilder:
         c, G = bn.c, self.groups
         assert count % G == 0
         count //= G                                   # the statistics of one group
-        co = {k: self.act.alloc(4 * c * G) for k in ("scale", "shift", "mean", "invstd")}      # [groups][c] each
+        co = {k: self.act.alloc(4 * c * G) for k in ("scale", "shift", "mean", "invstd", "uvar")}      # [groups][c] each
         if mode == "C":
             op = self.op(_ffi.OP_BN_EVAL)
             op["i"][0], op["i"][1] = c, G
@@ -303,8 +305,9 @@ class PlanBuilder:
         op["f"][0], op["f"][1] = EPS, MOMENTUM
         for idx, ref in enumerate([stats_ref, self.P(bn.g_off), self.P(bn.b_off), (S_B, 4 * bn.rm_off),
                                    (S_B, 4 * bn.rv_off), (S_NBT, 8 * bn.nbt_idx), co["scale"], co["shift"], co["mean"],
-                                   co["invstd"]]):
+                                   co["invstd"], co["uvar"]]):
             self.set_t(op, idx, ref)
+        self.bn_log.append((bn, co))
         return co
 
     @staticmethod
@@ -431,6 +434,7 @@ class PlanBuilder:
     def finish(self, rec=None, out_shapes=None) -> Plan:
         self.flush_wgrad_reductions()
         p = Plan()
+        p.replay = None
         p.table_np, p.table_dev = self.table, None
         p.ops = np.stack(self.ops) if self.ops else np.zeros(0, dtype=OP_DTYPE)
         p.ops = np.ascontiguousarray(p.ops)
@@ -438,6 +442,7 @@ class PlanBuilder:
         p.act_bytes, p.scr_bytes, p.bscr_bytes = self.act.size, self.scr_bytes, self.bscr.size
         p.rec, p.out_shapes = rec, out_shapes
         p.groups = self.groups
+        p.bn_log = self.bn_log
         return p
 
 
@@ -633,6 +638,53 @@ class CtlNet(nn.Module):
     def weights_changed(self):
         """Call after modifying parameters in place by other means than the engine's optimizer / load_state_dict."""
         self._packed_ok = False
+        self._wepoch = getattr(self, "_wepoch", 0) + 1
+        self._last_pass = None
+
+    # ---------------------------------------------------------------- a forward pass whose activations can serve a second, identical pass
+    def remember_pass(self, x, act, outs, plan, mode, groups):
+        """Called by the autograd bridge after every forward pass.  A training-mode, tracking ('A') pass is kept: a later request to run
+        the SAME input through the SAME weights in the same mode (the saliency forward of the targeted latent masks, model_util.py:214,
+        decodes the code the standard pass has just decoded) re-uses its activations instead of recomputing them (`reuse_pass`)."""
+        self._last_pass = (x, x._version, act, outs, plan, getattr(self, "_wepoch", 0)) if (mode == "A" and groups == 1) else None
+
+    def forget_pass(self):
+        self._last_pass = None
+
+    def reuse_pass(self, x: torch.Tensor):
+        """(outputs, backward) of the remembered pass if running `x` through the network NOW would repeat it exactly -- same storage, same
+        tensor version, same weights, training mode with tracking -- else None.  backward(douts) is the data-gradient-only backward
+        (frozen weights); the caller accounts for the second running-statistics update with `replay_running_stats`."""
+        lp = getattr(self, "_last_pass", None)
+        if lp is None or self.bn_mode() != "A" or self.drop_p is not None:
+            return None
+        x0, ver, act, outs, plan, wepoch = lp
+        # (x0 is held by the record, so its storage cannot have been handed to another tensor: equal pointers mean the same tensor)
+        if (x0.data_ptr() != x.data_ptr() or tuple(x0.shape) != tuple(x.shape) or x0.stride() != x.stride() or x0._version != ver or
+                wepoch != getattr(self, "_wepoch", 0) or not self._packed_ok):
+            return None
+
+        def backward(douts):
+            dx, _ = self.run_backward(x0, act, outs, plan, "A", tuple(douts), need_dx=True, need_w=False, affine=True)
+            return dx
+        return outs, backward, (act, plan)
+
+    def replay_running_stats(self, handle):
+        """The running-statistics update of every BatchNorm of a remembered pass, once more (ctl_bn_replay_running): ONE launch."""
+        act, plan = handle
+        if not plan.bn_log:
+            return
+        if plan.replay is None:
+            recs = [[co["mean"][1], co["uvar"][1], bn.rm_off, bn.rv_off, bn.nbt_idx, bn.c] for bn, co in plan.bn_log]
+            pb = PlanBuilder(self)
+            pb.table = np.asarray(recs, dtype=np.int64)
+            op = pb.op(_ffi.OP_BN_REPLAY)
+            op["i"][0] = len(recs)
+            op["f"][0] = MOMENTUM
+            for idx, ref in enumerate([(S_ACT, 0), (S_B, 0), (S_NBT, 0), (S_TAB, 0)]):
+                pb.set_t(op, idx, ref)
+            plan.replay = pb.finish()
+        self._run(plan.replay, {S_ACT: act.t, S_B: self._bflat, S_NBT: self._nbt})
 
     def param_list(self):
         """The network's parameters as a cached list (the module tree is fixed after construction): `Module.parameters()` walks ~100

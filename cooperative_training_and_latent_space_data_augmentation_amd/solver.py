@@ -398,8 +398,9 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
         (cooperative_step runs the image branch and the whole hard-example branch on the second stream)."""
         zero = torch.zeros((), device=clean_image_l.device)
         if _pre is not None:
-            z_i, z_s, image_recon_loss = _pre
-            y_0 = self._call(self.model["segmentation_decoder"], z_s, disable_track_bn_stats)
+            z_i, z_s, image_recon_loss, y_0 = _pre
+            if y_0 is None:
+                y_0 = self._call(self.model["segmentation_decoder"], z_s, disable_track_bn_stats)
         elif self.two_streams and self.training and not self._in_side:
             z_i, z_s = self._enc(perturbed_image, disable_track_bn_stats)
             image_recon_loss = self._image_recon_loss(z_i, clean_image_l)      # side stream, next to D_seg -> STN below
@@ -617,13 +618,28 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
                       seg_override=seg_override)
         xh = yh = None
         img_saliency_done = None
+        # Targeted masks: the saliency forward of a code is the standard pass of that decoder over again (same code, same weights, training
+        # mode; model_util._saliency_grad) -- issue the standard pass FIRST and the generator re-uses its activations (one decoder forward
+        # less per code).  'random' may still draw dropout: then the early pass only changed the issue order.
+        from . import model_util as _mu
+        scheme_of = lambda cfg, ov: None if cfg is None else (ov or {}).get("scheme", cfg["mask_type"])
+        early_img = _mu.REUSE_SALIENCY_FORWARD and scheme_of(img_cfg, image_override) not in (None, "dropout")
+        early_seg = _mu.REUSE_SALIENCY_FORWARD and scheme_of(seg_cfg, seg_override) not in (None, "dropout")
+        image_recon_loss = y_0 = None
+        if early_img:
+            image_recon_loss = scaled_mse(self.decode_image(z_i), clean_image_l, 0.5)
+            self._img_std_done = torch.cuda.Event()
+            self._img_std_done.record(cur)
+            side.wait_event(self._img_std_done)         # the image saliency pass reads these activations, and replays this pass' running update
+        if early_seg:
+            y_0 = self._call(self.model["segmentation_decoder"], z_s)
         self._in_side = True
         try:
             with torch.cuda.stream(side):
                 if img_cfg is not None:
                     xh, _ = self.hard_example_generation(clean_image_l.detach(), label_l.detach(), gen_corrupted_seg=False,
                                                          gen_corrupted_image=True, **gen_kw)
-                    if self.last_scheme != "dropout":
+                    if self.last_scheme != "dropout" and not early_img:
                         # targeted masks: the saliency pass decoded z_i through the image decoder with TRACKING BatchNorm (upstream
                         # calls decoder_function(code) in train mode, model_util.py:214) -- a third writer of that network's running
                         # statistics, on this chain.  The standard pass on the main chain must not overlap it: it waits for this
@@ -645,11 +661,12 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
         # the standard image decoder goes FIRST on the main chain: autograd replays a chain in reverse, and where two passes of a
         # network sit on different streams the later gradient has to wait for the earlier one at the accumulation -- as the first
         # backward node of the main chain it stalled 5 ms on the hard image decoder's backward, which comes late on the side chain
-        if img_saliency_done is not None:
-            cur.wait_event(img_saliency_done)
-        image_recon_loss = scaled_mse(self.decode_image(z_i), clean_image_l, 0.5)
-        self._img_std_done = torch.cuda.Event()
-        self._img_std_done.record(cur)               # the hard phase's image-decoder pass (side chain) waits for this one
+        if image_recon_loss is None:
+            if img_saliency_done is not None:
+                cur.wait_event(img_saliency_done)
+            image_recon_loss = scaled_mse(self.decode_image(z_i), clean_image_l, 0.5)
+            self._img_std_done = torch.cuda.Event()
+            self._img_std_done.record(cur)           # the hard phase's image-decoder pass (side chain) waits for this one
         # CPU issue order (one Python thread feeds both streams): the side chain's long part is issued BEFORE the main chain's
         # D_seg -> STN, while the GPU is still busy with what both streams already have -- issued after it, the side stream sat
         # idle for ~1.5 ms waiting for the host (tools/timeline.py)
@@ -662,7 +679,7 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
         finally:
             self._in_side = False
         std = self.standard_training(clean_image_l, label_l, perturbed_image=image_l, separate_training=separate_training,
-                                     _pre=(z_i, z_s, None))
+                                     _pre=(z_i, z_s, None, y_0))
         if self._chain_events is not None:          # tools/chain_timing.py: when does each chain finish its forward?
             ev = {k: torch.cuda.Event(enable_timing=True) for k in ("fork", "main_done", "side_done")}
             ev["fork"] = self._fork_event

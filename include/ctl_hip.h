@@ -30,8 +30,9 @@ enum ctl_status { CTL_OK = 0, CTL_EINVAL = -1, CTL_EUNSUPPORTED = -2, CTL_ELAUNC
 /* ABI version: bumped whenever a struct layout, an argument list or a plan-op slot assignment changes.  Bindings must compare
  * ctl_version() with the CTL_ABI_VERSION they were written against (and ctl_sizeof_conv / ctl_sizeof_op with their struct sizes)
  * at load time and refuse to run on a mismatch.  3 = round 3: fused-finalize entry points and side lanes removed, `ds` argument of
- * ctl_bwd_reduce_dt, ctl_red_blocks().  4 = CTL_EPI_TAILBWD / ctl_conv_forward_ex (plan op CONV slot 10). */
-#define CTL_ABI_VERSION 4
+ * ctl_bwd_reduce_dt, ctl_red_blocks().  4 = CTL_EPI_TAILBWD / ctl_conv_forward_ex (plan op CONV slot 10).
+ * 5 = ctl_bn_finalize_ex (save_uvar, plan op BN_FINALIZE slot 10), ctl_bn_replay_running / CTL_OP_BN_REPLAY. */
+#define CTL_ABI_VERSION 5
 int         ctl_version(void);
 const char* ctl_last_error(void);
 
@@ -143,6 +144,18 @@ int ctl_bn_finalize(const float* partial, int32_t blocks, int32_t c, int64_t cou
                     const float* beta, float eps, float momentum, int32_t update_running, float* running_mean,
                     float* running_var, int64_t* num_batches_tracked, float* scale, float* shift, float* save_mean,
                     float* save_invstd, int32_t groups, ctl_stream stream);
+/* ... additionally saving the unbiased batch variance as the float the running update used (save_uvar, [groups][c], may be NULL) */
+int ctl_bn_finalize_ex(const float* partial, int32_t blocks, int32_t c, int64_t count, const float* gamma,
+                       const float* beta, float eps, float momentum, int32_t update_running, float* running_mean,
+                       float* running_var, int64_t* num_batches_tracked, float* scale, float* shift, float* save_mean,
+                       float* save_invstd, float* save_uvar, int32_t groups, ctl_stream stream);
+/* The running-statistics update of n_rec BatchNorm layers replayed from saved batch statistics (save_mean / save_uvar of a forward pass
+ * whose activations are re-used instead of recomputed: the saliency pass of the targeted latent masks decodes, in training mode, the very
+ * code the standard pass has just decoded -- util.py:214 after model.py:444 / 436-440).  table: n_rec x 6 int64 {save_mean byte offset in
+ * `act`, save_uvar byte offset in `act`, running_mean / running_var float offsets in `buffers`, num_batches_tracked index, c}.
+ * Bit-identical to running the pass again: the same two floats enter the same momentum update. */
+int ctl_bn_replay_running(const void* act, float* buffers, int64_t* num_batches_tracked, const int64_t* table, int32_t n_rec,
+                          float momentum, ctl_stream stream);
 /* eval mode: scale = gamma/sqrt(running_var+eps), shift = beta - running_mean*scale */
 int ctl_bn_eval_coeffs(int32_t c, const float* gamma, const float* beta, const float* running_mean,
                        const float* running_var, float eps, float* scale, float* shift, int32_t groups, ctl_stream stream);
@@ -309,7 +322,7 @@ enum ctl_op_kind {
     CTL_OP_CONV = 1, CTL_OP_WGRAD = 2, CTL_OP_WGRAD_REDUCE = 3, CTL_OP_PACK = 4, CTL_OP_BN_FINALIZE = 5,
     CTL_OP_BN_EVAL = 6, CTL_OP_BN_ACT = 7, CTL_OP_BWD_REDUCE = 8, CTL_OP_BN_BWD_FINALIZE = 9, CTL_OP_BWD_APPLY = 10,
     CTL_OP_CHAN_SUM_FINALIZE = 11, CTL_OP_SUMPOOL2 = 12, CTL_OP_SIGMOID_BWD = 13, CTL_OP_ZERO = 14, CTL_OP_COPY = 15, CTL_OP_PACK_BATCH = 16,
-    CTL_OP_WGRAD_REDUCE_BATCH = 17, CTL_OP_DROPOUT2D = 18
+    CTL_OP_WGRAD_REDUCE_BATCH = 17, CTL_OP_DROPOUT2D = 18, CTL_OP_BN_REPLAY = 19
 };
 #define CTL_OP_MAX_T 12
 typedef struct ctl_op {
