@@ -545,6 +545,41 @@ def test_whole_volume_pass_is_bitwise_the_chunked_loop(golden_sd):
     assert max_slices_per_pass(4096, 4096) == 1
 
 
+@pytest.mark.parametrize("two_streams", [True, False])
+@pytest.mark.parametrize("case", ["C_step_channel_spatial", "E_step_soft_random"])
+def test_saliency_forward_reuse_is_bitwise(golden_cases, golden_sd, case, two_streams):
+    """Targeted masks: the saliency pass decodes, in training mode, the code the standard pass has just decoded (model_util.py:214 after
+    model.py:436-447).  The engine re-uses the standard pass' activations (CtlNet.reuse_pass), runs only the data-gradient backward on
+    them and replays the second running-statistics update from the saved batch statistics (ctl_bn_replay_running).  Three training steps
+    with and without the re-use must agree bit for bit: losses, masks, weights, BatchNorm buffers -- and the re-use must save launches."""
+    from cooperative_training_and_latent_space_data_augmentation_amd import model_util as MU
+    C = golden_cases[case]
+    res = []
+    for reuse in (False, True):
+        MU.REUSE_SALIENCY_FORWARD = reuse
+        try:
+            s = _solver(golden_sd)
+            s.two_streams = two_streams
+            ov_img, ov_seg = _overrides(C, (C["img_cfg"], C["seg_cfg"]))
+            n0 = _ffi.lib.ctl_launch_count()
+            for _ in range(3):
+                losses = s.cooperative_step(dev(C["clean"]), dev(C["label"]), dev(C["noisy"]), C["img_cfg"], C["seg_cfg"], image_override=ov_img,
+                                            seg_override=ov_seg)
+            torch.cuda.synchronize()
+            res.append((torch.stack([v.detach().float() for v in losses]).cpu(), {k: m._flat_data.detach().cpu().clone() for k, m in s.model.items()},
+                        {k: (m._bflat.detach().cpu().clone(), m._nbt.detach().cpu().clone()) for k, m in s.model.items()},
+                        {k: v.detach().cpu().clone() for k, v in s.last_masks.items()}, int(_ffi.lib.ctl_launch_count() - n0)))
+        finally:
+            MU.REUSE_SALIENCY_FORWARD = True
+    a, b = res
+    assert torch.equal(a[0], b[0])
+    for k in a[1]:
+        assert torch.equal(a[1][k], b[1][k]), k
+        assert torch.equal(a[2][k][0], b[2][k][0]) and torch.equal(a[2][k][1], b[2][k][1]), f"BatchNorm buffers of {k}"
+    assert all(torch.equal(a[3][k], b[3][k]) for k in a[3])
+    assert b[4] <= a[4] - 3 * 2 * 25, (a[4], b[4])              # two decoder forwards (~35 launches each, minus the replay launch) less per step
+
+
 def test_filter_code_and_remaining_solver_entries(golden_cases, golden_sd):
     """`Dual_Branch_Encoder.filter_code` (encoder_decoder.py:496-498) and the solver entries built on it
     (model.py:208-221, 292-295, 603-606): same numbers as the full forward / the oracle, forward only."""

@@ -7,19 +7,21 @@ from torch.profiler import profile, ProfilerActivity
 from cooperative_training_and_latent_space_data_augmentation_amd.solver import AdvancedTripletReconSegmentationModel
 import bench
 torch.manual_seed(0)
-s = AdvancedTripletReconSegmentationModel(use_gpu=True)
+dt = "bf16" if "bf16" in sys.argv else "fp32"
+CFG = (bench.TGT_IMG, bench.TGT_SEG) if "targeted" in sys.argv else (bench.DROP_IMG, bench.DROP_SEG)
+s = AdvancedTripletReconSegmentationModel(use_gpu=True, compute_dtype=dt)
 clean = torch.rand(16, 1, 256, 256, device="cuda"); noisy = (clean + 0.1 * torch.randn_like(clean)).clamp(0, 1)
 label = torch.randint(0, 4, (16, 256, 256), device="cuda")
-for _ in range(4): s.cooperative_step(clean, label, noisy, bench.DROP_IMG, bench.DROP_SEG)
+for _ in range(4): s.cooperative_step(clean, label, noisy, *CFG)
 torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU], record_shapes=True, with_stack=True) as prof:
-    s.cooperative_step(clean, label, noisy, bench.DROP_IMG, bench.DROP_SEG)
+    s.cooperative_step(clean, label, noisy, *CFG)
     torch.cuda.synchronize()
 agg = collections.Counter()
 for e in prof.events():
-    if e.name.startswith("aten::") and e.name.split("::")[1] not in ("empty", "empty_like", "empty_strided", "detach", "detach_", "alias", "view", "slice", "narrow", "as_strided", "to", "select", "reshape", "_reshape_alias", "expand", "unsqueeze", "squeeze", "permute", "t", "transpose", "is_pinned", "result_type", "item", "_local_scalar_dense", "lift_fresh", "requires_grad_", "set_", "resize_", "unbind", "chunk", "split", "contiguous", "clone", "zeros", "ones", "zero_", "full", "scalar_tensor", "_unsafe_view", "flatten", "view_as", "numel", "size", "stride"):
+    if e.name.startswith("aten::") and e.name.split("::")[1] not in ("empty", "empty_like", "empty_strided", "detach", "detach_", "alias", "view", "slice", "narrow", "as_strided", "to", "select", "reshape", "_reshape_alias", "expand", "unsqueeze", "squeeze", "permute", "t", "transpose", "is_pinned", "result_type", "item", "_local_scalar_dense", "lift_fresh", "requires_grad_", "set_", "resize_", "unbind", "chunk", "split", "contiguous", "clone", "zeros", "ones", "full", "scalar_tensor", "_unsafe_view", "flatten", "view_as", "numel", "size", "stride"):
         st = [f for f in (e.stack or []) if "cooperative_training" in f or "bench.py" in f]
-        where = st[0].split("/")[-1] if st else "(autograd engine)"
+        where = " < ".join(f.split("/")[-1].split(":")[0].replace(".py(", ":").rstrip(")") + ":" + f.split(": ")[-1] for f in st[:3]) if st else "(autograd engine)"
         agg[(e.name, str(e.input_shapes)[:60], where[:70])] += 1
 for (name, shp, where), n in sorted(agg.items(), key=lambda kv: -kv[1])[:60]:
-    print(f"{n:4d} {name:18s} {shp:60s} {where}")
+    print(f"{n:4d} {name:18s} {shp:44s} {where[:150]}")
