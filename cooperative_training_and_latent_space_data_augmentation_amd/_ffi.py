@@ -9,17 +9,15 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libctl_hip.so")
-ABI_VERSION = 6                      # CTL_ABI_VERSION of include/ctl_hip.h this binding was written against
+ABI_VERSION = 5                      # CTL_ABI_VERSION of include/ctl_hip.h this binding was written against
 RED_BLOCKS = 512                     # CTL_RED_BLOCKS of ctl_hip.h; checked against the library's compiled value (ctl_red_blocks) at load
 
 # enums of ctl_hip.h
 IN_PLAIN, IN_UP2, IN_ZINS2, IN_C4 = 0, 1, 2, 3
 ACT_NONE, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2
-EPI_BIAS, EPI_ACCUM, EPI_RES, EPI_STATS, EPI_BNBWD, EPI_TAILBWD, EPI_STATS_ACC = 1, 2, 4, 8, 16, 32, 64
-RED_ACC = 0x100                      # ctl_bwd_reduce_dt mode flag: exact accumulators instead of partial rows
+EPI_BIAS, EPI_ACCUM, EPI_RES, EPI_STATS, EPI_BNBWD, EPI_TAILBWD = 1, 2, 4, 8, 16, 32
 (OP_CONV, OP_WGRAD, OP_WGRAD_REDUCE, OP_PACK, OP_BN_FINALIZE, OP_BN_EVAL, OP_BN_ACT, OP_BWD_REDUCE, OP_BN_BWD_FINALIZE,
- OP_BWD_APPLY, OP_CHAN_SUM_FINALIZE, OP_SUMPOOL2, OP_SIGMOID_BWD, OP_ZERO, OP_COPY, OP_PACK_BATCH, OP_WGRAD_REDUCE_BATCH, OP_DROPOUT2D, OP_BN_REPLAY,
- OP_BWD_APPLY_PENDING) = range(1, 21)
+ OP_BWD_APPLY, OP_CHAN_SUM_FINALIZE, OP_SUMPOOL2, OP_SIGMOID_BWD, OP_ZERO, OP_COPY, OP_PACK_BATCH, OP_WGRAD_REDUCE_BATCH, OP_DROPOUT2D, OP_BN_REPLAY) = range(1, 20)
 OP_MAX_T = 12
 
 CONV_DTYPE = np.dtype([
@@ -56,7 +54,7 @@ class _Lib:
         lib.ctl_launch_count.restype = C.c_ulonglong
         for name in ("ctl_conv_wpack_floats", "ctl_conv_stats_floats", "ctl_wgrad_partial_floats",
                      "ctl_wgrad_bias_partial_floats", "ctl_latent_score_ws_floats", "ctl_latent_mask_apply_ws_floats",
-                     "ctl_rescale_intensity_ws_floats", "ctl_sizeof_op", "ctl_sizeof_conv", "ctl_latent_mask_fused_ws_floats", "ctl_acc_words"):
+                     "ctl_rescale_intensity_ws_floats", "ctl_sizeof_op", "ctl_sizeof_conv", "ctl_latent_mask_fused_ws_floats"):
             getattr(lib, name).restype = C.c_size_t
         p, i32, i64, f32, u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64
         sig = {
@@ -74,8 +72,7 @@ class _Lib:
             "ctl_crop_or_pad": [p, p, i32, i32, i32, i32, i32, i32, p],
             "ctl_bn_finalize": [p, i32, i32, i64, p, p, f32, f32, i32, p, p, p, p, p, p, p, i32, p],
             "ctl_bn_finalize_ex": [p, i32, i32, i64, p, p, f32, f32, i32, p, p, p, p, p, p, p, p, i32, p],
-            "ctl_bn_replay_running": [p, p, p, p, i32, f32, p], "ctl_acc_words": [i32, i32],
-            "ctl_bwd_apply_pending": [i32, p, p, p, p, p, f32, p, p, p, p, p, p, i64, i32, i64, i32, p, p, i32, C.c_uint32, p],
+            "ctl_bn_replay_running": [p, p, p, p, i32, f32, p],
             "ctl_bn_eval_coeffs": [i32, p, p, p, p, f32, p, p, i32, p],
             "ctl_bn_act": [p, p, p, f32, p, i64, i32, i32, p],
             "ctl_bwd_reduce": [i32, p, p, p, p, p, f32, i64, i32, p, i32, p], "ctl_red_blocks": [],
@@ -137,7 +134,7 @@ lib = _Lib()
 # every symbol include/ctl_hip.h declares (checked by tests/test_cabi.py without a GPU)
 EXPORTED = ["ctl_version", "ctl_last_error", "ctl_conv_wpack_floats", "ctl_conv_stats_floats", "ctl_conv_stats_blocks",
             "ctl_pack_weights", "ctl_conv_forward", "ctl_conv_forward_ex", "ctl_wgrad_splits", "ctl_wgrad_partial_floats",
-            "ctl_wgrad_bias_partial_floats", "ctl_conv_wgrad", "ctl_wgrad_reduce", "ctl_bn_finalize", "ctl_bn_finalize_ex", "ctl_bn_replay_running", "ctl_acc_words", "ctl_bwd_apply_pending", "ctl_bn_eval_coeffs",
+            "ctl_wgrad_bias_partial_floats", "ctl_conv_wgrad", "ctl_wgrad_reduce", "ctl_bn_finalize", "ctl_bn_finalize_ex", "ctl_bn_replay_running", "ctl_bn_eval_coeffs",
             "ctl_bn_act", "ctl_bwd_reduce", "ctl_bn_bwd_finalize", "ctl_bwd_apply", "ctl_chan_sum_finalize", "ctl_sumpool2",
             "ctl_sigmoid_bwd", "ctl_softmax_t_fwd", "ctl_softmax_t_bwd", "ctl_onehot", "ctl_ce2d_fwd", "ctl_ce2d_bwd",
             "ctl_mse_fwd", "ctl_mse_bwd", "ctl_argmax_c", "ctl_latent_score_ws_floats", "ctl_latent_score",

@@ -82,47 +82,6 @@ __device__ __forceinline__ void stq(void* __restrict__ p, int64_t i, f32x4 v, bo
     }
 }
 
-// Exact, order-independent accumulation of fp32 partial sums by many blocks WITHOUT a reduction launch: a partial is converted (truncating)
-// to a signed fixed-point integer with 2^-50 resolution and added limb-wise (52 + 64 bits) with 64-bit integer atomics -- integer addition
-// is associative, so the sum does not depend on the order in which the blocks arrive: bit-identical run to run, eager or graph, one
-// launch chain or two (double-precision float atomics would only be "almost always" identical).  Shards: block b adds into shard
-// b % CTL_ACC_SHARDS (same-address atomics serialise at ~12 ns each on this part); the reader adds the shards as integers.
-// Layout: acc[group][shard][stat (2)][channel][limb (2)] uint64, zero before the producing launch.  |partial| < 2^53 (sums of fp32
-// activations / gradients over a tile are far below); the 2^-50 resolution is below fp32's own for anything larger than 2^-26.
-#define CTL_ACC_SHARDS 8
-#define CTL_ACC_WORDS(groups, c) ((size_t)(groups) * CTL_ACC_SHARDS * 2 * (c) * 2)
-__device__ __forceinline__ void ctl_acc_add(unsigned long long* a, float p) {
-    const unsigned b = __builtin_bit_cast(unsigned, p);
-    int e = (int)((b >> 23) & 0xffu);
-    const unsigned m = (b & 0x7fffffu) | (e ? 0x800000u : 0u);
-    if (!e) e = 1;
-    int sh = e - 100;                                   // value = m * 2^(e - 150); fixed = value * 2^50 = m * 2^(e - 100)
-    if (sh > 90) sh = 90;                               // (out of the stated range: saturates deterministically)
-    __int128 x = sh >= 0 ? ((__int128)m << sh) : (__int128)(sh > -32 ? (m >> (-sh)) : 0u);
-    if (b >> 31) x = -x;
-    const unsigned long long l0 = (unsigned long long)(x & (((__int128)1 << 52) - 1));
-    const unsigned long long l1 = (unsigned long long)(long long)(x >> 52);
-    if (l0) __hip_atomic_fetch_add(a, l0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (l1) __hip_atomic_fetch_add(a + 1, l1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// the accumulated value of (stat, channel) of one group as a double: shards and limbs combined in integer arithmetic
-__device__ __forceinline__ double ctl_acc_value(const unsigned long long* __restrict__ group_base, int stat, int ch, int c) {
-    unsigned long long l0 = 0ull;
-    long long l1 = 0ll;
-#pragma unroll
-    for (int s = 0; s < CTL_ACC_SHARDS; ++s) {
-        const unsigned long long* a = group_base + (((int64_t)s * 2 + stat) * c + ch) * 2;
-        l0 += a[0];
-        l1 += (long long)a[1];
-    }
-    __int128 x = ((__int128)l1 << 52) + (__int128)l0;
-    const bool neg = x < 0;
-    if (neg) x = -x;
-    const unsigned long long hi = (unsigned long long)(x >> 64), lo = (unsigned long long)x;
-    const double v = ((double)hi * 18446744073709551616.0 + (double)lo) * 8.8817841970012523e-16;      // * 2^-50
-    return neg ? -v : v;
-}
-
 __device__ __forceinline__ double wave_sum_double(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;

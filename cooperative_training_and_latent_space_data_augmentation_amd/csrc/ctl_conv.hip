@@ -368,16 +368,12 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : ((MT * NT >= 4
 #pragma unroll
             for (int w = 0; w < 4; ++w) v += sred[((w * NT * 16) + cl) * 2 + stat];
             const int co = cot0 * 16 + cl;
-            if (flags & CTL_EPI_STATS_ACC) {        // exact integer accumulators (no finalize launch behind this one), see ctl_common.h
-                if (co < d.cout)
-                    ctl_acc_add(reinterpret_cast<unsigned long long*>(stats_partial) +
-                                ((((int64_t)grp * CTL_ACC_SHARDS + srow % CTL_ACC_SHARDS) * 2 + stat) * d.cout + co) * 2, v);
-            } else if (co < d.cout) stats_partial[(((int64_t)grp * srows + srow) * 2 + stat) * d.cout + co] = v;
+            if (co < d.cout) stats_partial[(((int64_t)grp * srows + srow) * 2 + stat) * d.cout + co] = v;
         }
         __syncthreads();
     };
     int cur_grp = (my_tiles > 0) ? cur.n / group_n : 0;
-    if ((flags & CTL_EPI_STATS) && !(flags & CTL_EPI_STATS_ACC) && ngroups > 1 && tid < NT * 16 * 2) {      // groups this block never visits contribute zeros
+    if ((flags & CTL_EPI_STATS) && ngroups > 1 && tid < NT * 16 * 2) {      // groups this block never visits contribute zeros
         const int stat = tid / (NT * 16), co = cot0 * 16 + tid % (NT * 16);
         if (co < d.cout)
             for (int gi = 0; gi < ngroups; ++gi) stats_partial[(((int64_t)gi * srows + srow) * 2 + stat) * d.cout + co] = 0.f;

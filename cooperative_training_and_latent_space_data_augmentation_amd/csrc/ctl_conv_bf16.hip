@@ -263,7 +263,6 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? CTL16_OCC_BIG : CT
     const int total_it = my_tiles * G_chunks;
     const int flags = FAST == 1 ? (d.epi_flags & (CTL_EPI_BIAS | CTL_EPI_STATS)) : (FAST == 4 ? CTL_EPI_STATS : (FAST ? (d.epi_flags & CTL_EPI_BIAS) : d.epi_flags));
     const bool y16 = FAST || (d.dt & CTL_DT_Y16) != 0, r16 = (d.dt & CTL_DT_RES16) != 0;
-    const bool flags_acc = (d.epi_flags & CTL_EPI_STATS_ACC) != 0;      // statistics into exact integer accumulators instead of partial rows
     const int yes = y16 ? 2 : 4, res_es = r16 ? 2 : 4;
     const int ngroups = d.groups > 1 ? d.groups : 1;
     const int group_n = d.n / ngroups;
@@ -413,16 +412,12 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? CTL16_OCC_BIG : CT
 #pragma unroll
             for (int w = 0; w < 4; ++w) v += sred[((w * NT * 16) + cl) * 2 + stat];
             const int co = cot0 * 16 + cl;
-            if (flags_acc) {
-                if (co < d.cout)
-                    ctl_acc_add(reinterpret_cast<unsigned long long*>(stats_partial) +
-                                ((((int64_t)grp * CTL_ACC_SHARDS + srow % CTL_ACC_SHARDS) * 2 + stat) * d.cout + co) * 2, v);
-            } else if (co < d.cout) stats_partial[(((int64_t)grp * srows + srow) * 2 + stat) * d.cout + co] = v;
+            if (co < d.cout) stats_partial[(((int64_t)grp * srows + srow) * 2 + stat) * d.cout + co] = v;
         }
         __syncthreads();
     };
     int cur_grp = (my_tiles > 0) ? cur.n / group_n : 0;
-    if ((flags & CTL_EPI_STATS) && !flags_acc && ngroups > 1 && tid < NT * 16 * 2) {
+    if ((flags & CTL_EPI_STATS) && ngroups > 1 && tid < NT * 16 * 2) {
         const int stat = tid / (NT * 16), co = cot0 * 16 + tid % (NT * 16);
         if (co < d.cout)
             for (int gi = 0; gi < ngroups; ++gi) stats_partial[(((int64_t)gi * srows + srow) * 2 + stat) * d.cout + co] = 0.f;

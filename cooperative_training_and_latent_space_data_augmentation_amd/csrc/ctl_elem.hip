@@ -156,7 +156,7 @@ __global__ __launch_bounds__(EB) void bwd_reduce_kernel(const void* __restrict__
                                                          const f32x4* __restrict__ scale,
                                                          const f32x4* __restrict__ shift, float slope, int64_t quads,
                                                          int cq, float* __restrict__ partial, unsigned m,      // m: bit 0 dy, 1 act_src, 2 bn_src, 3 ds
-                                                         void* __restrict__ ds_, unsigned long long* __restrict__ acc) {
+                                                         void* __restrict__ ds_) {
     // blockIdx.y = BatchNorm group: `quads` is the size of one group, its data start at blockIdx.y * quads
     __shared__ f32x4 sm[2][EB];
     const int64_t gtid = (int64_t)blockIdx.x * EB + threadIdx.x;
@@ -198,9 +198,7 @@ __global__ __launch_bounds__(EB) void bwd_reduce_kernel(const void* __restrict__
         float v = 0.f;
         // threads with (tid % cq) == qq hold this quad (EB % cq == 0 for every cq in use)
         for (int k = qq; k < EB; k += cq) v += sm[stat][k][comp];
-        // acc: exact integer accumulators instead of a row of partial sums (no finalize launch: the apply pass sums the shards itself)
-        if (acc) ctl_acc_add(acc + ((((int64_t)blockIdx.y * CTL_ACC_SHARDS + blockIdx.x % CTL_ACC_SHARDS) * 2 + stat) * c + ch) * 2, v);
-        else partial[(((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 + stat) * c + ch] = v;
+        partial[(((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 + stat) * c + ch] = v;
     }
 }
 
@@ -224,40 +222,14 @@ __global__ __launch_bounds__(EB) void bn_bwd_finalize_kernel(const float* __rest
     }
 }
 
-// BatchNorm-backward coefficients computed by the APPLY pass itself from the exact accumulators its reduction filled (no finalize launch
-// between the two): every block sums the shards of every channel (a few KB from L2) and keeps A, B, C in LDS; block 0 also writes
-// dgamma / dbeta (groups in order, `accumulate` like ctl_bn_bwd_finalize).  groups * c <= CTL_PEND_MAX.
-#define CTL_PEND_MAX 256
-struct ctl_bnb_pend {
-    const unsigned long long* acc; const float* gamma; const float* save_mean; const float* save_invstd; float* dgamma; float* dbeta;
-    double count; int accumulate;
-};
-__device__ __forceinline__ void bnb_pending_coefs(const ctl_bnb_pend& p, int c, int groups, float* __restrict__ cfs) {
-    for (int ch = threadIdx.x; ch < c; ch += EB) {
-        ctl_bnb_chan q = bnb_chan_load(ch, p.gamma, p.dgamma, p.dbeta, p.accumulate);
-        for (int gi = 0; gi < groups; ++gi) {
-            const unsigned long long* gb = p.acc + (int64_t)gi * CTL_ACC_SHARDS * 2 * c * 2;
-            const double s1 = ctl_acc_value(gb, 0, ch, c), s2 = ctl_acc_value(gb, 1, ch, c);
-            bn_bwd_coefs(s1, s2, p.count, c, gi, ch, q, p.save_mean[gi * c + ch], p.save_invstd[gi * c + ch], cfs,
-                         blockIdx.x == 0 ? p.dgamma : nullptr, blockIdx.x == 0 ? p.dbeta : nullptr);
-        }
-    }
-    __syncthreads();
-}
-
 template <int MODE>
 __global__ __launch_bounds__(EB) void bwd_apply_kernel(const void* __restrict__ dy, const void* __restrict__ act_src,
                                                         const void* __restrict__ bn_src,
                                                         const f32x4* __restrict__ scale,
                                                         const f32x4* __restrict__ shift, float slope,
-                                                        const f32x4* coef, int64_t quads, int cq,
+                                                        const f32x4* __restrict__ coef, int64_t quads, int cq,
                                                         void* __restrict__ ds, void* __restrict__ dx, int64_t group_quads,
-                                                        unsigned m, const ctl_bnb_pend pend) {      // m: bit 0 dy, 1 act_src, 2 bn_src, 3 ds, 4 dx
-    __shared__ __attribute__((aligned(16))) float cfs[3 * CTL_PEND_MAX];
-    if (pend.acc) {
-        bnb_pending_coefs(pend, cq * 4, (int)(quads / group_quads), cfs);
-        coef = reinterpret_cast<const f32x4*>(cfs);
-    }
+                                                        unsigned m) {      // m: bit 0 dy, 1 act_src, 2 bn_src, 3 ds, 4 dx
     const int64_t stride = (int64_t)gridDim.x * EB;
     for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < quads; i += stride) {
         const int q = (int)(i % cq);
@@ -312,7 +284,7 @@ template <int MODE>
 __global__ __launch_bounds__(EB) void bwd_reduce16_kernel(const u32x4e* __restrict__ dy, const u32x4e* __restrict__ act_src,
                                                            const u32x4e* __restrict__ bn_src, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, float slope, int64_t octs, int co,
-                                                           float* __restrict__ partial, unsigned long long* __restrict__ acc) {
+                                                           float* __restrict__ partial) {
     // blockIdx.y = BatchNorm group: `octs` is the size of one group; a thread always sees the same channel octet (256 % co == 0)
     __shared__ float sm[2][8][EB];
     const int64_t gtid = (int64_t)blockIdx.x * EB + threadIdx.x;
@@ -362,22 +334,16 @@ __global__ __launch_bounds__(EB) void bwd_reduce16_kernel(const u32x4e* __restri
         const int oo = ch >> 3, comp = ch & 7;
         float v = 0.f;
         for (int k = oo; k < EB; k += co) v += sm[stat][comp][k];
-        if (acc) ctl_acc_add(acc + ((((int64_t)blockIdx.y * CTL_ACC_SHARDS + blockIdx.x % CTL_ACC_SHARDS) * 2 + stat) * c + ch) * 2, v);
-        else partial[(((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 + stat) * c + ch] = v;
+        partial[(((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 + stat) * c + ch] = v;
     }
 }
 
 template <int MODE>
 __global__ __launch_bounds__(EB) void bwd_apply16_kernel(const u32x4e* __restrict__ dy, const u32x4e* __restrict__ act_src,
                                                           const u32x4e* __restrict__ bn_src, const float* __restrict__ scale,
-                                                          const float* __restrict__ shift, float slope, const float* coef,
+                                                          const float* __restrict__ shift, float slope, const float* __restrict__ coef,
                                                           int64_t octs, int co, u32x4e* __restrict__ ds, u32x4e* __restrict__ dx,
-                                                          int64_t group_octs, const ctl_bnb_pend pend) {
-    __shared__ __attribute__((aligned(16))) float cfs[3 * CTL_PEND_MAX];
-    if (pend.acc) {
-        bnb_pending_coefs(pend, co * 8, (int)(octs / group_octs), cfs);
-        coef = cfs;
-    }
+                                                          int64_t group_octs) {
     const int64_t stride = (int64_t)gridDim.x * EB;
     const int c = co * 8;
     for (int64_t i0 = (int64_t)blockIdx.x * EB + threadIdx.x; i0 < octs; i0 += 2 * stride) {
@@ -741,18 +707,12 @@ extern "C" int ctl_bn_act(const float* x, const float* scale, const float* shift
 static bool red_c_ok(int c) { return c >= 4 && c % 4 == 0 && (EB % (c / 4)) == 0; }
 
 extern "C" int ctl_red_blocks(void) { return CTL_RED_BLOCKS; }
-extern "C" size_t ctl_acc_words(int32_t groups, int32_t c) { return CTL_ACC_WORDS(groups > 1 ? groups : 1, c); }
 extern "C" int ctl_bwd_reduce_rows(int32_t mode, int64_t pixels_per_group, int32_t c) {
     return mode == 2 ? CTL_RED_BLOCKS : red_rows_for(pixels_per_group * (c / 4));
 }
 extern "C" int ctl_bwd_reduce_dt(int32_t mode, const float* dy, const float* act_src, const float* bn_src,
                                  const float* scale, const float* shift, float slope, int64_t pixels, int32_t c,
                                  float* partial, int32_t groups, uint32_t bf16_mask, float* ds, ctl_stream stream) {
-    // mode | CTL_RED_ACC: `partial` is a zeroed block of exact integer accumulators (CTL_ACC_WORDS(groups, c) uint64, see ctl_hip.h) instead
-    // of rows of partial sums: the apply pass (ctl_bwd_apply_pending) reads them directly, no finalize launch in between
-    unsigned long long* acc = (mode & CTL_RED_ACC) ? (unsigned long long*)partial : nullptr;
-    mode &= ~CTL_RED_ACC;
-    CTL_REQUIRE(!acc || mode != 2, "bwd_reduce: mode 2 has no accumulator form");
     CTL_REQUIRE(!ds || mode == 0, "bwd_reduce: ds (= dy * leaky'(act_src)) is an output of mode 0 only");
     CTL_REQUIRE(dy && partial && pixels > 0 && red_c_ok(c) && groups >= 1 && pixels % groups == 0, "bwd_reduce: bad arguments (c=%d)", c);
     const int64_t quads = (pixels / groups) * (c / 4);           // per group
@@ -765,20 +725,20 @@ extern "C" int ctl_bwd_reduce_dt(int32_t mode, const float* dy, const float* act
         CTL_REQUIRE(act_src && bn_src, "bwd_reduce mode 0 needs act_src and bn_src");
         if (oct)
             bwd_reduce16_kernel<0><<<grid, blk, 0, S_>>>((const u32x4e*)dy, (const u32x4e*)act_src, (const u32x4e*)bn_src, nullptr, nullptr, slope,
-                                                        quads / 2, c / 8, partial, acc);
+                                                        quads / 2, c / 8, partial);
         else
-            bwd_reduce_kernel<0><<<grid, blk, 0, S_>>>(dy, act_src, bn_src, nullptr, nullptr, slope, quads, c / 4, partial, bf16_mask, ds, acc);
+            bwd_reduce_kernel<0><<<grid, blk, 0, S_>>>(dy, act_src, bn_src, nullptr, nullptr, slope, quads, c / 4, partial, bf16_mask, ds);
     } else if (mode == 1) {
         CTL_REQUIRE(bn_src && scale && shift, "bwd_reduce mode 1 needs bn_src, scale, shift");
         if (oct)
             bwd_reduce16_kernel<1><<<grid, blk, 0, S_>>>((const u32x4e*)dy, nullptr, (const u32x4e*)bn_src, scale, shift, slope, quads / 2, c / 8,
-                                                        partial, acc);
+                                                        partial);
         else
             bwd_reduce_kernel<1><<<grid, blk, 0, S_>>>(dy, nullptr, bn_src, (const f32x4*)scale, (const f32x4*)shift, slope, quads, c / 4, partial,
-                                                      bf16_mask, nullptr, acc);
+                                                      bf16_mask, nullptr);
     } else if (mode == 2) {
         CTL_REQUIRE(groups == 1, "bwd_reduce mode 2 sums everything: groups must be 1");
-        bwd_reduce_kernel<2><<<grid, blk, 0, S_>>>(dy, nullptr, nullptr, nullptr, nullptr, slope, quads, c / 4, partial, bf16_mask, nullptr, nullptr);
+        bwd_reduce_kernel<2><<<grid, blk, 0, S_>>>(dy, nullptr, nullptr, nullptr, nullptr, slope, quads, c / 4, partial, bf16_mask, nullptr);
     } else {
         CTL_FAIL(CTL_EINVAL, "bwd_reduce: mode %d", mode);
     }
@@ -800,12 +760,10 @@ extern "C" int ctl_bn_bwd_finalize(const float* partial, int32_t c, int64_t coun
     CTL_LAUNCH_CHECK("bn_bwd_finalize");
     return CTL_OK;
 }
-static int bwd_apply_launch(int32_t mode, const float* dy, const float* act_src, const float* bn_src,
-                            const float* scale, const float* shift, float slope, const float* coef, const ctl_bnb_pend& pend, int64_t pixels,
-                            int32_t c, float* ds, float* dx, int32_t groups, uint32_t bf16_mask, ctl_stream stream) {
-    CTL_REQUIRE(dy && bn_src && (coef || pend.acc) && dx && pixels > 0 && c % 4 == 0 && groups >= 1 && pixels % groups == 0, "bwd_apply: bad arguments");
-    CTL_REQUIRE(!pend.acc || (groups * c <= CTL_PEND_MAX && pend.gamma && pend.save_mean && pend.save_invstd && pend.count > 0),
-                "bwd_apply (pending coefficients): groups * c <= %d, gamma / save_mean / save_invstd / count needed", CTL_PEND_MAX);
+extern "C" int ctl_bwd_apply_dt(int32_t mode, const float* dy, const float* act_src, const float* bn_src,
+                                const float* scale, const float* shift, float slope, const float* coef, int64_t pixels,
+                                int32_t c, float* ds, float* dx, int32_t groups, uint32_t bf16_mask, ctl_stream stream) {
+    CTL_REQUIRE(dy && bn_src && coef && dx && pixels > 0 && c % 4 == 0 && groups >= 1 && pixels % groups == 0, "bwd_apply: bad arguments");
     const int64_t quads = pixels * (c / 4);
     const dim3 grid(stream_blocks(quads)), blk(EB);
     // every tensor stored as bf16 and whole channel octets: 16 bytes per lane (mask bits: 0 dy, 1 act_src, 2 bn_src, 3 ds, 4 dx)
@@ -816,47 +774,30 @@ static int bwd_apply_launch(int32_t mode, const float* dy, const float* act_src,
         CTL_REQUIRE(act_src, "bwd_apply mode 0 needs act_src");
         if (oct)
             bwd_apply16_kernel<0><<<grid8, blk, 0, S_>>>((const u32x4e*)dy, (const u32x4e*)act_src, (const u32x4e*)bn_src, nullptr, nullptr, slope,
-                                                        coef, quads / 2, c / 8, (u32x4e*)ds, (u32x4e*)dx, quads / 2 / groups, pend);
+                                                        coef, quads / 2, c / 8, (u32x4e*)ds, (u32x4e*)dx, quads / 2 / groups);
         else
             bwd_apply_kernel<0><<<grid, blk, 0, S_>>>(dy, act_src, bn_src, nullptr, nullptr, slope, (const f32x4*)coef, quads, c / 4, ds, dx,
-                                                     quads / groups, bf16_mask, pend);
+                                                     quads / groups, bf16_mask);
     } else if (mode == 1) {
         CTL_REQUIRE(scale && shift, "bwd_apply mode 1 needs scale and shift");
         if (oct)
             bwd_apply16_kernel<1><<<grid8, blk, 0, S_>>>((const u32x4e*)dy, nullptr, (const u32x4e*)bn_src, scale, shift, slope, coef, quads / 2,
-                                                        c / 8, nullptr, (u32x4e*)dx, quads / 2 / groups, pend);
+                                                        c / 8, nullptr, (u32x4e*)dx, quads / 2 / groups);
         else
             bwd_apply_kernel<1><<<grid, blk, 0, S_>>>(dy, nullptr, bn_src, (const f32x4*)scale, (const f32x4*)shift, slope, (const f32x4*)coef, quads,
-                                                     c / 4, nullptr, dx, quads / groups, bf16_mask, pend);
+                                                     c / 4, nullptr, dx, quads / groups, bf16_mask);
     } else if (mode == 2) {
         if (oct)
             bwd_apply16_kernel<2><<<grid8, blk, 0, S_>>>((const u32x4e*)dy, nullptr, (const u32x4e*)bn_src, nullptr, nullptr, slope, coef, quads / 2,
-                                                        c / 8, nullptr, (u32x4e*)dx, quads / 2 / groups, pend);
+                                                        c / 8, nullptr, (u32x4e*)dx, quads / 2 / groups);
         else
             bwd_apply_kernel<2><<<grid, blk, 0, S_>>>(dy, nullptr, bn_src, nullptr, nullptr, slope, (const f32x4*)coef, quads, c / 4, nullptr, dx,
-                                                     quads / groups, bf16_mask, pend);
+                                                     quads / groups, bf16_mask);
     } else {
         CTL_FAIL(CTL_EINVAL, "bwd_apply: mode %d", mode);
     }
     CTL_LAUNCH_CHECK("bwd_apply");
     return CTL_OK;
-}
-extern "C" int ctl_bwd_apply_dt(int32_t mode, const float* dy, const float* act_src, const float* bn_src,
-                                const float* scale, const float* shift, float slope, const float* coef, int64_t pixels,
-                                int32_t c, float* ds, float* dx, int32_t groups, uint32_t bf16_mask, ctl_stream stream) {
-    CTL_REQUIRE(coef, "bwd_apply: coef is NULL");
-    return bwd_apply_launch(mode, dy, act_src, bn_src, scale, shift, slope, coef, ctl_bnb_pend{}, pixels, c, ds, dx, groups, bf16_mask, stream);
-}
-extern "C" int ctl_bwd_apply_pending(int32_t mode, const float* dy, const float* act_src, const float* bn_src,
-                                     const float* scale, const float* shift, float slope, const void* acc, const float* gamma,
-                                     const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, int64_t count,
-                                     int32_t accumulate, int64_t pixels, int32_t c, float* ds, float* dx, int32_t groups,
-                                     uint32_t bf16_mask, ctl_stream stream) {
-    CTL_REQUIRE(acc, "bwd_apply_pending: acc is NULL");
-    ctl_bnb_pend p;
-    p.acc = (const unsigned long long*)acc; p.gamma = gamma; p.save_mean = save_mean; p.save_invstd = save_invstd; p.dgamma = dgamma; p.dbeta = dbeta;
-    p.count = (double)count; p.accumulate = accumulate;
-    return bwd_apply_launch(mode, dy, act_src, bn_src, scale, shift, slope, nullptr, p, pixels, c, ds, dx, groups, bf16_mask, stream);
 }
 extern "C" int ctl_bwd_apply(int32_t mode, const float* dy, const float* act_src, const float* bn_src,
                              const float* scale, const float* shift, float slope, const float* coef, int64_t pixels,

@@ -264,11 +264,6 @@ extern "C" int ctl_plan_run(const ctl_op* ops, int32_t n_ops, void* const* bases
             case CTL_OP_BWD_APPLY:
                 rc = ctl_bwd_apply_dt(op.i[0], CF(0), CF(1), CF(2), CF(3), CF(4), op.f[0], CF(5), op.l[0], op.i[1], F(6), F(7), NG(op.i[2]), (uint32_t)op.i[25], stream);
                 break;
-            case CTL_OP_BWD_APPLY_PENDING:     // 0 dy 1 act_src 2 bn_src 3 scale 4 shift 5 acc 6 ds 7 dx 8 gamma 9 save_mean 10 save_invstd 11 dgamma
-                                               // i[0]=mode i[1]=c i[2]=groups i[3]=accumulate l[0]=pixels l[1]=count per group l[2]=dbeta - dgamma (floats) f[0]=slope
-                rc = ctl_bwd_apply_pending(op.i[0], CF(0), CF(1), CF(2), CF(3), CF(4), op.f[0], t[5], CF(8), CF(9), CF(10), F(11),
-                                           t[11] ? F(11) + op.l[2] : nullptr, op.l[1], op.i[3], op.l[0], op.i[1], F(6), F(7), NG(op.i[2]), (uint32_t)op.i[25], stream);
-                break;
             case CTL_OP_CHAN_SUM_FINALIZE:
                 rc = ctl_chan_sum_finalize(CF(0), op.i[0], F(1), op.i[1], stream);
                 break;

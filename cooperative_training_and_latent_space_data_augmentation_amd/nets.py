@@ -42,9 +42,6 @@ SMALL_CIN = True         # K-packed taps for the Cin <= 4 first layers
 PHASE_CONVS = True       # 2x2 phase forms of the up-sampled forward / stride-2 data gradient
 FUSE_BNBWD = False       # BN1-backward reduction inside the dgrad conv epilogue (fp32: matrix-bound kernel, measured no gain)
 FUSE_BNBWD16 = True      # the same in the bf16 family, where the data gradient is not matrix-bound
-PENDING_BWD = True       # BatchNorm-backward sums into exact integer accumulators (CTL_RED_ACC / CTL_EPI_STATS_ACC); the apply pass computes its
-                         # own coefficients (ctl_bwd_apply_pending): no BN_BWD_FINALIZE launch between reduction and apply
-ACC_RESERVE = 1 << 20    # bytes at the head of a backward arena that hold those accumulators (zeroed by ONE memset per plan run)
 FUSE_TAIL = True         # fp32: the residual tail's BatchNorm-backward reduction inside the launch that writes dOut (CTL_EPI_TAILBWD): dOut is
                          # never materialised, the stand-alone reduction launch (read dOut, out, v; write dS) disappears
 CONV_WORDS = _ffi.CONV_DTYPE.itemsize // 4      # ctl_conv as int32 words at the head of ctl_op.i
@@ -156,25 +153,10 @@ class PlanBuilder:
         self.b16 = bool(getattr(net, "bf16", False))
         self.act = Arena(S_ACT, self.b16)
         self.bscr = Arena(S_BSCR, self.b16)
-        self.bscr.size = ACC_RESERVE if PENDING_BWD else 0        # the head of the backward arena: exact accumulators
         self.scr_bytes = 0
         self.reduce_recs: List[list] = []     # batched wgrad reduction records (one launch at the end of the plan)
         self.table: Optional[np.ndarray] = None
         self.bn_log: List[tuple] = []         # (BNInfo, coefficient refs) of every training-mode BatchNorm of a forward plan, in order
-        self.acc_used, self.acc_zero_op = 0, None      # exact accumulators at the head of the backward arena (see PENDING_BWD)
-
-    def acc_alloc(self, c: int):
-        """A zeroed block of exact accumulators [groups][8 shards][2][c][2] uint64 in the head of the backward arena."""
-        if self.acc_zero_op is None:
-            if self.bscr.size != 0 and self.bscr.size < ACC_RESERVE:
-                raise _ffi.CtlError("accumulators must be reserved before the first backward-arena allocation")
-            self.acc_zero_op = self.op(_ffi.OP_ZERO)           # (size patched in finish())
-            self.set_t(self.acc_zero_op, 0, (S_BSCR, 0))
-        off = self.acc_used
-        self.acc_used += _rup(8 * int(lib.ctl_acc_words(self.groups, c)), 256)
-        if self.acc_used > ACC_RESERVE:
-            raise _ffi.CtlError("backward plan needs more accumulator space than ACC_RESERVE")
-        return (S_BSCR, off)
 
     # -- low level
     def op(self, kind: int) -> np.ndarray:
@@ -251,18 +233,11 @@ class PlanBuilder:
         if self.b16:        # bf16 MFMA family; which of x / y / res is STORED as bf16 follows from where the tensor lives
             assert bnbwd is None or (x.b16 and out.b16 and bnbwd[0].b16), "CTL_EPI_BNBWD (bf16): x, y and u must be bf16-stored"
             dt = _ffi.DT_BF16 | (_ffi.DT_X16 if x.b16 else 0) | (_ffi.DT_Y16 if out.b16 else 0) | (_ffi.DT_RES16 if res is not None and res[0].b16 else 0)
-        stats_ref, blocks = None, 0
-        if stats and PENDING_BWD and (bnbwd is not None or tail is not None) and self.groups * cout <= 256:
-            # BatchNorm-backward sums of a data-gradient launch: exact accumulators, read by the apply pass directly (blocks = -1 marks
-            # them).  Allocated BEFORE the op is appended: the first allocation emits the plan's accumulator memset.
-            flags |= _ffi.EPI_STATS_ACC
-            stats_ref, blocks = self.acc_alloc(cout), -1
         d = self._conv_desc(x, cout, ks, stride, in_mode, hout, wout, pro, flags, act, slope, nsub, pad, dt)
         op = self.op(_ffi.OP_CONV)
         op["i"][:CONV_WORDS] = np.frombuffer(d.tobytes(), dtype="<i4")
-        if blocks == -1:
-            pass
-        elif stats:
+        stats_ref, blocks = None, 0
+        if stats:
             blocks = lib.ctl_conv_stats_blocks(_ffi.desc_ptr(d))
             if blocks <= 0:
                 raise _ffi.CtlError("conv plan: " + lib.ctl_last_error().decode())
@@ -353,8 +328,6 @@ class PlanBuilder:
                     dx: T, affine_grad: bool):
         """reduce -> finalize -> apply.  mode_kind 0 = residual tail, 1 = BN->activation tail."""
         c, pixels, G = bn_src.c, bn_src.n * bn_src.h * bn_src.w, self.groups
-        if PENDING_BWD and G * c <= 256:
-            return self._bn_backward_pending(mode_kind, dy, act_src, bn_src, bn, co, slope, ds=ds, dx=dx, affine_grad=affine_grad)
         part, = self.scr(4 * G * _ffi.RED_BLOCKS * 2 * c)
         coef = self.bscr.alloc(4 * 3 * c * G)
         # residual tail (mode 0), fp32: the reduction also writes ds = dy * leaky'(act_src) (it has it in registers), and the apply pass
@@ -390,41 +363,8 @@ class PlanBuilder:
                                    ds.ref if ds else None, dx.ref]):
             self.set_t(op, idx, ref)
 
-    def _apply_pending(self, mode, dy: T, act_src: Optional[T], bn_src: T, bn: BNInfo, co, slope, acc_ref, *, ds: Optional[T], dx: T, affine_grad: bool):
-        """CTL_OP_BWD_APPLY_PENDING: the apply pass that computes A, B, C (and dgamma / dbeta) itself from the exact accumulators at acc_ref."""
-        c, pixels, G = bn_src.c, bn_src.n * bn_src.h * bn_src.w, self.groups
-        op = self.op(_ffi.OP_BWD_APPLY_PENDING)
-        op["i"][0], op["i"][1], op["i"][2], op["i"][3] = mode, c, G, 0
-        op["i"][25] = self.mask(dy, act_src, bn_src, ds, dx)
-        op["l"][0], op["l"][1], op["l"][2] = pixels, pixels // G, bn.b_off - bn.g_off
-        op["f"][0] = slope
-        for idx, ref in enumerate([dy.ref, act_src.ref if act_src else None, bn_src.ref, co["scale"] if mode == 1 else None,
-                                   co["shift"] if mode == 1 else None, acc_ref, ds.ref if ds else None, dx.ref, self.P(bn.g_off), co["mean"],
-                                   co["invstd"], self.G(bn.g_off) if affine_grad else None]):
-            self.set_t(op, idx, ref)
-
-    def _bn_backward_pending(self, mode_kind: int, dy: T, act_src: Optional[T], bn_src: T, bn: BNInfo, co, slope, *, ds, dx, affine_grad):
-        """reduce (into exact accumulators) -> apply (computes its own coefficients): two launches instead of three."""
-        c, pixels, G = bn_src.c, bn_src.n * bn_src.h * bn_src.w, self.groups
-        acc = self.acc_alloc(c)
-        ds_early = mode_kind == 0 and ds is not None and not self.b16
-        op = self.op(_ffi.OP_BWD_REDUCE)
-        op["i"][0], op["i"][1], op["i"][2] = mode_kind | _ffi.RED_ACC, c, G
-        op["i"][25] = self.mask(dy, act_src, bn_src)
-        op["l"][0] = pixels
-        op["f"][0] = slope
-        for idx, ref in enumerate([dy.ref, act_src.ref if act_src else None, bn_src.ref, co["scale"], co["shift"], acc,
-                                   ds.ref if ds_early else None]):
-            self.set_t(op, idx, ref)
-        if ds_early:
-            self._apply_pending(2, ds, None, bn_src, bn, co, slope, acc, ds=None, dx=dx, affine_grad=affine_grad)
-        else:
-            self._apply_pending(mode_kind, dy, act_src, bn_src, bn, co, slope, acc, ds=ds, dx=dx, affine_grad=affine_grad)
-
     def bn_backward_from_stats(self, g: T, bn_src: T, bn: BNInfo, co, stats_ref, blocks, *, dx: T, affine_grad: bool):
         """BatchNorm backward whose reduction already happened in the producing conv (conv(..., bnbwd=...)): finalize + apply."""
-        if blocks == -1:        # the producer filled exact accumulators: the apply pass reads them itself
-            return self._apply_pending(2, g, None, bn_src, bn, co, 0.0, stats_ref, ds=None, dx=dx, affine_grad=affine_grad)
         c, pixels, G = bn_src.c, bn_src.n * bn_src.h * bn_src.w, self.groups
         coef = self.bscr.alloc(4 * 3 * c * G)
         op = self.op(_ffi.OP_BN_BWD_FINALIZE)
@@ -493,8 +433,6 @@ class PlanBuilder:
 
     def finish(self, rec=None, out_shapes=None) -> Plan:
         self.flush_wgrad_reductions()
-        if self.acc_zero_op is not None:
-            self.acc_zero_op["l"][0] = self.acc_used
         p = Plan()
         p.replay = None
         p.table_np, p.table_dev = self.table, None

@@ -31,9 +31,8 @@ enum ctl_status { CTL_OK = 0, CTL_EINVAL = -1, CTL_EUNSUPPORTED = -2, CTL_ELAUNC
  * ctl_version() with the CTL_ABI_VERSION they were written against (and ctl_sizeof_conv / ctl_sizeof_op with their struct sizes)
  * at load time and refuse to run on a mismatch.  3 = round 3: fused-finalize entry points and side lanes removed, `ds` argument of
  * ctl_bwd_reduce_dt, ctl_red_blocks().  4 = CTL_EPI_TAILBWD / ctl_conv_forward_ex (plan op CONV slot 10).
- * 5 = ctl_bn_finalize_ex (save_uvar, plan op BN_FINALIZE slot 10), ctl_bn_replay_running / CTL_OP_BN_REPLAY.
- * 6 = exact accumulators (CTL_RED_ACC, CTL_EPI_STATS_ACC, ctl_acc_words, ctl_bwd_apply_pending / CTL_OP_BWD_APPLY_PENDING). */
-#define CTL_ABI_VERSION 6
+ * 5 = ctl_bn_finalize_ex (save_uvar, plan op BN_FINALIZE slot 10), ctl_bn_replay_running / CTL_OP_BN_REPLAY. */
+#define CTL_ABI_VERSION 5
 int         ctl_version(void);
 const char* ctl_last_error(void);
 
@@ -49,8 +48,7 @@ const char* ctl_last_error(void);
 enum { CTL_IN_PLAIN = 0, CTL_IN_UP2 = 1, CTL_IN_ZINS2 = 2, CTL_IN_C4 = 3 /* plain input with <= 4 channels, 3x3 stride 1: the taps are
        K-packed (weights from ctl_pack_weights_batched mode 4); 12 MFMAs per pixel tile instead of 36 */ };
 enum { CTL_ACT_NONE = 0, CTL_ACT_LEAKY = 1, CTL_ACT_SIGMOID = 2 };
-enum { CTL_EPI_BIAS = 1, CTL_EPI_ACCUM = 2, CTL_EPI_RES = 4, CTL_EPI_STATS = 8, CTL_EPI_BNBWD = 16, CTL_EPI_TAILBWD = 32,
-       CTL_EPI_STATS_ACC = 64 /* with CTL_EPI_STATS: exact accumulators instead of partial rows, see CTL_RED_ACC */ };
+enum { CTL_EPI_BIAS = 1, CTL_EPI_ACCUM = 2, CTL_EPI_RES = 4, CTL_EPI_STATS = 8, CTL_EPI_BNBWD = 16, CTL_EPI_TAILBWD = 32 };
 
 typedef struct ctl_conv {
     int32_t n, hin, win, cin;        /* stored input tensor [n,hin,win,cin]                                   */
@@ -175,17 +173,6 @@ int ctl_bn_act(const float* x, const float* scale, const float* shift, float slo
 int ctl_bwd_reduce(int32_t mode, const float* dy, const float* act_src, const float* bn_src, const float* scale,
                    const float* shift, float slope, int64_t pixels, int32_t c, float* partial, int32_t groups,
                    ctl_stream stream);
-/* Exact accumulators instead of partial rows (round 3): `mode | CTL_RED_ACC` makes ctl_bwd_reduce_dt add its per-block sums, and
- * CTL_EPI_STATS_ACC the statistics epilogue of a convolution, into `partial` / `stats_partial` taken as a ZEROED block of
- * ctl_acc_words(groups, c) uint64: [group][8 shards][2 stats][c][2 limbs] of a signed 2^-50 fixed-point integer added with integer
- * atomics -- order-independent, hence deterministic, and readable by the consumer without a finalize launch in between:
- * ctl_bwd_apply_pending computes the coefficients A, B, C (and dgamma / dbeta, block 0) itself.  groups * c <= 256. */
-#define CTL_RED_ACC 0x100
-size_t ctl_acc_words(int32_t groups, int32_t c);
-int ctl_bwd_apply_pending(int32_t mode, const float* dy, const float* act_src, const float* bn_src, const float* scale,
-                          const float* shift, float slope, const void* acc, const float* gamma, const float* save_mean,
-                          const float* save_invstd, float* dgamma, float* dbeta, int64_t count, int32_t accumulate, int64_t pixels,
-                          int32_t c, float* ds, float* dx, int32_t groups, uint32_t bf16_mask, ctl_stream stream);
 /* rows per group that ctl_bwd_reduce* writes for this problem: min(CTL_RED_BLOCKS, max(16, ceil(quads per group / 2048))) for modes
  * 0 / 1, CTL_RED_BLOCKS for mode 2; ctl_red_blocks() returns the compiled CTL_RED_BLOCKS (bindings size their scratch with it) */
 int ctl_bwd_reduce_rows(int32_t mode, int64_t pixels_per_group, int32_t c);
@@ -335,7 +322,7 @@ enum ctl_op_kind {
     CTL_OP_CONV = 1, CTL_OP_WGRAD = 2, CTL_OP_WGRAD_REDUCE = 3, CTL_OP_PACK = 4, CTL_OP_BN_FINALIZE = 5,
     CTL_OP_BN_EVAL = 6, CTL_OP_BN_ACT = 7, CTL_OP_BWD_REDUCE = 8, CTL_OP_BN_BWD_FINALIZE = 9, CTL_OP_BWD_APPLY = 10,
     CTL_OP_CHAN_SUM_FINALIZE = 11, CTL_OP_SUMPOOL2 = 12, CTL_OP_SIGMOID_BWD = 13, CTL_OP_ZERO = 14, CTL_OP_COPY = 15, CTL_OP_PACK_BATCH = 16,
-    CTL_OP_WGRAD_REDUCE_BATCH = 17, CTL_OP_DROPOUT2D = 18, CTL_OP_BN_REPLAY = 19, CTL_OP_BWD_APPLY_PENDING = 20
+    CTL_OP_WGRAD_REDUCE_BATCH = 17, CTL_OP_DROPOUT2D = 18, CTL_OP_BN_REPLAY = 19
 };
 #define CTL_OP_MAX_T 12
 typedef struct ctl_op {
