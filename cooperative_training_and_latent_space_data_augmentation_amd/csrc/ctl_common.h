@@ -135,13 +135,13 @@ int ctl_conv_pick_cfg(const ctl_conv* d, ctl_conv_cfg* c, int for_wgrad);
 int ctl_conv_grid_x(int ntiles, int other, int occ);      // persistent grid: the resident capacity (ctl_conv.hip)
 
 // bf16 kernel family (ctl_conv_bf16.hip), reached through the public entry points when ctl_conv.dt has CTL_DT_BF16
-int ctl_conv_forward_bf16(const ctl_conv* d, const void* x, const void* wpack, const float* bias, const float* pro_scale,
-                          const float* pro_shift, const void* res, const float* res_scale, const float* res_shift, void* y,
+int ctl_conv_forward_bf16(const ctl_conv* d, const void* x, const void* x2, const void* wpack, const float* bias, const float* pro_scale,
+                          const float* pro_shift, const void* res, const float* res_scale, const float* res_shift, const void* res2, void* y,
                           float* stats_partial, ctl_stream stream);
 int ctl_conv_bf16_stats_blocks(const ctl_conv* d);
 int ctl_wgrad_bf16_splits(const ctl_conv* d);
-int ctl_conv_wgrad_bf16(const ctl_conv* d, const void* x, const float* pro_scale, const float* pro_shift, const void* dy,
-                        float* w_partial, float* b_partial, ctl_stream stream);
+int ctl_conv_wgrad_bf16(const ctl_conv* d, const void* x, const float* pro_scale, const float* pro_shift, const void* dy, const void* dy2,
+                        const float* dy_coef, float* w_partial, float* b_partial, ctl_stream stream);
 
 // in-process profiling (ctl_plan.cpp): returns a token >= 0 if this launch is being timed
 int ctl_prof_begin(const char* kind, const ctl_conv* d, const ctl_conv_cfg* c, int nt, hipStream_t stream);

@@ -1202,11 +1202,11 @@ extern "C" int ctl_conv_forward(const ctl_conv* d, const float* x, const float* 
                                 const float* pro_scale, const float* pro_shift, const float* res,
                                 const float* res_scale, const float* res_shift, float* y, float* stats_partial,
                                 ctl_stream stream) {
-    return ctl_conv_forward_ex(d, x, wpack, bias, pro_scale, pro_shift, res, res_scale, res_shift, nullptr, y, stats_partial, stream);
+    return ctl_conv_forward_ex(d, x, wpack, bias, pro_scale, pro_shift, res, res_scale, res_shift, nullptr, nullptr, y, stats_partial, stream);
 }
 extern "C" int ctl_conv_forward_ex(const ctl_conv* d, const float* x, const float* wpack, const float* bias,
                                    const float* pro_scale, const float* pro_shift, const float* res,
-                                   const float* res_scale, const float* res_shift, const float* res2, float* y,
+                                   const float* res_scale, const float* res_shift, const float* res2, const float* x2, float* y,
                                    float* stats_partial, ctl_stream stream) {
     CTL_REQUIRE(d && x && wpack && y, "conv_forward: null argument");
     CTL_REQUIRE((d->dt & CTL_DT_BF16) || !(d->dt & (CTL_DT_X16 | CTL_DT_Y16 | CTL_DT_RES16)), "conv_forward: bf16-stored tensors need CTL_DT_BF16");
@@ -1223,15 +1223,17 @@ extern "C" int ctl_conv_forward_ex(const ctl_conv* d, const float* x, const floa
     if (d->epi_flags & CTL_EPI_TAILBWD) {
         const int k = d->ks, s = d->stride, m = d->in_mode;
         CTL_REQUIRE((d->epi_flags & CTL_EPI_STATS) && res && res2 && !(d->epi_flags & (CTL_EPI_RES | CTL_EPI_BNBWD | CTL_EPI_BIAS)) &&
-                    d->epi_act == CTL_ACT_NONE && d->cout % 16 == 0 && !(d->dt & CTL_DT_BF16),
-                    "conv_forward: CTL_EPI_TAILBWD needs CTL_EPI_STATS + res (= the block output) + res2 (= the BatchNorm input), cout %% 16 == 0, fp32, nothing else but CTL_EPI_ACCUM");
+                    d->epi_act == CTL_ACT_NONE && d->cout % 16 == 0,
+                    "conv_forward: CTL_EPI_TAILBWD needs CTL_EPI_STATS + res (= the block output) + res2 (= the BatchNorm input), cout %% 16 == 0, nothing else but CTL_EPI_ACCUM");
         CTL_REQUIRE((k == 1 && m == CTL_IN_PLAIN) || k == 2 || (k == 3 && s == 1 && m == CTL_IN_ZINS2),
                     "conv_forward: CTL_EPI_TAILBWD is built for the launches that write a block's output gradient (1x1, 2x2, zero-insert 3x3)");
         CTL_REQUIRE(d->epi_slope >= 0.f && d->epi_slope <= 1.f, "conv_forward: LeakyReLU slope must be in [0, 1]");
     }
-    CTL_REQUIRE(!d->pro_affine || (pro_scale && pro_shift), "conv_forward: prologue without scale/shift");
+    CTL_REQUIRE(d->pro_affine >= 0 && d->pro_affine <= 2, "conv_forward: pro_affine must be 0, 1 or 2");
+    CTL_REQUIRE(d->pro_affine != 1 || (pro_scale && pro_shift), "conv_forward: prologue without scale/shift");
+    CTL_REQUIRE(d->pro_affine != 2 || (d->dt & CTL_DT_BF16), "conv_forward: the BatchNorm-backward prologue (pro_affine 2) exists in the bf16 family only (the fp32 kernels are VALU-bound in their staging)");
     CTL_REQUIRE(!d->pro_affine || (d->groups > 1 ? d->groups : 1) * d->cin <= CTL_PRO_MAX, "conv_forward: groups * cin = %d prologue coefficients exceed %d", (d->groups > 1 ? d->groups : 1) * d->cin, CTL_PRO_MAX);
-    CTL_REQUIRE(!d->pro_affine || (d->pro_slope >= 0.f && d->pro_slope <= 1.f), "conv_forward: prologue slope must be in [0, 1]");
+    CTL_REQUIRE(d->pro_affine != 1 || (d->pro_slope >= 0.f && d->pro_slope <= 1.f), "conv_forward: prologue slope must be in [0, 1]");
     CTL_REQUIRE(d->epi_act != CTL_ACT_LEAKY || (d->epi_slope >= 0.f && d->epi_slope <= 1.f), "conv_forward: LeakyReLU slope must be in [0, 1]");
     CTL_REQUIRE(d->n > 0 && d->hout > 0 && d->wout > 0, "conv_forward: empty problem");
     CTL_REQUIRE(d->groups >= 0 && (d->groups <= 1 || d->n % d->groups == 0), "conv_forward: n=%d is not divisible into %d groups", d->n, d->groups);
@@ -1240,7 +1242,7 @@ extern "C" int ctl_conv_forward_ex(const ctl_conv* d, const float* x, const floa
                 "conv_forward: tensors must stay below 2 GiB (32-bit buffer offsets)");
     if (d->dt & CTL_DT_BF16) {
         const int ptok16 = ctl_prof_begin("conv_igemm_bf16", d, &a.c, a.c.nt, (hipStream_t)stream);
-        rc = ctl_conv_forward_bf16(d, x, wpack, bias, pro_scale, pro_shift, res, res_scale, res_shift, y, stats_partial, stream);
+        rc = ctl_conv_forward_bf16(d, x, x2, wpack, bias, pro_scale, pro_shift, res, res_scale, res_shift, res2, y, stats_partial, stream);
         ctl_prof_end(ptok16, (hipStream_t)stream);
         return rc;
     }
@@ -1355,7 +1357,14 @@ extern "C" size_t ctl_wgrad_bias_partial_floats(const ctl_conv* d) {
 
 extern "C" int ctl_conv_wgrad(const ctl_conv* d, const float* x, const float* pro_scale, const float* pro_shift,
                               const float* dy, float* w_partial, float* b_partial, ctl_stream stream) {
+    return ctl_conv_wgrad_ex(d, x, pro_scale, pro_shift, dy, nullptr, nullptr, w_partial, b_partial, stream);
+}
+extern "C" int ctl_conv_wgrad_ex(const ctl_conv* d, const float* x, const float* pro_scale, const float* pro_shift,
+                                 const float* dy, const float* dy2, const float* dy_coef, float* w_partial, float* b_partial,
+                                 ctl_stream stream) {
     CTL_REQUIRE(d && x && dy && w_partial, "conv_wgrad: null argument");
+    CTL_REQUIRE(d->pro_affine == 0 || d->pro_affine == 1, "conv_wgrad: pro_affine must be 0 or 1");
+    CTL_REQUIRE(!dy2 || (d->dt & CTL_DT_BF16), "conv_wgrad: the two-tensor output gradient (dy2) exists in the bf16 family only");
     CTL_REQUIRE(!d->pro_affine || (pro_scale && pro_shift), "conv_wgrad: prologue without scale/shift");
     CTL_REQUIRE(!d->pro_affine || (d->groups > 1 ? d->groups : 1) * d->cin <= CTL_PRO_MAX, "conv_wgrad: groups * cin = %d prologue coefficients exceed %d", (d->groups > 1 ? d->groups : 1) * d->cin, CTL_PRO_MAX);
     CTL_REQUIRE(!d->pro_affine || (d->pro_slope >= 0.f && d->pro_slope <= 1.f), "conv_wgrad: prologue slope must be in [0, 1]");
@@ -1367,7 +1376,7 @@ extern "C" int ctl_conv_wgrad(const ctl_conv* d, const float* x, const float* pr
     if (rc != CTL_OK) return rc;
     if (d->dt & CTL_DT_BF16) {
         const int ptok16 = ctl_prof_begin("conv_wgrad_bf16", d, &w.c, w.ntw, (hipStream_t)stream);
-        rc = ctl_conv_wgrad_bf16(d, x, pro_scale, pro_shift, dy, w_partial, b_partial, stream);
+        rc = ctl_conv_wgrad_bf16(d, x, pro_scale, pro_shift, dy, dy2, dy_coef, w_partial, b_partial, stream);
         ctl_prof_end(ptok16, (hipStream_t)stream);
         return rc;
     }

@@ -48,8 +48,12 @@ __device__ __forceinline__ u32x2 ctl_bload2u(__amdgpu_buffer_rsrc_t r, int voff,
 // image the same read strides 32 B and hits half the banks twice (2-way conflict on every operand read: measured ~10 of the 17.5 us of
 // the 16->16 layer at 256^2).  The second plane starts 128 B past a multiple of 256 B so that a staging write (8 pixels x 2 planes per
 // 16 lanes) is conflict-free too.  The weight-gradient kernel keeps the interleaved image (its transposed reads want pixel rows).
-template <int KS, int S, int MODE, int MT, int TW, bool X16C = false, bool PLANAR = false>      // X16C: the source is known to be stored as bf16
+// X2 (pro_affine == 2, the BatchNorm-backward prologue): the operand is the VIRTUAL tensor  A[c] * x + B[c] * x2 + C[c]  of two bf16 tensors
+// of one geometry (x = g = dL/da * leaky', x2 = the BatchNorm input u): the `apply` pass of the BatchNorm backward runs here, in the
+// staging of its consumers, and its output tensor never exists.  Rounded to bf16 once, exactly where the stored tensor was rounded.
+template <int KS, int S, int MODE, int MT, int TW, bool X16C = false, bool PLANAR = false, bool X2 = false>      // X16C: the source is known to be stored as bf16
 struct XStage16 {
+    static_assert(!X2 || X16C, "the two-tensor prologue works on bf16-stored tensors");
     using G = Geom<KS, S, MT, TW>;
     static constexpr int UNITS = G::IH * G::IW * 2;
     static constexpr int NU = (UNITS + 255) / 256;
@@ -59,7 +63,7 @@ struct XStage16 {
     int rel[NU];        // byte offset of the unit's first source element relative to the tile's source origin
     int rc[NU];         // r | c << 16 (tile-relative virtual coordinates); 0x7fff7fff past the tile
     int lds[NU];        // LDS byte offset; units past the tile write a dump slot behind the image
-    u32x4 v0[NU], v1[NU];     // source bf16: v0 = 8 channels; source fp32: v0 = channels 0-3, v1 = 4-7 of the unit
+    u32x4 v0[NU], v1[NU];     // source bf16: v0 = 8 channels (X2: v1 = 8 channels of the second tensor); source fp32: v0 = channels 0-3, v1 = 4-7 of the unit
     unsigned vmask;
     int pad_h, pad_w;
     bool all_in, x16;
@@ -86,7 +90,8 @@ struct XStage16 {
         pad_h = pad_w = G::PAD;
     }
 
-    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rx, const ctl_conv& d, int n, int ho0, int wo0, int g) {
+    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rx, const ctl_conv& d, int n, int ho0, int wo0, int g) { load(rx, rx, d, n, ho0, wo0, g); }
+    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rx, __amdgpu_buffer_rsrc_t rx2, const ctl_conv& d, int n, int ho0, int wo0, int g) {
         const int vh0 = ho0 * S - pad_h, vw0 = wo0 * S - pad_w;
         const unsigned hv = (MODE == CTL_IN_PLAIN) ? d.hin : 2 * d.hin;
         const unsigned wv = (MODE == CTL_IN_PLAIN) ? d.win : 2 * d.win;
@@ -97,7 +102,10 @@ struct XStage16 {
         all_in = MODE != CTL_IN_ZINS2 && vh0 >= 0 && vw0 >= 0 && vh0 + G::IH <= (int)hv && vw0 + G::IW <= (int)wv &&
                  g * 16 + 16 <= d.cin;
         if (all_in) {
-            if (x16) {
+            if (X2) {
+#pragma unroll
+                for (int i = 0; i < NU; ++i) { v0[i] = ctl_bload4u(rx, rel[i], tb); v1[i] = ctl_bload4u(rx2, rel[i], tb); }
+            } else if (x16) {
 #pragma unroll
                 for (int i = 0; i < NU; ++i) v0[i] = ctl_bload4u(rx, rel[i], tb);
             } else {
@@ -119,7 +127,10 @@ struct XStage16 {
         }
         vmask = m;
         const u32x4 z = {0u, 0u, 0u, 0u};
-        if (x16) {                                  // internal tensors: cin is a multiple of 16 (checked on the host)
+        if (X2) {
+#pragma unroll
+            for (int i = 0; i < NU; ++i) { v0[i] = ctl_bload4u(rx, vo[i], 0); v1[i] = ctl_bload4u(rx2, vo[i], 0); }
+        } else if (x16) {                           // internal tensors: cin is a multiple of 16 (checked on the host)
 #pragma unroll
             for (int i = 0; i < NU; ++i) v0[i] = ctl_bload4u(rx, vo[i], 0);
         } else if (d.cin >= 4) {                    // fp32 source: quads of 4 channels, the second one may lie past cin (4 or 12 channels)
@@ -135,8 +146,25 @@ struct XStage16 {
         }
     }
 
+    // X2: cf_scale / cf_shift / cf_c hold A / B / C of the block's groups ([group][cin] each)
     __device__ __forceinline__ void store(unsigned char* __restrict__ xt, const ctl_conv& d, int g, const float* cf_scale,
-                                          const float* cf_shift, int goff) {
+                                          const float* cf_shift, int goff, const float* cf_c = nullptr) {
+        if constexpr (X2) {
+            const int cb = g * 16 + (threadIdx.x & 1) * 8;
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(cf_scale + goff + cb), a1 = *reinterpret_cast<const f32x4*>(cf_scale + goff + cb + 4);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(cf_shift + goff + cb), b1 = *reinterpret_cast<const f32x4*>(cf_shift + goff + cb + 4);
+            const f32x4 c0 = *reinterpret_cast<const f32x4*>(cf_c + goff + cb), c1 = *reinterpret_cast<const f32x4*>(cf_c + goff + cb + 4);
+            const u32x4 zero = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int i = 0; i < NU; ++i) {
+                const f32x4 glo = unpack_bf16x4(v0[i].x, v0[i].y), ghi = unpack_bf16x4(v0[i].z, v0[i].w);
+                const f32x4 ulo = unpack_bf16x4(v1[i].x, v1[i].y), uhi = unpack_bf16x4(v1[i].z, v1[i].w);
+                u32x4 pk = pack_bf16x8(a0 * glo + b0 * ulo + c0, a1 * ghi + b1 * uhi + c1);
+                if (!all_in && !((vmask >> i) & 1u)) pk = zero;      // padding stays zero (C alone would leak into it)
+                *reinterpret_cast<u32x4*>(xt + lds[i]) = pk;
+            }
+            return;
+        }
         if (!d.pro_affine && x16) {                 // bf16 in, nothing to compute: out-of-range units were loaded as hardware zeros
 #pragma unroll
             for (int i = 0; i < NU; ++i) *reinterpret_cast<u32x4*>(xt + lds[i]) = v0[i];
@@ -226,25 +254,27 @@ extern "C" int ctl_debug_timing16(unsigned long long* out12) {
 // the fp32-source half of its registers.
 // XB: the input is stored as bf16 with whole 16-channel chunks (compile-time staging); the network-boundary layers (fp32 input with 1 or 4
 // channels) take the FAST epilogues with the generic staging.
-template <int KS, int S, int MODE, int MT, int TW, int NT, int FAST, bool XB>      // FAST: 0 generic; 1 plain; 2 + bf16 residual * scale + shift (+ LeakyReLU); 3 accumulate into y
+// X2: the input is the virtual BatchNorm-backward result  A * x + B * x2 + C  (XStage16; pro_scale = the [group][3][cin] coefficients)
+template <int KS, int S, int MODE, int MT, int TW, int NT, int FAST, bool XB, bool X2 = false>      // FAST: 0 generic; 1 plain; 2 + bf16 residual * scale + shift (+ LeakyReLU); 3 accumulate into y
 __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? CTL16_OCC_BIG : CTL16_OCC) void conv_igemm_bf16_kernel(
-    const ctl_conv d, const void* __restrict__ x, const void* __restrict__ wpack, const float* __restrict__ bias,
+    const ctl_conv d, const void* __restrict__ x, const void* __restrict__ x2, const void* __restrict__ wpack, const float* __restrict__ bias,
     const float* __restrict__ pro_scale, const float* __restrict__ pro_shift, const void* __restrict__ res,
-    const float* __restrict__ res_scale, const float* __restrict__ res_shift, void* __restrict__ y, float* __restrict__ stats_partial,
-    int tiles_h, int tiles_w, int G_chunks, int64_t wpack_sub_bytes, int ntiles) {
+    const float* __restrict__ res_scale, const float* __restrict__ res_shift, const void* __restrict__ res2, void* __restrict__ y,
+    float* __restrict__ stats_partial, int tiles_h, int tiles_w, int G_chunks, int64_t wpack_sub_bytes, int ntiles) {
     using G = Geom<KS, S, MT, TW>;
-    using XS = XStage16<KS, S, MODE, MT, TW, XB, true>;
+    using XS = XStage16<KS, S, MODE, MT, TW, XB, true, X2>;
     constexpr int TAPS = KS * KS;
     constexpr int NFRAG = NFRAG_OF(KS);
     constexpr int XT_ALLOC = XS::XT_BYTES + 16;            // + dump slot
     constexpr int WT_BYTES = NFRAG * NT * 1024;
     constexpr int RED_FLOATS = 4 * NT * 16 * 2;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[XT_ALLOC + WT_BYTES + (RED_FLOATS + 2 * CTL_PRO_MAX) * 4];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[XT_ALLOC + WT_BYTES + (RED_FLOATS + (X2 ? 3 : 2) * CTL_PRO_MAX) * 4];
     unsigned char* xt = smem;
     unsigned char* wt = smem + XT_ALLOC;
     float* sred = reinterpret_cast<float*>(wt + WT_BYTES);
     float* cf_scale = sred + RED_FLOATS;
     float* cf_shift = cf_scale + CTL_PRO_MAX;
+    float* cf_c = cf_shift + (X2 ? CTL_PRO_MAX : 0);
     constexpr int WU = NFRAG * NT * 64, NW = (WU + 255) / 256;
 
     const int tid = threadIdx.x;
@@ -261,16 +291,18 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? CTL16_OCC_BIG : CT
     const unsigned char* wp = reinterpret_cast<const unsigned char*>(wpack) + (int64_t)z * wpack_sub_bytes;
     const int my_tiles = (bid0 < t_hi) ? (t_hi - bid0 + nb - 1) / nb : 0;
     const int total_it = my_tiles * G_chunks;
-    const int flags = FAST == 1 ? (d.epi_flags & (CTL_EPI_BIAS | CTL_EPI_STATS)) : (FAST == 4 ? CTL_EPI_STATS : (FAST ? (d.epi_flags & CTL_EPI_BIAS) : d.epi_flags));
+    const int flags = FAST == 1 ? (d.epi_flags & (CTL_EPI_BIAS | CTL_EPI_STATS)) : ((FAST == 4 || FAST == 5) ? CTL_EPI_STATS : (FAST ? (d.epi_flags & CTL_EPI_BIAS) : d.epi_flags));
     const bool y16 = FAST || (d.dt & CTL_DT_Y16) != 0, r16 = (d.dt & CTL_DT_RES16) != 0;
     const int yes = y16 ? 2 : 4, res_es = r16 ? 2 : 4;
     const int ngroups = d.groups > 1 ? d.groups : 1;
     const int group_n = d.n / ngroups;
     const int oy0 = (z >> 1) * d.out_sub, ox0 = (z & 1) * d.out_sub;
     const __amdgpu_buffer_rsrc_t rx = ctl_rsrc(x, (int64_t)d.n * d.hin * d.win * d.cin * ((XB || (d.dt & CTL_DT_X16)) ? 2 : 4));
+    const __amdgpu_buffer_rsrc_t rx2 = X2 ? ctl_rsrc(x2, (int64_t)d.n * d.hin * d.win * d.cin * 2) : rx;
     const int64_t ypix = (int64_t)d.n * d.out_h * d.out_w * d.cout;
     const __amdgpu_buffer_rsrc_t ry = ctl_rsrc(y, ypix * yes);
     const __amdgpu_buffer_rsrc_t rres = ctl_rsrc(res ? res : y, ypix * (res ? res_es : yes));
+    const __amdgpu_buffer_rsrc_t rres2 = FAST == 5 ? ctl_rsrc(res2, ypix * 2) : ry;
 
     f32x4 ssum[NT], ssq[NT];
 #pragma unroll
@@ -350,15 +382,21 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? CTL16_OCC_BIG : CT
     nxt = cur;
     TM_DECL
     if (total_it > 0) {
-        xs.load(rx, d, cur.n, cur.th * G::TH, cur.tw * TW, 0);
+        xs.load(rx, rx2, d, cur.n, cur.th * G::TH, cur.tw * TW, 0);
         wload(0);
     }
-    if (d.pro_affine) {
+    if constexpr (X2) {          // coefficients as the BatchNorm-backward finalize writes them: [group][A | B | C][cin]
+        for (int i = tid; i < ngroups * d.cin; i += 256) {
+            const int gi = i / d.cin, ch = i - gi * d.cin;
+            cf_scale[i] = pro_scale[(gi * 3 + 0) * d.cin + ch]; cf_shift[i] = pro_scale[(gi * 3 + 1) * d.cin + ch]; cf_c[i] = pro_scale[(gi * 3 + 2) * d.cin + ch];
+        }
+        __syncthreads();
+    } else if (d.pro_affine) {
         for (int i = tid; i < ngroups * d.cin; i += 256) { cf_scale[i] = pro_scale[i]; cf_shift[i] = pro_shift[i]; }
         __syncthreads();
     }
     if (total_it > 0) {
-        xs.store(xt, d, 0, cf_scale, cf_shift, (cur.n / group_n) * d.cin);
+        xs.store(xt, d, 0, cf_scale, cf_shift, (cur.n / group_n) * d.cin, cf_c);
         wstore();
     }
     __syncthreads();
@@ -370,7 +408,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? CTL16_OCC_BIG : CT
     auto advance_nn = [&]() { gn = (gn + 1 == G_chunks) ? 0 : gn + 1; if (gn == 0) nn.next(); };
     if (total_it > 1) {
         advance_nn();
-        xs.load(rx, d, nn.n, nn.th * G::TH, nn.tw * TW, gn);
+        xs.load(rx, rx2, d, nn.n, nn.th * G::TH, nn.tw * TW, gn);
         if (G_chunks > 1) wload(gn);
     }
 
@@ -496,7 +534,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? CTL16_OCC_BIG : CT
         ctl_barrier_lds_reads_done();
         TM(2)
         if (has_next) {
-            xs.store(xt, d, g2, cf_scale, cf_shift, (nxt.n / group_n) * d.cin);
+            xs.store(xt, d, g2, cf_scale, cf_shift, (nxt.n / group_n) * d.cin, cf_c);
             if (new_w) wstore();
         }
         TM(3)
@@ -504,7 +542,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? CTL16_OCC_BIG : CT
         TM(4)
         if (it + 2 < total_it) {       // step it+2: its loads have the whole next step to land
             advance_nn();
-            if (!(CTL16_ABLATE & 2)) xs.load(rx, d, nn.n, nn.th * G::TH, nn.tw * TW, gn);
+            if (!(CTL16_ABLATE & 2)) xs.load(rx, rx2, d, nn.n, nn.th * G::TH, nn.tw * TW, gn);
             if (G_chunks > 1) wload(gn);
         }
 
@@ -547,6 +585,39 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? CTL16_OCC_BIG : CT
                         v.x *= sa.x > 0.f ? 1.f : sl; v.y *= sa.y > 0.f ? 1.f : sl;
                         v.z *= sa.z > 0.f ? 1.f : sl; v.w *= sa.w > 0.f ? 1.f : sl;
                         if (bo[m] != CTL_OOB) { ssum[t] += v; ssq[t] += v * u; }
+                        __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)}, ry,
+                                                              bo[m] == CTL_OOB ? CTL_OOB : bo[m] + t * 32, 0, CTL_STORE_AUX);
+                    }
+            } else if constexpr (FAST == 5) {
+                // CTL_EPI_TAILBWD on bf16 tensors: this launch produces dL/dOut of a residual block (+ the half already in y with
+                // CTL_EPI_ACCUM).  Write g = dOut * leaky'(out) (res = the stored block output) and take the tail's BatchNorm-backward
+                // sums (sum g, sum g*v; res2 = v) from the unrounded g: the reduction pass over dOut, out and v disappears, and dOut
+                // is never rounded on its own
+                const bool accum = (d.epi_flags & CTL_EPI_ACCUM) != 0;
+                int bo[MT];
+                u32x2 oq[MT][NT], vq[MT][NT], yq[MT][NT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const bool pv = full || ((ho0 + wrow + m / TWT < d.hout) && (wo0 + (m % TWT) * 16 + p < d.wout));
+                    bo[m] = pv ? (ybase + yrel[m]) * 2 : CTL_OOB;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const int o = bo[m] == CTL_OOB ? CTL_OOB : bo[m] + t * 32;
+                        oq[m][t] = ctl_bload2u(rres, o, 0);
+                        vq[m][t] = ctl_bload2u(rres2, o, 0);
+                        yq[m][t] = accum ? ctl_bload2u(ry, o, 0) : u32x2{0u, 0u};
+                    }
+                }
+                const float sl = d.epi_slope;
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        f32x4 v = acc[m][t] + unpack_bf16x4(yq[m][t].x, yq[m][t].y);
+                        const f32x4 o = unpack_bf16x4(oq[m][t].x, oq[m][t].y), r2 = unpack_bf16x4(vq[m][t].x, vq[m][t].y);
+                        v.x *= o.x > 0.f ? 1.f : sl; v.y *= o.y > 0.f ? 1.f : sl;
+                        v.z *= o.z > 0.f ? 1.f : sl; v.w *= o.w > 0.f ? 1.f : sl;
+                        if (bo[m] != CTL_OOB) { ssum[t] += v; ssq[t] += v * r2; }
                         __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)}, ry,
                                                               bo[m] == CTL_OOB ? CTL_OOB : bo[m] + t * 32, 0, CTL_STORE_AUX);
                     }
@@ -770,16 +841,16 @@ extern "C" int ctl_pack_weights_bf16_batched(const float* params, float* wpack, 
 // ------------------------------------------------------------------------------------------------ host side
 struct conv16_call {
     const ctl_conv* d; ctl_conv_cfg c;
-    const void *x, *wpack, *res; void* y;
+    const void *x, *x2, *wpack, *res, *res2; void* y;
     const float *bias, *pro_scale, *pro_shift, *res_scale, *res_shift; float* stats_partial;
     hipStream_t stream; bool query; int grid_x;
 };
-template <int KS, int S, int MODE, int MT, int TW, int NT, int FAST, bool XB>
+template <int KS, int S, int MODE, int MT, int TW, int NT, int FAST, bool XB, bool X2 = false>
 static void conv16_go_f(conv16_call& a) {
     static int occ = 0;
     if (!occ) {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_igemm_bf16_kernel<KS, S, MODE, MT, TW, NT, FAST, XB>, 256, 0) != hipSuccess || n < 1) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_igemm_bf16_kernel<KS, S, MODE, MT, TW, NT, FAST, XB, X2>, 256, 0) != hipSuccess || n < 1) {
             (void)hipGetLastError();
             n = 2;
         }
@@ -790,8 +861,8 @@ static void conv16_go_f(conv16_call& a) {
     a.grid_x = ctl_conv_grid_x(ntiles, (a.c.cot / NT) * d->nsub, occ);
     if (a.query) return;
     const dim3 grid((unsigned)a.grid_x, (unsigned)(a.c.cot / NT), (unsigned)d->nsub);
-    conv_igemm_bf16_kernel<KS, S, MODE, MT, TW, NT, FAST, XB><<<grid, dim3(256), 0, a.stream>>>(
-        *d, a.x, a.wpack, a.bias, a.pro_scale, a.pro_shift, a.res, a.res_scale, a.res_shift, a.y, a.stats_partial, a.c.tiles_h, a.c.tiles_w,
+    conv_igemm_bf16_kernel<KS, S, MODE, MT, TW, NT, FAST, XB, X2><<<grid, dim3(256), 0, a.stream>>>(
+        *d, a.x, a.x2, a.wpack, a.bias, a.pro_scale, a.pro_shift, a.res, a.res_scale, a.res_shift, a.res2, a.y, a.stats_partial, a.c.tiles_h, a.c.tiles_w,
         a.c.g, (int64_t)ctl_conv_wpack_floats(d->cin, d->cout, d->ks) * 4, ntiles);
 }
 template <int KS, int S, int MODE, int MT, int TW, int NT>
@@ -806,7 +877,21 @@ static void conv16_go(conv16_call& a) {
     if (o16 && !(e & ~CTL_EPI_STATS) && d->epi_act == CTL_ACT_NONE) fast = 1;
     else if (o16 && e == CTL_EPI_RES && (d->dt & CTL_DT_RES16) && (d->epi_act == CTL_ACT_NONE || d->epi_act == CTL_ACT_LEAKY)) fast = 2;
     else if (o16 && e == CTL_EPI_ACCUM && d->epi_act == CTL_ACT_NONE) fast = 3;
+    if (d->pro_affine == 2) {      // the BatchNorm-backward prologue: the data-gradient convs that consume a block's dU / dV (checked in ctl_conv_forward_bf16)
+        if constexpr ((KS == 3 && S == 1 && MODE == CTL_IN_PLAIN) || (KS == 4 && S == 2)) {
+            if (d->epi_flags & CTL_EPI_BNBWD) conv16_go_f<KS, S, MODE, MT, TW, NT, 4, true, true>(a);
+            else conv16_go_f<KS, S, MODE, MT, TW, NT, 1, true, true>(a);
+        }
+        return;
+    }
     if (d->epi_flags & CTL_EPI_BNBWD) { conv16_go_f<KS, S, MODE, MT, TW, NT, 4, true>(a); return; }      // (checked in ctl_conv_forward_bf16)
+    if (d->epi_flags & CTL_EPI_TAILBWD) {       // the launches that write a block's output gradient (checked in ctl_conv_forward_ex)
+        if constexpr ((KS == 1 && MODE == CTL_IN_PLAIN) || KS == 2 || (KS == 3 && S == 1 && MODE == CTL_IN_ZINS2)) {
+            if (xb) conv16_go_f<KS, S, MODE, MT, TW, NT, 5, true>(a);
+            else if constexpr (KS == 1) conv16_go_f<KS, S, MODE, MT, TW, NT, 5, false>(a);      // (the 1x1 data gradient of a network's fp32 output layer)
+        }
+        return;
+    }
     if (xb) {
         if (fast == 1) conv16_go_f<KS, S, MODE, MT, TW, NT, 1, true>(a);
         else if (fast == 2) conv16_go_f<KS, S, MODE, MT, TW, NT, 2, true>(a);
@@ -858,9 +943,20 @@ int ctl_conv_bf16_stats_blocks(const ctl_conv* d) {
     return a.grid_x * d->nsub;
 }
 
-int ctl_conv_forward_bf16(const ctl_conv* d, const void* x, const void* wpack, const float* bias, const float* pro_scale,
-                          const float* pro_shift, const void* res, const float* res_scale, const float* res_shift, void* y,
+int ctl_conv_forward_bf16(const ctl_conv* d, const void* x, const void* x2, const void* wpack, const float* bias, const float* pro_scale,
+                          const float* pro_shift, const void* res, const float* res_scale, const float* res_shift, const void* res2, void* y,
                           float* stats_partial, ctl_stream stream) {
+    if (d->epi_flags & CTL_EPI_TAILBWD) {
+        CTL_REQUIRE((d->dt & CTL_DT_Y16) && (d->dt & CTL_DT_RES16) && d->cout % 16 == 0 && ((d->dt & CTL_DT_X16) ? d->cin % 16 == 0 : d->ks == 1),
+                    "conv_forward(bf16): CTL_EPI_TAILBWD needs bf16-stored y / res / res2 with whole 16-channel tiles (and a bf16-stored x, except for 1x1 convs)");
+    }
+    if (d->pro_affine == 2) {
+        const int e = d->epi_flags & (CTL_EPI_RES | CTL_EPI_ACCUM | CTL_EPI_BIAS);
+        CTL_REQUIRE(x2 && pro_scale && (d->dt & CTL_DT_X16) && (d->dt & CTL_DT_Y16) && d->cin % 16 == 0 && d->cout % 16 == 0 && !e &&
+                    d->epi_act == CTL_ACT_NONE && d->in_mode == CTL_IN_PLAIN && ((d->ks == 3 && d->stride == 1) || (d->ks == 4 && d->stride == 2)),
+                    "conv_forward(bf16): the BatchNorm-backward prologue (pro_affine 2) needs x2 + coefficients, bf16-stored x / x2 / y with whole "
+                    "16-channel tiles, a plain 3x3 stride-1 or 4x4 stride-2 conv and no epilogue operand other than CTL_EPI_STATS / CTL_EPI_BNBWD");
+    }
     CTL_REQUIRE(!(d->epi_flags & CTL_EPI_BNBWD) || ((d->dt & CTL_DT_X16) && (d->dt & CTL_DT_Y16) && (d->dt & CTL_DT_RES16) && d->cin % 16 == 0 && d->cout % 16 == 0),
                 "conv_forward(bf16): CTL_EPI_BNBWD needs bf16-stored x, y and u with whole 16-channel tiles");
     CTL_REQUIRE(!(d->dt & CTL_DT_X16) || d->cin % 16 == 0, "conv_forward(bf16): bf16-stored inputs need cin %% 16 == 0 (got %d)", d->cin);
@@ -869,8 +965,8 @@ int ctl_conv_forward_bf16(const ctl_conv* d, const void* x, const void* wpack, c
     a.d = d;
     int rc = ctl_conv_pick_cfg(d, &a.c, 0);
     if (rc != CTL_OK) return rc;
-    a.x = x; a.wpack = wpack; a.bias = bias; a.pro_scale = pro_scale; a.pro_shift = pro_shift; a.res = res; a.res_scale = res_scale;
-    a.res_shift = res_shift; a.y = y; a.stats_partial = stats_partial; a.stream = (hipStream_t)stream;
+    a.x = x; a.x2 = x2; a.wpack = wpack; a.bias = bias; a.pro_scale = pro_scale; a.pro_shift = pro_shift; a.res = res; a.res_scale = res_scale;
+    a.res_shift = res_shift; a.res2 = res2; a.y = y; a.stats_partial = stats_partial; a.stream = (hipStream_t)stream;
     rc = conv16_dispatch(a);
     if (rc != CTL_OK) return rc;
     CTL_LAUNCH_CHECK("conv_forward(bf16)");
@@ -893,10 +989,13 @@ __device__ __forceinline__ bf16x8 tr_read8(const unsigned char* a0, const unsign
     return __builtin_bit_cast(bf16x8, s16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w});
 }
 
-template <int KS, int S, int MODE, int MT, int NTW>
+// DY2: the output gradient is the virtual BatchNorm-backward result  A * dy + B * dy2 + C  (coefficients [group][3][cout] as the
+// finalize writes them; dy = g, dy2 = the BatchNorm input): the `apply` pass runs in this staging (see XStage16 X2)
+template <int KS, int S, int MODE, int MT, int NTW, bool DY2 = false>
 __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const ctl_conv d, const void* __restrict__ x,
                                                                const float* __restrict__ pro_scale, const float* __restrict__ pro_shift,
-                                                               const void* __restrict__ dy, float* __restrict__ w_partial,
+                                                               const void* __restrict__ dy, const void* __restrict__ dy2,
+                                                               const float* __restrict__ dy_coef, float* __restrict__ w_partial,
                                                                float* __restrict__ b_partial, int tiles_h, int tiles_w, int ntiles,
                                                                int cin_p, int cout_p) {
     constexpr int TW = 16;
@@ -908,11 +1007,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const ctl_conv d, 
     constexpr int DYT_BYTES = NTW * G::TP * 32;
     constexpr int RED_BYTES = 4 * NTW * 256 * 4;
     constexpr int MAIN_BYTES = (XT_ALLOC + DYT_BYTES > RED_BYTES) ? (XT_ALLOC + DYT_BYTES) : RED_BYTES;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[MAIN_BYTES + 2 * CTL_PRO_MAX * 4];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[MAIN_BYTES + (DY2 ? 5 : 2) * CTL_PRO_MAX * 4];
     unsigned char* xt = smem;
     unsigned char* dyt = smem + XT_ALLOC;
     float* cf_scale = reinterpret_cast<float*>(smem + MAIN_BYTES);
     float* cf_shift = cf_scale + CTL_PRO_MAX;
+    float* cd = cf_shift + CTL_PRO_MAX;                  // DY2: A | B | C, [group][cout] each
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -935,6 +1035,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const ctl_conv d, 
 
     const __amdgpu_buffer_rsrc_t rx = ctl_rsrc(x, (int64_t)d.n * d.hin * d.win * d.cin * ((d.dt & CTL_DT_X16) ? 2 : 4));
     const __amdgpu_buffer_rsrc_t rdy = ctl_rsrc(dy, (int64_t)d.n * d.hout * d.wout * d.cout * des);
+    const __amdgpu_buffer_rsrc_t rdy2 = DY2 ? ctl_rsrc(dy2, (int64_t)d.n * d.hout * d.wout * d.cout * 2) : rdy;
     XS xs;
     xs.init(d);
     // dy tile [cout tile t][pixel][16 ch] bf16: units of 8 channels
@@ -942,6 +1043,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const ctl_conv d, 
     u32x4 dv0[ND], dv1[ND];
     int drel[ND], drc[ND], dlds[ND];
     bool dq1[ND];
+    unsigned dmask = 0;                                  // DY2: units of the tile in flight that lie inside the image
+    int dco = 0;                                         // DY2: first channel of this thread's units (the same for all of them: 256 % (2 NTW) == 0)
 #pragma unroll
     for (int i = 0; i < ND; ++i) {
         const int u = tid + i * 256;
@@ -954,20 +1057,45 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const ctl_conv d, 
         drel[i] = in ? ((pr * d.wout + pc) * d.cout + co) * des : CTL_OOB;
         dlds[i] = (u < DU) ? ((t * G::TP + pix) * 32 + h * 16) : DYT_BYTES - 16;      // (units past the tile cannot exist: DU is a multiple of 256 or ND covers it)
         dq1[i] = co + 4 < d.cout;
+        if (i == 0) dco = co < d.cout ? co : 0;
     }
     auto dyload = [&](int n, int ho0, int wo0) {
         const int tb = ((n * d.hout + ho0) * d.wout + wo0) * d.cout * des;
         const u32x4 z = {0u, 0u, 0u, 0u};
+        dmask = 0;
 #pragma unroll
         for (int i = 0; i < ND; ++i) {
             const bool ok = (unsigned)(ho0 + (drc[i] & 0xffff)) < (unsigned)d.hout && (unsigned)(wo0 + (drc[i] >> 16)) < (unsigned)d.wout;
             const int vo = ok ? (tb + drel[i]) : CTL_OOB;
+            if constexpr (DY2) {
+                dv0[i] = ctl_bload4u(rdy, vo, 0); dv1[i] = ctl_bload4u(rdy2, vo, 0);
+                dmask |= (ok && drel[i] != CTL_OOB) ? (1u << i) : 0u;
+                continue;
+            }
             if (dy16) dv0[i] = ctl_bload4u(rdy, vo, 0);
             else if (d.cout >= 4) { dv0[i] = ctl_bload4u(rdy, vo, 0); dv1[i] = dq1[i] ? ctl_bload4u(rdy, vo + 16, 0) : z; }
             else { dv0[i] = u32x4{__builtin_amdgcn_raw_buffer_load_b32(rdy, vo, 0, 0), 0u, 0u, 0u}; dv1[i] = z; }
         }
     };
-    auto dystore = [&]() {
+    auto dystore = [&](int goff) {
+        if constexpr (DY2) {
+            const float* cc = cd + goff + dco;
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(cc), a1 = *reinterpret_cast<const f32x4*>(cc + 4);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(cc + CTL_PRO_MAX), b1 = *reinterpret_cast<const f32x4*>(cc + CTL_PRO_MAX + 4);
+            const f32x4 c0 = *reinterpret_cast<const f32x4*>(cc + 2 * CTL_PRO_MAX), c1 = *reinterpret_cast<const f32x4*>(cc + 2 * CTL_PRO_MAX + 4);
+            const u32x4 zero = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int i = 0; i < ND; ++i) {
+                if (tid + i * 256 < DU) {
+                    const f32x4 glo = unpack_bf16x4(dv0[i].x, dv0[i].y), ghi = unpack_bf16x4(dv0[i].z, dv0[i].w);
+                    const f32x4 ulo = unpack_bf16x4(dv1[i].x, dv1[i].y), uhi = unpack_bf16x4(dv1[i].z, dv1[i].w);
+                    u32x4 pk = pack_bf16x8(a0 * glo + b0 * ulo + c0, a1 * ghi + b1 * uhi + c1);
+                    if (!((dmask >> i) & 1u)) pk = zero;          // pixels past the image contribute nothing (C alone would)
+                    *reinterpret_cast<u32x4*>(dyt + dlds[i]) = pk;
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < ND; ++i) {
             if (tid + i * 256 < DU)
@@ -984,13 +1112,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const ctl_conv d, 
         xs.load(rx, d, cur.n, cur.th * G::TH, cur.tw * TW, g);
         dyload(cur.n, cur.th * G::TH, cur.tw * TW);
     }
-    if (d.pro_affine) {
-        for (int i = tid; i < (d.groups > 1 ? d.groups : 1) * d.cin; i += 256) { cf_scale[i] = pro_scale[i]; cf_shift[i] = pro_shift[i]; }
+    if (d.pro_affine || DY2) {
+        if (d.pro_affine)
+            for (int i = tid; i < (d.groups > 1 ? d.groups : 1) * d.cin; i += 256) { cf_scale[i] = pro_scale[i]; cf_shift[i] = pro_shift[i]; }
+        if constexpr (DY2) {
+            for (int i = tid; i < (d.groups > 1 ? d.groups : 1) * d.cout; i += 256) {
+                const int gi = i / d.cout, ch = i - gi * d.cout;
+                cd[i] = dy_coef[(gi * 3 + 0) * d.cout + ch]; cd[CTL_PRO_MAX + i] = dy_coef[(gi * 3 + 1) * d.cout + ch];
+                cd[2 * CTL_PRO_MAX + i] = dy_coef[(gi * 3 + 2) * d.cout + ch];
+            }
+        }
         __syncthreads();
     }
     if ((int)blockIdx.x < ntiles) {
         xs.store(xt, d, g, cf_scale, cf_shift, (cur.n / group_n) * d.cin);
-        dystore();
+        dystore((cur.n / group_n) * d.cout);
     }
     __syncthreads();
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -1033,7 +1169,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const ctl_conv d, 
         ctl_barrier_lds_reads_done();
         if (has_next) {
             xs.store(xt, d, g, cf_scale, cf_shift, (cur.n / group_n) * d.cin);
-            dystore();
+            dystore((cur.n / group_n) * d.cout);
         }
         ctl_barrier_lds_writes_done();
     }
@@ -1100,15 +1236,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const ctl_conv d, 
 
 struct wgrad16_call {
     const ctl_conv* d; ctl_conv_cfg c; int ntw, splits, ntiles, cin_p, cout_p;
-    const void *x, *dy; const float *pro_scale, *pro_shift; float *w_partial, *b_partial;
+    const void *x, *dy, *dy2; const float *pro_scale, *pro_shift, *dy_coef; float *w_partial, *b_partial;
     hipStream_t stream; bool query;
 };
-template <int KS, int S, int MODE, int MT, int NTW>
-static void wgrad16_go(wgrad16_call& a) {
+template <int KS, int S, int MODE, int MT, int NTW, bool DY2>
+static void wgrad16_go_f(wgrad16_call& a) {
     static int occ = 0;
     if (!occ) {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_wgrad_bf16_kernel<KS, S, MODE, MT, NTW>, 256, 0) != hipSuccess || n < 1) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_wgrad_bf16_kernel<KS, S, MODE, MT, NTW, DY2>, 256, 0) != hipSuccess || n < 1) {
             (void)hipGetLastError();
             n = 2;
         }
@@ -1123,8 +1259,16 @@ static void wgrad16_go(wgrad16_call& a) {
     a.splits = splits;
     if (a.query) return;
     const dim3 grid((unsigned)splits, (unsigned)a.c.g, (unsigned)(a.c.cot / NTW));
-    conv_wgrad_bf16_kernel<KS, S, MODE, MT, NTW><<<grid, dim3(256), 0, a.stream>>>(*a.d, a.x, a.pro_scale, a.pro_shift, a.dy, a.w_partial,
-                                                                                   a.b_partial, a.c.tiles_h, a.c.tiles_w, a.ntiles, a.cin_p, a.cout_p);
+    conv_wgrad_bf16_kernel<KS, S, MODE, MT, NTW, DY2><<<grid, dim3(256), 0, a.stream>>>(*a.d, a.x, a.pro_scale, a.pro_shift, a.dy, a.dy2, a.dy_coef,
+                                                                                        a.w_partial, a.b_partial, a.c.tiles_h, a.c.tiles_w, a.ntiles,
+                                                                                        a.cin_p, a.cout_p);
+}
+template <int KS, int S, int MODE, int MT, int NTW>
+static void wgrad16_go(wgrad16_call& a) {
+    if constexpr (KS == 3 && S == 1) {      // the two-tensor output gradient: the 3x3 convs of the residual blocks
+        if (a.dy2) { wgrad16_go_f<KS, S, MODE, MT, NTW, true>(a); return; }
+    }
+    wgrad16_go_f<KS, S, MODE, MT, NTW, false>(a);
 }
 template <int KS, int S, int MODE>
 static void wgrad16_go_tile(wgrad16_call& a) {
@@ -1173,12 +1317,15 @@ int ctl_wgrad_bf16_splits(const ctl_conv* d) {
     wgrad16_call a = {};
     return wgrad16_pick(d, &a) == CTL_OK ? a.splits : -1;
 }
-int ctl_conv_wgrad_bf16(const ctl_conv* d, const void* x, const float* pro_scale, const float* pro_shift, const void* dy,
-                        float* w_partial, float* b_partial, ctl_stream stream) {
+int ctl_conv_wgrad_bf16(const ctl_conv* d, const void* x, const float* pro_scale, const float* pro_shift, const void* dy, const void* dy2,
+                        const float* dy_coef, float* w_partial, float* b_partial, ctl_stream stream) {
+    CTL_REQUIRE(!dy2 || (dy_coef && d->ks == 3 && d->stride == 1 && (d->dt & CTL_DT_Y16) && d->cout % 16 == 0 &&
+                         (d->groups > 1 ? d->groups : 1) * d->cout <= CTL_PRO_MAX),
+                "wgrad(bf16): the two-tensor output gradient needs coefficients, a 3x3 stride-1 conv, bf16-stored dy / dy2 with cout %% 16 == 0 and groups * cout <= %d", CTL_PRO_MAX);
     wgrad16_call a = {};
     int rc = wgrad16_pick(d, &a);
     if (rc != CTL_OK) return rc;
-    a.x = x; a.dy = dy; a.pro_scale = pro_scale; a.pro_shift = pro_shift; a.w_partial = w_partial; a.b_partial = b_partial;
+    a.x = x; a.dy = dy; a.dy2 = dy2; a.dy_coef = dy_coef; a.pro_scale = pro_scale; a.pro_shift = pro_shift; a.w_partial = w_partial; a.b_partial = b_partial;
     a.stream = (hipStream_t)stream;
     rc = wgrad16_dispatch(a);
     if (rc != CTL_OK) return rc;

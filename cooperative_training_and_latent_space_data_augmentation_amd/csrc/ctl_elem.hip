@@ -284,7 +284,7 @@ template <int MODE>
 __global__ __launch_bounds__(EB) void bwd_reduce16_kernel(const u32x4e* __restrict__ dy, const u32x4e* __restrict__ act_src,
                                                            const u32x4e* __restrict__ bn_src, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, float slope, int64_t octs, int co,
-                                                           float* __restrict__ partial) {
+                                                           float* __restrict__ partial, u32x4e* __restrict__ ds) {      // ds (mode 0): g = dy * leaky'(act_src), stored
     // blockIdx.y = BatchNorm group: `octs` is the size of one group; a thread always sees the same channel octet (256 % co == 0)
     __shared__ float sm[2][8][EB];
     const int64_t gtid = (int64_t)blockIdx.x * EB + threadIdx.x;
@@ -317,6 +317,7 @@ __global__ __launch_bounds__(EB) void bwd_reduce16_kernel(const u32x4e* __restri
                 const f32x8 a = unpack8(oq[u]);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) g.v[k] *= ctl_leaky_grad(a.v[k], slope);
+                if (ds && i0 + u * stride < octs) ds[gbase + i0 + u * stride] = pack8(g);
             } else {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) g.v[k] *= ctl_leaky_grad(x.v[k] * sc.v[k] + sh.v[k], slope);
@@ -719,20 +720,20 @@ extern "C" int ctl_bwd_reduce_dt(int32_t mode, const float* dy, const float* act
     // modes 0 / 1 feed ctl_bn_bwd_finalize, which derives the same row count from (count, c); mode 2 feeds ctl_chan_sum_finalize (fixed rows)
     const dim3 grid((unsigned)(mode == 2 ? CTL_RED_BLOCKS : red_rows_for(quads)), (unsigned)groups), blk(EB);
     // every tensor stored as bf16 and whole channel octets: 16 bytes per lane
-    const bool oct = c % 8 == 0 && (EB % (c / 8)) == 0 && (pixels / groups) * (int64_t)(c / 8) >= 1 && !ds &&
+    const bool oct = c % 8 == 0 && (EB % (c / 8)) == 0 && (pixels / groups) * (int64_t)(c / 8) >= 1 && (!ds || (bf16_mask & 8u)) &&
                      ((mode == 0 && (bf16_mask & 7u) == 7u) || (mode == 1 && (bf16_mask & 5u) == 5u));
     if (mode == 0) {
         CTL_REQUIRE(act_src && bn_src, "bwd_reduce mode 0 needs act_src and bn_src");
         if (oct)
             bwd_reduce16_kernel<0><<<grid, blk, 0, S_>>>((const u32x4e*)dy, (const u32x4e*)act_src, (const u32x4e*)bn_src, nullptr, nullptr, slope,
-                                                        quads / 2, c / 8, partial);
+                                                        quads / 2, c / 8, partial, (u32x4e*)ds);
         else
             bwd_reduce_kernel<0><<<grid, blk, 0, S_>>>(dy, act_src, bn_src, nullptr, nullptr, slope, quads, c / 4, partial, bf16_mask, ds);
     } else if (mode == 1) {
         CTL_REQUIRE(bn_src && scale && shift, "bwd_reduce mode 1 needs bn_src, scale, shift");
         if (oct)
             bwd_reduce16_kernel<1><<<grid, blk, 0, S_>>>((const u32x4e*)dy, nullptr, (const u32x4e*)bn_src, scale, shift, slope, quads / 2, c / 8,
-                                                        partial);
+                                                        partial, nullptr);
         else
             bwd_reduce_kernel<1><<<grid, blk, 0, S_>>>(dy, nullptr, bn_src, (const f32x4*)scale, (const f32x4*)shift, slope, quads, c / 4, partial,
                                                       bf16_mask, nullptr);

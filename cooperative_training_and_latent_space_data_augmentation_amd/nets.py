@@ -42,6 +42,8 @@ SMALL_CIN = True         # K-packed taps for the Cin <= 4 first layers
 PHASE_CONVS = True       # 2x2 phase forms of the up-sampled forward / stride-2 data gradient
 FUSE_BNBWD = False       # BN1-backward reduction inside the dgrad conv epilogue (fp32: matrix-bound kernel, measured no gain)
 FUSE_BNBWD16 = True      # the same in the bf16 family, where the data gradient is not matrix-bound
+FUSE_TAIL16 = True       # bf16: CTL_EPI_TAILBWD in the bf16 family (the tail's reduction pass and the separately rounded dOut disappear)
+FUSE_BNAPPLY16 = True    # bf16: the BatchNorm-backward apply passes of the residual blocks run inside the staging of their consumers (pro_affine 2 / dy2)
 FUSE_TAIL = True         # fp32: the residual tail's BatchNorm-backward reduction inside the launch that writes dOut (CTL_EPI_TAILBWD): dOut is
                          # never materialised, the stand-alone reduction launch (read dOut, out, v; write dS) disappears
 CONV_WORDS = _ffi.CONV_DTYPE.itemsize // 4      # ctl_conv as int32 words at the head of ctl_op.i
@@ -201,16 +203,17 @@ class PlanBuilder:
 
     def conv(self, x: T, wp_ref, cout, ks, *, stride=1, in_mode=0, pro=None, bias_ref=None, stats=False, act=0,
              slope=0.0, res=None, accum=False, out: Optional[T] = None, arena: Optional[Arena] = None, nsub=1,
-             hout=None, wout=None, bnbwd=None, pad=None, tail=None):
+             hout=None, wout=None, bnbwd=None, pad=None, tail=None, x2=None):
         """Emit one CTL_OP_CONV.  pro = (scale_ref, shift_ref, slope); res = (T v, scale_ref, shift_ref).
         bnbwd = (T u, scale_ref, shift_ref, slope): data-gradient conv whose result is dL/d leaky(BN(u)); the epilogue writes
         g = result * leaky'(BN(u)) and the BatchNorm-backward sums go to the statistics partials (CTL_EPI_BNBWD).
         tail = (T block_out, T v, slope): this conv writes dL/dOut of a residual block; the epilogue stores g = dOut * leaky'(block_out)
         instead and takes the BatchNorm-backward sums of the tail (sum g, sum g*v) into the statistics partials (CTL_EPI_TAILBWD).
+        x2 = (T u, coef_ref): the input is the virtual BatchNorm-backward result A*x + B*u + C (pro_affine 2, bf16 family).
         Returns (T y, stats_ref or None, stats_blocks)."""
         res2 = None
         if tail is not None:
-            assert res is None and bnbwd is None and bias_ref is None and act == 0 and not self.b16
+            assert res is None and bnbwd is None and bias_ref is None and act == 0
             stats, res2, slope = True, tail[1], tail[2]
         if bnbwd is not None:
             assert res is None and not accum and bias_ref is None and act == 0
@@ -232,8 +235,14 @@ class PlanBuilder:
         dt = 0
         if self.b16:        # bf16 MFMA family; which of x / y / res is STORED as bf16 follows from where the tensor lives
             assert bnbwd is None or (x.b16 and out.b16 and bnbwd[0].b16), "CTL_EPI_BNBWD (bf16): x, y and u must be bf16-stored"
-            dt = _ffi.DT_BF16 | (_ffi.DT_X16 if x.b16 else 0) | (_ffi.DT_Y16 if out.b16 else 0) | (_ffi.DT_RES16 if res is not None and res[0].b16 else 0)
+            assert tail is None or (out.b16 and tail[0].b16 and tail[1].b16), "CTL_EPI_TAILBWD (bf16): y, out and v must be bf16-stored"
+            dt = _ffi.DT_BF16 | (_ffi.DT_X16 if x.b16 else 0) | (_ffi.DT_Y16 if out.b16 else 0) | \
+                (_ffi.DT_RES16 if (res is not None and res[0].b16) or tail is not None else 0)
         d = self._conv_desc(x, cout, ks, stride, in_mode, hout, wout, pro, flags, act, slope, nsub, pad, dt)
+        if x2 is not None:
+            assert pro is None and self.b16 and x.b16 and x2[0].b16 and (x2[0].n, x2[0].h, x2[0].w, x2[0].c) == (x.n, x.h, x.w, x.c)
+            d["pro_affine"] = 2
+            pro = (x2[1], None)
         op = self.op(_ffi.OP_CONV)
         op["i"][:CONV_WORDS] = np.frombuffer(d.tobytes(), dtype="<i4")
         stats_ref, blocks = None, 0
@@ -241,15 +250,20 @@ class PlanBuilder:
             blocks = lib.ctl_conv_stats_blocks(_ffi.desc_ptr(d))
             if blocks <= 0:
                 raise _ffi.CtlError("conv plan: " + lib.ctl_last_error().decode())
-            stats_ref, = self.scr(4 * self.groups * blocks * 2 * cout)
+            if tail is not None:      # consumed by the NEXT block's finalize: kept in the backward arena, not in the transient scratch
+                stats_ref = self.bscr.alloc(4 * self.groups * blocks * 2 * cout)
+            else:
+                stats_ref, = self.scr(4 * self.groups * blocks * 2 * cout)
         for idx, ref in enumerate([x.ref, wp_ref, bias_ref, pro[0] if pro else None, pro[1] if pro else None,
                                    (tail[0].ref if tail is not None else (res[0].ref if res else None)), res[1] if res else None, res[2] if res else None,
-                                   out.ref, stats_ref, res2.ref if res2 is not None else None]):
+                                   out.ref, stats_ref, res2.ref if res2 is not None else None, x2[0].ref if x2 is not None else None]):
             self.set_t(op, idx, ref)
         return out, stats_ref, blocks
 
-    def wgrad(self, x: T, dy: T, ks, *, stride=1, in_mode=0, pro=None, dw_ref, strides, dbias_ref=None, accumulate=False):
-        """CTL_OP_WGRAD + CTL_OP_WGRAD_REDUCE for the conv x -> dy."""
+    def wgrad(self, x: T, dy: T, ks, *, stride=1, in_mode=0, pro=None, dw_ref, strides, dbias_ref=None, accumulate=False, dy2=None):
+        """CTL_OP_WGRAD + CTL_OP_WGRAD_REDUCE for the conv x -> dy.  dy2 = (T u, coef_ref): the output gradient is the virtual
+        BatchNorm-backward result A*dy + B*u + C (bf16 family)."""
+        assert dy2 is None or (self.b16 and dy.b16 and dy2[0].b16 and ks == 3 and stride == 1)
         dt = (_ffi.DT_BF16 | (_ffi.DT_X16 if x.b16 else 0) | (_ffi.DT_Y16 if dy.b16 else 0)) if self.b16 else 0
         d = self._conv_desc(x, dy.c, ks, stride, in_mode, dy.h, dy.w, pro, 0, 0, 0.0, dt=dt)
         dp = _ffi.desc_ptr(d)
@@ -262,7 +276,8 @@ class PlanBuilder:
         words = np.frombuffer(d.tobytes(), dtype="<i4")
         op = self.op(_ffi.OP_WGRAD)
         op["i"][:CONV_WORDS] = words
-        for idx, ref in enumerate([x.ref, pro[0] if pro else None, pro[1] if pro else None, dy.ref, wref, bref]):
+        for idx, ref in enumerate([x.ref, pro[0] if pro else None, pro[1] if pro else None, dy.ref, wref, bref,
+                                   dy2[0].ref if dy2 else None, dy2[1] if dy2 else None]):
             self.set_t(op, idx, ref)
         assert dw_ref[0] == S_GRAD and (dbias_ref is None or dbias_ref[0] == S_GRAD)
         splits = lib.ctl_wgrad_splits(dp)
@@ -326,17 +341,20 @@ class PlanBuilder:
 
     def bn_backward(self, mode_kind: int, dy: T, act_src: Optional[T], bn_src: T, bn: BNInfo, co, slope, *, ds: Optional[T],
                     dx: T, affine_grad: bool):
-        """reduce -> finalize -> apply.  mode_kind 0 = residual tail, 1 = BN->activation tail."""
+        """reduce -> finalize -> apply.  mode_kind 0 = residual tail, 1 = BN->activation tail.
+        dx = None (mode 0 with ds): no apply pass -- the consumers take (ds, bn_src, coef) through their BatchNorm-backward prologue
+        (conv(x2=...), wgrad(dy2=...)).  Returns the coefficient ref."""
         c, pixels, G = bn_src.c, bn_src.n * bn_src.h * bn_src.w, self.groups
+        assert dx is not None or (mode_kind == 0 and ds is not None)
         part, = self.scr(4 * G * _ffi.RED_BLOCKS * 2 * c)
         coef = self.bscr.alloc(4 * 3 * c * G)
         # residual tail (mode 0), fp32: the reduction also writes ds = dy * leaky'(act_src) (it has it in registers), and the apply pass
         # then runs in mode 2 on ds -- same arithmetic bit for bit, one tensor read less.  (bf16 keeps the two-operand apply: reading a
         # ROUNDED ds back would add a rounding point.)
-        ds_early = mode_kind == 0 and ds is not None and not self.b16
+        ds_early = mode_kind == 0 and ds is not None and (not self.b16 or dx is None)
         op = self.op(_ffi.OP_BWD_REDUCE)
         op["i"][0], op["i"][1], op["i"][2] = mode_kind, c, G
-        op["i"][25] = self.mask(dy, act_src, bn_src)
+        op["i"][25] = self.mask(dy, act_src, bn_src, ds if ds_early else None)
         op["l"][0] = pixels
         op["f"][0] = slope
         for idx, ref in enumerate([dy.ref, act_src.ref if act_src else None, bn_src.ref, co["scale"], co["shift"], part,
@@ -348,13 +366,16 @@ class PlanBuilder:
         for idx, ref in enumerate([part, self.P(bn.g_off), co["mean"], co["invstd"], coef,
                                    self.G(bn.g_off) if affine_grad else None, self.G(bn.b_off) if affine_grad else None]):
             self.set_t(op, idx, ref)
+        if dx is None:
+            return coef
         op = self.op(_ffi.OP_BWD_APPLY)
         if ds_early:
             op["i"][0], op["i"][1], op["i"][2] = 2, c, G
+            op["i"][25] = self.mask(ds, None, bn_src, None, dx)
             op["l"][0] = pixels
             for idx, ref in enumerate([ds.ref, None, bn_src.ref, None, None, coef, None, dx.ref]):
                 self.set_t(op, idx, ref)
-            return
+            return coef
         op["i"][0], op["i"][1], op["i"][2] = mode_kind, c, G
         op["i"][25] = self.mask(dy, act_src, bn_src, ds, dx)
         op["l"][0] = pixels
@@ -362,9 +383,11 @@ class PlanBuilder:
         for idx, ref in enumerate([dy.ref, act_src.ref if act_src else None, bn_src.ref, co["scale"], co["shift"], coef,
                                    ds.ref if ds else None, dx.ref]):
             self.set_t(op, idx, ref)
+        return coef
 
     def bn_backward_from_stats(self, g: T, bn_src: T, bn: BNInfo, co, stats_ref, blocks, *, dx: T, affine_grad: bool):
-        """BatchNorm backward whose reduction already happened in the producing conv (conv(..., bnbwd=...)): finalize + apply."""
+        """BatchNorm backward whose reduction already happened in the producing conv (conv(..., bnbwd=...)): finalize + apply.
+        dx = None: finalize only (the consumers apply the coefficients in their staging).  Returns the coefficient ref."""
         c, pixels, G = bn_src.c, bn_src.n * bn_src.h * bn_src.w, self.groups
         coef = self.bscr.alloc(4 * 3 * c * G)
         op = self.op(_ffi.OP_BN_BWD_FINALIZE)
@@ -373,12 +396,15 @@ class PlanBuilder:
         for idx, ref in enumerate([stats_ref, self.P(bn.g_off), co["mean"], co["invstd"], coef,
                                    self.G(bn.g_off) if affine_grad else None, self.G(bn.b_off) if affine_grad else None]):
             self.set_t(op, idx, ref)
+        if dx is None:
+            return coef
         op = self.op(_ffi.OP_BWD_APPLY)
         op["i"][0], op["i"][1], op["i"][2] = 2, c, G
         op["i"][25] = self.mask(g, None, bn_src, None, dx)
         op["l"][0] = pixels
         for idx, ref in enumerate([g.ref, None, bn_src.ref, None, None, coef, None, dx.ref]):
             self.set_t(op, idx, ref)
+        return coef
 
     def chan_sum(self, dy: T, out_ref):
         c = dy.c
@@ -842,7 +868,9 @@ class CtlNet(nn.Module):
 
     def _tail_of(self, pb: PlanBuilder, rec: Optional[dict]):
         """(T out, T v, slope) of the block whose output gradient the next launch writes, if its tail reduction can ride in that launch."""
-        if rec is None or not FUSE_TAIL or pb.b16 or rec.get("drop") is not None:
+        if rec is None or rec.get("drop") is not None or not (FUSE_TAIL16 if pb.b16 else FUSE_TAIL):
+            return None
+        if pb.b16 and not (rec["out"].b16 and rec["v"].b16):
             return None
         return (rec["out"], rec["v"], SLOPE)
 
@@ -862,25 +890,36 @@ class CtlNet(nn.Module):
             d_pre = A.tensor(out.n, out.h, out.w, out.c)
             pb.dropout(d_out, d_pre, rec["drop"][1], keep_in=rec["drop"][0])
             d_out = d_pre
+        # bf16: no apply passes at all -- dV and dU stay virtual (g, BatchNorm input, coefficients) and their consumers (the 3x3 weight
+        # gradients and the data-gradient convs) evaluate A*g + B*u + C while staging: two launches and three tensor passes less per
+        # BatchNorm.  The coefficient tables of a launch sit in LDS: groups * channels <= 256.
+        virt = FUSE_BNAPPLY16 and FUSE_BNBWD16 and pb.b16 and out.b16 and v.b16 and u.b16 and pb.groups * max(out.c, u.c) <= 256
+        # (the block whose input gradient leaves the network as fp32 keeps a stored dU: the staged form writes bf16 only)
+        virt_u = virt and not (pre == "nn" and d_in is not None and not d_in.b16)
+        dv2 = du2 = None
         # residual tail: dS (to conv_input) and dV (to conv.3)
         if pre_tail is not None:
             assert rec.get("drop") is None
-            ds, dv = d_out, A.tensor(out.n, out.h, out.w, out.c)
-            pb.bn_backward_from_stats(ds, v, B[prefix + ".conv.4"], rec["co2"], pre_tail[0], pre_tail[1], dx=dv, affine_grad=need_w and affine)
+            ds, dv = d_out, (None if virt else A.tensor(out.n, out.h, out.w, out.c))
+            coef2 = pb.bn_backward_from_stats(ds, v, B[prefix + ".conv.4"], rec["co2"], pre_tail[0], pre_tail[1], dx=dv, affine_grad=need_w and affine)
         else:
-            ds, dv = A.tensor(out.n, out.h, out.w, out.c), A.tensor(out.n, out.h, out.w, out.c)
-            pb.bn_backward(0, d_out, out, v, B[prefix + ".conv.4"], rec["co2"], SLOPE, ds=ds, dx=dv, affine_grad=need_w and affine)
+            ds, dv = A.tensor(out.n, out.h, out.w, out.c), (None if virt else A.tensor(out.n, out.h, out.w, out.c))
+            coef2 = pb.bn_backward(0, d_out, out, v, B[prefix + ".conv.4"], rec["co2"], SLOPE, ds=ds, dx=dv, affine_grad=need_w and affine)
+        if virt:
+            dv, dv2 = ds, (v, coef2)
         pro1 = (rec["co1"]["scale"], rec["co1"]["shift"], SLOPE)
         k9 = 9
         if need_w:
-            pb.wgrad(u, dv, 3, pro=pro1, dw_ref=pb.G(c3.w_off), strides=(c3.cin * k9, k9, 3, 1), dbias_ref=pb.G(c3.b_off))
+            pb.wgrad(u, dv, 3, pro=pro1, dw_ref=pb.G(c3.w_off), strides=(c3.cin * k9, k9, 3, 1), dbias_ref=pb.G(c3.b_off), dy2=dv2)
         # dgrad of conv.3; its epilogue already multiplies by leaky'(BN1(u)) and takes the BatchNorm-backward sums (no
         # separate reduction pass); the apply runs in place
         if (FUSE_BNBWD and not pb.b16) or (FUSE_BNBWD16 and pb.b16 and dv.b16 and u.b16):
             g1, st, blk = pb.conv(dv, self._wp_ref(c3.wp_dgrad), c3.cin, 3, arena=A,
-                                  bnbwd=(u, rec["co1"]["scale"], rec["co1"]["shift"], SLOPE))
-            pb.bn_backward_from_stats(g1, u, B[prefix + ".conv.1"], rec["co1"], st, blk, dx=g1, affine_grad=need_w and affine)
+                                  bnbwd=(u, rec["co1"]["scale"], rec["co1"]["shift"], SLOPE), x2=dv2)
+            coef1 = pb.bn_backward_from_stats(g1, u, B[prefix + ".conv.1"], rec["co1"], st, blk, dx=None if virt_u else g1, affine_grad=need_w and affine)
             du = g1
+            if virt_u:
+                du2 = (u, coef1)
         else:
             da, _, _ = pb.conv(dv, self._wp_ref(c3.wp_dgrad), c3.cin, 3, arena=A)
             # BN1 -> LeakyReLU tail (in place: dU overwrites dA)
@@ -893,7 +932,7 @@ class CtlNet(nn.Module):
             ds_low = A.tensor(ds.n, ds.h // 2, ds.w // 2, ds.c)
             pb.sumpool2(ds, ds_low)
         if need_w:
-            pb.wgrad(src, du, 3, in_mode=src_mode, dw_ref=pb.G(c0.w_off), strides=(c0.cin * k9, k9, 3, 1), dbias_ref=pb.G(c0.b_off))
+            pb.wgrad(src, du, 3, in_mode=src_mode, dw_ref=pb.G(c0.w_off), strides=(c0.cin * k9, k9, 3, 1), dbias_ref=pb.G(c0.b_off), dy2=du2)
             if ds_low is not None:
                 pb.wgrad(xin, ds_low, 1, dw_ref=pb.G(c1.w_off), strides=(c1.cin, 1, 1, 1), dbias_ref=pb.G(c1.b_off))
             else:
@@ -908,11 +947,11 @@ class CtlNet(nn.Module):
         fin = lambda st, blk: d_in if tail_next is None else (d_in, st, blk)
         if pre == "nn":
             # sumpool2(conv3x3^T(dU)) as one 4x4 stride-2 conv (no full-resolution gradient tensor at all), then the 1x1 part
-            pb.conv(du, self._wp_ref(c0.wp_up), c0.cin, 4, stride=2, out=d_in)
+            pb.conv(du, self._wp_ref(c0.wp_up), c0.cin, 4, stride=2, out=d_in, x2=du2)
             _, st, blk = pb.conv(ds_low, self._wp_ref(c1.wp_dgrad), c1.cin, 1, out=d_in, accum=True, tail=tail_next)
             return fin(st, blk)
         dsrc = A.tensor(*dsrc_shape)
-        pb.conv(du, self._wp_ref(c0.wp_dgrad), c0.cin, 3, out=dsrc)
+        pb.conv(du, self._wp_ref(c0.wp_dgrad), c0.cin, 3, out=dsrc, x2=du2)
         pb.conv(ds, self._wp_ref(c1.wp_dgrad), c1.cin, 1, out=dsrc, accum=True)
         if pre == "convT":
             ci = C[prefix + ".up"]
@@ -1072,6 +1111,7 @@ class MyEncoder(CtlNet):
         if tail is not None:
             d, pre = d[0], d[1:]
         dbg["d_down5"] = d               # gradient w.r.t. the output of down4 (with FUSE_TAIL: already times leaky'(out), i.e. dS of down4)
+        dbg["tail_down5"] = pre          # ... and where the tail's BatchNorm-backward sums of down4 are (statistics partials ref, rows)
         for i, brec in reversed(list(enumerate(blocks))):
             tail = self._tail_of(pb, blocks[i - 1]) if i >= 1 else None
             d = self._emit_block_bwd(pb, brec, d, None, need_w, affine, pre_tail=pre, tail_next=tail)
@@ -1079,6 +1119,7 @@ class MyEncoder(CtlNet):
             if tail is not None:
                 d, pre = d[0], d[1:]
             dbg[f"d_down{i + 1}"] = d    # gradient w.r.t. the input of block down{i+1}
+            dbg[f"tail_down{i + 1}"] = pre
         # d = gradient w.r.t. x1 = LReLU(BN(v0))
         pro0 = (rec["co0"]["scale"], rec["co0"]["shift"], SLOPE)
         d = self._emit_conv_bn_pair_bwd(pb, px + "inc.3", px + "inc.4", rec["u0"], pro0, rec["v0"], rec["co1"], SLOPE, d, None,
@@ -1260,7 +1301,7 @@ class MyDecoder(CtlNet):
         tail = self._tail_of(pb, blocks[3])
         d, st, blk = pb.conv(dout, self._wp_ref(cf.wp_dgrad), cf.cin, 1, arena=pb.bscr, tail=tail)
         pre = (st, blk) if tail is not None else None
-        dbg = {"d_out4": d}
+        dbg = {"d_out4": d, "tail_out4": pre}
         for i in range(3, -1, -1):
             d_in = T((S_DX, 0), *rec["x"][1:]) if (i == 0 and need_dx) else None
             tail = self._tail_of(pb, blocks[i - 1]) if i >= 1 else None
@@ -1269,6 +1310,7 @@ class MyDecoder(CtlNet):
             if tail is not None:
                 d, pre = d[0], d[1:]
             dbg[f"d_out{i}"] = d
+            dbg[f"tail_out{i}"] = pre
         return pb.finish(dbg)
 
     def forward(self, x):

@@ -89,13 +89,17 @@ def pack_oihw_dgrad_bf16(w: torch.Tensor) -> torch.Tensor:
 
 
 def conv_forward(d: np.ndarray, x, wpack, bias=None, pro_scale=None, pro_shift=None, res=None, res_scale=None,
-                 res_shift=None, y=None, want_stats=False):
+                 res_shift=None, y=None, want_stats=False, x2=None, res2=None):
     """Run one conv problem described by the ctl_conv record `d`.  Returns (y, stats_partial or None).  With d["dt"] & DT_BF16 the
-    storage dtypes of x / res / y must agree with the DT_X16 / DT_RES16 / DT_Y16 flags (y is allocated accordingly)."""
+    storage dtypes of x / res / y must agree with the DT_X16 / DT_RES16 / DT_Y16 flags (y is allocated accordingly).
+    x2 (d["pro_affine"] == 2): the BatchNorm-backward prologue, input = A*x + B*x2 + C with pro_scale = [groups][3][cin] coefficients.
+    res2 (CTL_EPI_TAILBWD): res = the block output, res2 = the BatchNorm input of the residual tail."""
     require_gpu(x, wpack)
+    if (x2 is not None) != (int(d["pro_affine"]) == 2) or (x2 is not None and (x2.dtype != x.dtype or x2.shape != x.shape)):
+        raise _ffi.CtlError("conv_forward: x2 goes with ctl_conv.pro_affine == 2 and has the dtype and shape of x")
     n, cout, oh, ow = int(d["n"]), int(d["cout"]), int(d["out_h"]), int(d["out_w"])
     dt = int(d["dt"])
-    for t, flag, what in ((x, _ffi.DT_X16, "x"), (res, _ffi.DT_RES16, "res"), (y, _ffi.DT_Y16, "y")):
+    for t, flag, what in ((x, _ffi.DT_X16, "x"), (res, _ffi.DT_RES16, "res"), (res2, _ffi.DT_RES16, "res2"), (y, _ffi.DT_Y16, "y")):
         if t is not None and (t.dtype == torch.bfloat16) != bool(dt & flag):
             raise _ffi.CtlError(f"conv_forward: dtype of {what} ({t.dtype}) disagrees with ctl_conv.dt = {dt}")
     if y is None:
@@ -103,22 +107,25 @@ def conv_forward(d: np.ndarray, x, wpack, bias=None, pro_scale=None, pro_shift=N
     stats = None
     if want_stats:
         stats = torch.empty(lib.ctl_conv_stats_floats(_ffi.desc_ptr(d)), dtype=torch.float32, device=x.device)
-    check(lib.ctl_conv_forward(_ffi.desc_ptr(d), ptr(x), ptr(wpack), ptr(bias), ptr(pro_scale), ptr(pro_shift), ptr(res),
-                               ptr(res_scale), ptr(res_shift), ptr(y), ptr(stats), stream_ptr()), "ctl_conv_forward")
+    check(lib.ctl_conv_forward_ex(_ffi.desc_ptr(d), ptr(x), ptr(wpack), ptr(bias), ptr(pro_scale), ptr(pro_shift), ptr(res),
+                                  ptr(res_scale), ptr(res_shift), ptr(res2), ptr(x2), ptr(y), ptr(stats), stream_ptr()), "ctl_conv_forward")
     return y, stats
 
 
 def conv_wgrad(d: np.ndarray, x, dy, dw: torch.Tensor, strides, dbias: Optional[torch.Tensor] = None, pro_scale=None,
-               pro_shift=None, accumulate=False):
+               pro_shift=None, accumulate=False, dy2=None, dy_coef=None):
+    """dy2 / dy_coef: the output gradient is the virtual BatchNorm-backward result A*dy + B*dy2 + C (ctl_conv_wgrad_ex)."""
     require_gpu(x, dy, dw)
+    if dy2 is not None and (dy_coef is None or dy2.dtype != dy.dtype or dy2.shape != dy.shape):
+        raise _ffi.CtlError("conv_wgrad: dy2 needs dy_coef and the dtype and shape of dy")
     dt = int(d["dt"])
     if (x.dtype == torch.bfloat16) != bool(dt & _ffi.DT_X16) or (dy.dtype == torch.bfloat16) != bool(dt & _ffi.DT_Y16):
         raise _ffi.CtlError(f"conv_wgrad: dtypes of x / dy ({x.dtype}, {dy.dtype}) disagree with ctl_conv.dt = {dt}")
     dp = _ffi.desc_ptr(d)
     wpart = torch.empty(lib.ctl_wgrad_partial_floats(dp), dtype=torch.float32, device=x.device)
     bpart = torch.empty(lib.ctl_wgrad_bias_partial_floats(dp), dtype=torch.float32, device=x.device) if dbias is not None else None
-    check(lib.ctl_conv_wgrad(dp, ptr(x), ptr(pro_scale), ptr(pro_shift), ptr(dy), ptr(wpart), ptr(bpart), stream_ptr()),
-          "ctl_conv_wgrad")
+    check(lib.ctl_conv_wgrad_ex(dp, ptr(x), ptr(pro_scale), ptr(pro_shift), ptr(dy), ptr(dy2), ptr(dy_coef), ptr(wpart), ptr(bpart),
+                                stream_ptr()), "ctl_conv_wgrad")
     check(lib.ctl_wgrad_reduce(dp, ptr(wpart), ptr(bpart), ptr(dw), *[int(s) for s in strides], ptr(dbias), int(accumulate),
                                stream_ptr()), "ctl_wgrad_reduce")
     return dw, dbias

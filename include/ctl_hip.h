@@ -31,8 +31,10 @@ enum ctl_status { CTL_OK = 0, CTL_EINVAL = -1, CTL_EUNSUPPORTED = -2, CTL_ELAUNC
  * ctl_version() with the CTL_ABI_VERSION they were written against (and ctl_sizeof_conv / ctl_sizeof_op with their struct sizes)
  * at load time and refuse to run on a mismatch.  3 = round 3: fused-finalize entry points and side lanes removed, `ds` argument of
  * ctl_bwd_reduce_dt, ctl_red_blocks().  4 = CTL_EPI_TAILBWD / ctl_conv_forward_ex (plan op CONV slot 10).
- * 5 = ctl_bn_finalize_ex (save_uvar, plan op BN_FINALIZE slot 10), ctl_bn_replay_running / CTL_OP_BN_REPLAY. */
-#define CTL_ABI_VERSION 5
+ * 5 = ctl_bn_finalize_ex (save_uvar, plan op BN_FINALIZE slot 10), ctl_bn_replay_running / CTL_OP_BN_REPLAY.
+ * 6 = the BatchNorm-backward prologue: ctl_conv.pro_affine == 2 + the x2 argument of ctl_conv_forward_ex (plan op CONV slot 11),
+ *     ctl_conv_wgrad_ex (plan op WGRAD slots 6, 7); CTL_EPI_TAILBWD in the bf16 family. */
+#define CTL_ABI_VERSION 6
 int         ctl_version(void);
 const char* ctl_last_error(void);
 
@@ -95,14 +97,21 @@ int ctl_conv_forward(const ctl_conv* d, const float* x, const float* wpack, cons
                      const float* pro_scale, const float* pro_shift,
                      const float* res, const float* res_scale, const float* res_shift,
                      float* y, float* stats_partial, ctl_stream stream);
-/* ... with a second epilogue tensor.  CTL_EPI_TAILBWD (with CTL_EPI_STATS, optionally CTL_EPI_ACCUM; fp32, cout % 16 == 0; the 1x1 / 2x2 /
+/* ... with a second epilogue tensor.  CTL_EPI_TAILBWD (with CTL_EPI_STATS, optionally CTL_EPI_ACCUM; cout % 16 == 0; fp32, or the bf16
+ * family with bf16-stored y / res / res2 -- there the sums come from the unrounded g and dOut is never rounded on its own; the 1x1 / 2x2 /
  * zero-insert 3x3 launches that write the output gradient of a residual block, encdec.py:64,344): the conv result (+ y with
  * CTL_EPI_ACCUM) is dL/dOut of out = leaky(S + BN(v), epi_slope); res = out, res2 = v.  y receives g = dOut * leaky'(out) and
  * stats_partial (sum g, sum g*v) per BatchNorm group: the reduction pass of the residual tail (ctl_bwd_reduce mode 0) folded into the
  * producer of dOut, which is then never materialised.  res2 == NULL: plain ctl_conv_forward. */
+/* x2 (with ctl_conv.pro_affine == 2; bf16 family, bf16-stored x / x2 / y with whole 16-channel tiles, plain 3x3 stride-1 or 4x4
+ * stride-2 conv, epilogue CTL_EPI_STATS / CTL_EPI_BNBWD only): the BatchNorm-backward prologue.  The conv input is the VIRTUAL tensor
+ *     A[c] * x + B[c] * x2 + C[c]     (zero outside the image; rounded to bf16 as the stored tensor would have been)
+ * with pro_scale = the [group][A | B | C][cin] coefficients ctl_bn_bwd_finalize writes (pro_shift is not read): x = g = dL/da * leaky',
+ * x2 = the BatchNorm input.  This is ctl_bwd_apply (mode 2) run inside the staging of its consumer: the data-gradient convs of a
+ * residual block read (g, u) instead of dU, which is never written.  x2 == NULL and pro_affine <= 1: as before. */
 int ctl_conv_forward_ex(const ctl_conv* d, const float* x, const float* wpack, const float* bias,
                         const float* pro_scale, const float* pro_shift,
-                        const float* res, const float* res_scale, const float* res_shift, const float* res2,
+                        const float* res, const float* res_scale, const float* res_shift, const float* res2, const float* x2,
                         float* y, float* stats_partial, ctl_stream stream);
 
 /* Weight gradient of the conv described by d (x [n,hin,win,cin] -> dy [n,hout,wout,cout], nsub must be 1):
@@ -113,6 +122,11 @@ size_t ctl_wgrad_partial_floats(const ctl_conv* d);          /* weights part  */
 size_t ctl_wgrad_bias_partial_floats(const ctl_conv* d);     /* bias part     */
 int ctl_conv_wgrad(const ctl_conv* d, const float* x, const float* pro_scale, const float* pro_shift,
                    const float* dy, float* w_partial, float* b_partial, ctl_stream stream);
+/* ... whose output gradient is the virtual BatchNorm-backward result  A[c] * dy + B[c] * dy2 + C[c]  (dy_coef = [group][A | B | C][cout]
+ * from ctl_bn_bwd_finalize; bf16 family, 3x3 stride-1 convs, bf16-stored dy / dy2, cout % 16 == 0, groups * cout <= 256): the other
+ * consumer of a block's dU / dV (see ctl_conv_forward_ex).  The bias gradient is the sum of the virtual tensor.  dy2 == NULL: ctl_conv_wgrad. */
+int ctl_conv_wgrad_ex(const ctl_conv* d, const float* x, const float* pro_scale, const float* pro_shift,
+                      const float* dy, const float* dy2, const float* dy_coef, float* w_partial, float* b_partial, ctl_stream stream);
 int ctl_wgrad_reduce(const ctl_conv* d, const float* w_partial, const float* b_partial,
                      float* dw, int64_t s_co, int64_t s_ci, int64_t s_kh, int64_t s_kw,
                      float* dbias, int32_t accumulate, ctl_stream stream);

@@ -32,6 +32,8 @@ import torch.nn.functional as F
 SLOPE = 0.2
 ROUND = True                 # False: no rounding anywhere (pins the backward formulas against autograd)
 FUSE_BNBWD16 = True          # nets.FUSE_BNBWD16: BatchNorm-backward sums of the in-block BatchNorm inside the data-gradient epilogue
+FUSE_TAIL16 = True           # nets.FUSE_TAIL16: the launch that writes a block's output gradient stores g = dOut * leaky'(out) and takes the tail's sums
+FUSE_BNAPPLY16 = True        # nets.FUSE_BNAPPLY16: dV / dU of a residual block are never stored; their consumers apply the coefficients to the stored g
 
 
 def rb(t: torch.Tensor) -> torch.Tensor:
@@ -203,18 +205,52 @@ def block_fwd(blk, pre: str, xin: torch.Tensor, xin_pro, mode: str) -> Tuple[tor
     return out, rec
 
 
-def block_bwd(blk, rec: dict, d_out: torch.Tensor, need_w: bool, affine: bool, grads: dict, prefix: str, last: bool) -> torch.Tensor:
+def tail_pack(t: torch.Tensor, tail_next):
+    """CTL_EPI_TAILBWD epilogue of the launch that writes the output gradient of the block (out, v) = tail_next: g = dOut * leaky'(out)
+    from the UNROUNDED dOut = t, the tail's BatchNorm-backward sums from the unrounded g, g stored.  Returns (g stored, (sum g, sum g*v))."""
+    out_n, v_n = tail_next
+    g = t * dleaky(out_n, SLOPE)
+    return rb(g), (g.sum((0, 2, 3)), (g * v_n).sum((0, 2, 3)))
+
+
+def tail_of(brec):
+    return (brec["out"], brec["v"]) if FUSE_TAIL16 else None
+
+
+def block_bwd(blk, rec: dict, d_out: torch.Tensor, need_w: bool, affine: bool, grads: dict, prefix: str, last: bool, *, pre_tail=None,
+              d_out_is_g: bool = False, tail_next=None):
     """nets._emit_block_bwd.  d_out: gradient w.r.t. the block output as stored by its producer.  Returns the gradient w.r.t. the block
     input (w.r.t. the activated virtual tensor if rec['xin_pro'] is set): rounded like a stored bf16 tensor unless `last` (then it is the
-    fp32 gradient leaving the network)."""
+    fp32 gradient leaving the network).
+    pre_tail = (sum g, sum g*v) from `tail_pack`: d_out is already the stored g of this block's tail (d_out_is_g without sums: teacher-
+    forced tests, the sums are then taken from the stored g).  tail_next = (out, v) of the block that consumes this block's input
+    gradient: returns `tail_pack` of it instead."""
     c0, bn1, c3, bn2, c1 = blk.conv[0], blk.conv[1], blk.conv[3], blk.conv[4], blk.conv_input
     pre, src, u, v, out, xin = rec["pre"], rec["src"], rec["u"], rec["v"], rec["out"], rec["xin"]
     co1, co2 = rec["co1"], rec["co2"]
-    store = (lambda t: t) if last else rb
+    assert not (last and tail_next is not None)
+    store = (lambda t: t) if last else ((lambda t: tail_pack(t, tail_next)) if tail_next is not None else rb)
     # residual tail (BatchNorm-backward mode 0): g = dOut * leaky'(out); dS = g, dV = A*g + B*v + C
-    g = d_out * dleaky(out, SLOPE)
-    dv_raw, dg2, db2 = bn_backward(bn2, co2, g, v)
-    ds, dv = rb(g), rb(dv_raw)
+    if pre_tail is not None or d_out_is_g:
+        ds = d_out
+        s1, s2 = pre_tail if pre_tail is not None else (ds.sum((0, 2, 3)), (ds * v).sum((0, 2, 3)))
+        A2, B2, C2, dg2, db2 = bn_bwd_coefs(bn2, co2, s1, s2, ds.numel() // ds.shape[1], ds.dtype)
+        dv = rb(_cv(0, A2) * ds + _cv(0, B2) * v + _cv(0, C2))          # (apply pass on the stored g, stand-alone or staged: same arithmetic)
+        g = None
+    else:
+        g = d_out * dleaky(out, SLOPE)
+    if g is None:
+        pass
+    elif FUSE_BNAPPLY16:
+        # no apply pass: the reduction stores dS = bf16(g) (sums from the unrounded g), and the consumers of dV evaluate A*dS + B*v + C
+        # on the STORED dS while staging, rounding the result once to their bf16 operand
+        cnt = g.numel() // g.shape[1]
+        A2, B2, C2, dg2, db2 = bn_bwd_coefs(bn2, co2, g.sum((0, 2, 3)), (g * v).sum((0, 2, 3)), cnt, g.dtype)
+        ds = rb(g)
+        dv = rb(_cv(0, A2) * ds + _cv(0, B2) * v + _cv(0, C2))
+    else:
+        dv_raw, dg2, db2 = bn_backward(bn2, co2, g, v)
+        ds, dv = rb(g), rb(dv_raw)
     if need_w and affine:
         grads[prefix + ".conv.4.weight"], grads[prefix + ".conv.4.bias"] = dg2, db2
     pro1 = (co1["scale"], co1["shift"], SLOPE)
@@ -239,7 +275,8 @@ def block_bwd(blk, rec: dict, d_out: torch.Tensor, need_w: bool, affine: bool, g
         if need_w:
             grads[prefix + ".conv.0.weight"], grads[prefix + ".conv.0.bias"] = conv_wgrad(c0, up2(rb(xin)), du)
             grads[prefix + ".conv_input.weight"], grads[prefix + ".conv_input.bias"] = conv_wgrad(c1, rb(xin), ds_low)
-        d1 = store(F.conv2d(du, rb(pooled_dgrad_kernel(c0.weight.detach().to(du.dtype))), None, stride=2, padding=1))
+        d1 = F.conv2d(du, rb(pooled_dgrad_kernel(c0.weight.detach().to(du.dtype))), None, stride=2, padding=1)
+        d1 = d1 if last else rb(d1)                                      # first launch stores, the second accumulates onto the stored tensor
         return store(d1 + conv_dgrad(c1, ds_low, xin.shape[2:]))
     if need_w:
         grads[prefix + ".conv.0.weight"], grads[prefix + ".conv.0.bias"] = conv_wgrad(c0, rb(src), du)
@@ -258,8 +295,9 @@ def block_bwd(blk, rec: dict, d_out: torch.Tensor, need_w: bool, affine: bool, g
     return store(conv_dgrad(blk.down, dsrc, xin.shape[2:]))
 
 
-def conv_bn_pair_bwd(conv, bn, x, x_pro, u, co, slope, d_act, need_w, affine, grads, ckey, bkey, need_dx=True, last=False):
-    """nets._emit_conv_bn_pair_bwd: backward of a = act(BN(conv(x))) given d_act (as stored); returns the gradient w.r.t. x."""
+def conv_bn_pair_bwd(conv, bn, x, x_pro, u, co, slope, d_act, need_w, affine, grads, ckey, bkey, need_dx=True, last=False, tail_next=None):
+    """nets._emit_conv_bn_pair_bwd: backward of a = act(BN(conv(x))) given d_act (as stored); returns the gradient w.r.t. x
+    (`tail_pack` of it if tail_next is given)."""
     g = d_act * dleaky(u * _cv(0, co["scale"]) + _cv(0, co["shift"]), slope)
     du_raw, dg, db = bn_backward(bn, co, g, u)
     du = rb(du_raw)
@@ -270,6 +308,8 @@ def conv_bn_pair_bwd(conv, bn, x, x_pro, u, co, slope, d_act, need_w, affine, gr
     if not need_dx:
         return None
     dx = conv_dgrad(conv, du, x.shape[2:])
+    if tail_next is not None:
+        return tail_pack(dx, tail_next)
     return dx if last else rb(dx)
 
 
@@ -306,10 +346,15 @@ def encoder_fwd(enc, x: torch.Tensor, mode: str, px: str = ""):
 
 def encoder_bwd(enc, rec, dz, need_dx, need_w, affine, grads):
     px = rec["px"]
+    blocks, pre = rec["blocks"], None
     d = conv_bn_pair_bwd(enc.final_conv[0], enc.final_conv[1], rec["x4"], None, rec["uf"], rec["cof"], 0.0, dz, need_w, affine, grads,
-                         px + "final_conv.0", px + "final_conv.1")
+                         px + "final_conv.0", px + "final_conv.1", tail_next=tail_of(blocks[3]))
+    if FUSE_TAIL16:
+        d, pre = d
     for i in range(4, 0, -1):
-        d = block_bwd(getattr(enc, f"down{i}"), rec["blocks"][i - 1], d, need_w, affine, grads, f"{px}down{i}", last=False)
+        tn = tail_of(blocks[i - 2]) if i >= 2 else None
+        d = block_bwd(getattr(enc, f"down{i}"), blocks[i - 1], d, need_w, affine, grads, f"{px}down{i}", last=False, pre_tail=pre, tail_next=tn)
+        d, pre = d if tn is not None else (d, None)
     pro0 = (rec["co0"]["scale"], rec["co0"]["shift"], SLOPE)
     d = conv_bn_pair_bwd(enc.inc[3], enc.inc[4], rec["u0"], pro0, rec["v0"], rec["co1"], SLOPE, d, need_w, affine, grads, px + "inc.3", px + "inc.4")
     return conv_bn_pair_bwd(enc.inc[0], enc.inc[1], rec["x"], None, rec["u0"], rec["co0"], SLOPE, d, need_w, affine, grads, px + "inc.0", px + "inc.1",
@@ -368,9 +413,13 @@ def decoder_bwd(dec, rec, dout, need_dx, need_w, affine, grads):
         dout = dout * rec["out"] * (1 - rec["out"])
     if need_w:
         grads["final_conv.weight"], grads["final_conv.bias"] = conv_wgrad(cf, rb(rec["x4"]), dout)
-    d = rb(conv_dgrad(cf, dout, rec["x4"].shape[2:]))
+    blocks, pre = rec["blocks"], None
+    t = conv_dgrad(cf, dout, rec["x4"].shape[2:])
+    d, pre = tail_pack(t, tail_of(blocks[3])) if FUSE_TAIL16 else (rb(t), None)
     for i in range(4, 0, -1):
-        d = block_bwd(getattr(dec, f"up{i}"), rec["blocks"][i - 1], d, need_w, affine, grads, f"up{i}", last=(i == 1))
+        tn = tail_of(blocks[i - 2]) if i >= 2 else None
+        d = block_bwd(getattr(dec, f"up{i}"), blocks[i - 1], d, need_w, affine, grads, f"up{i}", last=(i == 1), pre_tail=pre, tail_next=tn)
+        d, pre = d if tn is not None else (d, None)
     return d if need_dx else None
 
 

@@ -98,6 +98,14 @@ class _Arenas:
         slot, off = ref
         return self.bases[slot][off:off + 4 * c].view(torch.float32).float().cpu().clone()
 
+    def tail_sums(self, pre, c):
+        """(sum g, sum g*v) of a fused residual tail from the statistics partials the producing launch wrote ([rows][2][c], one group)"""
+        if pre is None:
+            return None
+        (slot, off), rows = pre
+        part = self.bases[slot][off:off + 4 * rows * 2 * c].view(torch.float32).double().cpu().view(rows, 2, c).sum(0)
+        return part[0].float(), part[1].float()
+
     def co(self, co, c):
         return {k: self.vec(co[k], c) for k in ("scale", "shift", "mean", "invstd")}
 
@@ -126,13 +134,45 @@ def _check_grads(errs, hp, grads, prefix_filter):
     return [k for k in grads]
 
 
-@pytest.mark.parametrize("fused", [True, False], ids=["fused_bnbwd16", "separate_bnbwd"])
+class _switches:
+    """plan-compiler switches and the emulator's mirror of them, together: (FUSE_BNBWD16, FUSE_BNAPPLY16, FUSE_TAIL16)"""
+    NAMES = ("FUSE_BNBWD16", "FUSE_BNAPPLY16", "FUSE_TAIL16")
+
+    def __init__(self, values):
+        self.values = values
+
+    def __enter__(self):
+        self.old = [(getattr(nets, n), getattr(P, n)) for n in self.NAMES]
+        for n, v in zip(self.NAMES, self.values):
+            setattr(nets, n, v)
+            setattr(P, n, v)
+
+    def __exit__(self, *exc):
+        for n, (a, b) in zip(self.NAMES, self.old):
+            setattr(nets, n, a)
+            setattr(P, n, b)
+
+
+def _tail_next(A, rec, i):
+    """(out, v) of the block that consumes block i's input gradient, when the engine's plan fuses that block's tail (block i - 1)"""
+    if not P.FUSE_TAIL16 or i < 1:
+        return None
+    b = A.block(rec["blocks"][i - 1])
+    return (b["out"], b["v"])
+
+
+def _first(r):
+    return r[0] if isinstance(r, tuple) else r
+
+
+@pytest.mark.parametrize("fused", [(True, True, True), (True, True, False), (True, False, True), (True, False, False), (False, False, False)],
+                         ids=["all_fused", "staged_apply", "tail_fused", "fused_bnbwd16", "separate_passes"])
 @pytest.mark.parametrize("mode", ["A", "B"])
 @pytest.mark.parametrize("name", ["segmentation_decoder", "image_decoder"])
 def test_bf16_backward_plan_wiring_decoder(name, mode, fused, golden_sd):
-    old = nets.FUSE_BNBWD16, P.FUSE_BNBWD16
-    nets.FUSE_BNBWD16 = P.FUSE_BNBWD16 = fused          # the fused reduction and the stand-alone one, both against the oracle
-    try:
+    # ADVICE r2: the fused reduction and the stand-alone one, both against the oracle; round 3: the apply passes inside the consumers'
+    # staging and the tail's reduction inside the launch that writes dOut, each on and off
+    with _switches(fused):
         hnet, x, xh, yh, douts, dd = _run_hip(name, mode, golden_sd)
         A = _Arenas(hnet, xh, yh, dd)
         onet = O.build_networks(init=False)[name]
@@ -144,19 +184,18 @@ def test_bf16_backward_plan_wiring_decoder(name, mode, fused, golden_sd):
         dl = douts[0] * (A.t(rec["out"]) * (1 - A.t(rec["out"]))) if onet.last_act is not None else douts[0]
         x4 = A.t(rec["x4"])
         grads["final_conv.weight"], grads["final_conv.bias"] = P.conv_wgrad(onet.final_conv, P.rb(x4), dl)
-        _check(errs, "d_out4", A.t(dbg["d_out4"]), P.rb(P.conv_dgrad(onet.final_conv, dl, x4.shape[2:])))
+        t4 = P.conv_dgrad(onet.final_conv, dl, x4.shape[2:])
+        _check(errs, "d_out4", A.t(dbg["d_out4"]), P.tail_pack(t4, _tail_next(A, rec, 4))[0] if P.FUSE_TAIL16 else P.rb(t4))
         seen += _check_grads(errs, hp, grads, "final_conv")
         for i in range(3, -1, -1):
             grads = {}
             d_in = P.block_bwd(getattr(onet, f"up{i + 1}"), A.block(rec["blocks"][i]), A.t(dbg[f"d_out{i + 1}"]), True, affine, grads, f"up{i + 1}",
-                               last=(i == 0))
-            _check(errs, f"d_in of up{i + 1}", xh.grad if i == 0 else A.t(dbg[f"d_out{i}"]), d_in)
+                               last=(i == 0), pre_tail=A.tail_sums(dbg[f"tail_out{i + 1}"], rec["blocks"][i]["out"].c), tail_next=_tail_next(A, rec, i))
+            _check(errs, f"d_in of up{i + 1}", xh.grad if i == 0 else A.t(dbg[f"d_out{i}"]), _first(d_in))
             seen += _check_grads(errs, hp, grads, f"up{i + 1}")
         expect = {n for n, p in onet.named_parameters() if affine or not any(s in n for s in (".conv.1.", ".conv.4."))}
         assert set(seen) == expect, set(seen) ^ expect                   # every parameter of the network was compared
         print(f"bf16 wiring {name} mode {mode} fused {fused}: worst {max(errs)[0]:.2e} ({max(errs)[1]}), median {sorted(errs)[len(errs) // 2][0]:.2e}, {len(errs)} tensors")
-    finally:
-        nets.FUSE_BNBWD16, P.FUSE_BNBWD16 = old
 
 
 @pytest.mark.parametrize("mode", ["A", "B"])
@@ -190,13 +229,14 @@ def test_bf16_backward_plan_wiring_encoder(name, mode, golden_sd):
         dz = A.t(dbg["dz"])
     grads = {}
     d = P.conv_bn_pair_bwd(enc.final_conv[0], enc.final_conv[1], A.t(rec["x4"]), None, A.t(rec["uf"]), A.co(rec["cof"], c_lat), 0.0, dz, True, affine,
-                           grads, px + "final_conv.0", px + "final_conv.1")
-    _check(errs, "d behind final_conv", A.t(dbg["d_down5"]), d)
+                           grads, px + "final_conv.0", px + "final_conv.1", tail_next=_tail_next(A, rec, 4))
+    _check(errs, "d behind final_conv", A.t(dbg["d_down5"]), _first(d))
     seen += _check_grads(errs, hp, grads, "final")
     for j in range(4, 0, -1):
         grads = {}
-        d_in = P.block_bwd(getattr(enc, f"down{j}"), A.block(rec["blocks"][j - 1]), A.t(dbg[f"d_down{j + 1}"]), True, affine, grads, f"{px}down{j}", last=False)
-        _check(errs, f"d_in of down{j}", A.t(dbg[f"d_down{j}"]), d_in)
+        d_in = P.block_bwd(getattr(enc, f"down{j}"), A.block(rec["blocks"][j - 1]), A.t(dbg[f"d_down{j + 1}"]), True, affine, grads, f"{px}down{j}", last=False,
+                           pre_tail=A.tail_sums(dbg[f"tail_down{j + 1}"], rec["blocks"][j - 1]["out"].c), tail_next=_tail_next(A, rec, j - 1))
+        _check(errs, f"d_in of down{j}", A.t(dbg[f"d_down{j}"]), _first(d_in))
         seen += _check_grads(errs, hp, grads, f"down{j}")
     c0 = rec["u0"].c
     co0, co1 = A.co(rec["co0"], c0), A.co(rec["co1"], c0)
@@ -272,10 +312,12 @@ def test_bf16_saliency_dgrad_only_pass_vs_oracle(golden_sd):
     onet = O.build_networks(init=False)[name]
     onet.load_state_dict(golden_sd[name])
     rec, dbg, errs = A.fplan.rec, A.bplan.rec, []
-    _check(errs, "d_out4", A.t(dbg["d_out4"]), P.rb(P.conv_dgrad(onet.final_conv, douts[0], A.t(rec["x4"]).shape[2:])))
+    t4 = P.conv_dgrad(onet.final_conv, douts[0], A.t(rec["x4"]).shape[2:])
+    _check(errs, "d_out4", A.t(dbg["d_out4"]), P.tail_pack(t4, _tail_next(A, rec, 4))[0] if P.FUSE_TAIL16 else P.rb(t4))
     for i in range(3, -1, -1):
-        d_in = P.block_bwd(getattr(onet, f"up{i + 1}"), A.block(rec["blocks"][i]), A.t(dbg[f"d_out{i + 1}"]), False, False, {}, f"up{i + 1}", last=(i == 0))
-        _check(errs, f"d_in of up{i + 1}", g if i == 0 else A.t(dbg[f"d_out{i}"]), d_in)
+        d_in = P.block_bwd(getattr(onet, f"up{i + 1}"), A.block(rec["blocks"][i]), A.t(dbg[f"d_out{i + 1}"]), False, False, {}, f"up{i + 1}", last=(i == 0),
+                           pre_tail=A.tail_sums(dbg[f"tail_out{i + 1}"], rec["blocks"][i]["out"].c), tail_next=_tail_next(A, rec, i))
+        _check(errs, f"d_in of up{i + 1}", g if i == 0 else A.t(dbg[f"d_out{i}"]), _first(d_in))
     assert all(p.grad is None or float(p.grad.abs().max()) == 0.0 for p in hnet.parameters())
 
 

@@ -240,3 +240,193 @@ def test_bf16_wgrad_other_forms(n, cin, cout, h, w):
     wref22 = torch.zeros(cout, cin, 2, 2, dtype=torch.float64, requires_grad=True)
     F.conv2d(rb(x2), wref22, stride=2).backward(rb(dy2))
     close(dw22, wref22.grad, 3e-4, "wgrad 2x2 stride 2")
+
+
+# ------------------------------------------------------------------------------------------------ BatchNorm-backward prologue (round 3)
+def _virtual(g, u, coef, groups):
+    """A*g + B*u + C in fp32 (coef [groups][3][c]), rounded to bf16 once -- what the apply pass would have stored."""
+    n = g.shape[0]
+    gi = torch.arange(n) // (n // groups)
+    A, B, C = (coef[gi, k].view(n, -1, 1, 1) for k in range(3))
+    return (A * g + B * u + C).to(torch.bfloat16).float()
+
+
+def _apply_on_device(g, u, coef, groups):
+    """the stand-alone apply pass (ctl_bwd_apply_dt, mode 2) on bf16 tensors"""
+    n, c, h, w = g.shape
+    gd, ud = dev(g, True), dev(u, True)
+    out = torch.empty_like(gd)
+    check(lib.ctl_bwd_apply_dt(2, ops.ptr(gd), None, ops.ptr(ud), None, None, 0.0, ops.ptr(dev(coef)), n * h * w, c, None, ops.ptr(out), groups,
+                               1 | 4 | 16, ops.stream_ptr()))
+    return out
+
+
+BNPRO = [(2, 16, 16, 32, 32, 1), (4, 32, 16, 24, 20, 2), (2, 64, 64, 16, 16, 1), (2, 128, 64, 8, 8, 2), (16, 16, 16, 128, 128, 1), (3, 48, 32, 19, 37, 1),
+         (32, 16, 16, 64, 64, 2)]
+
+
+@pytest.mark.parametrize("n,c,cout,h,w,groups", BNPRO)
+def test_bf16_conv_bn_backward_prologue(n, c, cout, h, w, groups):
+    """pro_affine 2: conv over the VIRTUAL tensor A*g + B*u + C (zero padding outside the image) == conv over the tensor the apply pass
+    stores.  3x3 stride 1 with and without the CTL_EPI_BNBWD epilogue, and the 4x4 stride-2 pooled data gradient."""
+    if n % groups:
+        pytest.skip("n % groups")
+    gen = torch.Generator().manual_seed(n + c + cout + h + groups)
+    g = torch.randn(n, c, h, w, generator=gen).to(torch.bfloat16).float()
+    u = torch.randn(n, c, h, w, generator=gen).to(torch.bfloat16).float()
+    coef = torch.stack([torch.rand(groups, c, generator=gen) + 0.5, torch.randn(groups, c, generator=gen) * 0.3,
+                        torch.randn(groups, c, generator=gen) * 0.3], 1).contiguous()            # [groups][3][c]
+    virt = _virtual(g, u, coef, groups)
+    stored = _apply_on_device(g, u, coef, groups)
+    mism = float((stored.float().cpu() != virt).float().mean())
+    assert mism < 2e-3, f"apply pass vs fp32 formula: {mism:.2e} of the elements round differently"
+    dt = BF | _ffi.DT_X16 | _ffi.DT_Y16
+    wt = torch.randn(cout, c, 3, 3, generator=gen) * 0.2
+    wp = ops.pack_oihw_fwd_bf16(dev(wt))
+    # plain
+    d = _ffi.conv_desc(n=n, hin=h, win=w, cin=c, hout=h, wout=w, cout=cout, ks=3, groups=groups, pro_affine=2, epi_flags=_ffi.EPI_STATS, dt=dt)
+    y, st = ops.conv_forward(d, dev(g, True), wp, pro_scale=dev(coef), x2=dev(u, True), want_stats=True)
+    ref = F.conv2d(rb(virt), rb(wt), padding=1)
+    close(y, ref, 1e-3, "conv3x3 over the virtual BatchNorm-backward tensor", True)
+    d0 = _ffi.conv_desc(n=n, hin=h, win=w, cin=c, hout=h, wout=w, cout=cout, ks=3, groups=groups, epi_flags=_ffi.EPI_STATS, dt=dt)
+    y0, st0 = ops.conv_forward(d0, stored, wp, want_stats=True)
+    same = float((y.float() == y0.float()).float().mean())
+    assert same > 0.98, f"staged apply vs stored apply: only {same:.4f} of the outputs are bit-identical"
+    close(y, y0.float(), 1e-3, "staged apply vs stored apply")
+    blocks = lib.ctl_conv_stats_blocks(_ffi.desc_ptr(d))
+    close(st.view(groups, blocks, 2, cout).sum(1), st0.view(groups, -1, 2, cout).sum(1), 1e-3, "statistics")
+    # with the BatchNorm-backward epilogue of the NEXT BatchNorm (the block's conv.3 data gradient)
+    u1 = torch.randn(n, cout, h, w, generator=gen).to(torch.bfloat16).float()
+    sc, sh = torch.rand(groups, cout, generator=gen) + 0.5, torch.randn(groups, cout, generator=gen) * 0.3
+    db = _ffi.conv_desc(n=n, hin=h, win=w, cin=c, hout=h, wout=w, cout=cout, ks=3, groups=groups, pro_affine=2,
+                        epi_flags=_ffi.EPI_BNBWD | _ffi.EPI_STATS, epi_slope=0.2, dt=dt | _ffi.DT_RES16)
+    yb, stb = ops.conv_forward(db, dev(g, True), wp, pro_scale=dev(coef), x2=dev(u, True), res=dev(u1, True), res_scale=dev(sc), res_shift=dev(sh),
+                               want_stats=True)
+    gi = torch.arange(n) // (n // groups)
+    sa = u1 * sc[gi].view(n, cout, 1, 1) + sh[gi].view(n, cout, 1, 1)
+    refb = ref * torch.where(sa > 0, 1.0, 0.2).double()
+    close(yb, refb, 1e-3, "virtual input + CTL_EPI_BNBWD", True)
+    part = stb.cpu().double().view(groups, -1, 2, cout).sum(1)
+    for k in range(groups):
+        sel = gi == k
+        r0, r1 = refb[sel].sum((0, 2, 3)), (refb[sel] * u1[sel].double()).sum((0, 2, 3))
+        assert float((part[k, 0] - r0).abs().max()) <= 2e-3 * float(r0.abs().max()) + 5e-2, "sum g"
+        assert float((part[k, 1] - r1).abs().max()) <= 2e-3 * float(r1.abs().max()) + 5e-2, "sum g*u"
+    # 4x4 stride 2 (the pooled data gradient of a conv on an up-sampled input)
+    if h % 2 == 0 and w % 2 == 0:
+        w4 = torch.randn(cout, c, 4, 4, generator=gen) * 0.2
+        d4 = _ffi.conv_desc(n=n, hin=h, win=w, cin=c, hout=h // 2, wout=w // 2, cout=cout, ks=4, stride=2, groups=groups, pro_affine=2, dt=dt)
+        y4, _ = ops.conv_forward(d4, dev(g, True), ops.pack_oihw_fwd_bf16(dev(w4)), pro_scale=dev(coef), x2=dev(u, True))
+        close(y4, F.conv2d(rb(virt), rb(w4), stride=2, padding=1), 1e-3, "conv4x4 s2 over the virtual tensor", True)
+
+
+@pytest.mark.parametrize("up", [0, 1])
+@pytest.mark.parametrize("n,cin,cout,h,w,groups", BNPRO)
+def test_bf16_wgrad_virtual_output_gradient(n, cin, cout, h, w, groups, up):
+    """ctl_conv_wgrad_ex: dy = A*g + B*u + C evaluated in the staging (3x3 on a plain or nearest-up-sampled input); the bias gradient is
+    the sum of the virtual tensor."""
+    if n % groups or (up and (h % 2 or w % 2)):
+        pytest.skip("shape")
+    gen = torch.Generator().manual_seed(n + cin + cout + h + groups + up)
+    hx, wx = (h // 2, w // 2) if up else (h, w)
+    x = torch.randn(n, cin, hx, wx, generator=gen).to(torch.bfloat16).float()
+    g = torch.randn(n, cout, h, w, generator=gen).to(torch.bfloat16).float()
+    u = torch.randn(n, cout, h, w, generator=gen).to(torch.bfloat16).float()
+    coef = torch.stack([torch.rand(groups, cout, generator=gen) + 0.5, torch.randn(groups, cout, generator=gen) * 0.3,
+                        torch.randn(groups, cout, generator=gen) * 0.3], 1).contiguous()
+    virt = _virtual(g, u, coef, groups)
+    sc, sh = torch.rand(groups, cin, generator=gen) + 0.5, torch.randn(groups, cin, generator=gen) * 0.3
+    dt = BF | _ffi.DT_X16 | _ffi.DT_Y16
+    for pro in (False, True):
+        d = _ffi.conv_desc(n=n, hin=hx, win=wx, cin=cin, hout=h, wout=w, cout=cout, ks=3, groups=groups, in_mode=_ffi.IN_UP2 if up else 0,
+                           pro_affine=int(pro), pro_slope=0.2, dt=dt)
+        dw, db = torch.zeros(cout, cin, 3, 3, device=DEV), torch.zeros(cout, device=DEV)
+        ops.conv_wgrad(d, dev(x, True), dev(g, True), dw, (cin * 9, 9, 3, 1), dbias=db, pro_scale=dev(sc) if pro else None,
+                       pro_shift=dev(sh) if pro else None, dy2=dev(u, True), dy_coef=dev(coef))
+        gi = torch.arange(n) // (n // groups)
+        xin = leaky(x * sc[gi].view(n, cin, 1, 1) + sh[gi].view(n, cin, 1, 1), 0.2) if pro else x
+        xr = rb(xin)
+        if up:
+            xr = xr.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)
+        wref = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+        F.conv2d(xr, wref, padding=1).backward(rb(virt))
+        close(dw, wref.grad, 1.5e-3, f"wgrad with a virtual output gradient (up {up}, prologue {pro})")
+        close(db, rb(virt).sum((0, 2, 3)), 1e-3, "bias gradient = sum of the virtual tensor")
+
+
+def test_bn_backward_prologue_argument_checks():
+    n, c, h, w = 2, 16, 8, 8
+    x = torch.zeros(n, c, h, w, device=DEV, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    wp = ops.pack_oihw_fwd_bf16(torch.zeros(c, c, 3, 3, device=DEV))
+    coef = torch.zeros(3 * c, device=DEV)
+    dt = BF | _ffi.DT_X16 | _ffi.DT_Y16
+    d = _ffi.conv_desc(n=n, hin=h, win=w, cin=c, hout=h, wout=w, cout=c, ks=3, pro_affine=2, dt=dt)
+    with pytest.raises(_ffi.CtlError):
+        ops.conv_forward(d, x, wp, pro_scale=coef)                                         # no x2
+    d1 = _ffi.conv_desc(n=n, hin=h, win=w, cin=c, hout=h, wout=w, cout=c, ks=1, pad=0, pro_affine=2, dt=dt)
+    with pytest.raises(_ffi.CtlError):
+        ops.conv_forward(d1, x, ops.pack_oihw_fwd_bf16(torch.zeros(c, c, 1, 1, device=DEV)), pro_scale=coef, x2=x)      # 1x1: no such kernel
+    xf = torch.zeros(n, c, h, w, device=DEV).contiguous(memory_format=torch.channels_last)
+    d32 = _ffi.conv_desc(n=n, hin=h, win=w, cin=c, hout=h, wout=w, cout=c, ks=3, pro_affine=2)
+    with pytest.raises(_ffi.CtlError):
+        ops.conv_forward(d32, xf, ops.pack_oihw_fwd(torch.zeros(c, c, 3, 3, device=DEV)), pro_scale=coef, x2=xf)         # fp32 family: unsupported
+    dw = torch.zeros(c, c, 3, 3, device=DEV)
+    d32w = _ffi.conv_desc(n=n, hin=h, win=w, cin=c, hout=h, wout=w, cout=c, ks=3)
+    with pytest.raises(_ffi.CtlError):
+        ops.conv_wgrad(d32w, xf, xf, dw, (c * 9, 9, 3, 1), dy2=xf, dy_coef=coef)
+
+
+@pytest.mark.parametrize("family", ["fp32", "bf16"])
+@pytest.mark.parametrize("form", ["1x1_accum", "1x1", "2x2_s2", "zins_3x3"])
+@pytest.mark.parametrize("n,cin,cout,h,w,groups", [(2, 16, 16, 32, 32, 1), (4, 32, 16, 24, 20, 2), (2, 128, 64, 8, 8, 1), (16, 16, 16, 128, 128, 1), (3, 48, 32, 18, 38, 1)])
+def test_tail_backward_epilogue(n, cin, cout, h, w, groups, form, family):
+    """CTL_EPI_TAILBWD: the launch that writes dL/dOut of a residual block stores g = dOut * leaky'(out) instead and leaves the tail's
+    BatchNorm-backward sums (sum g, sum g*v) in the statistics partials.  bf16 family: sums from the unrounded g, g stored as bf16."""
+    if n % groups:
+        pytest.skip("n % groups")
+    b16 = family == "bf16"
+    gen = torch.Generator().manual_seed(n + cin + cout + h + len(form))
+    q = (lambda t: t.to(torch.bfloat16).float()) if b16 else (lambda t: t)
+    out, v = q(torch.randn(n, cout, h, w, generator=gen)), q(torch.randn(n, cout, h, w, generator=gen))
+    dt = (BF | _ffi.DT_X16 | _ffi.DT_Y16 | _ffi.DT_RES16) if b16 else 0
+    flags = _ffi.EPI_TAILBWD | _ffi.EPI_STATS
+    y0 = None
+    if form.startswith("1x1"):
+        x = q(torch.randn(n, cin, h, w, generator=gen))
+        wt = torch.randn(cout, cin, 1, 1, generator=gen) * 0.3
+        wp = (ops.pack_oihw_fwd_bf16 if b16 else ops.pack_oihw_fwd)(dev(wt))
+        ref = F.conv2d(rb(x) if b16 else x.double(), rb(wt) if b16 else wt.double())
+        d = _ffi.conv_desc(n=n, hin=h, win=w, cin=cin, hout=h, wout=w, cout=cout, ks=1, pad=0, groups=groups, epi_slope=0.2, dt=dt,
+                           epi_flags=flags | (_ffi.EPI_ACCUM if form == "1x1_accum" else 0))
+        if form == "1x1_accum":
+            y0 = q(torch.randn(n, cout, h, w, generator=gen))
+            ref = ref + y0.double()
+    elif form == "2x2_s2":
+        x = q(torch.randn(n, cin, 2 * h, 2 * w, generator=gen))
+        wt = torch.randn(cout, cin, 2, 2, generator=gen) * 0.3
+        wp = (ops.pack_oihw_fwd_bf16 if b16 else ops.pack_oihw_fwd)(dev(wt))
+        ref = F.conv2d(rb(x) if b16 else x.double(), rb(wt) if b16 else wt.double(), stride=2)
+        d = _ffi.conv_desc(n=n, hin=2 * h, win=2 * w, cin=cin, hout=h, wout=w, cout=cout, ks=2, stride=2, pad=0, groups=groups, epi_slope=0.2, dt=dt,
+                           epi_flags=flags)
+    else:
+        if h % 2 or w % 2:
+            pytest.skip("even sizes")
+        x = q(torch.randn(n, cin, h // 2, w // 2, generator=gen))
+        wt = torch.randn(cout, cin, 3, 3, generator=gen) * 0.2
+        wp = (ops.pack_oihw_fwd_bf16 if b16 else ops.pack_oihw_fwd)(dev(wt))
+        xz = torch.zeros(n, cin, h, w, dtype=torch.float64)
+        xz[:, :, ::2, ::2] = rb(x) if b16 else x.double()
+        ref = F.conv2d(xz, rb(wt) if b16 else wt.double(), padding=1)
+        d = _ffi.conv_desc(n=n, hin=h // 2, win=w // 2, cin=cin, hout=h, wout=w, cout=cout, ks=3, in_mode=_ffi.IN_ZINS2, groups=groups, epi_slope=0.2,
+                           dt=dt, epi_flags=flags)
+    y = dev(y0, b16) if y0 is not None else None
+    y, st = ops.conv_forward(d, dev(x, b16), wp, res=dev(out, b16), res2=dev(v, b16), y=y, want_stats=True)
+    g = ref * torch.where(out > 0, 1.0, 0.2).double()
+    close(y, g, 3e-4 if b16 else 2e-4, f"tail epilogue {form}", b16)
+    part = st.cpu().double().view(groups, -1, 2, cout).sum(1)
+    gi = torch.arange(n) // (n // groups)
+    for k in range(groups):
+        sel = gi == k
+        r0, r1 = g[sel].sum((0, 2, 3)), (g[sel] * v[sel].double()).sum((0, 2, 3))
+        assert float((part[k, 0] - r0).abs().max()) <= 5e-4 * float(g[sel].abs().sum((0, 2, 3)).max()) + 1e-3, "sum g"
+        assert float((part[k, 1] - r1).abs().max()) <= 5e-4 * float((g[sel] * v[sel].double()).abs().sum((0, 2, 3)).max()) + 1e-3, "sum g*v"
