@@ -132,6 +132,7 @@ class CooperativeStepGraph:
                 self.pool = torch.cuda.graph_pool_handle()
             for m in s.model.values():
                 m.weights_changed()           # the weight re-pack launches belong INTO the graph (every replay follows an Adam step)
+                m._grad_is_zero = False       # ... and so does the step's first gradient fill (every replay follows a step that left gradients)
             e.graph = torch.cuda.CUDAGraph()
             split = self.grad_hook is not None
             with torch.cuda.graph(e.graph, pool=self.pool, stream=self.stream):
@@ -189,6 +190,7 @@ class CooperativeStepGraph:
         self._dev_adam_count = counts[0] + 1
         for m in s.model.values():
             m.weights_changed()
+            m.mark_grad_written()              # (the replay left this step's gradients in the buffers: the next zero_grad has work to do)
         s.z_i, s.z_s = e.z
         s.last_masks = dict(e.masks)
         self.replays += 1

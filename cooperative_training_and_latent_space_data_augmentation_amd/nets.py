@@ -42,6 +42,8 @@ SMALL_CIN = True         # K-packed taps for the Cin <= 4 first layers
 PHASE_CONVS = True       # 2x2 phase forms of the up-sampled forward / stride-2 data gradient
 FUSE_BNBWD = False       # BN1-backward reduction inside the dgrad conv epilogue (fp32: matrix-bound kernel, measured no gain)
 FUSE_BNBWD16 = True      # the same in the bf16 family, where the data gradient is not matrix-bound
+FUSE_PAIR16 = True       # bf16: the conv-BatchNorm-activation pairs at the head of the encoders get g = dAct * act' and their sums from the launch that
+                         # writes dAct (CTL_EPI_BNBWD on it), and no apply pass either (FUSE_BNAPPLY16)
 FUSE_TAIL16 = True       # bf16: CTL_EPI_TAILBWD in the bf16 family (the tail's reduction pass and the separately rounded dOut disappear)
 FUSE_BNAPPLY16 = True    # bf16: the BatchNorm-backward apply passes of the residual blocks run inside the staging of their consumers (pro_affine 2 / dy2)
 FUSE_TAIL = True         # fp32: the residual tail's BatchNorm-backward reduction inside the launch that writes dOut (CTL_EPI_TAILBWD): dOut is
@@ -203,7 +205,7 @@ class PlanBuilder:
 
     def conv(self, x: T, wp_ref, cout, ks, *, stride=1, in_mode=0, pro=None, bias_ref=None, stats=False, act=0,
              slope=0.0, res=None, accum=False, out: Optional[T] = None, arena: Optional[Arena] = None, nsub=1,
-             hout=None, wout=None, bnbwd=None, pad=None, tail=None, x2=None):
+             hout=None, wout=None, bnbwd=None, pad=None, tail=None, x2=None, keep_stats=False):
         """Emit one CTL_OP_CONV.  pro = (scale_ref, shift_ref, slope); res = (T v, scale_ref, shift_ref).
         bnbwd = (T u, scale_ref, shift_ref, slope): data-gradient conv whose result is dL/d leaky(BN(u)); the epilogue writes
         g = result * leaky'(BN(u)) and the BatchNorm-backward sums go to the statistics partials (CTL_EPI_BNBWD).
@@ -250,7 +252,7 @@ class PlanBuilder:
             blocks = lib.ctl_conv_stats_blocks(_ffi.desc_ptr(d))
             if blocks <= 0:
                 raise _ffi.CtlError("conv plan: " + lib.ctl_last_error().decode())
-            if tail is not None:      # consumed by the NEXT block's finalize: kept in the backward arena, not in the transient scratch
+            if tail is not None or keep_stats:      # consumed by the NEXT block's finalize: kept in the backward arena, not in the transient scratch
                 stats_ref = self.bscr.alloc(4 * self.groups * blocks * 2 * cout)
             else:
                 stats_ref, = self.scr(4 * self.groups * blocks * 2 * cout)
@@ -489,6 +491,7 @@ class CtlNet(nn.Module):
         self._plans: Dict[tuple, Plan] = {}
         self._packed_ok = False
         self._grad_written = True          # see zero_grad / FlatAdam.step
+        self._grad_is_zero = False         # the gradient buffer is KNOWN to hold zeros (zero_grad ran, nothing wrote since): see zero_grad
         # deferred parameter gradients (solver.cooperative_step): while set, a backward pass parks its flat gradient here instead of
         # handing it to autograd; collect_deferred_grads() adds them into `.grad` with ONE launch, in forward order
         self._defer_grads = False
@@ -630,13 +633,19 @@ class CtlNet(nn.Module):
         buf.copy_(self._flat.grad)
         self._flat.grad = buf
         self._grad_written = True
+        self._grad_is_zero = False
         for n, p in self.named_parameters():
             p.grad = buf[self._poff[n]:self._poff[n] + p.numel()].view(p.shape)
 
     def zero_grad(self, set_to_none: bool = False):
         """Gradients are views of one flat buffer that is never re-allocated: zero it in place.  (upstream calls
         `decoder_function.zero_grad()` inside the masking functions, model_util.py:251-254)"""
-        self._flat.grad.zero_()
+        # A buffer nothing has written since the last zero_grad is not filled again (upstream zeroes the decoders after every saliency
+        # pass, the step zeroes them once more: 17 of 22 fills per targeted step found nothing to clear).  Every writer inside the
+        # engine clears the flag; anything else that writes `.grad` says so through mark_grad_written().
+        if not self._grad_is_zero:
+            self._flat.grad.zero_()
+            self._grad_is_zero = True
         self._grad_written = False        # FlatAdam skips a network no backward pass has written since (torch: `.grad is None`)
 
     def collect_deferred_grads(self):
@@ -656,10 +665,12 @@ class CtlNet(nn.Module):
             for g in chunk:
                 g.record_stream(cur)
         self._grad_written = True
+        self._grad_is_zero = False
 
     def mark_grad_written(self):
         """Call after filling `.grad` by other means than a backward pass of this network (e.g. a hand-written gradient)."""
         self._grad_written = True
+        self._grad_is_zero = False
 
     def weights_changed(self):
         """Call after modifying parameters in place by other means than the engine's optimizer / load_state_dict."""
@@ -875,12 +886,16 @@ class CtlNet(nn.Module):
         return (rec["out"], rec["v"], SLOPE)
 
     def _emit_block_bwd(self, pb: PlanBuilder, rec: dict, d_out: T, d_in: Optional[T], need_w: bool, affine: bool, *, pre_tail=None,
-                        tail_next=None):
+                        tail_next=None, act_next=None):
         """Backward of one residual block.  Returns the gradient w.r.t. the block input `xin` (post-activation tensor
         the block consumed; if rec['xin_pro'] is set it is the gradient w.r.t. the *activated* virtual tensor).
         pre_tail = (stats_ref, blocks): `d_out` is already g = dOut * leaky'(out) and the tail's BatchNorm-backward sums are in the
         statistics partials (the launch that wrote it carried CTL_EPI_TAILBWD).  tail_next = `_tail_of` the block that consumes THIS
-        block's input gradient: the last launch writing it carries the flag; then returns (d_in, stats_ref, blocks)."""
+        block's input gradient: the last launch writing it carries the flag; then returns (d_in, stats_ref, blocks).
+        act_next = (T u, scale_ref, shift_ref, slope): the consumer is a conv-BatchNorm-activation pair with BatchNorm input u (`down`
+        blocks): the last launch carries CTL_EPI_BNBWD, d_in is g = dAct * act'(BN(u)); same return."""
+        assert not (tail_next is not None and act_next is not None)
+        ep = dict(tail=tail_next) if act_next is None else dict(bnbwd=act_next, keep_stats=True)
         C, B = self._convs, self._bns
         prefix, pre = rec["prefix"], rec["pre"]
         src, src_mode, u, v, out, xin = rec["src"], rec["src_mode"], rec["u"], rec["v"], rec["out"], rec["xin"]
@@ -944,10 +959,11 @@ class CtlNet(nn.Module):
             dsrc_shape = (src.n, 2 * src.h, 2 * src.w, src.c)
         if d_in is None:
             d_in = A.tensor(xin.n, xin.h, xin.w, xin.c)
-        fin = lambda st, blk: d_in if tail_next is None else (d_in, st, blk)
+        fin = lambda st, blk: d_in if (tail_next is None and act_next is None) else (d_in, st, blk)
         if pre == "nn":
             # sumpool2(conv3x3^T(dU)) as one 4x4 stride-2 conv (no full-resolution gradient tensor at all), then the 1x1 part
             pb.conv(du, self._wp_ref(c0.wp_up), c0.cin, 4, stride=2, out=d_in, x2=du2)
+            assert act_next is None
             _, st, blk = pb.conv(ds_low, self._wp_ref(c1.wp_dgrad), c1.cin, 1, out=d_in, accum=True, tail=tail_next)
             return fin(st, blk)
         dsrc = A.tensor(*dsrc_shape)
@@ -959,6 +975,7 @@ class CtlNet(nn.Module):
                 pb.chan_sum(dsrc, pb.G(ci.b_off))
                 # role swap: "input" = dsrc (full res), "output gradient" = xin  ->  Wt[ci][co][a][b]
                 pb.wgrad(dsrc, xin, 2, stride=2, dw_ref=pb.G(ci.w_off), strides=(ci.cout * 4, 4, 2, 1))
+            assert act_next is None
             _, st, blk = pb.conv(dsrc, self._wp_ref(ci.wp_dgrad), ci.cin, 2, stride=2, out=d_in, tail=tail_next)
         else:  # down: stride-2 conv
             ci = C[prefix + ".down"]
@@ -966,29 +983,44 @@ class CtlNet(nn.Module):
                 pb.wgrad(xin, dsrc, 3, stride=2, pro=rec["xin_pro"], dw_ref=pb.G(ci.w_off), strides=(ci.cin * k9, k9, 3, 1),
                          dbias_ref=pb.G(ci.b_off))
             if ci.wp_s2d >= 0 and xin.h == 2 * dsrc.h and xin.w == 2 * dsrc.w:
-                _, st, blk = pb.conv(dsrc, self._wp_ref(ci.wp_s2d), ci.cin, 2, nsub=4, pad=0, hout=dsrc.h, wout=dsrc.w, out=d_in, tail=tail_next)
+                _, st, blk = pb.conv(dsrc, self._wp_ref(ci.wp_s2d), ci.cin, 2, nsub=4, pad=0, hout=dsrc.h, wout=dsrc.w, out=d_in, **ep)
             else:       # odd sizes: 3x3 conv over the zero-inserted gradient
-                _, st, blk = pb.conv(dsrc, self._wp_ref(ci.wp_dgrad), ci.cin, 3, in_mode=_ffi.IN_ZINS2, out=d_in, hout=xin.h, wout=xin.w, tail=tail_next)
+                _, st, blk = pb.conv(dsrc, self._wp_ref(ci.wp_dgrad), ci.cin, 3, in_mode=_ffi.IN_ZINS2, out=d_in, hout=xin.h, wout=xin.w, **ep)
         return fin(st, blk)
 
     def _emit_conv_bn_pair_bwd(self, pb, conv_key, bn_key, x: T, x_pro, u: T, co, slope, d_act: T, d_x: Optional[T], need_w, affine,
-                               need_dx=True, tail_next=None):
+                               need_dx=True, tail_next=None, pre=None, act_next=None):
         """Backward of  a = act(BN(conv3x3/1x1(x)))  given d_act (gradient w.r.t. a).  Returns gradient w.r.t. x
-        (w.r.t. the activated virtual tensor if x_pro is set)."""
+        (w.r.t. the activated virtual tensor if x_pro is set).
+        pre = (stats_ref, blocks): d_act is already g = dAct * act'(BN(u)) and its BatchNorm-backward sums are in the statistics partials
+        (the launch that wrote it carried CTL_EPI_BNBWD: `act_next` of its producer); the apply pass then runs inside the consumers' staging
+        where they can take it (3x3 weight gradient; 3x3 data gradient into a bf16 tensor).  act_next: see _emit_block_bwd."""
         ci, bn = self._convs[conv_key], self._bns[bn_key]
         A = pb.bscr
-        du = A.tensor(u.n, u.h, u.w, u.c)
-        pb.bn_backward(1, d_act, None, u, bn, co, slope, ds=None, dx=du, affine_grad=need_w and affine)
         k2 = ci.ks * ci.ks
+        dy2 = None
+        if pre is not None:
+            assert pb.b16 and d_act.b16 and u.b16 and ci.ks == 3 and tail_next is None
+            if need_dx and d_x is None:
+                d_x = A.tensor(x.n, x.h, x.w, x.c)
+            stored = need_dx and not (d_x.b16 and x.c % 16 == 0)      # an fp32 / narrow input gradient: that conv reads a stored dU
+            du = A.tensor(u.n, u.h, u.w, u.c) if stored else None
+            coef = pb.bn_backward_from_stats(d_act, u, bn, co, pre[0], pre[1], dx=du, affine_grad=need_w and affine)
+            if not stored:
+                du, dy2 = d_act, (u, coef)
+        else:
+            du = A.tensor(u.n, u.h, u.w, u.c)
+            pb.bn_backward(1, d_act, None, u, bn, co, slope, ds=None, dx=du, affine_grad=need_w and affine)
         if need_w:
             pb.wgrad(x, du, ci.ks, pro=x_pro, in_mode=_ffi.IN_C4 if ci.wp_c4 >= 0 else 0, dw_ref=pb.G(ci.w_off),
-                     strides=(ci.cin * k2, k2, ci.ks, 1), dbias_ref=pb.G(ci.b_off))
+                     strides=(ci.cin * k2, k2, ci.ks, 1), dbias_ref=pb.G(ci.b_off), dy2=dy2)
         if not need_dx:
             return None
         if d_x is None:
             d_x = A.tensor(x.n, x.h, x.w, x.c)
-        _, st, blk = pb.conv(du, self._wp_ref(ci.wp_dgrad), ci.cin, ci.ks, out=d_x, tail=tail_next)
-        return d_x if tail_next is None else (d_x, st, blk)
+        ep = dict(tail=tail_next) if act_next is None else dict(bnbwd=act_next, keep_stats=True)
+        _, st, blk = pb.conv(du, self._wp_ref(ci.wp_dgrad), ci.cin, ci.ks, out=d_x, x2=dy2, **ep)
+        return d_x if (tail_next is None and act_next is None) else (d_x, st, blk)
 
     # ---------------------------------------------------------------- public compute entry points
     def _alloc_out(self, shape):
@@ -1059,6 +1091,7 @@ class CtlNet(nn.Module):
             gflat = torch.empty(self._pcount, dtype=torch.float32, device=self.device)
             tensors[S_GRAD] = gflat
             self._grad_written = True
+            self._grad_is_zero = False     # (the pass's gradient reaches the buffer through autograd or collect_deferred_grads)
         self._run(plan, tensors)
         return dx, gflat
 
@@ -1112,22 +1145,29 @@ class MyEncoder(CtlNet):
             d, pre = d[0], d[1:]
         dbg["d_down5"] = d               # gradient w.r.t. the output of down4 (with FUSE_TAIL: already times leaky'(out), i.e. dS of down4)
         dbg["tail_down5"] = pre          # ... and where the tail's BatchNorm-backward sums of down4 are (statistics partials ref, rows)
+        u0, v0 = rec["u0"], rec["v0"]
+        pair16 = FUSE_PAIR16 and FUSE_BNAPPLY16 and pb.b16 and u0.b16 and v0.b16 and pb.groups * u0.c <= 256 and blocks[0].get("drop") is None
+        act1 = (v0, rec["co1"]["scale"], rec["co1"]["shift"], SLOPE) if pair16 else None
+        act0 = (u0, rec["co0"]["scale"], rec["co0"]["shift"], SLOPE) if pair16 else None
         for i, brec in reversed(list(enumerate(blocks))):
             tail = self._tail_of(pb, blocks[i - 1]) if i >= 1 else None
-            d = self._emit_block_bwd(pb, brec, d, None, need_w, affine, pre_tail=pre, tail_next=tail)
+            d = self._emit_block_bwd(pb, brec, d, None, need_w, affine, pre_tail=pre, tail_next=tail, act_next=act1 if i == 0 else None)
             pre = None
-            if tail is not None:
+            if tail is not None or (i == 0 and act1 is not None):
                 d, pre = d[0], d[1:]
-            dbg[f"d_down{i + 1}"] = d    # gradient w.r.t. the input of block down{i+1}
+            dbg[f"d_down{i + 1}"] = d    # gradient w.r.t. the input of block down{i+1} (down1 with FUSE_PAIR16: g of the inc.3 pair)
             dbg[f"tail_down{i + 1}"] = pre
         # d = gradient w.r.t. x1 = LReLU(BN(v0))
         pro0 = (rec["co0"]["scale"], rec["co0"]["shift"], SLOPE)
-        d = self._emit_conv_bn_pair_bwd(pb, px + "inc.3", px + "inc.4", rec["u0"], pro0, rec["v0"], rec["co1"], SLOPE, d, None,
-                                        need_w, affine)
-        dbg["d_inc3"] = d
+        d = self._emit_conv_bn_pair_bwd(pb, px + "inc.3", px + "inc.4", u0, pro0, v0, rec["co1"], SLOPE, d, None,
+                                        need_w, affine, pre=pre, act_next=act0)
+        pre = None
+        if act0 is not None:
+            d, pre = d[0], d[1:]
+        dbg["d_inc3"], dbg["pre_inc3"] = d, pre
         dx = T((S_DX, 0), *rec["x"][1:]) if need_dx else None
-        self._emit_conv_bn_pair_bwd(pb, px + "inc.0", px + "inc.1", rec["x"], None, rec["u0"], rec["co0"], SLOPE, d, dx,
-                                    need_w, affine, need_dx=need_dx)
+        self._emit_conv_bn_pair_bwd(pb, px + "inc.0", px + "inc.1", rec["x"], None, u0, rec["co0"], SLOPE, d, dx,
+                                    need_w, affine, need_dx=need_dx, pre=pre)
         return dbg
 
     def _zdims(self, n, h, w):

@@ -32,6 +32,7 @@ import torch.nn.functional as F
 SLOPE = 0.2
 ROUND = True                 # False: no rounding anywhere (pins the backward formulas against autograd)
 FUSE_BNBWD16 = True          # nets.FUSE_BNBWD16: BatchNorm-backward sums of the in-block BatchNorm inside the data-gradient epilogue
+FUSE_PAIR16 = True           # nets.FUSE_PAIR16: the head pairs of the encoders get g and their sums from the launch that writes dAct (CTL_EPI_BNBWD)
 FUSE_TAIL16 = True           # nets.FUSE_TAIL16: the launch that writes a block's output gradient stores g = dOut * leaky'(out) and takes the tail's sums
 FUSE_BNAPPLY16 = True        # nets.FUSE_BNAPPLY16: dV / dU of a residual block are never stored; their consumers apply the coefficients to the stored g
 
@@ -213,23 +214,32 @@ def tail_pack(t: torch.Tensor, tail_next):
     return rb(g), (g.sum((0, 2, 3)), (g * v_n).sum((0, 2, 3)))
 
 
+def act_pack(t: torch.Tensor, act_next):
+    """CTL_EPI_BNBWD epilogue of the launch that writes dAct of a conv-BatchNorm-activation pair, act_next = (u, co, slope): g = dAct *
+    act'(BN(u)) from the UNROUNDED dAct = t, sums from the unrounded g, g stored.  Returns (g stored, (sum g, sum g*u))."""
+    u_n, co_n, slope = act_next
+    g = t * dleaky(u_n * _cv(0, co_n["scale"]) + _cv(0, co_n["shift"]), slope)
+    return rb(g), (g.sum((0, 2, 3)), (g * u_n).sum((0, 2, 3)))
+
+
 def tail_of(brec):
     return (brec["out"], brec["v"]) if FUSE_TAIL16 else None
 
 
 def block_bwd(blk, rec: dict, d_out: torch.Tensor, need_w: bool, affine: bool, grads: dict, prefix: str, last: bool, *, pre_tail=None,
-              d_out_is_g: bool = False, tail_next=None):
+              d_out_is_g: bool = False, tail_next=None, act_next=None):
     """nets._emit_block_bwd.  d_out: gradient w.r.t. the block output as stored by its producer.  Returns the gradient w.r.t. the block
     input (w.r.t. the activated virtual tensor if rec['xin_pro'] is set): rounded like a stored bf16 tensor unless `last` (then it is the
     fp32 gradient leaving the network).
     pre_tail = (sum g, sum g*v) from `tail_pack`: d_out is already the stored g of this block's tail (d_out_is_g without sums: teacher-
     forced tests, the sums are then taken from the stored g).  tail_next = (out, v) of the block that consumes this block's input
-    gradient: returns `tail_pack` of it instead."""
+    gradient: returns `tail_pack` of it instead; act_next = (u, co, slope) of the pair that consumes it: `act_pack`."""
     c0, bn1, c3, bn2, c1 = blk.conv[0], blk.conv[1], blk.conv[3], blk.conv[4], blk.conv_input
     pre, src, u, v, out, xin = rec["pre"], rec["src"], rec["u"], rec["v"], rec["out"], rec["xin"]
     co1, co2 = rec["co1"], rec["co2"]
-    assert not (last and tail_next is not None)
-    store = (lambda t: t) if last else ((lambda t: tail_pack(t, tail_next)) if tail_next is not None else rb)
+    assert not (last and (tail_next is not None or act_next is not None)) and not (tail_next is not None and act_next is not None)
+    store = (lambda t: t) if last else ((lambda t: tail_pack(t, tail_next)) if tail_next is not None else
+                                        ((lambda t: act_pack(t, act_next)) if act_next is not None else rb))
     # residual tail (BatchNorm-backward mode 0): g = dOut * leaky'(out); dS = g, dV = A*g + B*v + C
     if pre_tail is not None or d_out_is_g:
         ds = d_out
@@ -295,12 +305,17 @@ def block_bwd(blk, rec: dict, d_out: torch.Tensor, need_w: bool, affine: bool, g
     return store(conv_dgrad(blk.down, dsrc, xin.shape[2:]))
 
 
-def conv_bn_pair_bwd(conv, bn, x, x_pro, u, co, slope, d_act, need_w, affine, grads, ckey, bkey, need_dx=True, last=False, tail_next=None):
+def conv_bn_pair_bwd(conv, bn, x, x_pro, u, co, slope, d_act, need_w, affine, grads, ckey, bkey, need_dx=True, last=False, tail_next=None,
+                     pre=None, act_next=None):
     """nets._emit_conv_bn_pair_bwd: backward of a = act(BN(conv(x))) given d_act (as stored); returns the gradient w.r.t. x
-    (`tail_pack` of it if tail_next is given)."""
-    g = d_act * dleaky(u * _cv(0, co["scale"]) + _cv(0, co["shift"]), slope)
-    du_raw, dg, db = bn_backward(bn, co, g, u)
-    du = rb(du_raw)
+    (`tail_pack` / `act_pack` of it if tail_next / act_next is given).  pre = (sum g, sum g*u): d_act is the stored g of `act_pack`."""
+    if pre is not None:
+        A, B, C, dg, db = bn_bwd_coefs(bn, co, pre[0], pre[1], d_act.numel() // d_act.shape[1], d_act.dtype)
+        du = rb(_cv(0, A) * d_act + _cv(0, B) * u + _cv(0, C))          # apply on the stored g (staged in the consumers or stand-alone: same arithmetic)
+    else:
+        g = d_act * dleaky(u * _cv(0, co["scale"]) + _cv(0, co["shift"]), slope)
+        du_raw, dg, db = bn_backward(bn, co, g, u)
+        du = rb(du_raw)
     if need_w and affine:
         grads[bkey + ".weight"], grads[bkey + ".bias"] = dg, db
     if need_w:
@@ -310,6 +325,8 @@ def conv_bn_pair_bwd(conv, bn, x, x_pro, u, co, slope, d_act, need_w, affine, gr
     dx = conv_dgrad(conv, du, x.shape[2:])
     if tail_next is not None:
         return tail_pack(dx, tail_next)
+    if act_next is not None:
+        return act_pack(dx, act_next)
     return dx if last else rb(dx)
 
 
@@ -351,14 +368,20 @@ def encoder_bwd(enc, rec, dz, need_dx, need_w, affine, grads):
                          px + "final_conv.0", px + "final_conv.1", tail_next=tail_of(blocks[3]))
     if FUSE_TAIL16:
         d, pre = d
+    pair = FUSE_PAIR16 and FUSE_BNAPPLY16
+    act1 = (rec["v0"], rec["co1"], SLOPE) if pair else None
+    act0 = (rec["u0"], rec["co0"], SLOPE) if pair else None
     for i in range(4, 0, -1):
         tn = tail_of(blocks[i - 2]) if i >= 2 else None
-        d = block_bwd(getattr(enc, f"down{i}"), blocks[i - 1], d, need_w, affine, grads, f"{px}down{i}", last=False, pre_tail=pre, tail_next=tn)
-        d, pre = d if tn is not None else (d, None)
+        an = act1 if i == 1 else None
+        d = block_bwd(getattr(enc, f"down{i}"), blocks[i - 1], d, need_w, affine, grads, f"{px}down{i}", last=False, pre_tail=pre, tail_next=tn, act_next=an)
+        d, pre = d if (tn is not None or an is not None) else (d, None)
     pro0 = (rec["co0"]["scale"], rec["co0"]["shift"], SLOPE)
-    d = conv_bn_pair_bwd(enc.inc[3], enc.inc[4], rec["u0"], pro0, rec["v0"], rec["co1"], SLOPE, d, need_w, affine, grads, px + "inc.3", px + "inc.4")
+    d = conv_bn_pair_bwd(enc.inc[3], enc.inc[4], rec["u0"], pro0, rec["v0"], rec["co1"], SLOPE, d, need_w, affine, grads, px + "inc.3", px + "inc.4",
+                         pre=pre, act_next=act0)
+    d, pre = d if act0 is not None else (d, None)
     return conv_bn_pair_bwd(enc.inc[0], enc.inc[1], rec["x"], None, rec["u0"], rec["co0"], SLOPE, d, need_w, affine, grads, px + "inc.0", px + "inc.1",
-                            need_dx=need_dx, last=True)
+                            need_dx=need_dx, last=True, pre=pre)
 
 
 def dual_fwd(net, x, mode):

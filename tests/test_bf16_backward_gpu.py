@@ -198,9 +198,19 @@ def test_bf16_backward_plan_wiring_decoder(name, mode, fused, golden_sd):
         print(f"bf16 wiring {name} mode {mode} fused {fused}: worst {max(errs)[0]:.2e} ({max(errs)[1]}), median {sorted(errs)[len(errs) // 2][0]:.2e}, {len(errs)} tensors")
 
 
+@pytest.mark.parametrize("pair", [True, False], ids=["pairs_fused", "pairs_separate"])
 @pytest.mark.parametrize("mode", ["A", "B"])
 @pytest.mark.parametrize("name", ["image_encoder", "shape_encoder"])
-def test_bf16_backward_plan_wiring_encoder(name, mode, golden_sd):
+def test_bf16_backward_plan_wiring_encoder(name, mode, pair, golden_sd):
+    old = nets.FUSE_PAIR16, P.FUSE_PAIR16
+    nets.FUSE_PAIR16 = P.FUSE_PAIR16 = pair
+    try:
+        _wiring_encoder(name, mode, golden_sd)
+    finally:
+        nets.FUSE_PAIR16, P.FUSE_PAIR16 = old
+
+
+def _wiring_encoder(name, mode, golden_sd):
     hnet, x, xh, yh, douts, dd = _run_hip(name, mode, golden_sd)
     A = _Arenas(hnet, xh, yh, dd)
     onet = O.build_networks(init=False)[name]
@@ -232,22 +242,28 @@ def test_bf16_backward_plan_wiring_encoder(name, mode, golden_sd):
                            grads, px + "final_conv.0", px + "final_conv.1", tail_next=_tail_next(A, rec, 4))
     _check(errs, "d behind final_conv", A.t(dbg["d_down5"]), _first(d))
     seen += _check_grads(errs, hp, grads, "final")
+    c0 = rec["u0"].c
+    co0, co1 = A.co(rec["co0"], c0), A.co(rec["co1"], c0)
+    # FUSE_PAIR16: the launch that writes the gradient of a head pair's activation stores g and leaves the pair's BatchNorm-backward sums
+    pair = P.FUSE_PAIR16 and P.FUSE_BNAPPLY16
+    assert (dbg["tail_down1"] is not None) == pair and (dbg["pre_inc3"] is not None) == pair
+    act1 = (A.t(rec["v0"]), co1, P.SLOPE) if pair else None
+    act0 = (A.t(rec["u0"]), co0, P.SLOPE) if pair else None
     for j in range(4, 0, -1):
         grads = {}
         d_in = P.block_bwd(getattr(enc, f"down{j}"), A.block(rec["blocks"][j - 1]), A.t(dbg[f"d_down{j + 1}"]), True, affine, grads, f"{px}down{j}", last=False,
-                           pre_tail=A.tail_sums(dbg[f"tail_down{j + 1}"], rec["blocks"][j - 1]["out"].c), tail_next=_tail_next(A, rec, j - 1))
+                           pre_tail=A.tail_sums(dbg[f"tail_down{j + 1}"], rec["blocks"][j - 1]["out"].c), tail_next=_tail_next(A, rec, j - 1),
+                           act_next=act1 if j == 1 else None)
         _check(errs, f"d_in of down{j}", A.t(dbg[f"d_down{j}"]), _first(d_in))
         seen += _check_grads(errs, hp, grads, f"down{j}")
-    c0 = rec["u0"].c
-    co0, co1 = A.co(rec["co0"], c0), A.co(rec["co1"], c0)
     grads = {}
     d = P.conv_bn_pair_bwd(enc.inc[3], enc.inc[4], A.t(rec["u0"]), (co0["scale"], co0["shift"], P.SLOPE), A.t(rec["v0"]), co1, P.SLOPE, A.t(dbg["d_down1"]),
-                           True, affine, grads, px + "inc.3", px + "inc.4")
-    _check(errs, "d behind inc.3", A.t(dbg["d_inc3"]), d)
+                           True, affine, grads, px + "inc.3", px + "inc.4", pre=A.tail_sums(dbg["tail_down1"], c0), act_next=act0)
+    _check(errs, "d behind inc.3", A.t(dbg["d_inc3"]), _first(d))
     seen += _check_grads(errs, hp, grads, "inc3")
     grads = {}
     dx = P.conv_bn_pair_bwd(enc.inc[0], enc.inc[1], x, None, A.t(rec["u0"]), co0, P.SLOPE, A.t(dbg["d_inc3"]), True, affine, grads, px + "inc.0", px + "inc.1",
-                            last=True)
+                            last=True, pre=A.tail_sums(dbg["pre_inc3"], c0))
     _check(errs, "dx", xh.grad, dx)
     seen += _check_grads(errs, hp, grads, "inc0")
     bn_names = {n for n, m in onet.named_modules() if isinstance(m, torch.nn.BatchNorm2d)}
