@@ -144,5 +144,5 @@ int ctl_conv_wgrad_bf16(const ctl_conv* d, const void* x, const float* pro_scale
                         const float* dy_coef, float* w_partial, float* b_partial, ctl_stream stream);
 
 // in-process profiling (ctl_plan.cpp): returns a token >= 0 if this launch is being timed
-int ctl_prof_begin(const char* kind, const ctl_conv* d, const ctl_conv_cfg* c, int nt, hipStream_t stream);
+int ctl_prof_begin(const char* kind, const ctl_conv* d, const ctl_conv_cfg* c, int nt, hipStream_t stream, bool dy2 = false);
 void ctl_prof_end(int token, hipStream_t stream);

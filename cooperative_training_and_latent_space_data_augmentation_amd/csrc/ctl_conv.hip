@@ -29,7 +29,10 @@
 // CTL_IN_C4: plain stored input with <= 4 channels whose 3x3 taps are K-packed (see conv_igemm_kernel)
 #define CTL_MODE_IS_PLAIN(M) ((M) == CTL_IN_PLAIN || (M) == CTL_IN_C4)
 
-template <int KS, int S, int MODE, int MT, int TW>
+// X2 (ctl_conv.pro_affine == 2, the BatchNorm-backward prologue): the operand is the VIRTUAL tensor  A[c] * x + B[c] * x2 + C[c]  of two
+// tensors of one geometry (x = g = dL/da * leaky', x2 = the BatchNorm input): the `apply` pass of the BatchNorm backward runs here, in
+// the staging of its consumers, and its output tensor never exists (two packed fmas per element on top of the second load).
+template <int KS, int S, int MODE, int MT, int TW, bool X2 = false>
 struct XStage {
     using G = Geom<KS, S, MT, TW>;
     static constexpr int UNITS = G::IH * G::IW * 4;
@@ -39,6 +42,7 @@ struct XStage {
     int rc[NU];         // r | c << 16 (tile-relative virtual coordinates); 0x7fff7fff for the units past the tile
     int lds[NU];        // LDS float offset; the units past the tile write a dump slot behind the image
     f32x4 v[NU];
+    f32x4 v2[X2 ? NU : 1];      // X2: the second tensor's units
     unsigned vmask;     // bit i: unit i of the tile held in v[] lies inside the image (gets the prologue)
     int pad_h, pad_w;   // top / left padding of this block's problem (G::PAD except for the phase problems of the 2x2 kernels)
     bool all_in;        // wave-uniform: every unit of the tile held in v[] is inside the image and the channel range
@@ -66,7 +70,8 @@ struct XStage {
         pad_h = pad_w = G::PAD;
     }
 
-    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rx, const ctl_conv& d, int n, int ho0, int wo0, int g) {
+    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rx, const ctl_conv& d, int n, int ho0, int wo0, int g) { load(rx, rx, d, n, ho0, wo0, g); }
+    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rx, __amdgpu_buffer_rsrc_t rx2, const ctl_conv& d, int n, int ho0, int wo0, int g) {
         const int vh0 = ho0 * S - pad_h, vw0 = wo0 * S - pad_w;
         const unsigned hv = CTL_MODE_IS_PLAIN(MODE) ? d.hin : 2 * d.hin;
         const unsigned wv = CTL_MODE_IS_PLAIN(MODE) ? d.win : 2 * d.win;
@@ -85,6 +90,10 @@ struct XStage {
         if (all_in) {
 #pragma unroll
             for (int i = 0; i < NU; ++i) v[i] = ctl_bload4s(rx, rel[i], tb);
+            if constexpr (X2) {
+#pragma unroll
+                for (int i = 0; i < NU; ++i) v2[i] = ctl_bload4s(rx2, rel[i], tb);
+            }
             return;
         }
         const bool chan_ok = g * 16 + (threadIdx.x & 3) * 4 < d.cin;
@@ -99,7 +108,10 @@ struct XStage {
             m |= ok ? (1u << i) : 0u;
         }
         vmask = m;
-        if (d.cin >= 4) {
+        if constexpr (X2) {
+#pragma unroll
+            for (int i = 0; i < NU; ++i) { v[i] = ctl_bload4(rx, vo[i]); v2[i] = ctl_bload4(rx2, vo[i]); }
+        } else if (d.cin >= 4) {
 #pragma unroll
             for (int i = 0; i < NU; ++i) v[i] = ctl_bload4(rx, vo[i]);
         } else {
@@ -111,8 +123,24 @@ struct XStage {
     // `goff` = BatchNorm group of the tile held in v[] times cin (row of the [groups][cin] prologue coefficients).  The
     // coefficients are read from the block's LDS copy: a global load here sits between the two barriers of a step with nothing
     // to hide its latency behind
+    // X2: pro_scale / pro_shift / pro_c are the LDS copies of A / B / C ([group][cin] each)
     __device__ __forceinline__ void store(float* __restrict__ xt, const ctl_conv& d, int g,
-                                          const float* pro_scale, const float* pro_shift, int goff) {
+                                          const float* pro_scale, const float* pro_shift, int goff, const float* pro_c = nullptr) {
+        if constexpr (X2) {
+            const int cb = g * 16 + (threadIdx.x & 3) * 4;
+            const f32x4 ca = *reinterpret_cast<const f32x4*>(pro_scale + goff + cb), cbb = *reinterpret_cast<const f32x4*>(pro_shift + goff + cb);
+            const f32x4 cc = *reinterpret_cast<const f32x4*>(pro_c + goff + cb);
+            if (all_in) {
+#pragma unroll
+                for (int i = 0; i < NU; ++i) *reinterpret_cast<f32x4*>(xt + lds[i]) = ca * v[i] + cbb * v2[i] + cc;
+                return;
+            }
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < NU; ++i)      // padding stays zero (C alone would leak into it)
+                *reinterpret_cast<f32x4*>(xt + lds[i]) = ((vmask >> i) & 1u) ? (ca * v[i] + cbb * v2[i] + cc) : zero;
+            return;
+        }
         if (!d.pro_affine) {      // out-of-range units were loaded as hardware zeros: nothing to compute
 #pragma unroll
             for (int i = 0; i < NU; ++i) *reinterpret_cast<f32x4*>(xt + lds[i]) = v[i];
@@ -190,7 +218,7 @@ extern "C" int ctl_debug_timing(unsigned long long* out8) {
 #ifndef CTL_LB_SMALL
 #define CTL_LB_SMALL 4
 #endif
-template <int KS, int S, int MODE, int MT, int TW, int NT, int EPI>
+template <int KS, int S, int MODE, int MT, int TW, int NT, int EPI, bool X2 = false>      // X2: see XStage (pro_scale = the [group][3][cin] coefficients)
 __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : ((MT * NT >= 4) ? CTL_LB_MID : CTL_LB_SMALL)) void conv_igemm_kernel(const ctl_conv d, const float* __restrict__ x,
                                                           const float* __restrict__ wpack,
                                                           const float* __restrict__ bias,
@@ -201,7 +229,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : ((MT * NT >= 4
                                                           const float* __restrict__ res_shift, float* __restrict__ y,
                                                           float* __restrict__ stats_partial, int tiles_h, int tiles_w,
                                                           int G_chunks, int64_t wpack_sub_stride, int ntiles,
-                                                          const float* __restrict__ res2) {
+                                                          const float* __restrict__ res2, const float* __restrict__ x2) {
     using G = Geom<KS, S, MT, TW>;
     constexpr int TAPS = KS * KS;
     // C4: input with <= 4 channels.  The four lane groups of an MFMA (its k index) carry four different TAPS (channels 0-3 each)
@@ -213,11 +241,12 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : ((MT * NT >= 4
     constexpr int RED_FLOATS = 4 * NT * 16 * 2;
     constexpr int WT_FLOATS = NFRAG * NT * 256;
     constexpr int XT_ALLOC = G::XT_FLOATS;
-    __shared__ __attribute__((aligned(16))) float xt[XT_ALLOC + WT_FLOATS + RED_FLOATS + 2 * CTL_PRO_MAX];
+    __shared__ __attribute__((aligned(16))) float xt[XT_ALLOC + WT_FLOATS + RED_FLOATS + (X2 ? 3 : 2) * CTL_PRO_MAX];
     float* wt = xt + XT_ALLOC;
     float* sred = wt + WT_FLOATS;        // statistics reduction scratch (a flush can happen while xt holds the next tile)
     float* cf_scale = sred + RED_FLOATS; // prologue coefficients [groups][cin]
     float* cf_shift = cf_scale + CTL_PRO_MAX;
+    float* cf_c = cf_shift + (X2 ? CTL_PRO_MAX : 0);
     constexpr int WU = NFRAG * NT * 64, NW = (WU + 255) / 256;
 
     const int tid = threadIdx.x;
@@ -243,6 +272,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : ((MT * NT >= 4
     const int group_n = d.n / ngroups;                               // images per BatchNorm group
     const int oy0 = (z >> 1) * d.out_sub, ox0 = (z & 1) * d.out_sub;
     const __amdgpu_buffer_rsrc_t rx = ctl_rsrc(x, (int64_t)d.n * d.hin * d.win * d.cin * 4);
+    const __amdgpu_buffer_rsrc_t rx2 = X2 ? ctl_rsrc(x2, (int64_t)d.n * d.hin * d.win * d.cin * 4) : rx;
     const int64_t ybytes = (int64_t)d.n * d.out_h * d.out_w * d.cout * 4;
     const __amdgpu_buffer_rsrc_t ry = ctl_rsrc(y, ybytes);
     const __amdgpu_buffer_rsrc_t rres = ctl_rsrc(EPI ? (const void*)res : (const void*)y, ybytes);
@@ -290,7 +320,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : ((MT * NT >= 4
         xrd4[j] = xt + ((wrow + tp / 3) * G::IWP + p + tp % 3) * 16;
     }
 
-    XStage<KS, S, MODE, MT, TW> xs;
+    XStage<KS, S, MODE, MT, TW, X2> xs;
     xs.init(d);
     if (KS == 2 && S == 1) {
         // phase problems (z = 2a + b, outputs at (2i+a, 2j+b)): d.pad == 2 -> 3x3 conv on a nearest-upsampled input, phase (a,b)
@@ -326,15 +356,21 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : ((MT * NT >= 4
     nxt = cur;
     TM_DECL
     if (total_it > 0) {
-        xs.load(rx, d, cur.n, cur.th * G::TH, cur.tw * TW, 0);
+        xs.load(rx, rx2, d, cur.n, cur.th * G::TH, cur.tw * TW, 0);
         wload(0);
     }
-    if (d.pro_affine) {      // behind the first tile's loads, in front of their use
+    if constexpr (X2) {      // coefficients as the BatchNorm-backward finalize writes them: [group][A | B | C][cin]
+        for (int i = tid; i < ngroups * d.cin; i += 256) {
+            const int gi = i / d.cin, ch = i - gi * d.cin;
+            cf_scale[i] = pro_scale[(gi * 3 + 0) * d.cin + ch]; cf_shift[i] = pro_scale[(gi * 3 + 1) * d.cin + ch]; cf_c[i] = pro_scale[(gi * 3 + 2) * d.cin + ch];
+        }
+        __syncthreads();
+    } else if (d.pro_affine) {      // behind the first tile's loads, in front of their use
         for (int i = tid; i < ngroups * d.cin; i += 256) { cf_scale[i] = pro_scale[i]; cf_shift[i] = pro_shift[i]; }
         __syncthreads();
     }
     if (total_it > 0) {
-        xs.store(xt, d, 0, cf_scale, cf_shift, (cur.n / group_n) * d.cin);
+        xs.store(xt, d, 0, cf_scale, cf_shift, (cur.n / group_n) * d.cin, cf_c);
         wstore();
     }
     __syncthreads();
@@ -389,7 +425,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : ((MT * NT >= 4
         const bool new_w = has_next && G_chunks > 1;
         if (g2 == 0) nxt.next();
         if (has_next) {
-            xs.load(rx, d, nxt.n, nxt.th * G::TH, nxt.tw * TW, g2);
+            xs.load(rx, rx2, d, nxt.n, nxt.th * G::TH, nxt.tw * TW, g2);
             if (new_w) wload(g2);
         }
         TM(0)
@@ -442,7 +478,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : ((MT * NT >= 4
         ctl_barrier_lds_reads_done();    // every wave is done reading this step's LDS images
         TM(2)
         if (has_next) {    // refill LDS from the prefetched registers
-            xs.store(xt, d, g2, cf_scale, cf_shift, (nxt.n / group_n) * d.cin);   // v[] holds chunk g2 of tile nxt (== cur unless g2 == 0)
+            xs.store(xt, d, g2, cf_scale, cf_shift, (nxt.n / group_n) * d.cin, cf_c);   // v[] holds chunk g2 of tile nxt (== cur unless g2 == 0)
             if (new_w) wstore();
         }
         TM(3)
@@ -602,23 +638,27 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : ((MT * NT >= 4
 // blockIdx.x, +gridDim.x, ... and keeps all KS*KS*NTW accumulator tiles in registers; its four waves split the
 // tile's pixels and are summed through LDS at the end.  Partial results per split are reduced by wgrad_reduce_kernel
 // (deterministic: no float atomics).
-template <int KS, int S, int MODE, int MT, int TW, int NTW>
+// DY2: the output gradient is the virtual BatchNorm-backward result  A * dy + B * dy2 + C  (coefficients [group][3][cout] as the finalize
+// writes them; dy = g, dy2 = the BatchNorm input): the `apply` pass runs in this staging (see XStage X2)
+template <int KS, int S, int MODE, int MT, int TW, int NTW, bool DY2 = false>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ctl_conv d, const float* __restrict__ x,
                                                           const float* __restrict__ pro_scale,
                                                           const float* __restrict__ pro_shift,
                                                           const float* __restrict__ dy, float* __restrict__ w_partial,
                                                           float* __restrict__ b_partial, int tiles_h, int tiles_w,
-                                                          int ntiles, int cin_p, int cout_p) {
+                                                          int ntiles, int cin_p, int cout_p, const float* __restrict__ dy2,
+                                                          const float* __restrict__ dy_coef) {
     using G = Geom<KS, S, MT, TW>;
     constexpr int TAPS = KS * KS;
     constexpr int DYT_FLOATS = NTW * G::TP * 16;
     constexpr int RED_FLOATS = 4 * NTW * 256;
     constexpr int LDS_FLOATS = (G::XT_FLOATS + DYT_FLOATS > RED_FLOATS) ? (G::XT_FLOATS + DYT_FLOATS) : RED_FLOATS;
-    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS + 2 * CTL_PRO_MAX];
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS + (DY2 ? 5 : 2) * CTL_PRO_MAX];
     float* xt = lds;
     float* dyt = lds + G::XT_FLOATS;
     float* cf_scale = lds + LDS_FLOATS;  // prologue coefficients [groups][cin], see XStage::store
     float* cf_shift = cf_scale + CTL_PRO_MAX;
+    float* cd = cf_shift + CTL_PRO_MAX;  // DY2: A | B | C, [group][cout] each
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -651,10 +691,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ctl_conv d, const
     constexpr int DU = G::TP * NTW * 4, ND = DU / 256;       // TP is a multiple of 64 -> exact
     const __amdgpu_buffer_rsrc_t rx = ctl_rsrc(x, (int64_t)d.n * d.hin * d.win * d.cin * 4);
     const __amdgpu_buffer_rsrc_t rdy = ctl_rsrc(dy, (int64_t)d.n * d.hout * d.wout * d.cout * 4);
+    const __amdgpu_buffer_rsrc_t rdy2 = DY2 ? ctl_rsrc(dy2, (int64_t)d.n * d.hout * d.wout * d.cout * 4) : rdy;
     XStage<KS, S, MODE, MT, TW> xs;
     xs.init(d);
     // dy tile: per-thread constants (pixel row/col inside the tile, byte offset relative to the tile origin, LDS offset)
     f32x4 dv[ND];
+    f32x4 dv2[DY2 ? ND : 1];
+    unsigned dmask = 0;             // DY2: units of the tile in flight that lie inside the image
+    bool dwhole = false;            // DY2: ... all of them
+    int dco = 0;                    // DY2: first channel of this thread's units (the same for all of them: 256 % (4 NTW) == 0)
     int drel[ND], drc[ND], dlds[ND];
 #pragma unroll
     for (int i = 0; i < ND; ++i) {
@@ -667,23 +712,48 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ctl_conv d, const
         drc[i] = (co < d.cout) ? (pr | (pc << 16)) : 0x7fff7fff;
         drel[i] = (co < d.cout) ? ((pr * d.wout + pc) * d.cout + co) * 4 : CTL_OOB;
         dlds[i] = (t * G::TP + pix) * 16 + cq * 4;
+        if (i == 0) dco = co < d.cout ? co : 0;
     }
     auto dyload = [&](int n, int ho0, int wo0) {
         const int tb = ((n * d.hout + ho0) * d.wout + wo0) * d.cout * 4;
-        if (ho0 + G::TH <= d.hout && wo0 + TW <= d.wout && d.cout >= 4) {      // whole tile: scalar tile offset, no per-unit VALU
+        dwhole = ho0 + G::TH <= d.hout && wo0 + TW <= d.wout && d.cout >= 4;
+        if (dwhole) {      // whole tile: scalar tile offset, no per-unit VALU
 #pragma unroll
             for (int i = 0; i < ND; ++i) dv[i] = ctl_bload4s(rdy, drel[i], tb);
+            if constexpr (DY2) {
+#pragma unroll
+                for (int i = 0; i < ND; ++i) dv2[i] = ctl_bload4s(rdy2, drel[i], tb);
+            }
             return;
         }
+        dmask = 0;
 #pragma unroll
         for (int i = 0; i < ND; ++i) {
             const bool ok = (unsigned)(ho0 + (drc[i] & 0xffff)) < (unsigned)d.hout && (unsigned)(wo0 + (drc[i] >> 16)) < (unsigned)d.wout;
             const int vo = ok ? (tb + drel[i]) : CTL_OOB;
+            if constexpr (DY2) {
+                dv[i] = ctl_bload4(rdy, vo); dv2[i] = ctl_bload4(rdy2, vo);
+                dmask |= (ok && drel[i] != CTL_OOB) ? (1u << i) : 0u;
+                continue;
+            }
             if (d.cout >= 4) dv[i] = ctl_bload4(rdy, vo);
             else dv[i] = f32x4{ctl_bload1(rdy, vo), 0.f, 0.f, 0.f};
         }
     };
-    auto dystore = [&]() {
+    auto dystore = [&](int goff) {
+        if constexpr (DY2) {
+            const float* cc = cd + goff + dco;
+            const f32x4 ca = *reinterpret_cast<const f32x4*>(cc), cb = *reinterpret_cast<const f32x4*>(cc + CTL_PRO_MAX);
+            const f32x4 c3 = *reinterpret_cast<const f32x4*>(cc + 2 * CTL_PRO_MAX);
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < ND; ++i) {
+                const f32x4 r = ca * dv[i] + cb * dv2[i] + c3;
+                // pixels past the image contribute nothing (C alone would)
+                *reinterpret_cast<f32x4*>(dyt + dlds[i]) = (dwhole || ((dmask >> i) & 1u)) ? r : zero;
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < ND; ++i) *reinterpret_cast<f32x4*>(dyt + dlds[i]) = dv[i];
     };
@@ -694,13 +764,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ctl_conv d, const
         xs.load(rx, d, cur.n, cur.th * G::TH, cur.tw * TW, g);
         dyload(cur.n, cur.th * G::TH, cur.tw * TW);
     }
-    if (d.pro_affine) {
-        for (int i = tid; i < (d.groups > 1 ? d.groups : 1) * d.cin; i += 256) { cf_scale[i] = pro_scale[i]; cf_shift[i] = pro_shift[i]; }
+    if (d.pro_affine || DY2) {
+        if (d.pro_affine)
+            for (int i = tid; i < (d.groups > 1 ? d.groups : 1) * d.cin; i += 256) { cf_scale[i] = pro_scale[i]; cf_shift[i] = pro_shift[i]; }
+        if constexpr (DY2) {
+            for (int i = tid; i < (d.groups > 1 ? d.groups : 1) * d.cout; i += 256) {
+                const int gi = i / d.cout, ch = i - gi * d.cout;
+                cd[i] = dy_coef[(gi * 3 + 0) * d.cout + ch]; cd[CTL_PRO_MAX + i] = dy_coef[(gi * 3 + 1) * d.cout + ch];
+                cd[2 * CTL_PRO_MAX + i] = dy_coef[(gi * 3 + 2) * d.cout + ch];
+            }
+        }
         __syncthreads();
     }
     if ((int)blockIdx.x < ntiles) {
         xs.store(xt, d, g, cf_scale, cf_shift, (cur.n / group_n) * d.cin);
-        dystore();
+        dystore((cur.n / group_n) * d.cout);
     }
     __syncthreads();
     TM(7)
@@ -742,7 +820,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ctl_conv d, const
         TM(2)
         if (has_next) {
             xs.store(xt, d, g, cf_scale, cf_shift, (cur.n / group_n) * d.cin);
-            dystore();
+            dystore((cur.n / group_n) * d.cout);
         }
         TM(3)
         ctl_barrier_lds_writes_done();
@@ -1114,19 +1192,22 @@ extern "C" int ctl_pack_weights(const float* src, float* dst, int32_t cout, int3
 
 struct conv_call {
     const ctl_conv* d; ctl_conv_cfg c;
-    const float *x, *wpack, *bias, *pro_scale, *pro_shift, *res, *res_scale, *res_shift, *res2;
+    const float *x, *wpack, *bias, *pro_scale, *pro_shift, *res, *res_scale, *res_shift, *res2, *x2;
     float *y, *stats_partial;
     hipStream_t stream;
     bool query;      // only report the grid (ctl_conv_stats_blocks), launch nothing
     int grid_x;
 };
 
-template <int KS, int S, int MODE, int MT, int TW, int NT, int EPI>
+template <int KS, int S, int MODE, int MT, int TW, int NT, int EPI, bool X2 = false>
 static void conv_go(conv_call& a) {
+    if constexpr (!X2 && ((KS == 3 && S == 1 && MODE == CTL_IN_PLAIN) || (KS == 4 && S == 2)) && EPI != 2) {
+        if (a.d->pro_affine == 2) { conv_go<KS, S, MODE, MT, TW, NT, EPI, true>(a); return; }      // the BatchNorm-backward prologue (checked in ctl_conv_forward_ex)
+    }
     static int occ = 0;          // resident blocks per CU of this instantiation (asked once)
     if (!occ) {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_igemm_kernel<KS, S, MODE, MT, TW, NT, EPI>, 256, 0) != hipSuccess || n < 1) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_igemm_kernel<KS, S, MODE, MT, TW, NT, EPI, X2>, 256, 0) != hipSuccess || n < 1) {
             (void)hipGetLastError();
             n = 2;
         }
@@ -1137,9 +1218,9 @@ static void conv_go(conv_call& a) {
     a.grid_x = ctl_conv_grid_x(ntiles, (a.c.cot / NT) * d->nsub, occ);
     if (a.query) return;
     const dim3 grid((unsigned)a.grid_x, (unsigned)(a.c.cot / NT), (unsigned)d->nsub);
-    conv_igemm_kernel<KS, S, MODE, MT, TW, NT, EPI><<<grid, dim3(256), 0, a.stream>>>(
+    conv_igemm_kernel<KS, S, MODE, MT, TW, NT, EPI, X2><<<grid, dim3(256), 0, a.stream>>>(
         *d, a.x, a.wpack, a.bias, a.pro_scale, a.pro_shift, a.res, a.res_scale, a.res_shift, a.y, a.stats_partial, a.c.tiles_h,
-        a.c.tiles_w, a.c.g, (int64_t)ctl_conv_wpack_floats(d->cin, d->cout, d->ks), ntiles, a.res2);
+        a.c.tiles_w, a.c.g, (int64_t)ctl_conv_wpack_floats(d->cin, d->cout, d->ks), ntiles, a.res2, a.x2);
 }
 // the launches that write dL/dOut of a residual block (and can carry CTL_EPI_TAILBWD): the 1x1 data gradients, the 2x2 stride-2 conv
 // behind a ConvTranspose2d, the four phase problems / the zero-insert form of a stride-2 3x3 data gradient
@@ -1231,7 +1312,9 @@ extern "C" int ctl_conv_forward_ex(const ctl_conv* d, const float* x, const floa
     }
     CTL_REQUIRE(d->pro_affine >= 0 && d->pro_affine <= 2, "conv_forward: pro_affine must be 0, 1 or 2");
     CTL_REQUIRE(d->pro_affine != 1 || (pro_scale && pro_shift), "conv_forward: prologue without scale/shift");
-    CTL_REQUIRE(d->pro_affine != 2 || (d->dt & CTL_DT_BF16), "conv_forward: the BatchNorm-backward prologue (pro_affine 2) exists in the bf16 family only (the fp32 kernels are VALU-bound in their staging)");
+    CTL_REQUIRE(d->pro_affine != 2 || (x2 && pro_scale && d->cin % 16 == 0 && d->in_mode == CTL_IN_PLAIN &&
+                                       ((d->ks == 3 && d->stride == 1) || (d->ks == 4 && d->stride == 2)) && !(d->epi_flags & CTL_EPI_TAILBWD)),
+                "conv_forward: the BatchNorm-backward prologue (pro_affine 2) needs x2 + coefficients, cin %% 16 == 0 and a plain 3x3 stride-1 or 4x4 stride-2 conv");
     CTL_REQUIRE(!d->pro_affine || (d->groups > 1 ? d->groups : 1) * d->cin <= CTL_PRO_MAX, "conv_forward: groups * cin = %d prologue coefficients exceed %d", (d->groups > 1 ? d->groups : 1) * d->cin, CTL_PRO_MAX);
     CTL_REQUIRE(d->pro_affine != 1 || (d->pro_slope >= 0.f && d->pro_slope <= 1.f), "conv_forward: prologue slope must be in [0, 1]");
     CTL_REQUIRE(d->epi_act != CTL_ACT_LEAKY || (d->epi_slope >= 0.f && d->epi_slope <= 1.f), "conv_forward: LeakyReLU slope must be in [0, 1]");
@@ -1247,7 +1330,7 @@ extern "C" int ctl_conv_forward_ex(const ctl_conv* d, const float* x, const floa
         return rc;
     }
     a.x = x; a.wpack = wpack; a.bias = bias; a.pro_scale = pro_scale; a.pro_shift = pro_shift; a.res = res;
-    a.res_scale = res_scale; a.res_shift = res_shift; a.res2 = res2; a.y = y; a.stats_partial = stats_partial;
+    a.res_scale = res_scale; a.res_shift = res_shift; a.res2 = res2; a.x2 = x2; a.y = y; a.stats_partial = stats_partial;
     a.stream = (hipStream_t)stream;
     const int ptok = ctl_prof_begin("conv_igemm", d, &a.c, a.c.nt, a.stream);
     rc = conv_dispatch(a);
@@ -1262,7 +1345,7 @@ struct wgrad_cfg { ctl_conv_cfg c; int ntw, splits, ntiles, cin_p, cout_p; };
 
 struct wgrad_call {
     const ctl_conv* d; wgrad_cfg* w;
-    const float *x, *pro_scale, *pro_shift, *dy;
+    const float *x, *pro_scale, *pro_shift, *dy, *dy2, *dy_coef;
     float *w_partial, *b_partial;
     hipStream_t stream;
     bool query;          // only compute w->splits
@@ -1300,8 +1383,15 @@ static void wgrad_go(wgrad_call& a) {
     w.splits = splits;
     if (a.query) return;
     const dim3 grid((unsigned)splits, (unsigned)w.c.g, (unsigned)(w.c.cot / NTW));
+    if constexpr (KS == 3 && S == 1 && MODE != CTL_IN_C4) {      // the two-tensor output gradient: the 3x3 convs of the residual blocks
+        if (a.dy2) {
+            conv_wgrad_kernel<KS, S, MODE, MT, TW, NTW, true><<<grid, dim3(256), 0, a.stream>>>(
+                *a.d, a.x, a.pro_scale, a.pro_shift, a.dy, a.w_partial, a.b_partial, w.c.tiles_h, w.c.tiles_w, w.ntiles, w.cin_p, w.cout_p, a.dy2, a.dy_coef);
+            return;
+        }
+    }
     conv_wgrad_kernel<KS, S, MODE, MT, TW, NTW><<<grid, dim3(256), 0, a.stream>>>(
-        *a.d, a.x, a.pro_scale, a.pro_shift, a.dy, a.w_partial, a.b_partial, w.c.tiles_h, w.c.tiles_w, w.ntiles, w.cin_p, w.cout_p);
+        *a.d, a.x, a.pro_scale, a.pro_shift, a.dy, a.w_partial, a.b_partial, w.c.tiles_h, w.c.tiles_w, w.ntiles, w.cin_p, w.cout_p, nullptr, nullptr);
 }
 template <int KS, int S, int MODE>
 static void wgrad_go_tile(wgrad_call& a) {
@@ -1364,7 +1454,9 @@ extern "C" int ctl_conv_wgrad_ex(const ctl_conv* d, const float* x, const float*
                                  ctl_stream stream) {
     CTL_REQUIRE(d && x && dy && w_partial, "conv_wgrad: null argument");
     CTL_REQUIRE(d->pro_affine == 0 || d->pro_affine == 1, "conv_wgrad: pro_affine must be 0 or 1");
-    CTL_REQUIRE(!dy2 || (d->dt & CTL_DT_BF16), "conv_wgrad: the two-tensor output gradient (dy2) exists in the bf16 family only");
+    CTL_REQUIRE(!dy2 || (dy_coef && d->ks == 3 && d->stride == 1 && d->in_mode != CTL_IN_C4 && d->cout % 16 == 0 &&
+                         (d->groups > 1 ? d->groups : 1) * d->cout <= CTL_PRO_MAX),
+                "conv_wgrad: the two-tensor output gradient needs coefficients, a 3x3 stride-1 conv (not the K-packed first layer), cout %% 16 == 0 and groups * cout <= %d", CTL_PRO_MAX);
     CTL_REQUIRE(!d->pro_affine || (pro_scale && pro_shift), "conv_wgrad: prologue without scale/shift");
     CTL_REQUIRE(!d->pro_affine || (d->groups > 1 ? d->groups : 1) * d->cin <= CTL_PRO_MAX, "conv_wgrad: groups * cin = %d prologue coefficients exceed %d", (d->groups > 1 ? d->groups : 1) * d->cin, CTL_PRO_MAX);
     CTL_REQUIRE(!d->pro_affine || (d->pro_slope >= 0.f && d->pro_slope <= 1.f), "conv_wgrad: prologue slope must be in [0, 1]");
@@ -1375,15 +1467,15 @@ extern "C" int ctl_conv_wgrad_ex(const ctl_conv* d, const float* x, const float*
     int rc = wgrad_pick(d, &w);
     if (rc != CTL_OK) return rc;
     if (d->dt & CTL_DT_BF16) {
-        const int ptok16 = ctl_prof_begin("conv_wgrad_bf16", d, &w.c, w.ntw, (hipStream_t)stream);
+        const int ptok16 = ctl_prof_begin("conv_wgrad_bf16", d, &w.c, w.ntw, (hipStream_t)stream, dy2 != nullptr);
         rc = ctl_conv_wgrad_bf16(d, x, pro_scale, pro_shift, dy, dy2, dy_coef, w_partial, b_partial, stream);
         ctl_prof_end(ptok16, (hipStream_t)stream);
         return rc;
     }
     wgrad_call a = {};
-    a.d = d; a.w = &w; a.x = x; a.pro_scale = pro_scale; a.pro_shift = pro_shift; a.dy = dy; a.w_partial = w_partial;
+    a.d = d; a.w = &w; a.x = x; a.pro_scale = pro_scale; a.pro_shift = pro_shift; a.dy = dy; a.dy2 = dy2; a.dy_coef = dy_coef; a.w_partial = w_partial;
     a.b_partial = b_partial; a.stream = (hipStream_t)stream;
-    const int ptok = ctl_prof_begin("conv_wgrad", d, &w.c, w.ntw, a.stream);
+    const int ptok = ctl_prof_begin("conv_wgrad", d, &w.c, w.ntw, a.stream, dy2 != nullptr);
     rc = wgrad_dispatch(a);
     if (rc != CTL_OK) return rc;
     ctl_prof_end(ptok, a.stream);

@@ -1244,7 +1244,8 @@ static void wgrad16_go_f(wgrad16_call& a) {
     static int occ = 0;
     if (!occ) {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_wgrad_bf16_kernel<KS, S, MODE, MT, NTW, DY2>, 256, 0) != hipSuccess || n < 1) {
+        // (of the plain instantiation, also for DY2: the split count is queried at plan time from the descriptor alone and sizes the partials)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_wgrad_bf16_kernel<KS, S, MODE, MT, NTW, false>, 256, 0) != hipSuccess || n < 1) {
             (void)hipGetLastError();
             n = 2;
         }

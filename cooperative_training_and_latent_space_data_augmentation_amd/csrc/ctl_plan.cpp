@@ -58,15 +58,24 @@ hipEvent_t prof_event() {
 }
 }  // namespace
 
-int ctl_prof_begin(const char* kind, const ctl_conv* d, const ctl_conv_cfg* c, int nt, hipStream_t stream) {
+int ctl_prof_begin(const char* kind, const ctl_conv* d, const ctl_conv_cfg* c, int nt, hipStream_t stream, bool dy2) {
     if (!g_prof_on) return -1;
-    char id[160];
+    char id[160], sfx[24];
+    // one id per kernel instantiation family, as rocprofv3 lists them: the epilogue class (fp32: the EPI template value, 1 = residual /
+    // accumulate / BatchNorm-backward operand, 2 = tail reduction; bf16: the FAST value) and the two-tensor prologue are part of it
+    const int f = d->epi_flags;
+    const int e32 = (f & CTL_EPI_TAILBWD) ? 2 : ((f & (CTL_EPI_RES | CTL_EPI_ACCUM | CTL_EPI_BNBWD)) ? 1 : 0);
+    const int e16 = (f & CTL_EPI_TAILBWD) ? 5 : ((f & CTL_EPI_BNBWD) ? 4 : ((f & CTL_EPI_RES) ? 2 : ((f & CTL_EPI_ACCUM) ? 3 : 0)));
+    const int e = (d->dt & CTL_DT_BF16) ? e16 : e32;
+    const bool two = d->pro_affine == 2 || dy2;
+    if (e) snprintf(sfx, sizeof(sfx), ",e%d%s", e, two ? ",x2" : "");
+    else snprintf(sfx, sizeof(sfx), "%s", two ? ",x2" : "");
     static const bool shapes = ctl_tune_str("CTL_PROF_SHAPES") != nullptr;      // (-DCTL_TUNING builds: one id per layer shape)
     if (shapes)
-        snprintf(id, sizeof(id), "%s<ks%d,s%d,in%d,mt%d,tw%d,nt%d>[n%d,h%d,ci%d,co%d,e%d]", kind, d->ks, d->stride, d->in_mode, c->mt, c->tw, nt, d->n, d->hout,
-                 d->cin, d->cout, d->epi_flags);
+        snprintf(id, sizeof(id), "%s<ks%d,s%d,in%d,mt%d,tw%d,nt%d%s>[n%d,h%d,ci%d,co%d,e%d]", kind, d->ks, d->stride, d->in_mode, c->mt, c->tw, nt, sfx, d->n,
+                 d->hout, d->cin, d->cout, d->epi_flags);
     else
-        snprintf(id, sizeof(id), "%s<ks%d,s%d,in%d,mt%d,tw%d,nt%d>", kind, d->ks, d->stride, d->in_mode, c->mt, c->tw, nt);
+        snprintf(id, sizeof(id), "%s<ks%d,s%d,in%d,mt%d,tw%d,nt%d%s>", kind, d->ks, d->stride, d->in_mode, c->mt, c->tw, nt, sfx);
     if (!g_prof_filter.empty() && std::string(id).find(g_prof_filter) == std::string::npos) return -1;
     if (g_prof_every > 1 && (g_prof_seen++ % g_prof_every) != 0) return -1;
     ProfRec r;
@@ -79,6 +88,8 @@ int ctl_prof_begin(const char* kind, const ctl_conv* d, const ctl_conv_cfg* c, i
     r.flops = 2.0 * pix * d->cout * d->cin * d->ks * d->ks;
     const double in_b = ((d->dt & CTL_DT_X16) ? 2.0 : 4.0) * d->n * d->hin * d->win * d->cin, out_b = ((d->dt & CTL_DT_Y16) ? 2.0 : 4.0) * pix * d->cout;
     r.bytes = in_b + out_b;
+    if (d->pro_affine == 2) r.bytes += in_b;             // the second tensor of the BatchNorm-backward prologue
+    if (dy2) r.bytes += out_b;                           // ... of the weight gradient's virtual output gradient
     if (d->epi_flags & (CTL_EPI_RES | CTL_EPI_BNBWD)) r.bytes += ((d->dt & CTL_DT_RES16) ? 2.0 : 4.0) * pix * d->cout;
     if (d->epi_flags & CTL_EPI_TAILBWD) r.bytes += 2.0 * 4.0 * pix * d->cout;            // the block output and the BatchNorm input of the tail
     if (d->epi_flags & CTL_EPI_ACCUM) r.bytes += out_b;

@@ -41,6 +41,9 @@ MOMENTUM = 0.1
 SMALL_CIN = True         # K-packed taps for the Cin <= 4 first layers
 PHASE_CONVS = True       # 2x2 phase forms of the up-sampled forward / stride-2 data gradient
 FUSE_BNBWD = False       # BN1-backward reduction inside the dgrad conv epilogue (fp32: matrix-bound kernel, measured no gain)
+FUSE_BNAPPLY = True      # fp32: the residual tail's BatchNorm-backward apply pass inside the staging of its consumers (see FUSE_BNAPPLY16): 40 launches
+                         # and a tensor pass less per step for 17.52 -> 17.45 ms; with FUSE_BNBWD the in-block BatchNorm follows (875 launches) but
+                         # the step is no faster (17.55 ms): the matrix-bound kernels pay for every VALU instruction folded into them
 FUSE_BNBWD16 = True      # the same in the bf16 family, where the data gradient is not matrix-bound
 FUSE_PAIR16 = True       # bf16: the conv-BatchNorm-activation pairs at the head of the encoders get g = dAct * act' and their sums from the launch that
                          # writes dAct (CTL_EPI_BNBWD on it), and no apply pass either (FUSE_BNAPPLY16)
@@ -242,7 +245,7 @@ class PlanBuilder:
                 (_ffi.DT_RES16 if (res is not None and res[0].b16) or tail is not None else 0)
         d = self._conv_desc(x, cout, ks, stride, in_mode, hout, wout, pro, flags, act, slope, nsub, pad, dt)
         if x2 is not None:
-            assert pro is None and self.b16 and x.b16 and x2[0].b16 and (x2[0].n, x2[0].h, x2[0].w, x2[0].c) == (x.n, x.h, x.w, x.c)
+            assert pro is None and x.b16 == x2[0].b16 == self.b16 and (x2[0].n, x2[0].h, x2[0].w, x2[0].c) == (x.n, x.h, x.w, x.c)
             d["pro_affine"] = 2
             pro = (x2[1], None)
         op = self.op(_ffi.OP_CONV)
@@ -265,7 +268,7 @@ class PlanBuilder:
     def wgrad(self, x: T, dy: T, ks, *, stride=1, in_mode=0, pro=None, dw_ref, strides, dbias_ref=None, accumulate=False, dy2=None):
         """CTL_OP_WGRAD + CTL_OP_WGRAD_REDUCE for the conv x -> dy.  dy2 = (T u, coef_ref): the output gradient is the virtual
         BatchNorm-backward result A*dy + B*u + C (bf16 family)."""
-        assert dy2 is None or (self.b16 and dy.b16 and dy2[0].b16 and ks == 3 and stride == 1)
+        assert dy2 is None or (dy.b16 == dy2[0].b16 == self.b16 and ks == 3 and stride == 1)
         dt = (_ffi.DT_BF16 | (_ffi.DT_X16 if x.b16 else 0) | (_ffi.DT_Y16 if dy.b16 else 0)) if self.b16 else 0
         d = self._conv_desc(x, dy.c, ks, stride, in_mode, dy.h, dy.w, pro, 0, 0, 0.0, dt=dt)
         dp = _ffi.desc_ptr(d)
@@ -908,9 +911,15 @@ class CtlNet(nn.Module):
         # bf16: no apply passes at all -- dV and dU stay virtual (g, BatchNorm input, coefficients) and their consumers (the 3x3 weight
         # gradients and the data-gradient convs) evaluate A*g + B*u + C while staging: two launches and three tensor passes less per
         # BatchNorm.  The coefficient tables of a launch sit in LDS: groups * channels <= 256.
-        virt = FUSE_BNAPPLY16 and FUSE_BNBWD16 and pb.b16 and out.b16 and v.b16 and u.b16 and pb.groups * max(out.c, u.c) <= 256
-        # (the block whose input gradient leaves the network as fp32 keeps a stored dU: the staged form writes bf16 only)
-        virt_u = virt and not (pre == "nn" and d_in is not None and not d_in.b16)
+        if pb.b16:
+            virt = FUSE_BNAPPLY16 and FUSE_BNBWD16 and out.b16 and v.b16 and u.b16 and pb.groups * max(out.c, u.c) <= 256
+            # (the block whose input gradient leaves the network as fp32 keeps a stored dU: the staged form writes bf16 only)
+            virt_u = virt and not (pre == "nn" and d_in is not None and not d_in.b16)
+        else:
+            # fp32: the same staging exists (two packed fmas per element next to matrix-bound MFMA loops); dU can only be virtual when its g
+            # comes out of the data-gradient epilogue (FUSE_BNBWD)
+            virt = FUSE_BNAPPLY and pb.groups * max(out.c, u.c) <= 256 and out.c % 16 == 0 and u.c % 16 == 0
+            virt_u = virt and FUSE_BNBWD
         dv2 = du2 = None
         # residual tail: dS (to conv_input) and dV (to conv.3)
         if pre_tail is not None:
@@ -936,7 +945,7 @@ class CtlNet(nn.Module):
             if virt_u:
                 du2 = (u, coef1)
         else:
-            da, _, _ = pb.conv(dv, self._wp_ref(c3.wp_dgrad), c3.cin, 3, arena=A)
+            da, _, _ = pb.conv(dv, self._wp_ref(c3.wp_dgrad), c3.cin, 3, arena=A, x2=dv2)
             # BN1 -> LeakyReLU tail (in place: dU overwrites dA)
             pb.bn_backward(1, da, None, u, B[prefix + ".conv.1"], rec["co1"], SLOPE, ds=None, dx=da, affine_grad=need_w and affine)
             du = da
