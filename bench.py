@@ -124,8 +124,20 @@ def cpu_baseline(host_batch, threads, steps=3, cfgs=(DROP_IMG, DROP_SEG), what="
                       f"threads: 1 warm-up ({times[0]:.1f} s) + {steps} timed steps, median {med:.1f} s (all: {[round(t, 1) for t in times[1:]]})"}
 
 
-FAMILIES = (("conv_fwd_dgrad", ("conv_igemm",)), ("weight_gradients", ("conv_wgrad",)),
-            ("batchnorm_backward", ("bwd_reduce<0>", "bwd_reduce<1>", "bwd_apply")), ("other_hbm_passes", ("bn_act", "sumpool2", "bwd_reduce<2>")))
+def _narrow(k):
+    """1x1 convs and the <= 4-channel first layers (K-packed taps, in3): 8-32 flop per byte, HBM-side members of the conv families"""
+    return "<ks1," in k or ",in3," in k
+
+
+# (the two conv families whole, as round 2 reported them, and split by what bounds their members: the 3x3 / 4x4 / 2x2 forms on >= 16
+# channels are matrix work, the 1x1 convs and the first layers stream)
+FAMILIES = (("conv_fwd_dgrad", lambda k: k.startswith("conv_igemm")), ("weight_gradients", lambda k: k.startswith("conv_wgrad")),
+            ("conv_fwd_dgrad_3x3", lambda k: k.startswith("conv_igemm") and not _narrow(k)),
+            ("conv_fwd_dgrad_1x1_and_first_layers", lambda k: k.startswith("conv_igemm") and _narrow(k)),
+            ("weight_gradients_3x3", lambda k: k.startswith("conv_wgrad") and not _narrow(k)),
+            ("weight_gradients_1x1_and_first_layers", lambda k: k.startswith("conv_wgrad") and _narrow(k)),
+            ("batchnorm_backward", lambda k: k.startswith(("bwd_reduce<0>", "bwd_reduce<1>", "bwd_apply"))),
+            ("other_hbm_passes", lambda k: k.startswith(("bn_act", "sumpool2", "bwd_reduce<2>"))))
 
 
 def family_rooflines(prof, dtype, steps):
@@ -134,8 +146,8 @@ def family_rooflines(prof, dtype, steps):
     against HBM.  `ms_per_step` is serialised kernel time (the timed region overlaps two launch chains)."""
     peak_mfma = PEAK_MFMA_BF16_TFLOPS if dtype == "bf16" else PEAK_MFMA_F32_TFLOPS
     out = {}
-    for fam, keys in FAMILIES:
-        ids = {k: v for k, v in prof.items() if any(k.startswith(p) for p in keys)}
+    for fam, member in FAMILIES:
+        ids = {k: v for k, v in prof.items() if member(k)}
         if not ids:
             continue
         ms = sum(v["ms"] for v in ids.values())

@@ -14,7 +14,7 @@ python3 - $out/bench.json <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 print("fp32: %.1f slices/s %.3f ms mode %s launches %s roofline %.3f" % (d["value"], d["ms_per_step"], d["mode"], d["launches_per_step"]["library"], d["roofline"]["frac"]))
-for k, v in d.get("roofline_families", {}).items(): print("   family %-20s %6.2f ms/step %6.1f launches  frac %.3f (%s)" % (k, v["ms_per_step"], v["launches_per_step"], v["frac"], v["bound"]))
+for k, v in d.get("roofline_families", {}).items(): print("   family %-38s %6.2f ms/step %6.1f launches  frac %.3f (%s)" % (k, v["ms_per_step"], v["launches_per_step"], v["frac"], v["bound"]))
 c3 = d.get("config3_bf16", {}); c5 = d.get("config5_inference", {})
 print("config3_bf16:", {k: c3.get(k) for k in ("value", "ms_per_step", "mode", "error")}, "roofline", c3.get("roofline", {}).get("frac"))
 print("config5:", {k: c5.get(k) for k in ("value", "ms_per_step", "error")}, {k: round(v["value"]) for k, v in c5.get("forms", {}).items()})
