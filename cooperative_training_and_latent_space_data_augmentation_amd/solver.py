@@ -38,6 +38,8 @@ def basic_loss_fn(pred, target, loss_type="cross entropy"):
     return cross_entropy_2D(pred, target)
 
 
+SPLIT_BACKWARD = True       # one backward() sweep per launch chain, the standard branch first (see _cooperative_step)
+
 class AdvancedTripletReconSegmentationModel(nn.Module):
     def __init__(self, network_type="FCN_16_standard", image_ch=1, learning_rate=1e-4, encoder_dropout=None,
                  decoder_dropout=None, num_classes=4, n_iter=1, checkpoint_dir=None, use_gpu=True, debug=False, *, compute_dtype=None):
@@ -73,6 +75,7 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
         # the image decoder consumes z_i only: its launch chain (forward, loss, and through autograd its backward) can run on a
         # second HIP stream next to D_seg -> STN on the main stream
         self.two_streams = True
+        self.split_backward = SPLIT_BACKWARD
         # parameter gradients of the passes of a step are parked and added with one launch per network after backward (nets.py)
         self.defer_param_grads = True
         self._side = torch.cuda.Stream(device=self.device)
@@ -686,7 +689,8 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
             ev["main_done"].record(cur)
             ev["side_done"].record(side)
             self._chain_events.append(ev)
-        cur.wait_stream(side)
+        if not self.split_backward:
+            cur.wait_stream(side)           # (split_backward: the join comes behind the two backward sweeps, see _cooperative_step)
         self._img_std_done = None
         for t in tuple(hard):
             t.record_stream(cur)
@@ -723,12 +727,24 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
             self._ensure_chains_overlap()
             std, hard = self._two_chain_forward(clean_image_l, label_l, image_l, img_cfg, seg_cfg, separate_training, image_override,
                                                 seg_override)
-            # (two backward() calls, the standard branch's first -- it lives on the main chain alone and finishes its forward ~1.5 ms before
-            # the hard branch -- were measured in round 1 (682 vs 751 slices/s) and again in round 3 with parked parameter gradients:
-            # 20.4 vs 17.4 ms fp32, 12.0 vs 10.7 ms bf16, graph and eager alike: the two backward sweeps no longer interleave)
-            loss = (std[0] + std[1] + std[3] + std[2]) + (hard[0] + hard[1] + hard[2] + hard[3])
-            self.reset_all_optimizers()
-            self._backward(loss)
+            if self.split_backward and self.defer_param_grads:
+                # Each branch's backward is its own sweep on its own chain: the standard branch lives on the main chain alone (FTN encoder,
+                # its two decoders, the standard STN pair) and its forward ends ~1.5 ms before the hard branch's does on the side chain
+                # (tools/timeline.py), so its sweep starts right away.  The root gradient of the hard sweep is created ON the side
+                # stream: created on the main stream, the sweep's first node waits for everything main has queued (measured: 20.4 vs
+                # 17.4 ms).  Parameter gradients are parked per pass and summed in forward order either way: same bits.
+                # fp32 17.41 -> 17.31 ms same-box; bf16 unchanged.
+                self.reset_all_optimizers()
+                (std[0] + std[1] + std[3] + std[2]).backward()
+                with torch.cuda.stream(self._side):
+                    (hard[0] + hard[1] + hard[2] + hard[3]).backward()
+                torch.cuda.current_stream().wait_stream(self._side)
+                for net in self.model.values():
+                    net.collect_deferred_grads()
+            else:
+                loss = (std[0] + std[1] + std[3] + std[2]) + (hard[0] + hard[1] + hard[2] + hard[3])
+                self.reset_all_optimizers()
+                self._backward(loss)
             if grad_hook is not None:
                 grad_hook(self)
             if do_optim:
