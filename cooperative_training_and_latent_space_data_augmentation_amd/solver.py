@@ -75,7 +75,7 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
         # the image decoder consumes z_i only: its launch chain (forward, loss, and through autograd its backward) can run on a
         # second HIP stream next to D_seg -> STN on the main stream
         self.two_streams = True
-        self.split_backward = SPLIT_BACKWARD
+        self.split_backward = SPLIT_BACKWARD and self.compute_dtype != "bf16"      # (bf16: no gain eager, and the captured step replays 16 % slower)
         # parameter gradients of the passes of a step are parked and added with one launch per network after backward (nets.py)
         self.defer_param_grads = True
         self._side = torch.cuda.Stream(device=self.device)
@@ -733,7 +733,8 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
                 # (tools/timeline.py), so its sweep starts right away.  The root gradient of the hard sweep is created ON the side
                 # stream: created on the main stream, the sweep's first node waits for everything main has queued (measured: 20.4 vs
                 # 17.4 ms).  Parameter gradients are parked per pass and summed in forward order either way: same bits.
-                # fp32 17.41 -> 17.31 ms same-box; bf16 unchanged.
+                # fp32 17.41 -> 17.31 ms same-box.  bf16 (launch-rate bound): eager unchanged (10.61 vs 10.65), but the hipGraph replay of the
+                # two-sweep step takes 13.25 ms instead of 11.45 -- the one-sweep form stays there (profiles/r3_split_backward_ab3.txt).
                 self.reset_all_optimizers()
                 (std[0] + std[1] + std[3] + std[2]).backward()
                 with torch.cuda.stream(self._side):
