@@ -77,9 +77,29 @@ NET_INPUT = {"image_encoder": (1, 64, 48), "shape_encoder": (4, 48, 64), "segmen
              "shape_decoder": (128, 3, 4), "image_decoder": (128, 4, 4)}
 
 
+# plan-compiler switches of the fp32 backward (nets.py): the default (tail reduction in the launch that writes dOut, tail apply staged in
+# its consumers), everything folded into the convs (in-block BatchNorm too: reduction in the data-gradient epilogue, apply staged), and
+# every pass stand-alone -- each against the oracle
+PLAN_SWITCHES = {"default": {}, "all_folded": {"FUSE_BNBWD": True, "FUSE_BNAPPLY": True, "FUSE_TAIL": True},
+                 "stand_alone_passes": {"FUSE_BNBWD": False, "FUSE_BNAPPLY": False, "FUSE_TAIL": False},
+                 "staged_apply_without_tail_epilogue": {"FUSE_BNAPPLY": True, "FUSE_TAIL": False}}
+
+
+@pytest.mark.parametrize("switches", list(PLAN_SWITCHES))
 @pytest.mark.parametrize("mode", ["A", "B"])
 @pytest.mark.parametrize("name", list(NET_INPUT))
-def test_network_forward_backward_vs_oracle(name, mode, golden_sd):
+def test_network_forward_backward_vs_oracle(name, mode, switches, golden_sd):
+    old = {k: getattr(nets, k) for k in PLAN_SWITCHES[switches]}
+    for k, v in PLAN_SWITCHES[switches].items():
+        setattr(nets, k, v)
+    try:
+        _network_forward_backward_vs_oracle(name, mode, golden_sd)
+    finally:
+        for k, v in old.items():
+            setattr(nets, k, v)
+
+
+def _network_forward_backward_vs_oracle(name, mode, golden_sd):
     onet, hnet = make_pair(name, golden_sd)
     onet.train()
     hnet.train()

@@ -1,6 +1,6 @@
 """Soak run: N cooperative steps at the bench size (16 x 256 x 256) with the mask scheme changing every step (dropout / channel /
 spatial, both loss pairings) and fresh synthetic batches; every 100 steps the losses and all parameters are checked for finiteness.
-   python tools/soak.py [steps=3000]"""
+   python tools/soak.py [steps=3000] [fp32|bf16]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -8,7 +8,7 @@ from cooperative_training_and_latent_space_data_augmentation_amd.solver import A
 import bench
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
 torch.manual_seed(0)
-s = AdvancedTripletReconSegmentationModel(use_gpu=True)
+s = AdvancedTripletReconSegmentationModel(use_gpu=True, compute_dtype=sys.argv[2] if len(sys.argv) > 2 else "fp32")
 def cfg(loss, kind): return {"loss_name": loss, "mask_type": kind, "max_threshold": 0.5, "random_threshold": True, "if_soft": True}
 schemes = [(bench.DROP_IMG, bench.DROP_SEG), (cfg("mse", "channel"), cfg("ce", "spatial")), (cfg("mse", "spatial"), cfg("ce", "channel")),
            (cfg("mse", "channel"), cfg("ce", "channel"))]
