@@ -530,7 +530,11 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : ((MT * NT >= 4
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
                     pv[m] = FULL || ((ho0 + wrow + m / TWT < d.hout) && (wo0 + (m % TWT) * 16 + p < d.wout));
-                f32x4 rv[EPI ? MT : 1][EPI ? NT : 1], ov[EPI ? MT : 1][EPI ? NT : 1], r2[TAIL ? MT : 1][TAIL ? NT : 1];
+                // EPI == 3: CTL_EPI_BNBWD alone, known at compile time (the 3x3 data gradients of the residual blocks): no accumulate
+                // operand, no per-fragment flag tests -- 16 VGPRs less than the generic EPI == 1 form, which matters next to the second
+                // staged tensor of the X2 prologue (168 VGPRs + 120 B of scratch otherwise)
+                constexpr bool BNB = (EPI == 3), HAS_OV = (EPI == 1 || EPI == 2);
+                f32x4 rv[EPI ? MT : 1][EPI ? NT : 1], ov[HAS_OV ? MT : 1][HAS_OV ? NT : 1], r2[TAIL ? MT : 1][TAIL ? NT : 1];
                 if (EPI) {
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
@@ -539,8 +543,11 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : ((MT * NT >= 4
                         for (int m = 0; m < MT; ++m) {
                             const int vo = FULL ? (yrel[m] + t * 64) : ((pv[m] && cok) ? (ybase + yrel[m] + t * 64) : CTL_OOB);
                             const int so = FULL ? ybase : 0;
-                            rv[m][t] = ov[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                            if constexpr (TAIL) {           // (cout is a multiple of 16 here, checked on the host)
+                            rv[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                            if constexpr (HAS_OV) ov[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                            if constexpr (BNB) {            // (cout is a multiple of 16 here, checked on the host)
+                                rv[m][t] = ctl_bload4s(rres, vo, so);
+                            } else if constexpr (TAIL) {    // (likewise)
                                 rv[m][t] = ctl_bload4s(rres, vo, so);
                                 r2[m][t] = ctl_bload4s(rres2, vo, so);
                                 if (flags & CTL_EPI_ACCUM) ov[m][t] = ctl_bload4s(ry, vo, so);
@@ -560,7 +567,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : ((MT * NT >= 4
                     const bool cok = FULL || co0 < d.cout;
                     const int cc = cok ? co0 : 0;
                     f32x4 rs = {0.f, 0.f, 0.f, 0.f}, rh = {0.f, 0.f, 0.f, 0.f};
-                    if (EPI && !TAIL && (flags & (CTL_EPI_RES | CTL_EPI_BNBWD))) {
+                    if (EPI && !TAIL && (BNB || (flags & (CTL_EPI_RES | CTL_EPI_BNBWD)))) {
                         if (d.cout >= 4) {
                             rs = *reinterpret_cast<const f32x4*>(res_scale + grp * d.cout + cc);
                             rh = *reinterpret_cast<const f32x4*>(res_shift + grp * d.cout + cc);
@@ -580,7 +587,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : ((MT * NT >= 4
                             else ctl_bstore4(ry, (pv[m] && cok) ? (ybase + yrel[m] + t * 64) : CTL_OOB, v);
                             continue;
                         }
-                        if (EPI && (flags & CTL_EPI_BNBWD)) {
+                        if (BNB || (EPI == 1 && (flags & CTL_EPI_BNBWD))) {
                             // this conv produced dL/da of a = leaky(BN(u)): turn it into g = dL/da * leaky'(BN(u)) and take the two
                             // sums of the BatchNorm backward (sum g, sum g*u) here instead of in a separate pass over da and u
                             const f32x4 u = rv[m][t], sa = u * rs + rh;
@@ -601,7 +608,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : ((MT * NT >= 4
                             v.x = 1.f / (1.f + expf(-v.x)); v.y = 1.f / (1.f + expf(-v.y));
                             v.z = 1.f / (1.f + expf(-v.z)); v.w = 1.f / (1.f + expf(-v.w));
                         }
-                        if (EPI) v += ov[m][t];
+                        if constexpr (HAS_OV) v += ov[m][t];
                         if (FULL) {
                             ctl_bstore4(ry, ybase + yrel[m] + t * 64, v);     // no SGPR soffset on stores, see ctl_bload4s
                         } else {
@@ -1232,6 +1239,12 @@ static void conv_go_nt(conv_call& a) {
     if constexpr (conv_tail_ok<KS, S, MODE>()) {
         if (a.d->epi_flags & CTL_EPI_TAILBWD) {
             if (a.c.nt == 2) conv_go<KS, S, MODE, MT, TW, 2, 2>(a); else conv_go<KS, S, MODE, MT, TW, 1, 2>(a);
+            return;
+        }
+    }
+    if constexpr (KS == 3 && S == 1 && MODE == CTL_IN_PLAIN) {      // CTL_EPI_BNBWD alone on whole 16-channel tiles: its own instantiation
+        if ((a.d->epi_flags & (CTL_EPI_RES | CTL_EPI_ACCUM | CTL_EPI_BNBWD)) == CTL_EPI_BNBWD && a.d->cout % 16 == 0 && a.d->epi_act == CTL_ACT_NONE) {
+            if (a.c.nt == 2) conv_go<KS, S, MODE, MT, TW, 2, 3>(a); else conv_go<KS, S, MODE, MT, TW, 1, 3>(a);
             return;
         }
     }

@@ -62,9 +62,10 @@ int ctl_prof_begin(const char* kind, const ctl_conv* d, const ctl_conv_cfg* c, i
     if (!g_prof_on) return -1;
     char id[160], sfx[24];
     // one id per kernel instantiation family, as rocprofv3 lists them: the epilogue class (fp32: the EPI template value, 1 = residual /
-    // accumulate / BatchNorm-backward operand, 2 = tail reduction; bf16: the FAST value) and the two-tensor prologue are part of it
+    // accumulate / BatchNorm-backward operand, 2 = tail reduction, 3 = BatchNorm-backward reduction alone; bf16: the FAST value) and the two-tensor prologue are part of it
     const int f = d->epi_flags;
-    const int e32 = (f & CTL_EPI_TAILBWD) ? 2 : ((f & (CTL_EPI_RES | CTL_EPI_ACCUM | CTL_EPI_BNBWD)) ? 1 : 0);
+    const bool bnb_only = (f & (CTL_EPI_RES | CTL_EPI_ACCUM | CTL_EPI_BNBWD)) == CTL_EPI_BNBWD && d->ks == 3 && d->stride == 1 && d->in_mode == CTL_IN_PLAIN && d->cout % 16 == 0;
+    const int e32 = (f & CTL_EPI_TAILBWD) ? 2 : (bnb_only ? 3 : ((f & (CTL_EPI_RES | CTL_EPI_ACCUM | CTL_EPI_BNBWD)) ? 1 : 0));
     const int e16 = (f & CTL_EPI_TAILBWD) ? 5 : ((f & CTL_EPI_BNBWD) ? 4 : ((f & CTL_EPI_RES) ? 2 : ((f & CTL_EPI_ACCUM) ? 3 : 0)));
     const int e = (d->dt & CTL_DT_BF16) ? e16 : e32;
     const bool two = d->pro_affine == 2 || dy2;

@@ -40,10 +40,11 @@ MOMENTUM = 0.1
 # Plan-compiler switches (module attributes, no environment reads; tools/ab.py flips them for A/B runs)
 SMALL_CIN = True         # K-packed taps for the Cin <= 4 first layers
 PHASE_CONVS = True       # 2x2 phase forms of the up-sampled forward / stride-2 data gradient
-FUSE_BNBWD = False       # BN1-backward reduction inside the dgrad conv epilogue (fp32: matrix-bound kernel, measured no gain)
-FUSE_BNAPPLY = True      # fp32: the residual tail's BatchNorm-backward apply pass inside the staging of its consumers (see FUSE_BNAPPLY16): 40 launches
-                         # and a tensor pass less per step for 17.52 -> 17.45 ms; with FUSE_BNBWD the in-block BatchNorm follows (875 launches) but
-                         # the step is no faster (17.55 ms): the matrix-bound kernels pay for every VALU instruction folded into them
+FUSE_BNBWD = True        # fp32: the in-block BatchNorm-backward reduction inside the data-gradient epilogue (its own instantiation, EPI 3: no scratch).
+                         # Alone it was worth nothing in rounds 2-3 (matrix-bound host kernel); together with the staged apply it removes the last
+                         # element-wise BatchNorm-backward passes of the fp32 step: 955 -> 875 launches, 17.43 -> 17.26 ms same-box
+FUSE_BNAPPLY = True      # fp32: the BatchNorm-backward apply passes inside the staging of their consumers (see FUSE_BNAPPLY16); the tail's alone: 40
+                         # launches and a tensor pass less per step for 17.52 -> 17.45 ms; the in-block one follows FUSE_BNBWD
 FUSE_BNBWD16 = True      # the same in the bf16 family, where the data gradient is not matrix-bound
 FUSE_PAIR16 = True       # bf16: the conv-BatchNorm-activation pairs at the head of the encoders get g = dAct * act' and their sums from the launch that
                          # writes dAct (CTL_EPI_BNBWD on it), and no apply pass either (FUSE_BNAPPLY16)
