@@ -219,7 +219,19 @@ extern "C" int ctl_debug_timing(unsigned long long* out8) {
 #define CTL_LB_SMALL 4
 #endif
 template <int KS, int S, int MODE, int MT, int TW, int NT, int EPI, bool X2 = false>      // X2: see XStage (pro_scale = the [group][3][cin] coefficients)
-__global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : ((MT * NT >= 4) ? CTL_LB_MID : CTL_LB_SMALL)) void conv_igemm_kernel(const ctl_conv d, const float* __restrict__ x,
+// resident blocks of the X2 instantiations: two staged tensors (and with EPI an epilogue tensor) in registers -- at 3 blocks per CU the
+// 8x32-pixel form needs 92 B of scratch per lane, at 2 none: 17.15 -> 16.98 ms per step (tools/debug/fp32_x2_occ_ab.sh)
+#ifndef CTL_LB_X2EPI
+#define CTL_LB_X2EPI 2
+#endif
+#ifndef CTL_LB_X2
+#define CTL_LB_X2 2      // (X2 without an epilogue operand: 36 B of scratch at 3; 17.17 -> 17.12 ms)
+#endif
+#ifndef CTL_LB_SMALL_X2EPI
+#define CTL_LB_SMALL_X2EPI CTL_LB_SMALL
+#endif
+__global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : ((MT * NT >= 4) ? (X2 ? (EPI ? CTL_LB_X2EPI : CTL_LB_X2) : CTL_LB_MID)
+                                                                                    : ((X2 && EPI) ? CTL_LB_SMALL_X2EPI : CTL_LB_SMALL))) void conv_igemm_kernel(const ctl_conv d, const float* __restrict__ x,
                                                           const float* __restrict__ wpack,
                                                           const float* __restrict__ bias,
                                                           const float* __restrict__ pro_scale,

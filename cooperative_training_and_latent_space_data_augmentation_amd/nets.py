@@ -46,6 +46,7 @@ FUSE_BNBWD = True        # fp32: the in-block BatchNorm-backward reduction insid
 FUSE_BNAPPLY = True      # fp32: the BatchNorm-backward apply passes inside the staging of their consumers (see FUSE_BNAPPLY16); the tail's alone: 40
                          # launches and a tensor pass less per step for 17.52 -> 17.45 ms; the in-block one follows FUSE_BNBWD
 FUSE_BNBWD16 = True      # the same in the bf16 family, where the data gradient is not matrix-bound
+FUSE_PAIR = True         # fp32: the same for the fp32 family (these pairs are the 256^2 x 16-channel tensors: 0.87 ms of reduce + apply passes per step)
 FUSE_PAIR16 = True       # bf16: the conv-BatchNorm-activation pairs at the head of the encoders get g = dAct * act' and their sums from the launch that
                          # writes dAct (CTL_EPI_BNBWD on it), and no apply pass either (FUSE_BNAPPLY16)
 FUSE_TAIL16 = True       # bf16: CTL_EPI_TAILBWD in the bf16 family (the tail's reduction pass and the separately rounded dOut disappear)
@@ -1010,10 +1011,12 @@ class CtlNet(nn.Module):
         k2 = ci.ks * ci.ks
         dy2 = None
         if pre is not None:
-            assert pb.b16 and d_act.b16 and u.b16 and ci.ks == 3 and tail_next is None
+            assert d_act.b16 == u.b16 == pb.b16 and ci.ks == 3 and tail_next is None
             if need_dx and d_x is None:
                 d_x = A.tensor(x.n, x.h, x.w, x.c)
-            stored = need_dx and not (d_x.b16 and x.c % 16 == 0)      # an fp32 / narrow input gradient: that conv reads a stored dU
+            # who cannot stage the apply: a data gradient into a narrow (or, in the bf16 family, fp32) tensor; the fp32 family's K-packed
+            # first-layer weight gradient -- then ONE apply launch writes dU for both consumers (still no reduction pass)
+            stored = (need_dx and not (d_x.b16 == pb.b16 and x.c % 16 == 0)) or (not pb.b16 and ci.wp_c4 >= 0)
             du = A.tensor(u.n, u.h, u.w, u.c) if stored else None
             coef = pb.bn_backward_from_stats(d_act, u, bn, co, pre[0], pre[1], dx=du, affine_grad=need_w and affine)
             if not stored:
@@ -1156,7 +1159,11 @@ class MyEncoder(CtlNet):
         dbg["d_down5"] = d               # gradient w.r.t. the output of down4 (with FUSE_TAIL: already times leaky'(out), i.e. dS of down4)
         dbg["tail_down5"] = pre          # ... and where the tail's BatchNorm-backward sums of down4 are (statistics partials ref, rows)
         u0, v0 = rec["u0"], rec["v0"]
-        pair16 = FUSE_PAIR16 and FUSE_BNAPPLY16 and pb.b16 and u0.b16 and v0.b16 and pb.groups * u0.c <= 256 and blocks[0].get("drop") is None
+        if pb.b16:
+            pair16 = FUSE_PAIR16 and FUSE_BNAPPLY16 and u0.b16 and v0.b16
+        else:
+            pair16 = FUSE_PAIR and FUSE_BNAPPLY and FUSE_BNBWD and u0.c % 16 == 0
+        pair16 = pair16 and pb.groups * u0.c <= 256 and blocks[0].get("drop") is None
         act1 = (v0, rec["co1"]["scale"], rec["co1"]["shift"], SLOPE) if pair16 else None
         act0 = (u0, rec["co0"]["scale"], rec["co0"]["shift"], SLOPE) if pair16 else None
         for i, brec in reversed(list(enumerate(blocks))):

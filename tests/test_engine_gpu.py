@@ -80,9 +80,10 @@ NET_INPUT = {"image_encoder": (1, 64, 48), "shape_encoder": (4, 48, 64), "segmen
 # plan-compiler switches of the fp32 backward (nets.py): the default (tail reduction in the launch that writes dOut, tail apply staged in
 # its consumers), everything folded into the convs (in-block BatchNorm too: reduction in the data-gradient epilogue, apply staged), and
 # every pass stand-alone -- each against the oracle
-PLAN_SWITCHES = {"default": {}, "all_folded": {"FUSE_BNBWD": True, "FUSE_BNAPPLY": True, "FUSE_TAIL": True},
-                 "stand_alone_passes": {"FUSE_BNBWD": False, "FUSE_BNAPPLY": False, "FUSE_TAIL": False},
-                 "staged_apply_without_tail_epilogue": {"FUSE_BNAPPLY": True, "FUSE_TAIL": False}}
+PLAN_SWITCHES = {"default": {}, "all_folded": {"FUSE_BNBWD": True, "FUSE_BNAPPLY": True, "FUSE_TAIL": True, "FUSE_PAIR": True},
+                 "stand_alone_passes": {"FUSE_BNBWD": False, "FUSE_BNAPPLY": False, "FUSE_TAIL": False, "FUSE_PAIR": False},
+                 "staged_apply_without_tail_epilogue": {"FUSE_BNAPPLY": True, "FUSE_TAIL": False},
+                 "blocks_folded_head_pairs_not": {"FUSE_PAIR": False}}
 
 
 @pytest.mark.parametrize("switches", list(PLAN_SWITCHES))
