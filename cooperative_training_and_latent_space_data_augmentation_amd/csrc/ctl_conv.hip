@@ -1412,7 +1412,7 @@ static void wgrad_go(wgrad_call& a) {
     w.splits = splits;
     if (a.query) return;
     const dim3 grid((unsigned)splits, (unsigned)w.c.g, (unsigned)(w.c.cot / NTW));
-    if constexpr (KS == 3 && S == 1 && MODE != CTL_IN_C4) {      // the two-tensor output gradient: the 3x3 convs of the residual blocks
+    if constexpr (KS == 3 && S == 1) {      // the two-tensor output gradient: the 3x3 convs of the residual blocks and of the encoder heads
         if (a.dy2) {
             conv_wgrad_kernel<KS, S, MODE, MT, TW, NTW, true><<<grid, dim3(256), 0, a.stream>>>(
                 *a.d, a.x, a.pro_scale, a.pro_shift, a.dy, a.w_partial, a.b_partial, w.c.tiles_h, w.c.tiles_w, w.ntiles, w.cin_p, w.cout_p, a.dy2, a.dy_coef);
@@ -1483,9 +1483,9 @@ extern "C" int ctl_conv_wgrad_ex(const ctl_conv* d, const float* x, const float*
                                  ctl_stream stream) {
     CTL_REQUIRE(d && x && dy && w_partial, "conv_wgrad: null argument");
     CTL_REQUIRE(d->pro_affine == 0 || d->pro_affine == 1, "conv_wgrad: pro_affine must be 0 or 1");
-    CTL_REQUIRE(!dy2 || (dy_coef && d->ks == 3 && d->stride == 1 && d->in_mode != CTL_IN_C4 && d->cout % 16 == 0 &&
+    CTL_REQUIRE(!dy2 || (dy_coef && d->ks == 3 && d->stride == 1 && d->cout % 16 == 0 &&
                          (d->groups > 1 ? d->groups : 1) * d->cout <= CTL_PRO_MAX),
-                "conv_wgrad: the two-tensor output gradient needs coefficients, a 3x3 stride-1 conv (not the K-packed first layer), cout %% 16 == 0 and groups * cout <= %d", CTL_PRO_MAX);
+                "conv_wgrad: the two-tensor output gradient needs coefficients, a 3x3 stride-1 conv, cout %% 16 == 0 and groups * cout <= %d", CTL_PRO_MAX);
     CTL_REQUIRE(!d->pro_affine || (pro_scale && pro_shift), "conv_wgrad: prologue without scale/shift");
     CTL_REQUIRE(!d->pro_affine || (d->groups > 1 ? d->groups : 1) * d->cin <= CTL_PRO_MAX, "conv_wgrad: groups * cin = %d prologue coefficients exceed %d", (d->groups > 1 ? d->groups : 1) * d->cin, CTL_PRO_MAX);
     CTL_REQUIRE(!d->pro_affine || (d->pro_slope >= 0.f && d->pro_slope <= 1.f), "conv_wgrad: prologue slope must be in [0, 1]");

@@ -367,6 +367,25 @@ def test_wgrad_virtual_output_gradient(n, cin, cout, h, w, groups, up, family):
         close(db, rbf(virt).sum((0, 2, 3)), 1e-3 if b16 else 3e-4, "bias gradient = sum of the virtual tensor")
 
 
+@pytest.mark.parametrize("n,cin,h,w,groups", [(2, 1, 32, 32, 1), (4, 4, 24, 20, 2), (16, 1, 64, 64, 1)])
+def test_wgrad_virtual_output_gradient_first_layer_fp32(n, cin, h, w, groups):
+    """the K-packed <= 4-channel first layer of the fp32 family (in_mode C4) with a virtual output gradient: the encoder's inc.0 pair"""
+    gen = torch.Generator().manual_seed(n + cin + h)
+    cout = 16
+    x = torch.randn(n, cin, h, w, generator=gen)
+    g, u = torch.randn(n, cout, h, w, generator=gen), torch.randn(n, cout, h, w, generator=gen)
+    coef = torch.stack([torch.rand(groups, cout, generator=gen) + 0.5, torch.randn(groups, cout, generator=gen) * 0.3,
+                        torch.randn(groups, cout, generator=gen) * 0.3], 1).contiguous()
+    virt = _virtual(g, u, coef, groups, False)
+    d = _ffi.conv_desc(n=n, hin=h, win=w, cin=cin, hout=h, wout=w, cout=cout, ks=3, groups=groups, in_mode=_ffi.IN_C4)
+    dw, db = torch.zeros(cout, cin, 3, 3, device=DEV), torch.zeros(cout, device=DEV)
+    ops.conv_wgrad(d, dev(x), dev(g), dw, (cin * 9, 9, 3, 1), dbias=db, dy2=dev(u), dy_coef=dev(coef))
+    wref = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), wref, padding=1).backward(virt.double())
+    close(dw, wref.grad, 3e-4, "first-layer wgrad with a virtual output gradient")
+    close(db, virt.double().sum((0, 2, 3)), 3e-4, "bias gradient")
+
+
 def test_bn_backward_prologue_argument_checks():
     n, c, h, w = 2, 16, 8, 8
     x = torch.zeros(n, c, h, w, device=DEV, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
