@@ -9,7 +9,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libctl_hip.so")
-ABI_VERSION = 6                      # CTL_ABI_VERSION of include/ctl_hip.h this binding was written against
+ABI_VERSION = 7                      # CTL_ABI_VERSION of include/ctl_hip.h this binding was written against
 RED_BLOCKS = 512                     # CTL_RED_BLOCKS of ctl_hip.h; checked against the library's compiled value (ctl_red_blocks) at load
 
 # enums of ctl_hip.h
@@ -18,7 +18,7 @@ ACT_NONE, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2
 EPI_BIAS, EPI_ACCUM, EPI_RES, EPI_STATS, EPI_BNBWD, EPI_TAILBWD = 1, 2, 4, 8, 16, 32
 (OP_CONV, OP_WGRAD, OP_WGRAD_REDUCE, OP_PACK, OP_BN_FINALIZE, OP_BN_EVAL, OP_BN_ACT, OP_BWD_REDUCE, OP_BN_BWD_FINALIZE,
  OP_BWD_APPLY, OP_CHAN_SUM_FINALIZE, OP_SUMPOOL2, OP_SIGMOID_BWD, OP_ZERO, OP_COPY, OP_PACK_BATCH, OP_WGRAD_REDUCE_BATCH, OP_DROPOUT2D, OP_BN_REPLAY) = range(1, 20)
-OP_MAX_T = 12
+OP_MAX_T = 14
 
 CONV_DTYPE = np.dtype([
     ("n", "<i4"), ("hin", "<i4"), ("win", "<i4"), ("cin", "<i4"), ("hout", "<i4"), ("wout", "<i4"), ("cout", "<i4"),
@@ -62,7 +62,7 @@ class _Lib:
             "ctl_conv_stats_floats": [p], "ctl_conv_stats_blocks": [p],
             "ctl_wgrad_splits": [p], "ctl_wgrad_partial_floats": [p], "ctl_wgrad_bias_partial_floats": [p],
             "ctl_pack_weights": [p, p, i32, i32, i32, i64, i64, i64, i64, i32, p],
-            "ctl_conv_forward": [p] * 12, "ctl_conv_forward_ex": [p] * 14,
+            "ctl_conv_forward": [p] * 12, "ctl_conv_forward_ex": [p] * 15, "ctl_conv_pool_ok": [p],
             "ctl_conv_wgrad": [p] * 8, "ctl_conv_wgrad_ex": [p] * 10,
             "ctl_wgrad_reduce": [p, p, p, p, i64, i64, i64, i64, p, i32, p],
             "ctl_confusion_hist": [p, p, i64, i32, p, p],
@@ -133,7 +133,7 @@ lib = _Lib()
 
 # every symbol include/ctl_hip.h declares (checked by tests/test_cabi.py without a GPU)
 EXPORTED = ["ctl_version", "ctl_last_error", "ctl_conv_wpack_floats", "ctl_conv_stats_floats", "ctl_conv_stats_blocks",
-            "ctl_pack_weights", "ctl_conv_forward", "ctl_conv_forward_ex", "ctl_wgrad_splits", "ctl_wgrad_partial_floats",
+            "ctl_pack_weights", "ctl_conv_forward", "ctl_conv_forward_ex", "ctl_conv_pool_ok", "ctl_wgrad_splits", "ctl_wgrad_partial_floats",
             "ctl_wgrad_bias_partial_floats", "ctl_conv_wgrad", "ctl_conv_wgrad_ex", "ctl_wgrad_reduce", "ctl_bn_finalize", "ctl_bn_finalize_ex", "ctl_bn_replay_running", "ctl_bn_eval_coeffs",
             "ctl_bn_act", "ctl_bwd_reduce", "ctl_bn_bwd_finalize", "ctl_bwd_apply", "ctl_chan_sum_finalize", "ctl_sumpool2",
             "ctl_sigmoid_bwd", "ctl_softmax_t_fwd", "ctl_softmax_t_bwd", "ctl_onehot", "ctl_ce2d_fwd", "ctl_ce2d_bwd",

@@ -241,7 +241,8 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : ((MT * NT >= 4
                                                           const float* __restrict__ res_shift, float* __restrict__ y,
                                                           float* __restrict__ stats_partial, int tiles_h, int tiles_w,
                                                           int G_chunks, int64_t wpack_sub_stride, int ntiles,
-                                                          const float* __restrict__ res2, const float* __restrict__ x2) {
+                                                          const float* __restrict__ res2, const float* __restrict__ x2,
+                                                          float* __restrict__ pool) {
     using G = Geom<KS, S, MT, TW>;
     constexpr int TAPS = KS * KS;
     // C4: input with <= 4 channels.  The four lane groups of an MFMA (its k index) carry four different TAPS (channels 0-3 each)
@@ -293,6 +294,11 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : ((MT * NT >= 4
     // tail) -- the stand-alone reduction pass over dOut, out and v (ctl_bwd_reduce mode 0) and the dOut tensor itself disappear
     constexpr bool TAIL = (EPI == 2);
     const __amdgpu_buffer_rsrc_t rres2 = ctl_rsrc(TAIL ? (const void*)res2 : (const void*)y, ybytes);
+    // TAIL with `pool` (1x1 hosts whose waves own row pairs): the epilogue also writes sumpool2(g) -- the 2x2 sum-pool of the stored g, which
+    // the consuming block's 1x1 weight / data gradients read (nearest-upsample blocks): the stand-alone pooling pass disappears.  Same
+    // association as sumpool2_kernel, (a0 + a1) + (a2 + a3): bit-identical.
+    constexpr bool CAN_POOL = TAIL && KS == 1 && S == 1 && MODE == CTL_IN_PLAIN && (MT / (TW / 16)) == 2;
+    const __amdgpu_buffer_rsrc_t rpool = ctl_rsrc(CAN_POOL && pool ? (const void*)pool : (const void*)y, CAN_POOL && pool ? ybytes / 4 : ybytes);
 
     f32x4 ssum[NT], ssq[NT];
 #pragma unroll
@@ -597,6 +603,22 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : ((MT * NT >= 4
                             if (FULL || pv[m]) { ssum[t] += v; ssq[t] += v * r2[m][t]; }
                             if (FULL) ctl_bstore4(ry, ybase + yrel[m] + t * 64, v);
                             else ctl_bstore4(ry, (pv[m] && cok) ? (ybase + yrel[m] + t * 64) : CTL_OOB, v);
+                            if constexpr (CAN_POOL) {
+                                if (pool) {
+                                    // column pairs sit in neighbouring lanes (p, p ^ 1), the wave's two rows in M-tiles m and m + TWT
+                                    f32x4 hs;
+                                    hs.x = v.x + __shfl_xor(v.x, 1); hs.y = v.y + __shfl_xor(v.y, 1);
+                                    hs.z = v.z + __shfl_xor(v.z, 1); hs.w = v.w + __shfl_xor(v.w, 1);
+                                    if (m < TWT) ov[m][t] = hs;              // (the accumulate operand of this fragment is consumed: its registers hold the top row's pair sums)
+                                    else {
+                                        const f32x4 top = ov[m - TWT][t];
+                                        const f32x4 pl = {top.x + hs.x, top.y + hs.y, top.z + hs.z, top.w + hs.w};
+                                        // low-resolution pixel ((ho0 + wrow) / 2, (wo0 + (m % TWT) * 16 + p) / 2); written by the even lanes
+                                        const int lo = ((((n * (d.out_h >> 1) + ((ho0 + wrow) >> 1)) * (d.out_w >> 1) + ((wo0 + (m % TWT) * 16 + p) >> 1)) * d.cout) + co0) * 4;
+                                        ctl_bstore4(rpool, ((p & 1) == 0 && (FULL || (pv[m] && cok))) ? lo : CTL_OOB, pl);
+                                    }
+                                }
+                            }
                             continue;
                         }
                         if (BNB || (EPI == 1 && (flags & CTL_EPI_BNBWD))) {
@@ -1212,7 +1234,7 @@ extern "C" int ctl_pack_weights(const float* src, float* dst, int32_t cout, int3
 struct conv_call {
     const ctl_conv* d; ctl_conv_cfg c;
     const float *x, *wpack, *bias, *pro_scale, *pro_shift, *res, *res_scale, *res_shift, *res2, *x2;
-    float *y, *stats_partial;
+    float *y, *stats_partial, *pool;
     hipStream_t stream;
     bool query;      // only report the grid (ctl_conv_stats_blocks), launch nothing
     int grid_x;
@@ -1239,7 +1261,7 @@ static void conv_go(conv_call& a) {
     const dim3 grid((unsigned)a.grid_x, (unsigned)(a.c.cot / NT), (unsigned)d->nsub);
     conv_igemm_kernel<KS, S, MODE, MT, TW, NT, EPI, X2><<<grid, dim3(256), 0, a.stream>>>(
         *d, a.x, a.wpack, a.bias, a.pro_scale, a.pro_shift, a.res, a.res_scale, a.res_shift, a.y, a.stats_partial, a.c.tiles_h,
-        a.c.tiles_w, a.c.g, (int64_t)ctl_conv_wpack_floats(d->cin, d->cout, d->ks), ntiles, a.res2, a.x2);
+        a.c.tiles_w, a.c.g, (int64_t)ctl_conv_wpack_floats(d->cin, d->cout, d->ks), ntiles, a.res2, a.x2, a.pool);
 }
 // the launches that write dL/dOut of a residual block (and can carry CTL_EPI_TAILBWD): the 1x1 data gradients, the 2x2 stride-2 conv
 // behind a ConvTranspose2d, the four phase problems / the zero-insert form of a stride-2 3x3 data gradient
@@ -1308,12 +1330,22 @@ extern "C" int ctl_conv_forward(const ctl_conv* d, const float* x, const float* 
                                 const float* pro_scale, const float* pro_shift, const float* res,
                                 const float* res_scale, const float* res_shift, float* y, float* stats_partial,
                                 ctl_stream stream) {
-    return ctl_conv_forward_ex(d, x, wpack, bias, pro_scale, pro_shift, res, res_scale, res_shift, nullptr, nullptr, y, stats_partial, stream);
+    return ctl_conv_forward_ex(d, x, wpack, bias, pro_scale, pro_shift, res, res_scale, res_shift, nullptr, nullptr, y, stats_partial, nullptr, stream);
+}
+// the tile configuration of d gives every wave a row pair: its CTL_EPI_TAILBWD epilogue can write the 2x2 sum-pool of g as well
+extern "C" int ctl_conv_pool_ok(const ctl_conv* d) {
+    ctl_conv_cfg c;
+    if (!(d->epi_flags & CTL_EPI_TAILBWD) || d->ks != 1 || d->stride != 1 || d->in_mode != CTL_IN_PLAIN || d->nsub != 1 || (d->out_h & 1) || (d->out_w & 1) ||
+        d->out_h != d->hout || d->out_w != d->wout || d->cout % 16 != 0)
+        return 0;
+    if (ctl_conv_pick_cfg(d, &c, 0) != CTL_OK) return 0;
+    return (c.mt == 4 && c.tw == 32) || (c.mt == 2 && c.tw == 16);
 }
 extern "C" int ctl_conv_forward_ex(const ctl_conv* d, const float* x, const float* wpack, const float* bias,
                                    const float* pro_scale, const float* pro_shift, const float* res,
                                    const float* res_scale, const float* res_shift, const float* res2, const float* x2, float* y,
-                                   float* stats_partial, ctl_stream stream) {
+                                   float* stats_partial, float* pool, ctl_stream stream) {
+    CTL_REQUIRE(!pool || ctl_conv_pool_ok(d), "conv_forward: `pool` needs a CTL_EPI_TAILBWD 1x1 conv with even output sizes whose tile configuration gives every wave a row pair (ctl_conv_pool_ok)");
     CTL_REQUIRE(d && x && wpack && y, "conv_forward: null argument");
     CTL_REQUIRE((d->dt & CTL_DT_BF16) || !(d->dt & (CTL_DT_X16 | CTL_DT_Y16 | CTL_DT_RES16)), "conv_forward: bf16-stored tensors need CTL_DT_BF16");
     conv_call a = {};
@@ -1350,12 +1382,12 @@ extern "C" int ctl_conv_forward_ex(const ctl_conv* d, const float* x, const floa
                 "conv_forward: tensors must stay below 2 GiB (32-bit buffer offsets)");
     if (d->dt & CTL_DT_BF16) {
         const int ptok16 = ctl_prof_begin("conv_igemm_bf16", d, &a.c, a.c.nt, (hipStream_t)stream);
-        rc = ctl_conv_forward_bf16(d, x, x2, wpack, bias, pro_scale, pro_shift, res, res_scale, res_shift, res2, y, stats_partial, stream);
+        rc = ctl_conv_forward_bf16(d, x, x2, wpack, bias, pro_scale, pro_shift, res, res_scale, res_shift, res2, y, stats_partial, pool, stream);
         ctl_prof_end(ptok16, (hipStream_t)stream);
         return rc;
     }
     a.x = x; a.wpack = wpack; a.bias = bias; a.pro_scale = pro_scale; a.pro_shift = pro_shift; a.res = res;
-    a.res_scale = res_scale; a.res_shift = res_shift; a.res2 = res2; a.x2 = x2; a.y = y; a.stats_partial = stats_partial;
+    a.res_scale = res_scale; a.res_shift = res_shift; a.res2 = res2; a.x2 = x2; a.y = y; a.stats_partial = stats_partial; a.pool = pool;
     a.stream = (hipStream_t)stream;
     const int ptok = ctl_prof_begin("conv_igemm", d, &a.c, a.c.nt, a.stream);
     rc = conv_dispatch(a);

@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? CTL16_OCC_BIG : CT
     const ctl_conv d, const void* __restrict__ x, const void* __restrict__ x2, const void* __restrict__ wpack, const float* __restrict__ bias,
     const float* __restrict__ pro_scale, const float* __restrict__ pro_shift, const void* __restrict__ res,
     const float* __restrict__ res_scale, const float* __restrict__ res_shift, const void* __restrict__ res2, void* __restrict__ y,
-    float* __restrict__ stats_partial, int tiles_h, int tiles_w, int G_chunks, int64_t wpack_sub_bytes, int ntiles) {
+    float* __restrict__ stats_partial, int tiles_h, int tiles_w, int G_chunks, int64_t wpack_sub_bytes, int ntiles, void* __restrict__ pool) {
     using G = Geom<KS, S, MT, TW>;
     using XS = XStage16<KS, S, MODE, MT, TW, XB, true, X2>;
     constexpr int TAPS = KS * KS;
@@ -303,6 +303,9 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? CTL16_OCC_BIG : CT
     const __amdgpu_buffer_rsrc_t ry = ctl_rsrc(y, ypix * yes);
     const __amdgpu_buffer_rsrc_t rres = ctl_rsrc(res ? res : y, ypix * (res ? res_es : yes));
     const __amdgpu_buffer_rsrc_t rres2 = FAST == 5 ? ctl_rsrc(res2, ypix * 2) : ry;
+    // FAST 5 with `pool` (1x1 hosts whose waves own row pairs): the epilogue also writes sumpool2(g), from the UNROUNDED g (see ctl_conv.hip)
+    constexpr bool CAN_POOL = FAST == 5 && KS == 1 && S == 1 && MODE == CTL_IN_PLAIN && (MT / (TW / 16)) == 2;
+    const __amdgpu_buffer_rsrc_t rpool = (CAN_POOL && pool) ? ctl_rsrc(pool, ypix * 2 / 4) : ry;
 
     f32x4 ssum[NT], ssq[NT];
 #pragma unroll
@@ -609,6 +612,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? CTL16_OCC_BIG : CT
                     }
                 }
                 const float sl = d.epi_slope;
+                f32x4 hsum[CAN_POOL ? TWT : 1][CAN_POOL ? NT : 1];       // pair sums of the wave's top row, kept for the bottom row
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -620,6 +624,21 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? CTL16_OCC_BIG : CT
                         if (bo[m] != CTL_OOB) { ssum[t] += v; ssq[t] += v * r2; }
                         __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)}, ry,
                                                               bo[m] == CTL_OOB ? CTL_OOB : bo[m] + t * 32, 0, CTL_STORE_AUX);
+                        if constexpr (CAN_POOL) {
+                            if (pool) {
+                                f32x4 hs;
+                                hs.x = v.x + __shfl_xor(v.x, 1); hs.y = v.y + __shfl_xor(v.y, 1);
+                                hs.z = v.z + __shfl_xor(v.z, 1); hs.w = v.w + __shfl_xor(v.w, 1);
+                                if (m < TWT) hsum[m][t] = hs;
+                                else {
+                                    const f32x4 top = hsum[m - TWT][t];
+                                    const f32x4 pl = {top.x + hs.x, top.y + hs.y, top.z + hs.z, top.w + hs.w};
+                                    const int lo = ((((n * (d.out_h >> 1) + ((ho0 + wrow) >> 1)) * (d.out_w >> 1) + ((wo0 + (m % TWT) * 16 + p) >> 1)) * d.cout) + (cot0 + t) * 16 + q * 4) * 2;
+                                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack_bf16x2(pl.x, pl.y), pack_bf16x2(pl.z, pl.w)}, rpool,
+                                                                          ((p & 1) == 0 && bo[m] != CTL_OOB) ? lo : CTL_OOB, 0, CTL_STORE_AUX);
+                                }
+                            }
+                        }
                     }
             } else if constexpr (FAST >= 2) {
                 // the residual tail  out = LeakyReLU(conv + v * scale + shift)  (FAST 2) and  y += conv  (FAST 3) on bf16 operands: the
@@ -841,7 +860,7 @@ extern "C" int ctl_pack_weights_bf16_batched(const float* params, float* wpack, 
 // ------------------------------------------------------------------------------------------------ host side
 struct conv16_call {
     const ctl_conv* d; ctl_conv_cfg c;
-    const void *x, *x2, *wpack, *res, *res2; void* y;
+    const void *x, *x2, *wpack, *res, *res2; void *y, *pool;
     const float *bias, *pro_scale, *pro_shift, *res_scale, *res_shift; float* stats_partial;
     hipStream_t stream; bool query; int grid_x;
 };
@@ -863,7 +882,7 @@ static void conv16_go_f(conv16_call& a) {
     const dim3 grid((unsigned)a.grid_x, (unsigned)(a.c.cot / NT), (unsigned)d->nsub);
     conv_igemm_bf16_kernel<KS, S, MODE, MT, TW, NT, FAST, XB, X2><<<grid, dim3(256), 0, a.stream>>>(
         *d, a.x, a.x2, a.wpack, a.bias, a.pro_scale, a.pro_shift, a.res, a.res_scale, a.res_shift, a.res2, a.y, a.stats_partial, a.c.tiles_h, a.c.tiles_w,
-        a.c.g, (int64_t)ctl_conv_wpack_floats(d->cin, d->cout, d->ks) * 4, ntiles);
+        a.c.g, (int64_t)ctl_conv_wpack_floats(d->cin, d->cout, d->ks) * 4, ntiles, a.pool);
 }
 template <int KS, int S, int MODE, int MT, int TW, int NT>
 static void conv16_go(conv16_call& a) {
@@ -945,7 +964,7 @@ int ctl_conv_bf16_stats_blocks(const ctl_conv* d) {
 
 int ctl_conv_forward_bf16(const ctl_conv* d, const void* x, const void* x2, const void* wpack, const float* bias, const float* pro_scale,
                           const float* pro_shift, const void* res, const float* res_scale, const float* res_shift, const void* res2, void* y,
-                          float* stats_partial, ctl_stream stream) {
+                          float* stats_partial, void* pool, ctl_stream stream) {
     if (d->epi_flags & CTL_EPI_TAILBWD) {
         CTL_REQUIRE((d->dt & CTL_DT_Y16) && (d->dt & CTL_DT_RES16) && d->cout % 16 == 0 && ((d->dt & CTL_DT_X16) ? d->cin % 16 == 0 : d->ks == 1),
                     "conv_forward(bf16): CTL_EPI_TAILBWD needs bf16-stored y / res / res2 with whole 16-channel tiles (and a bf16-stored x, except for 1x1 convs)");
@@ -966,7 +985,7 @@ int ctl_conv_forward_bf16(const ctl_conv* d, const void* x, const void* x2, cons
     int rc = ctl_conv_pick_cfg(d, &a.c, 0);
     if (rc != CTL_OK) return rc;
     a.x = x; a.x2 = x2; a.wpack = wpack; a.bias = bias; a.pro_scale = pro_scale; a.pro_shift = pro_shift; a.res = res; a.res_scale = res_scale;
-    a.res_shift = res_shift; a.res2 = res2; a.y = y; a.stats_partial = stats_partial; a.stream = (hipStream_t)stream;
+    a.res_shift = res_shift; a.res2 = res2; a.y = y; a.stats_partial = stats_partial; a.pool = pool; a.stream = (hipStream_t)stream;
     rc = conv16_dispatch(a);
     if (rc != CTL_OK) return rc;
     CTL_LAUNCH_CHECK("conv_forward(bf16)");

@@ -46,6 +46,7 @@ FUSE_BNBWD = True        # fp32: the in-block BatchNorm-backward reduction insid
 FUSE_BNAPPLY = True      # fp32: the BatchNorm-backward apply passes inside the staging of their consumers (see FUSE_BNAPPLY16); the tail's alone: 40
                          # launches and a tensor pass less per step for 17.52 -> 17.45 ms; the in-block one follows FUSE_BNBWD
 FUSE_BNBWD16 = True      # the same in the bf16 family, where the data gradient is not matrix-bound
+FUSE_POOL = True         # both families: the tail epilogue of a 1x1 host also writes sumpool2(g) for a consuming nearest-upsample block (no ctl_sumpool2 pass)
 FUSE_PAIR = True         # fp32: the same for the fp32 family (these pairs are the 256^2 x 16-channel tensors: 0.87 ms of reduce + apply passes per step)
 FUSE_PAIR16 = True       # bf16: the conv-BatchNorm-activation pairs at the head of the encoders get g = dAct * act' and their sums from the launch that
                          # writes dAct (CTL_EPI_BNBWD on it), and no apply pass either (FUSE_BNAPPLY16)
@@ -211,6 +212,7 @@ class PlanBuilder:
     def conv(self, x: T, wp_ref, cout, ks, *, stride=1, in_mode=0, pro=None, bias_ref=None, stats=False, act=0,
              slope=0.0, res=None, accum=False, out: Optional[T] = None, arena: Optional[Arena] = None, nsub=1,
              hout=None, wout=None, bnbwd=None, pad=None, tail=None, x2=None, keep_stats=False):
+        # (tail may carry a 4th element: True = the consumer wants the 2x2 sum-pool of g as well, see below)
         """Emit one CTL_OP_CONV.  pro = (scale_ref, shift_ref, slope); res = (T v, scale_ref, shift_ref).
         bnbwd = (T u, scale_ref, shift_ref, slope): data-gradient conv whose result is dL/d leaky(BN(u)); the epilogue writes
         g = result * leaky'(BN(u)) and the BatchNorm-backward sums go to the statistics partials (CTL_EPI_BNBWD).
@@ -218,10 +220,11 @@ class PlanBuilder:
         instead and takes the BatchNorm-backward sums of the tail (sum g, sum g*v) into the statistics partials (CTL_EPI_TAILBWD).
         x2 = (T u, coef_ref): the input is the virtual BatchNorm-backward result A*x + B*u + C (pro_affine 2, bf16 family).
         Returns (T y, stats_ref or None, stats_blocks)."""
-        res2 = None
+        res2, want_pool, pool_t = None, False, None
         if tail is not None:
             assert res is None and bnbwd is None and bias_ref is None and act == 0
             stats, res2, slope = True, tail[1], tail[2]
+            want_pool = len(tail) > 3 and bool(tail[3])
         if bnbwd is not None:
             assert res is None and not accum and bias_ref is None and act == 0
             stats, res, slope = True, (bnbwd[0], bnbwd[1], bnbwd[2]), bnbwd[3]
@@ -252,6 +255,10 @@ class PlanBuilder:
             pro = (x2[1], None)
         op = self.op(_ffi.OP_CONV)
         op["i"][:CONV_WORDS] = np.frombuffer(d.tobytes(), dtype="<i4")
+        if want_pool and FUSE_POOL and lib.ctl_conv_pool_ok(_ffi.desc_ptr(d)):
+            # the tail epilogue also writes sumpool2(g) for the consuming nearest-upsample block (its 1x1 weight / data gradients)
+            pool_t = self.bscr.tensor(out.n, out.h // 2, out.w // 2, out.c)
+        self.last_pool = pool_t
         stats_ref, blocks = None, 0
         if stats:
             blocks = lib.ctl_conv_stats_blocks(_ffi.desc_ptr(d))
@@ -263,7 +270,8 @@ class PlanBuilder:
                 stats_ref, = self.scr(4 * self.groups * blocks * 2 * cout)
         for idx, ref in enumerate([x.ref, wp_ref, bias_ref, pro[0] if pro else None, pro[1] if pro else None,
                                    (tail[0].ref if tail is not None else (res[0].ref if res else None)), res[1] if res else None, res[2] if res else None,
-                                   out.ref, stats_ref, res2.ref if res2 is not None else None, x2[0].ref if x2 is not None else None]):
+                                   out.ref, stats_ref, res2.ref if res2 is not None else None, x2[0].ref if x2 is not None else None,
+                                   pool_t.ref if pool_t is not None else None]):
             self.set_t(op, idx, ref)
         return out, stats_ref, blocks
 
@@ -888,7 +896,7 @@ class CtlNet(nn.Module):
             return None
         if pb.b16 and not (rec["out"].b16 and rec["v"].b16):
             return None
-        return (rec["out"], rec["v"], SLOPE)
+        return (rec["out"], rec["v"], SLOPE, rec["pre"] == "nn")
 
     def _emit_block_bwd(self, pb: PlanBuilder, rec: dict, d_out: T, d_in: Optional[T], need_w: bool, affine: bool, *, pre_tail=None,
                         tail_next=None, act_next=None):
@@ -955,8 +963,11 @@ class CtlNet(nn.Module):
         if pre == "nn":
             # nearest-upsample backward = 2x2 sum-pool; it commutes with pointwise (1x1) convs, so both the 1x1 weight gradient
             # (sum up(x)*dS == sum x*pool(dS)) and the 1x1 data gradient below run on the pooled dS at a quarter of the pixels
-            ds_low = A.tensor(ds.n, ds.h // 2, ds.w // 2, ds.c)
-            pb.sumpool2(ds, ds_low)
+            if pre_tail is not None and len(pre_tail) > 2 and pre_tail[2] is not None:
+                ds_low = pre_tail[2]            # written by the tail epilogue of the launch that produced dS (FUSE_POOL)
+            else:
+                ds_low = A.tensor(ds.n, ds.h // 2, ds.w // 2, ds.c)
+                pb.sumpool2(ds, ds_low)
         if need_w:
             pb.wgrad(src, du, 3, in_mode=src_mode, dw_ref=pb.G(c0.w_off), strides=(c0.cin * k9, k9, 3, 1), dbias_ref=pb.G(c0.b_off), dy2=du2)
             if ds_low is not None:
@@ -970,7 +981,7 @@ class CtlNet(nn.Module):
             dsrc_shape = (src.n, 2 * src.h, 2 * src.w, src.c)
         if d_in is None:
             d_in = A.tensor(xin.n, xin.h, xin.w, xin.c)
-        fin = lambda st, blk: d_in if (tail_next is None and act_next is None) else (d_in, st, blk)
+        fin = lambda st, blk: d_in if (tail_next is None and act_next is None) else (d_in, st, blk, pb.last_pool)
         if pre == "nn":
             # sumpool2(conv3x3^T(dU)) as one 4x4 stride-2 conv (no full-resolution gradient tensor at all), then the 1x1 part
             pb.conv(du, self._wp_ref(c0.wp_up), c0.cin, 4, stride=2, out=d_in, x2=du2)
@@ -1033,7 +1044,7 @@ class CtlNet(nn.Module):
             d_x = A.tensor(x.n, x.h, x.w, x.c)
         ep = dict(tail=tail_next) if act_next is None else dict(bnbwd=act_next, keep_stats=True)
         _, st, blk = pb.conv(du, self._wp_ref(ci.wp_dgrad), ci.cin, ci.ks, out=d_x, x2=dy2, **ep)
-        return d_x if (tail_next is None and act_next is None) else (d_x, st, blk)
+        return d_x if (tail_next is None and act_next is None) else (d_x, st, blk, pb.last_pool)
 
     # ---------------------------------------------------------------- public compute entry points
     def _alloc_out(self, shape):
@@ -1357,7 +1368,7 @@ class MyDecoder(CtlNet):
         blocks = rec["blocks"]
         tail = self._tail_of(pb, blocks[3])
         d, st, blk = pb.conv(dout, self._wp_ref(cf.wp_dgrad), cf.cin, 1, arena=pb.bscr, tail=tail)
-        pre = (st, blk) if tail is not None else None
+        pre = (st, blk, pb.last_pool) if tail is not None else None
         dbg = {"d_out4": d, "tail_out4": pre}
         for i in range(3, -1, -1):
             d_in = T((S_DX, 0), *rec["x"][1:]) if (i == 0 and need_dx) else None

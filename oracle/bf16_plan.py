@@ -32,6 +32,7 @@ import torch.nn.functional as F
 SLOPE = 0.2
 ROUND = True                 # False: no rounding anywhere (pins the backward formulas against autograd)
 FUSE_BNBWD16 = True          # nets.FUSE_BNBWD16: BatchNorm-backward sums of the in-block BatchNorm inside the data-gradient epilogue
+FUSE_POOL = True             # nets.FUSE_POOL: the tail epilogue of a 1x1 host also writes sumpool2 of the UNROUNDED g (where the tile configuration allows)
 FUSE_PAIR16 = True           # nets.FUSE_PAIR16: the head pairs of the encoders get g and their sums from the launch that writes dAct (CTL_EPI_BNBWD)
 FUSE_TAIL16 = True           # nets.FUSE_TAIL16: the launch that writes a block's output gradient stores g = dOut * leaky'(out) and takes the tail's sums
 FUSE_BNAPPLY16 = True        # nets.FUSE_BNAPPLY16: dV / dU of a residual block are never stored; their consumers apply the coefficients to the stored g
@@ -209,9 +210,12 @@ def block_fwd(blk, pre: str, xin: torch.Tensor, xin_pro, mode: str) -> Tuple[tor
 def tail_pack(t: torch.Tensor, tail_next):
     """CTL_EPI_TAILBWD epilogue of the launch that writes the output gradient of the block (out, v) = tail_next: g = dOut * leaky'(out)
     from the UNROUNDED dOut = t, the tail's BatchNorm-backward sums from the unrounded g, g stored.  Returns (g stored, (sum g, sum g*v))."""
-    out_n, v_n = tail_next
+    out_n, v_n = tail_next[:2]
     g = t * dleaky(out_n, SLOPE)
-    return rb(g), (g.sum((0, 2, 3)), (g * v_n).sum((0, 2, 3)))
+    sums = (g.sum((0, 2, 3)), (g * v_n).sum((0, 2, 3)))
+    if len(tail_next) > 2 and tail_next[2]:          # ... and the 2x2 sum-pool of the unrounded g, stored (nets.FUSE_POOL)
+        return rb(g), sums + (rb(sumpool2(g)),)
+    return rb(g), sums
 
 
 def act_pack(t: torch.Tensor, act_next):
@@ -222,8 +226,12 @@ def act_pack(t: torch.Tensor, act_next):
     return rb(g), (g.sum((0, 2, 3)), (g * u_n).sum((0, 2, 3)))
 
 
-def tail_of(brec):
-    return (brec["out"], brec["v"]) if FUSE_TAIL16 else None
+def tail_of(brec, pooled=None):
+    """pooled: does the producing launch also write the sum-pool (None = whenever the consumer is a nearest-upsample block: what the plans do
+    where the producer's tile configuration gives every wave a row pair, i.e. everywhere but on the smallest layers)"""
+    if not FUSE_TAIL16:
+        return None
+    return (brec["out"], brec["v"], (FUSE_POOL and brec["pre"] == "nn") if pooled is None else pooled)
 
 
 def block_bwd(blk, rec: dict, d_out: torch.Tensor, need_w: bool, affine: bool, grads: dict, prefix: str, last: bool, *, pre_tail=None,
@@ -243,7 +251,7 @@ def block_bwd(blk, rec: dict, d_out: torch.Tensor, need_w: bool, affine: bool, g
     # residual tail (BatchNorm-backward mode 0): g = dOut * leaky'(out); dS = g, dV = A*g + B*v + C
     if pre_tail is not None or d_out_is_g:
         ds = d_out
-        s1, s2 = pre_tail if pre_tail is not None else (ds.sum((0, 2, 3)), (ds * v).sum((0, 2, 3)))
+        s1, s2 = pre_tail[:2] if pre_tail is not None else (ds.sum((0, 2, 3)), (ds * v).sum((0, 2, 3)))
         A2, B2, C2, dg2, db2 = bn_bwd_coefs(bn2, co2, s1, s2, ds.numel() // ds.shape[1], ds.dtype)
         dv = rb(_cv(0, A2) * ds + _cv(0, B2) * v + _cv(0, C2))          # (apply pass on the stored g, stand-alone or staged: same arithmetic)
         g = None
@@ -281,7 +289,7 @@ def block_bwd(blk, rec: dict, d_out: torch.Tensor, need_w: bool, affine: bool, g
     if need_w and affine:
         grads[prefix + ".conv.1.weight"], grads[prefix + ".conv.1.bias"] = dg1, db1
     if pre == "nn":
-        ds_low = rb(sumpool2(ds))
+        ds_low = pre_tail[2] if (pre_tail is not None and len(pre_tail) > 2) else rb(sumpool2(ds))
         if need_w:
             grads[prefix + ".conv.0.weight"], grads[prefix + ".conv.0.bias"] = conv_wgrad(c0, up2(rb(xin)), du)
             grads[prefix + ".conv_input.weight"], grads[prefix + ".conv_input.bias"] = conv_wgrad(c1, rb(xin), ds_low)

@@ -102,8 +102,10 @@ class _Arenas:
         """(sum g, sum g*v) of a fused residual tail from the statistics partials the producing launch wrote ([rows][2][c], one group)"""
         if pre is None:
             return None
-        (slot, off), rows = pre
+        (slot, off), rows = pre[:2]
         part = self.bases[slot][off:off + 4 * rows * 2 * c].view(torch.float32).double().cpu().view(rows, 2, c).sum(0)
+        if len(pre) > 2 and pre[2] is not None:        # FUSE_POOL: the producing launch also wrote the sum-pool of g
+            return part[0].float(), part[1].float(), self.t(pre[2])
         return part[0].float(), part[1].float()
 
     def co(self, co, c):
@@ -153,12 +155,13 @@ class _switches:
             setattr(P, n, b)
 
 
-def _tail_next(A, rec, i):
-    """(out, v) of the block that consumes block i's input gradient, when the engine's plan fuses that block's tail (block i - 1)"""
+def _tail_next(A, rec, i, pre=None):
+    """(out, v, pooled) of the block that consumes block i's input gradient, when the engine's plan fuses that block's tail (block
+    i - 1); pre = the engine's record of that launch (statistics ref, rows, pooled tensor or None)"""
     if not P.FUSE_TAIL16 or i < 1:
         return None
     b = A.block(rec["blocks"][i - 1])
-    return (b["out"], b["v"])
+    return (b["out"], b["v"], pre is not None and len(pre) > 2 and pre[2] is not None)
 
 
 def _first(r):
@@ -185,13 +188,19 @@ def test_bf16_backward_plan_wiring_decoder(name, mode, fused, golden_sd):
         x4 = A.t(rec["x4"])
         grads["final_conv.weight"], grads["final_conv.bias"] = P.conv_wgrad(onet.final_conv, P.rb(x4), dl)
         t4 = P.conv_dgrad(onet.final_conv, dl, x4.shape[2:])
-        _check(errs, "d_out4", A.t(dbg["d_out4"]), P.tail_pack(t4, _tail_next(A, rec, 4))[0] if P.FUSE_TAIL16 else P.rb(t4))
+        r4 = P.tail_pack(t4, _tail_next(A, rec, 4, dbg["tail_out4"])) if P.FUSE_TAIL16 else (P.rb(t4),)
+        _check(errs, "d_out4", A.t(dbg["d_out4"]), r4[0])
+        if P.FUSE_TAIL16 and len(r4[1]) > 2:
+            _check(errs, "sum-pool of d_out4 from the tail epilogue", A.t(dbg["tail_out4"][2]), r4[1][2])
         seen += _check_grads(errs, hp, grads, "final_conv")
         for i in range(3, -1, -1):
             grads = {}
             d_in = P.block_bwd(getattr(onet, f"up{i + 1}"), A.block(rec["blocks"][i]), A.t(dbg[f"d_out{i + 1}"]), True, affine, grads, f"up{i + 1}",
-                               last=(i == 0), pre_tail=A.tail_sums(dbg[f"tail_out{i + 1}"], rec["blocks"][i]["out"].c), tail_next=_tail_next(A, rec, i))
+                               last=(i == 0), pre_tail=A.tail_sums(dbg[f"tail_out{i + 1}"], rec["blocks"][i]["out"].c),
+                               tail_next=_tail_next(A, rec, i, dbg[f"tail_out{i}"]))
             _check(errs, f"d_in of up{i + 1}", xh.grad if i == 0 else A.t(dbg[f"d_out{i}"]), _first(d_in))
+            if isinstance(d_in, tuple) and len(d_in[1]) > 2:
+                _check(errs, f"sum-pool of d_in of up{i + 1} from the tail epilogue", A.t(dbg[f"tail_out{i}"][2]), d_in[1][2])
             seen += _check_grads(errs, hp, grads, f"up{i + 1}")
         expect = {n for n, p in onet.named_parameters() if affine or not any(s in n for s in (".conv.1.", ".conv.4."))}
         assert set(seen) == expect, set(seen) ^ expect                   # every parameter of the network was compared
@@ -239,7 +248,7 @@ def _wiring_encoder(name, mode, golden_sd):
         dz = A.t(dbg["dz"])
     grads = {}
     d = P.conv_bn_pair_bwd(enc.final_conv[0], enc.final_conv[1], A.t(rec["x4"]), None, A.t(rec["uf"]), A.co(rec["cof"], c_lat), 0.0, dz, True, affine,
-                           grads, px + "final_conv.0", px + "final_conv.1", tail_next=_tail_next(A, rec, 4))
+                           grads, px + "final_conv.0", px + "final_conv.1", tail_next=_tail_next(A, rec, 4, dbg["tail_down5"]))
     _check(errs, "d behind final_conv", A.t(dbg["d_down5"]), _first(d))
     seen += _check_grads(errs, hp, grads, "final")
     c0 = rec["u0"].c
@@ -252,7 +261,7 @@ def _wiring_encoder(name, mode, golden_sd):
     for j in range(4, 0, -1):
         grads = {}
         d_in = P.block_bwd(getattr(enc, f"down{j}"), A.block(rec["blocks"][j - 1]), A.t(dbg[f"d_down{j + 1}"]), True, affine, grads, f"{px}down{j}", last=False,
-                           pre_tail=A.tail_sums(dbg[f"tail_down{j + 1}"], rec["blocks"][j - 1]["out"].c), tail_next=_tail_next(A, rec, j - 1),
+                           pre_tail=A.tail_sums(dbg[f"tail_down{j + 1}"], rec["blocks"][j - 1]["out"].c), tail_next=_tail_next(A, rec, j - 1, dbg[f"tail_down{j}"]),
                            act_next=act1 if j == 1 else None)
         _check(errs, f"d_in of down{j}", A.t(dbg[f"d_down{j}"]), _first(d_in))
         seen += _check_grads(errs, hp, grads, f"down{j}")
@@ -329,10 +338,10 @@ def test_bf16_saliency_dgrad_only_pass_vs_oracle(golden_sd):
     onet.load_state_dict(golden_sd[name])
     rec, dbg, errs = A.fplan.rec, A.bplan.rec, []
     t4 = P.conv_dgrad(onet.final_conv, douts[0], A.t(rec["x4"]).shape[2:])
-    _check(errs, "d_out4", A.t(dbg["d_out4"]), P.tail_pack(t4, _tail_next(A, rec, 4))[0] if P.FUSE_TAIL16 else P.rb(t4))
+    _check(errs, "d_out4", A.t(dbg["d_out4"]), P.tail_pack(t4, _tail_next(A, rec, 4, dbg["tail_out4"]))[0] if P.FUSE_TAIL16 else P.rb(t4))
     for i in range(3, -1, -1):
         d_in = P.block_bwd(getattr(onet, f"up{i + 1}"), A.block(rec["blocks"][i]), A.t(dbg[f"d_out{i + 1}"]), False, False, {}, f"up{i + 1}", last=(i == 0),
-                           pre_tail=A.tail_sums(dbg[f"tail_out{i + 1}"], rec["blocks"][i]["out"].c), tail_next=_tail_next(A, rec, i))
+                           pre_tail=A.tail_sums(dbg[f"tail_out{i + 1}"], rec["blocks"][i]["out"].c), tail_next=_tail_next(A, rec, i, dbg[f"tail_out{i}"]))
         _check(errs, f"d_in of up{i + 1}", g if i == 0 else A.t(dbg[f"d_out{i}"]), _first(d_in))
     assert all(p.grad is None or float(p.grad.abs().max()) == 0.0 for p in hnet.parameters())
 

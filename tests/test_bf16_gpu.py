@@ -452,9 +452,19 @@ def test_tail_backward_epilogue(n, cin, cout, h, w, groups, form, family):
         d = _ffi.conv_desc(n=n, hin=h // 2, win=w // 2, cin=cin, hout=h, wout=w, cout=cout, ks=3, in_mode=_ffi.IN_ZINS2, groups=groups, epi_slope=0.2,
                            dt=dt, epi_flags=flags)
     y = dev(y0, b16) if y0 is not None else None
-    y, st = ops.conv_forward(d, dev(x, b16), wp, res=dev(out, b16), res2=dev(v, b16), y=y, want_stats=True)
+    # FUSE_POOL: where the tile configuration gives every wave a row pair, the 1x1 hosts also write the 2x2 sum-pool of g
+    pool = None
+    if form.startswith("1x1") and lib.ctl_conv_pool_ok(_ffi.desc_ptr(d)):
+        pool = ops.empty_nhwc(n, cout, h // 2, w // 2, DEV, torch.bfloat16 if b16 else torch.float32)
+    y, st = ops.conv_forward(d, dev(x, b16), wp, res=dev(out, b16), res2=dev(v, b16), y=y, want_stats=True, pool=pool)
     g = ref * torch.where(out > 0, 1.0, 0.2).double()
     close(y, g, 3e-4 if b16 else 2e-4, f"tail epilogue {form}", b16)
+    if pool is not None:
+        close(pool, F.avg_pool2d(g, 2) * 4.0, 3e-4 if b16 else 2e-4, "sum-pool of g from the tail epilogue", b16)
+        if not b16:      # the stand-alone pass on the stored g: the same association, bit for bit
+            sp = torch.empty_like(pool)
+            check(lib.ctl_sumpool2_dt(ops.ptr(y), ops.ptr(sp), n, h // 2, w // 2, cout, 0, 0, ops.stream_ptr()))
+            assert torch.equal(sp, pool), "fused sum-pool differs from ctl_sumpool2 on the stored g"
     part = st.cpu().double().view(groups, -1, 2, cout).sum(1)
     gi = torch.arange(n) // (n // groups)
     for k in range(groups):

@@ -54,7 +54,7 @@ def test_every_declared_symbol_is_exported():
 
 
 def test_struct_layouts_match():
-    assert _ffi.lib.ctl_sizeof_op() == _ffi.OP_DTYPE.itemsize == 304
+    assert _ffi.lib.ctl_sizeof_op() == _ffi.OP_DTYPE.itemsize == 328
     assert _ffi.lib.ctl_sizeof_conv() == _ffi.CONV_DTYPE.itemsize == 96
 
 
