@@ -37,7 +37,8 @@ PEAK_MFMA_F32_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 d
 PEAK_MFMA_BF16_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak
 PEAK_HBM_GBS = 8000.0
 # dominant kernel of this workload per profiles/ (rocprofv3 --kernel-trace --stats): the 3x3 stride-1 implicit-GEMM conv
-# at 8x32 tiles / 16 output channels, i.e. every 16->16 (and 1|4->16, 16->4) conv and dgrad at 256x256
+# at 8x32 tiles / 16 output channels, plain epilogue: the 16->16 convs and data gradients at 256x256 (and 32->16 at 128x128); the
+# launches of the same template with an epilogue operand, the two-tensor prologue or < 16 output channels have their own ids
 PROF_EVERY = 4                   # inside the timed region the dominant kernel's launches are sampled (two event records per launch cost
                                  # a launch-bound step ~1.5 %); the single-stream replay behind it brackets every launch
 SINGLE_STREAM_STEPS = 5
@@ -125,8 +126,9 @@ def cpu_baseline(host_batch, threads, steps=3, cfgs=(DROP_IMG, DROP_SEG), what="
 
 
 def _narrow(k):
-    """1x1 convs and the <= 4-channel first layers (K-packed taps, in3): 8-32 flop per byte, HBM-side members of the conv families"""
-    return "<ks1," in k or ",in3," in k
+    """1x1 convs, the <= 4-channel first layers (K-packed taps, in3) and the launches with fewer than 16 output channels (id suffix ,coN):
+    8-32 flop per byte, HBM-side members of the conv families"""
+    return "<ks1," in k or ",in3," in k or ",co" in k
 
 
 # (the two conv families whole, as round 2 reported them, and split by what bounds their members: the 3x3 / 4x4 / 2x2 forms on >= 16

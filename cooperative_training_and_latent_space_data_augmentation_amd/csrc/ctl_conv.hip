@@ -1434,8 +1434,9 @@ static void wgrad_go(wgrad_call& a) {
     const int par = w.c.g * (w.c.cot / NTW);
     static const int slots = ctl_tune_int("CTL_WGRAD_SLOTS", 0);      // tuning hook: total blocks
     // (the HBM-side members of the family -- 1x1 convs, the <= 4-channel first layers -- run at 0.28 of 8 TB/s with one block per CU and
-    // 0.36 with two or four; the STEP is no faster for it, 17.37-17.53 vs 17.43-17.59 ms: tuning hook CTL_WGRAD_NARROW_PERSIST, default 1)
-    static const int narrow_cu = ctl_tune_int("CTL_WGRAD_NARROW_PERSIST", 1);
+    // 0.37 with two or four.  While the backward still had its element-wise passes the STEP was no faster for it (17.37-17.53 vs
+    // 17.43-17.59 ms); without them two blocks give 16.80 -> 16.72 ms, four 16.79: tuning hook CTL_WGRAD_NARROW_PERSIST)
+    static const int narrow_cu = ctl_tune_int("CTL_WGRAD_NARROW_PERSIST", 2);
     const int cu_blocks = (KS == 1 || MODE == CTL_IN_C4) ? narrow_cu : per_cu;
     int splits = (slots > 0 ? slots : 256 * (occ < cu_blocks ? occ : cu_blocks)) / par;
     if (splits > 512) splits = 512;

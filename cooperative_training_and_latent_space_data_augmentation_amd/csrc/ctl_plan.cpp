@@ -60,7 +60,7 @@ hipEvent_t prof_event() {
 
 int ctl_prof_begin(const char* kind, const ctl_conv* d, const ctl_conv_cfg* c, int nt, hipStream_t stream, bool dy2) {
     if (!g_prof_on) return -1;
-    char id[160], sfx[24];
+    char id[160], sfx[40];
     // one id per kernel instantiation family, as rocprofv3 lists them: the epilogue class (fp32: the EPI template value, 1 = residual /
     // accumulate / BatchNorm-backward operand, 2 = tail reduction, 3 = BatchNorm-backward reduction alone; bf16: the FAST value) and the two-tensor prologue are part of it
     const int f = d->epi_flags;
@@ -69,8 +69,10 @@ int ctl_prof_begin(const char* kind, const ctl_conv* d, const ctl_conv_cfg* c, i
     const int e16 = (f & CTL_EPI_TAILBWD) ? 5 : ((f & CTL_EPI_BNBWD) ? 4 : ((f & CTL_EPI_RES) ? 2 : ((f & CTL_EPI_ACCUM) ? 3 : 0)));
     const int e = (d->dt & CTL_DT_BF16) ? e16 : e32;
     const bool two = d->pro_affine == 2 || dy2;
-    if (e) snprintf(sfx, sizeof(sfx), ",e%d%s", e, two ? ",x2" : "");
-    else snprintf(sfx, sizeof(sfx), "%s", two ? ",x2" : "");
+    char nar[12] = "";      // fewer than 16 output channels: most of the MFMA's N columns are padding -- an HBM-side launch of a matrix-side template
+    if (d->cout < 16) snprintf(nar, sizeof(nar), ",co%d", d->cout);
+    if (e) snprintf(sfx, sizeof(sfx), ",e%d%s%s", e, two ? ",x2" : "", nar);
+    else snprintf(sfx, sizeof(sfx), "%s%s", two ? ",x2" : "", nar);
     static const bool shapes = ctl_tune_str("CTL_PROF_SHAPES") != nullptr;      // (-DCTL_TUNING builds: one id per layer shape)
     if (shapes)
         snprintf(id, sizeof(id), "%s<ks%d,s%d,in%d,mt%d,tw%d,nt%d%s>[n%d,h%d,ci%d,co%d,e%d]", kind, d->ks, d->stride, d->in_mode, c->mt, c->tw, nt, sfx, d->n,
