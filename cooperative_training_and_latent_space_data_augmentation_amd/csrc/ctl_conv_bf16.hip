@@ -256,7 +256,10 @@ extern "C" int ctl_debug_timing16(unsigned long long* out12) {
 // channels) take the FAST epilogues with the generic staging.
 // X2: the input is the virtual BatchNorm-backward result  A * x + B * x2 + C  (XStage16; pro_scale = the [group][3][cin] coefficients)
 template <int KS, int S, int MODE, int MT, int TW, int NT, int FAST, bool XB, bool X2 = false>      // FAST: 0 generic; 1 plain; 2 + bf16 residual * scale + shift (+ LeakyReLU); 3 accumulate into y
-__global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? CTL16_OCC_BIG : CTL16_OCC) void conv_igemm_bf16_kernel(
+#ifndef CTL16_OCC_X2
+#define CTL16_OCC_X2 2      // resident blocks of the two-tensor instantiations: at 3 they need 20-44 B of scratch per lane (bf16 step 10.64 -> 10.48 ms)
+#endif
+__global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? CTL16_OCC_BIG : (X2 ? CTL16_OCC_X2 : CTL16_OCC)) void conv_igemm_bf16_kernel(
     const ctl_conv d, const void* __restrict__ x, const void* __restrict__ x2, const void* __restrict__ wpack, const float* __restrict__ bias,
     const float* __restrict__ pro_scale, const float* __restrict__ pro_shift, const void* __restrict__ res,
     const float* __restrict__ res_scale, const float* __restrict__ res_shift, const void* __restrict__ res2, void* __restrict__ y,
@@ -1010,7 +1013,10 @@ __device__ __forceinline__ bf16x8 tr_read8(const unsigned char* a0, const unsign
 
 // DY2: the output gradient is the virtual BatchNorm-backward result  A * dy + B * dy2 + C  (coefficients [group][3][cout] as the
 // finalize writes them; dy = g, dy2 = the BatchNorm input): the `apply` pass runs in this staging (see XStage16 X2)
-template <int KS, int S, int MODE, int MT, int NTW, bool DY2 = false>
+// BB: both operands are known to be STORED as bf16 with whole 16-channel chunks (every layer but the network boundaries): the staging is
+// straight-line code.  With the storage types as run-time flags the compiler keeps the staged units in SCRATCH memory and waits for every
+// global load right where it is issued (seen in the ISA: buffer_load, s_waitcnt vmcnt(0), scratch_store) -- no prefetch left at all.
+template <int KS, int S, int MODE, int MT, int NTW, bool DY2 = false, bool BB = false>
 __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const ctl_conv d, const void* __restrict__ x,
                                                                const float* __restrict__ pro_scale, const float* __restrict__ pro_shift,
                                                                const void* __restrict__ dy, const void* __restrict__ dy2,
@@ -1019,7 +1025,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const ctl_conv d, 
                                                                int cin_p, int cout_p) {
     constexpr int TW = 16;
     using G = Geom<KS, S, MT, TW>;
-    using XS = XStage16<KS, S, MODE, MT, TW>;
+    using XS = XStage16<KS, S, MODE, MT, TW, BB>;
     constexpr int TAPS = KS * KS;
     constexpr int KB = G::TP / 32;                       // k-blocks per tile: 4 (8x16 tile) or 2 (4x16)
     constexpr int XT_ALLOC = XS::XT_BYTES + 16;
@@ -1040,7 +1046,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const ctl_conv d, 
     const int g = blockIdx.y;
     const int cot0 = blockIdx.z * NTW;
     const int group_n = d.n / (d.groups > 1 ? d.groups : 1);
-    const bool dy16 = (d.dt & CTL_DT_Y16) != 0;
+    const bool dy16 = BB || (d.dt & CTL_DT_Y16) != 0;
     const int des = dy16 ? 2 : 4;
 
     f32x4 acc[TAPS][NTW];
@@ -1091,6 +1097,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const ctl_conv d, 
                 dmask |= (ok && drel[i] != CTL_OOB) ? (1u << i) : 0u;
                 continue;
             }
+            if constexpr (BB) { dv0[i] = ctl_bload4u(rdy, vo, 0); continue; }
             if (dy16) dv0[i] = ctl_bload4u(rdy, vo, 0);
             else if (d.cout >= 4) { dv0[i] = ctl_bload4u(rdy, vo, 0); dv1[i] = dq1[i] ? ctl_bload4u(rdy, vo + 16, 0) : z; }
             else { dv0[i] = u32x4{__builtin_amdgcn_raw_buffer_load_b32(rdy, vo, 0, 0), 0u, 0u, 0u}; dv1[i] = z; }
@@ -1112,6 +1119,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const ctl_conv d, 
                     if (!((dmask >> i) & 1u)) pk = zero;          // pixels past the image contribute nothing (C alone would)
                     *reinterpret_cast<u32x4*>(dyt + dlds[i]) = pk;
                 }
+            }
+            return;
+        }
+        if constexpr (BB) {
+#pragma unroll
+            for (int i = 0; i < ND; ++i) {
+                if (tid + i * 256 < DU) *reinterpret_cast<u32x4*>(dyt + dlds[i]) = dv0[i];
             }
             return;
         }
@@ -1258,13 +1272,13 @@ struct wgrad16_call {
     const void *x, *dy, *dy2; const float *pro_scale, *pro_shift, *dy_coef; float *w_partial, *b_partial;
     hipStream_t stream; bool query;
 };
-template <int KS, int S, int MODE, int MT, int NTW, bool DY2>
+template <int KS, int S, int MODE, int MT, int NTW, bool DY2, bool BB>
 static void wgrad16_go_f(wgrad16_call& a) {
     static int occ = 0;
     if (!occ) {
         int n = 0;
         // (of the plain instantiation, also for DY2: the split count is queried at plan time from the descriptor alone and sizes the partials)
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_wgrad_bf16_kernel<KS, S, MODE, MT, NTW, false>, 256, 0) != hipSuccess || n < 1) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_wgrad_bf16_kernel<KS, S, MODE, MT, NTW, false, false>, 256, 0) != hipSuccess || n < 1) {
             (void)hipGetLastError();
             n = 2;
         }
@@ -1279,16 +1293,22 @@ static void wgrad16_go_f(wgrad16_call& a) {
     a.splits = splits;
     if (a.query) return;
     const dim3 grid((unsigned)splits, (unsigned)a.c.g, (unsigned)(a.c.cot / NTW));
-    conv_wgrad_bf16_kernel<KS, S, MODE, MT, NTW, DY2><<<grid, dim3(256), 0, a.stream>>>(*a.d, a.x, a.pro_scale, a.pro_shift, a.dy, a.dy2, a.dy_coef,
+    conv_wgrad_bf16_kernel<KS, S, MODE, MT, NTW, DY2, BB><<<grid, dim3(256), 0, a.stream>>>(*a.d, a.x, a.pro_scale, a.pro_shift, a.dy, a.dy2, a.dy_coef,
                                                                                         a.w_partial, a.b_partial, a.c.tiles_h, a.c.tiles_w, a.ntiles,
                                                                                         a.cin_p, a.cout_p);
 }
 template <int KS, int S, int MODE, int MT, int NTW>
 static void wgrad16_go(wgrad16_call& a) {
     if constexpr (KS == 3 && S == 1) {      // the two-tensor output gradient: the 3x3 convs of the residual blocks
-        if (a.dy2) { wgrad16_go_f<KS, S, MODE, MT, NTW, true>(a); return; }
+        if (a.dy2) {      // (bf16-stored dy / dy2 by contract; x is fp32 in the encoders' first layer)
+            if ((a.d->dt & CTL_DT_X16) && a.d->cin % 16 == 0) wgrad16_go_f<KS, S, MODE, MT, NTW, true, true>(a);
+            else wgrad16_go_f<KS, S, MODE, MT, NTW, true, false>(a);
+            return;
+        }
     }
-    wgrad16_go_f<KS, S, MODE, MT, NTW, false>(a);
+    const ctl_conv* d = a.d;
+    if ((d->dt & CTL_DT_X16) && (d->dt & CTL_DT_Y16) && d->cin % 16 == 0 && d->cout % 16 == 0) wgrad16_go_f<KS, S, MODE, MT, NTW, false, true>(a);
+    else wgrad16_go_f<KS, S, MODE, MT, NTW, false, false>(a);
 }
 template <int KS, int S, int MODE>
 static void wgrad16_go_tile(wgrad16_call& a) {
