@@ -51,9 +51,13 @@ __device__ __forceinline__ u32x2 ctl_bload2u(__amdgpu_buffer_rsrc_t r, int voff,
 // X2 (pro_affine == 2, the BatchNorm-backward prologue): the operand is the VIRTUAL tensor  A[c] * x + B[c] * x2 + C[c]  of two bf16 tensors
 // of one geometry (x = g = dL/da * leaky', x2 = the BatchNorm input u): the `apply` pass of the BatchNorm backward runs here, in the
 // staging of its consumers, and its output tensor never exists.  Rounded to bf16 once, exactly where the stored tensor was rounded.
-template <int KS, int S, int MODE, int MT, int TW, bool X16C = false, bool PLANAR = false, bool X2 = false>      // X16C: the source is known to be stored as bf16
+// X16C: what is known at compile time about the source -- 1: stored as bf16 (whole 16-channel chunks); 2: stored as fp32 with a multiple of 4
+// channels; 3: fp32 with ONE channel; 0: decided at run time.  Run-time storage flags cost more than branches: with them the compiler keeps
+// v0 / v1 in scratch memory and waits for each global load where it is issued (no prefetch left), so every layer shape of the path has
+// its compile-time kind and 0 only serves shapes outside it.
+template <int KS, int S, int MODE, int MT, int TW, int X16C = 0, bool PLANAR = false, bool X2 = false>
 struct XStage16 {
-    static_assert(!X2 || X16C, "the two-tensor prologue works on bf16-stored tensors");
+    static_assert(!X2 || X16C == 1, "the two-tensor prologue works on bf16-stored tensors");
     using G = Geom<KS, S, MT, TW>;
     static constexpr int UNITS = G::IH * G::IW * 2;
     static constexpr int NU = (UNITS + 255) / 256;
@@ -70,7 +74,7 @@ struct XStage16 {
 
     __device__ __forceinline__ void init(const ctl_conv& d) {
         const int tid = threadIdx.x, h = tid & 1;
-        x16 = X16C || (d.dt & CTL_DT_X16) != 0;
+        x16 = X16C == 1 || (X16C == 0 && (d.dt & CTL_DT_X16) != 0);
         const int esz = x16 ? 2 : 4;
 #pragma unroll
         for (int i = 0; i < NU; ++i) {
@@ -105,7 +109,7 @@ struct XStage16 {
             if (X2) {
 #pragma unroll
                 for (int i = 0; i < NU; ++i) { v0[i] = ctl_bload4u(rx, rel[i], tb); v1[i] = ctl_bload4u(rx2, rel[i], tb); }
-            } else if (x16) {
+            } else if (X16C == 1 || (X16C == 0 && x16)) {
 #pragma unroll
                 for (int i = 0; i < NU; ++i) v0[i] = ctl_bload4u(rx, rel[i], tb);
             } else {
@@ -130,10 +134,10 @@ struct XStage16 {
         if (X2) {
 #pragma unroll
             for (int i = 0; i < NU; ++i) { v0[i] = ctl_bload4u(rx, vo[i], 0); v1[i] = ctl_bload4u(rx2, vo[i], 0); }
-        } else if (x16) {                           // internal tensors: cin is a multiple of 16 (checked on the host)
+        } else if (X16C == 1 || (X16C == 0 && x16)) {      // internal tensors: cin is a multiple of 16 (checked on the host)
 #pragma unroll
             for (int i = 0; i < NU; ++i) v0[i] = ctl_bload4u(rx, vo[i], 0);
-        } else if (d.cin >= 4) {                    // fp32 source: quads of 4 channels, the second one may lie past cin (4 or 12 channels)
+        } else if (X16C == 2 || (X16C == 0 && d.cin >= 4)) {      // fp32 source: quads of 4 channels, the second one may lie past cin (4 or 12 channels)
             const bool q1 = cb + 4 < d.cin;
 #pragma unroll
             for (int i = 0; i < NU; ++i) { v0[i] = ctl_bload4u(rx, vo[i], 0); v1[i] = q1 ? ctl_bload4u(rx, vo[i] + 16, 0) : z; }
@@ -165,7 +169,7 @@ struct XStage16 {
             }
             return;
         }
-        if (!d.pro_affine && x16) {                 // bf16 in, nothing to compute: out-of-range units were loaded as hardware zeros
+        if (!d.pro_affine && (X16C == 1 || (X16C == 0 && x16))) {      // bf16 in, nothing to compute: out-of-range units were loaded as hardware zeros
 #pragma unroll
             for (int i = 0; i < NU; ++i) *reinterpret_cast<u32x4*>(xt + lds[i]) = v0[i];
             return;
@@ -187,7 +191,7 @@ struct XStage16 {
 #pragma unroll
         for (int i = 0; i < NU; ++i) {
             f32x4 lo, hi;
-            if (x16) { lo = unpack_bf16x4(v0[i].x, v0[i].y); hi = unpack_bf16x4(v0[i].z, v0[i].w); }
+            if (X16C == 1 || (X16C == 0 && x16)) { lo = unpack_bf16x4(v0[i].x, v0[i].y); hi = unpack_bf16x4(v0[i].z, v0[i].w); }
             else { lo = __builtin_bit_cast(f32x4, v0[i]); hi = __builtin_bit_cast(f32x4, v1[i]); }
             if (d.pro_affine) { lo = ctl_leaky01(lo * sc0 + sh0, slope); hi = ctl_leaky01(hi * sc1 + sh1, slope); }
             u32x4 pk = pack_bf16x8(lo, hi);
@@ -255,11 +259,12 @@ extern "C" int ctl_debug_timing16(unsigned long long* out12) {
 // XB: the input is stored as bf16 with whole 16-channel chunks (compile-time staging); the network-boundary layers (fp32 input with 1 or 4
 // channels) take the FAST epilogues with the generic staging.
 // X2: the input is the virtual BatchNorm-backward result  A * x + B * x2 + C  (XStage16; pro_scale = the [group][3][cin] coefficients)
-template <int KS, int S, int MODE, int MT, int TW, int NT, int FAST, bool XB, bool X2 = false>      // FAST: 0 generic; 1 plain; 2 + bf16 residual * scale + shift (+ LeakyReLU); 3 accumulate into y
+template <int KS, int S, int MODE, int MT, int TW, int NT, int FAST, int XB, bool X2 = false>      // (XB: XStage16's X16C) FAST: 0 generic; 1 plain; 2 + bf16 residual * scale + shift (+ LeakyReLU); 3 accumulate into y
 #ifndef CTL16_OCC_X2
 #define CTL16_OCC_X2 2      // resident blocks of the two-tensor instantiations: at 3 they need 20-44 B of scratch per lane (bf16 step 10.64 -> 10.48 ms)
 #endif
-__global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? CTL16_OCC_BIG : (X2 ? CTL16_OCC_X2 : CTL16_OCC)) void conv_igemm_bf16_kernel(
+// (the same for the fp32-input kinds -- two registers per staged unit -- and the stride-2 3x3 form at 4 fragments per wave: 36-100 B of scratch at 3)
+__global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? CTL16_OCC_BIG : ((X2 || XB >= 2 || (KS == 3 && S == 2 && MT * NT >= 4)) ? CTL16_OCC_X2 : CTL16_OCC)) void conv_igemm_bf16_kernel(
     const ctl_conv d, const void* __restrict__ x, const void* __restrict__ x2, const void* __restrict__ wpack, const float* __restrict__ bias,
     const float* __restrict__ pro_scale, const float* __restrict__ pro_shift, const void* __restrict__ res,
     const float* __restrict__ res_scale, const float* __restrict__ res_shift, const void* __restrict__ res2, void* __restrict__ y,
@@ -300,7 +305,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? CTL16_OCC_BIG : (X
     const int ngroups = d.groups > 1 ? d.groups : 1;
     const int group_n = d.n / ngroups;
     const int oy0 = (z >> 1) * d.out_sub, ox0 = (z & 1) * d.out_sub;
-    const __amdgpu_buffer_rsrc_t rx = ctl_rsrc(x, (int64_t)d.n * d.hin * d.win * d.cin * ((XB || (d.dt & CTL_DT_X16)) ? 2 : 4));
+    const __amdgpu_buffer_rsrc_t rx = ctl_rsrc(x, (int64_t)d.n * d.hin * d.win * d.cin * ((XB == 1 || (XB == 0 && (d.dt & CTL_DT_X16))) ? 2 : 4));
     const __amdgpu_buffer_rsrc_t rx2 = X2 ? ctl_rsrc(x2, (int64_t)d.n * d.hin * d.win * d.cin * 2) : rx;
     const int64_t ypix = (int64_t)d.n * d.out_h * d.out_w * d.cout;
     const __amdgpu_buffer_rsrc_t ry = ctl_rsrc(y, ypix * yes);
@@ -867,7 +872,7 @@ struct conv16_call {
     const float *bias, *pro_scale, *pro_shift, *res_scale, *res_shift; float* stats_partial;
     hipStream_t stream; bool query; int grid_x;
 };
-template <int KS, int S, int MODE, int MT, int TW, int NT, int FAST, bool XB, bool X2 = false>
+template <int KS, int S, int MODE, int MT, int TW, int NT, int FAST, int XB, bool X2 = false>
 static void conv16_go_f(conv16_call& a) {
     static int occ = 0;
     if (!occ) {
@@ -909,8 +914,12 @@ static void conv16_go(conv16_call& a) {
     if (d->epi_flags & CTL_EPI_BNBWD) { conv16_go_f<KS, S, MODE, MT, TW, NT, 4, true>(a); return; }      // (checked in ctl_conv_forward_bf16)
     if (d->epi_flags & CTL_EPI_TAILBWD) {       // the launches that write a block's output gradient (checked in ctl_conv_forward_ex)
         if constexpr ((KS == 1 && MODE == CTL_IN_PLAIN) || KS == 2 || (KS == 3 && S == 1 && MODE == CTL_IN_ZINS2)) {
-            if (xb) conv16_go_f<KS, S, MODE, MT, TW, NT, 5, true>(a);
-            else if constexpr (KS == 1) conv16_go_f<KS, S, MODE, MT, TW, NT, 5, false>(a);      // (the 1x1 data gradient of a network's fp32 output layer)
+            if (xb) conv16_go_f<KS, S, MODE, MT, TW, NT, 5, 1>(a);
+            else if constexpr (KS == 1) {          // (the 1x1 data gradient of a network's fp32 output layer: 4 or 1 channels)
+                if (!(d->dt & CTL_DT_X16) && d->cin >= 4) conv16_go_f<KS, S, MODE, MT, TW, NT, 5, 2>(a);
+                else if (!(d->dt & CTL_DT_X16) && d->cin == 1) conv16_go_f<KS, S, MODE, MT, TW, NT, 5, 3>(a);
+                else conv16_go_f<KS, S, MODE, MT, TW, NT, 5, 0>(a);
+            }
         }
         return;
     }
@@ -918,11 +927,18 @@ static void conv16_go(conv16_call& a) {
         if (fast == 1) conv16_go_f<KS, S, MODE, MT, TW, NT, 1, true>(a);
         else if (fast == 2) conv16_go_f<KS, S, MODE, MT, TW, NT, 2, true>(a);
         else if (fast == 3) conv16_go_f<KS, S, MODE, MT, TW, NT, 3, true>(a);
-        else conv16_go_f<KS, S, MODE, MT, TW, NT, 0, false>(a);
-    } else {          // fp32 (or partial-chunk) input: first layers of the encoders
-        if (fast == 1) conv16_go_f<KS, S, MODE, MT, TW, NT, 1, false>(a);
-        else if (fast == 2) conv16_go_f<KS, S, MODE, MT, TW, NT, 2, false>(a);
-        else conv16_go_f<KS, S, MODE, MT, TW, NT, 0, false>(a);
+        else conv16_go_f<KS, S, MODE, MT, TW, NT, 0, 1>(a);      // (bf16 in, generic epilogue: the fp32 output layers)
+    } else if constexpr (KS == 3 && S == 1 && MODE == CTL_IN_PLAIN) {          // fp32 input: first layers of the encoders (4 or 1 channels)
+        const int xk = (d->dt & CTL_DT_X16) ? 0 : (d->cin == 1 ? 3 : 2);
+        if (fast == 1 && xk == 2) conv16_go_f<KS, S, MODE, MT, TW, NT, 1, 2>(a);
+        else if (fast == 1 && xk == 3) conv16_go_f<KS, S, MODE, MT, TW, NT, 1, 3>(a);
+        else if (fast == 1) conv16_go_f<KS, S, MODE, MT, TW, NT, 1, 0>(a);
+        else if (fast == 2) conv16_go_f<KS, S, MODE, MT, TW, NT, 2, 0>(a);
+        else conv16_go_f<KS, S, MODE, MT, TW, NT, 0, 0>(a);
+    } else {          // (shapes outside the path)
+        if (fast == 1) conv16_go_f<KS, S, MODE, MT, TW, NT, 1, 0>(a);
+        else if (fast == 2) conv16_go_f<KS, S, MODE, MT, TW, NT, 2, 0>(a);
+        else conv16_go_f<KS, S, MODE, MT, TW, NT, 0, 0>(a);
     }
 }
 template <int KS, int S, int MODE>
