@@ -1032,7 +1032,9 @@ __device__ __forceinline__ bf16x8 tr_read8(const unsigned char* a0, const unsign
 // BB: both operands are known to be STORED as bf16 with whole 16-channel chunks (every layer but the network boundaries): the staging is
 // straight-line code.  With the storage types as run-time flags the compiler keeps the staged units in SCRATCH memory and waits for every
 // global load right where it is issued (seen in the ISA: buffer_load, s_waitcnt vmcnt(0), scratch_store) -- no prefetch left at all.
-template <int KS, int S, int MODE, int MT, int NTW, bool DY2 = false, bool BB = false>
+// XK / DYK: the same compile-time storage kinds as XStage16's X16C for x and for dy (1 bf16 with whole chunks, 2 fp32 quads, 3 fp32 single
+// channel, 0 run time); BB = both bf16.  The network-boundary layers are (fp32 x, bf16 dy) first layers and (bf16 x, fp32 dy) output layers.
+template <int KS, int S, int MODE, int MT, int NTW, bool DY2 = false, int XK = 0, int DYK = 0>
 __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const ctl_conv d, const void* __restrict__ x,
                                                                const float* __restrict__ pro_scale, const float* __restrict__ pro_shift,
                                                                const void* __restrict__ dy, const void* __restrict__ dy2,
@@ -1041,7 +1043,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const ctl_conv d, 
                                                                int cin_p, int cout_p) {
     constexpr int TW = 16;
     using G = Geom<KS, S, MT, TW>;
-    using XS = XStage16<KS, S, MODE, MT, TW, BB>;
+    constexpr bool BB = XK == 1 && DYK == 1;
+    using XS = XStage16<KS, S, MODE, MT, TW, XK>;
     constexpr int TAPS = KS * KS;
     constexpr int KB = G::TP / 32;                       // k-blocks per tile: 4 (8x16 tile) or 2 (4x16)
     constexpr int XT_ALLOC = XS::XT_BYTES + 16;
@@ -1062,7 +1065,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const ctl_conv d, 
     const int g = blockIdx.y;
     const int cot0 = blockIdx.z * NTW;
     const int group_n = d.n / (d.groups > 1 ? d.groups : 1);
-    const bool dy16 = BB || (d.dt & CTL_DT_Y16) != 0;
+    const bool dy16 = DYK == 1 || (DYK == 0 && (d.dt & CTL_DT_Y16) != 0);
     const int des = dy16 ? 2 : 4;
 
     f32x4 acc[TAPS][NTW];
@@ -1074,7 +1077,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const ctl_conv d, 
 #pragma unroll
     for (int t = 0; t < NTW; ++t) bsum[t] = 0.f;
 
-    const __amdgpu_buffer_rsrc_t rx = ctl_rsrc(x, (int64_t)d.n * d.hin * d.win * d.cin * ((d.dt & CTL_DT_X16) ? 2 : 4));
+    const __amdgpu_buffer_rsrc_t rx = ctl_rsrc(x, (int64_t)d.n * d.hin * d.win * d.cin * ((XK == 1 || (XK == 0 && (d.dt & CTL_DT_X16))) ? 2 : 4));
     const __amdgpu_buffer_rsrc_t rdy = ctl_rsrc(dy, (int64_t)d.n * d.hout * d.wout * d.cout * des);
     const __amdgpu_buffer_rsrc_t rdy2 = DY2 ? ctl_rsrc(dy2, (int64_t)d.n * d.hout * d.wout * d.cout * 2) : rdy;
     XS xs;
@@ -1113,7 +1116,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const ctl_conv d, 
                 dmask |= (ok && drel[i] != CTL_OOB) ? (1u << i) : 0u;
                 continue;
             }
-            if constexpr (BB) { dv0[i] = ctl_bload4u(rdy, vo, 0); continue; }
+            if constexpr (DYK == 1) { dv0[i] = ctl_bload4u(rdy, vo, 0); continue; }
+            if constexpr (DYK == 2) { dv0[i] = ctl_bload4u(rdy, vo, 0); dv1[i] = dq1[i] ? ctl_bload4u(rdy, vo + 16, 0) : z; continue; }
+            if constexpr (DYK == 3) { dv0[i] = u32x4{__builtin_amdgcn_raw_buffer_load_b32(rdy, vo, 0, 0), 0u, 0u, 0u}; dv1[i] = z; continue; }
             if (dy16) dv0[i] = ctl_bload4u(rdy, vo, 0);
             else if (d.cout >= 4) { dv0[i] = ctl_bload4u(rdy, vo, 0); dv1[i] = dq1[i] ? ctl_bload4u(rdy, vo + 16, 0) : z; }
             else { dv0[i] = u32x4{__builtin_amdgcn_raw_buffer_load_b32(rdy, vo, 0, 0), 0u, 0u, 0u}; dv1[i] = z; }
@@ -1138,10 +1143,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const ctl_conv d, 
             }
             return;
         }
-        if constexpr (BB) {
+        if constexpr (DYK == 1) {
 #pragma unroll
             for (int i = 0; i < ND; ++i) {
                 if (tid + i * 256 < DU) *reinterpret_cast<u32x4*>(dyt + dlds[i]) = dv0[i];
+            }
+            return;
+        }
+        if constexpr (DYK == 2 || DYK == 3) {
+#pragma unroll
+            for (int i = 0; i < ND; ++i) {
+                if (tid + i * 256 < DU)
+                    *reinterpret_cast<u32x4*>(dyt + dlds[i]) = pack_bf16x8(__builtin_bit_cast(f32x4, dv0[i]), __builtin_bit_cast(f32x4, dv1[i]));
             }
             return;
         }
@@ -1288,13 +1301,13 @@ struct wgrad16_call {
     const void *x, *dy, *dy2; const float *pro_scale, *pro_shift, *dy_coef; float *w_partial, *b_partial;
     hipStream_t stream; bool query;
 };
-template <int KS, int S, int MODE, int MT, int NTW, bool DY2, bool BB>
+template <int KS, int S, int MODE, int MT, int NTW, bool DY2, int XK, int DYK>
 static void wgrad16_go_f(wgrad16_call& a) {
     static int occ = 0;
     if (!occ) {
         int n = 0;
         // (of the plain instantiation, also for DY2: the split count is queried at plan time from the descriptor alone and sizes the partials)
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_wgrad_bf16_kernel<KS, S, MODE, MT, NTW, false, false>, 256, 0) != hipSuccess || n < 1) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_wgrad_bf16_kernel<KS, S, MODE, MT, NTW, false, 0, 0>, 256, 0) != hipSuccess || n < 1) {
             (void)hipGetLastError();
             n = 2;
         }
@@ -1309,22 +1322,34 @@ static void wgrad16_go_f(wgrad16_call& a) {
     a.splits = splits;
     if (a.query) return;
     const dim3 grid((unsigned)splits, (unsigned)a.c.g, (unsigned)(a.c.cot / NTW));
-    conv_wgrad_bf16_kernel<KS, S, MODE, MT, NTW, DY2, BB><<<grid, dim3(256), 0, a.stream>>>(*a.d, a.x, a.pro_scale, a.pro_shift, a.dy, a.dy2, a.dy_coef,
+    conv_wgrad_bf16_kernel<KS, S, MODE, MT, NTW, DY2, XK, DYK><<<grid, dim3(256), 0, a.stream>>>(*a.d, a.x, a.pro_scale, a.pro_shift, a.dy, a.dy2, a.dy_coef,
                                                                                         a.w_partial, a.b_partial, a.c.tiles_h, a.c.tiles_w, a.ntiles,
                                                                                         a.cin_p, a.cout_p);
 }
 template <int KS, int S, int MODE, int MT, int NTW>
 static void wgrad16_go(wgrad16_call& a) {
     if constexpr (KS == 3 && S == 1) {      // the two-tensor output gradient: the 3x3 convs of the residual blocks
-        if (a.dy2) {      // (bf16-stored dy / dy2 by contract; x is fp32 in the encoders' first layer)
-            if ((a.d->dt & CTL_DT_X16) && a.d->cin % 16 == 0) wgrad16_go_f<KS, S, MODE, MT, NTW, true, true>(a);
-            else wgrad16_go_f<KS, S, MODE, MT, NTW, true, false>(a);
+        if (a.dy2) {      // (bf16-stored dy / dy2 by contract; x is fp32 with 1 or 4 channels in the encoders' first layer)
+            if ((a.d->dt & CTL_DT_X16) && a.d->cin % 16 == 0) wgrad16_go_f<KS, S, MODE, MT, NTW, true, 1, 1>(a);
+            else if (!(a.d->dt & CTL_DT_X16) && a.d->cin == 1) wgrad16_go_f<KS, S, MODE, MT, NTW, true, 3, 1>(a);
+            else if (!(a.d->dt & CTL_DT_X16) && a.d->cin >= 4) wgrad16_go_f<KS, S, MODE, MT, NTW, true, 2, 1>(a);
+            else wgrad16_go_f<KS, S, MODE, MT, NTW, true, 0, 1>(a);
             return;
         }
     }
     const ctl_conv* d = a.d;
-    if ((d->dt & CTL_DT_X16) && (d->dt & CTL_DT_Y16) && d->cin % 16 == 0 && d->cout % 16 == 0) wgrad16_go_f<KS, S, MODE, MT, NTW, false, true>(a);
-    else wgrad16_go_f<KS, S, MODE, MT, NTW, false, false>(a);
+    const int xk = (d->dt & CTL_DT_X16) ? (d->cin % 16 == 0 ? 1 : 0) : (d->cin == 1 ? 3 : 2);
+    const int dk = (d->dt & CTL_DT_Y16) ? (d->cout % 16 == 0 ? 1 : 0) : (d->cout == 1 ? 3 : 2);
+    if (xk == 1 && dk == 1) { wgrad16_go_f<KS, S, MODE, MT, NTW, false, 1, 1>(a); return; }
+    if constexpr (KS == 3 && S == 1 && MODE == CTL_IN_PLAIN) {      // first layers: fp32 network input, bf16 output gradient
+        if (xk == 2 && dk == 1) { wgrad16_go_f<KS, S, MODE, MT, NTW, false, 2, 1>(a); return; }
+        if (xk == 3 && dk == 1) { wgrad16_go_f<KS, S, MODE, MT, NTW, false, 3, 1>(a); return; }
+    }
+    if constexpr (KS == 1 && MODE == CTL_IN_PLAIN) {                // output layers: bf16 input, fp32 gradient of the network output (4 or 1 channels)
+        if (xk == 1 && dk == 2) { wgrad16_go_f<KS, S, MODE, MT, NTW, false, 1, 2>(a); return; }
+        if (xk == 1 && dk == 3) { wgrad16_go_f<KS, S, MODE, MT, NTW, false, 1, 3>(a); return; }
+    }
+    wgrad16_go_f<KS, S, MODE, MT, NTW, false, 0, 0>(a);
 }
 template <int KS, int S, int MODE>
 static void wgrad16_go_tile(wgrad16_call& a) {
