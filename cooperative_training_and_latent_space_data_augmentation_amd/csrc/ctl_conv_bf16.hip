@@ -14,193 +14,7 @@
 // bf16 once (v_cvt_pk_bf16_f32, round-to-nearest-even) -- the rounding points of the path are: MFMA operands (activations after the
 // prologue, weights) and stored tensors; accumulation, bias, statistics, residual and activation arithmetic stay fp32.
 // With 14x fewer matrix cycles than fp32 these kernels are HBM-bound: what matters is bytes in flight, not VALU.
-#include <stdlib.h>
-
-#include <type_traits>
-
-#include "ctl_conv_common.h"
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2));
-}
-__device__ __forceinline__ u32x4 pack_bf16x8(f32x4 lo, f32x4 hi) {
-    return u32x4{pack_bf16x2(lo.x, lo.y), pack_bf16x2(lo.z, lo.w), pack_bf16x2(hi.x, hi.y), pack_bf16x2(hi.z, hi.w)};
-}
-__device__ __forceinline__ f32x4 unpack_bf16x4(unsigned a, unsigned b) {
-    return f32x4{__builtin_bit_cast(float, a << 16), __builtin_bit_cast(float, a & 0xffff0000u), __builtin_bit_cast(float, b << 16),
-                 __builtin_bit_cast(float, b & 0xffff0000u)};
-}
-__device__ __forceinline__ u32x4 ctl_bload4u(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-    return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
-}
-__device__ __forceinline__ u32x2 ctl_bload2u(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-    return __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
-}
-
-// Staging of one 16-channel chunk of the (virtual) input tile: a unit = 8 channels of a pixel = 16 B of bf16 in LDS.
-// PLANAR: the LDS image is two planes [channels 0-7 | channels 8-15] of [row][col][8 ch] = 16 B per pixel and plane.  A B-operand
-// read (16 lanes = 16 consecutive pixels x 16 B) then covers 256 contiguous bytes = every bank once; in the interleaved [pixel][16 ch]
-// image the same read strides 32 B and hits half the banks twice (2-way conflict on every operand read: measured ~10 of the 17.5 us of
-// the 16->16 layer at 256^2).  The second plane starts 128 B past a multiple of 256 B so that a staging write (8 pixels x 2 planes per
-// 16 lanes) is conflict-free too.  The weight-gradient kernel keeps the interleaved image (its transposed reads want pixel rows).
-// X2 (pro_affine == 2, the BatchNorm-backward prologue): the operand is the VIRTUAL tensor  A[c] * x + B[c] * x2 + C[c]  of two bf16 tensors
-// of one geometry (x = g = dL/da * leaky', x2 = the BatchNorm input u): the `apply` pass of the BatchNorm backward runs here, in the
-// staging of its consumers, and its output tensor never exists.  Rounded to bf16 once, exactly where the stored tensor was rounded.
-// X16C: what is known at compile time about the source -- 1: stored as bf16 (whole 16-channel chunks); 2: stored as fp32 with a multiple of 4
-// channels; 3: fp32 with ONE channel; 0: decided at run time.  Run-time storage flags cost more than branches: with them the compiler keeps
-// v0 / v1 in scratch memory and waits for each global load where it is issued (no prefetch left), so every layer shape of the path has
-// its compile-time kind and 0 only serves shapes outside it.
-template <int KS, int S, int MODE, int MT, int TW, int X16C = 0, bool PLANAR = false, bool X2 = false>
-struct XStage16 {
-    static_assert(!X2 || X16C == 1, "the two-tensor prologue works on bf16-stored tensors");
-    using G = Geom<KS, S, MT, TW>;
-    static constexpr int UNITS = G::IH * G::IW * 2;
-    static constexpr int NU = (UNITS + 255) / 256;
-    static constexpr int PADH = (G::PAD + 1) >> 1;
-    static constexpr int PLANE = ((G::IH * G::IWP * 16 + 255) / 256) * 256 + 128;
-    static constexpr int XT_BYTES = PLANAR ? 2 * PLANE : G::IH * G::IWP * 32;
-    int rel[NU];        // byte offset of the unit's first source element relative to the tile's source origin
-    int rc[NU];         // r | c << 16 (tile-relative virtual coordinates); 0x7fff7fff past the tile
-    int lds[NU];        // LDS byte offset; units past the tile write a dump slot behind the image
-    u32x4 v0[NU], v1[NU];     // source bf16: v0 = 8 channels (X2: v1 = 8 channels of the second tensor); source fp32: v0 = channels 0-3, v1 = 4-7 of the unit
-    unsigned vmask;
-    int pad_h, pad_w;
-    bool all_in, x16;
-
-    __device__ __forceinline__ void init(const ctl_conv& d) {
-        const int tid = threadIdx.x, h = tid & 1;
-        x16 = X16C == 1 || (X16C == 0 && (d.dt & CTL_DT_X16) != 0);
-        const int esz = x16 ? 2 : 4;
-#pragma unroll
-        for (int i = 0; i < NU; ++i) {
-            const int u = tid + i * 256;
-            const int pix = u >> 1;
-            const int r = pix / G::IW;
-            const int c = pix - r * G::IW;
-            const bool in = u < UNITS;
-            const int rr = (MODE == CTL_IN_PLAIN) ? r : (((r - G::PAD) >> 1) + PADH);
-            const int cc = (MODE == CTL_IN_PLAIN) ? c : (((c - G::PAD) >> 1) + PADH);
-            rel[i] = in ? ((rr * d.win + cc) * d.cin + h * 8) * esz : CTL_OOB;
-            rc[i] = in ? (r | (c << 16)) : 0x7fff7fff;
-            lds[i] = in ? (PLANAR ? (h * PLANE + (r * G::IWP + G::ldscol(c)) * 16) : ((r * G::IWP + G::ldscol(c)) * 32 + h * 16)) : XT_BYTES;
-        }
-        vmask = 0;
-        all_in = false;
-        pad_h = pad_w = G::PAD;
-    }
-
-    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rx, const ctl_conv& d, int n, int ho0, int wo0, int g) { load(rx, rx, d, n, ho0, wo0, g); }
-    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rx, __amdgpu_buffer_rsrc_t rx2, const ctl_conv& d, int n, int ho0, int wo0, int g) {
-        const int vh0 = ho0 * S - pad_h, vw0 = wo0 * S - pad_w;
-        const unsigned hv = (MODE == CTL_IN_PLAIN) ? d.hin : 2 * d.hin;
-        const unsigned wv = (MODE == CTL_IN_PLAIN) ? d.win : 2 * d.win;
-        const int oh = (MODE == CTL_IN_PLAIN) ? vh0 : ((ho0 >> 1) - PADH);
-        const int ow = (MODE == CTL_IN_PLAIN) ? vw0 : ((wo0 >> 1) - PADH);
-        const int esz = x16 ? 2 : 4;
-        const int tb = (((n * d.hin + oh) * d.win + ow) * d.cin + g * 16) * esz;
-        all_in = MODE != CTL_IN_ZINS2 && vh0 >= 0 && vw0 >= 0 && vh0 + G::IH <= (int)hv && vw0 + G::IW <= (int)wv &&
-                 g * 16 + 16 <= d.cin;
-        if (all_in) {
-            if (X2) {
-#pragma unroll
-                for (int i = 0; i < NU; ++i) { v0[i] = ctl_bload4u(rx, rel[i], tb); v1[i] = ctl_bload4u(rx2, rel[i], tb); }
-            } else if (X16C == 1 || (X16C == 0 && x16)) {
-#pragma unroll
-                for (int i = 0; i < NU; ++i) v0[i] = ctl_bload4u(rx, rel[i], tb);
-            } else {
-#pragma unroll
-                for (int i = 0; i < NU; ++i) { v0[i] = ctl_bload4u(rx, rel[i], tb); v1[i] = ctl_bload4u(rx, rel[i] + 16, tb); }
-            }
-            return;
-        }
-        const int cb = g * 16 + (threadIdx.x & 1) * 8;          // first channel of this thread's units
-        unsigned m = 0;
-        int vo[NU];
-#pragma unroll
-        for (int i = 0; i < NU; ++i) {
-            const int vh = vh0 + (rc[i] & 0xffff), vw = vw0 + (rc[i] >> 16);
-            bool ok = cb < d.cin && (unsigned)vh < hv && (unsigned)vw < wv;
-            if (MODE == CTL_IN_ZINS2) ok = ok && (((vh | vw) & 1) == 0);
-            vo[i] = ok ? (tb + rel[i]) : CTL_OOB;
-            m |= ok ? (1u << i) : 0u;
-        }
-        vmask = m;
-        const u32x4 z = {0u, 0u, 0u, 0u};
-        if (X2) {
-#pragma unroll
-            for (int i = 0; i < NU; ++i) { v0[i] = ctl_bload4u(rx, vo[i], 0); v1[i] = ctl_bload4u(rx2, vo[i], 0); }
-        } else if (X16C == 1 || (X16C == 0 && x16)) {      // internal tensors: cin is a multiple of 16 (checked on the host)
-#pragma unroll
-            for (int i = 0; i < NU; ++i) v0[i] = ctl_bload4u(rx, vo[i], 0);
-        } else if (X16C == 2 || (X16C == 0 && d.cin >= 4)) {      // fp32 source: quads of 4 channels, the second one may lie past cin (4 or 12 channels)
-            const bool q1 = cb + 4 < d.cin;
-#pragma unroll
-            for (int i = 0; i < NU; ++i) { v0[i] = ctl_bload4u(rx, vo[i], 0); v1[i] = q1 ? ctl_bload4u(rx, vo[i] + 16, 0) : z; }
-        } else {                                    // one input channel
-#pragma unroll
-            for (int i = 0; i < NU; ++i) {
-                v0[i] = u32x4{__builtin_amdgcn_raw_buffer_load_b32(rx, vo[i], 0, 0), 0u, 0u, 0u};
-                v1[i] = z;
-            }
-        }
-    }
-
-    // X2: cf_scale / cf_shift / cf_c hold A / B / C of the block's groups ([group][cin] each)
-    __device__ __forceinline__ void store(unsigned char* __restrict__ xt, const ctl_conv& d, int g, const float* cf_scale,
-                                          const float* cf_shift, int goff, const float* cf_c = nullptr) {
-        if constexpr (X2) {
-            const int cb = g * 16 + (threadIdx.x & 1) * 8;
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(cf_scale + goff + cb), a1 = *reinterpret_cast<const f32x4*>(cf_scale + goff + cb + 4);
-            const f32x4 b0 = *reinterpret_cast<const f32x4*>(cf_shift + goff + cb), b1 = *reinterpret_cast<const f32x4*>(cf_shift + goff + cb + 4);
-            const f32x4 c0 = *reinterpret_cast<const f32x4*>(cf_c + goff + cb), c1 = *reinterpret_cast<const f32x4*>(cf_c + goff + cb + 4);
-            const u32x4 zero = {0u, 0u, 0u, 0u};
-#pragma unroll
-            for (int i = 0; i < NU; ++i) {
-                const f32x4 glo = unpack_bf16x4(v0[i].x, v0[i].y), ghi = unpack_bf16x4(v0[i].z, v0[i].w);
-                const f32x4 ulo = unpack_bf16x4(v1[i].x, v1[i].y), uhi = unpack_bf16x4(v1[i].z, v1[i].w);
-                u32x4 pk = pack_bf16x8(a0 * glo + b0 * ulo + c0, a1 * ghi + b1 * uhi + c1);
-                if (!all_in && !((vmask >> i) & 1u)) pk = zero;      // padding stays zero (C alone would leak into it)
-                *reinterpret_cast<u32x4*>(xt + lds[i]) = pk;
-            }
-            return;
-        }
-        if (!d.pro_affine && (X16C == 1 || (X16C == 0 && x16))) {      // bf16 in, nothing to compute: out-of-range units were loaded as hardware zeros
-#pragma unroll
-            for (int i = 0; i < NU; ++i) *reinterpret_cast<u32x4*>(xt + lds[i]) = v0[i];
-            return;
-        }
-        const int cb = g * 16 + (threadIdx.x & 1) * 8;
-        f32x4 sc0 = {1.f, 1.f, 1.f, 1.f}, sh0 = {0.f, 0.f, 0.f, 0.f}, sc1 = sc0, sh1 = sh0;
-        if (d.pro_affine && cb < d.cin) {
-            if (d.cin >= 4) {
-                sc0 = *reinterpret_cast<const f32x4*>(cf_scale + goff + cb);
-                sh0 = *reinterpret_cast<const f32x4*>(cf_shift + goff + cb);
-                if (cb + 4 < d.cin) {
-                    sc1 = *reinterpret_cast<const f32x4*>(cf_scale + goff + cb + 4);
-                    sh1 = *reinterpret_cast<const f32x4*>(cf_shift + goff + cb + 4);
-                }
-            } else { sc0.x = cf_scale[goff]; sh0.x = cf_shift[goff]; }
-        }
-        const float slope = d.pro_slope;
-        const u32x4 zero = {0u, 0u, 0u, 0u};
-#pragma unroll
-        for (int i = 0; i < NU; ++i) {
-            f32x4 lo, hi;
-            if (X16C == 1 || (X16C == 0 && x16)) { lo = unpack_bf16x4(v0[i].x, v0[i].y); hi = unpack_bf16x4(v0[i].z, v0[i].w); }
-            else { lo = __builtin_bit_cast(f32x4, v0[i]); hi = __builtin_bit_cast(f32x4, v1[i]); }
-            if (d.pro_affine) { lo = ctl_leaky01(lo * sc0 + sh0, slope); hi = ctl_leaky01(hi * sc1 + sh1, slope); }
-            u32x4 pk = pack_bf16x8(lo, hi);
-            // padding / channel-pad lanes hold hardware zeros and must stay zero under the affine prologue
-            if (d.pro_affine && !all_in && !((vmask >> i) & 1u)) pk = zero;
-            *reinterpret_cast<u32x4*>(xt + lds[i]) = pk;
-        }
-    }
-};
+#include "ctl_conv_bf16_common.h"
 
 #define NFRAG_OF(KS) (((KS) * (KS) + 1) / 2)
 
@@ -1011,405 +825,3 @@ int ctl_conv_forward_bf16(const ctl_conv* d, const void* x, const void* x2, cons
     return CTL_OK;
 }
 
-// ------------------------------------------------------------------------------------------------ weight gradient (bf16 operands)
-// dW[tap][ci][co] = sum_pixels x_virtual[pixel*S + tap - pad][ci] * dy[pixel][co]:  D[ci][co] += A[ci][k = pixel] B[pixel][co], K = 32 pixels.
-// Both operands want 8 PIXELS of one channel per lane, i.e. the transpose of the [pixel][16 channel] LDS tiles -- which is what
-// gfx950's ds_read_b64_tr_b16 delivers for free: per 16-lane group it reads 4 rows (pixels) x 16 columns (channels) of 16-bit elements and
-// hands lane i column i.  Lane 4q'+p' of a group supplies the address of row q', columns 4p'..4p'+3; every lane supplies its own row
-// address, so a tap shift is just another pixel address.  k-block kb of a tile = tile rows 2kb, 2kb+1 (TW = 16): lane group gk takes row
-// 2kb + (gk >> 1), columns 8(gk & 1) .. +7 (two transposed reads of 4 pixels each).  Wave w owns k-block w; the four waves are summed
-// through LDS at the end exactly like the fp32 kernel, same partial layout, same deterministic split reduction.
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ bf16x8 tr_read8(const unsigned char* a0, const unsigned char* a1) {
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a0));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a1));
-    typedef short s16x8 __attribute__((ext_vector_type(8)));
-    return __builtin_bit_cast(bf16x8, s16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w});
-}
-
-// DY2: the output gradient is the virtual BatchNorm-backward result  A * dy + B * dy2 + C  (coefficients [group][3][cout] as the
-// finalize writes them; dy = g, dy2 = the BatchNorm input): the `apply` pass runs in this staging (see XStage16 X2)
-// BB: both operands are known to be STORED as bf16 with whole 16-channel chunks (every layer but the network boundaries): the staging is
-// straight-line code.  With the storage types as run-time flags the compiler keeps the staged units in SCRATCH memory and waits for every
-// global load right where it is issued (seen in the ISA: buffer_load, s_waitcnt vmcnt(0), scratch_store) -- no prefetch left at all.
-// XK / DYK: the same compile-time storage kinds as XStage16's X16C for x and for dy (1 bf16 with whole chunks, 2 fp32 quads, 3 fp32 single
-// channel, 0 run time); BB = both bf16.  The network-boundary layers are (fp32 x, bf16 dy) first layers and (bf16 x, fp32 dy) output layers.
-template <int KS, int S, int MODE, int MT, int NTW, bool DY2 = false, int XK = 0, int DYK = 0>
-__global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const ctl_conv d, const void* __restrict__ x,
-                                                               const float* __restrict__ pro_scale, const float* __restrict__ pro_shift,
-                                                               const void* __restrict__ dy, const void* __restrict__ dy2,
-                                                               const float* __restrict__ dy_coef, float* __restrict__ w_partial,
-                                                               float* __restrict__ b_partial, int tiles_h, int tiles_w, int ntiles,
-                                                               int cin_p, int cout_p) {
-    constexpr int TW = 16;
-    using G = Geom<KS, S, MT, TW>;
-    constexpr bool BB = XK == 1 && DYK == 1;
-    using XS = XStage16<KS, S, MODE, MT, TW, XK>;
-    constexpr int TAPS = KS * KS;
-    constexpr int KB = G::TP / 32;                       // k-blocks per tile: 4 (8x16 tile) or 2 (4x16)
-    constexpr int XT_ALLOC = XS::XT_BYTES + 16;
-    constexpr int DYT_BYTES = NTW * G::TP * 32;
-    constexpr int RED_BYTES = 4 * NTW * 256 * 4;
-    constexpr int MAIN_BYTES = (XT_ALLOC + DYT_BYTES > RED_BYTES) ? (XT_ALLOC + DYT_BYTES) : RED_BYTES;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[MAIN_BYTES + (DY2 ? 5 : 2) * CTL_PRO_MAX * 4];
-    unsigned char* xt = smem;
-    unsigned char* dyt = smem + XT_ALLOC;
-    float* cf_scale = reinterpret_cast<float*>(smem + MAIN_BYTES);
-    float* cf_shift = cf_scale + CTL_PRO_MAX;
-    float* cd = cf_shift + CTL_PRO_MAX;                  // DY2: A | B | C, [group][cout] each
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int p = lane & 15, q = lane >> 4;
-    const int g = blockIdx.y;
-    const int cot0 = blockIdx.z * NTW;
-    const int group_n = d.n / (d.groups > 1 ? d.groups : 1);
-    const bool dy16 = DYK == 1 || (DYK == 0 && (d.dt & CTL_DT_Y16) != 0);
-    const int des = dy16 ? 2 : 4;
-
-    f32x4 acc[TAPS][NTW];
-#pragma unroll
-    for (int a = 0; a < TAPS; ++a)
-#pragma unroll
-        for (int t = 0; t < NTW; ++t) acc[a][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float bsum[NTW];
-#pragma unroll
-    for (int t = 0; t < NTW; ++t) bsum[t] = 0.f;
-
-    const __amdgpu_buffer_rsrc_t rx = ctl_rsrc(x, (int64_t)d.n * d.hin * d.win * d.cin * ((XK == 1 || (XK == 0 && (d.dt & CTL_DT_X16))) ? 2 : 4));
-    const __amdgpu_buffer_rsrc_t rdy = ctl_rsrc(dy, (int64_t)d.n * d.hout * d.wout * d.cout * des);
-    const __amdgpu_buffer_rsrc_t rdy2 = DY2 ? ctl_rsrc(dy2, (int64_t)d.n * d.hout * d.wout * d.cout * 2) : rdy;
-    XS xs;
-    xs.init(d);
-    // dy tile [cout tile t][pixel][16 ch] bf16: units of 8 channels
-    constexpr int DU = G::TP * NTW * 2, ND = (DU + 255) / 256;
-    u32x4 dv0[ND], dv1[ND];
-    int drel[ND], drc[ND], dlds[ND];
-    bool dq1[ND];
-    unsigned dmask = 0;                                  // DY2: units of the tile in flight that lie inside the image
-    int dco = 0;                                         // DY2: first channel of this thread's units (the same for all of them: 256 % (2 NTW) == 0)
-#pragma unroll
-    for (int i = 0; i < ND; ++i) {
-        const int u = tid + i * 256;
-        const int pix = u / (NTW * 2), rest = u - pix * (NTW * 2);
-        const int t = rest >> 1, h = rest & 1;
-        const int pr = pix / TW, pc = pix % TW;
-        const int co = (cot0 + t) * 16 + h * 8;
-        const bool in = u < DU && co < d.cout;
-        drc[i] = in ? (pr | (pc << 16)) : 0x7fff7fff;
-        drel[i] = in ? ((pr * d.wout + pc) * d.cout + co) * des : CTL_OOB;
-        dlds[i] = (u < DU) ? ((t * G::TP + pix) * 32 + h * 16) : DYT_BYTES - 16;      // (units past the tile cannot exist: DU is a multiple of 256 or ND covers it)
-        dq1[i] = co + 4 < d.cout;
-        if (i == 0) dco = co < d.cout ? co : 0;
-    }
-    auto dyload = [&](int n, int ho0, int wo0) {
-        const int tb = ((n * d.hout + ho0) * d.wout + wo0) * d.cout * des;
-        const u32x4 z = {0u, 0u, 0u, 0u};
-        dmask = 0;
-#pragma unroll
-        for (int i = 0; i < ND; ++i) {
-            const bool ok = (unsigned)(ho0 + (drc[i] & 0xffff)) < (unsigned)d.hout && (unsigned)(wo0 + (drc[i] >> 16)) < (unsigned)d.wout;
-            const int vo = ok ? (tb + drel[i]) : CTL_OOB;
-            if constexpr (DY2) {
-                dv0[i] = ctl_bload4u(rdy, vo, 0); dv1[i] = ctl_bload4u(rdy2, vo, 0);
-                dmask |= (ok && drel[i] != CTL_OOB) ? (1u << i) : 0u;
-                continue;
-            }
-            if constexpr (DYK == 1) { dv0[i] = ctl_bload4u(rdy, vo, 0); continue; }
-            if constexpr (DYK == 2) { dv0[i] = ctl_bload4u(rdy, vo, 0); dv1[i] = dq1[i] ? ctl_bload4u(rdy, vo + 16, 0) : z; continue; }
-            if constexpr (DYK == 3) { dv0[i] = u32x4{__builtin_amdgcn_raw_buffer_load_b32(rdy, vo, 0, 0), 0u, 0u, 0u}; dv1[i] = z; continue; }
-            if (dy16) dv0[i] = ctl_bload4u(rdy, vo, 0);
-            else if (d.cout >= 4) { dv0[i] = ctl_bload4u(rdy, vo, 0); dv1[i] = dq1[i] ? ctl_bload4u(rdy, vo + 16, 0) : z; }
-            else { dv0[i] = u32x4{__builtin_amdgcn_raw_buffer_load_b32(rdy, vo, 0, 0), 0u, 0u, 0u}; dv1[i] = z; }
-        }
-    };
-    auto dystore = [&](int goff) {
-        if constexpr (DY2) {
-            const float* cc = cd + goff + dco;
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(cc), a1 = *reinterpret_cast<const f32x4*>(cc + 4);
-            const f32x4 b0 = *reinterpret_cast<const f32x4*>(cc + CTL_PRO_MAX), b1 = *reinterpret_cast<const f32x4*>(cc + CTL_PRO_MAX + 4);
-            const f32x4 c0 = *reinterpret_cast<const f32x4*>(cc + 2 * CTL_PRO_MAX), c1 = *reinterpret_cast<const f32x4*>(cc + 2 * CTL_PRO_MAX + 4);
-            const u32x4 zero = {0u, 0u, 0u, 0u};
-#pragma unroll
-            for (int i = 0; i < ND; ++i) {
-                if (tid + i * 256 < DU) {
-                    const f32x4 glo = unpack_bf16x4(dv0[i].x, dv0[i].y), ghi = unpack_bf16x4(dv0[i].z, dv0[i].w);
-                    const f32x4 ulo = unpack_bf16x4(dv1[i].x, dv1[i].y), uhi = unpack_bf16x4(dv1[i].z, dv1[i].w);
-                    u32x4 pk = pack_bf16x8(a0 * glo + b0 * ulo + c0, a1 * ghi + b1 * uhi + c1);
-                    if (!((dmask >> i) & 1u)) pk = zero;          // pixels past the image contribute nothing (C alone would)
-                    *reinterpret_cast<u32x4*>(dyt + dlds[i]) = pk;
-                }
-            }
-            return;
-        }
-        if constexpr (DYK == 1) {
-#pragma unroll
-            for (int i = 0; i < ND; ++i) {
-                if (tid + i * 256 < DU) *reinterpret_cast<u32x4*>(dyt + dlds[i]) = dv0[i];
-            }
-            return;
-        }
-        if constexpr (DYK == 2 || DYK == 3) {
-#pragma unroll
-            for (int i = 0; i < ND; ++i) {
-                if (tid + i * 256 < DU)
-                    *reinterpret_cast<u32x4*>(dyt + dlds[i]) = pack_bf16x8(__builtin_bit_cast(f32x4, dv0[i]), __builtin_bit_cast(f32x4, dv1[i]));
-            }
-            return;
-        }
-#pragma unroll
-        for (int i = 0; i < ND; ++i) {
-            if (tid + i * 256 < DU)
-                *reinterpret_cast<u32x4*>(dyt + dlds[i]) =
-                    dy16 ? dv0[i] : pack_bf16x8(__builtin_bit_cast(f32x4, dv0[i]), __builtin_bit_cast(f32x4, dv1[i]));
-        }
-    };
-    // transposed-read addresses of this lane: block row q' = (lane & 15) >> 2 (pixel), 8-byte column chunk p' = lane & 3
-    const int qp = (lane & 15) >> 2, pp = lane & 3;
-    const int krow = (q >> 1), kcol0 = 8 * (q & 1);     // tile row (within the k-block's two rows) and first column of this lane group
-    TileWalk cur;
-    cur.init(blockIdx.x, gridDim.x, tiles_h, tiles_w);
-    if ((int)blockIdx.x < ntiles) {
-        xs.load(rx, d, cur.n, cur.th * G::TH, cur.tw * TW, g);
-        dyload(cur.n, cur.th * G::TH, cur.tw * TW);
-    }
-    if (d.pro_affine || DY2) {
-        if (d.pro_affine)
-            for (int i = tid; i < (d.groups > 1 ? d.groups : 1) * d.cin; i += 256) { cf_scale[i] = pro_scale[i]; cf_shift[i] = pro_shift[i]; }
-        if constexpr (DY2) {
-            for (int i = tid; i < (d.groups > 1 ? d.groups : 1) * d.cout; i += 256) {
-                const int gi = i / d.cout, ch = i - gi * d.cout;
-                cd[i] = dy_coef[(gi * 3 + 0) * d.cout + ch]; cd[CTL_PRO_MAX + i] = dy_coef[(gi * 3 + 1) * d.cout + ch];
-                cd[2 * CTL_PRO_MAX + i] = dy_coef[(gi * 3 + 2) * d.cout + ch];
-            }
-        }
-        __syncthreads();
-    }
-    if ((int)blockIdx.x < ntiles) {
-        xs.store(xt, d, g, cf_scale, cf_shift, (cur.n / group_n) * d.cin);
-        dystore((cur.n / group_n) * d.cout);
-    }
-    __syncthreads();
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const bool has_next = tile + (int)gridDim.x < ntiles;
-        if (has_next) {
-            cur.next();
-            xs.load(rx, d, cur.n, cur.th * G::TH, cur.tw * TW, g);
-            dyload(cur.n, cur.th * G::TH, cur.tw * TW);
-        }
-        for (int kb = wave; kb < KB; kb += 4) {          // (4x16 tiles: two k-blocks, waves 2 and 3 only stage; 16x16 tiles: two k-blocks per wave)
-            const int tr = kb * 2 + krow;                // tile row of this lane group's 8 pixels
-            bf16x8 bf[NTW];
-#pragma unroll
-            for (int t = 0; t < NTW; ++t) {
-                const unsigned char* b0 = dyt + ((t * G::TP + tr * TW + kcol0 + qp) * 32) + pp * 8;
-                bf[t] = tr_read8(b0, b0 + 4 * 32);
-                float s = 0.f;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) s += (float)bf[t][j];
-                bsum[t] += s;
-            }
-            // the A operand of tap+1 is requested before the MFMAs of tap; the empty asm pins that order (the scheduler otherwise sinks
-            // every transposed read to its use: read, wait, MFMA, nine times per tile -- see the forward kernel)
-            auto a_operand = [&](int tap) -> bf16x8 {
-                const int kh = tap / KS, kw = tap % KS;
-                const int c0 = G::ldscol((kcol0 + qp) * S + kw);          // consecutive output columns are consecutive LDS columns (stride 2: de-interleaved)
-                const unsigned char* a0 = xt + (((tr * S + kh) * G::IWP + c0) * 32) + pp * 8;
-                return tr_read8(a0, a0 + 4 * 32);
-            };
-            bf16x8 af[2];
-            af[0] = a_operand(0);
-#pragma unroll
-            for (int tap = 0; tap < TAPS; ++tap) {
-                if (tap + 1 < TAPS) af[(tap + 1) & 1] = a_operand(tap + 1);
-                asm volatile("" : "+v"(af[tap & 1]) : : "memory");
-#pragma unroll
-                for (int t = 0; t < NTW; ++t) acc[tap][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tap & 1], bf[t], acc[tap][t], 0, 0, 0);
-            }
-        }
-        ctl_barrier_lds_reads_done();
-        if (has_next) {
-            xs.store(xt, d, g, cf_scale, cf_shift, (cur.n / group_n) * d.cin);
-            dystore((cur.n / group_n) * d.cout);
-        }
-        ctl_barrier_lds_writes_done();
-    }
-    __syncthreads();
-
-    // ---------------- sum the four waves through LDS and write this split's partial (layout of the fp32 kernel)
-    float* red = reinterpret_cast<float*>(smem);
-    constexpr int TAP_FLOATS = 4 * NTW * 256;
-    constexpr int TPR = (MAIN_BYTES / 4 / TAP_FLOATS) < TAPS ? (MAIN_BYTES / 4 / TAP_FLOATS) : TAPS;
-    static_assert(TPR >= 1, "reduction scratch");
-    const int64_t split_base = (int64_t)blockIdx.x * TAPS * cin_p * cout_p;
-#pragma unroll
-    for (int tap0 = 0; tap0 < TAPS; tap0 += TPR) {
-        if (tap0 > 0) ctl_barrier_lds_reads_done();
-#pragma unroll
-        for (int tp = 0; tp < TPR; ++tp) {
-            const int tap = tap0 + tp;
-            if (tap < TAPS) {
-#pragma unroll
-                for (int t = 0; t < NTW; ++t) {
-                    float* r0 = red + tp * TAP_FLOATS + ((wave * NTW + t) * 4) * 64 + lane;
-                    r0[0] = acc[tap][t].x; r0[64] = acc[tap][t].y; r0[128] = acc[tap][t].z; r0[192] = acc[tap][t].w;
-                }
-            }
-        }
-        ctl_barrier_lds_writes_done();
-#pragma unroll
-        for (int tp = 0; tp < TPR; ++tp) {
-            const int tap = tap0 + tp;
-            if (tap < TAPS) {
-#pragma unroll
-                for (int e0 = 0; e0 < NTW * 256; e0 += 256) {
-                    const int e = e0 + tid;
-                    const int t = e >> 8, r = (e >> 6) & 3, l = e & 63;
-                    float v = 0.f;
-#pragma unroll
-                    for (int w = 0; w < 4; ++w) v += red[tp * TAP_FLOATS + ((w * NTW + t) * 4 + r) * 64 + l];
-                    const int co = (cot0 + t) * 16 + (l & 15);
-                    const int ci = g * 16 + (l >> 4) * 4 + r;
-                    if (co < cout_p) w_partial[split_base + ((int64_t)tap * cin_p + ci) * cout_p + co] = v;
-                }
-            }
-        }
-    }
-    if (g == 0 && b_partial != nullptr) {
-        ctl_barrier_lds_reads_done();
-#pragma unroll
-        for (int t = 0; t < NTW; ++t) {
-            float v = bsum[t];
-            v += __shfl_xor(v, 16);
-            v += __shfl_xor(v, 32);
-            if (q == 0) red[(wave * NTW + t) * 16 + p] = v;
-        }
-        ctl_barrier_lds_writes_done();
-        if (tid < NTW * 16) {
-            float v = 0.f;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) v += red[w * NTW * 16 + tid];
-            const int co = cot0 * 16 + tid;
-            if (co < cout_p) b_partial[(int64_t)blockIdx.x * cout_p + co] = v;
-        }
-    }
-}
-
-struct wgrad16_call {
-    const ctl_conv* d; ctl_conv_cfg c; int ntw, splits, ntiles, cin_p, cout_p;
-    const void *x, *dy, *dy2; const float *pro_scale, *pro_shift, *dy_coef; float *w_partial, *b_partial;
-    hipStream_t stream; bool query;
-};
-template <int KS, int S, int MODE, int MT, int NTW, bool DY2, int XK, int DYK>
-static void wgrad16_go_f(wgrad16_call& a) {
-    static int occ = 0;
-    if (!occ) {
-        int n = 0;
-        // (of the plain instantiation, also for DY2: the split count is queried at plan time from the descriptor alone and sizes the partials)
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_wgrad_bf16_kernel<KS, S, MODE, MT, NTW, false, 0, 0>, 256, 0) != hipSuccess || n < 1) {
-            (void)hipGetLastError();
-            n = 2;
-        }
-        occ = n;
-    }
-    const int par = a.c.g * (a.c.cot / NTW);
-    static const int cap = ctl_tune_int("CTL16_WGRAD_SPLITS", 1024);      // tuning hook (measured: 512 -> 768/1024 splits = 28.7 -> 24.5 us on the 16->16 3x3 layer at 256^2)
-    int splits = (256 * (occ < 4 ? occ : 4)) / par;
-    if (splits > cap) splits = cap;
-    if (splits > a.ntiles) splits = a.ntiles;
-    if (splits < 1) splits = 1;
-    a.splits = splits;
-    if (a.query) return;
-    const dim3 grid((unsigned)splits, (unsigned)a.c.g, (unsigned)(a.c.cot / NTW));
-    conv_wgrad_bf16_kernel<KS, S, MODE, MT, NTW, DY2, XK, DYK><<<grid, dim3(256), 0, a.stream>>>(*a.d, a.x, a.pro_scale, a.pro_shift, a.dy, a.dy2, a.dy_coef,
-                                                                                        a.w_partial, a.b_partial, a.c.tiles_h, a.c.tiles_w, a.ntiles,
-                                                                                        a.cin_p, a.cout_p);
-}
-template <int KS, int S, int MODE, int MT, int NTW>
-static void wgrad16_go(wgrad16_call& a) {
-    if constexpr (KS == 3 && S == 1) {      // the two-tensor output gradient: the 3x3 convs of the residual blocks
-        if (a.dy2) {      // (bf16-stored dy / dy2 by contract; x is fp32 with 1 or 4 channels in the encoders' first layer)
-            if ((a.d->dt & CTL_DT_X16) && a.d->cin % 16 == 0) wgrad16_go_f<KS, S, MODE, MT, NTW, true, 1, 1>(a);
-            else if (!(a.d->dt & CTL_DT_X16) && a.d->cin == 1) wgrad16_go_f<KS, S, MODE, MT, NTW, true, 3, 1>(a);
-            else if (!(a.d->dt & CTL_DT_X16) && a.d->cin >= 4) wgrad16_go_f<KS, S, MODE, MT, NTW, true, 2, 1>(a);
-            else wgrad16_go_f<KS, S, MODE, MT, NTW, true, 0, 1>(a);
-            return;
-        }
-    }
-    const ctl_conv* d = a.d;
-    const int xk = (d->dt & CTL_DT_X16) ? (d->cin % 16 == 0 ? 1 : 0) : (d->cin == 1 ? 3 : 2);
-    const int dk = (d->dt & CTL_DT_Y16) ? (d->cout % 16 == 0 ? 1 : 0) : (d->cout == 1 ? 3 : 2);
-    if (xk == 1 && dk == 1) { wgrad16_go_f<KS, S, MODE, MT, NTW, false, 1, 1>(a); return; }
-    if constexpr (KS == 3 && S == 1 && MODE == CTL_IN_PLAIN) {      // first layers: fp32 network input, bf16 output gradient
-        if (xk == 2 && dk == 1) { wgrad16_go_f<KS, S, MODE, MT, NTW, false, 2, 1>(a); return; }
-        if (xk == 3 && dk == 1) { wgrad16_go_f<KS, S, MODE, MT, NTW, false, 3, 1>(a); return; }
-    }
-    if constexpr (KS == 1 && MODE == CTL_IN_PLAIN) {                // output layers: bf16 input, fp32 gradient of the network output (4 or 1 channels)
-        if (xk == 1 && dk == 2) { wgrad16_go_f<KS, S, MODE, MT, NTW, false, 1, 2>(a); return; }
-        if (xk == 1 && dk == 3) { wgrad16_go_f<KS, S, MODE, MT, NTW, false, 1, 3>(a); return; }
-    }
-    wgrad16_go_f<KS, S, MODE, MT, NTW, false, 0, 0>(a);
-}
-template <int KS, int S, int MODE>
-static void wgrad16_go_tile(wgrad16_call& a) {
-    if constexpr (S == 1 && (KS == 3 || KS == 1)) {
-        if (a.c.mt == 4) { if (a.ntw == 2) wgrad16_go<KS, S, MODE, 4, 2>(a); else wgrad16_go<KS, S, MODE, 4, 1>(a); return; }
-    }
-    if (a.c.mt == 2) { if (a.ntw == 2) wgrad16_go<KS, S, MODE, 2, 2>(a); else wgrad16_go<KS, S, MODE, 2, 1>(a); }
-    else { if (a.ntw == 2) wgrad16_go<KS, S, MODE, 1, 2>(a); else wgrad16_go<KS, S, MODE, 1, 1>(a); }
-}
-static int wgrad16_dispatch(wgrad16_call& a) {
-    const int k = a.d->ks, s = a.d->stride, m = a.d->in_mode == CTL_IN_C4 ? CTL_IN_PLAIN : a.d->in_mode;
-    if (k == 3 && s == 1 && m == CTL_IN_PLAIN) wgrad16_go_tile<3, 1, CTL_IN_PLAIN>(a);
-    else if (k == 3 && s == 1 && m == CTL_IN_UP2) wgrad16_go_tile<3, 1, CTL_IN_UP2>(a);
-    else if (k == 3 && s == 2) wgrad16_go_tile<3, 2, CTL_IN_PLAIN>(a);
-    else if (k == 1 && m == CTL_IN_PLAIN) wgrad16_go_tile<1, 1, CTL_IN_PLAIN>(a);
-    else if (k == 1 && m == CTL_IN_UP2) wgrad16_go_tile<1, 1, CTL_IN_UP2>(a);
-    else if (k == 2 && s == 2) wgrad16_go_tile<2, 2, CTL_IN_PLAIN>(a);
-    else CTL_FAIL(CTL_EUNSUPPORTED, "conv_wgrad(bf16): no kernel for this combination");
-    return CTL_OK;
-}
-static int wgrad16_pick(const ctl_conv* d, wgrad16_call* a) {
-    CTL_REQUIRE(d->nsub == 1 && d->in_mode != CTL_IN_ZINS2, "wgrad(bf16): nsub must be 1, no zero-insert input");
-    CTL_REQUIRE(!(d->dt & CTL_DT_X16) || d->cin % 16 == 0, "wgrad(bf16): bf16-stored x needs cin %% 16 == 0");
-    CTL_REQUIRE(!(d->dt & CTL_DT_Y16) || d->cout % 16 == 0, "wgrad(bf16): bf16-stored dy needs cout %% 16 == 0");
-    a->d = d;
-    int rc = ctl_conv_pick_cfg(d, &a->c, 1);
-    if (rc != CTL_OK) return rc;
-    // With 16-cycle bf16 MFMAs a tile's matrix work (9 per wave for a 3x3 kernel) is far shorter than the load latency of the next tile,
-    // which the single-buffered loop then exposes every time: the large layers take 16x16-pixel tiles (twice the bytes in flight per
-    // block, half the barriers per byte).  Measured 16->16 at 256^2: 41.9 us with 8x16 tiles.
-    static const int big_ok = ctl_tune_int("CTL16_WGRAD_MT4", 1);
-    if (big_ok && d->stride == 1 && d->ks == 3 && d->hout >= 64 && d->wout >= 16) {      // (1x1: 8x16 tiles measured faster)
-        a->c.mt = 4; a->c.th = 16;
-        a->c.tiles_h = ctl_cdiv(d->hout, 16);
-    }
-    a->ntw = (a->c.cot >= 2 && a->c.cot % 2 == 0) ? 2 : 1;
-    a->ntiles = d->n * a->c.tiles_h * a->c.tiles_w;
-    a->cin_p = a->c.g * 16;
-    a->cout_p = a->c.cot * 16;
-    a->query = true;
-    rc = wgrad16_dispatch(*a);
-    a->query = false;
-    return rc;
-}
-int ctl_wgrad_bf16_splits(const ctl_conv* d) {
-    wgrad16_call a = {};
-    return wgrad16_pick(d, &a) == CTL_OK ? a.splits : -1;
-}
-int ctl_conv_wgrad_bf16(const ctl_conv* d, const void* x, const float* pro_scale, const float* pro_shift, const void* dy, const void* dy2,
-                        const float* dy_coef, float* w_partial, float* b_partial, ctl_stream stream) {
-    CTL_REQUIRE(!dy2 || (dy_coef && d->ks == 3 && d->stride == 1 && (d->dt & CTL_DT_Y16) && d->cout % 16 == 0 &&
-                         (d->groups > 1 ? d->groups : 1) * d->cout <= CTL_PRO_MAX),
-                "wgrad(bf16): the two-tensor output gradient needs coefficients, a 3x3 stride-1 conv, bf16-stored dy / dy2 with cout %% 16 == 0 and groups * cout <= %d", CTL_PRO_MAX);
-    wgrad16_call a = {};
-    int rc = wgrad16_pick(d, &a);
-    if (rc != CTL_OK) return rc;
-    a.x = x; a.dy = dy; a.dy2 = dy2; a.dy_coef = dy_coef; a.pro_scale = pro_scale; a.pro_shift = pro_shift; a.w_partial = w_partial; a.b_partial = b_partial;
-    a.stream = (hipStream_t)stream;
-    rc = wgrad16_dispatch(a);
-    if (rc != CTL_OK) return rc;
-    CTL_LAUNCH_CHECK("conv_wgrad(bf16)");
-    return CTL_OK;
-}
