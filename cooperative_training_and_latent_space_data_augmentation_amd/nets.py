@@ -1025,9 +1025,10 @@ class CtlNet(nn.Module):
             assert d_act.b16 == u.b16 == pb.b16 and ci.ks == 3 and tail_next is None
             if need_dx and d_x is None:
                 d_x = A.tensor(x.n, x.h, x.w, x.c)
-            # who cannot stage the apply: a data gradient into a narrow (or, in the bf16 family, fp32) tensor -- then ONE apply launch writes
-            # dU for both consumers (still no reduction pass)
-            stored = need_dx and not (d_x.b16 == pb.b16 and x.c % 16 == 0)
+            # who cannot stage the apply: in the bf16 family a data gradient into an fp32 or narrow tensor (the staged form writes whole bf16
+            # tiles) -- then ONE apply launch writes dU for both consumers (still no reduction pass); the fp32 family's generic epilogue
+            # takes any output width (the shape encoder's 4-channel input gradient)
+            stored = need_dx and not (d_x.b16 == pb.b16 and (x.c % 16 == 0 or not pb.b16))
             du = A.tensor(u.n, u.h, u.w, u.c) if stored else None
             coef = pb.bn_backward_from_stats(d_act, u, bn, co, pre[0], pre[1], dx=du, affine_grad=need_w and affine)
             if not stored:
