@@ -9,7 +9,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libctl_hip.so")
-ABI_VERSION = 7                      # CTL_ABI_VERSION of include/ctl_hip.h this binding was written against
+ABI_VERSION = 8                      # CTL_ABI_VERSION of include/ctl_hip.h this binding was written against
 RED_BLOCKS = 512                     # CTL_RED_BLOCKS of ctl_hip.h; checked against the library's compiled value (ctl_red_blocks) at load
 
 # enums of ctl_hip.h
@@ -62,7 +62,7 @@ class _Lib:
             "ctl_conv_stats_floats": [p], "ctl_conv_stats_blocks": [p],
             "ctl_wgrad_splits": [p], "ctl_wgrad_partial_floats": [p], "ctl_wgrad_bias_partial_floats": [p],
             "ctl_pack_weights": [p, p, i32, i32, i32, i64, i64, i64, i64, i32, p],
-            "ctl_conv_forward": [p] * 12, "ctl_conv_forward_ex": [p] * 15, "ctl_conv_pool_ok": [p],
+            "ctl_conv_forward": [p] * 12, "ctl_conv_forward_ex": [p] * 16, "ctl_conv_pool_ok": [p],
             "ctl_conv_wgrad": [p] * 8, "ctl_conv_wgrad_ex": [p] * 10,
             "ctl_wgrad_reduce": [p, p, p, p, i64, i64, i64, i64, p, i32, p],
             "ctl_confusion_hist": [p, p, i64, i32, p, p],

@@ -137,7 +137,7 @@ int ctl_conv_grid_x(int ntiles, int other, int occ);      // persistent grid: th
 // bf16 kernel family (ctl_conv_bf16.hip), reached through the public entry points when ctl_conv.dt has CTL_DT_BF16
 int ctl_conv_forward_bf16(const ctl_conv* d, const void* x, const void* x2, const void* wpack, const float* bias, const float* pro_scale,
                           const float* pro_shift, const void* res, const float* res_scale, const float* res_shift, const void* res2, void* y,
-                          float* stats_partial, void* pool, ctl_stream stream);
+                          float* stats_partial, void* pool, void* xout, ctl_stream stream);
 int ctl_conv_bf16_stats_blocks(const ctl_conv* d);
 int ctl_wgrad_bf16_splits(const ctl_conv* d);
 int ctl_conv_wgrad_bf16(const ctl_conv* d, const void* x, const float* pro_scale, const float* pro_shift, const void* dy, const void* dy2,

@@ -46,6 +46,7 @@ struct XStage {
     unsigned vmask;     // bit i: unit i of the tile held in v[] lies inside the image (gets the prologue)
     int pad_h, pad_w;   // top / left padding of this block's problem (G::PAD except for the phase problems of the 2x2 kernels)
     bool all_in;        // wave-uniform: every unit of the tile held in v[] is inside the image and the channel range
+    int tb_last;        // X2: byte offset of the tile held in v[] (for the side output of the virtual tensor, see store)
 
     __device__ __forceinline__ void init(const ctl_conv& d) {
         const int tid = threadIdx.x, cq = tid & 3;
@@ -78,6 +79,7 @@ struct XStage {
         const int oh = CTL_MODE_IS_PLAIN(MODE) ? vh0 : ((ho0 >> 1) - PADH);
         const int ow = CTL_MODE_IS_PLAIN(MODE) ? vw0 : ((wo0 >> 1) - PADH);
         const int tb = (((n * d.hin + oh) * d.win + ow) * d.cin + g * 16) * 4;      // uniform; may be negative at the border
+        tb_last = tb;
         // interior tile (most of them): every unit is in range -> the tile origin goes into the scalar offset of the buffer
         // loads and the per-thread offsets are the loop-invariant rel[]: no VALU at all (fp32 MFMA shares the VALU issue
         // port on this part, so every VALU instruction in the loop is time taken from the matrix work)
@@ -123,22 +125,33 @@ struct XStage {
     // `goff` = BatchNorm group of the tile held in v[] times cin (row of the [groups][cin] prologue coefficients).  The
     // coefficients are read from the block's LDS copy: a global load here sits between the two barriers of a step with nothing
     // to hide its latency behind
-    // X2: pro_scale / pro_shift / pro_c are the LDS copies of A / B / C ([group][cin] each)
+    // X2: pro_scale / pro_shift / pro_c are the LDS copies of A / B / C ([group][cin] each).  xout (a buffer resource over a tensor of x's
+    // geometry, `xout_on` on the blocks of the first cout group only): the units of the tile's INTERIOR -- the input pixels no other tile
+    // owns -- are also written to global memory: the virtual tensor materialises as a by-product of this conv's staging, for the weight-
+    // gradient kernel of the same layer (which would otherwise evaluate it again in each of its cin-chunk blocks).
     __device__ __forceinline__ void store(float* __restrict__ xt, const ctl_conv& d, int g,
                                           const float* pro_scale, const float* pro_shift, int goff, const float* pro_c = nullptr) {
+        store(xt, d, g, pro_scale, pro_shift, goff, pro_c, ctl_rsrc((const void*)nullptr, 0), false);
+    }
+    __device__ __forceinline__ void store(float* __restrict__ xt, const ctl_conv& d, int g,
+                                          const float* pro_scale, const float* pro_shift, int goff, const float* pro_c,
+                                          __amdgpu_buffer_rsrc_t rxout, bool xout_on) {
         if constexpr (X2) {
             const int cb = g * 16 + (threadIdx.x & 3) * 4;
             const f32x4 ca = *reinterpret_cast<const f32x4*>(pro_scale + goff + cb), cbb = *reinterpret_cast<const f32x4*>(pro_shift + goff + cb);
             const f32x4 cc = *reinterpret_cast<const f32x4*>(pro_c + goff + cb);
-            if (all_in) {
-#pragma unroll
-                for (int i = 0; i < NU; ++i) *reinterpret_cast<f32x4*>(xt + lds[i]) = ca * v[i] + cbb * v2[i] + cc;
-                return;
-            }
             const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int i = 0; i < NU; ++i)      // padding stays zero (C alone would leak into it)
-                *reinterpret_cast<f32x4*>(xt + lds[i]) = ((vmask >> i) & 1u) ? (ca * v[i] + cbb * v2[i] + cc) : zero;
+            for (int i = 0; i < NU; ++i) {
+                const bool in = all_in || ((vmask >> i) & 1u);
+                const f32x4 r = in ? (ca * v[i] + cbb * v2[i] + cc) : zero;      // padding stays zero (C alone would leak into it)
+                *reinterpret_cast<f32x4*>(xt + lds[i]) = r;
+                if (xout_on) {
+                    const unsigned tr = (unsigned)((rc[i] & 0xffff) - pad_h), tc = (unsigned)((rc[i] >> 16) - pad_w);
+                    const bool own = in && tr < (unsigned)(G::TH * S) && tc < (unsigned)(TW * S);
+                    ctl_bstore4(rxout, own ? (tb_last + rel[i]) : CTL_OOB, r);
+                }
+            }
             return;
         }
         if (!d.pro_affine) {      // out-of-range units were loaded as hardware zeros: nothing to compute
@@ -242,7 +255,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : ((MT * NT >= 4
                                                           float* __restrict__ stats_partial, int tiles_h, int tiles_w,
                                                           int G_chunks, int64_t wpack_sub_stride, int ntiles,
                                                           const float* __restrict__ res2, const float* __restrict__ x2,
-                                                          float* __restrict__ pool) {
+                                                          float* __restrict__ pool, float* __restrict__ xout) {
     using G = Geom<KS, S, MT, TW>;
     constexpr int TAPS = KS * KS;
     // C4: input with <= 4 channels.  The four lane groups of an MFMA (its k index) carry four different TAPS (channels 0-3 each)
@@ -286,6 +299,8 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : ((MT * NT >= 4
     const int oy0 = (z >> 1) * d.out_sub, ox0 = (z & 1) * d.out_sub;
     const __amdgpu_buffer_rsrc_t rx = ctl_rsrc(x, (int64_t)d.n * d.hin * d.win * d.cin * 4);
     const __amdgpu_buffer_rsrc_t rx2 = X2 ? ctl_rsrc(x2, (int64_t)d.n * d.hin * d.win * d.cin * 4) : rx;
+    const bool xout_on = X2 && xout != nullptr && blockIdx.y == 0 && blockIdx.z == 0;
+    const __amdgpu_buffer_rsrc_t rxout = xout_on ? ctl_rsrc(xout, (int64_t)d.n * d.hin * d.win * d.cin * 4) : rx;
     const int64_t ybytes = (int64_t)d.n * d.out_h * d.out_w * d.cout * 4;
     const __amdgpu_buffer_rsrc_t ry = ctl_rsrc(y, ybytes);
     const __amdgpu_buffer_rsrc_t rres = ctl_rsrc(EPI ? (const void*)res : (const void*)y, ybytes);
@@ -388,7 +403,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : ((MT * NT >= 4
         __syncthreads();
     }
     if (total_it > 0) {
-        xs.store(xt, d, 0, cf_scale, cf_shift, (cur.n / group_n) * d.cin, cf_c);
+        xs.store(xt, d, 0, cf_scale, cf_shift, (cur.n / group_n) * d.cin, cf_c, rxout, xout_on);
         wstore();
     }
     __syncthreads();
@@ -496,7 +511,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : ((MT * NT >= 4
         ctl_barrier_lds_reads_done();    // every wave is done reading this step's LDS images
         TM(2)
         if (has_next) {    // refill LDS from the prefetched registers
-            xs.store(xt, d, g2, cf_scale, cf_shift, (nxt.n / group_n) * d.cin, cf_c);   // v[] holds chunk g2 of tile nxt (== cur unless g2 == 0)
+            xs.store(xt, d, g2, cf_scale, cf_shift, (nxt.n / group_n) * d.cin, cf_c, rxout, xout_on);   // v[] holds chunk g2 of tile nxt (== cur unless g2 == 0)
             if (new_w) wstore();
         }
         TM(3)
@@ -1234,7 +1249,7 @@ extern "C" int ctl_pack_weights(const float* src, float* dst, int32_t cout, int3
 struct conv_call {
     const ctl_conv* d; ctl_conv_cfg c;
     const float *x, *wpack, *bias, *pro_scale, *pro_shift, *res, *res_scale, *res_shift, *res2, *x2;
-    float *y, *stats_partial, *pool;
+    float *y, *stats_partial, *pool, *xout;
     hipStream_t stream;
     bool query;      // only report the grid (ctl_conv_stats_blocks), launch nothing
     int grid_x;
@@ -1261,7 +1276,7 @@ static void conv_go(conv_call& a) {
     const dim3 grid((unsigned)a.grid_x, (unsigned)(a.c.cot / NT), (unsigned)d->nsub);
     conv_igemm_kernel<KS, S, MODE, MT, TW, NT, EPI, X2><<<grid, dim3(256), 0, a.stream>>>(
         *d, a.x, a.wpack, a.bias, a.pro_scale, a.pro_shift, a.res, a.res_scale, a.res_shift, a.y, a.stats_partial, a.c.tiles_h,
-        a.c.tiles_w, a.c.g, (int64_t)ctl_conv_wpack_floats(d->cin, d->cout, d->ks), ntiles, a.res2, a.x2, a.pool);
+        a.c.tiles_w, a.c.g, (int64_t)ctl_conv_wpack_floats(d->cin, d->cout, d->ks), ntiles, a.res2, a.x2, a.pool, a.xout);
 }
 // the launches that write dL/dOut of a residual block (and can carry CTL_EPI_TAILBWD): the 1x1 data gradients, the 2x2 stride-2 conv
 // behind a ConvTranspose2d, the four phase problems / the zero-insert form of a stride-2 3x3 data gradient
@@ -1330,7 +1345,7 @@ extern "C" int ctl_conv_forward(const ctl_conv* d, const float* x, const float* 
                                 const float* pro_scale, const float* pro_shift, const float* res,
                                 const float* res_scale, const float* res_shift, float* y, float* stats_partial,
                                 ctl_stream stream) {
-    return ctl_conv_forward_ex(d, x, wpack, bias, pro_scale, pro_shift, res, res_scale, res_shift, nullptr, nullptr, y, stats_partial, nullptr, stream);
+    return ctl_conv_forward_ex(d, x, wpack, bias, pro_scale, pro_shift, res, res_scale, res_shift, nullptr, nullptr, y, stats_partial, nullptr, nullptr, stream);
 }
 // the tile configuration of d gives every wave a row pair: its CTL_EPI_TAILBWD epilogue can write the 2x2 sum-pool of g as well
 extern "C" int ctl_conv_pool_ok(const ctl_conv* d) {
@@ -1344,7 +1359,8 @@ extern "C" int ctl_conv_pool_ok(const ctl_conv* d) {
 extern "C" int ctl_conv_forward_ex(const ctl_conv* d, const float* x, const float* wpack, const float* bias,
                                    const float* pro_scale, const float* pro_shift, const float* res,
                                    const float* res_scale, const float* res_shift, const float* res2, const float* x2, float* y,
-                                   float* stats_partial, float* pool, ctl_stream stream) {
+                                   float* stats_partial, float* pool, float* xout, ctl_stream stream) {
+    CTL_REQUIRE(!xout || d->pro_affine == 2, "conv_forward: `xout` (the virtual input written out) goes with the BatchNorm-backward prologue (pro_affine 2)");
     CTL_REQUIRE(!pool || ctl_conv_pool_ok(d), "conv_forward: `pool` needs a CTL_EPI_TAILBWD 1x1 conv with even output sizes whose tile configuration gives every wave a row pair (ctl_conv_pool_ok)");
     CTL_REQUIRE(d && x && wpack && y, "conv_forward: null argument");
     CTL_REQUIRE((d->dt & CTL_DT_BF16) || !(d->dt & (CTL_DT_X16 | CTL_DT_Y16 | CTL_DT_RES16)), "conv_forward: bf16-stored tensors need CTL_DT_BF16");
@@ -1382,12 +1398,12 @@ extern "C" int ctl_conv_forward_ex(const ctl_conv* d, const float* x, const floa
                 "conv_forward: tensors must stay below 2 GiB (32-bit buffer offsets)");
     if (d->dt & CTL_DT_BF16) {
         const int ptok16 = ctl_prof_begin("conv_igemm_bf16", d, &a.c, a.c.nt, (hipStream_t)stream);
-        rc = ctl_conv_forward_bf16(d, x, x2, wpack, bias, pro_scale, pro_shift, res, res_scale, res_shift, res2, y, stats_partial, pool, stream);
+        rc = ctl_conv_forward_bf16(d, x, x2, wpack, bias, pro_scale, pro_shift, res, res_scale, res_shift, res2, y, stats_partial, pool, xout, stream);
         ctl_prof_end(ptok16, (hipStream_t)stream);
         return rc;
     }
     a.x = x; a.wpack = wpack; a.bias = bias; a.pro_scale = pro_scale; a.pro_shift = pro_shift; a.res = res;
-    a.res_scale = res_scale; a.res_shift = res_shift; a.res2 = res2; a.x2 = x2; a.y = y; a.stats_partial = stats_partial; a.pool = pool;
+    a.res_scale = res_scale; a.res_shift = res_shift; a.res2 = res2; a.x2 = x2; a.y = y; a.stats_partial = stats_partial; a.pool = pool; a.xout = xout;
     a.stream = (hipStream_t)stream;
     const int ptok = ctl_prof_begin("conv_igemm", d, &a.c, a.c.nt, a.stream);
     rc = conv_dispatch(a);

@@ -82,7 +82,8 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? CTL16_OCC_BIG : ((
     const ctl_conv d, const void* __restrict__ x, const void* __restrict__ x2, const void* __restrict__ wpack, const float* __restrict__ bias,
     const float* __restrict__ pro_scale, const float* __restrict__ pro_shift, const void* __restrict__ res,
     const float* __restrict__ res_scale, const float* __restrict__ res_shift, const void* __restrict__ res2, void* __restrict__ y,
-    float* __restrict__ stats_partial, int tiles_h, int tiles_w, int G_chunks, int64_t wpack_sub_bytes, int ntiles, void* __restrict__ pool) {
+    float* __restrict__ stats_partial, int tiles_h, int tiles_w, int G_chunks, int64_t wpack_sub_bytes, int ntiles, void* __restrict__ pool,
+    void* __restrict__ xout) {
     using G = Geom<KS, S, MT, TW>;
     using XS = XStage16<KS, S, MODE, MT, TW, XB, true, X2>;
     constexpr int TAPS = KS * KS;
@@ -121,6 +122,8 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? CTL16_OCC_BIG : ((
     const int oy0 = (z >> 1) * d.out_sub, ox0 = (z & 1) * d.out_sub;
     const __amdgpu_buffer_rsrc_t rx = ctl_rsrc(x, (int64_t)d.n * d.hin * d.win * d.cin * ((XB == 1 || (XB == 0 && (d.dt & CTL_DT_X16))) ? 2 : 4));
     const __amdgpu_buffer_rsrc_t rx2 = X2 ? ctl_rsrc(x2, (int64_t)d.n * d.hin * d.win * d.cin * 2) : rx;
+    const bool xout_on = X2 && xout != nullptr && blockIdx.y == 0 && blockIdx.z == 0;
+    const __amdgpu_buffer_rsrc_t rxout = xout_on ? ctl_rsrc(xout, (int64_t)d.n * d.hin * d.win * d.cin * 2) : rx;
     const int64_t ypix = (int64_t)d.n * d.out_h * d.out_w * d.cout;
     const __amdgpu_buffer_rsrc_t ry = ctl_rsrc(y, ypix * yes);
     const __amdgpu_buffer_rsrc_t rres = ctl_rsrc(res ? res : y, ypix * (res ? res_es : yes));
@@ -221,7 +224,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? CTL16_OCC_BIG : ((
         __syncthreads();
     }
     if (total_it > 0) {
-        xs.store(xt, d, 0, cf_scale, cf_shift, (cur.n / group_n) * d.cin, cf_c);
+        xs.store(xt, d, 0, cf_scale, cf_shift, (cur.n / group_n) * d.cin, cf_c, rxout, xout_on);
         wstore();
     }
     __syncthreads();
@@ -359,7 +362,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? CTL16_OCC_BIG : ((
         ctl_barrier_lds_reads_done();
         TM(2)
         if (has_next) {
-            xs.store(xt, d, g2, cf_scale, cf_shift, (nxt.n / group_n) * d.cin, cf_c);
+            xs.store(xt, d, g2, cf_scale, cf_shift, (nxt.n / group_n) * d.cin, cf_c, rxout, xout_on);
             if (new_w) wstore();
         }
         TM(3)
@@ -682,7 +685,7 @@ extern "C" int ctl_pack_weights_bf16_batched(const float* params, float* wpack, 
 // ------------------------------------------------------------------------------------------------ host side
 struct conv16_call {
     const ctl_conv* d; ctl_conv_cfg c;
-    const void *x, *x2, *wpack, *res, *res2; void *y, *pool;
+    const void *x, *x2, *wpack, *res, *res2; void *y, *pool, *xout;
     const float *bias, *pro_scale, *pro_shift, *res_scale, *res_shift; float* stats_partial;
     hipStream_t stream; bool query; int grid_x;
 };
@@ -704,7 +707,7 @@ static void conv16_go_f(conv16_call& a) {
     const dim3 grid((unsigned)a.grid_x, (unsigned)(a.c.cot / NT), (unsigned)d->nsub);
     conv_igemm_bf16_kernel<KS, S, MODE, MT, TW, NT, FAST, XB, X2><<<grid, dim3(256), 0, a.stream>>>(
         *d, a.x, a.x2, a.wpack, a.bias, a.pro_scale, a.pro_shift, a.res, a.res_scale, a.res_shift, a.res2, a.y, a.stats_partial, a.c.tiles_h, a.c.tiles_w,
-        a.c.g, (int64_t)ctl_conv_wpack_floats(d->cin, d->cout, d->ks) * 4, ntiles, a.pool);
+        a.c.g, (int64_t)ctl_conv_wpack_floats(d->cin, d->cout, d->ks) * 4, ntiles, a.pool, a.xout);
 }
 template <int KS, int S, int MODE, int MT, int TW, int NT>
 static void conv16_go(conv16_call& a) {
@@ -797,7 +800,7 @@ int ctl_conv_bf16_stats_blocks(const ctl_conv* d) {
 
 int ctl_conv_forward_bf16(const ctl_conv* d, const void* x, const void* x2, const void* wpack, const float* bias, const float* pro_scale,
                           const float* pro_shift, const void* res, const float* res_scale, const float* res_shift, const void* res2, void* y,
-                          float* stats_partial, void* pool, ctl_stream stream) {
+                          float* stats_partial, void* pool, void* xout, ctl_stream stream) {
     if (d->epi_flags & CTL_EPI_TAILBWD) {
         CTL_REQUIRE((d->dt & CTL_DT_Y16) && (d->dt & CTL_DT_RES16) && d->cout % 16 == 0 && ((d->dt & CTL_DT_X16) ? d->cin % 16 == 0 : d->ks == 1),
                     "conv_forward(bf16): CTL_EPI_TAILBWD needs bf16-stored y / res / res2 with whole 16-channel tiles (and a bf16-stored x, except for 1x1 convs)");
@@ -818,7 +821,7 @@ int ctl_conv_forward_bf16(const ctl_conv* d, const void* x, const void* x2, cons
     int rc = ctl_conv_pick_cfg(d, &a.c, 0);
     if (rc != CTL_OK) return rc;
     a.x = x; a.x2 = x2; a.wpack = wpack; a.bias = bias; a.pro_scale = pro_scale; a.pro_shift = pro_shift; a.res = res; a.res_scale = res_scale;
-    a.res_shift = res_shift; a.res2 = res2; a.y = y; a.stats_partial = stats_partial; a.pool = pool; a.stream = (hipStream_t)stream;
+    a.res_shift = res_shift; a.res2 = res2; a.y = y; a.stats_partial = stats_partial; a.pool = pool; a.xout = xout; a.stream = (hipStream_t)stream;
     rc = conv16_dispatch(a);
     if (rc != CTL_OK) return rc;
     CTL_LAUNCH_CHECK("conv_forward(bf16)");

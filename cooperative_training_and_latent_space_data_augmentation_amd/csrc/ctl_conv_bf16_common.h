@@ -57,6 +57,7 @@ struct XStage16 {
     u32x4 v0[NU], v1[NU];     // source bf16: v0 = 8 channels (X2: v1 = 8 channels of the second tensor); source fp32: v0 = channels 0-3, v1 = 4-7 of the unit
     unsigned vmask;
     int pad_h, pad_w;
+    int tb_last;        // X2: byte offset of the tile held in v0 / v1 (side output of the virtual tensor, see store)
     bool all_in, x16;
 
     __device__ __forceinline__ void init(const ctl_conv& d) {
@@ -90,6 +91,7 @@ struct XStage16 {
         const int ow = (MODE == CTL_IN_PLAIN) ? vw0 : ((wo0 >> 1) - PADH);
         const int esz = x16 ? 2 : 4;
         const int tb = (((n * d.hin + oh) * d.win + ow) * d.cin + g * 16) * esz;
+        tb_last = tb;
         all_in = MODE != CTL_IN_ZINS2 && vh0 >= 0 && vw0 >= 0 && vh0 + G::IH <= (int)hv && vw0 + G::IW <= (int)wv &&
                  g * 16 + 16 <= d.cin;
         if (all_in) {
@@ -138,8 +140,15 @@ struct XStage16 {
     }
 
     // X2: cf_scale / cf_shift / cf_c hold A / B / C of the block's groups ([group][cin] each)
+    // rxout / xout_on (X2): the tile's interior units are also written to a tensor of x's geometry -- the virtual tensor materialises as a
+    // by-product of this staging for the weight-gradient kernel of the same layer (see ctl_conv.hip)
     __device__ __forceinline__ void store(unsigned char* __restrict__ xt, const ctl_conv& d, int g, const float* cf_scale,
                                           const float* cf_shift, int goff, const float* cf_c = nullptr) {
+        store(xt, d, g, cf_scale, cf_shift, goff, cf_c, ctl_rsrc((const void*)nullptr, 0), false);
+    }
+    __device__ __forceinline__ void store(unsigned char* __restrict__ xt, const ctl_conv& d, int g, const float* cf_scale,
+                                          const float* cf_shift, int goff, const float* cf_c,
+                                          __amdgpu_buffer_rsrc_t rxout, bool xout_on) {
         if constexpr (X2) {
             const int cb = g * 16 + (threadIdx.x & 1) * 8;
             const f32x4 a0 = *reinterpret_cast<const f32x4*>(cf_scale + goff + cb), a1 = *reinterpret_cast<const f32x4*>(cf_scale + goff + cb + 4);
@@ -151,8 +160,14 @@ struct XStage16 {
                 const f32x4 glo = unpack_bf16x4(v0[i].x, v0[i].y), ghi = unpack_bf16x4(v0[i].z, v0[i].w);
                 const f32x4 ulo = unpack_bf16x4(v1[i].x, v1[i].y), uhi = unpack_bf16x4(v1[i].z, v1[i].w);
                 u32x4 pk = pack_bf16x8(a0 * glo + b0 * ulo + c0, a1 * ghi + b1 * uhi + c1);
-                if (!all_in && !((vmask >> i) & 1u)) pk = zero;      // padding stays zero (C alone would leak into it)
+                const bool in = all_in || ((vmask >> i) & 1u);
+                if (!in) pk = zero;      // padding stays zero (C alone would leak into it)
                 *reinterpret_cast<u32x4*>(xt + lds[i]) = pk;
+                if (xout_on) {
+                    const unsigned tr = (unsigned)((rc[i] & 0xffff) - pad_h), tc = (unsigned)((rc[i] >> 16) - pad_w);
+                    const bool own = in && tr < (unsigned)(G::TH * S) && tc < (unsigned)(TW * S);
+                    __builtin_amdgcn_raw_buffer_store_b128(pk, rxout, own ? (tb_last + rel[i]) : CTL_OOB, 0, 0);
+                }
             }
             return;
         }

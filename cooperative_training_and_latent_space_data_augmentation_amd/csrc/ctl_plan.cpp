@@ -243,7 +243,7 @@ extern "C" int ctl_plan_run(const ctl_op* ops, int32_t n_ops, void* const* bases
         switch (op.kind) {
             case CTL_OP_CONV:
                 memcpy(&d, op.i, sizeof(d));
-                rc = ctl_conv_forward_ex(&d, CF(0), CF(1), CF(2), CF(3), CF(4), CF(5), CF(6), CF(7), CF(10), CF(11), F(8), F(9), F(12), stream);
+                rc = ctl_conv_forward_ex(&d, CF(0), CF(1), CF(2), CF(3), CF(4), CF(5), CF(6), CF(7), CF(10), CF(11), F(8), F(9), F(12), F(13), stream);
                 break;
             case CTL_OP_WGRAD:
                 memcpy(&d, op.i, sizeof(d));

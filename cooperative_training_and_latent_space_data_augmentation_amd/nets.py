@@ -46,6 +46,10 @@ FUSE_BNBWD = True        # fp32: the in-block BatchNorm-backward reduction insid
 FUSE_BNAPPLY = True      # fp32: the BatchNorm-backward apply passes inside the staging of their consumers (see FUSE_BNAPPLY16); the tail's alone: 40
                          # launches and a tensor pass less per step for 17.52 -> 17.45 ms; the in-block one follows FUSE_BNBWD
 FUSE_BNBWD16 = True      # the same in the bf16 family, where the data gradient is not matrix-bound
+FUSE_XOUT16 = True       # bf16: the data-gradient conv that stages a virtual tensor also WRITES it (its tiles' interiors), and the weight gradient of the
+                         # same layer -- issued behind it -- reads it as a plain tensor instead of evaluating it again in every cin-chunk block
+                         # (the virtual output gradient costs the bf16 weight gradients +14-44 % in isolation): 9.76 -> 9.49 ms same-box
+FUSE_XOUT = False        # fp32: the same, parity-tested, and 16.64 -> 16.85 ms: the extra stores sit in the serial staging phase of matrix-bound kernels
 FUSE_POOL = True         # both families: the tail epilogue of a 1x1 host also writes sumpool2(g) for a consuming nearest-upsample block (no ctl_sumpool2 pass)
 FUSE_PAIR = True         # fp32: the same for the fp32 family (these pairs are the 256^2 x 16-channel tensors: 0.87 ms of reduce + apply passes per step)
 FUSE_PAIR16 = True       # bf16: the conv-BatchNorm-activation pairs at the head of the encoders get g = dAct * act' and their sums from the launch that
@@ -211,7 +215,7 @@ class PlanBuilder:
 
     def conv(self, x: T, wp_ref, cout, ks, *, stride=1, in_mode=0, pro=None, bias_ref=None, stats=False, act=0,
              slope=0.0, res=None, accum=False, out: Optional[T] = None, arena: Optional[Arena] = None, nsub=1,
-             hout=None, wout=None, bnbwd=None, pad=None, tail=None, x2=None, keep_stats=False):
+             hout=None, wout=None, bnbwd=None, pad=None, tail=None, x2=None, keep_stats=False, xout: Optional[T] = None):
         # (tail may carry a 4th element: True = the consumer wants the 2x2 sum-pool of g as well, see below)
         """Emit one CTL_OP_CONV.  pro = (scale_ref, shift_ref, slope); res = (T v, scale_ref, shift_ref).
         bnbwd = (T u, scale_ref, shift_ref, slope): data-gradient conv whose result is dL/d leaky(BN(u)); the epilogue writes
@@ -271,8 +275,9 @@ class PlanBuilder:
         for idx, ref in enumerate([x.ref, wp_ref, bias_ref, pro[0] if pro else None, pro[1] if pro else None,
                                    (tail[0].ref if tail is not None else (res[0].ref if res else None)), res[1] if res else None, res[2] if res else None,
                                    out.ref, stats_ref, res2.ref if res2 is not None else None, x2[0].ref if x2 is not None else None,
-                                   pool_t.ref if pool_t is not None else None]):
+                                   pool_t.ref if pool_t is not None else None, xout.ref if xout is not None else None]):
             self.set_t(op, idx, ref)
+        assert xout is None or (x2 is not None and (xout.n, xout.h, xout.w, xout.c, xout.b16) == (x.n, x.h, x.w, x.c, x.b16))
         return out, stats_ref, blocks
 
     def wgrad(self, x: T, dy: T, ks, *, stride=1, in_mode=0, pro=None, dw_ref, strides, dbias_ref=None, accumulate=False, dy2=None):
@@ -943,22 +948,32 @@ class CtlNet(nn.Module):
             dv, dv2 = ds, (v, coef2)
         pro1 = (rec["co1"]["scale"], rec["co1"]["shift"], SLOPE)
         k9 = 9
-        if need_w:
-            pb.wgrad(u, dv, 3, pro=pro1, dw_ref=pb.G(c3.w_off), strides=(c3.cin * k9, k9, 3, 1), dbias_ref=pb.G(c3.b_off), dy2=dv2)
+        # FUSE_XOUT: the data gradient runs FIRST and leaves the virtual dV behind for the weight gradient
+        dv_out = A.tensor(out.n, out.h, out.w, out.c) if (need_w and dv2 is not None and (FUSE_XOUT16 if pb.b16 else FUSE_XOUT)) else None
+        def wgrad_c3():
+            if need_w:
+                if dv_out is not None:
+                    pb.wgrad(u, dv_out, 3, pro=pro1, dw_ref=pb.G(c3.w_off), strides=(c3.cin * k9, k9, 3, 1), dbias_ref=pb.G(c3.b_off))
+                else:
+                    pb.wgrad(u, dv, 3, pro=pro1, dw_ref=pb.G(c3.w_off), strides=(c3.cin * k9, k9, 3, 1), dbias_ref=pb.G(c3.b_off), dy2=dv2)
+        if dv_out is None:
+            wgrad_c3()
         # dgrad of conv.3; its epilogue already multiplies by leaky'(BN1(u)) and takes the BatchNorm-backward sums (no
         # separate reduction pass); the apply runs in place
         if (FUSE_BNBWD and not pb.b16) or (FUSE_BNBWD16 and pb.b16 and dv.b16 and u.b16):
             g1, st, blk = pb.conv(dv, self._wp_ref(c3.wp_dgrad), c3.cin, 3, arena=A,
-                                  bnbwd=(u, rec["co1"]["scale"], rec["co1"]["shift"], SLOPE), x2=dv2)
+                                  bnbwd=(u, rec["co1"]["scale"], rec["co1"]["shift"], SLOPE), x2=dv2, xout=dv_out)
             coef1 = pb.bn_backward_from_stats(g1, u, B[prefix + ".conv.1"], rec["co1"], st, blk, dx=None if virt_u else g1, affine_grad=need_w and affine)
             du = g1
             if virt_u:
                 du2 = (u, coef1)
         else:
-            da, _, _ = pb.conv(dv, self._wp_ref(c3.wp_dgrad), c3.cin, 3, arena=A, x2=dv2)
+            da, _, _ = pb.conv(dv, self._wp_ref(c3.wp_dgrad), c3.cin, 3, arena=A, x2=dv2, xout=dv_out)
             # BN1 -> LeakyReLU tail (in place: dU overwrites dA)
             pb.bn_backward(1, da, None, u, B[prefix + ".conv.1"], rec["co1"], SLOPE, ds=None, dx=da, affine_grad=need_w and affine)
             du = da
+        if dv_out is not None:
+            wgrad_c3()
         ds_low = None
         if pre == "nn":
             # nearest-upsample backward = 2x2 sum-pool; it commutes with pointwise (1x1) convs, so both the 1x1 weight gradient
@@ -968,12 +983,19 @@ class CtlNet(nn.Module):
             else:
                 ds_low = A.tensor(ds.n, ds.h // 2, ds.w // 2, ds.c)
                 pb.sumpool2(ds, ds_low)
-        if need_w:
-            pb.wgrad(src, du, 3, in_mode=src_mode, dw_ref=pb.G(c0.w_off), strides=(c0.cin * k9, k9, 3, 1), dbias_ref=pb.G(c0.b_off), dy2=du2)
-            if ds_low is not None:
-                pb.wgrad(xin, ds_low, 1, dw_ref=pb.G(c1.w_off), strides=(c1.cin, 1, 1, 1), dbias_ref=pb.G(c1.b_off))
-            else:
-                pb.wgrad(src, ds, 1, in_mode=src_mode, dw_ref=pb.G(c1.w_off), strides=(c1.cin, 1, 1, 1), dbias_ref=pb.G(c1.b_off))
+        du_out = A.tensor(du.n, du.h, du.w, du.c) if (need_w and du2 is not None and (FUSE_XOUT16 if pb.b16 else FUSE_XOUT)) else None      # (FUSE_XOUT, as for dV above)
+        def wgrads_c0_c1():
+            if need_w:
+                if du_out is not None:
+                    pb.wgrad(src, du_out, 3, in_mode=src_mode, dw_ref=pb.G(c0.w_off), strides=(c0.cin * k9, k9, 3, 1), dbias_ref=pb.G(c0.b_off))
+                else:
+                    pb.wgrad(src, du, 3, in_mode=src_mode, dw_ref=pb.G(c0.w_off), strides=(c0.cin * k9, k9, 3, 1), dbias_ref=pb.G(c0.b_off), dy2=du2)
+                if ds_low is not None:
+                    pb.wgrad(xin, ds_low, 1, dw_ref=pb.G(c1.w_off), strides=(c1.cin, 1, 1, 1), dbias_ref=pb.G(c1.b_off))
+                else:
+                    pb.wgrad(src, ds, 1, in_mode=src_mode, dw_ref=pb.G(c1.w_off), strides=(c1.cin, 1, 1, 1), dbias_ref=pb.G(c1.b_off))
+        if du_out is None:
+            wgrads_c0_c1()
         # gradient w.r.t. x' (full resolution of this block)
         if pre == "down" or pre == "convT":
             dsrc_shape = (src.n, src.h, src.w, src.c)
@@ -984,12 +1006,16 @@ class CtlNet(nn.Module):
         fin = lambda st, blk: d_in if (tail_next is None and act_next is None) else (d_in, st, blk, pb.last_pool)
         if pre == "nn":
             # sumpool2(conv3x3^T(dU)) as one 4x4 stride-2 conv (no full-resolution gradient tensor at all), then the 1x1 part
-            pb.conv(du, self._wp_ref(c0.wp_up), c0.cin, 4, stride=2, out=d_in, x2=du2)
+            pb.conv(du, self._wp_ref(c0.wp_up), c0.cin, 4, stride=2, out=d_in, x2=du2, xout=du_out)
+            if du_out is not None:
+                wgrads_c0_c1()
             assert act_next is None
             _, st, blk = pb.conv(ds_low, self._wp_ref(c1.wp_dgrad), c1.cin, 1, out=d_in, accum=True, tail=tail_next)
             return fin(st, blk)
         dsrc = A.tensor(*dsrc_shape)
-        pb.conv(du, self._wp_ref(c0.wp_dgrad), c0.cin, 3, out=dsrc, x2=du2)
+        pb.conv(du, self._wp_ref(c0.wp_dgrad), c0.cin, 3, out=dsrc, x2=du2, xout=du_out)
+        if du_out is not None:
+            wgrads_c0_c1()
         pb.conv(ds, self._wp_ref(c1.wp_dgrad), c1.cin, 1, out=dsrc, accum=True)
         if pre == "convT":
             ci = C[prefix + ".up"]
@@ -1036,15 +1062,21 @@ class CtlNet(nn.Module):
         else:
             du = A.tensor(u.n, u.h, u.w, u.c)
             pb.bn_backward(1, d_act, None, u, bn, co, slope, ds=None, dx=du, affine_grad=need_w and affine)
-        if need_w:
-            pb.wgrad(x, du, ci.ks, pro=x_pro, in_mode=_ffi.IN_C4 if ci.wp_c4 >= 0 else 0, dw_ref=pb.G(ci.w_off),
-                     strides=(ci.cin * k2, k2, ci.ks, 1), dbias_ref=pb.G(ci.b_off), dy2=dy2)
+        du_out = A.tensor(u.n, u.h, u.w, u.c) if (need_w and need_dx and dy2 is not None and (FUSE_XOUT16 if pb.b16 else FUSE_XOUT)) else None      # (FUSE_XOUT, see _emit_block_bwd)
+        def wgrad():
+            if need_w:
+                pb.wgrad(x, du if du_out is None else du_out, ci.ks, pro=x_pro, in_mode=_ffi.IN_C4 if ci.wp_c4 >= 0 else 0, dw_ref=pb.G(ci.w_off),
+                         strides=(ci.cin * k2, k2, ci.ks, 1), dbias_ref=pb.G(ci.b_off), dy2=dy2 if du_out is None else None)
+        if du_out is None:
+            wgrad()
         if not need_dx:
             return None
         if d_x is None:
             d_x = A.tensor(x.n, x.h, x.w, x.c)
         ep = dict(tail=tail_next) if act_next is None else dict(bnbwd=act_next, keep_stats=True)
-        _, st, blk = pb.conv(du, self._wp_ref(ci.wp_dgrad), ci.cin, ci.ks, out=d_x, x2=dy2, **ep)
+        _, st, blk = pb.conv(du, self._wp_ref(ci.wp_dgrad), ci.cin, ci.ks, out=d_x, x2=dy2, xout=du_out, **ep)
+        if du_out is not None:
+            wgrad()
         return d_x if (tail_next is None and act_next is None) else (d_x, st, blk, pb.last_pool)
 
     # ---------------------------------------------------------------- public compute entry points

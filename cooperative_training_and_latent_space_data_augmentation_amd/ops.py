@@ -89,12 +89,13 @@ def pack_oihw_dgrad_bf16(w: torch.Tensor) -> torch.Tensor:
 
 
 def conv_forward(d: np.ndarray, x, wpack, bias=None, pro_scale=None, pro_shift=None, res=None, res_scale=None,
-                 res_shift=None, y=None, want_stats=False, x2=None, res2=None, pool=None):
+                 res_shift=None, y=None, want_stats=False, x2=None, res2=None, pool=None, xout=None):
     """Run one conv problem described by the ctl_conv record `d`.  Returns (y, stats_partial or None).  With d["dt"] & DT_BF16 the
     storage dtypes of x / res / y must agree with the DT_X16 / DT_RES16 / DT_Y16 flags (y is allocated accordingly).
     x2 (d["pro_affine"] == 2): the BatchNorm-backward prologue, input = A*x + B*x2 + C with pro_scale = [groups][3][cin] coefficients.
     res2 (CTL_EPI_TAILBWD): res = the block output, res2 = the BatchNorm input of the residual tail; pool: that epilogue also writes the
-    2x2 sum-pool of its result into this [n, h/2, w/2, cout] tensor (lib.ctl_conv_pool_ok(desc) says whether the problem can)."""
+    2x2 sum-pool of its result into this [n, h/2, w/2, cout] tensor (lib.ctl_conv_pool_ok(desc) says whether the problem can);
+    xout (with x2): the virtual input the conv stages is also written to this tensor of x's shape and dtype."""
     require_gpu(x, wpack)
     if (x2 is not None) != (int(d["pro_affine"]) == 2) or (x2 is not None and (x2.dtype != x.dtype or x2.shape != x.shape)):
         raise _ffi.CtlError("conv_forward: x2 goes with ctl_conv.pro_affine == 2 and has the dtype and shape of x")
@@ -109,7 +110,7 @@ def conv_forward(d: np.ndarray, x, wpack, bias=None, pro_scale=None, pro_shift=N
     if want_stats:
         stats = torch.empty(lib.ctl_conv_stats_floats(_ffi.desc_ptr(d)), dtype=torch.float32, device=x.device)
     check(lib.ctl_conv_forward_ex(_ffi.desc_ptr(d), ptr(x), ptr(wpack), ptr(bias), ptr(pro_scale), ptr(pro_shift), ptr(res),
-                                  ptr(res_scale), ptr(res_shift), ptr(res2), ptr(x2), ptr(y), ptr(stats), ptr(pool), stream_ptr()), "ctl_conv_forward")
+                                  ptr(res_scale), ptr(res_shift), ptr(res2), ptr(x2), ptr(y), ptr(stats), ptr(pool), ptr(xout), stream_ptr()), "ctl_conv_forward")
     return y, stats
 
 

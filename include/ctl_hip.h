@@ -34,8 +34,9 @@ enum ctl_status { CTL_OK = 0, CTL_EINVAL = -1, CTL_EUNSUPPORTED = -2, CTL_ELAUNC
  * 5 = ctl_bn_finalize_ex (save_uvar, plan op BN_FINALIZE slot 10), ctl_bn_replay_running / CTL_OP_BN_REPLAY.
  * 6 = the BatchNorm-backward prologue: ctl_conv.pro_affine == 2 + the x2 argument of ctl_conv_forward_ex (plan op CONV slot 11),
  *     ctl_conv_wgrad_ex (plan op WGRAD slots 6, 7); CTL_EPI_TAILBWD in the bf16 family.
- * 7 = the `pool` argument of ctl_conv_forward_ex (plan op CONV slot 12; CTL_OP_MAX_T 12 -> 14: sizeof(ctl_op) 304 -> 328), ctl_conv_pool_ok. */
-#define CTL_ABI_VERSION 7
+ * 7 = the `pool` argument of ctl_conv_forward_ex (plan op CONV slot 12; CTL_OP_MAX_T 12 -> 14: sizeof(ctl_op) 304 -> 328), ctl_conv_pool_ok.
+ * 8 = the `xout` argument of ctl_conv_forward_ex (plan op CONV slot 13). */
+#define CTL_ABI_VERSION 8
 int         ctl_version(void);
 const char* ctl_last_error(void);
 
@@ -113,12 +114,16 @@ int ctl_conv_forward(const ctl_conv* d, const float* x, const float* wpack, cons
 int ctl_conv_forward_ex(const ctl_conv* d, const float* x, const float* wpack, const float* bias,
                         const float* pro_scale, const float* pro_shift,
                         const float* res, const float* res_scale, const float* res_shift, const float* res2, const float* x2,
-                        float* y, float* stats_partial, float* pool, ctl_stream stream);
+                        float* y, float* stats_partial, float* pool, float* xout, ctl_stream stream);
 /* pool (with CTL_EPI_TAILBWD on a 1x1 conv with even output sizes; ctl_conv_pool_ok(d) says whether d's tile configuration can do it):
  * the epilogue also writes the 2x2 sum-pool of g, [n, out_h/2, out_w/2, cout] -- the input of the consuming block's 1x1 weight / data
  * gradients behind a nearest-neighbour up-sampling (encdec.py:344): the stand-alone ctl_sumpool2 pass disappears.  fp32: the same
  * association as ctl_sumpool2, bit-identical; bf16: pooled from the unrounded g, rounded once.  NULL: not written. */
 int ctl_conv_pool_ok(const ctl_conv* d);
+/* xout (with pro_affine == 2; a tensor of x's geometry and storage type): the conv also WRITES the virtual input A*x + B*x2 + C it stages --
+ * every input pixel by the tile that owns it, from the blocks of the first output-channel group -- so that the weight-gradient kernel of
+ * the same layer reads it as a plain output gradient (ctl_conv_wgrad) instead of evaluating it again in each of its cin-chunk blocks
+ * (ctl_conv_wgrad_ex: +10-18 % fp32, +14-44 % bf16 in isolation).  Issue this conv BEFORE that weight gradient.  NULL: not written. */
 
 /* Weight gradient of the conv described by d (x [n,hin,win,cin] -> dy [n,hout,wout,cout], nsub must be 1):
  * partial[split][tap][cin16][cout16] (+ bias partial[split][cout16]); then ctl_wgrad_reduce sums the splits and

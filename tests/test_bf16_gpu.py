@@ -294,9 +294,14 @@ def test_conv_bn_backward_prologue(n, c, cout, h, w, groups, family):
     wp = pack(dev(wt))
     # plain
     d = _ffi.conv_desc(n=n, hin=h, win=w, cin=c, hout=h, wout=w, cout=cout, ks=3, groups=groups, pro_affine=2, epi_flags=_ffi.EPI_STATS, dt=dt)
-    y, st = ops.conv_forward(d, dev(g, b16), wp, pro_scale=dev(coef), x2=dev(u, b16), want_stats=True)
+    # xout: the conv also writes the virtual tensor it stages (every pixel, by the tile that owns it): pre-filled with NaN to see the coverage
+    xo = torch.full((n, c, h, w), float("nan"), device=DEV, dtype=torch.bfloat16 if b16 else torch.float32).contiguous(memory_format=torch.channels_last)
+    y, st = ops.conv_forward(d, dev(g, b16), wp, pro_scale=dev(coef), x2=dev(u, b16), want_stats=True, xout=xo)
     ref = F.conv2d(rbf(virt), rbf(wt), padding=1)
     close(y, ref, 1e-3 if b16 else 2e-4, "conv3x3 over the virtual BatchNorm-backward tensor", b16)
+    assert bool(torch.isfinite(xo.float()).all()), "xout: pixels left unwritten"
+    assert torch.equal(xo.float(), stored.float()) or float((xo.float() != stored.float()).float().mean()) < 2e-3, "xout differs from the stored apply pass"
+    close(xo, virt, 1e-6 if not b16 else 1e-3, "xout = the virtual tensor", b16)
     d0 = _ffi.conv_desc(n=n, hin=h, win=w, cin=c, hout=h, wout=w, cout=cout, ks=3, groups=groups, epi_flags=_ffi.EPI_STATS, dt=dt)
     y0, st0 = ops.conv_forward(d0, stored, wp, want_stats=True)
     same = float((y.float() == y0.float()).float().mean())
@@ -325,8 +330,11 @@ def test_conv_bn_backward_prologue(n, c, cout, h, w, groups, family):
     if h % 2 == 0 and w % 2 == 0:
         w4 = torch.randn(cout, c, 4, 4, generator=gen) * 0.2
         d4 = _ffi.conv_desc(n=n, hin=h, win=w, cin=c, hout=h // 2, wout=w // 2, cout=cout, ks=4, stride=2, groups=groups, pro_affine=2, dt=dt)
-        y4, _ = ops.conv_forward(d4, dev(g, b16), pack(dev(w4)), pro_scale=dev(coef), x2=dev(u, b16))
+        xo4 = torch.full_like(xo, float("nan"))
+        y4, _ = ops.conv_forward(d4, dev(g, b16), pack(dev(w4)), pro_scale=dev(coef), x2=dev(u, b16), xout=xo4)
         close(y4, F.conv2d(rbf(virt), rbf(w4), stride=2, padding=1), 1e-3 if b16 else 2e-4, "conv4x4 s2 over the virtual tensor", b16)
+        assert bool(torch.isfinite(xo4.float()).all()), "xout (4x4 stride 2): pixels left unwritten"
+        close(xo4, virt, 1e-6 if not b16 else 1e-3, "xout of the 4x4 stride-2 form", b16)
 
 
 @pytest.mark.parametrize("family", ["bf16", "fp32"])

@@ -83,7 +83,8 @@ NET_INPUT = {"image_encoder": (1, 64, 48), "shape_encoder": (4, 48, 64), "segmen
 PLAN_SWITCHES = {"default": {}, "all_folded": {"FUSE_BNBWD": True, "FUSE_BNAPPLY": True, "FUSE_TAIL": True, "FUSE_PAIR": True},
                  "stand_alone_passes": {"FUSE_BNBWD": False, "FUSE_BNAPPLY": False, "FUSE_TAIL": False, "FUSE_PAIR": False},
                  "staged_apply_without_tail_epilogue": {"FUSE_BNAPPLY": True, "FUSE_TAIL": False},
-                 "blocks_folded_head_pairs_not": {"FUSE_PAIR": False}}
+                 "blocks_folded_head_pairs_not": {"FUSE_PAIR": False},
+                 "virtual_tensors_written_by_the_data_gradients": {"FUSE_XOUT": True}}
 
 
 @pytest.mark.parametrize("switches", list(PLAN_SWITCHES))
