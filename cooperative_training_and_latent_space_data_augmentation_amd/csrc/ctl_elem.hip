@@ -5,6 +5,9 @@
 #include "ctl_common.h"
 
 #define EB 256               // threads per block for the streaming kernels
+#ifndef CTL_FIN_THREADS
+#define CTL_FIN_THREADS EB      // threads per block of the BatchNorm finalize kernels (one block per channel)
+#endif
 #define MAX_STREAM_BLOCKS 2048
 
 static inline unsigned stream_blocks(int64_t work_items) {
@@ -29,11 +32,12 @@ __device__ __forceinline__ void block_sum_double2(double& a, double& b, double* 
 // the rows a thread owns (b = tid, tid + 256, ...; at most 4 * 256 rows) requested back to back: ONE memory round trip instead of one per
 // 256 rows -- these kernels are pure latency (a few KB of partial sums), and there are ~220 of them in a training step
 __device__ __forceinline__ void sum_rows2(const float* __restrict__ partial, int64_t row0, int blocks, int c, int ch, double& s1, double& s2) {
-    for (int b0 = threadIdx.x; b0 < blocks; b0 += 4 * EB) {
+    const int nthr = (int)blockDim.x;          // (the finalize kernels may run narrower than EB, see CTL_FIN_THREADS)
+    for (int b0 = threadIdx.x; b0 < blocks; b0 += 4 * nthr) {
         float v1[4], v2[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int b = b0 + u * EB;
+            const int b = b0 + u * nthr;
             const bool ok = b < blocks;
             v1[u] = ok ? partial[((row0 + b) * 2 + 0) * c + ch] : 0.f;
             v2[u] = ok ? partial[((row0 + b) * 2 + 1) * c + ch] : 0.f;
@@ -678,7 +682,7 @@ extern "C" int ctl_bn_finalize_ex(const float* partial, int32_t blocks, int32_t 
                                   float* save_mean, float* save_invstd, float* save_uvar, int32_t groups, ctl_stream stream) {
     CTL_REQUIRE(partial && gamma && beta && scale && shift && blocks > 0 && c > 0 && count > 0 && groups >= 1, "bn_finalize: bad arguments");
     CTL_REQUIRE(!update_running || (running_mean && running_var), "bn_finalize: update_running without buffers");
-    bn_finalize_kernel<<<dim3(c), dim3(EB), 0, S_>>>(partial, blocks, c, (double)count, gamma, beta, eps, momentum,
+    bn_finalize_kernel<<<dim3(c), dim3(CTL_FIN_THREADS), 0, S_>>>(partial, blocks, c, (double)count, gamma, beta, eps, momentum,
                                                       update_running, running_mean, running_var, nbt, scale, shift,
                                                       save_mean, save_invstd, groups, save_uvar);
     CTL_LAUNCH_CHECK("bn_finalize");
@@ -756,7 +760,7 @@ extern "C" int ctl_bn_bwd_finalize(const float* partial, int32_t c, int64_t coun
                                    float* dbeta, int32_t accumulate, int32_t groups, int32_t blocks, ctl_stream stream) {
     CTL_REQUIRE(partial && gamma && save_mean && save_invstd && coef && c > 0 && count > 0 && groups >= 1 && blocks >= 0, "bn_bwd_finalize: bad arguments");
     // blocks == 0: rows as written by ctl_bwd_reduce for a group of `count` pixels
-    bn_bwd_finalize_kernel<<<dim3(c), dim3(EB), 0, S_>>>(partial, blocks > 0 ? blocks : red_rows_for(count * (c / 4)), c, (double)count, gamma, save_mean,
+    bn_bwd_finalize_kernel<<<dim3(c), dim3(CTL_FIN_THREADS), 0, S_>>>(partial, blocks > 0 ? blocks : red_rows_for(count * (c / 4)), c, (double)count, gamma, save_mean,
                                                           save_invstd, coef, dgamma, dbeta, accumulate, groups);
     CTL_LAUNCH_CHECK("bn_bwd_finalize");
     return CTL_OK;
