@@ -229,7 +229,7 @@ extern "C" int ctl_debug_timing(unsigned long long* out8) {
 #define CTL_LB_MID 3
 #endif
 #ifndef CTL_LB_SMALL
-#define CTL_LB_SMALL 4
+#define CTL_LB_SMALL 3      // (4: 28-76 B of scratch in the epilogue-operand forms of this class; 16.61 -> 16.57 ms)
 #endif
 template <int KS, int S, int MODE, int MT, int TW, int NT, int EPI, bool X2 = false>      // X2: see XStage (pro_scale = the [group][3][cin] coefficients)
 // resident blocks of the X2 instantiations: two staged tensors (and with EPI an epilogue tensor) in registers -- at 3 blocks per CU the
