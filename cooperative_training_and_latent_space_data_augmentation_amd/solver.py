@@ -92,6 +92,7 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
         self._gstate = None
         self._gk = None
         self._perturb_calls = 0          # call-site salt of the device RNG within one step
+        self._step_schemes = []          # mask schemes drawn since the start of the current cooperative_step
         self.training = True
 
     # ------------------------------------------------------------------ construction / checkpoints
@@ -478,6 +479,7 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
             random.shuffle(cands)
             perturb_type = cands[0]
         self.last_scheme = perturb_type
+        self._step_schemes.append(perturb_type)      # (every scheme drawn in this step, see _cooperative_step)
         self._perturb_calls += 1
         salt, gstate = self._perturb_calls, self._gstate
         if perturb_type == "dropout":
@@ -702,6 +704,7 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
         8 loss tensors (device scalars): standard (seg, image, gt_shape, shape) + hard (seg, image, shape, perturbed)."""
         self.train()
         self._perturb_calls = 0
+        self._step_schemes = []
         if self._gstate is not None:
             ops.step_tick(self._gstate)           # (graph capture) RNG counter and Adam step advance on the device
         self.reset_all_optimizers()
@@ -727,7 +730,11 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
             self._ensure_chains_overlap()
             std, hard = self._two_chain_forward(clean_image_l, label_l, image_l, img_cfg, seg_cfg, separate_training, image_override,
                                                 seg_override)
-            if self.split_backward and self.defer_param_grads:
+            # Under stream capture the two-sweep form only pays for the dropout scheme: with targeted masks the hipGraph replay of the
+            # two-sweep step is 13 % SLOWER than that of the one-sweep step (21.4 vs 18.9 ms), while the live streams gain 1.3 % (17.77 vs
+            # 18.00): the replay's overlap depends on the topology the capture produces (profiles/r3_split_backward_ab4.txt)
+            targeted = any(t != "dropout" for t in self._step_schemes)
+            if self.split_backward and self.defer_param_grads and not (targeted and torch.cuda.is_current_stream_capturing()):
                 # Each branch's backward is its own sweep on its own chain: the standard branch lives on the main chain alone (FTN encoder,
                 # its two decoders, the standard STN pair) and its forward ends ~1.5 ms before the hard branch's does on the side chain
                 # (tools/timeline.py), so its sweep starts right away.  The root gradient of the hard sweep is created ON the side
@@ -743,6 +750,8 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
                 for net in self.model.values():
                     net.collect_deferred_grads()
             else:
+                if self.split_backward:
+                    torch.cuda.current_stream().wait_stream(self._side)     # the join _two_chain_forward left to the sweeps
                 loss = (std[0] + std[1] + std[3] + std[2]) + (hard[0] + hard[1] + hard[2] + hard[3])
                 self.reset_all_optimizers()
                 self._backward(loss)
