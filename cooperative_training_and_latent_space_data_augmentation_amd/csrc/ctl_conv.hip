@@ -685,6 +685,18 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : ((MT * NT >= 4
     if (flags & CTL_EPI_STATS) flush_stats(cur_grp);
 }
 
+#ifndef CTL_WGRAD_PIPE_LAG
+#define CTL_WGRAD_PIPE_LAG 2
+#endif
+// compile-time loop: f(std::integral_constant<int, K>) for K in [K0, N)
+template <int K, int N, class F>
+__device__ __forceinline__ void ctl_unroll(F&& f) {
+    if constexpr (K < N) {
+        f(std::integral_constant<int, K>{});
+        ctl_unroll<K + 1, N>(f);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ weight gradient
 // dW[tap][ci][co] = sum_pixels x_virtual[pixel*S + tap - pad][ci] * dy[pixel][co]:  D[ci][co] += A[ci][k=pixel] B[pixel][co]
 //   A: lane l -> x[pixel 4s + (l>>4) shifted by tap][ci = l&15]   (ds_read_b32, 256 B contiguous per wave)
@@ -696,7 +708,11 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : ((MT * NT >= 4
 // (deterministic: no float atomics).
 // DY2: the output gradient is the virtual BatchNorm-backward result  A * dy + B * dy2 + C  (coefficients [group][3][cout] as the finalize
 // writes them; dy = g, dy2 = the BatchNorm input): the `apply` pass runs in this staging (see XStage X2)
-template <int KS, int S, int MODE, int MT, int TW, int NTW, bool DY2 = false>
+// PIPE (3x3 stride-1 layers with cin, cout multiples of 4): two LDS images.  While the MFMAs of tile t read one, the units of tile t+1
+// go from their staging registers into the other and the loads of tile t+2 refill those registers, one unit per k-slot, all of it
+// branch-free inside the MFMA stream: one barrier per tile, no exposed load-issue / staging phase (they were 13 % + 9 % of a tile's
+// time in the single-image loop with one block per CU, profiles/r3_wgrad_phase_timers.txt).
+template <int KS, int S, int MODE, int MT, int TW, int NTW, bool DY2 = false, bool PIPE = false>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ctl_conv d, const float* __restrict__ x,
                                                           const float* __restrict__ pro_scale,
                                                           const float* __restrict__ pro_shift,
@@ -708,7 +724,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ctl_conv d, const
     constexpr int TAPS = KS * KS;
     constexpr int DYT_FLOATS = NTW * G::TP * 16;
     constexpr int RED_FLOATS = 4 * NTW * 256;
-    constexpr int LDS_FLOATS = (G::XT_FLOATS + DYT_FLOATS > RED_FLOATS) ? (G::XT_FLOATS + DYT_FLOATS) : RED_FLOATS;
+    constexpr int BUF_FLOATS = G::XT_FLOATS + DYT_FLOATS;          // one LDS image: the input tile + the output-gradient tile
+    constexpr int IMG_FLOATS = (PIPE ? 2 : 1) * BUF_FLOATS;
+    constexpr int LDS_FLOATS = (IMG_FLOATS > RED_FLOATS) ? IMG_FLOATS : RED_FLOATS;
+    static_assert(!PIPE || (KS == 3 && S == 1 && MODE != CTL_IN_C4), "pipelined weight gradient: 3x3 stride-1 layers");
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS + (DY2 ? 5 : 2) * CTL_PRO_MAX];
     float* xt = lds;
     float* dyt = lds + G::XT_FLOATS;
@@ -816,6 +835,243 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ctl_conv d, const
     TileWalk cur;
     cur.init(blockIdx.x, gridDim.x, tiles_h, tiles_w);
     TM_DECL
+    if constexpr (PIPE) {
+        using XS = XStage<KS, S, MODE, MT, TW>;
+        constexpr int NU = XS::NU, NITEM = NU + ND, NSLOT = MT * 4;
+        constexpr bool PLAIN = CTL_MODE_IS_PLAIN(MODE);
+        static_assert(TW == 16, "pipelined weight gradient: 16-pixel-wide tiles");
+        // The loads of the pipeline go through resources built from laundered pointers: from `const __restrict__` arguments they are
+        // loads of constant memory, which the optimizer may move anywhere -- it sank every load of a tile body across the barrier,
+        // right in front of their use.
+        const float *xl = x, *dyl = dy, *dy2l = DY2 ? dy2 : dy;
+        asm volatile("" : "+s"(xl), "+s"(dyl), "+s"(dy2l));
+        const __amdgpu_buffer_rsrc_t rx = ctl_rsrc(xl, (int64_t)d.n * d.hin * d.win * d.cin * 4);
+        const __amdgpu_buffer_rsrc_t rdy = ctl_rsrc(dyl, (int64_t)d.n * d.hout * d.wout * d.cout * 4);
+        const __amdgpu_buffer_rsrc_t rdy2 = ctl_rsrc(dy2l, (int64_t)d.n * d.hout * d.wout * d.cout * 4);
+        const int ngrp = d.groups > 1 ? d.groups : 1;
+        if (d.pro_affine)
+            for (int i = tid; i < ngrp * d.cin; i += 256) { cf_scale[i] = pro_scale[i]; cf_shift[i] = pro_shift[i]; }
+        if constexpr (DY2) {
+            for (int i = tid; i < ngrp * d.cout; i += 256) {
+                const int gi = i / d.cout, ch = i - gi * d.cout;
+                cd[i] = dy_coef[(gi * 3 + 0) * d.cout + ch]; cd[CTL_PRO_MAX + i] = dy_coef[(gi * 3 + 1) * d.cout + ch];
+                cd[2 * CTL_PRO_MAX + i] = dy_coef[(gi * 3 + 2) * d.cout + ch];
+            }
+        }
+        const bool pro = d.pro_affine != 0;
+        const float slope = d.pro_slope;
+        const unsigned hv = PLAIN ? d.hin : 2 * d.hin, wv = PLAIN ? d.win : 2 * d.win;
+        const bool chan_ok = g * 16 + (tid & 3) * 4 < d.cin;
+        const bool chan_all = g * 16 + 16 <= d.cin;
+        const int xcb = chan_ok ? g * 16 + (tid & 3) * 4 : 0;
+        // L: the tile whose units are being LOADED into the staging registers; R: the tile held in them (wave-uniform scalars).
+        // `xall` / `dall`: every unit of the tile lies inside the tensor -> the tile origin rides in the scalar offset of the loads and
+        // the staging needs no masks (the fp32 MFMA shares the VALU issue port: VALU work is never hidden behind a wave's own MFMAs)
+        int L_tb = 0, L_vh0 = 0, L_vw0 = 0, L_dtb = 0, L_ho0 = 0, L_wo0 = 0, L_n = 0, R_n = 0;
+        bool L_live = false, L_xall = false, L_dall = false, R_xall = false, R_dall = false;
+        int L_oh = 0, L_ow = 0;
+        auto L_set_a = [&](bool live) {
+            const int ho0 = cur.th * G::TH, wo0 = cur.tw * TW;
+            L_live = live; L_n = live ? cur.n : 0; L_ho0 = ho0; L_wo0 = wo0;
+            L_vh0 = ho0 - G::PAD; L_vw0 = wo0 - G::PAD;
+            L_oh = PLAIN ? L_vh0 : ((ho0 >> 1) - XS::PADH); L_ow = PLAIN ? L_vw0 : ((wo0 >> 1) - XS::PADH);
+        };
+        auto L_set_b = [&]() {
+            L_tb = (((cur.n * d.hin + L_oh) * d.win + L_ow) * d.cin + g * 16) * 4;
+            L_dtb = ((cur.n * d.hout + L_ho0) * d.wout + L_wo0) * d.cout * 4;
+        };
+        auto L_set_c = [&]() {
+            L_xall = L_live && chan_all && L_vh0 >= 0 && L_vw0 >= 0 && L_vh0 + G::IH <= (int)hv && L_vw0 + G::IW <= (int)wv;
+            L_dall = L_live && L_ho0 + G::TH <= d.hout && L_wo0 + TW <= d.wout;
+        };
+        auto L_set = [&](bool live) { L_set_a(live); L_set_b(); L_set_c(); };
+        // (every memory instruction sits outside the uniform branches: with loads on both sides of a branch the compiler loses count of
+        // the loads in flight and waits for ALL of them -- vmcnt(0) in the first k-slot, i.e. for loads issued one slot earlier)
+        // Each unit's work comes in four pieces, so that every piece fits behind one pair of MFMAs: value, LDS write, address, load.
+        auto x_addr = [&](auto I) -> int {
+            constexpr int i = decltype(I)::value;
+            int vo = L_tb + xs.rel[i];             // (a unit past the tile: CTL_OOB + tile offset is still out of range)
+            if (__builtin_expect(!L_xall, 0)) {
+                const int vh = L_vh0 + (xs.rc[i] & 0xffff), vw = L_vw0 + (xs.rc[i] >> 16);
+                const bool ok = (L_live & chan_ok) & ((unsigned)vh < hv) & ((unsigned)vw < wv);
+                vo = ok ? vo : CTL_OOB;
+                xs.vmask = (xs.vmask & ~(1u << i)) | (ok ? (1u << i) : 0u);
+            }
+            return vo;
+        };
+        auto x_value = [&](auto I, f32x4 sc, f32x4 sh) -> f32x4 {
+            constexpr int i = decltype(I)::value;
+            f32x4 t = xs.v[i];                     // no prologue: out-of-range units were loaded as hardware zeros
+            if (pro) {
+                t = ctl_leaky01(t * sc + sh, slope);
+                if (__builtin_expect(!R_xall, 0)) {
+                    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                    t = ((xs.vmask >> i) & 1u) ? t : zero;      // padding stays zero
+                }
+            }
+            return t;
+        };
+        auto dy_addr = [&](auto I) -> int {
+            constexpr int i = decltype(I)::value;
+            int vo = L_dtb + drel[i];
+            if (__builtin_expect(!L_dall, 0)) {
+                const bool ok = L_live & ((unsigned)(L_ho0 + (drc[i] & 0xffff)) < (unsigned)d.hout) & ((unsigned)(L_wo0 + (drc[i] >> 16)) < (unsigned)d.wout);
+                vo = ok ? vo : CTL_OOB;
+                if constexpr (DY2) dmask = (dmask & ~(1u << i)) | ((ok & (drel[i] != CTL_OOB)) ? (1u << i) : 0u);
+            }
+            return vo;
+        };
+        auto dy_value = [&](auto I, f32x4 ca, f32x4 cb, f32x4 c3) -> f32x4 {
+            constexpr int i = decltype(I)::value;
+            f32x4 r = dv[i];
+            if constexpr (DY2) {
+                r = ca * dv[i] + cb * dv2[i] + c3;
+                if (__builtin_expect(!(R_dall && d.cout % 16 == 0), 0)) {
+                    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                    r = ((dmask >> i) & 1u) ? r : zero;     // pixels past the image contribute nothing (C alone would)
+                }
+            }
+            return r;
+        };
+        // unit k of the tile (k < NU: input unit k, else output-gradient unit k - NU)
+        auto u_value = [&](auto K, f32x4 sc, f32x4 sh, f32x4 ca, f32x4 cb, f32x4 c3) -> f32x4 {
+            constexpr int k = decltype(K)::value;
+            if constexpr (k < NU) return x_value(std::integral_constant<int, k>{}, sc, sh);
+            else return dy_value(std::integral_constant<int, k - NU>{}, ca, cb, c3);
+        };
+        auto u_write = [&](auto K, float* img_w, f32x4 v) {
+            constexpr int k = decltype(K)::value;
+            if constexpr (k < NU) *reinterpret_cast<f32x4*>(img_w + xs.lds[k]) = v;
+            else *reinterpret_cast<f32x4*>(img_w + G::XT_FLOATS + dlds[k - NU]) = v;
+        };
+        auto u_addr = [&](auto K) -> int {
+            constexpr int k = decltype(K)::value;
+            if constexpr (k < NU) return x_addr(std::integral_constant<int, k>{});
+            else return dy_addr(std::integral_constant<int, k - NU>{});
+        };
+        auto u_load = [&](auto K, int vo) {
+            constexpr int k = decltype(K)::value;
+            if constexpr (k < NU) xs.v[k] = ctl_bload4(rx, vo);
+            else {
+                dv[k - NU] = ctl_bload4(rdy, vo);
+                if constexpr (DY2) dv2[k - NU] = ctl_bload4(rdy2, vo);
+            }
+        };
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f}, ca = sh, cb = sh, c3 = sh;
+        // coefficients of the tile in the staging registers (BatchNorm group of image n)
+        auto coefs = [&](int n) {
+            const int gi = ngrp > 1 ? n / group_n : 0;
+            if (pro) {
+                sc = *reinterpret_cast<const f32x4*>(cf_scale + gi * d.cin + xcb); sh = *reinterpret_cast<const f32x4*>(cf_shift + gi * d.cin + xcb);
+            }
+            if constexpr (DY2) {
+                const float* cc = cd + gi * d.cout + dco;
+                ca = *reinterpret_cast<const f32x4*>(cc); cb = *reinterpret_cast<const f32x4*>(cc + CTL_PRO_MAX);
+                c3 = *reinterpret_cast<const f32x4*>(cc + 2 * CTL_PRO_MAX);
+            }
+        };
+        auto all_units = [&](auto&& f) { ctl_unroll<0, NITEM>(f); };
+        // tile 0 -> image 0, tile 1 -> the staging registers, L -> tile 2
+        L_set((int)blockIdx.x < ntiles);
+        all_units([&](auto K) { u_load(K, u_addr(K)); });
+        __syncthreads();                                   // the coefficient tables
+        R_xall = L_xall; R_dall = L_dall;
+        coefs(L_n);
+        all_units([&](auto K) { u_write(K, lds, u_value(K, sc, sh, ca, cb, c3)); });
+        cur.next();
+        L_set((int)blockIdx.x + (int)gridDim.x < ntiles);
+        all_units([&](auto K) { u_load(K, u_addr(K)); });
+        R_xall = L_xall; R_dall = L_dall;
+        coefs(L_n);
+        cur.next();
+        L_set((int)blockIdx.x + 2 * (int)gridDim.x < ntiles);
+        ctl_barrier_lds_writes_done();
+        // one lane address per M-tile and operand (image 0); every tap / k-slot / cout tile is an immediate offset from it
+        const float *xrb0[MT], *drb0[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            xrb0[m] = lds + (((wave * MT + m) * G::IWP + q) * 16 + p);
+            drb0[m] = lds + G::XT_FLOATS + (((wave * MT + m) * TW + q) * 16 + p);
+        }
+        int img = 0;
+        for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+            TM_COUNT(6)
+            const float *xrb[MT], *drb[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) { xrb[m] = xrb0[m] + img * BUF_FLOATS; drb[m] = drb0[m] + img * BUF_FLOATS; }
+            float* img_w = lds + (img ^ 1) * BUF_FLOATS;
+            // The operands of a k-slot are read one slot ahead (two register sets).  A slot is nine MFMA pairs (one per tap); behind
+            // each pair goes one small piece of the other work -- the next slot's operand reads (taps 0-2), this slot's unit of the
+            // staging (value, LDS write, address, load: taps 3-6) and, in the last slot, the scalars of the next tile (taps 7-8) --
+            // so that it issues while the pair executes.  MFMAs have no side effects: the two empty asm statements tie each pair to
+            // its place (instruction selection would sink them below every fence), the fences keep the machine scheduler from
+            // regrouping what the asm statements ordered.
+            float af[2][TAPS], bf[2][NTW];
+            f32x4 stg = {0.f, 0.f, 0.f, 0.f};
+            int ldvo = CTL_OOB;
+            auto opread = [&](auto J, auto T0, auto T1, bool with_b) {
+                constexpr int slot = decltype(J)::value, m = slot / 4, s = slot % 4;
+                if (with_b) {
+#pragma unroll
+                    for (int t = 0; t < NTW; ++t) bf[slot & 1][t] = drb[m][(t * G::TP + 4 * s) * 16];
+                }
+#pragma unroll
+                for (int tap = decltype(T0)::value; tap < decltype(T1)::value; ++tap)
+                    af[slot & 1][tap] = xrb[m][((tap / KS) * G::IWP + 4 * s + tap % KS) * 16];
+            };
+            opread(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, TAPS>{}, true);
+            TM(0)
+            ctl_unroll<0, NSLOT>([&](auto J) {
+                constexpr int slot = decltype(J)::value;
+                constexpr int NXT = (slot + 1 < NSLOT) ? slot + 1 : 0;
+                // the unit staged / loaded in this slot (at most one: NITEM <= NSLOT)
+                constexpr int UK = [] { for (int k = 0; k < NITEM; ++k) if (k * NSLOT / NITEM == slot) return k; return -1; }();
+                ctl_unroll<0, TAPS>([&](auto T) {
+                    constexpr int tap = decltype(T)::value;
+                    asm volatile("" : "+v"(af[slot & 1][tap]));
+#pragma unroll
+                    for (int t = 0; t < NTW; ++t)
+                        acc[tap][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[slot & 1][tap], bf[slot & 1][t], acc[tap][t], 0, 0, 0);
+                    // (the output tie names the pair issued CTL_WGRAD_PIPE_LAG pairs earlier, which has completed: a tie on the pair
+                    // just issued makes the compiler wait for its result before the piece below, out of the pair's shadow)
+                    constexpr int tp = (tap + TAPS - CTL_WGRAD_PIPE_LAG) % TAPS;
+                    if constexpr (NTW == 2) asm volatile("" : "+a"(acc[tp][0]), "+a"(acc[tp][NTW - 1]) :: "memory");
+                    else asm volatile("" : "+a"(acc[tp][0]) :: "memory");
+                    if constexpr (tap < 3) {
+                        if constexpr (slot + 1 < NSLOT)
+                            opread(std::integral_constant<int, NXT>{}, std::integral_constant<int, 3 * tap>{}, std::integral_constant<int, 3 * tap + 3>{}, tap == 0);
+                    } else if constexpr (UK >= 0) {
+                        constexpr int UKK = UK >= 0 ? UK : 0;
+                        if constexpr (tap == 3) stg = u_value(std::integral_constant<int, UKK>{}, sc, sh, ca, cb, c3);
+                        else if constexpr (tap == 4) u_write(std::integral_constant<int, UKK>{}, img_w, stg);
+                        else if constexpr (tap == 5) ldvo = u_addr(std::integral_constant<int, UKK>{});
+                        else if constexpr (tap == 6) u_load(std::integral_constant<int, UKK>{}, ldvo);
+                    }
+                    // the last slot, behind its unit if it has one: every unit of the tile in the registers is staged -> R <- L, L <- next
+                    if constexpr (slot == NSLOT - 1) {
+                        constexpr int P0 = UK >= 0 ? 7 : 3;          // first free piece
+                        if constexpr (tap == P0) { R_xall = L_xall; R_dall = L_dall; coefs(L_n); cur.next(); }
+                        if constexpr (UK >= 0) {
+                            if constexpr (tap == 8) L_set(tile + 3 * (int)gridDim.x < ntiles);
+                        } else {
+                            if constexpr (tap == 5) L_set_a(tile + 3 * (int)gridDim.x < ntiles);
+                            if constexpr (tap == 6) L_set_b();
+                            if constexpr (tap == 7) L_set_c();
+                        }
+                    }
+                    if constexpr (tap == 8) {
+#pragma unroll
+                        for (int t = 0; t < NTW; ++t) bsum[t] += bf[slot & 1][t];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            });
+            TM(1)
+            ctl_barrier_lds_writes_done();       // everybody is done reading this image and has written the other
+            TM(2)
+            img ^= 1;
+        }
+    } else {
     if ((int)blockIdx.x < ntiles) {
         xs.load(rx, d, cur.n, cur.th * G::TH, cur.tw * TW, g);
         dyload(cur.n, cur.th * G::TH, cur.tw * TW);
@@ -881,6 +1137,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ctl_conv d, const
         TM(3)
         ctl_barrier_lds_writes_done();
         TM(4)
+    }
     }
     __syncthreads();
 #ifdef CTL_TIMING_WGRAD
@@ -1414,6 +1671,9 @@ extern "C" int ctl_conv_forward_ex(const ctl_conv* d, const float* x, const floa
 }
 
 // ---- wgrad host side
+#ifndef CTL_WGRAD_PIPE
+#define CTL_WGRAD_PIPE 1
+#endif
 struct wgrad_cfg { ctl_conv_cfg c; int ntw, splits, ntiles, cin_p, cout_p; };
 
 struct wgrad_call {
@@ -1461,6 +1721,23 @@ static void wgrad_go(wgrad_call& a) {
     w.splits = splits;
     if (a.query) return;
     const dim3 grid((unsigned)splits, (unsigned)w.c.g, (unsigned)(w.c.cot / NTW));
+    if constexpr (KS == 3 && S == 1 && MODE != CTL_IN_C4) {
+        // Two LDS images, staging inside the MFMA stream.  Measured alone (profiles/r3_wgrad_pipe.txt): with the two-tensor output
+        // gradient 5-8 % faster than the single-image loop on layers with >= 16 tiles per block (its extra loads and FMAs ride behind
+        // the MFMAs), equal without it, 10 % slower at 4 tiles per block (one more exposed load latency per block) -> 1 = the
+        // two-tensor launches with >= 8 tiles per block, 2 = every eligible launch, 0 = off
+        static const int pipe = ctl_tune_int("CTL_WGRAD_PIPE", CTL_WGRAD_PIPE);
+        const bool pipe_on = pipe >= 2 || (pipe == 1 && a.dy2 && w.ntiles >= 8 * splits);
+        if (pipe_on && a.d->cin % 4 == 0 && a.d->cout % 4 == 0 && a.d->cin <= CTL_PRO_MAX) {
+            if (a.dy2)
+                conv_wgrad_kernel<KS, S, MODE, MT, TW, NTW, true, true><<<grid, dim3(256), 0, a.stream>>>(
+                    *a.d, a.x, a.pro_scale, a.pro_shift, a.dy, a.w_partial, a.b_partial, w.c.tiles_h, w.c.tiles_w, w.ntiles, w.cin_p, w.cout_p, a.dy2, a.dy_coef);
+            else
+                conv_wgrad_kernel<KS, S, MODE, MT, TW, NTW, false, true><<<grid, dim3(256), 0, a.stream>>>(
+                    *a.d, a.x, a.pro_scale, a.pro_shift, a.dy, a.w_partial, a.b_partial, w.c.tiles_h, w.c.tiles_w, w.ntiles, w.cin_p, w.cout_p, nullptr, nullptr);
+            return;
+        }
+    }
     if constexpr (KS == 3 && S == 1) {      // the two-tensor output gradient: the 3x3 convs of the residual blocks and of the encoder heads
         if (a.dy2) {
             conv_wgrad_kernel<KS, S, MODE, MT, TW, NTW, true><<<grid, dim3(256), 0, a.stream>>>(

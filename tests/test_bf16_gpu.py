@@ -263,7 +263,9 @@ def _apply_on_device(g, u, coef, groups, b16=True):
 
 
 BNPRO = [(2, 16, 16, 32, 32, 1), (4, 32, 16, 24, 20, 2), (2, 64, 64, 16, 16, 1), (2, 128, 64, 8, 8, 2), (16, 16, 16, 128, 128, 1), (3, 48, 32, 19, 37, 1),
-         (32, 16, 16, 64, 64, 2)]
+         (32, 16, 16, 64, 64, 2),
+         # >= 8 tiles per block of the fp32 weight gradient: the pipelined (two LDS images) kernel, whole and ragged tiles, two groups
+         (8, 64, 64, 64, 64, 1), (16, 64, 32, 60, 52, 2)]
 
 
 @pytest.mark.parametrize("family", ["bf16", "fp32"])

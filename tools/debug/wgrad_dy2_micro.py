@@ -2,10 +2,13 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from _variant import use_variant
+use_variant()               # CTL_TOOL_LIB=<name>: an A/B build of the kernels (tools/build_variant.sh)
 from cooperative_training_and_latent_space_data_augmentation_amd import _ffi, ops
 from cooperative_training_and_latent_space_data_augmentation_amd._ffi import lib, check
 LAYERS = [(32, 16, 16, 256), (32, 32, 32, 128), (32, 64, 64, 64), (32, 128, 128, 32), (16, 64, 64, 64), (16, 128, 128, 16)]
-for b16 in (False, True):
+for b16 in ((False,) if os.environ.get("FP32_ONLY") else (False, True)):
     for n, cin, cout, h in LAYERS:
         dt = (_ffi.DT_BF16 | _ffi.DT_X16 | _ffi.DT_Y16) if b16 else 0
         td = torch.bfloat16 if b16 else torch.float32
