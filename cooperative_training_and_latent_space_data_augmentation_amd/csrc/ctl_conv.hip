@@ -685,6 +685,9 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : ((MT * NT >= 4
     if (flags & CTL_EPI_STATS) flush_stats(cur_grp);
 }
 
+#ifndef CTL_WGRAD_PIPE_ABLATE
+#define CTL_WGRAD_PIPE_ABLATE 0
+#endif
 #ifndef CTL_WGRAD_PIPE_LAG
 #define CTL_WGRAD_PIPE_LAG 2
 #endif
@@ -993,12 +996,31 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ctl_conv d, const
             xrb0[m] = lds + (((wave * MT + m) * G::IWP + q) * 16 + p);
             drb0[m] = lds + G::XT_FLOATS + (((wave * MT + m) * TW + q) * 16 + p);
         }
+        // EARLY: the last k-slot stages no unit, and its operands are read one slot ahead -- the tile's last LDS access is the unit write
+        // of the slot before it.  The barrier goes there, and the last slot's spare pieces read the NEXT tile's first operands from the
+        // other image: no LDS latency and no barrier skew between the last MFMA of a tile and the first of the next.
+        constexpr bool EARLY = NSLOT >= 2 && NSLOT % 2 == 0 && (NITEM - 1) * NSLOT / NITEM < NSLOT - 1;
+        float af[2][TAPS], bf[2][NTW];
+        auto opread_from = [&](const float* const* xb, const float* const* db, auto J, auto T0, auto T1, bool with_b) {
+            constexpr int slot = decltype(J)::value, m = slot / 4, s = slot % 4;
+            if (with_b) {
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) bf[slot & 1][t] = db[m][(t * G::TP + 4 * s) * 16];
+            }
+#pragma unroll
+            for (int tap = decltype(T0)::value; tap < decltype(T1)::value; ++tap)
+                af[slot & 1][tap] = xb[m][((tap / KS) * G::IWP + 4 * s + tap % KS) * 16];
+        };
+        if constexpr (EARLY) opread_from(xrb0, drb0, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, TAPS>{}, true);
         int img = 0;
         for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
             TM_COUNT(6)
-            const float *xrb[MT], *drb[MT];
+            const float *xrb[MT], *drb[MT], *xrn[MT], *drn[MT];          // this tile's image, the next tile's
 #pragma unroll
-            for (int m = 0; m < MT; ++m) { xrb[m] = xrb0[m] + img * BUF_FLOATS; drb[m] = drb0[m] + img * BUF_FLOATS; }
+            for (int m = 0; m < MT; ++m) {
+                xrb[m] = xrb0[m] + img * BUF_FLOATS; drb[m] = drb0[m] + img * BUF_FLOATS;
+                xrn[m] = xrb0[m] + (img ^ 1) * BUF_FLOATS; drn[m] = drb0[m] + (img ^ 1) * BUF_FLOATS;
+            }
             float* img_w = lds + (img ^ 1) * BUF_FLOATS;
             // The operands of a k-slot are read one slot ahead (two register sets).  A slot is nine MFMA pairs (one per tap); behind
             // each pair goes one small piece of the other work -- the next slot's operand reads (taps 0-2), this slot's unit of the
@@ -1006,20 +1028,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ctl_conv d, const
             // so that it issues while the pair executes.  MFMAs have no side effects: the two empty asm statements tie each pair to
             // its place (instruction selection would sink them below every fence), the fences keep the machine scheduler from
             // regrouping what the asm statements ordered.
-            float af[2][TAPS], bf[2][NTW];
             f32x4 stg = {0.f, 0.f, 0.f, 0.f};
             int ldvo = CTL_OOB;
-            auto opread = [&](auto J, auto T0, auto T1, bool with_b) {
-                constexpr int slot = decltype(J)::value, m = slot / 4, s = slot % 4;
-                if (with_b) {
-#pragma unroll
-                    for (int t = 0; t < NTW; ++t) bf[slot & 1][t] = drb[m][(t * G::TP + 4 * s) * 16];
-                }
-#pragma unroll
-                for (int tap = decltype(T0)::value; tap < decltype(T1)::value; ++tap)
-                    af[slot & 1][tap] = xrb[m][((tap / KS) * G::IWP + 4 * s + tap % KS) * 16];
-            };
-            opread(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, TAPS>{}, true);
+            auto opread = [&](auto J, auto T0, auto T1, bool with_b) { opread_from(xrb, drb, J, T0, T1, with_b); };
+            if constexpr (!EARLY) opread(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, TAPS>{}, true);
             TM(0)
             ctl_unroll<0, NSLOT>([&](auto J) {
                 constexpr int slot = decltype(J)::value;
@@ -1028,24 +1040,28 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ctl_conv d, const
                 constexpr int UK = [] { for (int k = 0; k < NITEM; ++k) if (k * NSLOT / NITEM == slot) return k; return -1; }();
                 ctl_unroll<0, TAPS>([&](auto T) {
                     constexpr int tap = decltype(T)::value;
-                    asm volatile("" : "+v"(af[slot & 1][tap]));
+                    if constexpr (CTL_WGRAD_PIPE_ABLATE < 3) asm volatile("" : "+v"(af[slot & 1][tap]));      // (3 = no ties)
 #pragma unroll
                     for (int t = 0; t < NTW; ++t)
                         acc[tap][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[slot & 1][tap], bf[slot & 1][t], acc[tap][t], 0, 0, 0);
                     // (the output tie names the pair issued CTL_WGRAD_PIPE_LAG pairs earlier, which has completed: a tie on the pair
                     // just issued makes the compiler wait for its result before the piece below, out of the pair's shadow)
                     constexpr int tp = (tap + TAPS - CTL_WGRAD_PIPE_LAG) % TAPS;
-                    if constexpr (NTW == 2) asm volatile("" : "+a"(acc[tp][0]), "+a"(acc[tp][NTW - 1]) :: "memory");
+                    if constexpr (CTL_WGRAD_PIPE_ABLATE >= 3) {}
+                    else if constexpr (NTW == 2) asm volatile("" : "+a"(acc[tp][0]), "+a"(acc[tp][NTW - 1]) :: "memory");
                     else asm volatile("" : "+a"(acc[tp][0]) :: "memory");
-                    if constexpr (tap < 3) {
+                    if constexpr (tap < 3 && CTL_WGRAD_PIPE_ABLATE < 2) {          // (2 = no operand reads either)
                         if constexpr (slot + 1 < NSLOT)
                             opread(std::integral_constant<int, NXT>{}, std::integral_constant<int, 3 * tap>{}, std::integral_constant<int, 3 * tap + 3>{}, tap == 0);
-                    } else if constexpr (UK >= 0) {
+                        else if constexpr (EARLY)         // (behind the barrier of the slot before: the next tile's first operands)
+                            opread_from(xrn, drn, std::integral_constant<int, 0>{}, std::integral_constant<int, 3 * tap>{}, std::integral_constant<int, 3 * tap + 3>{}, tap == 0);
+                    } else if constexpr (UK >= 0 && CTL_WGRAD_PIPE_ABLATE < 1) {      // (timing ablations: 1 = no staging, wrong results)
                         constexpr int UKK = UK >= 0 ? UK : 0;
-                        if constexpr (tap == 3) stg = u_value(std::integral_constant<int, UKK>{}, sc, sh, ca, cb, c3);
-                        else if constexpr (tap == 4) u_write(std::integral_constant<int, UKK>{}, img_w, stg);
-                        else if constexpr (tap == 5) ldvo = u_addr(std::integral_constant<int, UKK>{});
-                        else if constexpr (tap == 6) u_load(std::integral_constant<int, UKK>{}, ldvo);
+                        constexpr bool ST = CTL_WGRAD_PIPE_ABLATE != -1, LD = CTL_WGRAD_PIPE_ABLATE != -2;      // (-1: no LDS writes, -2: no loads)
+                        if constexpr (tap == 3 && ST) stg = u_value(std::integral_constant<int, UKK>{}, sc, sh, ca, cb, c3);
+                        else if constexpr (tap == 4 && ST) u_write(std::integral_constant<int, UKK>{}, img_w, stg);
+                        else if constexpr (tap == 5 && LD) ldvo = u_addr(std::integral_constant<int, UKK>{});
+                        else if constexpr (tap == 6 && LD) u_load(std::integral_constant<int, UKK>{}, ldvo);
                     }
                     // the last slot, behind its unit if it has one: every unit of the tile in the registers is staged -> R <- L, L <- next
                     if constexpr (slot == NSLOT - 1) {
@@ -1063,12 +1079,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ctl_conv d, const
 #pragma unroll
                         for (int t = 0; t < NTW; ++t) bsum[t] += bf[slot & 1][t];
                     }
+                    if constexpr (EARLY && slot == NSLOT - 2 && tap == 4) {
+                        TM(1)
+                        ctl_barrier_lds_writes_done();       // everybody is done reading this image and has written the other
+                        TM(2)
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 });
             });
-            TM(1)
-            ctl_barrier_lds_writes_done();       // everybody is done reading this image and has written the other
-            TM(2)
+            if constexpr (!EARLY) {
+                TM(1)
+                ctl_barrier_lds_writes_done();       // everybody is done reading this image and has written the other
+                TM(2)
+            }
             img ^= 1;
         }
     } else {
