@@ -685,6 +685,9 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : ((MT * NT >= 4
     if (flags & CTL_EPI_STATS) flush_stats(cur_grp);
 }
 
+#ifndef CTL_WGRAD_PIPE_ASM_MFMA
+#define CTL_WGRAD_PIPE_ASM_MFMA 0      // 1: the MFMA pairs as volatile asm (in place, no ties): measured 1.5-3 % slower, see the loop
+#endif
 #ifndef CTL_WGRAD_PIPE_ABLATE
 #define CTL_WGRAD_PIPE_ABLATE 0
 #endif
@@ -1040,6 +1043,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ctl_conv d, const
                 constexpr int UK = [] { for (int k = 0; k < NITEM; ++k) if (k * NSLOT / NITEM == slot) return k; return -1; }();
                 ctl_unroll<0, TAPS>([&](auto T) {
                     constexpr int tap = decltype(T)::value;
+#if CTL_WGRAD_PIPE_ASM_MFMA
+                    // The pair as ONE volatile asm statement: in place (the builtin form lets the register allocator rotate accumulator
+                    // tiles, ~80 v_accvgpr moves per tile at the loop's back edge) and ordered like every other side effect, so no
+                    // ties are needed; 148 + 72 registers instead of 164 + 104.  Safe without the compiler's hazard tracking: an
+                    // accumulator tile is touched again 17 MFMAs later at the earliest, and the code behind the loop reads the tiles
+                    // behind a barrier.  Measured (profiles/r3_wgrad_pipe.txt): 54.3 vs 53.5 us (64->64 at 64^2), 99.6 vs 96.7 with the
+                    // second tensor -- the moves were not what the loop loses its time to; off.
+                    if constexpr (NTW == 2)
+                        asm volatile("v_mfma_f32_16x16x4_f32 %0, %2, %3, %0\n\tv_mfma_f32_16x16x4_f32 %1, %2, %4, %1"
+                                     : "+a"(acc[tap][0]), "+a"(acc[tap][1]) : "v"(af[slot & 1][tap]), "v"(bf[slot & 1][0]), "v"(bf[slot & 1][NTW - 1]) : "memory");
+                    else
+                        asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[tap][0]) : "v"(af[slot & 1][tap]), "v"(bf[slot & 1][0]) : "memory");
+#else
                     if constexpr (CTL_WGRAD_PIPE_ABLATE < 3) asm volatile("" : "+v"(af[slot & 1][tap]));      // (3 = no ties)
 #pragma unroll
                     for (int t = 0; t < NTW; ++t)
@@ -1050,6 +1066,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ctl_conv d, const
                     if constexpr (CTL_WGRAD_PIPE_ABLATE >= 3) {}
                     else if constexpr (NTW == 2) asm volatile("" : "+a"(acc[tp][0]), "+a"(acc[tp][NTW - 1]) :: "memory");
                     else asm volatile("" : "+a"(acc[tp][0]) :: "memory");
+#endif
                     if constexpr (tap < 3 && CTL_WGRAD_PIPE_ABLATE < 2) {          // (2 = no operand reads either)
                         if constexpr (slot + 1 < NSLOT)
                             opread(std::integral_constant<int, NXT>{}, std::integral_constant<int, 3 * tap>{}, std::integral_constant<int, 3 * tap + 3>{}, tap == 0);
@@ -1094,6 +1111,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ctl_conv d, const
             }
             img ^= 1;
         }
+#if CTL_WGRAD_PIPE_ASM_MFMA
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // the last MFMAs complete before anything reads their tiles
+#endif
     } else {
     if ((int)blockIdx.x < ntiles) {
         xs.load(rx, d, cur.n, cur.th * G::TH, cur.tw * TW, g);
