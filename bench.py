@@ -6,12 +6,14 @@ codes) + hard_example_training + backward + 5x Adam, fp32, one process per GPU.
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0.  `roofline` is measured live: HIP events bracket every launch of the dominant kernel
-(on the launch stream).  `cpu_baseline` times the CPU oracle (oracle/ref_cpu.py, a port of the reference's PyTorch-CPU
-path) on one step of the same workload on the host cores (N=1 only).  At N=1 the line also carries `roofline_families`
-(weight gradients, BatchNorm-backward passes, ... of the same step) and two sub-records measured by child processes
-running this same script: `config3_bf16` (BASELINE configs[2]: targeted masks, bf16) and `config5_inference`
-(configs[4]: 192x192 volume inference); the headline keys are configs[1] and nothing else."""
+The LAST line of stdout (rank 0) is ONE JSON object of at most 3 KB (`headline()` below): the driver's contract keys, `roofline`
+of the kernel with the largest serial time in the step (arg-max of the per-launch HIP-event profile, measured live on the
+launch stream), `cpu_baseline` (the CPU oracle oracle/ref_cpu.py, a port of the reference's PyTorch-CPU path, timed on one step
+of the same workload on the host cores, N=1 only) and, at N=1, two sub-records cut down to six numbers each: `config3_bf16`
+(BASELINE configs[2]: targeted masks, bf16) and `config5_inference` (configs[4]: 192x192 volume inference), measured by
+child processes running this same script.  Everything else (per-family / per-kernel rooflines, per-step times, allocation
+counters, mode calibration, the full sub-records) goes to `bench_detail.json` next to this script and, as one line prefixed
+`BENCH_DETAIL `, to stderr -- stdout carries nothing but the headline line."""
 import argparse
 import json
 import os
@@ -36,14 +38,13 @@ MASKS = {"dropout": (DROP_IMG, DROP_SEG, "dropout latent masks"),               
 PEAK_MFMA_F32_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
 PEAK_MFMA_BF16_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak
 PEAK_HBM_GBS = 8000.0
-# dominant kernel of this workload per profiles/ (rocprofv3 --kernel-trace --stats): the 3x3 stride-1 implicit-GEMM conv
-# at 8x32 tiles / 16 output channels, plain epilogue: the 16->16 convs and data gradients at 256x256 (and 32->16 at 128x128); the
-# launches of the same template with an epilogue operand, the two-tensor prologue or < 16 output channels have their own ids
+# the dominant kernel is not a constant: it is the profiling id with the largest serial time in a single-stream replay of the step
+# (every launch bracketed with HIP events on its launch stream), picked before the timed region and re-measured behind it
 PROF_EVERY = 4                   # inside the timed region the dominant kernel's launches are sampled (two event records per launch cost
                                  # a launch-bound step ~1.5 %); the single-stream replay behind it brackets every launch
 SINGLE_STREAM_STEPS = 5
-DOMINANT = "conv_igemm<ks3,s1,in0,mt4,tw32,nt1>"
-DOMINANT_BF16 = "conv_igemm_bf16<ks3,s1,in0,mt4,tw32,nt1>"
+HEADLINE_MAX_BYTES = 3072        # the driver keeps the last ~8 KB of stdout and parses the last line: the headline line stays under 3 KB
+DETAIL_FILE = "bench_detail.json"
 
 
 def synthetic(n, h, w, seed, device):
@@ -120,9 +121,10 @@ def cpu_baseline(host_batch, threads, steps=3, cfgs=(DROP_IMG, DROP_SEG), what="
         s.cooperative_step(clean, label, noisy, cfgs[0], cfgs[1])
         times.append(time.perf_counter() - t0)
     med = sorted(times[1:])[len(times[1:]) // 2]
-    return {"value": clean.shape[0] / med, "unit": "slices/s", "cores": threads, "kind": "port",
-            "sample": f"full cooperative step (bs{clean.shape[0]}, {clean.shape[-1]}x{clean.shape[-1]}, {what}; fp32, the reference's arithmetic) of oracle/ref_cpu.py on {threads} torch "
-                      f"threads: 1 warm-up ({times[0]:.1f} s) + {steps} timed steps, median {med:.1f} s (all: {[round(t, 1) for t in times[1:]]})"}
+    n, hw = clean.shape[0], clean.shape[-1]
+    return {"value": n / med, "unit": "slices/s", "cores": threads, "kind": "port",
+            "sample": f"oracle/ref_cpu.py, full cooperative step bs{n} {hw}x{hw} fp32, {threads} torch threads: 1 warm-up + {steps} timed steps, median {med:.1f} s/step",
+            "sample_detail": f"{what}; warm-up {times[0]:.1f} s, timed {[round(t, 1) for t in times[1:]]} s; the reference's arithmetic"}
 
 
 def _narrow(k):
@@ -167,15 +169,19 @@ def family_rooflines(prof, dtype, steps):
     return out
 
 
-def sub_record(argv, keep):
-    """Run this script in a child process (never an exec of this one: it holds the GPU) and return its JSON line, cut down to `keep`."""
+def sub_record(argv, tag):
+    """Run this script in a child process (never an exec of this one: it holds the GPU) and return its full record: the child writes
+    its detail file, the parent embeds it; the child's stdout line is its own (cut-down) headline."""
+    dfile = f"bench_detail_{tag}.json"
     try:
-        r = subprocess.run([sys.executable, os.path.abspath(__file__)] + argv, capture_output=True, text=True, timeout=900, cwd=ROOT)
+        r = subprocess.run([sys.executable, os.path.abspath(__file__)] + argv + ["--detail-file", dfile], capture_output=True, text=True, timeout=900, cwd=ROOT)
         lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
         if r.returncode != 0 or not lines:
             return {"error": f"rc={r.returncode}: {r.stderr[-300:]}"}
-        rec = json.loads(lines[-1])
-        return rec if keep is None else {k: rec[k] for k in keep if k in rec}
+        try:
+            return json.load(open(os.path.join(ROOT, dfile)))
+        except (OSError, ValueError):
+            return json.loads(lines[-1])
     except Exception as exc:
         return {"error": f"{type(exc).__name__}: {str(exc)[:200]}"}
 
@@ -243,10 +249,9 @@ def inference_main(args, device):
                 ts.append(time.perf_counter() - t0)
         med = sorted(ts[1:])[1]
         out["cpu_baseline"] = {"value": slices / med, "unit": "slices/s", "cores": threads, "kind": "port",
-                               "sample": f"the same {slices}-slice volume in chunks of 10 through oracle/ref_cpu.py predict(n_iter={n_iter}) + argmax on {threads} "
-                                         f"torch threads: 1 warm-up + 3 volumes, median {med:.2f} s"}
-    flush_c_stdio()
-    print(json.dumps(out), flush=True)
+                               "sample": f"oracle/ref_cpu.py predict(n_iter={n_iter})+argmax, {slices}-slice volume in chunks of 10, {threads} torch threads: "
+                                         f"1 warm-up + 3 volumes, median {med:.2f} s"}
+    emit(out, args)
 
 
 def flush_c_stdio():
@@ -283,7 +288,9 @@ def main():
                     help="A/B aid: set a plan-compiler switch before the solver is built, e.g. nets.FUSE_BNBWD=True")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
-    ap.add_argument("--prof-filter", default=None)
+    ap.add_argument("--prof-filter", default=None, help="profiling id to report as `roofline.kernel` instead of the arg-max of serial time")
+    ap.add_argument("--detail-file", default=DETAIL_FILE, help="where the full record goes (relative to this script)")
+    ap.add_argument("--detail-to-stdout", action="store_true", help="also print the BENCH_DETAIL line to stdout (before the headline line)")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even for a world of 1")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo only for control-flow tests)")
     ap.add_argument("--all-on-device0", action="store_true", help="test aid: every rank uses GPU 0 (needs --backend gloo)")
@@ -291,8 +298,6 @@ def main():
 
     if args.masks is None:
         args.masks = "targeted" if args.dtype == "bf16" else "dropout"
-    if args.prof_filter is None:
-        args.prof_filter = DOMINANT_BF16 if args.dtype == "bf16" else DOMINANT
     IMG_CFG, SEG_CFG, mask_text = MASKS[args.masks]
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -361,6 +366,38 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    fence()
+
+    def single_stream_profile(nsteps):
+        """The step replayed on ONE stream with every conv-family launch and every HBM-bound plan op bracketed by HIP events on its
+        launch stream, each with its algorithmic work (rank 0 profiles; EVERY rank replays: step() contains the gradient all-reduce).
+        In the timed region two launch chains share the GPU, so a kernel's event-timed duration there includes the time it shares
+        the CUs with the other chain; this replay is the kernel-quality figure and what rocprofv3 --kernel-trace (which serialises
+        dispatches) shows."""
+        two = getattr(solver, "two_streams", False)
+        solver.two_streams = False
+        try:
+            for _ in range(2):
+                eager_step()
+            torch.cuda.synchronize()
+            if rank == 0:
+                _ffi.prof_start("")
+            for _ in range(nsteps):
+                eager_step()
+            torch.cuda.synchronize()
+            return _ffi.prof_stop() if rank == 0 else {}
+        finally:
+            solver.two_streams = two
+
+    # which kernel is `roofline.kernel`: the arg-max of serial time over the profiling ids of one step (still untimed)
+    dominant = user_filter = args.prof_filter
+    if rank == 0 and dominant is None:
+        pre = single_stream_profile(2)
+        dominant = max(pre.items(), key=lambda kv: kv[1]["ms"])[0] if pre else ""
+    elif dominant is None:
+        single_stream_profile(2)
+        dominant = ""
+    args.prof_filter = dominant
     fence()
     # ---- execution mode (still untimed): the step as a hipGraph replay vs Python-issued launches
     from cooperative_training_and_latent_space_data_augmentation_amd.graph import CooperativeStepGraph
@@ -439,24 +476,12 @@ def main():
     step_ms = sorted(step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(args.steps))
     allocs_in_region = torch.cuda.memory_stats().get("num_device_alloc", 0) - alloc0
     prof = _ffi.prof_stop() if (rank == 0 and mode == "eager") else {}
-    # In the timed region two launch chains share the GPU (solver.two_streams), so a kernel's event-timed duration includes
-    # the time it shares the CUs with the other chain.  For the kernel-quality figure the same step is replayed on ONE stream
-    # afterwards (outside the timed region): that is also what rocprofv3 --kernel-trace shows, because it serialises dispatches.
-    prof_single, prof_all = {}, {}
-    if getattr(solver, "two_streams", False):          # EVERY rank replays (step() contains the gradient all-reduce); rank 0 profiles
-        solver.two_streams = False
-        for _ in range(2):
-            eager_step()
-        torch.cuda.synchronize()
-        if rank == 0:
-            _ffi.prof_start("")                        # every conv-family launch and every HBM-bound plan op, each with its algorithmic work
-        for _ in range(SINGLE_STREAM_STEPS):
-            eager_step()
-        torch.cuda.synchronize()
-        if rank == 0:
-            prof_all = _ffi.prof_stop()
-            prof_single = {k: v for k, v in prof_all.items() if args.prof_filter in k}
-        solver.two_streams = True
+    # kernel-quality figures: the same step on ONE stream behind the timed region (see single_stream_profile)
+    prof_all = single_stream_profile(SINGLE_STREAM_STEPS)
+    if user_filter:                                      # --prof-filter: report that id (exact, else substring match)
+        prof_single = {k: v for k, v in prof_all.items() if k == user_filter} or {k: v for k, v in prof_all.items() if user_filter in k}
+    else:                                                # the arg-max of THIS profile (the pre-region pick only chose what to sample in-region)
+        prof_single = dict([max(prof_all.items(), key=lambda kv: kv[1]["ms"])]) if prof_all else {}
     if phase_tm is not None:
         _ffi.lib.ctl_debug_timing(phase_tm)
         steps = max(phase_tm[6], 1)
@@ -507,33 +532,31 @@ def main():
                 r["sampled_every"] = sampled_every
                 r["launches_note"] = f"every {sampled_every}-th launch was bracketed: `launches` counts the samples"
             elif region_s:
-                r["share_of_step_time"] = secs / region_s
+                r["share_of_serial_kernel_time"] = secs / region_s
             return r
 
-        if prof:                                          # eager mode: HIP events around every launch of the kernel INSIDE the timed region
-            kid, rec = max(prof.items(), key=lambda kv: kv[1]["ms"])
-            out["roofline"] = roofline_of(kid, rec, dt, PROF_EVERY)
-            out["roofline"]["note"] = ("timed region: two launch chains share the GPU, so this kernel's event-timed duration includes the time it "
-                                       "shares the CUs with the other chain; kernel quality = single_stream below")
-            if kid in prof_single:
-                r1 = roofline_of(kid, prof_single[kid])
-                out["roofline"]["single_stream"] = {
-                    "achieved": r1["achieved"], "frac": r1["frac"], "avg_us": r1["avg_us"], "launches": r1["launches"],
-                    "note": "same kernel, same step replayed on one stream after the timed region (no second chain sharing the CUs); "
-                            "rocprofv3 --kernel-trace serialises dispatches and agrees with this duration"}
-        elif prof_single:                                 # graph mode: a replay has no per-launch events; same step, eager, one stream
+        # `roofline`: the profiling id with the largest serial time, from the single-stream replay behind the timed region (HIP events
+        # around EVERY launch on its launch stream; rocprofv3 --kernel-trace serialises dispatches and agrees with this duration).  In
+        # eager mode the same kernel is also sampled INSIDE the timed region (`timed_region`: there it shares the CUs with the other chain).
+        if prof_single:
             kid, rec = max(prof_single.items(), key=lambda kv: kv[1]["ms"])
-            out["roofline"] = roofline_of(kid, rec)
-            out["roofline"]["note"] = ("timed region = hipGraph replays (no per-launch events possible): HIP events around every launch of this "
-                                       "kernel in 5 eager single-stream steps run right after the timed region, same process, same inputs; "
-                                       "rocprofv3 --kernel-trace agrees with this duration")
-        tfile = os.path.join(ROOT, "profiles", "dominant_kernel_traffic_bf16.json" if args.dtype == "bf16" else "dominant_kernel_traffic.json")      # committed rocprofv3 --pmc measurement
+            out["roofline"] = roofline_of(kid, rec, sum(v["ms"] for v in prof_all.values()) * 1e-3)
+            out["roofline"]["measured"] = (f"HIP events around every launch of this id in {SINGLE_STREAM_STEPS} single-stream steps right behind the timed "
+                                           "region (same process, same inputs); id = arg-max of serial kernel time over the step's profiling ids")
+            if kid in prof:
+                r1 = roofline_of(kid, prof[kid], None, PROF_EVERY)
+                out["roofline"]["timed_region"] = {k: r1[k] for k in ("achieved", "frac", "avg_us", "launches", "sampled_every")}
+        tfile = os.path.join(ROOT, "profiles", "kernel_traffic.json")      # committed rocprofv3 --pmc measurement, keyed by profiling id
         if "roofline" in out and os.path.exists(tfile):
-            t = json.load(open(tfile))
-            if t.get("kernel") == out["roofline"]["kernel"]:
-                out["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
+            t = json.load(open(tfile)).get(args.dtype, {})
+            if out["roofline"]["kernel"] in t.get("kernels", {}):
+                out["roofline"]["traffic"] = t["kernels"][out["roofline"]["kernel"]]["hbm_bytes_per_launch"]
+                out["roofline"]["traffic_source"] = t.get("source", "profiles/kernel_traffic.json")
         if prof_all:
             out["roofline_families"] = family_rooflines(prof_all, args.dtype, SINGLE_STREAM_STEPS)
+            out["kernels_by_serial_time"] = [{"kernel": k, "ms_per_step": v["ms"] / SINGLE_STREAM_STEPS, "launches_per_step": v["launches"] / SINGLE_STREAM_STEPS,
+                                              "avg_us": 1e3 * v["ms"] / v["launches"]}
+                                             for k, v in sorted(prof_all.items(), key=lambda kv: -kv[1]["ms"])[:16]]
         if world == 1:
             out["roofline_latent_mask"] = latent_mask_roofline(device)
         if world == 1 and not args.no_cpu_baseline:
@@ -543,16 +566,65 @@ def main():
             # streams, pools and graphs; this process is idle meanwhile).  The headline keys above are untouched.
             common = ["--steps", str(args.steps), "--warmup", str(args.warmup), "--no-sub-records"] + (["--no-cpu-baseline"] if args.no_cpu_baseline else []) + \
                      (["--lib", args.lib] if args.lib else []) + [x for kv in args.set for x in ("--set", kv)]
-            out["config3_bf16"] = sub_record(["--dtype", "bf16", "--masks", "targeted"] + common,
-                                             ("metric", "value", "unit", "ms_per_step", "dtype", "mode", "mode_calibration", "step_ms", "cpu_issue_ms",
-                                              "device_allocs_in_timed_region", "launches_per_step", "roofline", "roofline_families", "cpu_baseline",
-                                              "final_losses", "config"))
-            out["config5_inference"] = sub_record(["--workload", "inference"] + common, None)
+            out["config3_bf16"] = sub_record(["--dtype", "bf16", "--masks", "targeted"] + common, "config3_bf16")
+            out["config5_inference"] = sub_record(["--workload", "inference"] + common, "config5_inference")
     if use_dist:
         dist.destroy_process_group()
+    if rank == 0:
+        emit(out, args)
+
+
+def emit(detail, args):
+    """bench_detail.json + the BENCH_DETAIL line (stderr), then the headline line: the LAST thing this job writes to stdout."""
+    detail["detail_file"] = args.detail_file
+    line = json.dumps(headline(detail))
+    assert len(line) < HEADLINE_MAX_BYTES, len(line)
+    blob = json.dumps(detail)
+    try:
+        with open(os.path.join(ROOT, args.detail_file), "w") as f:
+            f.write(blob + "\n")
+    except OSError as exc:                                # a read-only checkout must not cost the run its headline
+        print(f"bench.py: could not write {args.detail_file}: {exc}", file=sys.stderr)
+    print("BENCH_DETAIL " + blob, file=sys.stderr, flush=True)
     flush_c_stdio()
-    if rank == 0:                                         # the JSON line is the LAST thing this job writes to stdout
-        print(json.dumps(out), flush=True)
+    if args.detail_to_stdout:
+        print("BENCH_DETAIL " + blob, flush=True)
+    print(line, flush=True)
+
+
+def _sub_headline(rec):
+    if not isinstance(rec, dict) or "value" not in rec:
+        return {"error": str((rec or {}).get("error", "no record"))[:120]}
+    return {"value": rec.get("value"), "ms_per_step": rec.get("ms_per_step"), "dtype": rec.get("dtype"), "mode": rec.get("mode"),
+            "roofline_frac": (rec.get("roofline") or {}).get("frac"), "roofline_kernel": (rec.get("roofline") or {}).get("kernel"),
+            "cpu_baseline_value": (rec.get("cpu_baseline") or {}).get("value")}
+
+
+def headline(d):
+    """The driver's line: contract keys + roofline + cpu_baseline + the two sub-records cut down; nothing that grows with the workload."""
+    h = {k: d.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                               "vs_baseline", "dtype", "data")}
+    c = d.get("config", {})
+    h["config"] = {"workload": str(c.get("workload", ""))[:420], **{k: c[k] for k in ("global_batch", "parallelism") if k in c}}
+    if "mode" in d:
+        h["mode"] = d["mode"]
+    r = d.get("roofline")
+    if r:
+        h["roofline"] = {k: r.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_us", "launches", "traffic") }
+        if r.get("traffic_source"):
+            h["roofline"]["traffic_source"] = str(r["traffic_source"])[:160]
+    cb = d.get("cpu_baseline")
+    if cb:
+        h["cpu_baseline"] = {"value": cb.get("value"), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
+                             "sample": str(cb.get("sample", ""))[:160]}
+    lm = (d.get("roofline_latent_mask") or {})
+    if lm:
+        h["latent_mask_hbm_frac"] = {k.split("_")[0] + "_" + k.split("_")[-1]: (v.get("graph_replay_frac") or v.get("frac")) for k, v in lm.items()}
+    for k in ("config3_bf16", "config5_inference"):
+        if k in d:
+            h[k] = _sub_headline(d[k])
+    h["detail"] = d.get("detail_file", DETAIL_FILE)
+    return h
 
 
 if __name__ == "__main__":

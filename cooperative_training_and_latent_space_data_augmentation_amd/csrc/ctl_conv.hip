@@ -1650,6 +1650,7 @@ extern "C" int ctl_conv_forward(const ctl_conv* d, const float* x, const float* 
 // the tile configuration of d gives every wave a row pair: its CTL_EPI_TAILBWD epilogue can write the 2x2 sum-pool of g as well
 extern "C" int ctl_conv_pool_ok(const ctl_conv* d) {
     ctl_conv_cfg c;
+    if (!d) return 0;
     if (!(d->epi_flags & CTL_EPI_TAILBWD) || d->ks != 1 || d->stride != 1 || d->in_mode != CTL_IN_PLAIN || d->nsub != 1 || (d->out_h & 1) || (d->out_w & 1) ||
         d->out_h != d->hout || d->out_w != d->wout || d->cout % 16 != 0)
         return 0;
@@ -1660,9 +1661,9 @@ extern "C" int ctl_conv_forward_ex(const ctl_conv* d, const float* x, const floa
                                    const float* pro_scale, const float* pro_shift, const float* res,
                                    const float* res_scale, const float* res_shift, const float* res2, const float* x2, float* y,
                                    float* stats_partial, float* pool, float* xout, ctl_stream stream) {
+    CTL_REQUIRE(d && x && wpack && y, "conv_forward: null argument");
     CTL_REQUIRE(!xout || d->pro_affine == 2, "conv_forward: `xout` (the virtual input written out) goes with the BatchNorm-backward prologue (pro_affine 2)");
     CTL_REQUIRE(!pool || ctl_conv_pool_ok(d), "conv_forward: `pool` needs a CTL_EPI_TAILBWD 1x1 conv with even output sizes whose tile configuration gives every wave a row pair (ctl_conv_pool_ok)");
-    CTL_REQUIRE(d && x && wpack && y, "conv_forward: null argument");
     CTL_REQUIRE((d->dt & CTL_DT_BF16) || !(d->dt & (CTL_DT_X16 | CTL_DT_Y16 | CTL_DT_RES16)), "conv_forward: bf16-stored tensors need CTL_DT_BF16");
     conv_call a = {};
     a.d = d;

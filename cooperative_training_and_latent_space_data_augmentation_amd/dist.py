@@ -10,8 +10,10 @@ Round 3 (SURVEY 5 comm row / 8(e): "a single bucket, or 5 per-module buckets ove
 exchanged as its five per-network ranges.  A network's range is all-reduced (async, on the communicator's stream) as soon as the LAST
 backward pass of that network has been issued -- the decoders and the STN finish well before the FTN encoder, whose backward is the
 tail of the sweep -- and each network's Adam launch waits for its own range only.  With 17.7 MB per GPU on the ring the transfer is
-latency- not bandwidth-bound, so the point of the split is the overlap, not the size.  The sums are the same numbers in the same
-order per element (an all-reduce is element-wise): bit-identical to the single-bucket exchange (tests/test_dist_gpu.py).
+latency- not bandwidth-bound, so the point of the split is the overlap, not the size.  Every rank ends with the same bits in every
+range.  Against the single-bucket exchange the sums are bit-identical at world size 2 (one addition per element: tested,
+tests/test_dist_gpu.py); with more ranks a ring all-reduce ties each element's summation order to its position in the buffer, so
+splitting the bucket may change the fp32 rounding of a sum -- identical across ranks, not necessarily against the single bucket.
 No scaling curve has been measured by the builder (1-GPU boxes); see DESIGN.md section 5."""
 from __future__ import annotations
 
@@ -52,6 +54,7 @@ class DataParallel:
         self._works: Dict[str, object] = {}
         self.launched_in_backward = []          # (diagnostics / tests) names, in launch order, of the last step
         self.suspended = False                  # graph capture / its warm-up step: no exchange from inside backward
+        self.armed = False                      # set per step by the solver: True only if that step was given a grad_hook
         solver.grad_scale = 1.0 / self.world
         solver._dp = self
         self.overlap = overlap
@@ -73,7 +76,19 @@ class DataParallel:
             #  which is the stream that produced this range; gloo: host-side, the call returns a handle as well)
             self._works[name] = dist.all_reduce(self.bucket.ranges[name], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
 
+    def begin_step(self, exchange: bool):
+        """Called by `cooperative_step` at the head of every step.  Handles left over by a step that ended without its waits
+        (`do_optim=False`, an exception between launch and wait) are waited for and dropped: a stale handle would make `_launch`
+        skip that network's all-reduce in THIS step.  The launch from inside backward is armed only if the step has a grad_hook:
+        `grad_hook=None` means 'no exchange'."""
+        for name in list(self._works):
+            self.wait(name)
+        self.launched_in_backward = []
+        self.armed = bool(exchange)
+
     def _from_backward(self, name: str):
+        if not self.armed:
+            return
         if self.suspended or (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()):
             return                                # (graph mode: the exchange runs eagerly between the two graphs)
         self.solver.model[name].collect_deferred_grads()      # the parked per-pass gradients of this network -> its range of the bucket

@@ -701,7 +701,8 @@ class CtlNet(nn.Module):
         """Called by the autograd bridge after every forward pass.  A training-mode, tracking ('A') pass is kept: a later request to run
         the SAME input through the SAME weights in the same mode (the saliency forward of the targeted latent masks, model_util.py:214,
         decodes the code the standard pass has just decoded) re-uses its activations instead of recomputing them (`reuse_pass`)."""
-        self._last_pass = (x, x._version, act, outs, plan, getattr(self, "_wepoch", 0)) if (mode == "A" and groups == 1) else None
+        self._last_pass = ((x, x._version, act, outs, plan, getattr(self, "_wepoch", 0), tuple(o._version for o in outs))
+                           if (mode == "A" and groups == 1) else None)
 
     def forget_pass(self):
         self._last_pass = None
@@ -713,10 +714,11 @@ class CtlNet(nn.Module):
         lp = getattr(self, "_last_pass", None)
         if lp is None or self.bn_mode() != "A" or self.drop_p is not None:
             return None
-        x0, ver, act, outs, plan, wepoch = lp
-        # (x0 is held by the record, so its storage cannot have been handed to another tensor: equal pointers mean the same tensor)
+        x0, ver, act, outs, plan, wepoch, out_vers = lp
+        # (x0 is held by the record, so its storage cannot have been handed to another tensor: equal pointers mean the same tensor;
+        #  an output modified in place since the pass -- the backward reads the outputs -- voids the record as well)
         if (x0.data_ptr() != x.data_ptr() or tuple(x0.shape) != tuple(x.shape) or x0.stride() != x.stride() or x0._version != ver or
-                wepoch != getattr(self, "_wepoch", 0) or not self._packed_ok):
+                wepoch != getattr(self, "_wepoch", 0) or not self._packed_ok or tuple(o._version for o in outs) != out_vers):
             return None
 
         def backward(douts):

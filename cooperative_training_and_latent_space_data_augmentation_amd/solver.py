@@ -540,6 +540,10 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
         finally:
             set_grad(d_seg, requires_grad=True)
             set_grad(d_img, requires_grad=True)
+            # the standard pass' activations were kept for the saliency passes above (CtlNet.reuse_pass); nothing after this point
+            # may re-use them, and the record pins a whole activation arena per decoder (289 MB at bs16 256x256) until the next forward
+            d_seg.forget_pass()
+            d_img.forget_pass()
         return perturbed_image_0, perturbed_y_0
 
     # ------------------------------------------------------------------ inference (model.py:375-394, 608-664)
@@ -711,13 +715,14 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
         for net in self.model.values():
             net._defer_grads, net._deferred, net._pending_bwd = self.defer_param_grads, [], 0
         if self._dp is not None:
-            self._dp.launched_in_backward = []
+            self._dp.begin_step(grad_hook is not None)
         try:
             return self._cooperative_step(clean_image_l, label_l, image_l, img_cfg, seg_cfg, latent_DA, separate_training, image_override,
                                           seg_override, do_optim, grad_hook)
         finally:
             for net in self.model.values():
                 net._defer_grads, net._deferred = False, []
+                net.forget_pass()
 
     def _backward(self, loss):
         loss.backward()
@@ -734,7 +739,11 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
             # two-sweep step is 13 % SLOWER than that of the one-sweep step (21.4 vs 18.9 ms), while the live streams gain 1.3 % (17.77 vs
             # 18.00): the replay's overlap depends on the topology the capture produces (profiles/r3_split_backward_ab4.txt)
             targeted = any(t != "dropout" for t in self._step_schemes)
-            if self.split_backward and self.defer_param_grads and not (targeted and torch.cuda.is_current_stream_capturing()):
+            hard_sum = hard[0] + hard[1] + hard[2] + hard[3]
+            # (with neither code perturbed -- img_cfg and seg_cfg both None -- hard_example_training returns four constant zeros: nothing
+            # to sweep on the side chain, the one-sweep form below handles it)
+            if self.split_backward and self.defer_param_grads and hard_sum.requires_grad and \
+                    not (targeted and torch.cuda.is_current_stream_capturing()):
                 # Each branch's backward is its own sweep on its own chain: the standard branch lives on the main chain alone (FTN encoder,
                 # its two decoders, the standard STN pair) and its forward ends ~1.5 ms before the hard branch's does on the side chain
                 # (tools/timeline.py), so its sweep starts right away.  The root gradient of the hard sweep is created ON the side
@@ -745,14 +754,14 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
                 self.reset_all_optimizers()
                 (std[0] + std[1] + std[3] + std[2]).backward()
                 with torch.cuda.stream(self._side):
-                    (hard[0] + hard[1] + hard[2] + hard[3]).backward()
+                    hard_sum.backward()
                 torch.cuda.current_stream().wait_stream(self._side)
                 for net in self.model.values():
                     net.collect_deferred_grads()
             else:
                 if self.split_backward:
                     torch.cuda.current_stream().wait_stream(self._side)     # the join _two_chain_forward left to the sweeps
-                loss = (std[0] + std[1] + std[3] + std[2]) + (hard[0] + hard[1] + hard[2] + hard[3])
+                loss = (std[0] + std[1] + std[3] + std[2]) + hard_sum
                 self.reset_all_optimizers()
                 self._backward(loss)
             if grad_hook is not None:

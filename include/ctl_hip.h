@@ -105,9 +105,10 @@ int ctl_conv_forward(const ctl_conv* d, const float* x, const float* wpack, cons
  * CTL_EPI_ACCUM) is dL/dOut of out = leaky(S + BN(v), epi_slope); res = out, res2 = v.  y receives g = dOut * leaky'(out) and
  * stats_partial (sum g, sum g*v) per BatchNorm group: the reduction pass of the residual tail (ctl_bwd_reduce mode 0) folded into the
  * producer of dOut, which is then never materialised.  res2 == NULL: plain ctl_conv_forward. */
-/* x2 (with ctl_conv.pro_affine == 2; bf16 family, bf16-stored x / x2 / y with whole 16-channel tiles, plain 3x3 stride-1 or 4x4
- * stride-2 conv, epilogue CTL_EPI_STATS / CTL_EPI_BNBWD only): the BatchNorm-backward prologue.  The conv input is the VIRTUAL tensor
- *     A[c] * x + B[c] * x2 + C[c]     (zero outside the image; rounded to bf16 as the stored tensor would have been)
+/* x2 (with ctl_conv.pro_affine == 2; BOTH families -- fp32 tensors, or the bf16 family with bf16-stored x / x2 / y; cin % 16 == 0,
+ * plain (CTL_IN_PLAIN) 3x3 stride-1 or 4x4 stride-2 conv, groups * cin <= 256, not together with CTL_EPI_TAILBWD): the
+ * BatchNorm-backward prologue.  The conv input is the VIRTUAL tensor
+ *     A[c] * x + B[c] * x2 + C[c]     (zero outside the image; bf16 family: rounded to bf16 as the stored tensor would have been)
  * with pro_scale = the [group][A | B | C][cin] coefficients ctl_bn_bwd_finalize writes (pro_shift is not read): x = g = dL/da * leaky',
  * x2 = the BatchNorm input.  This is ctl_bwd_apply (mode 2) run inside the staging of its consumer: the data-gradient convs of a
  * residual block read (g, u) instead of dU, which is never written.  x2 == NULL and pro_affine <= 1: as before. */
@@ -134,7 +135,8 @@ size_t ctl_wgrad_bias_partial_floats(const ctl_conv* d);     /* bias part     */
 int ctl_conv_wgrad(const ctl_conv* d, const float* x, const float* pro_scale, const float* pro_shift,
                    const float* dy, float* w_partial, float* b_partial, ctl_stream stream);
 /* ... whose output gradient is the virtual BatchNorm-backward result  A[c] * dy + B[c] * dy2 + C[c]  (dy_coef = [group][A | B | C][cout]
- * from ctl_bn_bwd_finalize; bf16 family, 3x3 stride-1 convs, bf16-stored dy / dy2, cout % 16 == 0, groups * cout <= 256): the other
+ * from ctl_bn_bwd_finalize; BOTH families -- fp32 dy / dy2, or the bf16 family with bf16-stored dy / dy2; 3x3 stride-1 convs,
+ * cout % 16 == 0, groups * cout <= 256): the other
  * consumer of a block's dU / dV (see ctl_conv_forward_ex).  The bias gradient is the sum of the virtual tensor.  dy2 == NULL: ctl_conv_wgrad. */
 int ctl_conv_wgrad_ex(const ctl_conv* d, const float* x, const float* pro_scale, const float* pro_shift,
                       const float* dy, const float* dy2, const float* dy_coef, float* w_partial, float* b_partial, ctl_stream stream);

@@ -624,7 +624,7 @@ class OracleSolver:
         loss.backward()
         if do_optim:
             self.optimize_all_params()
-        return tuple(float(v) for v in std) + tuple(float(v) for v in hard)
+        return tuple(float(v.detach()) if torch.is_tensor(v) else float(v) for v in tuple(std) + tuple(hard))
 
     def predict(self, x, softmax=False, n_iter=None):
         """model.py:375-394 with 608-641: `predict` calls `slow_refinement(pred, n_steps=n_iter)` n_iter-1 times, feeding each

@@ -1,0 +1,74 @@
+"""The driver's contract on bench.py's output: the LAST line of stdout is one JSON object of at most 3 KB that
+carries the headline keys, `roofline` and `cpu_baseline`; everything else goes to bench_detail.json.  The round-3 line had grown to
+28.9 KB and overflowed the driver's ~8 KB tail window, so the driver parsed nothing."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+            "data", "config")
+
+
+def test_headline_of_the_round3_record_fits():
+    """The very record that broke the driver in round 3 (profiles/r3_bench_line_m.json, 28.9 KB) cut down by bench.headline()."""
+    import bench
+    full = json.loads(open(os.path.join(ROOT, "profiles", "r3_bench_line_m.json")).read().strip().splitlines()[-1])
+    assert len(json.dumps(full)) > 20000
+    line = json.dumps(bench.headline(full))
+    assert len(line) < bench.HEADLINE_MAX_BYTES == 3072
+    h = json.loads(line)
+    for k in CONTRACT:
+        assert k in h, k
+    assert h["value"] == full["value"] and h["ms_per_step"] == full["ms_per_step"]
+    assert set(h["config"]) == {"workload", "global_batch", "parallelism"}
+    assert h["roofline"]["frac"] == full["roofline"]["frac"] and h["roofline"]["kernel"]
+    assert h["cpu_baseline"]["value"] == full["cpu_baseline"]["value"] and len(h["cpu_baseline"]["sample"]) <= 160
+    for sub in ("config3_bf16", "config5_inference"):
+        assert set(h[sub]) == {"value", "ms_per_step", "dtype", "mode", "roofline_frac", "roofline_kernel", "cpu_baseline_value"}
+        assert h[sub]["value"] == full[sub]["value"]
+
+
+def test_headline_survives_failed_sub_records_and_missing_parts():
+    import bench
+    d = {"metric": "m", "value": 1.0, "unit": "slices/s", "n_gpus": 8, "steps": 2, "warmup": 1, "ms_per_step": 3.0, "higher_is_better": True,
+         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": {"workload": "w" * 5000, "global_batch": 128,
+                                                                                               "parallelism": "dp8"},
+         "config3_bf16": {"error": "rc=1: " + "x" * 5000}, "roofline_families": {"a": {"kernels": {str(i): {} for i in range(500)}}}}
+    line = json.dumps(bench.headline(d))
+    assert len(line) < 3072 and "roofline_families" not in line
+    assert json.loads(line)["config3_bf16"]["error"].startswith("rc=1")
+
+
+@pytest.mark.gpu
+def test_bench_last_stdout_line_is_the_small_headline(tmp_path):
+    """bench.py end to end at a small size: the last stdout line parses, is < 3 KB, carries roofline.frac and cpu_baseline.value, the
+    detail file holds the families; stdout carries nothing else."""
+    dfile = "bench_detail_test.json"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--size", "64", "--batch", "4", "--steps", "2", "--warmup", "1", "--cpu-threads", "8",
+           "--detail-file", dfile]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = out.stdout.strip().splitlines()
+    last = lines[-1]
+    assert len(last) < 3072, len(last)
+    rec = json.loads(last)
+    for k in CONTRACT:
+        assert k in rec, k
+    assert rec["value"] > 0 and rec["steps"] == 2 and rec["warmup"] == 1 and rec["n_gpus"] == 1
+    assert 0 < rec["roofline"]["frac"] < 1 and rec["roofline"]["kernel"] and rec["roofline"]["bound"] in ("mfma", "hbm")
+    assert rec["cpu_baseline"]["value"] > 0 and rec["cpu_baseline"]["kind"] == "port"
+    assert rec["config3_bf16"]["value"] > 0 and rec["config5_inference"]["value"] > 0
+    assert not any(l.startswith("BENCH_DETAIL") for l in lines)            # the big record goes to stderr and the file
+    assert any(l.startswith("BENCH_DETAIL ") for l in out.stderr.splitlines())
+    assert "UserWarning" not in out.stderr, out.stderr[-2000:]
+    detail = json.load(open(os.path.join(ROOT, dfile)))
+    assert "roofline_families" in detail and detail["value"] == rec["value"]
+    # the reported kernel is the arg-max of serial time over the profiling ids of the step
+    assert rec["roofline"]["kernel"] == detail["kernels_by_serial_time"][0]["kernel"], (rec["roofline"], detail["kernels_by_serial_time"][:3])
+    os.remove(os.path.join(ROOT, dfile))
