@@ -739,10 +739,10 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
             # two-sweep step is 13 % SLOWER than that of the one-sweep step (21.4 vs 18.9 ms), while the live streams gain 1.3 % (17.77 vs
             # 18.00): the replay's overlap depends on the topology the capture produces (profiles/r3_split_backward_ab4.txt)
             targeted = any(t != "dropout" for t in self._step_schemes)
-            hard_sum = hard[0] + hard[1] + hard[2] + hard[3]
             # (with neither code perturbed -- img_cfg and seg_cfg both None -- hard_example_training returns four constant zeros: nothing
-            # to sweep on the side chain, the one-sweep form below handles it)
-            if self.split_backward and self.defer_param_grads and hard_sum.requires_grad and \
+            # to sweep on the side chain, the one-sweep form below handles it.  The hard sum itself must NOT be formed here, on the main
+            # stream: its add nodes would tie the hard sweep to the main chain, see below -- 18.8 instead of 16.5 ms)
+            if self.split_backward and self.defer_param_grads and any(t.requires_grad for t in hard) and \
                     not (targeted and torch.cuda.is_current_stream_capturing()):
                 # Each branch's backward is its own sweep on its own chain: the standard branch lives on the main chain alone (FTN encoder,
                 # its two decoders, the standard STN pair) and its forward ends ~1.5 ms before the hard branch's does on the side chain
@@ -754,14 +754,14 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
                 self.reset_all_optimizers()
                 (std[0] + std[1] + std[3] + std[2]).backward()
                 with torch.cuda.stream(self._side):
-                    hard_sum.backward()
+                    (hard[0] + hard[1] + hard[2] + hard[3]).backward()
                 torch.cuda.current_stream().wait_stream(self._side)
                 for net in self.model.values():
                     net.collect_deferred_grads()
             else:
                 if self.split_backward:
                     torch.cuda.current_stream().wait_stream(self._side)     # the join _two_chain_forward left to the sweeps
-                loss = (std[0] + std[1] + std[3] + std[2]) + hard_sum
+                loss = (std[0] + std[1] + std[3] + std[2]) + (hard[0] + hard[1] + hard[2] + hard[3])
                 self.reset_all_optimizers()
                 self._backward(loss)
             if grad_hook is not None:
