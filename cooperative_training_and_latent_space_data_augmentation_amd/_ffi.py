@@ -9,7 +9,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libctl_hip.so")
-ABI_VERSION = 8                      # CTL_ABI_VERSION of include/ctl_hip.h this binding was written against
+ABI_VERSION = 9                      # CTL_ABI_VERSION of include/ctl_hip.h this binding was written against
 RED_BLOCKS = 512                     # CTL_RED_BLOCKS of ctl_hip.h; checked against the library's compiled value (ctl_red_blocks) at load
 
 # enums of ctl_hip.h
@@ -25,7 +25,8 @@ CONV_DTYPE = np.dtype([
     ("ks", "<i4"), ("stride", "<i4"), ("pad", "<i4"), ("in_mode", "<i4"), ("pro_affine", "<i4"), ("pro_slope", "<f4"),
     ("epi_flags", "<i4"), ("epi_act", "<i4"), ("epi_slope", "<f4"), ("out_h", "<i4"), ("out_w", "<i4"),
     ("out_sy", "<i4"), ("out_sx", "<i4"), ("nsub", "<i4"), ("out_sub", "<i4"), ("groups", "<i4"), ("dt", "<i4")])
-DT_BF16, DT_X16, DT_Y16, DT_RES16 = 1, 2, 4, 8
+DT_BF16, DT_X16, DT_Y16, DT_RES16, DT_X3 = 1, 2, 4, 8, 16
+PACK_X3 = 16                         # or-ed into the mode word of a pack record (CTL_PACK_X3)
 OP_DTYPE = np.dtype([("kind", "<i4"), ("i", "<i4", (27,)), ("f", "<f4", (4,)), ("slot", "<i4", (OP_MAX_T,)),
                      ("off", "<i8", (OP_MAX_T,)), ("l", "<i8", (4,))], align=True)
 
@@ -54,7 +55,7 @@ class _Lib:
         lib.ctl_launch_count.restype = C.c_ulonglong
         for name in ("ctl_conv_wpack_floats", "ctl_conv_stats_floats", "ctl_wgrad_partial_floats",
                      "ctl_wgrad_bias_partial_floats", "ctl_latent_score_ws_floats", "ctl_latent_mask_apply_ws_floats",
-                     "ctl_rescale_intensity_ws_floats", "ctl_sizeof_op", "ctl_sizeof_conv", "ctl_latent_mask_fused_ws_floats"):
+                     "ctl_rescale_intensity_ws_floats", "ctl_sizeof_op", "ctl_sizeof_conv", "ctl_latent_mask_fused_ws_floats", "ctl_conv_wpack_floats_x3"):
             getattr(lib, name).restype = C.c_size_t
         p, i32, i64, f32, u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64
         sig = {
@@ -109,6 +110,7 @@ class _Lib:
             "ctl_prof_start": [C.c_char_p], "ctl_prof_start_sampled": [C.c_char_p, i32], "ctl_prof_stop": [p, C.c_size_t],
             "ctl_pack_weights_batched": [p, p, p, i32, i64, p], "ctl_wgrad_reduce_batched": [p, p, p, i32, i64, p],
             "ctl_pack_weights_bf16_batched": [p, p, p, i32, i64, p],
+            "ctl_pack_weights_x3_batched": [p, p, p, i32, i64, p], "ctl_conv_wpack_floats_x3": [i32, i32, i32],
             "ctl_bwd_reduce_rows": [i32, i64, i32],
             "ctl_bn_act_dt": [p, p, p, f32, p, i64, i32, i32, C.c_uint32, p],
             "ctl_bwd_reduce_dt": [i32, p, p, p, p, p, f32, i64, i32, p, i32, C.c_uint32, p, p],
@@ -144,7 +146,7 @@ EXPORTED = ["ctl_version", "ctl_last_error", "ctl_conv_wpack_floats", "ctl_conv_
             "ctl_noise_clamp", "ctl_crop_or_pad", "ctl_step_tick", "ctl_spin", "ctl_dropout2d_ex", "ctl_dropout2d_dt", "ctl_uniform_dev", "ctl_adam_dev",
             "ctl_latent_mask_fused_ws_floats", "ctl_latent_mask_fused", "ctl_accumulate", "ctl_pack_weights_bf16_batched",
             "ctl_bn_act_dt", "ctl_bwd_reduce_dt", "ctl_bwd_apply_dt", "ctl_sumpool2_dt", "ctl_bwd_reduce_rows", "ctl_red_blocks",
-            "ctl_launch_count"]
+            "ctl_launch_count", "ctl_conv_wpack_floats_x3", "ctl_pack_weights_x3_batched"]
 
 
 def prof_start(kernel_filter: str = "", every: int = 1) -> None:

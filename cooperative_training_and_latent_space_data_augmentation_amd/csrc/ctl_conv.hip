@@ -22,178 +22,6 @@
 
 #include "ctl_conv_common.h"
 
-// Staging of one 16-channel chunk of the (virtual) input tile into LDS, with the BN+LeakyReLU prologue.  Everything that
-// depends only on the thread (tile-relative coordinates, source byte offset, LDS offset) is computed ONCE (init); per tile a
-// unit costs two adds + two unsigned compares (bounds) + one select for the buffer offset.  LOAD issues all buffer loads of
-// the tile back to back (nothing consumes them), STORE (after the MFMA phase) applies the prologue and writes LDS.
-// CTL_IN_C4: plain stored input with <= 4 channels whose 3x3 taps are K-packed (see conv_igemm_kernel)
-#define CTL_MODE_IS_PLAIN(M) ((M) == CTL_IN_PLAIN || (M) == CTL_IN_C4)
-
-// X2 (ctl_conv.pro_affine == 2, the BatchNorm-backward prologue): the operand is the VIRTUAL tensor  A[c] * x + B[c] * x2 + C[c]  of two
-// tensors of one geometry (x = g = dL/da * leaky', x2 = the BatchNorm input): the `apply` pass of the BatchNorm backward runs here, in
-// the staging of its consumers, and its output tensor never exists (two packed fmas per element on top of the second load).
-template <int KS, int S, int MODE, int MT, int TW, bool X2 = false>
-struct XStage {
-    using G = Geom<KS, S, MT, TW>;
-    static constexpr int UNITS = G::IH * G::IW * 4;
-    static constexpr int NU = (UNITS + 255) / 256;
-    static constexpr int PADH = (G::PAD + 1) >> 1;   // source-space padding of the x2 modes
-    int rel[NU];        // byte offset of the unit relative to the tile's source origin
-    int rc[NU];         // r | c << 16 (tile-relative virtual coordinates); 0x7fff7fff for the units past the tile
-    int lds[NU];        // LDS float offset; the units past the tile write a dump slot behind the image
-    f32x4 v[NU];
-    f32x4 v2[X2 ? NU : 1];      // X2: the second tensor's units
-    unsigned vmask;     // bit i: unit i of the tile held in v[] lies inside the image (gets the prologue)
-    int pad_h, pad_w;   // top / left padding of this block's problem (G::PAD except for the phase problems of the 2x2 kernels)
-    bool all_in;        // wave-uniform: every unit of the tile held in v[] is inside the image and the channel range
-    int tb_last;        // X2: byte offset of the tile held in v[] (for the side output of the virtual tensor, see store)
-
-    __device__ __forceinline__ void init(const ctl_conv& d) {
-        const int tid = threadIdx.x, cq = tid & 3;
-#pragma unroll
-        for (int i = 0; i < NU; ++i) {
-            const int u = tid + i * 256;
-            const int pix = u >> 2;
-            const int r = pix / G::IW;
-            const int c = pix - r * G::IW;
-            const bool in = u < UNITS;
-            // source = virtual for plain inputs; for x2 nearest / zero-insert inputs the tile origin is even, so
-            // (origin - PAD + r) >> 1 = origin/2 + ((r - PAD) >> 1); the source origin is moved up/left by PADH so that
-            // the per-thread offsets are never negative (they are unsigned voffsets next to a scalar tile offset)
-            const int rr = CTL_MODE_IS_PLAIN(MODE) ? r : (((r - G::PAD) >> 1) + PADH);
-            const int cc = CTL_MODE_IS_PLAIN(MODE) ? c : (((c - G::PAD) >> 1) + PADH);
-            rel[i] = in ? ((rr * d.win + cc) * d.cin + cq * 4) * 4 : CTL_OOB;
-            rc[i] = in ? (r | (c << 16)) : 0x7fff7fff;
-            lds[i] = in ? ((r * G::IWP + G::ldscol(c)) * 16 + cq * 4) : G::XT_IMAGE;
-        }
-        vmask = 0;
-        all_in = false;
-        pad_h = pad_w = G::PAD;
-    }
-
-    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rx, const ctl_conv& d, int n, int ho0, int wo0, int g) { load(rx, rx, d, n, ho0, wo0, g); }
-    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rx, __amdgpu_buffer_rsrc_t rx2, const ctl_conv& d, int n, int ho0, int wo0, int g) {
-        const int vh0 = ho0 * S - pad_h, vw0 = wo0 * S - pad_w;
-        const unsigned hv = CTL_MODE_IS_PLAIN(MODE) ? d.hin : 2 * d.hin;
-        const unsigned wv = CTL_MODE_IS_PLAIN(MODE) ? d.win : 2 * d.win;
-        const int oh = CTL_MODE_IS_PLAIN(MODE) ? vh0 : ((ho0 >> 1) - PADH);
-        const int ow = CTL_MODE_IS_PLAIN(MODE) ? vw0 : ((wo0 >> 1) - PADH);
-        const int tb = (((n * d.hin + oh) * d.win + ow) * d.cin + g * 16) * 4;      // uniform; may be negative at the border
-        tb_last = tb;
-        // interior tile (most of them): every unit is in range -> the tile origin goes into the scalar offset of the buffer
-        // loads and the per-thread offsets are the loop-invariant rel[]: no VALU at all (fp32 MFMA shares the VALU issue
-        // port on this part, so every VALU instruction in the loop is time taken from the matrix work)
-#ifdef CTL_NO_INTERIOR
-        all_in = false;
-#else
-        all_in = MODE != CTL_IN_ZINS2 && vh0 >= 0 && vw0 >= 0 && vh0 + G::IH <= (int)hv && vw0 + G::IW <= (int)wv &&
-                 g * 16 + 16 <= d.cin;
-#endif
-        if (all_in) {
-#pragma unroll
-            for (int i = 0; i < NU; ++i) v[i] = ctl_bload4s(rx, rel[i], tb);
-            if constexpr (X2) {
-#pragma unroll
-                for (int i = 0; i < NU; ++i) v2[i] = ctl_bload4s(rx2, rel[i], tb);
-            }
-            return;
-        }
-        const bool chan_ok = g * 16 + (threadIdx.x & 3) * 4 < d.cin;
-        unsigned m = 0;
-        int vo[NU];
-#pragma unroll
-        for (int i = 0; i < NU; ++i) {
-            const int vh = vh0 + (rc[i] & 0xffff), vw = vw0 + (rc[i] >> 16);
-            bool ok = chan_ok && (unsigned)vh < hv && (unsigned)vw < wv;
-            if (MODE == CTL_IN_ZINS2) ok = ok && (((vh | vw) & 1) == 0);
-            vo[i] = ok ? (tb + rel[i]) : CTL_OOB;
-            m |= ok ? (1u << i) : 0u;
-        }
-        vmask = m;
-        if constexpr (X2) {
-#pragma unroll
-            for (int i = 0; i < NU; ++i) { v[i] = ctl_bload4(rx, vo[i]); v2[i] = ctl_bload4(rx2, vo[i]); }
-        } else if (d.cin >= 4) {
-#pragma unroll
-            for (int i = 0; i < NU; ++i) v[i] = ctl_bload4(rx, vo[i]);
-        } else {
-#pragma unroll
-            for (int i = 0; i < NU; ++i) v[i] = f32x4{ctl_bload1(rx, vo[i]), 0.f, 0.f, 0.f};
-        }
-    }
-
-    // `goff` = BatchNorm group of the tile held in v[] times cin (row of the [groups][cin] prologue coefficients).  The
-    // coefficients are read from the block's LDS copy: a global load here sits between the two barriers of a step with nothing
-    // to hide its latency behind
-    // X2: pro_scale / pro_shift / pro_c are the LDS copies of A / B / C ([group][cin] each).  xout (a buffer resource over a tensor of x's
-    // geometry, `xout_on` on the blocks of the first cout group only): the units of the tile's INTERIOR -- the input pixels no other tile
-    // owns -- are also written to global memory: the virtual tensor materialises as a by-product of this conv's staging, for the weight-
-    // gradient kernel of the same layer (which would otherwise evaluate it again in each of its cin-chunk blocks).
-    __device__ __forceinline__ void store(float* __restrict__ xt, const ctl_conv& d, int g,
-                                          const float* pro_scale, const float* pro_shift, int goff, const float* pro_c = nullptr) {
-        store(xt, d, g, pro_scale, pro_shift, goff, pro_c, ctl_rsrc((const void*)nullptr, 0), false);
-    }
-    __device__ __forceinline__ void store(float* __restrict__ xt, const ctl_conv& d, int g,
-                                          const float* pro_scale, const float* pro_shift, int goff, const float* pro_c,
-                                          __amdgpu_buffer_rsrc_t rxout, bool xout_on) {
-        if constexpr (X2) {
-            const int cb = g * 16 + (threadIdx.x & 3) * 4;
-            const f32x4 ca = *reinterpret_cast<const f32x4*>(pro_scale + goff + cb), cbb = *reinterpret_cast<const f32x4*>(pro_shift + goff + cb);
-            const f32x4 cc = *reinterpret_cast<const f32x4*>(pro_c + goff + cb);
-            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int i = 0; i < NU; ++i) {
-                const bool in = all_in || ((vmask >> i) & 1u);
-                const f32x4 r = in ? (ca * v[i] + cbb * v2[i] + cc) : zero;      // padding stays zero (C alone would leak into it)
-                *reinterpret_cast<f32x4*>(xt + lds[i]) = r;
-                if (xout_on) {
-                    const unsigned tr = (unsigned)((rc[i] & 0xffff) - pad_h), tc = (unsigned)((rc[i] >> 16) - pad_w);
-                    const bool own = in && tr < (unsigned)(G::TH * S) && tc < (unsigned)(TW * S);
-                    ctl_bstore4(rxout, own ? (tb_last + rel[i]) : CTL_OOB, r);
-                }
-            }
-            return;
-        }
-        if (!d.pro_affine) {      // out-of-range units were loaded as hardware zeros: nothing to compute
-#pragma unroll
-            for (int i = 0; i < NU; ++i) *reinterpret_cast<f32x4*>(xt + lds[i]) = v[i];
-            return;
-        }
-        const int cb = g * 16 + (threadIdx.x & 3) * 4;
-        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-        if (cb < d.cin) {
-            if (d.cin >= 4) {
-                sc = *reinterpret_cast<const f32x4*>(pro_scale + goff + cb);
-                sh = *reinterpret_cast<const f32x4*>(pro_shift + goff + cb);
-            } else {
-                sc.x = pro_scale[goff];
-                sh.x = pro_shift[goff];
-            }
-        }
-        const float slope = d.pro_slope;
-        if (all_in) {
-#pragma unroll
-            for (int i = 0; i < NU; ++i) *reinterpret_cast<f32x4*>(xt + lds[i]) = ctl_leaky01(v[i] * sc + sh, slope);
-            return;
-        }
-        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < NU; ++i) {
-            const f32x4 t = ctl_leaky01(v[i] * sc + sh, slope);
-            // padding / channel-pad lanes hold hardware zeros and must stay zero; units past the tile go to the dump slot
-            *reinterpret_cast<f32x4*>(xt + lds[i]) = ((vmask >> i) & 1u) ? t : zero;
-        }
-    }
-};
-
-// ------------------------------------------------------------------------------------------------ forward-type kernel
-// Persistent, software-pipelined: a block walks tiles bid, bid+grid, ... and for every (tile, 16-channel chunk) step
-//   1. issues the NEXT step's buffer loads (input tile + weight chunk) into registers        -- HBM/L2 latency in flight
-//   2. runs the MFMA loop of the CURRENT step out of LDS
-//   3. bare s_barrier; ds_write the prefetched registers; lgkmcnt(0) + s_barrier               -- no vmcnt drain
-//   4. (last chunk of a tile) epilogue: bias / residual / activation, buffer stores that are never waited for in the loop;
-//      BatchNorm statistics stay in registers until the block is done.
-// Weight chunks [tap][nt][64 lanes][4] go through LDS (shared by the four waves; staged once when Cin <= 16).
 // Phase timers of the forward kernel (variant builds only: tools/build_variant.sh tm "-DCTL_TIMING"; read with
 // ctl_debug_timing).  Sums s_memtime deltas over every wave: [0] prefetch issue, [1] MFMA loop, [2] barrier after the
 // reads, [3] staging (vmcnt wait + prologue + ds_write), [4] barrier after the writes, [5] epilogue, [6] steps, [7] setup.
@@ -225,465 +53,8 @@ extern "C" int ctl_debug_timing(unsigned long long* out8) {
 #define TM_COUNT(i)
 #define TM_FLUSH
 #endif
-#ifndef CTL_LB_MID
-#define CTL_LB_MID 3
-#endif
-#ifndef CTL_LB_SMALL
-#define CTL_LB_SMALL 3      // (4: 28-76 B of scratch in the epilogue-operand forms of this class; 16.61 -> 16.57 ms)
-#endif
-template <int KS, int S, int MODE, int MT, int TW, int NT, int EPI, bool X2 = false>      // X2: see XStage (pro_scale = the [group][3][cin] coefficients)
-// resident blocks of the X2 instantiations: two staged tensors (and with EPI an epilogue tensor) in registers -- at 3 blocks per CU the
-// 8x32-pixel form needs 92 B of scratch per lane, at 2 none: 17.15 -> 16.98 ms per step (tools/debug/fp32_x2_occ_ab.sh)
-#ifndef CTL_LB_X2EPI
-#define CTL_LB_X2EPI 2
-#endif
-#ifndef CTL_LB_X2
-#define CTL_LB_X2 2      // (X2 without an epilogue operand: 36 B of scratch at 3; 17.17 -> 17.12 ms)
-#endif
-#ifndef CTL_LB_SMALL_X2EPI
-#define CTL_LB_SMALL_X2EPI CTL_LB_SMALL
-#endif
-__global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? 2 : ((MT * NT >= 4) ? (X2 ? (EPI ? CTL_LB_X2EPI : CTL_LB_X2) : CTL_LB_MID)
-                                                                                    : ((X2 && EPI) ? CTL_LB_SMALL_X2EPI : CTL_LB_SMALL))) void conv_igemm_kernel(const ctl_conv d, const float* __restrict__ x,
-                                                          const float* __restrict__ wpack,
-                                                          const float* __restrict__ bias,
-                                                          const float* __restrict__ pro_scale,
-                                                          const float* __restrict__ pro_shift,
-                                                          const float* __restrict__ res,
-                                                          const float* __restrict__ res_scale,
-                                                          const float* __restrict__ res_shift, float* __restrict__ y,
-                                                          float* __restrict__ stats_partial, int tiles_h, int tiles_w,
-                                                          int G_chunks, int64_t wpack_sub_stride, int ntiles,
-                                                          const float* __restrict__ res2, const float* __restrict__ x2,
-                                                          float* __restrict__ pool, float* __restrict__ xout) {
-    using G = Geom<KS, S, MT, TW>;
-    constexpr int TAPS = KS * KS;
-    // C4: input with <= 4 channels.  The four lane groups of an MFMA (its k index) carry four different TAPS (channels 0-3 each)
-    // instead of four channel groups of one tap: 3 fragments ("quads" of taps 0-3, 4-7, 8) cover the 3x3 kernel, so a pixel tile
-    // costs 12 MFMAs instead of 36.  Only the per-lane LDS read base and the weight fragment order differ from the plain path.
-    constexpr bool C4 = (MODE == CTL_IN_C4);
-    static_assert(!C4 || (KS == 3 && S == 1), "K-packed taps: 3x3 stride-1 only");
-    constexpr int NFRAG = C4 ? 3 : TAPS;             // weight fragments per cout tile and chunk
-    constexpr int RED_FLOATS = 4 * NT * 16 * 2;
-    constexpr int WT_FLOATS = NFRAG * NT * 256;
-    constexpr int XT_ALLOC = G::XT_FLOATS;
-    __shared__ __attribute__((aligned(16))) float xt[XT_ALLOC + WT_FLOATS + RED_FLOATS + (X2 ? 3 : 2) * CTL_PRO_MAX];
-    float* wt = xt + XT_ALLOC;
-    float* sred = wt + WT_FLOATS;        // statistics reduction scratch (a flush can happen while xt holds the next tile)
-    float* cf_scale = sred + RED_FLOATS; // prologue coefficients [groups][cin]
-    float* cf_shift = cf_scale + CTL_PRO_MAX;
-    float* cf_c = cf_shift + (X2 ? CTL_PRO_MAX : 0);
-    constexpr int WU = NFRAG * NT * 64, NW = (WU + 255) / 256;
+#include "ctl_conv_igemm.h"
 
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int p = lane & 15, q = lane >> 4;
-    // Tile ownership.  Blocks b, b+8, ... share an XCD (and its L2) and the dispatcher spreads blocks breadth-first: the
-    // first 256 land on distinct CUs (tools/micro/dispatch_probe.hip).  So the tile list is cut into one contiguous range
-    // per XCD (neighbouring tiles share halos in one L2) and the j-th block of an XCD walks tiles j, j+nb, ... of that
-    // range: the blocks that get one tile more are the first of each XCD, i.e. sit on different CUs.
-    const int P = gridDim.x < 8 ? (int)gridDim.x : 8;
-    const int xcd = blockIdx.x % P, jblk = blockIdx.x / P;
-    const int nb = ((int)gridDim.x - xcd + P - 1) / P;                 // blocks of this XCD
-    const int t_lo = (int)(((int64_t)ntiles * xcd) / P), t_hi = (int)(((int64_t)ntiles * (xcd + 1)) / P);
-    const int bid0 = t_lo + jblk;
-    const int z = blockIdx.z;
-    const int cot0 = blockIdx.y * NT;
-    const float* wp = wpack + (int64_t)z * wpack_sub_stride;
-    const int my_tiles = (bid0 < t_hi) ? (t_hi - bid0 + nb - 1) / nb : 0;
-    const int total_it = my_tiles * G_chunks;
-    const int flags = d.epi_flags;
-    const int ngroups = d.groups > 1 ? d.groups : 1;
-    const int group_n = d.n / ngroups;                               // images per BatchNorm group
-    const int oy0 = (z >> 1) * d.out_sub, ox0 = (z & 1) * d.out_sub;
-    const __amdgpu_buffer_rsrc_t rx = ctl_rsrc(x, (int64_t)d.n * d.hin * d.win * d.cin * 4);
-    const __amdgpu_buffer_rsrc_t rx2 = X2 ? ctl_rsrc(x2, (int64_t)d.n * d.hin * d.win * d.cin * 4) : rx;
-    const bool xout_on = X2 && xout != nullptr && blockIdx.y == 0 && blockIdx.z == 0;
-    const __amdgpu_buffer_rsrc_t rxout = xout_on ? ctl_rsrc(xout, (int64_t)d.n * d.hin * d.win * d.cin * 4) : rx;
-    const int64_t ybytes = (int64_t)d.n * d.out_h * d.out_w * d.cout * 4;
-    const __amdgpu_buffer_rsrc_t ry = ctl_rsrc(y, ybytes);
-    const __amdgpu_buffer_rsrc_t rres = ctl_rsrc(EPI ? (const void*)res : (const void*)y, ybytes);
-    // EPI == 2 (CTL_EPI_TAILBWD): this launch produces dL/dOut of a residual block; the epilogue turns it into g = dOut * leaky'(out)
-    // (res = the block's stored output), stores g and takes the BatchNorm-backward sums (sum g, sum g*v; res2 = v, the BatchNorm input of the
-    // tail) -- the stand-alone reduction pass over dOut, out and v (ctl_bwd_reduce mode 0) and the dOut tensor itself disappear
-    constexpr bool TAIL = (EPI == 2);
-    const __amdgpu_buffer_rsrc_t rres2 = ctl_rsrc(TAIL ? (const void*)res2 : (const void*)y, ybytes);
-    // TAIL with `pool` (1x1 hosts whose waves own row pairs): the epilogue also writes sumpool2(g) -- the 2x2 sum-pool of the stored g, which
-    // the consuming block's 1x1 weight / data gradients read (nearest-upsample blocks): the stand-alone pooling pass disappears.  Same
-    // association as sumpool2_kernel, (a0 + a1) + (a2 + a3): bit-identical.
-    constexpr bool CAN_POOL = TAIL && KS == 1 && S == 1 && MODE == CTL_IN_PLAIN && (MT / (TW / 16)) == 2;
-    const __amdgpu_buffer_rsrc_t rpool = ctl_rsrc(CAN_POOL && pool ? (const void*)pool : (const void*)y, CAN_POOL && pool ? ybytes / 4 : ybytes);
-
-    f32x4 ssum[NT], ssq[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) ssum[t] = ssq[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // M-tile m of this wave: tile row tr = wave*(MT/TWT) + m/TWT, first column tc = (m % TWT) * 16
-    constexpr int TWT = TW / 16;
-    static_assert(MT % TWT == 0, "a wave's M-tiles must cover whole tile rows");
-    const int wrow = wave * (MT / TWT);
-    // per-thread constants of the epilogue: byte offset of this lane's 4 channels of M-tile m relative to the tile's output origin
-    int yrel[MT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-        yrel[m] = (((wrow + m / TWT) * d.out_sy * d.out_w + ((m % TWT) * 16 + p) * d.out_sx) * d.cout + q * 4) * 4;
-    // bias of this lane's 4 output channels: the accumulators start from it (no add in the epilogue)
-    f32x4 bias4[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int co0 = (cot0 + t) * 16 + q * 4;
-        f32x4 b = {0.f, 0.f, 0.f, 0.f};
-        if (flags & CTL_EPI_BIAS) {
-            if (d.cout >= 4) b = *reinterpret_cast<const f32x4*>(bias + (co0 < d.cout ? co0 : 0));
-            else b.x = bias[0];
-        }
-        bias4[t] = b;
-        // pin the load's completion here: left to itself the wait-count pass puts an s_waitcnt vmcnt(0) in front of the first
-        // read of bias4 INSIDE the tile loop (the accumulator init), right behind the next tile's prefetch loads
-        asm volatile("" ::"v"(bias4[t]));
-    }
-    // LDS operand addresses: one per-thread base; (M-tile, tap) offsets are compile-time immediates of the ds_read
-    const float* xrd = xt + ((wrow * S) * G::IWP + p) * 16 + q * 4;
-    const float* wrd = wt + lane * 4;
-    const float* xrd4[3];            // C4: lane group q reads channels 0-3 of the pixel shifted by tap 4j+q (tap 8 only for q = 0)
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const int tp = (4 * j + q < 9) ? 4 * j + q : 8;
-        xrd4[j] = xt + ((wrow + tp / 3) * G::IWP + p + tp % 3) * 16;
-    }
-
-    XStage<KS, S, MODE, MT, TW, X2> xs;
-    xs.init(d);
-    if (KS == 2 && S == 1) {
-        // phase problems (z = 2a + b, outputs at (2i+a, 2j+b)): d.pad == 2 -> 3x3 conv on a nearest-upsampled input, phase (a,b)
-        // reads rows i+a-1, i+a (pad 1-a); d.pad == 0 -> data gradient of a stride-2 3x3 conv, every phase reads rows i, i+1
-        xs.pad_h = d.pad == 2 ? 1 - (z >> 1) : 0;
-        xs.pad_w = d.pad == 2 ? 1 - (z & 1) : 0;
-    }
-    // weight chunk g: [tap][t][64 lanes][4] floats; per-thread byte offsets are loop-invariant, the chunk goes in the scalar offset
-    const __amdgpu_buffer_rsrc_t rw = ctl_rsrc(wp, (int64_t)ctl_cdiv(d.cout, 16) * NFRAG * G_chunks * 1024);
-    f32x4 wv[NW];
-    int wrel[NW];
-#pragma unroll
-    for (int i = 0; i < NW; ++i) {
-        const int u = tid + i * 256;
-        const int tt = u >> 6, l = u & 63;           // tt = tap * NT + t
-        const int tap = tt / NT, t = tt - tap * NT;
-        wrel[i] = (u < WU) ? ((((cot0 + t) * NFRAG + tap) * G_chunks) * 64 + l) * 16 : CTL_OOB;
-    }
-    auto wload = [&](int g) {
-#pragma unroll
-        for (int i = 0; i < NW; ++i) wv[i] = ctl_bload4s(rw, wrel[i], g * 1024);
-    };
-    auto wstore = [&]() {
-#pragma unroll
-        for (int i = 0; i < NW; ++i) {
-            const int u = tid + i * 256;
-            if (u < WU) *reinterpret_cast<f32x4*>(wt + u * 4) = wv[i];
-        }
-    };
-
-    TileWalk cur, nxt;
-    cur.init(bid0, nb, tiles_h, tiles_w);
-    nxt = cur;
-    TM_DECL
-    if (total_it > 0) {
-        xs.load(rx, rx2, d, cur.n, cur.th * G::TH, cur.tw * TW, 0);
-        wload(0);
-    }
-    if constexpr (X2) {      // coefficients as the BatchNorm-backward finalize writes them: [group][A | B | C][cin]
-        for (int i = tid; i < ngroups * d.cin; i += 256) {
-            const int gi = i / d.cin, ch = i - gi * d.cin;
-            cf_scale[i] = pro_scale[(gi * 3 + 0) * d.cin + ch]; cf_shift[i] = pro_scale[(gi * 3 + 1) * d.cin + ch]; cf_c[i] = pro_scale[(gi * 3 + 2) * d.cin + ch];
-        }
-        __syncthreads();
-    } else if (d.pro_affine) {      // behind the first tile's loads, in front of their use
-        for (int i = tid; i < ngroups * d.cin; i += 256) { cf_scale[i] = pro_scale[i]; cf_shift[i] = pro_shift[i]; }
-        __syncthreads();
-    }
-    if (total_it > 0) {
-        xs.store(xt, d, 0, cf_scale, cf_shift, (cur.n / group_n) * d.cin, cf_c, rxout, xout_on);
-        wstore();
-    }
-    __syncthreads();
-
-    // Statistics of one BatchNorm group: block-level sum through LDS -> stats_partial[group][block][2][cout].  Called when the
-    // walk enters the next group (tiles are visited in increasing order) and once at the end; every wave takes part.
-    const int srows = gridDim.x * gridDim.z, srow = z * gridDim.x + blockIdx.x;       // statistics rows of one group: [sub-problem][block]
-    auto flush_stats = [&](int grp) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            float a[8] = {ssum[t].x, ssum[t].y, ssum[t].z, ssum[t].w, ssq[t].x, ssq[t].y, ssq[t].z, ssq[t].w};
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                float v = a[i];
-                v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
-                a[i] = v;
-            }
-            if (p == 0) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    sred[((wave * NT + t) * 16 + q * 4 + r) * 2 + 0] = a[r];
-                    sred[((wave * NT + t) * 16 + q * 4 + r) * 2 + 1] = a[4 + r];
-                }
-            }
-            ssum[t] = ssq[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        __syncthreads();
-        if (tid < NT * 16 * 2) {
-            const int stat = tid / (NT * 16), cl = tid % (NT * 16);
-            float v = 0.f;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) v += sred[((w * NT * 16) + cl) * 2 + stat];
-            const int co = cot0 * 16 + cl;
-            if (co < d.cout) stats_partial[(((int64_t)grp * srows + srow) * 2 + stat) * d.cout + co] = v;
-        }
-        __syncthreads();
-    };
-    int cur_grp = (my_tiles > 0) ? cur.n / group_n : 0;
-    if ((flags & CTL_EPI_STATS) && ngroups > 1 && tid < NT * 16 * 2) {      // groups this block never visits contribute zeros
-        const int stat = tid / (NT * 16), co = cot0 * 16 + tid % (NT * 16);
-        if (co < d.cout)
-            for (int gi = 0; gi < ngroups; ++gi) stats_partial[(((int64_t)gi * srows + srow) * 2 + stat) * d.cout + co] = 0.f;
-    }
-
-    TM(7)
-    f32x4 acc[MT][NT];
-    for (int it = 0, g = 0; it < total_it; ++it) {
-        TM_COUNT(6)
-        const int n = cur.n, ho0 = cur.th * G::TH, wo0 = cur.tw * TW;
-        const bool has_next = it + 1 < total_it;
-        const int g2 = (g + 1 == G_chunks) ? 0 : g + 1;
-        const bool new_w = has_next && G_chunks > 1;
-        if (g2 == 0) nxt.next();
-        if (has_next) {
-            xs.load(rx, rx2, d, nxt.n, nxt.th * G::TH, nxt.tw * TW, g2);
-            if (new_w) wload(g2);
-        }
-        TM(0)
-        if (g == 0) {        // (taking the bias as the C operand of each accumulator's first MFMA instead costs 25-55 VGPRs)
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int t = 0; t < NT; ++t) acc[m][t] = bias4[t];
-        }
-        {   // operands of tap+1 are requested before the MFMAs of tap.  The machine scheduler sinks the reads back to their uses
-            // (register pressure); pinning them with sched_barriers (-DCTL_PIN_READ_AHEAD) costs 12 VGPRs and measures the
-            // same: with fp32 MFMA on the VALU port the LDS latency of one wave is covered by the other waves of the SIMD.
-            f32x4 wf[2][NT], xf[2][MT];
-            auto lds_operands = [&](int tap, int b) {
-                const int kh = tap / KS, kw = tap % KS;
-                const int kcol = (S == 2) ? ((kw & 1) * G::IWH + (kw >> 1)) : kw;
-#pragma unroll
-                for (int t = 0; t < NT; ++t) wf[b][t] = *reinterpret_cast<const f32x4*>(wrd + (tap * NT + t) * 256);
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    if (C4) xf[b][m] = *reinterpret_cast<const f32x4*>(xrd4[tap] + ((m / TWT) * G::IWP + (m % TWT) * 16) * 16);   // tap = quad
-                    else xf[b][m] = *reinterpret_cast<const f32x4*>(xrd + (((m / TWT) * S + kh) * G::IWP + (m % TWT) * 16 + kcol) * 16);
-                }
-            };
-            lds_operands(0, 0);
-#pragma unroll
-            for (int tap = 0; tap < NFRAG; ++tap) {
-                const int b = tap & 1;
-                if (tap + 1 < NFRAG) lds_operands(tap + 1, b ^ 1);
-#ifdef CTL_PIN_READ_AHEAD
-                __builtin_amdgcn_sched_barrier(0);
-#endif
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) {
-                        acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[b][t].x, xf[b][m].x, acc[m][t], 0, 0, 0);
-                        acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[b][t].y, xf[b][m].y, acc[m][t], 0, 0, 0);
-                        acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[b][t].z, xf[b][m].z, acc[m][t], 0, 0, 0);
-                        acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[b][t].w, xf[b][m].w, acc[m][t], 0, 0, 0);
-                    }
-                }
-#ifdef CTL_PIN_READ_AHEAD
-                __builtin_amdgcn_sched_barrier(0);
-#endif
-            }
-        }
-
-        TM(1)
-        ctl_barrier_lds_reads_done();    // every wave is done reading this step's LDS images
-        TM(2)
-        if (has_next) {    // refill LDS from the prefetched registers
-            xs.store(xt, d, g2, cf_scale, cf_shift, (nxt.n / group_n) * d.cin, cf_c, rxout, xout_on);   // v[] holds chunk g2 of tile nxt (== cur unless g2 == 0)
-            if (new_w) wstore();
-        }
-        TM(3)
-        ctl_barrier_lds_writes_done();
-        TM(4)
-
-        if (g == G_chunks - 1) {
-            // ---------------- epilogue: lane (p,q) holds channels co0..co0+3 of pixel p of each M-tile.  Buffer stores with
-            // hardware bounds checks; nothing here is waited for in the loop.  Whole tiles with whole channel tiles (FULL) put
-            // the tile origin into the scalar offset of the loads and skip every mask; ragged ones redirect dropped lanes to
-            // CTL_OOB.  (Requesting the residual / accumulate operands before the barriers was measured: the extra live
-            // registers cost more than the hidden latency gains.)
-            const int grp = n / group_n;
-            if ((flags & CTL_EPI_STATS) && grp != cur_grp) {
-                flush_stats(cur_grp);
-                cur_grp = grp;
-            }
-            const int ybase = (((n * d.out_h + ho0 * d.out_sy + oy0) * d.out_w + wo0 * d.out_sx + ox0) * d.cout + cot0 * 16) * 4;
-#ifdef CTL_NO_FULL_EPI
-            const bool full = false;
-#else
-            const bool full = ho0 + G::TH <= d.hout && wo0 + TW <= d.wout && (cot0 + NT) * 16 <= d.cout;
-#endif
-            auto epilogue = [&](auto full_tag) {
-                constexpr bool FULL = decltype(full_tag)::value;
-#ifndef CTL_NO_FAST_EPI
-                if constexpr (!EPI && FULL) {
-                    // the common case (whole tile, no residual / accumulate operand, no activation): the stores read the accumulator
-                    // registers directly and the statistics sit behind a real branch.  Written as its own path because the generic
-                    // code below funnels every variant through one set of store registers (4 v_mov per fragment) and turns the
-                    // statistics flag into 8 v_cndmask per tile -- VALU issue slots taken from the matrix pipe.
-                    if (d.epi_act == CTL_ACT_NONE) {
-                        if (flags & CTL_EPI_STATS) {
-                            asm volatile("" ::: "memory");                  // keeps the branch (not a select)
-#pragma unroll
-                            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                                for (int m = 0; m < MT; ++m) { ssum[t] += acc[m][t]; ssq[t] += acc[m][t] * acc[m][t]; }
-                        }
-#pragma unroll
-                        for (int t = 0; t < NT; ++t)
-#pragma unroll
-                            for (int m = 0; m < MT; ++m) ctl_bstore4(ry, ybase + yrel[m] + t * 64, acc[m][t]);
-                        return;
-                    }
-                }
-#endif
-                bool pv[MT];
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-                    pv[m] = FULL || ((ho0 + wrow + m / TWT < d.hout) && (wo0 + (m % TWT) * 16 + p < d.wout));
-                // EPI == 3: CTL_EPI_BNBWD alone, known at compile time (the 3x3 data gradients of the residual blocks): no accumulate
-                // operand, no per-fragment flag tests -- 16 VGPRs less than the generic EPI == 1 form, which matters next to the second
-                // staged tensor of the X2 prologue (168 VGPRs + 120 B of scratch otherwise)
-                constexpr bool BNB = (EPI == 3), HAS_OV = (EPI == 1 || EPI == 2);
-                f32x4 rv[EPI ? MT : 1][EPI ? NT : 1], ov[HAS_OV ? MT : 1][HAS_OV ? NT : 1], r2[TAIL ? MT : 1][TAIL ? NT : 1];
-                if (EPI) {
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) {
-                        const bool cok = FULL || (cot0 + t) * 16 + q * 4 < d.cout;
-#pragma unroll
-                        for (int m = 0; m < MT; ++m) {
-                            const int vo = FULL ? (yrel[m] + t * 64) : ((pv[m] && cok) ? (ybase + yrel[m] + t * 64) : CTL_OOB);
-                            const int so = FULL ? ybase : 0;
-                            rv[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                            if constexpr (HAS_OV) ov[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                            if constexpr (BNB) {            // (cout is a multiple of 16 here, checked on the host)
-                                rv[m][t] = ctl_bload4s(rres, vo, so);
-                            } else if constexpr (TAIL) {    // (likewise)
-                                rv[m][t] = ctl_bload4s(rres, vo, so);
-                                r2[m][t] = ctl_bload4s(rres2, vo, so);
-                                if (flags & CTL_EPI_ACCUM) ov[m][t] = ctl_bload4s(ry, vo, so);
-                            } else if (d.cout >= 4) {
-                                if (flags & (CTL_EPI_RES | CTL_EPI_BNBWD)) rv[m][t] = ctl_bload4s(rres, vo, so);
-                                if (flags & CTL_EPI_ACCUM) ov[m][t] = ctl_bload4s(ry, vo, so);
-                            } else {
-                                if (flags & (CTL_EPI_RES | CTL_EPI_BNBWD)) rv[m][t].x = ctl_bload1(rres, vo);
-                                if (flags & CTL_EPI_ACCUM) ov[m][t].x = ctl_bload1(ry, vo);
-                            }
-                        }
-                    }
-                }
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const int co0 = (cot0 + t) * 16 + q * 4;
-                    const bool cok = FULL || co0 < d.cout;
-                    const int cc = cok ? co0 : 0;
-                    f32x4 rs = {0.f, 0.f, 0.f, 0.f}, rh = {0.f, 0.f, 0.f, 0.f};
-                    if (EPI && !TAIL && (BNB || (flags & (CTL_EPI_RES | CTL_EPI_BNBWD)))) {
-                        if (d.cout >= 4) {
-                            rs = *reinterpret_cast<const f32x4*>(res_scale + grp * d.cout + cc);
-                            rh = *reinterpret_cast<const f32x4*>(res_shift + grp * d.cout + cc);
-                        } else { rs.x = res_scale[grp]; rh.x = res_shift[grp]; }
-                    }
-#pragma unroll
-                    for (int m = 0; m < MT; ++m) {
-                        f32x4 v = acc[m][t];
-                        if constexpr (TAIL) {
-                            v += ov[m][t];                                   // (CTL_EPI_ACCUM: the other half of dOut, already in y)
-                            const f32x4 o = rv[m][t];
-                            const float sl = d.epi_slope;
-                            v.x *= o.x > 0.f ? 1.f : sl; v.y *= o.y > 0.f ? 1.f : sl;
-                            v.z *= o.z > 0.f ? 1.f : sl; v.w *= o.w > 0.f ? 1.f : sl;
-                            if (FULL || pv[m]) { ssum[t] += v; ssq[t] += v * r2[m][t]; }
-                            if (FULL) ctl_bstore4(ry, ybase + yrel[m] + t * 64, v);
-                            else ctl_bstore4(ry, (pv[m] && cok) ? (ybase + yrel[m] + t * 64) : CTL_OOB, v);
-                            if constexpr (CAN_POOL) {
-                                if (pool) {
-                                    // column pairs sit in neighbouring lanes (p, p ^ 1), the wave's two rows in M-tiles m and m + TWT
-                                    f32x4 hs;
-                                    hs.x = v.x + __shfl_xor(v.x, 1); hs.y = v.y + __shfl_xor(v.y, 1);
-                                    hs.z = v.z + __shfl_xor(v.z, 1); hs.w = v.w + __shfl_xor(v.w, 1);
-                                    if (m < TWT) ov[m][t] = hs;              // (the accumulate operand of this fragment is consumed: its registers hold the top row's pair sums)
-                                    else {
-                                        const f32x4 top = ov[m - TWT][t];
-                                        const f32x4 pl = {top.x + hs.x, top.y + hs.y, top.z + hs.z, top.w + hs.w};
-                                        // low-resolution pixel ((ho0 + wrow) / 2, (wo0 + (m % TWT) * 16 + p) / 2); written by the even lanes
-                                        const int lo = ((((n * (d.out_h >> 1) + ((ho0 + wrow) >> 1)) * (d.out_w >> 1) + ((wo0 + (m % TWT) * 16 + p) >> 1)) * d.cout) + co0) * 4;
-                                        ctl_bstore4(rpool, ((p & 1) == 0 && (FULL || (pv[m] && cok))) ? lo : CTL_OOB, pl);
-                                    }
-                                }
-                            }
-                            continue;
-                        }
-                        if (BNB || (EPI == 1 && (flags & CTL_EPI_BNBWD))) {
-                            // this conv produced dL/da of a = leaky(BN(u)): turn it into g = dL/da * leaky'(BN(u)) and take the two
-                            // sums of the BatchNorm backward (sum g, sum g*u) here instead of in a separate pass over da and u
-                            const f32x4 u = rv[m][t], sa = u * rs + rh;
-                            const float sl = d.epi_slope;
-                            v.x *= sa.x > 0.f ? 1.f : sl; v.y *= sa.y > 0.f ? 1.f : sl;
-                            v.z *= sa.z > 0.f ? 1.f : sl; v.w *= sa.w > 0.f ? 1.f : sl;
-                            if (FULL || pv[m]) { ssum[t] += v; ssq[t] += v * u; }
-                        } else {
-                            if (EPI) v += rv[m][t] * rs + rh;
-                            if (flags & CTL_EPI_STATS) {
-                                if (FULL) { ssum[t] += v; ssq[t] += v * v; }
-                                else if (pv[m]) { ssum[t] += v; ssq[t] += v * v; }
-                            }
-                        }
-                        if (d.epi_act == CTL_ACT_LEAKY) {
-                            v = ctl_leaky01(v, d.epi_slope);
-                        } else if (d.epi_act == CTL_ACT_SIGMOID) {
-                            v.x = 1.f / (1.f + expf(-v.x)); v.y = 1.f / (1.f + expf(-v.y));
-                            v.z = 1.f / (1.f + expf(-v.z)); v.w = 1.f / (1.f + expf(-v.w));
-                        }
-                        if constexpr (HAS_OV) v += ov[m][t];
-                        if (FULL) {
-                            ctl_bstore4(ry, ybase + yrel[m] + t * 64, v);     // no SGPR soffset on stores, see ctl_bload4s
-                        } else {
-                            const int vo = (pv[m] && cok) ? (ybase + yrel[m] + t * 64) : CTL_OOB;
-                            if (d.cout >= 4) ctl_bstore4(ry, vo, v);
-                            else ctl_bstore1(ry, vo, v.x);       // cout == 1: only q == 0 passes `cok`, component x is the channel
-                        }
-                    }
-                }
-            };
-            if (full) epilogue(std::true_type{});
-            else epilogue(std::false_type{});
-        }
-        TM(5)
-        if (g2 == 0) cur = nxt;
-        g = g2;
-    }
-#ifndef CTL_TIMING_WGRAD
-#ifdef CTL_TIMING_DOMINANT_ONLY
-    if (KS == 3 && S == 1 && MODE == 0 && MT == 4 && TW == 32 && NT == 1 && EPI == 0)
-#endif
-    TM_FLUSH
-#endif
-
-    if (flags & CTL_EPI_STATS) flush_stats(cur_grp);
-}
 
 #ifndef CTL_WGRAD_PIPE_ASM_MFMA
 #define CTL_WGRAD_PIPE_ASM_MFMA 0      // 1: the MFMA pairs as volatile asm (in place, no ties): measured 1.5-3 % slower, see the loop
@@ -1320,7 +691,7 @@ __global__ void pack_weights_batched_kernel(const float* __restrict__ params, fl
     const int64_t* r = table + (int64_t)blockIdx.y * 12;
     const int64_t total = r[10];
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
+    if (idx >= total || (r[11] & CTL_PACK_X3)) return;      // (CTL_PACK_X3 records: ctl_pack_weights_x3_batched)
     const float* src = params + r[0];
     float* dst = wpack + r[1];
     const int cout = (int)r[2], cin = (int)r[3], ks = (int)r[4], flip = (int)r[5];
@@ -1629,6 +1000,7 @@ static int conv_dispatch(conv_call& a) {
 
 extern "C" int ctl_conv_stats_blocks(const ctl_conv* d) {
     if (d->dt & CTL_DT_BF16) return ctl_conv_bf16_stats_blocks(d);
+    if (d->dt & CTL_DT_X3) return ctl_conv_x3_stats_blocks(d);
     conv_call a = {};
     a.d = d;
     if (ctl_conv_pick_cfg(d, &a.c, 0) != CTL_OK) return -1;
@@ -1697,6 +1069,8 @@ extern "C" int ctl_conv_forward_ex(const ctl_conv* d, const float* x, const floa
     CTL_REQUIRE((int64_t)d->n * d->hin * d->win * d->cin * 4 < (1ll << 31) &&
                 (int64_t)d->n * d->out_h * d->out_w * d->cout * 4 < (1ll << 31),
                 "conv_forward: tensors must stay below 2 GiB (32-bit buffer offsets)");
+    if (d->dt & CTL_DT_X3)
+        return ctl_conv_forward_x3(d, x, wpack, bias, pro_scale, pro_shift, res, res_scale, res_shift, res2, x2, y, stats_partial, pool, xout, stream);
     if (d->dt & CTL_DT_BF16) {
         const int ptok16 = ctl_prof_begin("conv_igemm_bf16", d, &a.c, a.c.nt, (hipStream_t)stream);
         rc = ctl_conv_forward_bf16(d, x, x2, wpack, bias, pro_scale, pro_shift, res, res_scale, res_shift, res2, y, stats_partial, pool, xout, stream);

@@ -649,7 +649,7 @@ __global__ void pack_weights_bf16_batched_kernel(const float* __restrict__ param
                                                  const int64_t* __restrict__ table) {
     const int64_t* r = table + (int64_t)blockIdx.y * 12;
     const int cout = (int)r[2], cin = (int)r[3], ks = (int)r[4];
-    if (r[11] == 4) return;                                  // (not a bf16 layout)
+    if (r[11] == 4 || (r[11] & CTL_PACK_X3)) return;         // (not a bf16 layout)
     const int g_chunks = (cin + 15) / 16, taps = ks * ks, nfrag = (taps + 1) / 2;
     const int64_t total = (int64_t)((cout + 15) / 16) * nfrag * g_chunks * 64 * 4;      // uint32 words
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -19,7 +19,7 @@
 //   SIGMOID_BWD       0 dy 1 y 2 dx                                      l[0]=count
 //   ZERO              0 ptr                                              l[0]=bytes
 //   COPY              0 src 1 dst                                        l[0]=bytes
-//   PACK_BATCH        0 params 1 wpack 2 table                           i[0]=n_rec i[1]=bf16 fragments l[0]=max_total
+//   PACK_BATCH        0 params 1 wpack 2 table                           i[0]=n_rec i[1]=bit 0 bf16 fragments, bit 1 CTL_PACK_X3 records l[0]=max_total
 //   WGRAD_REDUCE_BATCH 0 scratch 1 grad 2 table                          i[0]=n_rec l[0]=max_elems
 //   DROPOUT2D         0 z 1 keep (given pattern, optional) 2 state (device RNG state, optional) 3 out 4 keep_out (optional)
 //                                                                        i[0..2]=n,hw,c f[0]=p l[0]=seed (no state) | call-site salt (state)
@@ -294,9 +294,10 @@ extern "C" int ctl_plan_run(const ctl_op* ops, int32_t n_ops, void* const* bases
                 if (e != hipSuccess) CTL_FAIL(CTL_ELAUNCH, "plan_run: memset: %s", hipGetErrorString(e));
                 break;
             }
-            case CTL_OP_PACK_BATCH:       // i[1] = 1: bf16 fragments (CTL_DT_BF16 kernels)
-                rc = op.i[1] ? ctl_pack_weights_bf16_batched(CF(0), F(1), (const int64_t*)t[2], op.i[0], op.l[0], stream)
-                             : ctl_pack_weights_batched(CF(0), F(1), (const int64_t*)t[2], op.i[0], op.l[0], stream);
+            case CTL_OP_PACK_BATCH:       // i[1] bit 0: bf16 fragments (CTL_DT_BF16 kernels); bit 1: the table has CTL_PACK_X3 records
+                rc = (op.i[1] & 1) ? ctl_pack_weights_bf16_batched(CF(0), F(1), (const int64_t*)t[2], op.i[0], op.l[0], stream)
+                                   : ctl_pack_weights_batched(CF(0), F(1), (const int64_t*)t[2], op.i[0], op.l[0], stream);
+                if (rc == CTL_OK && (op.i[1] & 2)) rc = ctl_pack_weights_x3_batched(CF(0), F(1), (const int64_t*)t[2], op.i[0], op.l[0], stream);
                 break;
             case CTL_OP_WGRAD_REDUCE_BATCH:
                 rc = ctl_wgrad_reduce_batched(CF(0), F(1), (const int64_t*)t[2], op.i[0], op.l[0], stream);

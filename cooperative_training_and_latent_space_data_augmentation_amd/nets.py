@@ -56,6 +56,9 @@ FUSE_PAIR16 = True       # bf16: the conv-BatchNorm-activation pairs at the head
                          # writes dAct (CTL_EPI_BNBWD on it), and no apply pass either (FUSE_BNAPPLY16)
 FUSE_TAIL16 = True       # bf16: CTL_EPI_TAILBWD in the bf16 family (the tail's reduction pass and the separately rounded dOut disappear)
 FUSE_BNAPPLY16 = True    # bf16: the BatchNorm-backward apply passes of the residual blocks run inside the staging of their consumers (pro_affine 2 / dy2)
+X3 = True                # fp32: the 2x2 / 3x3 / 4x4 convs with cin, cout multiples of 16 contract on the bf16 matrix pipe over an exact three-way
+                         # bf16 split of both fp32 operands (CTL_DT_X3, csrc/ctl_conv_x3_stage.h): same tensors, same epilogues, error per product
+                         # below an fp32 multiply's rounding, 16/6 of the fp32 MFMA rate
 FUSE_TAIL = True         # fp32: the residual tail's BatchNorm-backward reduction inside the launch that writes dOut (CTL_EPI_TAILBWD): dOut is
                          # never materialised, the stand-alone reduction launch (read dOut, out, v; write dS) disappears
 CONV_WORDS = _ffi.CONV_DTYPE.itemsize // 4      # ctl_conv as int32 words at the head of ctl_op.i
@@ -246,7 +249,7 @@ class PlanBuilder:
         if out is None:
             out = (arena or self.act).tensor(x.n, oh, ow, cout)
         assert (out.n, out.h, out.w, out.c) == (x.n, oh, ow, cout), (out, x.n, oh, ow, cout)
-        dt = 0
+        dt = _ffi.DT_X3 if (wp_ref[0] == S_WP and wp_ref[1] // 4 in self.net._x3_packs) else 0      # (the pack's layout decides: see CtlNet._finalize_storage)
         if self.b16:        # bf16 MFMA family; which of x / y / res is STORED as bf16 follows from where the tensor lives
             assert bnbwd is None or (x.b16 and out.b16 and bnbwd[0].b16), "CTL_EPI_BNBWD (bf16): x, y and u must be bf16-stored"
             assert tail is None or (out.b16 and tail[0].b16 and tail[1].b16), "CTL_EPI_TAILBWD (bf16): y, out and v must be bf16-stored"
@@ -582,6 +585,22 @@ class CtlNet(nn.Module):
         self._boff, self._nbt_names = boff, nbt_names
         # op-level descriptors + packed-weight layout
         wp = 0
+        self._x3_packs = set()             # float offsets (into the packed-weight buffer) of the packs in the three-plane X3 layout
+        x3_on = X3 and not self.bf16
+
+        def wp_floats(cin_eff, cout_eff, ks):
+            """(float count of one packed sub-problem, X3 layout?) of an effective conv cin_eff -> cout_eff"""
+            if x3_on and ks >= 2 and cin_eff % 16 == 0 and cout_eff % 16 == 0:
+                return lib.ctl_conv_wpack_floats_x3(cin_eff, cout_eff, ks), True
+            return lib.ctl_conv_wpack_floats(cin_eff, cout_eff, ks), False
+
+        def take(cin_eff, cout_eff, ks, count=1):
+            nonlocal wp
+            n, x3 = wp_floats(cin_eff, cout_eff, ks)
+            off, wp = wp, wp + count * n
+            if x3:
+                self._x3_packs.update(off + z * n for z in range(count))
+            return off, n
         for key, kind, a in self._spec:
             if kind == "bn":
                 bi = BNInfo()
@@ -595,18 +614,17 @@ class CtlNet(nn.Module):
                 ci.key, ci.cin, ci.cout, ci.ks, ci.transposed = key, a[0], a[1], a[2], kind == "convT"
                 ci.w_off, ci.b_off = poff[key + ".weight"], poff[key + ".bias"]
                 if ci.transposed:     # forward = 4 scattered 1x1 problems, dgrad = 2x2 stride-2 conv
-                    ci.wp_sub = lib.ctl_conv_wpack_floats(ci.cin, ci.cout, 1)
-                    ci.wp_fwd, wp = wp, wp + 4 * ci.wp_sub
-                    ci.wp_dgrad, wp = wp, wp + lib.ctl_conv_wpack_floats(ci.cout, ci.cin, 2)
+                    ci.wp_fwd, ci.wp_sub = take(ci.cin, ci.cout, 1, 4)
+                    ci.wp_dgrad, _ = take(ci.cout, ci.cin, 2)
                 else:
                     ci.wp_sub = 0
-                    ci.wp_fwd, wp = wp, wp + lib.ctl_conv_wpack_floats(ci.cin, ci.cout, ci.ks)
-                    ci.wp_dgrad, wp = wp, wp + lib.ctl_conv_wpack_floats(ci.cout, ci.cin, ci.ks)
+                    ci.wp_fwd, _ = take(ci.cin, ci.cout, ci.ks)
+                    ci.wp_dgrad, _ = take(ci.cout, ci.cin, ci.ks)
                 ci.wp_up = -1
                 if getattr(self, "up_type", None) == "NN" and ci.ks == 3 and key.startswith("up") and key.endswith(".conv.0"):
                     # first conv of a nearest-upsample block: its data gradient followed by the upsample backward (2x2 sum-pool)
                     # is ONE 4x4 stride-2 conv over dU (16 taps per low-res pixel instead of 36 + a full-resolution round trip)
-                    ci.wp_up, wp = wp, wp + lib.ctl_conv_wpack_floats(ci.cout, ci.cin, 4)
+                    ci.wp_up, _ = take(ci.cout, ci.cin, 4)
                 ci.wp_upf = ci.wp_s2d = ci.wp_c4 = -1
                 ci.wp_ph = 0
                 if SMALL_CIN and not self.bf16 and ci.ks == 3 and not ci.transposed and ci.cin <= 4:
@@ -614,13 +632,11 @@ class CtlNet(nn.Module):
                     ci.wp_c4, wp = wp, wp + ((ci.cout + 15) // 16) * 3 * 256
                 if ci.wp_up >= 0 and PHASE_CONVS:
                     # ... and its forward on the nearest-upsampled input is four 2x2 phase convs on the stored input
-                    ci.wp_ph = lib.ctl_conv_wpack_floats(ci.cin, ci.cout, 2)
-                    ci.wp_upf, wp = wp, wp + 4 * ci.wp_ph
+                    ci.wp_upf, ci.wp_ph = take(ci.cin, ci.cout, 2, 4)
                 if PHASE_CONVS and ci.ks == 3 and not ci.transposed and key.endswith(".down"):
                     # stride-2 conv of a down block: its data gradient is four phase convs with <= 2x2 taps over dy (instead of a
                     # 3x3 conv over a zero-inserted tensor that is 75 % zeros)
-                    ci.wp_ph = lib.ctl_conv_wpack_floats(ci.cout, ci.cin, 2)
-                    ci.wp_s2d, wp = wp, wp + 4 * ci.wp_ph
+                    ci.wp_s2d, ci.wp_ph = take(ci.cout, ci.cin, 2, 4)
                 self._convs[key] = ci
         self._wp = torch.zeros(max(wp, 1), dtype=torch.float32, device=device)
         self._pack_plan = self._build_pack_plan()
@@ -769,7 +785,10 @@ class CtlNet(nn.Module):
         recs = []
 
         def pack(src_off_f, dst_off_f, cout, cin, ks, strides, flip, mode=0):
-            total = lib.ctl_conv_wpack_floats(cin, cout, ks)
+            if dst_off_f in self._x3_packs:        # three bf16 planes per fragment for the CTL_DT_X3 launches (ctl_pack_weights_x3_batched)
+                total, mode = lib.ctl_conv_wpack_floats_x3(cin, cout, ks), mode | _ffi.PACK_X3
+            else:
+                total = lib.ctl_conv_wpack_floats(cin, cout, ks)
             recs.append([src_off_f, dst_off_f, cout, cin, ks, int(flip), *strides, total, mode])
 
         for ci in self._convs.values():
@@ -793,7 +812,7 @@ class CtlNet(nn.Module):
         pb.table = np.asarray(recs, dtype=np.int64)
         op = pb.op(_ffi.OP_PACK_BATCH)                 # ONE launch re-packs every conv of the network
         op["i"][0] = len(recs)
-        op["i"][1] = 1 if self.bf16 else 0             # bf16 MFMA fragments (tap pairs) instead of fp32 ones
+        op["i"][1] = (1 if self.bf16 else 0) | (2 if self._x3_packs else 0)      # bit 0: bf16 MFMA fragments (tap pairs) instead of fp32 ones; bit 1: X3 records
         op["l"][0] = max(r[10] for r in recs)
         pb.set_t(op, 0, (S_P, 0))
         pb.set_t(op, 1, (S_WP, 0))

@@ -78,6 +78,28 @@ def pack_weights_bf16(w: torch.Tensor, cout: int, cin: int, ks: int, strides, fl
     return dst
 
 
+def pack_weights_x3(w: torch.Tensor, cout: int, cin: int, ks: int, strides, flip=0, mode: int = 0) -> torch.Tensor:
+    """Three-plane bf16 fragments for CTL_DT_X3 launches (hi | mid | lo planes summing exactly to the fp32 weight, ctl_conv_x3.hip) of
+    one effective conv; `strides` / `flip` / `mode` as in ctl_pack_weights_batched records."""
+    require_gpu(w)
+    total = lib.ctl_conv_wpack_floats_x3(cin, cout, ks)
+    table = torch.tensor([[0, 0, cout, cin, ks, int(flip), *[int(v) for v in strides], total, mode | _ffi.PACK_X3]], dtype=torch.int64, device=w.device)
+    dst = torch.zeros(total, dtype=torch.float32, device=w.device)
+    src = w.contiguous().float()
+    check(lib.ctl_pack_weights_x3_batched(src.data_ptr(), dst.data_ptr(), table.data_ptr(), 1, total, stream_ptr()), "ctl_pack_weights_x3_batched")
+    return dst
+
+
+def pack_oihw_fwd_x3(w: torch.Tensor) -> torch.Tensor:
+    co, ci, ks, _ = w.shape
+    return pack_weights_x3(w, co, ci, ks, (ci * ks * ks, ks * ks, ks, 1), 0)
+
+
+def pack_oihw_dgrad_x3(w: torch.Tensor) -> torch.Tensor:
+    co, ci, ks, _ = w.shape
+    return pack_weights_x3(w, ci, co, ks, (ks * ks, ci * ks * ks, ks, 1), 1)
+
+
 def pack_oihw_fwd_bf16(w: torch.Tensor) -> torch.Tensor:
     co, ci, ks, _ = w.shape
     return pack_weights_bf16(w, co, ci, ks, (ci * ks * ks, ks * ks, ks, 1), 0)

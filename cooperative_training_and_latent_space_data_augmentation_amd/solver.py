@@ -540,10 +540,13 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
         finally:
             set_grad(d_seg, requires_grad=True)
             set_grad(d_img, requires_grad=True)
-            # the standard pass' activations were kept for the saliency passes above (CtlNet.reuse_pass); nothing after this point
-            # may re-use them, and the record pins a whole activation arena per decoder (289 MB at bs16 256x256) until the next forward
-            d_seg.forget_pass()
-            d_img.forget_pass()
+            # the standard pass' activations were kept for the saliency pass of a decoder whose code was perturbed above
+            # (CtlNet.reuse_pass); nothing after this point may re-use them, and the record pins a whole activation arena per decoder
+            # (289 MB at bs16 256x256).  The OTHER decoder's record stays: the two-chain step perturbs the two codes in two calls.
+            if gen_corrupted_seg:
+                d_seg.forget_pass()
+            if gen_corrupted_image:
+                d_img.forget_pass()
         return perturbed_image_0, perturbed_y_0
 
     # ------------------------------------------------------------------ inference (model.py:375-394, 608-664)

@@ -35,8 +35,9 @@ enum ctl_status { CTL_OK = 0, CTL_EINVAL = -1, CTL_EUNSUPPORTED = -2, CTL_ELAUNC
  * 6 = the BatchNorm-backward prologue: ctl_conv.pro_affine == 2 + the x2 argument of ctl_conv_forward_ex (plan op CONV slot 11),
  *     ctl_conv_wgrad_ex (plan op WGRAD slots 6, 7); CTL_EPI_TAILBWD in the bf16 family.
  * 7 = the `pool` argument of ctl_conv_forward_ex (plan op CONV slot 12; CTL_OP_MAX_T 12 -> 14: sizeof(ctl_op) 304 -> 328), ctl_conv_pool_ok.
- * 8 = the `xout` argument of ctl_conv_forward_ex (plan op CONV slot 13). */
-#define CTL_ABI_VERSION 8
+ * 8 = the `xout` argument of ctl_conv_forward_ex (plan op CONV slot 13).
+ * 9 = CTL_DT_X3 / CTL_PACK_X3, ctl_conv_wpack_floats_x3, ctl_pack_weights_x3_batched; plan op PACK_BATCH i[1] is a bit mask. */
+#define CTL_ABI_VERSION 9
 int         ctl_version(void);
 const char* ctl_last_error(void);
 
@@ -75,9 +76,16 @@ typedef struct ctl_conv {
                                         (v_mfma_f32_16x16x32_bf16: operands rounded to bf16 AFTER the fp32 prologue, fp32 accumulate,
                                         fp32 bias / BatchNorm statistics / epilogue; weights packed as bf16 by the *_batched pack with
                                         the same flag); CTL_DT_X16 / _Y16 / _RES16: that tensor is STORED as bf16 (activation storage
-                                        of BASELINE config 3) -- network inputs / outputs stay fp32                              */
+                                        of BASELINE config 3) -- network inputs / outputs stay fp32.
+                                        CTL_DT_X3 (alone; fp32 tensors; cin, cout multiples of 16; 2x2 / 3x3 / 4x4 kernels): the SAME
+                                        fp32 computation with the contraction on the bf16 matrix pipe -- every operand is split
+                                        exactly into three bf16 numbers while it is staged, six v_mfma_f32_16x16x32_bf16 per
+                                        contraction step (hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi, fp32 accumulate): error
+                                        per product < 2^-25, below the rounding of an fp32 multiply; 16/6 of the fp32 MFMA rate.
+                                        Weights come from ctl_pack_weights_x3_batched (records with CTL_PACK_X3)                    */
 } ctl_conv;
-enum { CTL_DT_BF16 = 1, CTL_DT_X16 = 2, CTL_DT_Y16 = 4, CTL_DT_RES16 = 8 };
+enum { CTL_DT_BF16 = 1, CTL_DT_X16 = 2, CTL_DT_Y16 = 4, CTL_DT_RES16 = 8, CTL_DT_X3 = 16 };
+enum { CTL_PACK_X3 = 16 };          /* or-ed into the mode word of a pack record: three-plane bf16 fragments for CTL_DT_X3 launches */
 
 /* number of floats of the packed weight buffer for one sub-problem, and of the statistics partial buffer */
 size_t ctl_conv_wpack_floats(int32_t cin, int32_t cout, int32_t ks);
@@ -158,6 +166,13 @@ int ctl_wgrad_reduce_batched(const float* scratch, float* grad, const int64_t* t
  * float offsets as the fp32 layout (it is smaller: 5 of 9 fragments for a 3x3 kernel).  max_total as for ctl_pack_weights_batched. */
 int ctl_pack_weights_bf16_batched(const float* params, float* wpack, const int64_t* table, int32_t n_rec, int64_t max_total,
                                   ctl_stream stream);
+/* Fragments for the CTL_DT_X3 launches from the pack records whose mode word carries CTL_PACK_X3 (the other records are skipped; the
+ * fp32 / bf16 pack entries skip these): [cout tile][tap pair][chunk][split hi | mid | lo][64 lanes][8 bf16], the three bf16 numbers of
+ * a split summing EXACTLY to the fp32 weight.  ctl_conv_wpack_floats_x3 = the float count of one sub-problem's buffer (15 KB per
+ * (cout tile, chunk) of a 3x3 kernel against 9 KB of the fp32 layout); max_total = the largest such count among the records. */
+size_t ctl_conv_wpack_floats_x3(int32_t cin, int32_t cout, int32_t ks);
+int ctl_pack_weights_x3_batched(const float* params, float* wpack, const int64_t* table, int32_t n_rec, int64_t max_total,
+                                ctl_stream stream);
 
 /* ------------------------------------------------------------------------------------------------ BatchNorm2d
  * encdec.py: every `norm(out_ch)`; three modes of SURVEY 8a row 4 (util.py:414-451).

@@ -1,0 +1,224 @@
+"""CTL_DT_X3 (csrc/ctl_conv_x3_stage.h): the fp32 convolutions contracted on the bf16 matrix pipe over an exact three-way bf16 split of both
+operands.  The claim under test is that this is STILL the fp32 computation: every case runs the X3 kernel and the fp32-MFMA kernel on the
+same descriptor and compares both against an fp64 CPU reference -- the X3 error must stay within the fp32 kernel's own error class
+(<= max(2x the fp32 kernel's error, 2e-6 of max|ref|)), far inside the 2e-4 tolerance the fp32 kernels are held to (tests/test_kernels_gpu.py).
+The split itself is checked for exactness on adversarial values."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from cooperative_training_and_latent_space_data_augmentation_amd import _ffi, ops  # noqa: E402
+from cooperative_training_and_latent_space_data_augmentation_amd._ffi import lib, check  # noqa: E402
+
+DEV = "cuda"
+
+
+def dev(x):
+    return x.to(DEV).contiguous(memory_format=torch.channels_last) if x.dim() == 4 else x.to(DEV).contiguous()
+
+
+def leaky(x, s):
+    return torch.where(x > 0, x, x * s)
+
+
+def errs(y3, y0, ref, what):
+    ref = ref.detach().double()
+    scale = max(float(ref.abs().max()), 1e-30)
+    e3 = float((y3.detach().cpu().double() - ref).abs().max()) / scale
+    e0 = float((y0.detach().cpu().double() - ref).abs().max()) / scale
+    assert e0 <= 2e-4, f"{what}: the fp32 kernel itself is off ({e0:.2e})"
+    assert e3 <= max(2.0 * e0, 2e-6), f"{what}: X3 error {e3:.3e} vs fp32-MFMA error {e0:.3e} (relative to max|ref|)"
+    return e3, e0
+
+
+def both(kw, x, packs, **args):
+    """run the descriptor on the fp32 pipe (packs[0]) and as CTL_DT_X3 (packs[1])"""
+    d0, d3 = _ffi.conv_desc(**kw), _ffi.conv_desc(dt=_ffi.DT_X3, **kw)
+    a0 = {k: (v.clone() if k == "y" and v is not None else v) for k, v in args.items()}
+    a3 = {k: (v.clone() if k == "y" and v is not None else v) for k, v in args.items()}
+    r0 = ops.conv_forward(d0, x, packs[0], **a0)
+    r3 = ops.conv_forward(d3, x, packs[1], **a3)
+    return r0, r3, d0, d3
+
+
+def test_split_is_exact_on_adversarial_values():
+    """hi + mid + lo == x bit for bit (fp64 sum of the three bf16 planes), including values whose bf16 rounding carries, tiny and huge
+    magnitudes, and negative numbers: read back through the X3 weight pack of a 1-tap-pair problem."""
+    g = torch.Generator().manual_seed(3)
+    vals = torch.cat([torch.randn(2000, generator=g), torch.randn(500, generator=g) * 1e-20, torch.randn(500, generator=g) * 1e20,
+                      torch.tensor([1.0, -1.0, 1.00390625, 1.0078125, 0.99609375, 3.3e38, -3.3e38, 1.1754944e-38 * 1e8, 0.0, 255.99998, 1.9999999]),
+                      (torch.randint(0, 2 ** 31 - 2 ** 24, (1085,), generator=g, dtype=torch.int64).to(torch.int32).view(torch.float32))])
+    # (the domain of the split: |x| below the largest bf16, 3.39e38 -- beyond it `hi` rounds to infinity -- and far enough above the
+    # fp32 denormals that `lo`, 2^-17 |x| or less, is still a normal number)
+    vals = vals[torch.isfinite(vals) & ((vals == 0) | ((vals.abs() > 1e-30) & (vals.abs() < 3.38e38)))][:4096]
+    vals = torch.cat([vals, torch.zeros(4096 - vals.numel())])
+    w = vals.view(16, 16, 4, 4).contiguous()               # [co][ci][kh][kw]
+    pk = ops.pack_oihw_fwd_x3(dev(w)).cpu()
+    words = pk.view(torch.int32).view(1, 8, 1, 3, 64, 4)   # [cot][fragment][chunk][split][lane][word]
+    lo16 = (words & 0xffff).to(torch.int32) << 16
+    hi16 = words & ~0xffff
+    parts = torch.stack([lo16.view(torch.float32), hi16.view(torch.float32)], -1).double()      # [..., word, element of the pair]
+    total = parts.sum(3)                                   # hi + mid + lo
+    for f in range(8):
+        for lane in range(64):
+            co, q = lane & 15, lane >> 4
+            tap = 2 * f + (q >> 1)
+            for j in range(8):
+                ci = (q & 1) * 8 + j
+                got = float(total[0, f, 0, lane, j // 2, j % 2])
+                want = float(w[co, ci, tap // 4, tap % 4])
+                assert got == want, (f, lane, j, got, want)
+
+
+CASES = [(2, 16, 16, 32, 32), (16, 16, 16, 64, 64), (4, 16, 16, 128, 128), (2, 32, 64, 16, 16), (2, 128, 128, 8, 8), (2, 64, 32, 24, 20),
+         (1, 32, 32, 6, 6), (2, 128, 64, 3, 3), (2, 32, 32, 48, 48), (1, 64, 48, 40, 72), (2, 128, 32, 36, 52), (3, 48, 16, 70, 70), (2, 16, 16, 9, 7)]
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w", CASES)
+def test_conv3x3_s1_forward_prologue_stats(n, cin, cout, h, w):
+    g = torch.Generator().manual_seed(n * 1000 + cin * 10 + cout + h)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * 0.2
+    b = torch.randn(cout, generator=g)
+    sc, sh = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.3
+    packs = (ops.pack_oihw_fwd(dev(wt)), ops.pack_oihw_fwd_x3(dev(wt)))
+    kw = dict(n=n, hin=h, win=w, cin=cin, hout=h, wout=w, cout=cout, ks=3, epi_flags=_ffi.EPI_BIAS | _ffi.EPI_STATS)
+    (y0, s0), (y3, s3), d0, d3 = both(kw, dev(x), packs, bias=dev(b), want_stats=True)
+    ref = F.conv2d(x.double(), wt.double(), b.double(), padding=1)
+    errs(y3, y0, ref, "conv3x3")
+    st = s3.view(-1, 2, cout).double().sum(0).cpu()
+    assert float((st[0] - ref.sum((0, 2, 3))).abs().max()) <= 1e-4 * float(ref.sum((0, 2, 3)).abs().max()) + 1e-3
+    assert float((st[1] - (ref ** 2).sum((0, 2, 3))).abs().max()) <= 1e-4 * float((ref ** 2).sum((0, 2, 3)).max())
+    kw2 = dict(kw, epi_flags=_ffi.EPI_BIAS, pro_affine=1, pro_slope=0.2)
+    (y0, _), (y3, _), _, _ = both(kw2, dev(x), packs, bias=dev(b), pro_scale=dev(sc), pro_shift=dev(sh))
+    ref2 = F.conv2d(leaky(x.double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1), 0.2), wt.double(), b.double(), padding=1)
+    errs(y3, y0, ref2, "conv3x3 + prologue")
+    # nearest-upsampled input (decoder conv.0) and the residual epilogue
+    if h <= 64:
+        kw3 = dict(n=n, hin=h, win=w, cin=cin, hout=2 * h, wout=2 * w, cout=cout, ks=3, in_mode=_ffi.IN_UP2, epi_flags=_ffi.EPI_RES, epi_act=_ffi.ACT_LEAKY,
+                   epi_slope=0.2)
+        v = torch.randn(n, cout, 2 * h, 2 * w, generator=g)
+        rs, rh = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.2
+        (y0, _), (y3, _), _, _ = both(kw3, dev(x), packs, res=dev(v), res_scale=dev(rs), res_shift=dev(rh))
+        ref3 = leaky(F.conv2d(F.interpolate(x.double(), scale_factor=2, mode="nearest"), wt.double(), padding=1)
+                     + v.double() * rs.double().view(1, -1, 1, 1) + rh.double().view(1, -1, 1, 1), 0.2)
+        errs(y3, y0, ref3, "conv3x3(up2) + residual + leaky")
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w", [(2, 16, 32, 32, 32), (2, 32, 64, 24, 40), (3, 128, 128, 12, 8), (16, 16, 32, 128, 128), (2, 64, 128, 7, 9)])
+def test_conv3x3_s2_and_its_data_gradients(n, cin, cout, h, w):
+    g = torch.Generator().manual_seed(cin + h)
+    x = torch.randn(n, cin, h, w, generator=g, requires_grad=True)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * 0.2
+    kw = dict(n=n, hin=h, win=w, cin=cin, hout=(h + 1) // 2, wout=(w + 1) // 2, cout=cout, ks=3, stride=2)
+    packs = (ops.pack_oihw_fwd(dev(wt)), ops.pack_oihw_fwd_x3(dev(wt)))
+    (y0, _), (y3, _), _, _ = both(kw, dev(x.detach()), packs)
+    ref = F.conv2d(x.double(), wt.double(), stride=2, padding=1)
+    errs(y3, y0, ref, "conv3x3 s2")
+    # zero-insert form of the data gradient (3x3 stride 1 over the zero-inserted dy, flipped / transposed weights) on even sizes
+    if h % 2 == 0 and w % 2 == 0:
+        dy = torch.randn(ref.shape, generator=g)
+        ref.backward(dy.double())
+        kwz = dict(n=n, hin=h // 2, win=w // 2, cin=cout, hout=h, wout=w, cout=cin, ks=3, in_mode=_ffi.IN_ZINS2)
+        pz = (ops.pack_oihw_dgrad(dev(wt)), ops.pack_oihw_dgrad_x3(dev(wt)))
+        (d0, _), (d3, _), _, _ = both(kwz, dev(dy), pz)
+        errs(d3, d0, x.grad, "zero-insert data gradient of conv3x3 s2")
+
+
+def _pack_phases(w, cout_eff, cin_eff, strides, mode, x3):
+    sub = (lib.ctl_conv_wpack_floats_x3 if x3 else lib.ctl_conv_wpack_floats)(cin_eff, cout_eff, 2)
+    table = np.asarray([[0, z * sub, cout_eff, cin_eff, 2, z, *strides, sub, mode | (_ffi.PACK_X3 if x3 else 0)] for z in range(4)], dtype=np.int64)
+    wd, td = dev(w).contiguous(), torch.from_numpy(table).to(DEV)
+    out = torch.zeros(4 * sub, device=DEV)
+    fn = lib.ctl_pack_weights_x3_batched if x3 else lib.ctl_pack_weights_batched
+    check(fn(wd.data_ptr(), out.data_ptr(), td.data_ptr(), 4, sub, ops.stream_ptr()))
+    return out
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w", [(2, 16, 16, 16, 16), (2, 128, 64, 4, 4), (3, 32, 16, 24, 20), (16, 16, 16, 64, 64), (2, 64, 32, 40, 36)])
+def test_phase_convs_and_pooled_4x4(n, cin, cout, h, w):
+    g = torch.Generator().manual_seed(cin + h)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * 0.2
+    b = torch.randn(cout, generator=g)
+    kw = dict(n=n, hin=h, win=w, cin=cin, hout=h, wout=w, cout=cout, ks=2, stride=1, pad=2, nsub=4, out_h=2 * h, out_w=2 * w, out_sy=2, out_sx=2, out_sub=1,
+              epi_flags=_ffi.EPI_BIAS | _ffi.EPI_STATS)
+    packs = (_pack_phases(wt, cout, cin, (cin * 9, 9, 3, 1), 2, False), _pack_phases(wt, cout, cin, (cin * 9, 9, 3, 1), 2, True))
+    y = ops.empty_nhwc(n, cout, 2 * h, 2 * w, DEV)
+    (y0, _), (y3, s3), d0, d3 = both(kw, dev(x), packs, bias=dev(b), y=y, want_stats=True)
+    ref = F.conv2d(F.interpolate(x.double(), scale_factor=2, mode="nearest"), wt.double(), b.double(), padding=1)
+    errs(y3, y0, ref, "phase forward of conv3x3(up2(x))")
+    rows = lib.ctl_conv_stats_blocks(_ffi.desc_ptr(d3))
+    part = s3.cpu().double().view(rows, 2, cout).sum(0)
+    assert float((part[1] - (ref ** 2).sum((0, 2, 3))).abs().max()) <= 2e-4 * float((ref ** 2).sum((0, 2, 3)).max())
+    # data gradient of a stride-2 3x3 conv as four phase convs over dy (pad code 0)
+    xs = torch.randn(n, cin, 2 * h, 2 * w, generator=g, dtype=torch.float64, requires_grad=True)
+    ws = torch.randn(cout, cin, 3, 3, generator=g) * 0.2
+    ys = F.conv2d(xs, ws.double(), stride=2, padding=1)
+    dy = torch.randn(ys.shape, generator=g)
+    ys.backward(dy.double())
+    kw2 = dict(n=n, hin=h, win=w, cin=cout, hout=h, wout=w, cout=cin, ks=2, stride=1, pad=0, nsub=4, out_h=2 * h, out_w=2 * w, out_sy=2, out_sx=2, out_sub=1)
+    p2 = (_pack_phases(ws, cin, cout, (9, cin * 9, 3, 1), 3, False), _pack_phases(ws, cin, cout, (9, cin * 9, 3, 1), 3, True))
+    dx = ops.empty_nhwc(n, cin, 2 * h, 2 * w, DEV)
+    (d0, _), (d3, _), _, _ = both(kw2, dev(dy), p2, y=dx)
+    errs(d3, d0, xs.grad, "phase data gradient of conv3x3 s2")
+    # the 4x4 stride-2 conv (pooled data gradient of a conv on a nearest-upsampled input), generic weights, with accumulate
+    if h % 2 == 0 and w % 2 == 0:
+        k4 = torch.randn(cout, cin, 4, 4, generator=g) * 0.2
+        kw4 = dict(n=n, hin=h, win=w, cin=cin, hout=h // 2, wout=w // 2, cout=cout, ks=4, stride=2, epi_flags=_ffi.EPI_ACCUM)
+        base = torch.randn(n, cout, h // 2, w // 2, generator=g)
+        (y0, _), (y3, _), _, _ = both(kw4, dev(x), (ops.pack_oihw_fwd(dev(k4)), ops.pack_oihw_fwd_x3(dev(k4))), y=dev(base))
+        errs(y3, y0, F.conv2d(x.double(), k4.double(), stride=2, padding=1) + base.double(), "conv4x4 s2 + accumulate")
+        # 2x2 stride-2 conv (data gradient of a ConvTranspose2d)
+        k2 = torch.randn(cout, cin, 2, 2, generator=g) * 0.3
+        kw5 = dict(n=n, hin=h, win=w, cin=cin, hout=h // 2, wout=w // 2, cout=cout, ks=2, stride=2, pad=0)
+        (y0, _), (y3, _), _, _ = both(kw5, dev(x), (ops.pack_oihw_fwd(dev(k2)), ops.pack_oihw_fwd_x3(dev(k2))))
+        errs(y3, y0, F.conv2d(x.double(), k2.double(), stride=2), "conv2x2 s2")
+
+
+@pytest.mark.parametrize("n,c,cout,h,w,groups", [(2, 16, 16, 32, 32, 1), (4, 32, 64, 24, 40, 2), (16, 16, 16, 128, 128, 1), (2, 64, 32, 9, 7, 1)])
+def test_batchnorm_backward_prologue_epilogue_and_side_output(n, c, cout, h, w, groups):
+    """pro_affine 2 (the conv input is the virtual tensor A*g + B*u + C of two fp32 tensors) with the CTL_EPI_BNBWD epilogue and the `xout` side
+    output, as the 3x3 data gradients of a residual block run them; X3 against the fp32 pipe against fp64."""
+    g = torch.Generator().manual_seed(c + h + groups)
+    gt, u = torch.randn(n, c, h, w, generator=g), torch.randn(n, c, h, w, generator=g)
+    coef = torch.randn(groups, 3, c, generator=g) * 0.5
+    wt = torch.randn(c, cout, 3, 3, generator=g) * 0.2            # forward weights [c_out_f = c][c_in_f = cout]: the data gradient maps c -> cout
+    u2 = torch.randn(n, cout, h, w, generator=g)
+    rs, rh = torch.rand(groups, cout, generator=g) + 0.5, torch.randn(groups, cout, generator=g) * 0.3
+    kw = dict(n=n, hin=h, win=w, cin=c, hout=h, wout=w, cout=cout, ks=3, pro_affine=2, epi_flags=_ffi.EPI_STATS | _ffi.EPI_BNBWD, epi_slope=0.2, groups=groups)
+    packs = (ops.pack_oihw_dgrad(dev(wt)), ops.pack_oihw_dgrad_x3(dev(wt)))
+    xo0, xo3 = torch.zeros_like(dev(gt)), torch.zeros_like(dev(gt))
+    d0, d3 = _ffi.conv_desc(**kw), _ffi.conv_desc(dt=_ffi.DT_X3, **kw)
+    args = dict(pro_scale=dev(coef), res=dev(u2), res_scale=dev(rs), res_shift=dev(rh), x2=dev(u), want_stats=True)
+    y0, s0 = ops.conv_forward(d0, dev(gt), packs[0], xout=xo0, **args)
+    y3, s3 = ops.conv_forward(d3, dev(gt), packs[1], xout=xo3, **args)
+    gi = torch.arange(n) // (n // groups)
+    virt = coef[gi, 0].double().view(n, c, 1, 1) * gt.double() + coef[gi, 1].double().view(n, c, 1, 1) * u.double() + coef[gi, 2].double().view(n, c, 1, 1)
+    da = F.conv_transpose2d(virt, wt.double(), padding=1)
+    sa = u2.double() * rs[gi].double().view(n, cout, 1, 1) + rh[gi].double().view(n, cout, 1, 1)
+    ref = da * torch.where(sa > 0, 1.0, 0.2)
+    errs(y3, y0, ref, "data gradient over the virtual tensor + BNBWD epilogue")
+    # (the side output is fp32 arithmetic in both families; the compiler contracts a*g + b*u + c into fmas differently in the two stagings)
+    assert float((xo3 - xo0).abs().max()) <= 1e-6 * float(xo0.abs().max())
+    assert float((xo3.cpu().double() - virt).abs().max()) <= 1e-5 * float(virt.abs().max())
+    rows0, rows3 = lib.ctl_conv_stats_blocks(_ffi.desc_ptr(d0)), lib.ctl_conv_stats_blocks(_ffi.desc_ptr(d3))
+    for gidx in range(groups):
+        sel = gi == gidx
+        want = torch.stack([ref[sel].sum((0, 2, 3)), (ref[sel] * u2[sel].double()).sum((0, 2, 3))])
+        got3 = s3.view(groups, rows3, 2, cout)[gidx].double().sum(0).cpu()
+        assert float((got3 - want).abs().max()) <= 2e-4 * float(want.abs().max()) + 1e-3
+
+
+def test_x3_rejects_what_it_does_not_cover():
+    x = dev(torch.randn(2, 4, 16, 16))
+    wt = dev(torch.randn(16, 4, 3, 3))
+    d = _ffi.conv_desc(n=2, hin=16, win=16, cin=4, hout=16, wout=16, cout=16, ks=3, dt=_ffi.DT_X3)
+    with pytest.raises(_ffi.CtlError):
+        ops.conv_forward(d, x, ops.pack_oihw_fwd(wt))
+    d1 = _ffi.conv_desc(n=2, hin=16, win=16, cin=16, hout=16, wout=16, cout=16, ks=1, dt=_ffi.DT_X3)
+    with pytest.raises(_ffi.CtlError):
+        ops.conv_forward(d1, dev(torch.randn(2, 16, 16, 16)), ops.pack_oihw_fwd(dev(torch.randn(16, 16, 1, 1))))
