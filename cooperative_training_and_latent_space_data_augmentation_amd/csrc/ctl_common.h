@@ -150,6 +150,11 @@ int ctl_conv_forward_x3(const ctl_conv* d, const float* x, const float* wpack, c
                         const float* res, const float* res_scale, const float* res_shift, const float* res2, const float* x2, float* y,
                         float* stats_partial, float* pool, float* xout, ctl_stream stream);
 
+int ctl_wgrad_x3_ok(const ctl_conv* d);
+int ctl_wgrad_x3_splits(const ctl_conv* d);
+int ctl_conv_wgrad_x3(const ctl_conv* d, const float* x, const float* pro_scale, const float* pro_shift, const float* dy, const float* dy2,
+                      const float* dy_coef, float* w_partial, float* b_partial, ctl_stream stream);
+
 // in-process profiling (ctl_plan.cpp): returns a token >= 0 if this launch is being timed
 int ctl_prof_begin(const char* kind, const ctl_conv* d, const ctl_conv_cfg* c, int nt, hipStream_t stream, bool dy2 = false);
 void ctl_prof_end(int token, hipStream_t stream);

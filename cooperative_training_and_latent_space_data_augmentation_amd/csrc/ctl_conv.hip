@@ -1198,6 +1198,10 @@ static int wgrad_pick(const ctl_conv* d, wgrad_cfg* w) {
         w->splits = ctl_wgrad_bf16_splits(d);
         return w->splits > 0 ? CTL_OK : CTL_EUNSUPPORTED;
     }
+    if (d->dt & CTL_DT_X3) {              // ... and so has the X3 kernel (ctl_wgrad_x3.hip)
+        w->splits = ctl_wgrad_x3_splits(d);
+        return w->splits > 0 ? CTL_OK : CTL_EUNSUPPORTED;
+    }
     wgrad_call a = {};
     a.d = d; a.w = w; a.query = true;
     return wgrad_dispatch(a);
@@ -1239,6 +1243,7 @@ extern "C" int ctl_conv_wgrad_ex(const ctl_conv* d, const float* x, const float*
     wgrad_cfg w;
     int rc = wgrad_pick(d, &w);
     if (rc != CTL_OK) return rc;
+    if (d->dt & CTL_DT_X3) return ctl_conv_wgrad_x3(d, x, pro_scale, pro_shift, dy, dy2, dy_coef, w_partial, b_partial, stream);
     if (d->dt & CTL_DT_BF16) {
         const int ptok16 = ctl_prof_begin("conv_wgrad_bf16", d, &w.c, w.ntw, (hipStream_t)stream, dy2 != nullptr);
         rc = ctl_conv_wgrad_bf16(d, x, pro_scale, pro_shift, dy, dy2, dy_coef, w_partial, b_partial, stream);

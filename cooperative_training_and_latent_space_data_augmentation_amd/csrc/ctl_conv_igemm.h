@@ -510,6 +510,10 @@ __global__ __launch_bounds__(256, X3 ? CTL_LB_X3(MT, NT, X2) : (MT * NT >= 8 || 
                 };
                 xread(0, 0);
                 wread(0, 0);
+#ifndef CTL_X3_PRIO
+#define CTL_X3_PRIO 0
+#endif
+                if constexpr (CTL_X3_PRIO > 0) __builtin_amdgcn_s_setprio(CTL_X3_PRIO);      // (experiment hook: the matrix phase outranks the other waves' staging)
 #pragma unroll
                 for (int st = 0; st < NSTEP; ++st) {
                     const int f = st / (MT / MS), m0 = (st % (MT / MS)) * MS, b = st & 1;
@@ -536,6 +540,7 @@ __global__ __launch_bounds__(256, X3 ? CTL_LB_X3(MT, NT, X2) : (MT * NT >= 8 || 
 #undef CTL_X3_MFMA
                     }
                 }
+                if constexpr (CTL_X3_PRIO > 0) __builtin_amdgcn_s_setprio(0);
             };
             if constexpr (WREG3) {
                 if (wreg_on) mfma_phase3(std::true_type{});

@@ -69,16 +69,20 @@ __device__ __forceinline__ float x3_part(float v, int s) {
 // Staging of one 16-channel chunk of the (virtual) input tile; a unit = 8 channels of a pixel = two 16-byte fp32 loads -> three 16-byte
 // bf16 LDS writes.  Same tile geometry, bounds handling, prologues (BatchNorm apply + LeakyReLU; X2: the BatchNorm-backward prologue on
 // two fp32 tensors, with the optional side output of the virtual tensor) as XStage.  cin is a multiple of 16 (checked on the host).
-template <int KS, int S, int MODE, int MT, int TW, bool X2 = false>
+// PLANAR = false (the weight-gradient kernel, whose transposed reads want whole pixel rows): three interleaved images [row][col][16 channels]
+// bf16 = 32 B per pixel; 8 consecutive lanes then write both halves of 4 consecutive pixels (lane = 2 pixel + half): 128 contiguous bytes.
+template <int KS, int S, int MODE, int MT, int TW, bool X2 = false, bool PLANAR = true>
 struct XStage3 {
     using G = Geom<KS, S, MT, TW>;
     static constexpr int NPIX = G::IH * G::IW;
-    static constexpr int SLOTS = ((NPIX + 7) / 8) * 16;
+    static constexpr int SLOTS = PLANAR ? ((NPIX + 7) / 8) * 16 : NPIX * 2;
     static constexpr int NU = (SLOTS + 255) / 256;
     static constexpr int PADH = (G::PAD + 1) >> 1;
     static constexpr int PLANE = ((G::IH * G::IWP * 16 + 16 + 255) / 256) * 256;      // >= 16 B of slack behind every plane: the dump slot
-    static constexpr int XT_BYTES = 6 * PLANE;
-    static constexpr int DUMP = PLANE - 16;
+    static constexpr int IMAGE = ((G::IH * G::IWP * 32 + 16 + 255) / 256) * 256;      // (interleaved form)
+    static constexpr int SPLIT = PLANAR ? 2 * PLANE : IMAGE;                           // byte distance between the images of two splits
+    static constexpr int XT_BYTES = 3 * SPLIT;
+    static constexpr int DUMP = (PLANAR ? PLANE : IMAGE) - 16;
     static constexpr bool PLAIN = (MODE == CTL_IN_PLAIN);
     int rel[NU];        // byte offset of the unit's first source element relative to the tile's source origin
     int rc[NU];         // r | c << 16 (tile-relative virtual coordinates); 0x7fff7fff past the tile
@@ -95,7 +99,7 @@ struct XStage3 {
 #pragma unroll
         for (int i = 0; i < NU; ++i) {
             const int u = tid + i * 256;
-            const int pix = ((u >> 4) << 3) | (u & 7), h = (u >> 3) & 1;
+            const int pix = PLANAR ? (((u >> 4) << 3) | (u & 7)) : (u >> 1), h = PLANAR ? ((u >> 3) & 1) : (u & 1);
             const int r = pix / G::IW;
             const int c = pix - r * G::IW;
             const bool in = pix < NPIX;
@@ -103,7 +107,7 @@ struct XStage3 {
             const int cc = PLAIN ? c : (((c - G::PAD) >> 1) + PADH);
             rel[i] = in ? ((rr * d.win + cc) * d.cin + h * 8) * 4 : CTL_OOB;
             rc[i] = in ? (r | (c << 16)) : 0x7fff7fff;
-            lds[i] = in ? (h * PLANE + (r * G::IWP + G::ldscol(c)) * 16) : DUMP;
+            lds[i] = in ? (PLANAR ? (h * PLANE + (r * G::IWP + G::ldscol(c)) * 16) : ((r * G::IWP + G::ldscol(c)) * 32 + h * 16)) : DUMP;
         }
         vmask = 0;
         all_in = false;
@@ -151,7 +155,7 @@ struct XStage3 {
     __device__ __forceinline__ void store(float* __restrict__ xtf, const ctl_conv& d, int g, const float* pro_scale, const float* pro_shift,
                                           int goff, const float* pro_c, __amdgpu_buffer_rsrc_t rxout, bool xout_on) {
         unsigned char* xt = reinterpret_cast<unsigned char*>(xtf);
-        const int cb = g * 16 + ((threadIdx.x >> 3) & 1) * 8;
+        const int cb = g * 16 + (PLANAR ? ((threadIdx.x >> 3) & 1) : (threadIdx.x & 1)) * 8;
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
         f32x4 a0 = {1.f, 1.f, 1.f, 1.f}, a1 = a0, b0 = zero, b1 = zero, c0 = zero, c1 = zero;
         if (X2 || d.pro_affine) {
@@ -180,8 +184,8 @@ struct XStage3 {
             u32x4 ph, pm, pl;
             x3_split8(lo, hi, ph, pm, pl);
             *reinterpret_cast<u32x4*>(xt + lds[i]) = ph;
-            *reinterpret_cast<u32x4*>(xt + lds[i] + 2 * PLANE) = pm;
-            *reinterpret_cast<u32x4*>(xt + lds[i] + 4 * PLANE) = pl;
+            *reinterpret_cast<u32x4*>(xt + lds[i] + SPLIT) = pm;
+            *reinterpret_cast<u32x4*>(xt + lds[i] + 2 * SPLIT) = pl;
         }
     }
 };

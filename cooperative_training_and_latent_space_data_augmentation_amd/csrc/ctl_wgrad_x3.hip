@@ -1,0 +1,364 @@
+// X3 weight gradient for gfx950 (MI355X): the fp32 weight gradient (same tensors, same partial layout and deterministic split reduction
+// as conv_wgrad_kernel in ctl_conv.hip) contracted on v_mfma_f32_16x16x32_bf16 over the exact three-way bf16 split of both operands
+// (ctl_conv_x3_stage.h).  Structure of the bf16 family's kernel (ctl_wgrad_bf16.hip):
+//   dW[tap][ci][co] = sum_pixels x_virtual[pixel*S + tap - pad][ci] * dy[pixel][co]:  D[ci][co] += A[ci][k = pixel] B[pixel][co], K = 32 pixels.
+// Both operands want 8 PIXELS of one channel per lane -- the transpose of the [pixel][16 channel] LDS images -- which ds_read_b64_tr_b16
+// delivers: per 16-lane group it reads 4 rows (pixels) x 16 columns (channels) of 16-bit elements and hands lane i column i.  Here every
+// operand exists three times (hi | mid | lo image), and a (tap, cout tile) step is six MFMAs
+//     x_hi*dy_hi + x_hi*dy_mid + x_mid*dy_hi + x_mid*dy_mid + x_hi*dy_lo + x_lo*dy_hi
+// -- 108 MFMAs of 16 cycles per 32 pixels, 16 cin and 32 cout where the fp32 kernel issues 144 of 32 cycles.
+// The bias gradient (column sums of dy) is taken from the staged fp32 values, before the split.
+#include "ctl_conv_x3_stage.h"
+
+typedef short x3_s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ x3_bf16x8 x3_tr_read8(const unsigned char* a0, const unsigned char* a1) {
+    const x3_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((x3_s16x4 __attribute__((address_space(3)))*)(a0));
+    const x3_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((x3_s16x4 __attribute__((address_space(3)))*)(a1));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    return __builtin_bit_cast(x3_bf16x8, s16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w});
+}
+
+#ifndef CTL_X3W_LB
+#define CTL_X3W_LB 2
+#endif
+// DY2: the output gradient is the virtual BatchNorm-backward result  A * dy + B * dy2 + C  (coefficients [group][3][cout] as the finalize
+// writes them; dy = g, dy2 = the BatchNorm input), evaluated in fp32 in this staging, then split
+template <int KS, int S, int MODE, int MT, int NTW, bool DY2>
+__global__ __launch_bounds__(256, CTL_X3W_LB) void conv_wgrad_x3_kernel(const ctl_conv d, const float* __restrict__ x,
+                                                                       const float* __restrict__ pro_scale, const float* __restrict__ pro_shift,
+                                                                       const float* __restrict__ dy, const float* __restrict__ dy2,
+                                                                       const float* __restrict__ dy_coef, float* __restrict__ w_partial,
+                                                                       float* __restrict__ b_partial, int tiles_h, int tiles_w, int ntiles,
+                                                                       int cin_p, int cout_p) {
+    constexpr int TW = 16;
+    using G = Geom<KS, S, MT, TW>;
+    using XS = XStage3<KS, S, MODE, MT, TW, false, false>;
+    constexpr int TAPS = KS * KS;
+    constexpr int KB = G::TP / 32;                       // k-blocks per tile: 8 (16x16 tile), 4 (8x16) or 2 (4x16)
+    constexpr int DYI = NTW * G::TP * 32;                // one split image of the dy tile: [cout tile][pixel][16 ch] bf16
+    constexpr int DYT_BYTES = 3 * DYI;
+    constexpr int RED_BYTES = 4 * NTW * 256 * 4;
+    constexpr int MAIN_BYTES = (XS::XT_BYTES + DYT_BYTES > RED_BYTES) ? (XS::XT_BYTES + DYT_BYTES) : RED_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[MAIN_BYTES + (DY2 ? 5 : 2) * CTL_PRO_MAX * 4];
+    unsigned char* xt = smem;
+    unsigned char* dyt = smem + XS::XT_BYTES;
+    float* cf_scale = reinterpret_cast<float*>(smem + MAIN_BYTES);
+    float* cf_shift = cf_scale + CTL_PRO_MAX;
+    float* cd = cf_shift + CTL_PRO_MAX;                  // DY2: A | B | C, [group][cout] each
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p = lane & 15, q = lane >> 4;
+    const int g = blockIdx.y;
+    const int cot0 = blockIdx.z * NTW;
+    const int group_n = d.n / (d.groups > 1 ? d.groups : 1);
+
+    f32x4 acc[TAPS][NTW];
+#pragma unroll
+    for (int a = 0; a < TAPS; ++a)
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) acc[a][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const __amdgpu_buffer_rsrc_t rx = ctl_rsrc(x, (int64_t)d.n * d.hin * d.win * d.cin * 4);
+    const __amdgpu_buffer_rsrc_t rdy = ctl_rsrc(dy, (int64_t)d.n * d.hout * d.wout * d.cout * 4);
+    const __amdgpu_buffer_rsrc_t rdy2 = DY2 ? ctl_rsrc(dy2, (int64_t)d.n * d.hout * d.wout * d.cout * 4) : rdy;
+    XS xs;
+    xs.init(d);
+    // dy tile: units of 8 channels (two 16-byte fp32 loads); all units of a thread share (cout tile, half): 256 % (2 NTW) == 0
+    constexpr int DU = G::TP * NTW * 2, ND = (DU + 255) / 256;
+    f32x4 dv0[ND], dv1[ND], dw0[DY2 ? ND : 1], dw1[DY2 ? ND : 1];
+    int drel[ND], drc[ND], dlds[ND];
+    unsigned dmask = 0;
+    bool dall = false;
+    f32x4 bs0 = {0.f, 0.f, 0.f, 0.f}, bs1 = bs0;        // bias gradient: this thread's 8 channels summed over its pixels (fp32, before the split)
+    const int drest = tid % (NTW * 2), dt_ = drest >> 1, dh = drest & 1;
+    const int dco = (cot0 + dt_) * 16 + dh * 8;          // first channel of this thread's units (cout is a multiple of 16: in range)
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+        const int u = tid + i * 256;
+        const int pix = u / (NTW * 2);
+        const int pr = pix / TW, pc = pix % TW;
+        drc[i] = (u < DU) ? (pr | (pc << 16)) : 0x7fff7fff;            // (4x16 tiles with one cout tile: 128 units, half of the threads have none)
+        drel[i] = (u < DU) ? ((pr * d.wout + pc) * d.cout + dco) * 4 : CTL_OOB;
+        dlds[i] = (dt_ * G::TP + pix) * 32 + dh * 16;
+    }
+    auto dyload = [&](int n, int ho0, int wo0) {
+        const int tb = ((n * d.hout + ho0) * d.wout + wo0) * d.cout * 4;
+        dall = ho0 + G::TH <= d.hout && wo0 + TW <= d.wout;
+        if (dall) {
+#pragma unroll
+            for (int i = 0; i < ND; ++i) { dv0[i] = ctl_bload4s(rdy, drel[i], tb); dv1[i] = ctl_bload4s(rdy, drel[i] + 16, tb); }
+            if constexpr (DY2) {
+#pragma unroll
+                for (int i = 0; i < ND; ++i) { dw0[i] = ctl_bload4s(rdy2, drel[i], tb); dw1[i] = ctl_bload4s(rdy2, drel[i] + 16, tb); }
+            }
+            return;
+        }
+        dmask = 0;
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const bool ok = (unsigned)(ho0 + (drc[i] & 0xffff)) < (unsigned)d.hout && (unsigned)(wo0 + (drc[i] >> 16)) < (unsigned)d.wout;
+            const int vo = ok ? (tb + drel[i]) : CTL_OOB, vo1 = ok ? (tb + drel[i] + 16) : CTL_OOB;
+            dv0[i] = ctl_bload4(rdy, vo); dv1[i] = ctl_bload4(rdy, vo1);
+            if constexpr (DY2) { dw0[i] = ctl_bload4(rdy2, vo); dw1[i] = ctl_bload4(rdy2, vo1); }
+            dmask |= ok ? (1u << i) : 0u;
+        }
+    };
+    auto dystore = [&](int goff) {
+        f32x4 a0, a1, b0, b1, c0, c1;
+        if constexpr (DY2) {
+            const float* cc = cd + goff + dco;
+            a0 = *reinterpret_cast<const f32x4*>(cc); a1 = *reinterpret_cast<const f32x4*>(cc + 4);
+            b0 = *reinterpret_cast<const f32x4*>(cc + CTL_PRO_MAX); b1 = *reinterpret_cast<const f32x4*>(cc + CTL_PRO_MAX + 4);
+            c0 = *reinterpret_cast<const f32x4*>(cc + 2 * CTL_PRO_MAX); c1 = *reinterpret_cast<const f32x4*>(cc + 2 * CTL_PRO_MAX + 4);
+        }
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            f32x4 lo = dv0[i], hi = dv1[i];
+            if constexpr (DY2) {      // pixels past the image contribute nothing (C alone would)
+                const bool in = dall || ((dmask >> i) & 1u);
+                lo = in ? (a0 * lo + b0 * dw0[i] + c0) : zero;
+                hi = in ? (a1 * hi + b1 * dw1[i] + c1) : zero;
+            }
+            if (DU % 256 != 0 && tid + i * 256 >= DU) continue;
+            bs0 += lo; bs1 += hi;
+            u32x4 ph, pm, pl;
+            x3_split8(lo, hi, ph, pm, pl);
+            *reinterpret_cast<u32x4*>(dyt + dlds[i]) = ph;
+            *reinterpret_cast<u32x4*>(dyt + dlds[i] + DYI) = pm;
+            *reinterpret_cast<u32x4*>(dyt + dlds[i] + 2 * DYI) = pl;
+        }
+    };
+    // transposed-read addresses of this lane: block row q' = (lane & 15) >> 2 (pixel), 8-byte column chunk p' = lane & 3
+    const int qp = (lane & 15) >> 2, pp = lane & 3;
+    const int krow = (q >> 1), kcol0 = 8 * (q & 1);     // tile row (within the k-block's two rows) and first column of this lane group
+    const __amdgpu_buffer_rsrc_t rnone = ctl_rsrc((const void*)nullptr, 0);
+    TileWalk cur;
+    cur.init(blockIdx.x, gridDim.x, tiles_h, tiles_w);
+    if ((int)blockIdx.x < ntiles) {
+        xs.load(rx, rx, d, cur.n, cur.th * G::TH, cur.tw * TW, g);
+        dyload(cur.n, cur.th * G::TH, cur.tw * TW);
+    }
+    if (d.pro_affine || DY2) {
+        if (d.pro_affine)
+            for (int i = tid; i < (d.groups > 1 ? d.groups : 1) * d.cin; i += 256) { cf_scale[i] = pro_scale[i]; cf_shift[i] = pro_shift[i]; }
+        if constexpr (DY2) {
+            for (int i = tid; i < (d.groups > 1 ? d.groups : 1) * d.cout; i += 256) {
+                const int gi = i / d.cout, ch = i - gi * d.cout;
+                cd[i] = dy_coef[(gi * 3 + 0) * d.cout + ch]; cd[CTL_PRO_MAX + i] = dy_coef[(gi * 3 + 1) * d.cout + ch];
+                cd[2 * CTL_PRO_MAX + i] = dy_coef[(gi * 3 + 2) * d.cout + ch];
+            }
+        }
+        __syncthreads();
+    }
+    if ((int)blockIdx.x < ntiles) {
+        xs.store(reinterpret_cast<float*>(xt), d, g, cf_scale, cf_shift, (cur.n / group_n) * d.cin, nullptr, rnone, false);
+        dystore((cur.n / group_n) * d.cout);
+    }
+    __syncthreads();
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const bool has_next = tile + (int)gridDim.x < ntiles;
+        if (has_next) {
+            cur.next();
+            xs.load(rx, rx, d, cur.n, cur.th * G::TH, cur.tw * TW, g);
+            dyload(cur.n, cur.th * G::TH, cur.tw * TW);
+        }
+        for (int kb = wave; kb < KB; kb += 4) {          // (4x16 tiles: two k-blocks, waves 2 and 3 only stage; 16x16 tiles: two k-blocks per wave)
+            const int tr = kb * 2 + krow;                // tile row of this lane group's 8 pixels
+            x3_bf16x8 bf[3][NTW];
+#pragma unroll
+            for (int sp = 0; sp < 3; ++sp)
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) {
+                    const unsigned char* b0 = dyt + sp * DYI + ((t * G::TP + tr * TW + kcol0 + qp) * 32) + pp * 8;
+                    bf[sp][t] = x3_tr_read8(b0, b0 + 4 * 32);
+                }
+            // the A operands of tap+1 are requested before the MFMAs of tap; the empty asm pins that order (see ctl_wgrad_bf16.hip)
+            auto a_operand = [&](int tap, x3_bf16x8* af) {
+                const int kh = tap / KS, kw = tap % KS;
+                const int c0 = G::ldscol((kcol0 + qp) * S + kw);
+                const unsigned char* a0 = xt + (((tr * S + kh) * G::IWP + c0) * 32) + pp * 8;
+#pragma unroll
+                for (int sp = 0; sp < 3; ++sp) af[sp] = x3_tr_read8(a0 + sp * XS::SPLIT, a0 + sp * XS::SPLIT + 4 * 32);
+            };
+            x3_bf16x8 af[2][3];
+            a_operand(0, af[0]);
+#pragma unroll
+            for (int tap = 0; tap < TAPS; ++tap) {
+                if (tap + 1 < TAPS) a_operand(tap + 1, af[(tap + 1) & 1]);
+                x3_bf16x8* a = af[tap & 1];
+                asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]) : : "memory");
+#define CTL_X3W_MFMA(SA, SB) _Pragma("unroll") for (int t = 0; t < NTW; ++t) \
+                    acc[tap][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[SA], bf[SB][t], acc[tap][t], 0, 0, 0);
+                CTL_X3W_MFMA(2, 0)
+                CTL_X3W_MFMA(0, 2)
+                CTL_X3W_MFMA(1, 1)
+                CTL_X3W_MFMA(1, 0)
+                CTL_X3W_MFMA(0, 1)
+                CTL_X3W_MFMA(0, 0)
+#undef CTL_X3W_MFMA
+            }
+        }
+        ctl_barrier_lds_reads_done();
+        if (has_next) {
+            xs.store(reinterpret_cast<float*>(xt), d, g, cf_scale, cf_shift, (cur.n / group_n) * d.cin, nullptr, rnone, false);
+            dystore((cur.n / group_n) * d.cout);
+        }
+        ctl_barrier_lds_writes_done();
+    }
+    __syncthreads();
+
+    // ---------------- sum the four waves through LDS and write this split's partial (layout of the fp32 kernel)
+    float* red = reinterpret_cast<float*>(smem);
+    constexpr int TAP_FLOATS = 4 * NTW * 256;
+    constexpr int TPR = (MAIN_BYTES / 4 / TAP_FLOATS) < TAPS ? (MAIN_BYTES / 4 / TAP_FLOATS) : TAPS;
+    static_assert(TPR >= 1, "reduction scratch");
+    const int64_t split_base = (int64_t)blockIdx.x * TAPS * cin_p * cout_p;
+#pragma unroll
+    for (int tap0 = 0; tap0 < TAPS; tap0 += TPR) {
+        if (tap0 > 0) ctl_barrier_lds_reads_done();
+#pragma unroll
+        for (int tp = 0; tp < TPR; ++tp) {
+            const int tap = tap0 + tp;
+            if (tap < TAPS) {
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) {
+                    float* r0 = red + tp * TAP_FLOATS + ((wave * NTW + t) * 4) * 64 + lane;
+                    r0[0] = acc[tap][t].x; r0[64] = acc[tap][t].y; r0[128] = acc[tap][t].z; r0[192] = acc[tap][t].w;
+                }
+            }
+        }
+        ctl_barrier_lds_writes_done();
+#pragma unroll
+        for (int tp = 0; tp < TPR; ++tp) {
+            const int tap = tap0 + tp;
+            if (tap < TAPS) {
+#pragma unroll
+                for (int e0 = 0; e0 < NTW * 256; e0 += 256) {
+                    const int e = e0 + tid;
+                    const int t = e >> 8, r = (e >> 6) & 3, l = e & 63;
+                    float v = 0.f;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) v += red[tp * TAP_FLOATS + ((w * NTW + t) * 4 + r) * 64 + l];
+                    const int co = (cot0 + t) * 16 + (l & 15);
+                    const int ci = g * 16 + (l >> 4) * 4 + r;
+                    if (co < cout_p) w_partial[split_base + ((int64_t)tap * cin_p + ci) * cout_p + co] = v;
+                }
+            }
+        }
+    }
+    if (g == 0 && b_partial != nullptr) {      // bias gradient: the threads' channel sums, thread (pixel slot, cout tile, half) -> [256][8] floats
+        ctl_barrier_lds_reads_done();
+        *reinterpret_cast<f32x4*>(red + tid * 8) = bs0;
+        *reinterpret_cast<f32x4*>(red + tid * 8 + 4) = bs1;
+        ctl_barrier_lds_writes_done();
+        if (tid < NTW * 16) {
+            const int t = tid >> 4, c = tid & 15, h = c >> 3, j = c & 7;
+            float v = 0.f;
+            for (int s = t * 2 + h; s < 256; s += NTW * 2) v += red[s * 8 + j];      // fixed order: deterministic
+            const int co = cot0 * 16 + tid;
+            if (co < cout_p) b_partial[(int64_t)blockIdx.x * cout_p + co] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+struct wgrad3_call {
+    const ctl_conv* d; ctl_conv_cfg c; int ntw, splits, ntiles, cin_p, cout_p;
+    const float *x, *dy, *dy2, *pro_scale, *pro_shift, *dy_coef; float *w_partial, *b_partial;
+    hipStream_t stream; bool query;
+};
+template <int KS, int S, int MODE, int MT, int NTW, bool DY2>
+static void wgrad3_go_f(wgrad3_call& a) {
+    static int occ = 0;
+    if (!occ) {
+        int n = 0;
+        // (of the plain instantiation, also for DY2: the split count is queried at plan time from the descriptor alone and sizes the partials)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_wgrad_x3_kernel<KS, S, MODE, MT, NTW, false>, 256, 0) != hipSuccess || n < 1) {
+            (void)hipGetLastError();
+            n = 1;
+        }
+        occ = n;
+    }
+    const int par = a.c.g * (a.c.cot / NTW);
+    static const int per_cu = ctl_tune_int("CTL_X3W_PERSIST", 2);      // tuning hook: resident blocks per CU
+    int splits = (256 * (occ < per_cu ? occ : per_cu)) / par;
+    if (splits > 512) splits = 512;
+    if (splits > a.ntiles) splits = a.ntiles;
+    if (splits < 1) splits = 1;
+    a.splits = splits;
+    if (a.query) return;
+    const dim3 grid((unsigned)splits, (unsigned)a.c.g, (unsigned)(a.c.cot / NTW));
+    conv_wgrad_x3_kernel<KS, S, MODE, MT, NTW, DY2><<<grid, dim3(256), 0, a.stream>>>(*a.d, a.x, a.pro_scale, a.pro_shift, a.dy, a.dy2, a.dy_coef, a.w_partial,
+                                                                                    a.b_partial, a.c.tiles_h, a.c.tiles_w, a.ntiles, a.cin_p, a.cout_p);
+}
+template <int KS, int S, int MODE, int MT, int NTW>
+static void wgrad3_go(wgrad3_call& a) {
+    if constexpr (KS == 3 && S == 1) {
+        if (a.dy2) { wgrad3_go_f<KS, S, MODE, MT, NTW, true>(a); return; }
+    }
+    wgrad3_go_f<KS, S, MODE, MT, NTW, false>(a);
+}
+template <int KS, int S, int MODE>
+static void wgrad3_go_tile(wgrad3_call& a) {
+    if constexpr (S == 1 && KS == 3) {
+        if (a.c.mt == 4) { if (a.ntw == 2) wgrad3_go<KS, S, MODE, 4, 2>(a); else wgrad3_go<KS, S, MODE, 4, 1>(a); return; }
+    }
+    if (a.c.mt == 2) { if (a.ntw == 2) wgrad3_go<KS, S, MODE, 2, 2>(a); else wgrad3_go<KS, S, MODE, 2, 1>(a); }
+    else { if (a.ntw == 2) wgrad3_go<KS, S, MODE, 1, 2>(a); else wgrad3_go<KS, S, MODE, 1, 1>(a); }
+}
+static int wgrad3_dispatch(wgrad3_call& a) {
+    const int k = a.d->ks, s = a.d->stride, m = a.d->in_mode;
+    if (k == 3 && s == 1 && m == CTL_IN_PLAIN) wgrad3_go_tile<3, 1, CTL_IN_PLAIN>(a);
+    else if (k == 3 && s == 1 && m == CTL_IN_UP2) wgrad3_go_tile<3, 1, CTL_IN_UP2>(a);
+    else if (k == 3 && s == 2 && m == CTL_IN_PLAIN) wgrad3_go_tile<3, 2, CTL_IN_PLAIN>(a);
+    else if (k == 2 && s == 2 && m == CTL_IN_PLAIN) wgrad3_go_tile<2, 2, CTL_IN_PLAIN>(a);
+    else CTL_FAIL(CTL_EUNSUPPORTED, "conv_wgrad(x3): no kernel for ks/stride/in_mode %d/%d/%d", k, s, m);
+    return CTL_OK;
+}
+int ctl_wgrad_x3_ok(const ctl_conv* d) {
+    const int k = d->ks, s = d->stride, m = d->in_mode;
+    const bool combo = (k == 3 && s == 1 && (m == CTL_IN_PLAIN || m == CTL_IN_UP2)) || (k == 3 && s == 2 && m == CTL_IN_PLAIN) || (k == 2 && s == 2 && m == CTL_IN_PLAIN);
+    return combo && d->cin % 16 == 0 && d->cout % 16 == 0 && d->nsub == 1 && !(d->dt & (CTL_DT_BF16 | CTL_DT_X16 | CTL_DT_Y16 | CTL_DT_RES16));
+}
+static int wgrad3_pick(const ctl_conv* d, wgrad3_call* a) {
+    CTL_REQUIRE(ctl_wgrad_x3_ok(d), "wgrad(x3): CTL_DT_X3 needs fp32-stored tensors, cin %% 16 == 0, cout %% 16 == 0 and a 3x3 (stride 1 / 2) or 2x2 stride-2 "
+                                    "kernel (got cin %d, cout %d, ks %d, stride %d, in_mode %d, dt %d)", d->cin, d->cout, d->ks, d->stride, d->in_mode, d->dt);
+    a->d = d;
+    int rc = ctl_conv_pick_cfg(d, &a->c, 1);
+    if (rc != CTL_OK) return rc;
+    // 16x16-pixel tiles for the large stride-1 3x3 layers: half the halo per pixel and two k-blocks per wave between barriers
+    static const int big_ok = ctl_tune_int("CTL_X3W_MT4", 1);
+    if (big_ok && d->stride == 1 && d->ks == 3 && d->hout >= 32 && d->wout >= 16 && d->cout == 16) {      // (two cout tiles: three images of a 256-pixel dy tile x 2 exceed half the LDS)
+        a->c.mt = 4; a->c.th = 16;
+        a->c.tiles_h = ctl_cdiv(d->hout, 16);
+    }
+    a->ntw = (a->c.cot >= 2 && a->c.cot % 2 == 0) ? 2 : 1;
+    a->ntiles = d->n * a->c.tiles_h * a->c.tiles_w;
+    a->cin_p = a->c.g * 16;
+    a->cout_p = a->c.cot * 16;
+    a->query = true;
+    rc = wgrad3_dispatch(*a);
+    a->query = false;
+    return rc;
+}
+int ctl_wgrad_x3_splits(const ctl_conv* d) {
+    wgrad3_call a = {};
+    return wgrad3_pick(d, &a) == CTL_OK ? a.splits : -1;
+}
+int ctl_conv_wgrad_x3(const ctl_conv* d, const float* x, const float* pro_scale, const float* pro_shift, const float* dy, const float* dy2,
+                      const float* dy_coef, float* w_partial, float* b_partial, ctl_stream stream) {
+    wgrad3_call a = {};
+    int rc = wgrad3_pick(d, &a);
+    if (rc != CTL_OK) return rc;
+    a.x = x; a.dy = dy; a.dy2 = dy2; a.dy_coef = dy_coef; a.pro_scale = pro_scale; a.pro_shift = pro_shift; a.w_partial = w_partial; a.b_partial = b_partial;
+    a.stream = (hipStream_t)stream;
+    const int ptok = ctl_prof_begin("conv_wgrad_x3", d, &a.c, a.ntw, a.stream, dy2 != nullptr);
+    rc = wgrad3_dispatch(a);
+    if (ptok >= 0) ctl_prof_end(ptok, a.stream);
+    if (rc != CTL_OK) return rc;
+    CTL_LAUNCH_CHECK("conv_wgrad(x3)");
+    return CTL_OK;
+}

@@ -59,6 +59,7 @@ FUSE_BNAPPLY16 = True    # bf16: the BatchNorm-backward apply passes of the resi
 X3 = True                # fp32: the 2x2 / 3x3 / 4x4 convs with cin, cout multiples of 16 contract on the bf16 matrix pipe over an exact three-way
                          # bf16 split of both fp32 operands (CTL_DT_X3, csrc/ctl_conv_x3_stage.h): same tensors, same epilogues, error per product
                          # below an fp32 multiply's rounding, 16/6 of the fp32 MFMA rate
+X3_WGRAD = True          # ... and so do the weight gradients of those layers (3x3 stride 1 / 2, 2x2 stride 2)
 FUSE_TAIL = True         # fp32: the residual tail's BatchNorm-backward reduction inside the launch that writes dOut (CTL_EPI_TAILBWD): dOut is
                          # never materialised, the stand-alone reduction launch (read dOut, out, v; write dS) disappears
 CONV_WORDS = _ffi.CONV_DTYPE.itemsize // 4      # ctl_conv as int32 words at the head of ctl_op.i
@@ -288,6 +289,9 @@ class PlanBuilder:
         BatchNorm-backward result A*dy + B*u + C (bf16 family)."""
         assert dy2 is None or (dy.b16 == dy2[0].b16 == self.b16 and ks == 3 and stride == 1)
         dt = (_ffi.DT_BF16 | (_ffi.DT_X16 if x.b16 else 0) | (_ffi.DT_Y16 if dy.b16 else 0)) if self.b16 else 0
+        if (X3 and X3_WGRAD and not self.b16 and x.c % 16 == 0 and dy.c % 16 == 0 and
+                ((ks == 3 and in_mode in (_ffi.IN_PLAIN, _ffi.IN_UP2) and (stride == 1 or in_mode == _ffi.IN_PLAIN)) or (ks == 2 and stride == 2 and in_mode == _ffi.IN_PLAIN))):
+            dt = _ffi.DT_X3          # the weight gradient on the bf16 matrix pipe over the exact three-way split (csrc/ctl_wgrad_x3.hip)
         d = self._conv_desc(x, dy.c, ks, stride, in_mode, dy.h, dy.w, pro, 0, 0, 0.0, dt=dt)
         dp = _ffi.desc_ptr(d)
         wb, bb = 4 * lib.ctl_wgrad_partial_floats(dp), 4 * lib.ctl_wgrad_bias_partial_floats(dp)

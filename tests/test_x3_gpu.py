@@ -213,6 +213,66 @@ def test_batchnorm_backward_prologue_epilogue_and_side_output(n, c, cout, h, w, 
         assert float((got3 - want).abs().max()) <= 2e-4 * float(want.abs().max()) + 1e-3
 
 
+WGRAD_CASES = [  # n, cin, cout, h, w, ks, stride, up
+    (2, 16, 16, 32, 32, 3, 1, False), (16, 16, 16, 64, 64, 3, 1, False), (2, 32, 64, 16, 16, 3, 1, False), (2, 128, 128, 8, 8, 3, 1, False),
+    (2, 64, 32, 24, 20, 3, 1, False), (3, 48, 16, 70, 70, 3, 1, False), (2, 16, 16, 9, 7, 3, 1, False), (2, 128, 64, 3, 3, 3, 1, False),
+    (2, 32, 16, 16, 16, 3, 1, True), (2, 128, 64, 8, 8, 3, 1, True), (2, 16, 32, 32, 32, 3, 2, False), (2, 64, 128, 14, 18, 3, 2, False),
+    (2, 32, 32, 16, 16, 2, 2, False), (4, 16, 16, 128, 128, 3, 1, False)]
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w,ks,stride,up", WGRAD_CASES)
+def test_weight_gradient(n, cin, cout, h, w, ks, stride, up):
+    """dW, db of the conv  leaky(x * sc + sh) -> (up-sampling) -> conv ks / stride  against fp64 autograd: X3 next to the fp32-MFMA kernel."""
+    g = torch.Generator().manual_seed(cin * 7 + cout + h + ks)
+    x = torch.randn(n, cin, h, w, generator=g)
+    sc, sh = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.3
+    wt = (torch.randn(cout, cin, ks, ks, generator=g, dtype=torch.float64) * 0.2).requires_grad_(True)
+    b = torch.zeros(cout, dtype=torch.float64, requires_grad=True)
+    xin = leaky(x.double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1), 0.2)
+    if up:
+        xin = F.interpolate(xin, scale_factor=2, mode="nearest")
+    ref = F.conv2d(xin, wt, b, stride=stride, padding=1 if ks == 3 else 0)
+    dy = torch.randn(ref.shape, generator=g)
+    ref.backward(dy.double())
+    ho, wo = ref.shape[2:]
+    kw = dict(n=n, hin=h, win=w, cin=cin, hout=ho, wout=wo, cout=cout, ks=ks, stride=stride, pad=1 if ks == 3 else 0, in_mode=_ffi.IN_UP2 if up else 0,
+              pro_affine=1, pro_slope=0.2)
+    out = []
+    for dt in (0, _ffi.DT_X3):
+        d = _ffi.conv_desc(dt=dt, **kw)
+        dw, db = torch.full((cout, cin, ks, ks), 7.0, device=DEV), torch.full((cout,), 7.0, device=DEV)
+        ops.conv_wgrad(d, dev(x), dev(dy), dw, (cin * ks * ks, ks * ks, ks, 1), dbias=db, pro_scale=dev(sc), pro_shift=dev(sh))
+        out.append((dw.clone(), db.clone()))
+        if dt:
+            ops.conv_wgrad(d, dev(x), dev(dy), dw, (cin * ks * ks, ks * ks, ks, 1), dbias=db, pro_scale=dev(sc), pro_shift=dev(sh), accumulate=True)
+            errs(dw, 2 * out[0][0], 2 * wt.grad, "weight gradient, accumulate")
+    errs(out[1][0], out[0][0], wt.grad, "weight gradient")
+    errs(out[1][1], out[0][1], b.grad, "bias gradient")
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w,groups", [(2, 16, 16, 32, 32, 1), (4, 32, 64, 24, 40, 2), (16, 16, 16, 128, 128, 1), (2, 64, 32, 9, 7, 1), (2, 128, 128, 16, 16, 1)])
+def test_weight_gradient_with_virtual_output_gradient(n, cin, cout, h, w, groups):
+    """ctl_conv_wgrad_ex: the output gradient is the virtual BatchNorm-backward result A*g + B*u + C (fp32 arithmetic in the staging, then the split)."""
+    g = torch.Generator().manual_seed(cin + cout + h + groups)
+    x = torch.randn(n, cin, h, w, generator=g)
+    gt, u = torch.randn(n, cout, h, w, generator=g), torch.randn(n, cout, h, w, generator=g)
+    coef = torch.randn(groups, 3, cout, generator=g) * 0.5
+    gi = torch.arange(n) // (n // groups)
+    dyv = coef[gi, 0].double().view(n, cout, 1, 1) * gt.double() + coef[gi, 1].double().view(n, cout, 1, 1) * u.double() + coef[gi, 2].double().view(n, cout, 1, 1)
+    wt = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    b = torch.zeros(cout, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), wt, b, padding=1).backward(dyv)
+    kw = dict(n=n, hin=h, win=w, cin=cin, hout=h, wout=w, cout=cout, ks=3, groups=groups)
+    out = []
+    for dt in (0, _ffi.DT_X3):
+        d = _ffi.conv_desc(dt=dt, **kw)
+        dw, db = torch.zeros(cout, cin, 3, 3, device=DEV), torch.zeros(cout, device=DEV)
+        ops.conv_wgrad(d, dev(x), dev(gt), dw, (cin * 9, 9, 3, 1), dbias=db, dy2=dev(u), dy_coef=dev(coef))
+        out.append((dw, db))
+    errs(out[1][0], out[0][0], wt.grad, "weight gradient over the virtual output gradient")
+    errs(out[1][1], out[0][1], b.grad, "bias gradient over the virtual output gradient")
+
+
 def test_x3_rejects_what_it_does_not_cover():
     x = dev(torch.randn(2, 4, 16, 16))
     wt = dev(torch.randn(16, 4, 3, 3))

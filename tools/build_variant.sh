@@ -7,7 +7,7 @@
 set -e
 cd "$(dirname "$0")/../cooperative_training_and_latent_space_data_augmentation_amd/csrc"
 name=$1; flags=$2; shift; shift
-all="ctl_conv.hip ctl_conv_x3.hip ctl_conv_bf16.hip ctl_wgrad_bf16.hip ctl_elem.hip ctl_mask.hip ctl_io.hip ctl_plan.cpp"
+all="ctl_conv.hip ctl_conv_x3.hip ctl_conv_bf16.hip ctl_wgrad_bf16.hip ctl_wgrad_x3.hip ctl_elem.hip ctl_mask.hip ctl_io.hip ctl_plan.cpp"
 files=${*:-$all}
 mkdir -p variants/obj_$name
 F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-gpu-rdc -Wall -Wno-unused-function -I../../include -I. $flags"
