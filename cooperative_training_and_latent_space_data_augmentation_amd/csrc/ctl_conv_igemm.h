@@ -469,7 +469,10 @@ __global__ __launch_bounds__(256, X3 ? CTL_LB_X3(MT, NT, X2) : (MT * NT >= 8 || 
         const int g2 = (g + 1 == G_chunks) ? 0 : g + 1;
         const bool new_w = has_next && G_chunks > 1;
         if (g2 == 0) nxt.next();
-        if (has_next) {
+#ifndef CTL_X3_ABLATE
+#define CTL_X3_ABLATE 0      // timing ablations of the X3 instantiations (variant builds only, WRONG results): 1 no split arithmetic, 2 no global
+#endif                       // loads in the loop, 4 no matrix phase, 8 no epilogue (profiles/r4_x3_ablation.txt)
+        if (has_next && !(X3 && (CTL_X3_ABLATE & 2))) {
             xs.load(rx, rx2, d, nxt.n, nxt.th * G::TH, nxt.tw * TW, g2);
             if (new_w) wload(g2);
         }
@@ -480,7 +483,8 @@ __global__ __launch_bounds__(256, X3 ? CTL_LB_X3(MT, NT, X2) : (MT * NT >= 8 || 
 #pragma unroll
                 for (int t = 0; t < NT; ++t) acc[m][t] = bias4[t];
         }
-        if constexpr (X3) {
+        if constexpr (X3 && (CTL_X3_ABLATE & 4)) {
+        } else if constexpr (X3) {
             // Six MFMAs per (fragment, M-tile, cout tile): hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi (ctl_conv_x3_stage.h).  A step is one
             // fragment of MS M-tiles; the three split operands of the next step are requested before this step's MFMAs (the empty asm
             // pins that order: the scheduler otherwise sinks every read to its use -- read, wait, MFMA, see ctl_conv_bf16.hip)
@@ -510,10 +514,6 @@ __global__ __launch_bounds__(256, X3 ? CTL_LB_X3(MT, NT, X2) : (MT * NT >= 8 || 
                 };
                 xread(0, 0);
                 wread(0, 0);
-#ifndef CTL_X3_PRIO
-#define CTL_X3_PRIO 0
-#endif
-                if constexpr (CTL_X3_PRIO > 0) __builtin_amdgcn_s_setprio(CTL_X3_PRIO);      // (experiment hook: the matrix phase outranks the other waves' staging)
 #pragma unroll
                 for (int st = 0; st < NSTEP; ++st) {
                     const int f = st / (MT / MS), m0 = (st % (MT / MS)) * MS, b = st & 1;
@@ -540,7 +540,6 @@ __global__ __launch_bounds__(256, X3 ? CTL_LB_X3(MT, NT, X2) : (MT * NT >= 8 || 
 #undef CTL_X3_MFMA
                     }
                 }
-                if constexpr (CTL_X3_PRIO > 0) __builtin_amdgcn_s_setprio(0);
             };
             if constexpr (WREG3) {
                 if (wreg_on) mfma_phase3(std::true_type{});
@@ -599,7 +598,7 @@ __global__ __launch_bounds__(256, X3 ? CTL_LB_X3(MT, NT, X2) : (MT * NT >= 8 || 
         ctl_barrier_lds_writes_done();
         TM(4)
 
-        if (g == G_chunks - 1) {
+        if (g == G_chunks - 1 && !(X3 && (CTL_X3_ABLATE & 8))) {
             // ---------------- epilogue: lane (p,q) holds channels co0..co0+3 of pixel p of each M-tile.  Buffer stores with
             // hardware bounds checks; nothing here is waited for in the loop.  Whole tiles with whole channel tiles (FULL) put
             // the tile origin into the scalar offset of the loads and skip every mask; ragged ones redirect dropped lanes to

@@ -182,7 +182,11 @@ struct XStage3 {
                 hi = in ? ctl_leaky01(hi * a1 + b1, slope) : zero;
             }
             u32x4 ph, pm, pl;
+#if defined(CTL_X3_ABLATE) && (CTL_X3_ABLATE & 1)      // (timing ablation, WRONG results: no split arithmetic)
+            ph = pm = pl = x3_pack8(lo, hi);
+#else
             x3_split8(lo, hi, ph, pm, pl);
+#endif
             *reinterpret_cast<u32x4*>(xt + lds[i]) = ph;
             *reinterpret_cast<u32x4*>(xt + lds[i] + SPLIT) = pm;
             *reinterpret_cast<u32x4*>(xt + lds[i] + 2 * SPLIT) = pl;
