@@ -38,6 +38,17 @@ MASKS = {"dropout": (DROP_IMG, DROP_SEG, "dropout latent masks"),               
 PEAK_MFMA_F32_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
 PEAK_MFMA_BF16_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak
 PEAK_HBM_GBS = 8000.0
+X3_PRODUCTS = 6                  # an X3 launch (fp32 operands split exactly into three bf16 numbers, csrc/ctl_conv_x3_stage.h) issues six bf16 MFMA
+                                 # products per fp32 product: its matrix-side ceiling for ALGORITHMIC flops is the bf16 peak / 6 = 416.7 TFLOP/s
+
+
+def peak_mfma_of(kernel_id, dtype):
+    """dense matrix peak, in algorithmic TFLOP/s, of the pipe a profiling id runs on"""
+    if dtype == "bf16":
+        return PEAK_MFMA_BF16_TFLOPS
+    if kernel_id.startswith(("conv_igemm_x3", "conv_wgrad_x3")):
+        return PEAK_MFMA_BF16_TFLOPS / X3_PRODUCTS
+    return PEAK_MFMA_F32_TFLOPS
 # the dominant kernel is not a constant: it is the profiling id with the largest serial time in a single-stream replay of the step
 # (every launch bracketed with HIP events on its launch stream), picked before the timed region and re-measured behind it
 PROF_EVERY = 4                   # inside the timed region the dominant kernel's launches are sampled (two event records per launch cost
@@ -148,7 +159,6 @@ def family_rooflines(prof, dtype, steps):
     """Per-family and per-kernel rooflines of ONE step from the single-stream replay (every launch bracketed with HIP events on its
     launch stream): conv families against the MFMA peak of the arithmetic type or HBM, whichever bounds them; the element-wise passes
     against HBM.  `ms_per_step` is serialised kernel time (the timed region overlaps two launch chains)."""
-    peak_mfma = PEAK_MFMA_BF16_TFLOPS if dtype == "bf16" else PEAK_MFMA_F32_TFLOPS
     out = {}
     for fam, member in FAMILIES:
         ids = {k: v for k, v in prof.items() if member(k)}
@@ -157,14 +167,18 @@ def family_rooflines(prof, dtype, steps):
         ms = sum(v["ms"] for v in ids.values())
         fl, by, n = sum(v["flops"] for v in ids.values()), sum(v["bytes"] for v in ids.values()), sum(v["launches"] for v in ids.values())
         tf, gbs = fl / ms / 1e9, by / ms / 1e6
-        f_m, f_h = tf / peak_mfma, gbs / PEAK_HBM_GBS
+        # matrix side: every member against the peak of ITS pipe (fp32 MFMA, or bf16 MFMA / 6 for the X3 launches), weighted by time
+        f_m = sum(v["flops"] / 1e9 / peak_mfma_of(k, dtype) for k, v in ids.items()) / ms
+        f_h = gbs / PEAK_HBM_GBS
         rec = {"bound": "mfma" if f_m >= f_h else "hbm", "frac": max(f_m, f_h), "tflops": tf, "hbm_gbs": gbs, "mfma_frac": f_m, "hbm_frac": f_h,
+               "tflops_over_fp32_mfma_peak": tf / PEAK_MFMA_F32_TFLOPS if dtype != "bf16" else None,
                "launches_per_step": n / steps, "ms_per_step": ms / steps, "algorithmic_gflop_per_step": fl / steps / 1e9,
                "algorithmic_gb_per_step": by / steps / 1e9, "kernels": {}}
         for k, v in sorted(ids.items(), key=lambda kv: -kv[1]["ms"])[:6]:
             ktf, kgb = v["flops"] / v["ms"] / 1e9, v["bytes"] / v["ms"] / 1e6
+            pk = peak_mfma_of(k, dtype)
             rec["kernels"][k] = {"launches_per_step": v["launches"] / steps, "avg_us": 1e3 * v["ms"] / v["launches"], "tflops": ktf, "hbm_gbs": kgb,
-                                 "frac": max(ktf / peak_mfma, kgb / PEAK_HBM_GBS), "bound": "mfma" if ktf / peak_mfma >= kgb / PEAK_HBM_GBS else "hbm"}
+                                 "peak_tflops": pk, "frac": max(ktf / pk, kgb / PEAK_HBM_GBS), "bound": "mfma" if ktf / pk >= kgb / PEAK_HBM_GBS else "hbm"}
         out[fam] = rec
     return out
 
@@ -276,7 +290,8 @@ def main():
                     help="eager: Python issues the ~1100 launches of a step on two HIP streams; graph: the whole step is one hipGraph replay "
                          "(host-insensitive); auto: both are timed for a few untimed steps after the warm-up and the faster one is measured")
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
-                    help="fp32: the reference's arithmetic (BASELINE configs[1], the headline); bf16: configs[2] -- network-internal "
+                    help="fp32: the reference's arithmetic (BASELINE configs[1], the headline; nets.X3: the 3x3 / 4x4 / 2x2 contractions run on the bf16 "
+                         "matrix pipe over an exact three-way split of the fp32 operands, same results class as fp32 MFMA); bf16: configs[2] -- network-internal "
                          "activations / gradients stored as bf16, convolutions on v_mfma_f32_16x16x32_bf16, fp32 accumulate / BatchNorm "
                          "statistics / master weights / losses")
     ap.add_argument("--masks", default=None, choices=list(MASKS), help="latent masking scheme (default: dropout for fp32, targeted for bf16)")
@@ -495,15 +510,18 @@ def main():
     loss_vals = [float(v) for v in losses]
     assert all(v == v and abs(v) < 1e6 for v in loss_vals), loss_vals
 
+    from cooperative_training_and_latent_space_data_augmentation_amd import nets as _nets
+    x3_on = args.dtype == "fp32" and bool(_nets.X3)
     if rank == 0:
         out = {
             "metric": "cooperative-training slices/sec (256x256, bs16 per GPU)", "value": world * args.batch * args.steps / dt,
             "unit": "slices/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.dtype == "bf16" else "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.dtype == "bf16" else ("f32 (bf16x3 split)" if x3_on else "f32"), "data": "synthetic",
             "config": {"workload": f"ACDC-shaped synthetic {args.size}x{args.size}x1, batch {args.batch}/GPU, full cooperative step "
                                    f"(FTN+STN standard + {mask_text} + hard-example training + backward + 5x Adam), "
                                    "reference-init weights" + ("; bf16 storage of network-internal tensors + bf16 MFMA, fp32 accumulate / "
-                                   "statistics / master weights (BASELINE configs[2])" if args.dtype == "bf16" else ""),
+                                   "statistics / master weights (BASELINE configs[2])" if args.dtype == "bf16" else "") +
+                                  ("; fp32 tensors and results, the 3x3/4x4/2x2 contractions on the bf16 matrix pipe over an exact 3-way split of the fp32 operands" if x3_on else ""),
                        "global_batch": world * args.batch,
                        "parallelism": f"dp{world}" if world > 1 else "single GPU"},
             "final_losses": loss_vals, "mode": mode, "mode_calibration": calib,
@@ -519,7 +537,7 @@ def main():
         def roofline_of(kid, rec, region_s=None, sampled_every=1):
             secs = rec["ms"] * 1e-3
             tf, gbs = rec["flops"] / secs / 1e12, rec["bytes"] / secs / 1e9
-            peak_mfma = PEAK_MFMA_BF16_TFLOPS if args.dtype == "bf16" else PEAK_MFMA_F32_TFLOPS
+            peak_mfma = peak_mfma_of(kid, args.dtype)
             f_mfma, f_hbm = tf / peak_mfma, gbs / PEAK_HBM_GBS
             bound = "mfma" if f_mfma >= f_hbm else "hbm"
             r = {"bound": bound, "achieved": tf if bound == "mfma" else gbs,
@@ -527,7 +545,10 @@ def main():
                  "unit": "TFLOP/s" if bound == "mfma" else "GB/s", "frac": max(f_mfma, f_hbm), "traffic": None,
                  "kernel": kid, "launches": int(rec["launches"]), "avg_us": 1e3 * rec["ms"] / rec["launches"],
                  "algorithmic_gflop_per_launch": rec["flops"] / rec["launches"] / 1e9,
-                 "algorithmic_mb_per_launch": rec["bytes"] / rec["launches"] / 1e6, "hbm_gbs": gbs, "hbm_frac": f_hbm}
+                 "algorithmic_mb_per_launch": rec["bytes"] / rec["launches"] / 1e6, "hbm_gbs": gbs, "hbm_frac": f_hbm, "tflops": tf}
+            if peak_mfma not in (PEAK_MFMA_BF16_TFLOPS, PEAK_MFMA_F32_TFLOPS):
+                r["peak_note"] = (f"X3 launch: fp32 operands split exactly into three bf16 numbers, {X3_PRODUCTS} bf16 MFMA products per fp32 product; peak = "
+                                  f"{PEAK_MFMA_BF16_TFLOPS:.0f} / {X3_PRODUCTS} TFLOP/s algorithmic ({tf / PEAK_MFMA_F32_TFLOPS:.2f} of the 157.3 TFLOP/s fp32-MFMA peak)")
             if sampled_every > 1:                          # (the sampled count is not the launch count)
                 r["sampled_every"] = sampled_every
                 r["launches_note"] = f"every {sampled_every}-th launch was bracketed: `launches` counts the samples"
