@@ -42,6 +42,9 @@ torch.set_num_threads(16)
 STEP = 2.0 ** -8
 NET_INPUT = {"image_encoder": (1, 128, 128), "shape_encoder": (4, 128, 128), "segmentation_decoder": (128, 8, 8),
              "shape_decoder": (128, 8, 8), "image_decoder": (128, 8, 8)}
+# the sizes the model runs (BASELINE configs[2]: bs16, 256 x 256; latent codes 128 x 16 x 16): other tile / occupancy choices than the small ones
+NET_INPUT_FULL = {"image_encoder": (1, 256, 256), "shape_encoder": (4, 256, 256), "segmentation_decoder": (128, 16, 16),
+                  "shape_decoder": (128, 16, 16), "image_decoder": (128, 16, 16)}
 DEAD = ("conv.0.bias", "conv.3.bias", "inc.0.bias", "inc.3.bias", "final_conv.0.bias", "code_decoupler.0.bias", "code_decoupler.3.bias")
 
 
@@ -54,8 +57,9 @@ def rel(a, b):
     return float((a - b).norm() / b.norm().clamp_min(1e-30))
 
 
-def _run_hip(name, mode, golden_sd, seed=3, n=4):
-    c, h, w = NET_INPUT[name]
+def _run_hip(name, mode, golden_sd, seed=3, n=4, full=False):
+    c, h, w = (NET_INPUT_FULL if full else NET_INPUT)[name]
+    n = 16 if full else n
     g = torch.Generator().manual_seed(seed)
     x = torch.relu(torch.randn(n, c, h, w, generator=g)) if "decoder" in name else torch.rand(n, c, h, w, generator=g)
     hnet = nets.build_networks(device=DEV, state_dicts={name: golden_sd[name]}, dtype="bf16")[name]
@@ -175,8 +179,31 @@ def _first(r):
 def test_bf16_backward_plan_wiring_decoder(name, mode, fused, golden_sd):
     # the fused reduction and the stand-alone one, both against the oracle; round 3: the apply passes inside the consumers'
     # staging and the tail's reduction inside the launch that writes dOut, each on and off
+    _wiring_decoder(name, mode, fused, golden_sd)
+
+
+@pytest.mark.parametrize("name", ["segmentation_decoder", "image_decoder"])
+def test_bf16_backward_plan_wiring_decoder_full_size(name, golden_sd):
+    """the same teacher-forced check at bs16 x 256^2, where the plan picks the 8x32-pixel tiles (`mt4,tw32`), the
+    two-blocks-per-CU two-tensor forms and the FUSE_XOUT16 tile-interior stores (up4: 16 -> 16 channels at 256^2) -- same 2^-8 bound on every
+    gradient of every block."""
+    _wiring_decoder(name, "A", (True, True, True), golden_sd, full=True)
+
+
+@pytest.mark.parametrize("name", ["image_encoder", "shape_encoder"])
+def test_bf16_backward_plan_wiring_encoder_full_size(name, golden_sd):
+    """... and the encoders (inc / down1 at 256^2 with the fused head pairs), bs16 x 256^2."""
+    old = nets.FUSE_PAIR16, P.FUSE_PAIR16
+    nets.FUSE_PAIR16 = P.FUSE_PAIR16 = True
+    try:
+        _wiring_encoder(name, "A", golden_sd, full=True)
+    finally:
+        nets.FUSE_PAIR16, P.FUSE_PAIR16 = old
+
+
+def _wiring_decoder(name, mode, fused, golden_sd, full=False):
     with _switches(fused):
-        hnet, x, xh, yh, douts, dd = _run_hip(name, mode, golden_sd)
+        hnet, x, xh, yh, douts, dd = _run_hip(name, mode, golden_sd, full=full)
         A = _Arenas(hnet, xh, yh, dd)
         onet = O.build_networks(init=False)[name]
         onet.load_state_dict(golden_sd[name])
@@ -219,8 +246,8 @@ def test_bf16_backward_plan_wiring_encoder(name, mode, pair, golden_sd):
         nets.FUSE_PAIR16, P.FUSE_PAIR16 = old
 
 
-def _wiring_encoder(name, mode, golden_sd):
-    hnet, x, xh, yh, douts, dd = _run_hip(name, mode, golden_sd)
+def _wiring_encoder(name, mode, golden_sd, full=False):
+    hnet, x, xh, yh, douts, dd = _run_hip(name, mode, golden_sd, full=full)
     A = _Arenas(hnet, xh, yh, dd)
     onet = O.build_networks(init=False)[name]
     onet.load_state_dict(golden_sd[name])

@@ -56,9 +56,23 @@ def projections(g, key):
 # PROJ_FLOOR x ||g64||).  Measured on both records: worst tensor 2.5 % of ||g64|| for the HIP step (the rms of four projections scatters
 # around the tensor's 0.3-1.6 % L2 error by up to ~1.6x), update-sign agreement 0.9996.
 PROJ_FACTOR, PROJ_FLOOR = 5.0, 4e-2
+# Round 4: the floor is per tensor.  tests/golden/proj_measured_r4.json holds, for every parameter tensor of the two
+# bs16 x 256^2 records, the HIP step's own measured error (rms of the four projection errors / ||g64||; tools: this test writes them to
+# gpurun_out/ on every run).  A tensor's floor is PROJ_MARGIN x its measured error, at least PROJ_MIN (the rms of four projections of a
+# noise-like error scatters by ~1.6x between builds whose summation order differs) and never above the old global 4e-2: a 3 % systematic
+# scale error in a tensor whose error was measured at 0.4 % now fails.
+PROJ_MARGIN, PROJ_MIN = 2.0, 6e-3
+_MEASURED_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "proj_measured_r4.json")
 
 
-def check_grad_projections(named_grads, rec3, what, factor=PROJ_FACTOR, floor=PROJ_FLOOR, against="fp64"):
+def measured_floors(case):
+    if not os.path.exists(_MEASURED_FILE):
+        return None
+    import json
+    return json.load(open(_MEASURED_FILE)).get(case)
+
+
+def check_grad_projections(named_grads, rec3, what, factor=PROJ_FACTOR, floor=PROJ_FLOOR, against="fp64", measured=None, dump=None):
     bad, worst = [], 0.0
     for key in rec3["keys"]:
         p64, p32, n64 = rec3["grad_proj_64"][key], rec3["grad_proj"][key], rec3["grad_norm_64"][key]
@@ -69,7 +83,10 @@ def check_grad_projections(named_grads, rec3, what, factor=PROJ_FACTOR, floor=PR
             err, tol = float((mine - p32).abs().max()), floor * n64
         else:
             rms = lambda v: float(v.pow(2).mean().sqrt())
-            err, tol = rms(mine - p64), max(factor * rms(p32 - p64), floor * n64)
+            fl = floor if measured is None or key not in measured else min(floor, max(PROJ_MARGIN * measured[key], PROJ_MIN))
+            err, tol = rms(mine - p64), max(factor * rms(p32 - p64), fl * n64)
+            if dump is not None:
+                dump[key] = err / max(n64, 1e-30)
         worst = max(worst, err / max(n64, 1e-30))
         if not err <= tol:
             bad.append((key, f"{err:.3e}", f"{tol:.3e}", f"||g64|| {n64:.3e}"))
@@ -300,7 +317,7 @@ def _hip_step(rec, golden_sd, two_streams=None, **kw):
     return s, torch.stack([v.detach().float() for v in losses]).cpu().double(), captured["grads"]
 
 
-def _check_hip_step(rec, s, got, grads, grad_rtol, yardstick=None, rec3=None, sd_before=None):
+def _check_hip_step(rec, s, got, grads, grad_rtol, yardstick=None, rec3=None, sd_before=None, case=None):
     assert torch.allclose(got, rec["losses"], atol=1e-4, rtol=0), (got, rec["losses"])
     for tag, m in zip(("image", "seg"), rec["masks"]):
         if m is not None and m.numel() == s.last_masks[tag].numel():
@@ -314,7 +331,13 @@ def _check_hip_step(rec, s, got, grads, grad_rtol, yardstick=None, rec3=None, sd
         k, n = key.split("/")
         assert float((dict(s.model[k].named_parameters())[n].detach().cpu() - p).abs().max()) <= 2.1e-4, key
     if rec3 is not None:
-        worst = check_grad_projections(grads, rec3, "hip")
+        dump = {}
+        worst = check_grad_projections(grads, rec3, "hip", measured=measured_floors(case) if case else None, dump=dump)
+        if case:                                             # (the measured values of THIS build, for the record / the next fixture)
+            import json
+            root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+            os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+            json.dump(dump, open(os.path.join(root, "gpurun_out", f"proj_measured_{case}.json"), "w"))
         params = {f"{k}/{n}": p for k, m in s.model.items() for n, p in m.named_parameters()}
         agree = check_update_signs(params, sd_before, rec3, "hip")
         print(f"[r3] worst projection error {worst:.3e} of ||g64||; update-sign agreement {agree:.5f}")
@@ -330,7 +353,7 @@ def test_hip_full_size_step_vs_reference(r2, r3, golden_sd, case):
     fp64 value."""
     rec = r2[case]
     s, got, grads = _hip_step(rec, golden_sd)
-    _check_hip_step(rec, s, got, grads, grad_rtol=1e-2, yardstick=rec["grad_stats_64"], rec3=r3[case], sd_before=golden_sd)
+    _check_hip_step(rec, s, got, grads, grad_rtol=1e-2, yardstick=rec["grad_stats_64"], rec3=r3[case], sd_before=golden_sd, case=case)
     for z, key in ((s.z_i, "z_i_stats"), (s.z_s, "z_s_stats")):
         assert torch.allclose(stats(z), rec[key], rtol=2e-4), key
     rel = lambda a, b: float((a - b).norm() / b.norm().clamp_min(1e-30))
