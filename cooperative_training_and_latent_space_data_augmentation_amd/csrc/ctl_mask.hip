@@ -282,11 +282,17 @@ __global__ __launch_bounds__(IB) void latent_mask_image_kernel(const f32x4* __re
                                                                 const float* __restrict__ soft_noise, int k_host,
                                                                 const int* __restrict__ k_dev, f32x4* __restrict__ masked,
                                                                 float* __restrict__ mask_out, float* __restrict__ score_out, int hw,
-                                                                int cq, int split_pix, int splits, int S, int slab_pix) {
+                                                                int cq, int split_pix, int splits, int S, int slab_pix, int n_img, int xcd_map) {
     // S blocks per image (small batches: more CUs at work): every block builds the WHOLE score row (the image's grad is re-read
     // from L2 by its S blocks) but holds and stores only its own slab of the code
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int c = cq * 4, img = blockIdx.x / S, sl = blockIdx.x - img * S, tid = threadIdx.x;
+    // Block -> (image, slab): the S blocks of an image sit on ONE XCD (block b runs on XCD b % 8), so that the image's grad -- which every one of
+    // them reads whole -- is fetched from HBM once and served from that XCD's L2 to the others (round 3 spread them over S XCDs: FETCH_SIZE
+    // counted 2.0x the algorithmic bytes).  XCD x hosts images x, x + 8, ...; the j-th block of an XCD is slab j % S of its (j / S)-th image.
+    const int c = cq * 4, tid = threadIdx.x;
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+    const int img = xcd_map ? (xcd + 8 * (jx / S)) : (int)(blockIdx.x / S), sl = xcd_map ? (jx % S) : (int)(blockIdx.x - img * S);
+    if (img >= n_img) return;      // (the grid is rounded up to whole XCD rounds)
     const int L = (MODE == 0) ? c : hw;
     float* srow = sm;                                                   // [L]
     float* mval = sm + L;                                               // [L]
@@ -575,10 +581,12 @@ extern "C" int ctl_latent_mask_fused(int32_t mode, const float* grad, const floa
         const int cpf = ctl_cdiv(slab_pix * (c / 4), IB);
         const int gpf = mode == 0 ? ctl_cdiv(split_pix, 256 / (c / 4)) : ctl_cdiv(hw * (c / 4), IB);
         const bool small = cpf <= 4 && gpf <= 8;
+        const int xcd_map = (S > 1 && n * S >= 8) ? 1 : 0;                                   // (see the kernel: an image's S blocks on one XCD)
+        const int grid_x = xcd_map ? 8 * ctl_cdiv(n, 8) * S : n * S;
 #define CTL_IMG_LAUNCH(M, CP, GP)                                                                                                  \
-        latent_mask_image_kernel<M, CP, GP><<<dim3(n * S), dim3(IB), lds, s>>>((const f32x4*)grad, (const f32x4*)code, soft_noise, k_host, \
-                                                                               k_dev, (f32x4*)masked, mask_out, score_out, hw, c / 4,  \
-                                                                               split_pix, splits, S, slab_pix)
+        latent_mask_image_kernel<M, CP, GP><<<dim3(grid_x), dim3(IB), lds, s>>>((const f32x4*)grad, (const f32x4*)code, soft_noise, k_host, \
+                                                                                k_dev, (f32x4*)masked, mask_out, score_out, hw, c / 4,  \
+                                                                                split_pix, splits, S, slab_pix, n, xcd_map)
         if (mode == 0) { if (small) CTL_IMG_LAUNCH(0, 4, 8); else CTL_IMG_LAUNCH(0, IPF, 8); }      // (more than 8 loads per split: rolled loop)
         else { if (small) CTL_IMG_LAUNCH(1, 4, 8); else CTL_IMG_LAUNCH(1, IPF, IPF); }
 #undef CTL_IMG_LAUNCH
