@@ -589,6 +589,10 @@ def main():
                      (["--lib", args.lib] if args.lib else []) + [x for kv in args.set for x in ("--set", kv)]
             out["config3_bf16"] = sub_record(["--dtype", "bf16", "--masks", "targeted"] + common, "config3_bf16")
             out["config5_inference"] = sub_record(["--workload", "inference"] + common, "config5_inference")
+            # BASELINE configs[3]'s masking scheme (all three schemes randomly sampled per step: one captured graph per scheme pair) at N = 1 --
+            # the 8-GPU run itself is the driver's; this is the per-GPU step it scales from
+            out["config4_random_masks_n1"] = sub_record(["--masks", "random", "--mode", "graph", "--no-cpu-baseline"] + [a for a in common if a != "--no-cpu-baseline"],
+                                                        "config4_random_masks_n1")
     if use_dist:
         dist.destroy_process_group()
     if rank == 0:
@@ -641,7 +645,7 @@ def headline(d):
     lm = (d.get("roofline_latent_mask") or {})
     if lm:
         h["latent_mask_hbm_frac"] = {k.split("_")[0] + "_" + k.split("_")[-1]: (v.get("graph_replay_frac") or v.get("frac")) for k, v in lm.items()}
-    for k in ("config3_bf16", "config5_inference"):
+    for k in ("config3_bf16", "config5_inference", "config4_random_masks_n1"):
         if k in d:
             h[k] = _sub_headline(d[k])
     h["detail"] = d.get("detail_file", DETAIL_FILE)

@@ -63,7 +63,8 @@ def test_bench_last_stdout_line_is_the_small_headline(tmp_path):
     assert rec["value"] > 0 and rec["steps"] == 2 and rec["warmup"] == 1 and rec["n_gpus"] == 1
     assert 0 < rec["roofline"]["frac"] < 1 and rec["roofline"]["kernel"] and rec["roofline"]["bound"] in ("mfma", "hbm")
     assert rec["cpu_baseline"]["value"] > 0 and rec["cpu_baseline"]["kind"] == "port"
-    assert rec["config3_bf16"]["value"] > 0 and rec["config5_inference"]["value"] > 0
+    assert rec["config3_bf16"]["value"] > 0 and rec["config5_inference"]["value"] > 0 and rec["config4_random_masks_n1"]["value"] > 0
+    assert rec["config4_random_masks_n1"]["mode"] == "graph"
     assert not any(l.startswith("BENCH_DETAIL") for l in lines)            # the big record goes to stderr and the file
     assert any(l.startswith("BENCH_DETAIL ") for l in out.stderr.splitlines())
     assert "UserWarning" not in out.stderr, out.stderr[-2000:]
