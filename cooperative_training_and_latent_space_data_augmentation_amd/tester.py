@@ -21,17 +21,23 @@ def max_slices_per_pass(h: int, w: int, widest_channels: int = 16) -> int:
     return max(1, (2 ** 31 - 1) // (h * w * widest_channels * 4))
 
 
-def predict_volume(segmentation_model, image_d: torch.Tensor, n_iter=None, chunk=None, out: torch.Tensor = None) -> torch.Tensor:
+COALESCE_CHUNKS = True      # run consecutive <= `maximum_batch_size`-slice chunks of a volume as one pass (see predict_volume)
+
+
+def predict_volume(segmentation_model, image_d: torch.Tensor, n_iter=None, chunk=None, out: torch.Tensor = None, coalesce=None) -> torch.Tensor:
     """uint8 label volume [n,H,W] of a device volume [n,1,H,W]: `predict` (model.py:375-394) + arg-max on the device.
-    chunk = 10 is the reference's loop (test_basic_segmentation_solver.py:85-114, a GPU-memory workaround); chunk = None runs the
-    whole volume as ONE pass -- exact, because `predict` uses eval-mode BatchNorm (running statistics): slices are independent, so
-    batching changes nothing but the number of launches (bitwise equal labels, tests/test_engine_gpu.py).  A volume whose widest
-    tensor would pass the 2 GiB addressing limit is cut into the largest passes that fit."""
+    chunk = 10 is the reference's loop (test_basic_segmentation_solver.py:85-114): a GPU-MEMORY workaround, not part of the computation --
+    `predict` puts every network in eval mode (running BatchNorm statistics), so slices are independent and batching changes nothing but
+    the number of launches (bitwise equal logits and labels, tests/test_engine_gpu.py::test_whole_volume_pass_is_bitwise_the_chunked_loop).
+    With `coalesce` (default: tester.COALESCE_CHUNKS = True) consecutive chunks therefore run as ONE pass, as many as the 2 GiB
+    addressing limit of a tensor allows (288 GB of HBM hold any volume); coalesce=False is the reference's literal loop.  chunk = None:
+    the whole volume per pass either way."""
     n, _, h, w = image_d.shape
     limit = max_slices_per_pass(h, w)
-    chunk = limit if chunk is None else min(int(chunk), limit)
-    if chunk < 1:
+    coalesce = COALESCE_CHUNKS if coalesce is None else bool(coalesce)
+    if chunk is not None and int(chunk) < 1:
         raise ValueError("chunk must be positive")
+    chunk = limit if (chunk is None or coalesce) else min(int(chunk), limit)
     pred = out if out is not None else torch.empty((n, h, w), dtype=torch.uint8, device=image_d.device)
     for lo in range(0, n, chunk):
         hi = min(n, lo + chunk)
@@ -72,17 +78,20 @@ class TestSegmentationNetwork(object):
             save_path=join(self.save_path, self.detailed_report_file_name) if self.save_path else None)
         return self.df
 
-    def evaluate(self, i, data_tensor_pack, total_number, maximum_batch_size=10):
-        """One patient: chunked `predict`, device arg-max into one uint8 volume, metric update from the device tensors.
-        maximum_batch_size = 10 is upstream's default (drop-in behaviour); None = the whole volume per pass (same labels, see
-        predict_volume; 2x the slices/s on a 40-slice volume)."""
+    def evaluate(self, i, data_tensor_pack, total_number, maximum_batch_size=10, coalesce=None):
+        """One patient: `predict` over the volume, device arg-max into one uint8 volume, metric update from the device tensors.
+        maximum_batch_size = 10 is upstream's default argument (a GPU-memory workaround); the chunks it asks for are run as one pass
+        (tester.COALESCE_CHUNKS, exact: see predict_volume; 2x the slices/s on a 40-slice volume); coalesce=False: the literal loop."""
         dev = torch.device("cuda", torch.cuda.current_device())
         image = data_tensor_pack["image"]
         if image.dim() == 5:                              # DataLoader(batch_size=1) adds a leading axis upstream
             image = image[0]
         limit = max_slices_per_pass(image.shape[-2], image.shape[-1])
-        maximum_batch_size = min(int(image.shape[0]), limit) if maximum_batch_size is None else min(int(maximum_batch_size), limit)
-        assert maximum_batch_size > 0
+        assert maximum_batch_size is None or int(maximum_batch_size) > 0
+        if maximum_batch_size is None or (COALESCE_CHUNKS if coalesce is None else coalesce):
+            maximum_batch_size = min(int(image.shape[0]), limit)
+        else:
+            maximum_batch_size = min(int(maximum_batch_size), limit)
         label = torch.as_tensor(data_tensor_pack["label"]).reshape(-1, image.shape[-2], image.shape[-1])
         assert image.size(1) == 1, "currently only support gray images, found: {}".format(image.size(1))
         image_d = image.to(dev, dtype=torch.float32, non_blocking=True)

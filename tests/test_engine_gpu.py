@@ -564,8 +564,17 @@ def test_whole_volume_pass_is_bitwise_the_chunked_loop(golden_sd):
         whole = s.predict(vol, n_iter=n_iter)
         parts = torch.cat([s.predict(vol[lo:lo + 10], n_iter=n_iter) for lo in range(0, 40, 10)], 0)
         assert torch.equal(whole, parts)
-        assert torch.equal(predict_volume(s, vol, n_iter=n_iter, chunk=None), predict_volume(s, vol, n_iter=n_iter, chunk=10))
-        assert torch.equal(predict_volume(s, vol, n_iter=n_iter, chunk=7), predict_volume(s, vol, n_iter=n_iter, chunk=10))     # ragged tail
+        # the reference's literal loop (coalesce=False), the default call with the reference's arguments (its chunks run as one pass) and
+        # the explicit whole-volume call: the same labels
+        literal = predict_volume(s, vol, n_iter=n_iter, chunk=10, coalesce=False)
+        n0 = _ffi.lib.ctl_launch_count()
+        default = predict_volume(s, vol, n_iter=n_iter, chunk=10)
+        n1 = _ffi.lib.ctl_launch_count()
+        predict_volume(s, vol, n_iter=n_iter, chunk=10, coalesce=False)
+        n2 = _ffi.lib.ctl_launch_count()
+        assert torch.equal(predict_volume(s, vol, n_iter=n_iter, chunk=None), literal) and torch.equal(default, literal)
+        assert (n2 - n1) > 3 * (n1 - n0)                                   # ... in a quarter of the launches
+        assert torch.equal(predict_volume(s, vol, n_iter=n_iter, chunk=7, coalesce=False), literal)     # ragged tail
     assert max_slices_per_pass(192, 192) == (2 ** 31 - 1) // (192 * 192 * 64) == 910
     assert max_slices_per_pass(4096, 4096) == 1
 
