@@ -433,6 +433,12 @@ def main():
             gstep = CooperativeStepGraph(solver, IMG_CFG, SEG_CFG, grad_hook=hook_graph)
             graph_step = lambda: gstep(clean, label, noisy)
             graph_step()                                  # capture + first replay
+            if args.masks == "random":                    # one captured graph per (image scheme, shape scheme) pair: capture all nine BEFORE the timed
+                for _ in range(200):                      # region (the scheme is drawn per step: a first-time pair inside it would time a capture)
+                    if len(gstep.entries) >= 9:
+                        break
+                    graph_step()
+                calib["scheme_pair_graphs"] = len(gstep.entries)
             fence()
         except Exception as exc:                          # capture is an optimisation: the eager path is the same computation
             if mode == "graph":

@@ -590,6 +590,10 @@ __global__ __launch_bounds__(256, X3 ? CTL_LB_X3(MT, NT, X2) : (MT * NT >= 8 || 
         TM(1)
         ctl_barrier_lds_reads_done();    // every wave is done reading this step's LDS images
         TM(2)
+#ifdef CTL_TIMING_X3_VMCNT      // (timing variant: split the staging phase into the wait for the prefetched loads [2 -> 9] and the rest [3])
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        TM(9)
+#endif
         if (has_next) {    // refill LDS from the prefetched registers
             xs.store(xt, d, g2, cf_scale, cf_shift, (nxt.n / group_n) * d.cin, cf_c, rxout, xout_on);   // v[] holds chunk g2 of tile nxt (== cur unless g2 == 0)
             if (new_w) wstore();

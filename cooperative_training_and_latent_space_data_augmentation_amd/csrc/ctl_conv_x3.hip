@@ -14,8 +14,13 @@ __device__ unsigned long long ctl_tm3[CTL_TM_WAVES][10];
                 const unsigned long long tm_t0 = tm_prev, tm_r0 = __builtin_amdgcn_s_memrealtime();
 #define TM(i) { const unsigned long long tm_now = __builtin_amdgcn_s_memtime(); tm_acc[i] += tm_now - tm_prev; tm_prev = tm_now; }
 #define TM_COUNT(i) { tm_acc[i] += 1; }
+#ifdef CTL_TIMING_X3_VMCNT      // slot 9 then holds the vmcnt wait of the staging phase instead of the realtime span
+#define CTL_TM3_REAL
+#else
+#define CTL_TM3_REAL tm_acc[9] = __builtin_amdgcn_s_memrealtime() - tm_r0;
+#endif
 #define TM_FLUSH { const unsigned w_ = ((blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 4 + (threadIdx.x >> 6)) % CTL_TM_WAVES; \
-                   tm_acc[8] = __builtin_amdgcn_s_memtime() - tm_t0; tm_acc[9] = __builtin_amdgcn_s_memrealtime() - tm_r0; \
+                   tm_acc[8] = __builtin_amdgcn_s_memtime() - tm_t0; CTL_TM3_REAL \
                    if ((threadIdx.x & 63) == 0) { _Pragma("unroll") for (int i_ = 0; i_ < 10; ++i_) ctl_tm3[w_][i_] += tm_acc[i_]; } }
 extern "C" int ctl_debug_timing_x3(unsigned long long* out12) {
     static unsigned long long host[CTL_TM_WAVES][10];

@@ -64,7 +64,7 @@ def one(n, cin, cout, h, w, check_n=2, pro=False, stats=True):
         steps = max(tm[6], 1)
         names = ["issue", "mfma", "bar_rd", "stage", "bar_wr", "epi"]
         print("   x3 phase cycles per (tile, chunk) step per wave:", {k: round(tm[i] / steps) for i, k in enumerate(names)}, "setup/wave", round(tm[7] / max(tm[11], 1)),
-              "span/wave", round(tm[8] / max(tm[11], 1)), "MHz", round(100.0 * tm[8] / max(tm[9], 1)), "steps/wave", round(steps / max(tm[11], 1), 1))
+              "span/wave", round(tm[8] / max(tm[11], 1)), "MHz or vmcnt-wait/step", round(100.0 * tm[8] / max(tm[9], 1)), round(tm[9] / steps), "steps/wave", round(steps / max(tm[11], 1), 1))
     fl = 2.0 * n * h * w * cin * cout * 9
     by = 4.0 * n * h * w * (cin + cout)
     print(f"n{n} {cin:3d}->{cout:3d} @{h}x{w} pro={int(pro)}: fp32 {t0:7.1f} us ({fl / t0 / 1e6:6.1f} TF, err {e0:.2e})   x3 {t3:7.1f} us ({fl / t3 / 1e6:6.1f} TF alg, {by / t3 / 1e3:6.0f} GB/s, err {e3:.2e})   x{t0 / t3:.2f}", flush=True)

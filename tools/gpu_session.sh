@@ -10,15 +10,17 @@ if [ "$tests" = "tests" ]; then
   tail -5 $out/pytest_gpu.log
 fi
 timeout 1200 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench.json 2> $out/bench.err; echo "bench exit $?"
-python3 - $out/bench.json <<'PY'
+cp bench_detail.json $out/bench_detail.json; cp bench_detail_config3_bf16.json bench_detail_config5_inference.json bench_detail_config4_random_masks_n1.json $out/ 2>/dev/null
+python3 - $out <<'PY'
 import json, sys
-d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-print("fp32: %.1f slices/s %.3f ms mode %s launches %s roofline %.3f" % (d["value"], d["ms_per_step"], d["mode"], d["launches_per_step"]["library"], d["roofline"]["frac"]))
+out = sys.argv[1]
+line = open(out + "/bench.json").read().strip().splitlines()[-1]
+h = json.loads(line)
+print("headline line: %d bytes; %.1f slices/s %.3f ms mode %s; roofline %s frac %.3f; cpu %s" % (len(line), h["value"], h["ms_per_step"], h["mode"], h["roofline"]["kernel"], h["roofline"]["frac"], h.get("cpu_baseline", {}).get("value")))
+for k in ("config3_bf16", "config5_inference", "config4_random_masks_n1"): print("  ", k, h.get(k))
+d = json.load(open(out + "/bench_detail.json"))
+print("launches", d["launches_per_step"]["library"], "calibration", d["mode_calibration"])
 for k, v in d.get("roofline_families", {}).items(): print("   family %-38s %6.2f ms/step %6.1f launches  frac %.3f (%s)" % (k, v["ms_per_step"], v["launches_per_step"], v["frac"], v["bound"]))
-c3 = d.get("config3_bf16", {}); c5 = d.get("config5_inference", {})
-print("config3_bf16:", {k: c3.get(k) for k in ("value", "ms_per_step", "mode", "error")}, "roofline", c3.get("roofline", {}).get("frac"))
-print("config5:", {k: c5.get(k) for k in ("value", "ms_per_step", "error")}, {k: round(v["value"]) for k, v in c5.get("forms", {}).items()})
-print("cpu:", d.get("cpu_baseline", {}).get("value"))
 PY
 timeout 600 bash tools/prof_bench.sh ${tag}_fp32 > $out/prof_fp32.txt 2>&1; cp gpurun_out/prof_${tag}_fp32/stats.csv $out/kernel_stats_fp32.csv
 timeout 600 bash tools/prof_bench.sh ${tag}_bf16 --dtype bf16 > $out/prof_bf16.txt 2>&1; cp gpurun_out/prof_${tag}_bf16/stats.csv $out/kernel_stats_bf16.csv
