@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256, CTL_X3W_LB) void conv_wgrad_x3_kernel(const ct
     using G = Geom<KS, S, MT, TW>;
     using XS = XStage3<KS, S, MODE, MT, TW, false, false>;
     constexpr int TAPS = KS * KS;
-    constexpr int KB = G::TP / 32;                       // k-blocks per tile: 8 (16x16 tile), 4 (8x16) or 2 (4x16)
+    constexpr int KB = G::TP / 32;                       // k-blocks per tile: 4 (8x16) or 2 (4x16)
     constexpr int DYI = NTW * G::TP * 32;                // one split image of the dy tile: [cout tile][pixel][16 ch] bf16
     constexpr int DYT_BYTES = 3 * DYI;
     constexpr int RED_BYTES = 4 * NTW * 256 * 4;
@@ -303,9 +303,6 @@ static void wgrad3_go(wgrad3_call& a) {
 }
 template <int KS, int S, int MODE>
 static void wgrad3_go_tile(wgrad3_call& a) {
-    if constexpr (S == 1 && KS == 3) {
-        if (a.c.mt == 4) { if (a.ntw == 2) wgrad3_go<KS, S, MODE, 4, 2>(a); else wgrad3_go<KS, S, MODE, 4, 1>(a); return; }
-    }
     if (a.c.mt == 2) { if (a.ntw == 2) wgrad3_go<KS, S, MODE, 2, 2>(a); else wgrad3_go<KS, S, MODE, 2, 1>(a); }
     else { if (a.ntw == 2) wgrad3_go<KS, S, MODE, 1, 2>(a); else wgrad3_go<KS, S, MODE, 1, 1>(a); }
 }
@@ -329,12 +326,8 @@ static int wgrad3_pick(const ctl_conv* d, wgrad3_call* a) {
     a->d = d;
     int rc = ctl_conv_pick_cfg(d, &a->c, 1);
     if (rc != CTL_OK) return rc;
-    // 16x16-pixel tiles for the large stride-1 3x3 layers: half the halo per pixel and two k-blocks per wave between barriers
-    static const int big_ok = ctl_tune_int("CTL_X3W_MT4", 1);
-    if (big_ok && d->stride == 1 && d->ks == 3 && d->hout >= 32 && d->wout >= 16 && d->cout == 16) {      // (two cout tiles: three images of a 256-pixel dy tile x 2 exceed half the LDS)
-        a->c.mt = 4; a->c.th = 16;
-        a->c.tiles_h = ctl_cdiv(d->hout, 16);
-    }
+    // (16x16-pixel tiles for the full-resolution 16-channel layers, the bf16 family's choice, measured slower here at two resident blocks per
+    //  CU: 16->16 @256^2 45.0 vs 47.6 us, up-sampled 16->16 @128^2 42.4 vs 44.7 us, tools/sweep_wgrad_x3.sh -- the 8x16 tile stays)
     a->ntw = (a->c.cot >= 2 && a->c.cot % 2 == 0) ? 2 : 1;
     a->ntiles = d->n * a->c.tiles_h * a->c.tiles_w;
     a->cin_p = a->c.g * 16;

@@ -22,8 +22,11 @@ def child(kind):
     from cooperative_training_and_latent_space_data_augmentation_amd import ops
     from cooperative_training_and_latent_space_data_augmentation_amd._ffi import lib, check
     res = {}
+    x3 = bool(os.environ.get("CTL_BENCH_X3"))          # the same layers as CTL_DT_X3 launches (those X3 covers)
     for name, cin, cout, h, ks, stride, mode in LAYERS:
-        n = 16
+        n = int(os.environ.get("CTL_BENCH_N", "16"))
+        if x3 and (ks == 1 or cin % 16 or cout % 16):
+            continue
         hv = h * (2 if mode else 1)
         ho = (hv + 1) // 2 if stride == 2 else hv
         x = torch.randn(n, cin, h, h, device="cuda").contiguous(memory_format=torch.channels_last)
@@ -31,11 +34,11 @@ def child(kind):
         if os.environ.get("CTL_ZERO_DATA"):      # power/DVFS probe: all-zero operands
             x.zero_(); w.zero_()
         d = _ffi.conv_desc(n=n, hin=h, win=h, cin=cin, hout=ho, wout=ho, cout=cout, ks=ks, stride=stride, in_mode=mode,
-                           epi_flags=_ffi.EPI_BIAS | (_ffi.EPI_STATS if kind == "fwd" else 0))
+                           epi_flags=_ffi.EPI_BIAS | (_ffi.EPI_STATS if kind == "fwd" else 0), dt=_ffi.DT_X3 if x3 else 0)
         b = torch.zeros(cout, device="cuda")
         flops = 2.0 * n * ho * ho * cout * cin * ks * ks
         if kind == "fwd":
-            wp = ops.pack_oihw_fwd(w)
+            wp = ops.pack_oihw_fwd_x3(w) if x3 else ops.pack_oihw_fwd(w)
             y = torch.empty(n, cout, ho, ho, device="cuda").contiguous(memory_format=torch.channels_last)
             st = torch.empty(lib.ctl_conv_stats_floats(_ffi.desc_ptr(d)), device="cuda")
             run = lambda: check(lib.ctl_conv_forward(_ffi.desc_ptr(d), x.data_ptr(), wp.data_ptr(), b.data_ptr(), None, None, None, None,
