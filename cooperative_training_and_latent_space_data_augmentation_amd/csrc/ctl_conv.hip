@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ctl_conv d, const
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         const int tp = (4 * j + (p >> 2) < 9) ? 4 * j + (p >> 2) : 8;      // rows past tap 8 are computed on tap 8 and dropped
-        c4off[j] = ((tp / 3) * G::IWP + tp % 3) * 16 + (p & 3);
+        c4off[j] = ((tp / 3) * G::IWP + tp % 3) * 4 + (p & 3);      // (dense image: 4 floats per pixel, see XStage)
     }
     float bsum[NTW];
 #pragma unroll
@@ -533,7 +533,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ctl_conv d, const
 #pragma unroll
                 for (int tap = 0; tap < NACC; ++tap) {
                     const int kh = tap / KS, kw = tap % KS;
-                    const float af = C4 ? xt[(tr * G::IWP + pc) * 16 + c4off[tap]]
+                    const float af = C4 ? xt[(tr * G::IWP + pc) * 4 + c4off[tap]]
                                         : xt[((tr * S + kh) * G::IWP + G::ldscol(pc * S + kw)) * 16 + p];
 #pragma unroll
                     for (int t = 0; t < NTW; ++t)

@@ -31,7 +31,12 @@
 template <int KS, int S, int MODE, int MT, int TW, bool X2 = false>
 struct XStage {
     using G = Geom<KS, S, MT, TW>;
-    static constexpr int UNITS = G::IH * G::IW * 4;
+    // C4M (round 4): inputs with <= 4 channels keep a DENSE image, [row][col][4 floats] = 16 B per pixel, one staging unit per pixel.  In
+    // the 64-B-per-pixel image of the other modes only every fourth quad was used: 3 of 4 staging threads idled and the 16 lanes of an
+    // operand read hit four banks' worth of addresses four times over (SQ_LDS_BANK_CONFLICT = 0.53 of the LDS-active cycles on the
+    // first-layer convs, profiles/r4_sq_counters_fp32.json).
+    static constexpr bool C4M = (MODE == CTL_IN_C4);
+    static constexpr int UNITS = G::IH * G::IW * (C4M ? 1 : 4);
     static constexpr int NU = (UNITS + 255) / 256;
     static constexpr int PADH = (G::PAD + 1) >> 1;   // source-space padding of the x2 modes
     int rel[NU];        // byte offset of the unit relative to the tile's source origin
@@ -45,11 +50,11 @@ struct XStage {
     int tb_last;        // X2: byte offset of the tile held in v[] (for the side output of the virtual tensor, see store)
 
     __device__ __forceinline__ void init(const ctl_conv& d) {
-        const int tid = threadIdx.x, cq = tid & 3;
+        const int tid = threadIdx.x, cq = C4M ? 0 : (tid & 3);
 #pragma unroll
         for (int i = 0; i < NU; ++i) {
             const int u = tid + i * 256;
-            const int pix = u >> 2;
+            const int pix = C4M ? u : (u >> 2);
             const int r = pix / G::IW;
             const int c = pix - r * G::IW;
             const bool in = u < UNITS;
@@ -60,7 +65,7 @@ struct XStage {
             const int cc = CTL_MODE_IS_PLAIN(MODE) ? c : (((c - G::PAD) >> 1) + PADH);
             rel[i] = in ? ((rr * d.win + cc) * d.cin + cq * 4) * 4 : CTL_OOB;
             rc[i] = in ? (r | (c << 16)) : 0x7fff7fff;
-            lds[i] = in ? ((r * G::IWP + G::ldscol(c)) * 16 + cq * 4) : G::XT_IMAGE;
+            lds[i] = in ? (C4M ? (r * G::IWP + c) * 4 : ((r * G::IWP + G::ldscol(c)) * 16 + cq * 4)) : G::XT_IMAGE;
         }
         vmask = 0;
         all_in = false;
@@ -94,7 +99,7 @@ struct XStage {
             }
             return;
         }
-        const bool chan_ok = g * 16 + (threadIdx.x & 3) * 4 < d.cin;
+        const bool chan_ok = C4M || g * 16 + (threadIdx.x & 3) * 4 < d.cin;
         unsigned m = 0;
         int vo[NU];
 #pragma unroll
@@ -155,7 +160,7 @@ struct XStage {
             for (int i = 0; i < NU; ++i) *reinterpret_cast<f32x4*>(xt + lds[i]) = v[i];
             return;
         }
-        const int cb = g * 16 + (threadIdx.x & 3) * 4;
+        const int cb = C4M ? 0 : g * 16 + (threadIdx.x & 3) * 4;
         f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
         if (cb < d.cin) {
             if (d.cin >= 4) {
@@ -329,7 +334,7 @@ __global__ __launch_bounds__(256, X3 ? CTL_LB_X3(MT, NT, X2) : (MT * NT >= 8 || 
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         const int tp = (4 * j + q < 9) ? 4 * j + q : 8;
-        xrd4[j] = xt + ((wrow + tp / 3) * G::IWP + p + tp % 3) * 16;
+        xrd4[j] = xt + ((wrow + tp / 3) * G::IWP + p + tp % 3) * 4;      // (dense image: 4 floats per pixel)
     }
     // X3: byte offsets of the B operand inside plane (split 0, half q & 1): lane group q carries tap 2f + (q >> 1) of fragment f (clamped
     // to the last tap: its pair partner has zero weights); M-tile and split offsets are compile-time immediates
@@ -559,7 +564,7 @@ __global__ __launch_bounds__(256, X3 ? CTL_LB_X3(MT, NT, X2) : (MT * NT >= 8 || 
                 for (int t = 0; t < NT; ++t) wf[b][t] = *reinterpret_cast<const f32x4*>(wrd + (tap * NT + t) * 256);
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
-                    if (C4) xf[b][m] = *reinterpret_cast<const f32x4*>(xrd4[tap] + ((m / TWT) * G::IWP + (m % TWT) * 16) * 16);   // tap = quad
+                    if (C4) xf[b][m] = *reinterpret_cast<const f32x4*>(xrd4[tap] + ((m / TWT) * G::IWP + (m % TWT) * 16) * 4);   // tap = quad
                     else xf[b][m] = *reinterpret_cast<const f32x4*>(xrd + (((m / TWT) * S + kh) * G::IWP + (m % TWT) * 16 + kcol) * 16);
                 }
             };
