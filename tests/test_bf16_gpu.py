@@ -418,7 +418,7 @@ def test_bn_backward_prologue_argument_checks():
         ops.conv_wgrad(d32w, xf, xf, dw, (c, 1, 1, 1), dy2=xf, dy_coef=coef)                                           # 1x1 weight gradient: no such kernel
 
 
-@pytest.mark.parametrize("family", ["fp32", "bf16"])
+@pytest.mark.parametrize("family", ["fp32", "bf16", "x3"])
 @pytest.mark.parametrize("form", ["1x1_accum", "1x1", "2x2_s2", "zins_3x3"])
 @pytest.mark.parametrize("n,cin,cout,h,w,groups", [(2, 16, 16, 32, 32, 1), (4, 32, 16, 24, 20, 2), (2, 128, 64, 8, 8, 1), (16, 16, 16, 128, 128, 1), (3, 48, 32, 18, 38, 1)])
 def test_tail_backward_epilogue(n, cin, cout, h, w, groups, form, family):
@@ -426,12 +426,15 @@ def test_tail_backward_epilogue(n, cin, cout, h, w, groups, form, family):
     BatchNorm-backward sums (sum g, sum g*v) in the statistics partials.  bf16 family: sums from the unrounded g, g stored as bf16."""
     if n % groups:
         pytest.skip("n % groups")
+    if family == "x3" and form.startswith("1x1"):
+        pytest.skip("the 1x1 hosts stay on the fp32 pipe")
     b16 = family == "bf16"
     gen = torch.Generator().manual_seed(n + cin + cout + h + len(form))
     q = (lambda t: t.to(torch.bfloat16).float()) if b16 else (lambda t: t)
     out, v = q(torch.randn(n, cout, h, w, generator=gen)), q(torch.randn(n, cout, h, w, generator=gen))
-    dt = (BF | _ffi.DT_X16 | _ffi.DT_Y16 | _ffi.DT_RES16) if b16 else 0
+    dt = (BF | _ffi.DT_X16 | _ffi.DT_Y16 | _ffi.DT_RES16) if b16 else (_ffi.DT_X3 if family == "x3" else 0)      # (x3: the fp32 tensors, CTL_DT_X3 launch)
     flags = _ffi.EPI_TAILBWD | _ffi.EPI_STATS
+    pack32 = ops.pack_oihw_fwd_x3 if family == "x3" else ops.pack_oihw_fwd
     y0 = None
     if form.startswith("1x1"):
         x = q(torch.randn(n, cin, h, w, generator=gen))
@@ -446,7 +449,7 @@ def test_tail_backward_epilogue(n, cin, cout, h, w, groups, form, family):
     elif form == "2x2_s2":
         x = q(torch.randn(n, cin, 2 * h, 2 * w, generator=gen))
         wt = torch.randn(cout, cin, 2, 2, generator=gen) * 0.3
-        wp = (ops.pack_oihw_fwd_bf16 if b16 else ops.pack_oihw_fwd)(dev(wt))
+        wp = (ops.pack_oihw_fwd_bf16 if b16 else pack32)(dev(wt))
         ref = F.conv2d(rb(x) if b16 else x.double(), rb(wt) if b16 else wt.double(), stride=2)
         d = _ffi.conv_desc(n=n, hin=2 * h, win=2 * w, cin=cin, hout=h, wout=w, cout=cout, ks=2, stride=2, pad=0, groups=groups, epi_slope=0.2, dt=dt,
                            epi_flags=flags)
@@ -455,7 +458,7 @@ def test_tail_backward_epilogue(n, cin, cout, h, w, groups, form, family):
             pytest.skip("even sizes")
         x = q(torch.randn(n, cin, h // 2, w // 2, generator=gen))
         wt = torch.randn(cout, cin, 3, 3, generator=gen) * 0.2
-        wp = (ops.pack_oihw_fwd_bf16 if b16 else ops.pack_oihw_fwd)(dev(wt))
+        wp = (ops.pack_oihw_fwd_bf16 if b16 else pack32)(dev(wt))
         xz = torch.zeros(n, cin, h, w, dtype=torch.float64)
         xz[:, :, ::2, ::2] = rb(x) if b16 else x.double()
         ref = F.conv2d(xz, rb(wt) if b16 else wt.double(), padding=1)
