@@ -192,15 +192,8 @@ static int conv3_dispatch(conv3_call& a) {
 static int conv3_pick_cfg(const ctl_conv* d, ctl_conv_cfg* c) {
     const int rc = ctl_conv_pick_cfg(d, c, 0);
     if (rc != CTL_OK) return rc;
-    // the 8x32-pixel tile whenever it still gives 512 blocks: the fp32 family leaves it for 8x16 above 768 blocks with two cout tiles (there
-    // the smaller tile runs three blocks per CU); here both run two, and the larger tile stages less halo per pixel
-    // (tools/bench_conv.py, CTL_BENCH_X3=1, n = 32: 32->32 @128^2 87.4 -> 79.8 us, 64->64 @64^2 69.7 -> 64.6 us)
-    if (d->stride == 1 && d->ks == 3 && d->wout >= 32 && c->nt == 2 && !(c->mt == 4 && c->tw == 32) &&
-        (int64_t)d->n * ctl_cdiv(d->hout, 8) * ctl_cdiv(d->wout, 32) * (c->cot / c->nt) * d->nsub >= 512) {
-        c->mt = 4; c->tw = 32; c->th = 8;
-        c->tiles_h = ctl_cdiv(d->hout, c->th);
-        c->tiles_w = ctl_cdiv(d->wout, c->tw);
-    }
+    // (the fp32 family's tile choice is kept for stride 1: forcing the 8x32-pixel tile wherever it gives 512 blocks is 7-9 % faster per launch on the
+    //  n = 32 layers alone -- tools/bench_conv.py, CTL_BENCH_X3=1 -- and worth nothing in the step: 15.69 vs 15.65 ms same-box)
     if (d->stride == 2 && d->ks >= 3) {
         c->nt = 1;
         if (d->ks == 4 && c->mt != 1) {
