@@ -9,9 +9,9 @@ codes) + hard_example_training + backward + 5x Adam, fp32, one process per GPU.
 The LAST line of stdout (rank 0) is ONE JSON object of at most 3 KB (`headline()` below): the driver's contract keys, `roofline`
 of the kernel with the largest serial time in the step (arg-max of the per-launch HIP-event profile, measured live on the
 launch stream), `cpu_baseline` (the CPU oracle oracle/ref_cpu.py, a port of the reference's PyTorch-CPU path, timed on one step
-of the same workload on the host cores, N=1 only) and, at N=1, two sub-records cut down to six numbers each: `config3_bf16`
-(BASELINE configs[2]: targeted masks, bf16) and `config5_inference` (configs[4]: 192x192 volume inference), measured by
-child processes running this same script.  Everything else (per-family / per-kernel rooflines, per-step times, allocation
+of the same workload on the host cores, N=1 only) and, at N=1, three sub-records cut down to seven numbers each: `config3_bf16`
+(BASELINE configs[2]: targeted masks, bf16), `config5_inference` (configs[4]: 192x192 volume inference) and `config4_random_masks_n1`
+(configs[3]'s masking scheme -- all three schemes randomly sampled -- on one GPU), measured by child processes running this same script.  Everything else (per-family / per-kernel rooflines, per-step times, allocation
 counters, mode calibration, the full sub-records) goes to `bench_detail.json` next to this script and, as one line prefixed
 `BENCH_DETAIL `, to stderr -- stdout carries nothing but the headline line."""
 import argparse
