@@ -435,7 +435,10 @@ def main():
             graph_step()                                  # capture + first replay
             if args.masks == "random":                    # one captured graph per (image scheme, shape scheme) pair: capture all nine BEFORE the timed
                 for _ in range(200):                      # region (the scheme is drawn per step: a first-time pair inside it would time a capture)
-                    if len(gstep.entries) >= 9:
+                    done = torch.tensor([1.0 if len(gstep.entries) >= 9 else 0.0], device=device)
+                    if use_dist:                          # each rank draws its own schemes but every step carries the gradient exchange:
+                        dist.all_reduce(done, op=dist.ReduceOp.MIN)   # all ranks run the same number of steps
+                    if done.item() > 0:
                         break
                     graph_step()
                 calib["scheme_pair_graphs"] = len(gstep.entries)
