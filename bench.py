@@ -313,6 +313,7 @@ def main():
     ap.add_argument("--set", action="append", default=[], metavar="MODULE.ATTR=VALUE",
                     help="A/B aid: set a plan-compiler switch before the solver is built, e.g. nets.FUSE_BNBWD=True")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--single-stream", action="store_true", help="A/B aid: one launch chain instead of two (solver.two_streams = False)")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--prof-filter", default=None, help="profiling id to report as `roofline.kernel` instead of the arg-max of serial time")
     ap.add_argument("--detail-file", default=DETAIL_FILE, help="where the full record goes (relative to this script)")
@@ -363,6 +364,8 @@ def main():
     torch.manual_seed(0)                                 # identical initial weights on every rank
     solver = AdvancedTripletReconSegmentationModel(network_type="FCN_16_standard", image_ch=1, num_classes=4,
                                                    learning_rate=1e-4, use_gpu=True, compute_dtype=args.dtype)
+    if args.single_stream:
+        solver.two_streams = False
     dp = DataParallel(solver) if use_dist else None
     if use_dist:
         flush_c_stdio()                                   # (the weight broadcast built the communicator: its banner goes out now)
