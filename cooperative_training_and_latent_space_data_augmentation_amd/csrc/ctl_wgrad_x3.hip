@@ -21,6 +21,10 @@ __device__ __forceinline__ x3_bf16x8 x3_tr_read8(const unsigned char* a0, const 
 #ifndef CTL_X3W_LB
 #define CTL_X3W_LB 2
 #endif
+#ifndef CTL_X3W_ABLATE
+#define CTL_X3W_ABLATE 0      // timing ablations (variant builds only, WRONG results): 1 no split of dy (with -DCTL_X3_ABLATE=1: nor of x),
+#endif                        // 2 no global loads after the first tile, 4 no MFMAs, 8 no A-operand reads after tap 0, 16 no staging stores,
+                              // 32 no cross-wave reduction (one wave's sums are written), 64 return at once, 128 no tile loop at all
 // DY2: the output gradient is the virtual BatchNorm-backward result  A * dy + B * dy2 + C  (coefficients [group][3][cout] as the finalize
 // writes them; dy = g, dy2 = the BatchNorm input), evaluated in fp32 in this staging, then split
 template <int KS, int S, int MODE, int MT, int NTW, bool DY2>
@@ -30,6 +34,7 @@ __global__ __launch_bounds__(256, CTL_X3W_LB) void conv_wgrad_x3_kernel(const ct
                                                                        const float* __restrict__ dy_coef, float* __restrict__ w_partial,
                                                                        float* __restrict__ b_partial, int tiles_h, int tiles_w, int ntiles,
                                                                        int cin_p, int cout_p) {
+    if constexpr (CTL_X3W_ABLATE & 64) return;
     constexpr int TW = 16;
     using G = Geom<KS, S, MT, TW>;
     using XS = XStage3<KS, S, MODE, MT, TW, false, false>;
@@ -125,7 +130,8 @@ __global__ __launch_bounds__(256, CTL_X3W_LB) void conv_wgrad_x3_kernel(const ct
             if (DU % 256 != 0 && tid + i * 256 >= DU) continue;
             bs0 += lo; bs1 += hi;
             u32x4 ph, pm, pl;
-            x3_split8(lo, hi, ph, pm, pl);
+            if constexpr (CTL_X3W_ABLATE & 1) { ph = x3_pack8(lo, hi); pm = ph; pl = ph; }
+            else x3_split8(lo, hi, ph, pm, pl);
             *reinterpret_cast<u32x4*>(dyt + dlds[i]) = ph;
             *reinterpret_cast<u32x4*>(dyt + dlds[i] + DYI) = pm;
             *reinterpret_cast<u32x4*>(dyt + dlds[i] + 2 * DYI) = pl;
@@ -158,12 +164,14 @@ __global__ __launch_bounds__(256, CTL_X3W_LB) void conv_wgrad_x3_kernel(const ct
         dystore((cur.n / group_n) * d.cout);
     }
     __syncthreads();
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (int tile = blockIdx.x; tile < ((CTL_X3W_ABLATE & 128) ? 0 : ntiles); tile += gridDim.x) {
         const bool has_next = tile + (int)gridDim.x < ntiles;
         if (has_next) {
             cur.next();
-            xs.load(rx, rx, d, cur.n, cur.th * G::TH, cur.tw * TW, g);
-            dyload(cur.n, cur.th * G::TH, cur.tw * TW);
+            if constexpr (!(CTL_X3W_ABLATE & 2)) {
+                xs.load(rx, rx, d, cur.n, cur.th * G::TH, cur.tw * TW, g);
+                dyload(cur.n, cur.th * G::TH, cur.tw * TW);
+            }
         }
         for (int kb = wave; kb < KB; kb += 4) {          // (4x16 tiles: two k-blocks, waves 2 and 3 only stage; 16x16 tiles: two k-blocks per wave)
             const int tr = kb * 2 + krow;                // tile row of this lane group's 8 pixels
@@ -187,11 +195,12 @@ __global__ __launch_bounds__(256, CTL_X3W_LB) void conv_wgrad_x3_kernel(const ct
             a_operand(0, af[0]);
 #pragma unroll
             for (int tap = 0; tap < TAPS; ++tap) {
-                if (tap + 1 < TAPS) a_operand(tap + 1, af[(tap + 1) & 1]);
-                x3_bf16x8* a = af[tap & 1];
+                if constexpr (!(CTL_X3W_ABLATE & 8)) { if (tap + 1 < TAPS) a_operand(tap + 1, af[(tap + 1) & 1]); }
+                x3_bf16x8* a = af[(CTL_X3W_ABLATE & 8) ? 0 : (tap & 1)];
                 asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]) : : "memory");
-#define CTL_X3W_MFMA(SA, SB) _Pragma("unroll") for (int t = 0; t < NTW; ++t) \
-                    acc[tap][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[SA], bf[SB][t], acc[tap][t], 0, 0, 0);
+#define CTL_X3W_MFMA(SA, SB) _Pragma("unroll") for (int t = 0; t < NTW; ++t) { \
+                    if constexpr (CTL_X3W_ABLATE & 4) { if (SA == 0 && SB == 0) acc[tap][t].x += (float)a[SA][0] * (float)bf[SB][t][0]; } \
+                    else acc[tap][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[SA], bf[SB][t], acc[tap][t], 0, 0, 0); }
                 CTL_X3W_MFMA(2, 0)
                 CTL_X3W_MFMA(0, 2)
                 CTL_X3W_MFMA(1, 1)
@@ -202,7 +211,7 @@ __global__ __launch_bounds__(256, CTL_X3W_LB) void conv_wgrad_x3_kernel(const ct
             }
         }
         ctl_barrier_lds_reads_done();
-        if (has_next) {
+        if (has_next && !(CTL_X3W_ABLATE & 16)) {
             xs.store(reinterpret_cast<float*>(xt), d, g, cf_scale, cf_shift, (cur.n / group_n) * d.cin, nullptr, rnone, false);
             dystore((cur.n / group_n) * d.cout);
         }
@@ -216,6 +225,19 @@ __global__ __launch_bounds__(256, CTL_X3W_LB) void conv_wgrad_x3_kernel(const ct
     constexpr int TPR = (MAIN_BYTES / 4 / TAP_FLOATS) < TAPS ? (MAIN_BYTES / 4 / TAP_FLOATS) : TAPS;
     static_assert(TPR >= 1, "reduction scratch");
     const int64_t split_base = (int64_t)blockIdx.x * TAPS * cin_p * cout_p;
+    if constexpr (CTL_X3W_ABLATE & 32) {
+        if (wave == 0)
+#pragma unroll
+            for (int tap = 0; tap < TAPS; ++tap)
+#pragma unroll
+                for (int t = 0; t < NTW; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int co = (cot0 + t) * 16 + (lane & 15), ci = g * 16 + (lane >> 4) * 4 + r;
+                        if (co < cout_p) w_partial[split_base + ((int64_t)tap * cin_p + ci) * cout_p + co] = acc[tap][t][r];
+                    }
+        return;
+    }
 #pragma unroll
     for (int tap0 = 0; tap0 < TAPS; tap0 += TPR) {
         if (tap0 > 0) ctl_barrier_lds_reads_done();
@@ -329,6 +351,15 @@ static int wgrad3_pick(const ctl_conv* d, wgrad3_call* a) {
     // (16x16-pixel tiles for the full-resolution 16-channel layers, the bf16 family's choice, measured slower here at two resident blocks per
     //  CU: 16->16 @256^2 45.0 vs 47.6 us, up-sampled 16->16 @128^2 42.4 vs 44.7 us, tools/sweep_wgrad_x3.sh -- the 8x16 tile stays)
     a->ntw = (a->c.cot >= 2 && a->c.cot % 2 == 0) ? 2 : 1;
+    // stride-2 3x3 with two cout tiles: the 17x33-pixel input tile of an 8x16 output tile costs 238 + 126 registers -> ONE resident block per
+    // CU; the 4x16 tile (194 registers, two blocks) is 7-15 % faster (tools/sweep_wgrad_x3_s2.sh: 16->32 @256^2 35.5 -> 33.2 us,
+    // 32->64 @128^2 37.6 -> 32.1, 64->128 @64^2 35.0 -> 31.5); with one cout tile the 8x16 tile fits twice and stays (25.6 vs 27.6 us)
+    static const int s2_mt = ctl_tune_int("CTL_X3W_S2_MT", 0), s2_ntw = ctl_tune_int("CTL_X3W_S2_NTW", 0);      // tuning hooks
+    if (d->ks == 3 && d->stride == 2) {
+        if (s2_ntw) a->ntw = s2_ntw;
+        const int mt = s2_mt ? s2_mt : (a->ntw == 2 ? 1 : a->c.mt);
+        if (mt != a->c.mt) { a->c.mt = mt; a->c.th = 4 * mt; a->c.tiles_h = ctl_cdiv(d->hout, a->c.th); }
+    }
     a->ntiles = d->n * a->c.tiles_h * a->c.tiles_w;
     a->cin_p = a->c.g * 16;
     a->cout_p = a->c.cot * 16;

@@ -11,6 +11,8 @@ LAYERS = [  # name, cin, cout, h(in), ks, stride, in_mode
     # round 3: the mid-resolution layers of the n=16 passes (layer table: 0.34-0.5 of peak inside the step)
     ("c16-16@128", 16, 16, 128, 3, 1, 0), ("c32-32@64", 32, 32, 64, 3, 1, 0), ("c64-64@32", 64, 64, 32, 3, 1, 0), ("c32-16@128", 32, 16, 128, 3, 1, 0),
     ("c64-32@64", 64, 32, 64, 3, 1, 0), ("1x1 128-64@32", 128, 64, 32, 1, 1, 0), ("1x1 32-32@64", 32, 32, 64, 1, 1, 0),
+    # round 4: the stride-2 3x3 convs of the down-sampling blocks
+    ("s2 16-32@256", 16, 32, 256, 3, 2, 0), ("s2 32-64@128", 32, 64, 128, 3, 2, 0), ("s2 64-128@64", 64, 128, 64, 3, 2, 0), ("s2 32-32@128", 32, 32, 128, 3, 2, 0),
 ]
 CFGS = ["4,32,1", "2,16,1", "1,16,1", "4,32,2", "2,16,2", "1,16,2", "4,32,4", "2,16,4", "1,16,4"]
 
