@@ -297,9 +297,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--size", type=int, default=256)
-    ap.add_argument("--mode", default="auto", choices=["auto", "eager", "graph"],
-                    help="eager: Python issues the ~1100 launches of a step on two HIP streams; graph: the whole step is one hipGraph replay "
-                         "(host-insensitive); auto: both are timed for a few untimed steps after the warm-up and the faster one is measured")
+    ap.add_argument("--mode", default="auto", choices=["auto", "eager", "graph", "segments"],
+                    help="eager: Python issues the ~900 launches of a step on two HIP streams; graph: the whole step is one hipGraph replay "
+                         "(host-insensitive); segments: the captured step replayed as linear per-chain segment graphs on two streams "
+                         "(hipgraph.SegmentReplay, also host-insensitive); auto: all three are timed for a few untimed steps after the warm-up "
+                         "and the fastest one is measured")
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
                     help="fp32: the reference's arithmetic (BASELINE configs[1], the headline; nets.X3: the 3x3 / 4x4 / 2x2 contractions run on the bf16 "
                          "matrix pipe over an exact three-way split of the fp32 operands, same results class as fp32 MFMA); bf16: configs[2] -- network-internal "
@@ -431,9 +433,9 @@ def main():
     # ---- execution mode (still untimed): the step as a hipGraph replay vs Python-issued launches
     from cooperative_training_and_latent_space_data_augmentation_amd.graph import CooperativeStepGraph
     calib, mode, gstep = {}, args.mode, None
-    if mode in ("auto", "graph"):
+    if mode in ("auto", "graph", "segments"):
         try:
-            gstep = CooperativeStepGraph(solver, IMG_CFG, SEG_CFG, grad_hook=hook_graph)
+            gstep = CooperativeStepGraph(solver, IMG_CFG, SEG_CFG, grad_hook=hook_graph, replay="segments" if mode == "segments" else "runtime")
             graph_step = lambda: gstep(clean, label, noisy)
             graph_step()                                  # capture + first replay
             if args.masks == "random":                    # one captured graph per (image scheme, shape scheme) pair: capture all nine BEFORE the timed
@@ -447,7 +449,7 @@ def main():
                 calib["scheme_pair_graphs"] = len(gstep.entries)
             fence()
         except Exception as exc:                          # capture is an optimisation: the eager path is the same computation
-            if mode == "graph":
+            if mode in ("graph", "segments"):
                 raise
             calib["graph_error"], gstep = f"{type(exc).__name__}: {str(exc)[:160]}", None
     if mode == "auto":
@@ -465,11 +467,21 @@ def main():
             _ffi.prof_stop()
         if gstep is not None:
             calib["graph_ms"] = time_steps(graph_step)
-        pick = torch.tensor([1.0 if (gstep is not None and calib["graph_ms"] < calib["eager_ms"]) else 0.0], device=device)
+            try:                                          # the same captured graphs as linear segment graphs on two streams
+                gstep.set_replay_mode("segments")
+                calib["segments_ms"] = time_steps(graph_step)
+                calib["segments"] = next(iter(gstep.entries.values())).segments.describe()
+            except Exception as exc:
+                calib["segments_error"] = f"{type(exc).__name__}: {str(exc)[:160]}"
+                gstep.set_replay_mode("runtime")
+        best = min((calib.get(k + "_ms", float("inf")), i) for i, k in enumerate(("eager", "graph", "segments")))[1]
+        pick = torch.tensor([float(best)], device=device)
         if use_dist:                                      # every rank must run the same mode: rank 0 decides
             dist.broadcast(pick, 0)
-        mode = "graph" if pick.item() > 0 else "eager"
-    if mode == "graph":
+        mode = ("eager", "graph", "segments")[int(pick.item())]
+        if gstep is not None:
+            gstep.set_replay_mode("segments" if mode == "segments" else "runtime")
+    if mode in ("graph", "segments"):
         step = graph_step
     elif gstep is not None:                               # eager chosen: give the graph's private pool back and let the allocator settle
         del gstep, graph_step

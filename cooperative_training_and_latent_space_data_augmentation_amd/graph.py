@@ -12,7 +12,11 @@ What may not be baked into a captured launch lives on the device instead:
   * the masking scheme of `mask_type='random'` (python `random.shuffle`, model.py:325-329) changes the launch sequence: one graph per
     (image scheme, segmentation scheme) pair, picked per step by the same host draw.
 Inputs are copied into static buffers; the returned losses / `solver.z_i` / `last_masks` are the graph's static outputs (valid until
-the next replay).  torch.cuda.graph is hipGraph capture of the launches this package enqueues: plumbing, no tracing compiler."""
+the next replay).  torch.cuda.graph is hipGraph capture of the launches this package enqueues: plumbing, no tracing compiler.
+
+Two ways to replay the captured step (`replay=`): "runtime" = hipGraphLaunch of the captured two-chain graph; "segments" = the same
+nodes re-cut into linear per-chain segment graphs launched on two streams (hipgraph.SegmentReplay: the runtime's fast path for linear
+graphs; 8 % faster on the bf16 step, whose kernels are too short to hide the general path's per-node cost).  Same results bit for bit."""
 from __future__ import annotations
 
 import random
@@ -23,13 +27,14 @@ import torch
 
 from . import ops
 from ._ffi import CtlError
+from .hipgraph import SegmentReplay
 from .model_util import _draw_seed
 
 _SCHEMES = ["dropout", "spatial", "channel"]
 
 
 class _Entry:
-    __slots__ = ("graph", "adam_graph", "losses", "k_slots", "masks", "z")
+    __slots__ = ("graph", "adam_graph", "losses", "k_slots", "masks", "z", "segments")
 
 
 class CooperativeStepGraph:
@@ -39,7 +44,10 @@ class CooperativeStepGraph:
     between the forward/backward graph and the Adam graph."""
 
     def __init__(self, solver, img_cfg: Optional[dict], seg_cfg: Optional[dict], separate_training: bool = False,
-                 latent_DA: bool = True, grad_hook=None):
+                 latent_DA: bool = True, grad_hook=None, replay: str = "runtime"):
+        if replay not in ("runtime", "segments"):
+            raise ValueError("replay must be 'runtime' or 'segments'")
+        self.replay_mode = replay
         self.solver, self.img_cfg, self.seg_cfg = solver, img_cfg, seg_cfg
         self.separate_training, self.latent_DA, self.grad_hook = separate_training, latent_DA, grad_hook
         self.entries: Dict[tuple, _Entry] = {}
@@ -53,6 +61,17 @@ class CooperativeStepGraph:
         self.replays = 0
         self.k_log = []                # the k values handed to the replays, in draw order (tests compare them with the eager sequence)
         self._dev_adam_count = None    # what state[2] holds on the device after the launches issued so far
+
+    def set_replay_mode(self, mode: str):
+        """Switch between the two replay forms of the captured graphs (see the module docstring); "segments" builds the segment graphs
+        of every graph captured so far (graphs captured later build theirs at capture)."""
+        if mode not in ("runtime", "segments"):
+            raise ValueError("replay mode must be 'runtime' or 'segments'")
+        if mode == "segments":
+            for e in self.entries.values():
+                if e.segments is None:
+                    e.segments = SegmentReplay(e.graph)
+        self.replay_mode = mode
 
     # ------------------------------------------------------------------ host draws, in the reference's order
     def _draw_schemes(self):
@@ -133,7 +152,8 @@ class CooperativeStepGraph:
             for m in s.model.values():
                 m.weights_changed()           # the weight re-pack launches belong INTO the graph (every replay follows an Adam step)
                 m._grad_is_zero = False       # ... and so does the step's first gradient fill (every replay follows a step that left gradients)
-            e.graph = torch.cuda.CUDAGraph()
+            e.graph = torch.cuda.CUDAGraph(keep_graph=True)       # (the hipGraph_t stays available to SegmentReplay)
+            e.segments = None
             split = self.grad_hook is not None
             with torch.cuda.graph(e.graph, pool=self.pool, stream=self.stream):
                 e.losses = self._run_step(schemes, do_optim=not split, hook=None)
@@ -143,6 +163,8 @@ class CooperativeStepGraph:
                 with torch.cuda.graph(e.adam_graph, pool=self.pool, stream=self.stream):
                     s.optimize_all_params()
             e.masks, e.z = dict(s.last_masks), (s.z_i, s.z_s)
+            if self.replay_mode == "segments":
+                e.segments = SegmentReplay(e.graph)
         finally:
             s._gstate = s._gk = None
             if dp is not None:
@@ -181,7 +203,12 @@ class CooperativeStepGraph:
             raise CtlError("CooperativeStepGraph: the five optimizers must be at the same step count (one device-side counter)")
         if counts[0] != self._dev_adam_count:
             self.state[2:3].fill_(counts[0])
-        e.graph.replay()
+        if self.replay_mode == "segments":
+            if e.segments is None:
+                e.segments = SegmentReplay(e.graph)
+            e.segments.replay()
+        else:
+            e.graph.replay()
         if e.adam_graph is not None:
             self.grad_hook(s)
             e.adam_graph.replay()

@@ -50,18 +50,20 @@ def _same(a, b):
         assert torch.equal(a[2][k][0], b[2][k][0]) and torch.equal(a[2][k][1], b[2][k][1]) and a[2][k][2] == b[2][k][2], f"Adam state of {k}"
 
 
+@pytest.mark.parametrize("replay", ["runtime", "segments"])
 @pytest.mark.parametrize("cfgs", [(CH_MSE, SP_CE), (CH_MSE_RT, SP_CE_RT)], ids=["fixed_k", "random_k"])
 @pytest.mark.parametrize("two_streams", [True, False])
-def test_graph_replay_is_bitwise_the_eager_step(golden_sd, cfgs, two_streams):
+def test_graph_replay_is_bitwise_the_eager_step(golden_sd, cfgs, two_streams, replay):
     """4 training steps, eager vs graph replay, from the same weights and the same seeded host RNG (the random thresholds k are drawn
-    by the host per replay in the reference's order and handed over in device memory)."""
+    by the host per replay in the reference's order and handed over in device memory).  replay = "segments": the captured graph re-cut
+    into linear per-chain segment graphs on two streams (hipgraph.SegmentReplay) -- same nodes, same edges, same bits."""
     clean, label, noisy = (dev(t) for t in O.synthetic_batch(4, 64, 64, seed=5))
     res = []
     for use_graph in (False, True):
         s = _solver(golden_sd)
         s.two_streams = two_streams
         np.random.seed(3)
-        g = CooperativeStepGraph(s, *cfgs) if use_graph else None
+        g = CooperativeStepGraph(s, *cfgs, replay=replay) if use_graph else None
         losses = []
         for _ in range(4):
             l = g(clean, label, noisy) if use_graph else s.cooperative_step(clean, label, noisy, *cfgs)
@@ -69,6 +71,10 @@ def test_graph_replay_is_bitwise_the_eager_step(golden_sd, cfgs, two_streams):
         res.append((losses, _state(s), np.random.rand()))
         if use_graph:
             assert g.replays == 4 and len(g.entries) == 1
+            if replay == "segments":
+                d = next(iter(g.entries.values())).segments.describe()
+                assert d["chains"] == (2 if two_streams else 1) and d["segments"] >= d["chains"] and d["nodes"] > 300, d
+                assert (d["events"] > 0) == two_streams, d
     for a, b in zip(res[0][0], res[1][0]):
         assert torch.equal(a, b), (a, b)
     _same(res[0][1], res[1][1])
@@ -209,3 +215,20 @@ def test_eager_steps_between_replays_keep_the_adam_count(golden_sd):
     g(clean, label, noisy)
     assert int(g.state[2]) == 4
     _same(_state(ref), _state(s))
+
+
+def test_replay_mode_can_be_switched_between_replays(golden_sd):
+    """runtime replay, segment replay, runtime replay ... of ONE captured graph continue one trajectory: bitwise the all-runtime run."""
+    clean, label, noisy = (dev(t) for t in O.synthetic_batch(4, 64, 64, seed=9))
+    res = []
+    for modes in (["runtime"] * 4, ["runtime", "segments", "segments", "runtime"]):
+        s = _solver(golden_sd)
+        g = CooperativeStepGraph(s, CH_MSE, SP_CE)
+        losses = []
+        for m in modes:
+            g.set_replay_mode(m)
+            losses.append(torch.stack([v.detach().float() for v in g(clean, label, noisy)]).cpu())
+        res.append((losses, _state(s)))
+    for a, b in zip(res[0][0], res[1][0]):
+        assert torch.equal(a, b), (a, b)
+    _same(res[0][1], res[1][1])
