@@ -152,7 +152,7 @@ class SegmentReplay:
     """`SegmentReplay(g)` for a captured `torch.cuda.CUDAGraph(keep_graph=True)`; `.replay()` on the current stream is `g.replay()`.
     `g` must stay alive (it owns the captured graph's memory pool and the kernel-argument storage the clones were copied from)."""
 
-    def __init__(self, cuda_graph: "torch.cuda.CUDAGraph"):
+    def __init__(self, cuda_graph: "torch.cuda.CUDAGraph", side_priority: int = 0):
         hip = _lib()
         self._hip = hip
         self._owner = cuda_graph
@@ -200,7 +200,7 @@ class SegmentReplay:
         except Exception:
             self.close()
             raise
-        self._side = [torch.cuda.Stream() for _ in range(K - 1)]
+        self._side = [torch.cuda.Stream(priority=side_priority) for _ in range(K - 1)]
         self.n_events = sum(1 for s in segs if s.event is not None)
 
     def _new_event(self):

@@ -64,7 +64,7 @@ def graph_main(rank, world, device, out, sd):
             m.load_state_dict(sd[k])
     dp = DataParallel(s)
     torch.manual_seed(7000 + rank); np.random.seed(7000 + rank); random.seed(7000 + rank)
-    g = CooperativeStepGraph(s, RND_MSE, RND_CE, grad_hook=dp.sync_gradients)
+    g = CooperativeStepGraph(s, RND_MSE, RND_CE, grad_hook=dp.sync_gradients, replay="segments")      # (the segment replay under DP as well)
     per_step = []
     for _ in range(4):
         l = g(clean, label, noisy)
