@@ -206,7 +206,8 @@ static int conv3_pick_cfg(const ctl_conv* d, ctl_conv_cfg* c) {
 }
 
 int ctl_conv_x3_ok(const ctl_conv* d) {
-    return d->cin % 16 == 0 && d->cout % 16 == 0 && d->ks >= 2 && d->in_mode != CTL_IN_C4 && !(d->dt & (CTL_DT_BF16 | CTL_DT_X16 | CTL_DT_Y16 | CTL_DT_RES16));
+    // (cout 4 / 8 / 12: one padded cout tile -- the fp32 pipe pays the padding 16x dearer; the STN's first-layer data gradient 16 -> 4)
+    return d->cin % 16 == 0 && (d->cout % 16 == 0 || (d->cout < 16 && d->cout % 4 == 0)) && d->ks >= 2 && d->in_mode != CTL_IN_C4 && !(d->dt & (CTL_DT_BF16 | CTL_DT_X16 | CTL_DT_Y16 | CTL_DT_RES16));
 }
 int ctl_conv_x3_stats_blocks(const ctl_conv* d) {
     conv3_call a = {};
@@ -220,7 +221,7 @@ int ctl_conv_x3_stats_blocks(const ctl_conv* d) {
 int ctl_conv_forward_x3(const ctl_conv* d, const float* x, const float* wpack, const float* bias, const float* pro_scale, const float* pro_shift,
                         const float* res, const float* res_scale, const float* res_shift, const float* res2, const float* x2, float* y,
                         float* stats_partial, float* pool, float* xout, ctl_stream stream) {
-    CTL_REQUIRE(ctl_conv_x3_ok(d), "conv_forward(x3): CTL_DT_X3 needs fp32-stored tensors, cin %% 16 == 0, cout %% 16 == 0 and a 2x2 / 3x3 / 4x4 kernel "
+    CTL_REQUIRE(ctl_conv_x3_ok(d), "conv_forward(x3): CTL_DT_X3 needs fp32-stored tensors, cin %% 16 == 0, cout %% 16 == 0 (or 4 / 8 / 12) and a 2x2 / 3x3 / 4x4 kernel "
                                    "(got cin %d, cout %d, ks %d, in_mode %d, dt %d)", d->cin, d->cout, d->ks, d->in_mode, d->dt);
     CTL_REQUIRE(!pool, "conv_forward(x3): `pool` belongs to the 1x1 hosts, which stay on the fp32 pipe");
     conv3_call a = {};

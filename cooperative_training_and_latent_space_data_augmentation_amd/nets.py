@@ -594,7 +594,7 @@ class CtlNet(nn.Module):
 
         def wp_floats(cin_eff, cout_eff, ks):
             """(float count of one packed sub-problem, X3 layout?) of an effective conv cin_eff -> cout_eff"""
-            if x3_on and ks >= 2 and cin_eff % 16 == 0 and cout_eff % 16 == 0:
+            if x3_on and ks >= 2 and cin_eff % 16 == 0 and (cout_eff % 16 == 0 or cout_eff in (4, 8, 12)):
                 return lib.ctl_conv_wpack_floats_x3(cin_eff, cout_eff, ks), True
             return lib.ctl_conv_wpack_floats(cin_eff, cout_eff, ks), False
 

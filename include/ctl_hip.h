@@ -77,7 +77,8 @@ typedef struct ctl_conv {
                                         fp32 bias / BatchNorm statistics / epilogue; weights packed as bf16 by the *_batched pack with
                                         the same flag); CTL_DT_X16 / _Y16 / _RES16: that tensor is STORED as bf16 (activation storage
                                         of BASELINE config 3) -- network inputs / outputs stay fp32.
-                                        CTL_DT_X3 (alone; fp32 tensors; cin, cout multiples of 16; 2x2 / 3x3 / 4x4 kernels): the SAME
+                                        CTL_DT_X3 (alone; fp32 tensors; cin a multiple of 16, cout a multiple of 16 or 4 / 8 / 12 (the
+                                        weight gradient: both multiples of 16); 2x2 / 3x3 / 4x4 kernels): the SAME
                                         fp32 computation with the contraction on the bf16 matrix pipe -- every operand is split
                                         exactly into three bf16 numbers while it is staged, six v_mfma_f32_16x16x32_bf16 per
                                         contraction step (hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi, fp32 accumulate): error

@@ -74,7 +74,8 @@ def test_split_is_exact_on_adversarial_values():
 
 
 CASES = [(2, 16, 16, 32, 32), (16, 16, 16, 64, 64), (4, 16, 16, 128, 128), (2, 32, 64, 16, 16), (2, 128, 128, 8, 8), (2, 64, 32, 24, 20),
-         (1, 32, 32, 6, 6), (2, 128, 64, 3, 3), (2, 32, 32, 48, 48), (1, 64, 48, 40, 72), (2, 128, 32, 36, 52), (3, 48, 16, 70, 70), (2, 16, 16, 9, 7)]
+         (1, 32, 32, 6, 6), (2, 128, 64, 3, 3), (2, 32, 32, 48, 48), (1, 64, 48, 40, 72), (2, 128, 32, 36, 52), (3, 48, 16, 70, 70), (2, 16, 16, 9, 7),
+         (2, 16, 4, 40, 40), (4, 16, 4, 128, 128), (2, 32, 8, 17, 23), (2, 16, 12, 16, 16)]      # cout 4 / 8 / 12: one padded cout tile (the STN's first-layer data gradient)
 
 
 @pytest.mark.parametrize("n,cin,cout,h,w", CASES)
