@@ -467,12 +467,18 @@ def main():
             _ffi.prof_stop()
         if gstep is not None:
             calib["graph_ms"] = time_steps(graph_step)
+            seg_ok = 1.0
             try:                                          # the same captured graphs as linear segment graphs on two streams
                 gstep.set_replay_mode("segments")
+            except Exception as exc:
+                seg_ok, calib["segments_error"] = 0.0, f"{type(exc).__name__}: {str(exc)[:160]}"
+            flag = torch.tensor([seg_ok], device=device)
+            if use_dist:                                  # (every timed step carries the gradient exchange: all ranks time it, or none)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if flag.item() > 0:
                 calib["segments_ms"] = time_steps(graph_step)
                 calib["segments"] = next(iter(gstep.entries.values())).segments.describe()
-            except Exception as exc:
-                calib["segments_error"] = f"{type(exc).__name__}: {str(exc)[:160]}"
+            else:
                 gstep.set_replay_mode("runtime")
         best = min((calib.get(k + "_ms", float("inf")), i) for i, k in enumerate(("eager", "graph", "segments")))[1]
         pick = torch.tensor([float(best)], device=device)
