@@ -62,6 +62,10 @@ class CooperativeStepGraph:
         self.k_log = []                # the k values handed to the replays, in draw order (tests compare them with the eager sequence)
         self._dev_adam_count = None    # what state[2] holds on the device after the launches issued so far
 
+    def _new_segments(self, graph):
+        other = next((x.segments for x in self.entries.values() if x.segments is not None), None)
+        return SegmentReplay(graph, streams_of=other)
+
     def set_replay_mode(self, mode: str):
         """Switch between the two replay forms of the captured graphs (see the module docstring); "segments" builds the segment graphs
         of every graph captured so far (graphs captured later build theirs at capture)."""
@@ -70,7 +74,7 @@ class CooperativeStepGraph:
         if mode == "segments":
             for e in self.entries.values():
                 if e.segments is None:
-                    e.segments = SegmentReplay(e.graph)
+                    e.segments = self._new_segments(e.graph)
         self.replay_mode = mode
 
     # ------------------------------------------------------------------ host draws, in the reference's order
@@ -164,7 +168,7 @@ class CooperativeStepGraph:
                     s.optimize_all_params()
             e.masks, e.z = dict(s.last_masks), (s.z_i, s.z_s)
             if self.replay_mode == "segments":
-                e.segments = SegmentReplay(e.graph)
+                e.segments = self._new_segments(e.graph)
         finally:
             s._gstate = s._gk = None
             if dp is not None:
@@ -205,7 +209,7 @@ class CooperativeStepGraph:
             self.state[2:3].fill_(counts[0])
         if self.replay_mode == "segments":
             if e.segments is None:
-                e.segments = SegmentReplay(e.graph)
+                e.segments = self._new_segments(e.graph)
             e.segments.replay()
         else:
             e.graph.replay()

@@ -52,6 +52,24 @@ def _ck(rc: int, what: str):
         raise CtlError(f"SegmentReplay: {what} failed with HIP error {rc}")
 
 
+def streams_overlap_ratio(a: "torch.cuda.Stream", b: "torch.cuda.Stream", us: int = 300) -> float:
+    """Two idle `us`-microsecond kernels (ctl_spin), one per stream, between two events: ~1.0 = they ran side by side, ~2.0 = one behind
+    the other.  HIP streams share a few hardware queues (4 by default) in creation order, and two streams on one queue run IN ORDER."""
+    from ._ffi import lib, check
+    for st in (a, b):
+        check(lib.ctl_spin(1, st.cuda_stream), "ctl_spin")
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    b.wait_stream(a)
+    e0.record(a)
+    for st in (a, b):
+        check(lib.ctl_spin(us, st.cuda_stream), "ctl_spin")
+    a.wait_stream(b)
+    e1.record(a)
+    e1.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / us
+
+
 class _Segment:
     __slots__ = ("chain", "nodes", "waits", "event", "exe", "graph")
 
@@ -59,7 +77,7 @@ class _Segment:
         self.chain, self.nodes, self.waits, self.event, self.exe, self.graph = chain, [], [], None, None, None
 
 
-def plan_segments(n_nodes: int, edges) -> "tuple[List[int], List[_Segment]]":
+def plan_segments(n_nodes: int, edges, emit: str = "close") -> "tuple[List[int], List[_Segment]]":
     """Pure host logic (no HIP): nodes 0..n-1 in creation order, edges (a, b) = b depends on a.  Returns (chain of every node, the segments
     in launch order).  Every node is in exactly one segment; inside a segment the nodes are consecutive nodes of one chain; an edge
     between two chains is covered by `waits` (the consumer's segment waits for the event behind the producer's segment, which was
@@ -140,6 +158,9 @@ def plan_segments(n_nodes: int, edges) -> "tuple[List[int], List[_Segment]]":
             close(c)
     for c in range(K):
         close(c)
+    if emit == "open":                            # launch order = order of the segments' first nodes (also legal: a waited-for segment
+        order = {v: i for i, v in enumerate(topo)}  # closed, hence opened, before its waiter opened)
+        segs.sort(key=lambda s: order[s.nodes[0]])
     emitted = set()
     for s in segs:                                # (the invariant the replay loop relies on)
         if any(id(w) not in emitted for w in s.waits):
@@ -152,7 +173,8 @@ class SegmentReplay:
     """`SegmentReplay(g)` for a captured `torch.cuda.CUDAGraph(keep_graph=True)`; `.replay()` on the current stream is `g.replay()`.
     `g` must stay alive (it owns the captured graph's memory pool and the kernel-argument storage the clones were copied from)."""
 
-    def __init__(self, cuda_graph: "torch.cuda.CUDAGraph", side_priority: int = 0):
+    def __init__(self, cuda_graph: "torch.cuda.CUDAGraph", side_priority: int = 0, emit: str = "close", swap_chains: bool = False,
+                 streams_of: "SegmentReplay" = None):
         hip = _lib()
         self._hip = hip
         self._owner = cuda_graph
@@ -171,8 +193,11 @@ class SegmentReplay:
         if N == 0:
             raise CtlError("SegmentReplay: the captured graph is empty")
         idx = {v: i for i, v in enumerate(nodes)}
-        chain_of, segs = plan_segments(N, [(idx[int(a)], idx[int(b)]) for a, b in zip(fr, to)])
+        chain_of, segs = plan_segments(N, [(idx[int(a)], idx[int(b)]) for a, b in zip(fr, to)], emit=emit)
         K = max(chain_of) + 1
+        if swap_chains and K == 2:                # (tuning aid: which chain runs on the stream the replay is launched on)
+            for sg in segs:
+                sg.chain = 1 - sg.chain
         if K > MAX_CHAINS:
             raise CtlError(f"SegmentReplay: the captured graph needs {K} chains (at most {MAX_CHAINS} are replayed)")
         self.segments, self.n_nodes, self.n_edges, self.n_chains = segs, N, int(ne.value), K
@@ -200,8 +225,20 @@ class SegmentReplay:
         except Exception:
             self.close()
             raise
-        self._side = [torch.cuda.Stream(priority=side_priority) for _ in range(K - 1)]
+        self._side_priority = side_priority
+        if streams_of is not None and len(streams_of._side) >= K - 1:      # (the graphs of one step object share the probed streams)
+            self._pool = streams_of._pool
+        else:
+            self._pool = {"side": [torch.cuda.Stream(priority=side_priority) for _ in range(K - 1)], "checked": None, "overlap": None}
         self.n_events = sum(1 for s in segs if s.event is not None)
+
+    @property
+    def _side(self):
+        return self._pool["side"]
+
+    @property
+    def overlap(self):
+        return self._pool["overlap"]
 
     def _new_event(self):
         ev = _VP()
@@ -209,10 +246,28 @@ class SegmentReplay:
         self._events.append(ev)
         return ev
 
+    def _ensure_chains_overlap(self, cur: "torch.cuda.Stream"):
+        """Before the first replay on a launch stream: every other chain's stream must sit on another hardware queue than the launch
+        stream (probe with idle kernels; on a collision take the next stream of torch's pool).  A chain that shares the launch stream's
+        queue overlaps nothing: the fp32 step replays in 17.9 instead of 15.2 ms (tools/segments_probe.py)."""
+        if self._pool["checked"] == cur.cuda_stream or not self._side or torch.cuda.is_current_stream_capturing():
+            return
+        self._pool["checked"] = cur.cuda_stream
+        report = []
+        for i in range(len(self._side)):
+            ratio, attempts = streams_overlap_ratio(cur, self._side[i]), 1
+            while ratio > 1.5 and attempts < 8:
+                self._side[i] = torch.cuda.Stream(priority=self._side_priority)
+                ratio, attempts = streams_overlap_ratio(cur, self._side[i]), attempts + 1
+            report.append({"probe_ratio": round(ratio, 2), "streams_tried": attempts, "overlap": ratio <= 1.5})
+        self._pool["overlap"] = report
+
     def replay(self):
         hip = self._hip
-        cur = _VP(torch.cuda.current_stream().cuda_stream)
-        raw = [cur] + [_VP(s.cuda_stream) for s in self._side]
+        cur_stream = torch.cuda.current_stream()
+        self._ensure_chains_overlap(cur_stream)
+        cur = _VP(cur_stream.cuda_stream)
+        raw = [cur] + [_VP(s.cuda_stream) for s in self._side[:self.n_chains - 1]]
         if len(raw) > 1:
             _ck(hip.hipEventRecord(self._fork, cur), "hipEventRecord")
             for st in raw[1:]:
@@ -230,7 +285,7 @@ class SegmentReplay:
 
     def describe(self) -> dict:
         return {"nodes": self.n_nodes, "edges": self.n_edges, "chains": self.n_chains, "segments": len(self.segments), "events": self.n_events,
-                "largest_segment": max(len(s.nodes) for s in self.segments)}
+                "largest_segment": max(len(s.nodes) for s in self.segments), "queue_probe": self.overlap}
 
     def close(self):
         hip = self._hip

@@ -238,19 +238,8 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
     @staticmethod
     def _overlap_probe(a, b, us=300) -> float:
         """Two idle 300-us kernels, one per stream, between two events: ~1.0 = they ran side by side, ~2.0 = one behind the other."""
-        from ._ffi import lib, check
-        for st in (a, b):
-            check(lib.ctl_spin(1, st.cuda_stream), "ctl_spin")
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        b.wait_stream(a)
-        e0.record(a)
-        for st in (a, b):
-            check(lib.ctl_spin(us, st.cuda_stream), "ctl_spin")
-        a.wait_stream(b)
-        e1.record(a)
-        e1.synchronize()
-        return e0.elapsed_time(e1) * 1e3 / us
+        from .hipgraph import streams_overlap_ratio
+        return streams_overlap_ratio(a, b, us)
 
     def _ensure_chains_overlap(self):
         """HIP streams share a few hardware queues (4 by default) in creation order, and two streams on one queue run IN ORDER: the

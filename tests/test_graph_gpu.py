@@ -75,6 +75,8 @@ def test_graph_replay_is_bitwise_the_eager_step(golden_sd, cfgs, two_streams, re
                 d = next(iter(g.entries.values())).segments.describe()
                 assert d["chains"] == (2 if two_streams else 1) and d["segments"] >= d["chains"] and d["nodes"] > 300, d
                 assert (d["events"] > 0) == two_streams, d
+                if two_streams:          # the second chain's stream was probed against the launch stream (another hardware queue)
+                    assert d["queue_probe"] and all(q["overlap"] for q in d["queue_probe"]), d
     for a, b in zip(res[0][0], res[1][0]):
         assert torch.equal(a, b), (a, b)
     _same(res[0][1], res[1][1])
@@ -232,3 +234,24 @@ def test_replay_mode_can_be_switched_between_replays(golden_sd):
     for a, b in zip(res[0][0], res[1][0]):
         assert torch.equal(a, b), (a, b)
     _same(res[0][1], res[1][1])
+
+
+def test_segment_replays_move_off_the_launch_streams_hardware_queue(golden_sd):
+    """HIP maps streams onto a few hardware queues in creation order; a second chain on the launch stream's queue overlaps nothing.  Six
+    SegmentReplay objects in a row (each takes the next stream of torch's pool): every one ends up on a stream that overlaps."""
+    from cooperative_training_and_latent_space_data_augmentation_amd.hipgraph import SegmentReplay
+    clean, label, noisy = (dev(t) for t in O.synthetic_batch(2, 64, 64, seed=10))
+    s = _solver(golden_sd)
+    g = CooperativeStepGraph(s, CH_MSE, SP_CE)
+    g(clean, label, noisy)
+    e = next(iter(g.entries.values()))
+    g.replay_mode = "segments"
+    tried = 0
+    for _ in range(6):
+        e.segments = SegmentReplay(e.graph)
+        losses = g(clean, label, noisy)
+        assert all(torch.isfinite(v) for v in losses)
+        q = e.segments.describe()["queue_probe"]
+        assert q and q[0]["overlap"], q
+        tried += q[0]["streams_tried"]
+    assert tried >= 6

@@ -35,14 +35,10 @@ def timed(fn, n=20):
 
 print(f"{dtype} runtime replay: {timed(lambda: g(clean, label, noisy)):.3f} ms", flush=True)
 g.replay_mode = "segments"
-hi = torch.cuda.Stream(priority=-1)
-for side_prio in (0, -1):
-    e.segments = SegmentReplay(e.graph, side_priority=side_prio)
-    t0 = timed(lambda: g(clean, label, noisy))
-    def on_hi():
-        hi.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(hi):
-            g(clean, label, noisy)
-        torch.cuda.current_stream().wait_stream(hi)
-    t1 = timed(on_hi)
-    print(f"{dtype} segments, second chain priority {side_prio}: {t0:.3f} ms launched on the default-priority stream, {t1:.3f} ms on a high-priority stream", flush=True)
+for emit in ("close", "open"):
+    for swap in (False, True):
+        e.segments = SegmentReplay(e.graph, emit=emit, swap_chains=swap)
+        ts = [timed(lambda: g(clean, label, noisy)) for _ in range(3)]
+        print(f"{dtype} segments, launch order by segment {emit}, chains swapped {swap}: " + " / ".join(f"{t:.3f}" for t in ts) + " ms", flush=True)
+g.replay_mode = "runtime"
+print(f"{dtype} runtime replay again: {timed(lambda: g(clean, label, noisy)):.3f} ms", flush=True)
