@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import ctypes as C
 import heapq
+import sys
 from typing import List
 
 import torch
@@ -303,7 +304,10 @@ class SegmentReplay:
         self._events = []
 
     def __del__(self):
+        # not at interpreter shutdown: the HIP runtime may already be tearing down, and the process' exit frees everything anyway
         try:
+            if sys is None or sys.is_finalizing():
+                return
             self.close()
         except Exception:
             pass

@@ -73,6 +73,28 @@ def test_split_is_exact_on_adversarial_values():
                 assert got == want, (f, lane, j, got, want)
 
 
+def test_staged_split_is_exact_identity_conv_returns_its_input_bit_for_bit():
+    """The split the conv kernels do while they stage activations (x3_split8: v_cvt_pk_bf16_f32 + v_dot2c_f32_bf16): a 3x3 conv whose only
+    non-zero weights are 1.0 at the centre tap of the same channel must return x EXACTLY -- hi * 1 + mid * 1 + lo * 1 accumulates without
+    rounding in any order iff hi + mid + lo == x.  Adversarial values: full mantissas, bf16 rounding carries, 1e-18 ... 1e18, raw bit patterns."""
+    g = torch.Generator().manual_seed(11)
+    n, c, h, w = 2, 32, 24, 40
+    raw = torch.randint(0, 2 ** 31 - 2 ** 24, (n * c * h * w,), generator=g, dtype=torch.int64).to(torch.int32).view(torch.float32)
+    raw = torch.where(torch.isfinite(raw) & (raw.abs() > 1e-18) & (raw.abs() < 1e18), raw, torch.zeros(()))
+    sign = torch.where(torch.rand(raw.shape, generator=g) < 0.5, -1.0, 1.0)
+    x = (raw * sign).view(n, c, h, w).clone()
+    x[0, :, :4] = torch.randn(c, 4, w, generator=g)
+    x[0, :, 4:8] = torch.randn(c, 4, w, generator=g) * 1e-12
+    x[1, :, :4] = torch.tensor([1.00390625, 1.0078125, 0.99609375, 255.99998, 1.9999999, -1.00390625, 3.0e17, 1.5e-17]).repeat(5)[:w]
+    wt = torch.zeros(c, c, 3, 3)
+    wt[torch.arange(c), torch.arange(c), 1, 1] = 1.0
+    d3 = _ffi.conv_desc(n=n, hin=h, win=w, cin=c, hout=h, wout=w, cout=c, ks=3, dt=_ffi.DT_X3)
+    y = ops.conv_forward(d3, dev(x), ops.pack_oihw_fwd_x3(dev(wt)))[0]
+    got = y.cpu().contiguous()
+    same = got == x
+    assert bool(same.all()), f"{int((~same).sum())} of {x.numel()} values differ, e.g. {x[~same][:4].tolist()} -> {got[~same][:4].tolist()}"
+
+
 CASES = [(2, 16, 16, 32, 32), (16, 16, 16, 64, 64), (4, 16, 16, 128, 128), (2, 32, 64, 16, 16), (2, 128, 128, 8, 8), (2, 64, 32, 24, 20),
          (1, 32, 32, 6, 6), (2, 128, 64, 3, 3), (2, 32, 32, 48, 48), (1, 64, 48, 40, 72), (2, 128, 32, 36, 52), (3, 48, 16, 70, 70), (2, 16, 16, 9, 7),
          (2, 16, 4, 40, 40), (4, 16, 4, 128, 128), (2, 32, 8, 17, 23), (2, 16, 12, 16, 16)]      # cout 4 / 8 / 12: one padded cout tile (the STN's first-layer data gradient)
