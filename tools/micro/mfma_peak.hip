@@ -1,35 +1,45 @@
-// Register-only MFMA f32 16x16x4 throughput probe: WAVES waves per SIMD, NACC independent accumulators.
+// Micro-test: sustained rate of v_mfma_f32_16x16x32_bf16 with 1, 2 and 4 waves per SIMD on every CU, and the shader clock the chip holds
+// under that load (s_memtime cycles against the 100 MHz wall clock).   hipcc --offload-arch=gfx950 -O3 -o mfma_peak mfma_peak.hip
 #include <hip/hip_runtime.h>
-#include <stdio.h>
-#include <stdlib.h>
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-template <int NACC>
-__global__ __launch_bounds__(256) void k(float* out, int iters, float a0, float b0) {
-    f32x4 acc[NACC];
-    for (int i = 0; i < NACC; ++i) acc[i] = f32x4{0, 0, 0, 0};
-    float a = a0 + threadIdx.x, b = b0 - threadIdx.x;
+#include <cstdio>
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k(float* out, int iters, unsigned long long* clk, int random_data) {
+    f4 acc[8];
+    for (int i = 0; i < 8; ++i) acc[i] = f4{0, 0, 0, 0};
+    bf8 a8, b8;
+    for (int i = 0; i < 8; ++i) {
+        unsigned h = (threadIdx.x * 8 + i + blockIdx.x * 2048) * 2654435761u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        a8[i] = random_data ? (__bf16)(((int)(h & 0xffff) - 32768) * (1.0f / 32768.0f)) : (__bf16)0.0f;
+        b8[i] = random_data ? (__bf16)(((int)(h >> 16) - 32768) * (1.0f / 32768.0f)) : (__bf16)0.0f;
+    }
+    const unsigned long long c0 = clock64(), w0 = wall_clock64();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, b8, acc[i], 0, 0, 0);
     }
-    float s = 0;
-    for (int i = 0; i < NACC; ++i) s += acc[i].x + acc[i].y + acc[i].z + acc[i].w;
-    out[blockIdx.x * 256 + threadIdx.x] = s;
-}
-template <int NACC> void run(int blocks_per_cu, int iters) {
-    float* out; hipMalloc(&out, 256 * 256 * 16 * 4);
-    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    int grid = 256 * blocks_per_cu;
-    k<NACC><<<grid, 256>>>(out, iters, 1.f, 2.f); hipDeviceSynchronize();
-    hipEventRecord(e0); k<NACC><<<grid, 256>>>(out, iters, 1.f, 2.f); hipEventRecord(e1); hipEventSynchronize(e1);
-    float ms; hipEventElapsedTime(&ms, e0, e1);
-    double flops = (double)grid * 4 * iters * 4 * NACC * 2048.0;
-    printf("NACC=%d waves/SIMD=%d: %.1f TFLOP/s (%.3f ms)\n", NACC, blocks_per_cu, flops / ms / 1e9, ms);
-    hipFree(out);
+    const unsigned long long c1 = clock64(), w1 = wall_clock64();
+    f4 s = acc[0];
+    for (int i = 1; i < 8; ++i) s += acc[i];
+    out[blockIdx.x * 256 + threadIdx.x] = s.x + s.y + s.z + s.w;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = c1 - c0; clk[1] = w1 - w0; }
 }
 int main() {
-    for (int w = 1; w <= 4; ++w) { run<1>(w, 20000); run<2>(w, 10000); run<4>(w, 5000); run<8>(w, 2500); }
+    float* d; hipMalloc(&d, 4096 * 256 * 4);
+    unsigned long long* clk; hipMalloc(&clk, 16);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int random_data = 0; random_data < 2; ++random_data)
+    for (int waves = 1; waves <= 4; waves *= 2) {
+        const int iters = 400000 / waves, blocks = 256 * waves;
+        for (int rep = 0; rep < 3; ++rep) {
+            hipEventRecord(e0);
+            k<<<blocks, 256>>>(d, iters, clk, random_data);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            unsigned long long h[2]; hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost);
+            if (rep == 2) printf("%s operands, %d wave(s) per SIMD: %.3f ms, %.0f TFLOP/s dense bf16; s_memtime/wall = %.0f MHz; %.1f shader cycles per MFMA and wave\n", random_data ? "random" : "all-zero", waves, ms,
+                            16384.0 * iters * 8 * 4 * blocks / (ms * 1e-3) / 1e12, 100.0 * (double)h[0] / (double)h[1], (double)h[0] / (iters * 8.0));
+        }
+    }
     return 0;
 }
