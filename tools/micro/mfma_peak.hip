@@ -16,7 +16,8 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, unsigned long lo
     const unsigned long long c0 = clock64(), w0 = wall_clock64();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, b8, acc[i], 0, 0, 0);
+        for (int i = 0; i < 8; ++i) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a8), "v"(b8));      // (the builtin form
+        // made the compiler rotate the accumulators through AGPRs: ~50 v_accvgpr moves per 8 MFMAs, which is what that loop then measured)
     }
     const unsigned long long c1 = clock64(), w1 = wall_clock64();
     f4 s = acc[0];
