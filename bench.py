@@ -117,9 +117,10 @@ def latent_mask_roofline(device):
     return out
 
 
-def cpu_baseline(host_batch, threads, steps=3, cfgs=(DROP_IMG, DROP_SEG), what="dropout masks"):
-    """BASELINE.md section 3 procedure: the full bs16 batch, 1 warm-up step + `steps` timed steps, median (the oracle is the checker,
-    timed here as the reported CPU baseline -- never on the product path)."""
+def cpu_baseline(host_batch, threads, steps=5, warm=3, cfgs=(DROP_IMG, DROP_SEG), what="dropout masks"):
+    """BASELINE.md section 3 procedure: the full bs16 batch, `warm` warm-up steps + `steps` timed steps, median (the oracle is the checker,
+    timed here as the reported CPU baseline -- never on the product path).  The headline run does 3 + 5; the
+    sub-record children do 1 + 3 so that the default run stays within a few minutes (--cpu-baseline-steps)."""
     from oracle import ref_cpu as O
     from cooperative_training_and_latent_space_data_augmentation_amd.init import reference_init_state_dicts
     torch.set_num_threads(threads)
@@ -127,15 +128,15 @@ def cpu_baseline(host_batch, threads, steps=3, cfgs=(DROP_IMG, DROP_SEG), what="
     s = O.OracleSolver(state_dicts=reference_init_state_dicts())
     clean, label, noisy = host_batch
     times = []
-    for i in range(1 + steps):
+    for i in range(warm + steps):
         t0 = time.perf_counter()
         s.cooperative_step(clean, label, noisy, cfgs[0], cfgs[1])
         times.append(time.perf_counter() - t0)
-    med = sorted(times[1:])[len(times[1:]) // 2]
+    med = sorted(times[warm:])[len(times[warm:]) // 2]
     n, hw = clean.shape[0], clean.shape[-1]
     return {"value": n / med, "unit": "slices/s", "cores": threads, "kind": "port",
-            "sample": f"oracle/ref_cpu.py, full cooperative step bs{n} {hw}x{hw} fp32, {threads} torch threads: 1 warm-up + {steps} timed steps, median {med:.1f} s/step",
-            "sample_detail": f"{what}; warm-up {times[0]:.1f} s, timed {[round(t, 1) for t in times[1:]]} s; the reference's arithmetic"}
+            "sample": f"oracle/ref_cpu.py, full cooperative step bs{n} {hw}x{hw} fp32, {threads} torch threads: {warm} warm-up + {steps} timed steps, median {med:.1f} s/step",
+            "sample_detail": f"{what}; warm-up {[round(t, 1) for t in times[:warm]]} s, timed {[round(t, 1) for t in times[warm:]]} s; the reference's arithmetic"}
 
 
 def _narrow(k):
@@ -290,6 +291,43 @@ def flush_c_stdio():
     sys.stdout.flush()
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) without a launcher: this process touches no GPU (torch.cuda.device_count() does not initialise
+    one on this image), starts the N ranks as a CHILD process -- python -m torch.distributed.run, one rank per GPU, rendezvous on
+    127.0.0.1 -- relays the job's stdout (rank 0's headline line last) and exits with the job's code.  Fewer than N visible devices is
+    an error, never a silent smaller run."""
+    import socket
+    n_dev = torch.cuda.device_count()
+    if n_dev < 1 or (n_dev < args.gpus and not args.all_on_device0):
+        print(f"bench.py: --gpus {args.gpus} but {n_dev} GPU(s) visible: refusing to run a smaller job under that label", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:                           # a free rendezvous port
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env, cwd=ROOT)
+    lines = r.stdout.splitlines()
+    head = [l for l in lines if l.startswith("{")]
+    for l in lines:                                       # everything the job printed, then rank 0's headline line as the LAST line
+        if not head or l is not head[-1]:
+            print(l)
+    if r.returncode == 0 and not head:
+        print("bench.py: the launched job printed no headline line", file=sys.stderr)
+        return 3
+    if head:
+        rec = json.loads(head[-1])
+        if r.returncode == 0 and rec.get("n_gpus") != args.gpus:
+            print(f"bench.py: asked for {args.gpus} ranks, the job reports n_gpus = {rec.get('n_gpus')}", file=sys.stderr)
+            return 4
+        flush_c_stdio()
+        print(head[-1], flush=True)
+    return r.returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -317,6 +355,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--single-stream", action="store_true", help="A/B aid: one launch chain instead of two (solver.two_streams = False)")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--cpu-baseline-steps", default="3+5", help="warm-up + timed steps of the CPU baseline (BASELINE.md section 3: >= 3 + >= 5)")
     ap.add_argument("--prof-filter", default=None, help="profiling id to report as `roofline.kernel` instead of the arg-max of serial time")
     ap.add_argument("--detail-file", default=DETAIL_FILE, help="where the full record goes (relative to this script)")
     ap.add_argument("--detail-to-stdout", action="store_true", help="also print the BENCH_DETAIL line to stdout (before the headline line)")
@@ -328,10 +367,12 @@ def main():
     if args.masks is None:
         args.masks = "targeted" if args.dtype == "bf16" else "dropout"
     IMG_CFG, SEG_CFG, mask_text = MASKS[args.masks]
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))              # (before anything in this process touches a GPU)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback of the product path)")
@@ -452,6 +493,11 @@ def main():
             if mode in ("graph", "segments"):
                 raise
             calib["graph_error"], gstep = f"{type(exc).__name__}: {str(exc)[:160]}", None
+    if use_dist and mode == "auto":                       #  every later collective is reached by all ranks or by none: a rank
+        cap_ok = torch.tensor([1.0 if gstep is not None else 0.0], device=device)   # whose capture failed takes the others to the eager step too
+        dist.all_reduce(cap_ok, op=dist.ReduceOp.MIN)
+        if cap_ok.item() == 0 and gstep is not None:
+            calib["graph_error"], gstep = "capture failed on another rank", None
     if mode == "auto":
         def time_steps(fn, n=8):
             fence()
@@ -476,6 +522,7 @@ def main():
             if use_dist:                                  # (every timed step carries the gradient exchange: all ranks time it, or none)
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if flag.item() > 0:
+                graph_step()                              # (untimed: the first segment replay probes the hardware queues of its streams)
                 calib["segments_ms"] = time_steps(graph_step)
                 calib["segments"] = next(iter(gstep.entries.values())).segments.describe()
             else:
@@ -622,12 +669,19 @@ def main():
         if world == 1:
             out["roofline_latent_mask"] = latent_mask_roofline(device)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(host_batch, args.cpu_threads or min(32, os.cpu_count()), cfgs=(IMG_CFG, SEG_CFG), what=mask_text)
+            cb_warm, cb_steps = (int(v) for v in args.cpu_baseline_steps.split("+"))
+            out["cpu_baseline"] = cpu_baseline(host_batch, args.cpu_threads or min(32, os.cpu_count()), steps=cb_steps, warm=cb_warm, cfgs=(IMG_CFG, SEG_CFG), what=mask_text)
         if world == 1 and not args.no_sub_records and args.dtype == "fp32" and args.masks == "dropout":
             # BASELINE configs[2] and configs[4], each measured by a child process running this script (a fresh process: its own
             # streams, pools and graphs; this process is idle meanwhile).  The headline keys above are untouched.
-            common = ["--steps", str(args.steps), "--warmup", str(args.warmup), "--no-sub-records"] + (["--no-cpu-baseline"] if args.no_cpu_baseline else []) + \
+            common = ["--steps", str(args.steps), "--warmup", str(args.warmup), "--no-sub-records", "--cpu-baseline-steps", "1+3"] + \
+                     (["--no-cpu-baseline"] if args.no_cpu_baseline else []) + \
                      (["--lib", args.lib] if args.lib else []) + [x for kv in args.set for x in ("--set", kv)]
+            # the control next to the X3 headline: the same step with every contraction on the fp32 matrix pipe
+            # (v_mfma_f32_16x16x4_f32), i.e. nets.X3 = nets.X3_WGRAD = False
+            if x3_on:
+                out["config2_fp32_mfma"] = sub_record(["--set", "nets.X3=False", "--set", "nets.X3_WGRAD=False", "--no-cpu-baseline"] +
+                                                      [a for a in common if a != "--no-cpu-baseline"], "config2_fp32_mfma")
             out["config3_bf16"] = sub_record(["--dtype", "bf16", "--masks", "targeted"] + common, "config3_bf16")
             out["config5_inference"] = sub_record(["--workload", "inference"] + common, "config5_inference")
             # BASELINE configs[3]'s masking scheme (all three schemes randomly sampled per step: one captured graph per scheme pair) at N = 1 --
@@ -686,7 +740,7 @@ def headline(d):
     lm = (d.get("roofline_latent_mask") or {})
     if lm:
         h["latent_mask_hbm_frac"] = {k.split("_")[0] + "_" + k.split("_")[-1]: (v.get("graph_replay_frac") or v.get("frac")) for k, v in lm.items()}
-    for k in ("config3_bf16", "config5_inference", "config4_random_masks_n1"):
+    for k in ("config2_fp32_mfma", "config3_bf16", "config5_inference", "config4_random_masks_n1"):
         if k in d:
             h[k] = _sub_headline(d[k])
     h["detail"] = d.get("detail_file", DETAIL_FILE)

@@ -5,10 +5,11 @@
 // takes 8 significant bits plus the sign of the remainder; the two subtractions are exact in fp32, and what is left after two steps
 // has at most 24 - 16 = 8 significant bits, so `lo` needs no rounding).  A product x*w is then the sum of nine bf16 x bf16 products,
 // each of which the matrix pipe forms exactly (16 significant bits) and adds into an fp32 accumulator.  The three smallest -- mid*lo,
-// lo*mid, lo*lo, together below 2^-25 |x*w| -- are dropped: six MFMAs
+// lo*mid, lo*lo, together at most 2^-24 (1 + 2^-8) |x*w| (|mid| <= 2^-8 |x|, |lo| <= 2^-17 |x|; worst case x = w = 1 + 2^-8 - 2^-16 + 2^-17:
+// tests/test_x3_split_cpu.py), typically 2^-25 and less -- are dropped: six MFMAs
 //     hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi
 // per fp32 contraction step, each with K = 32, against eight fp32 MFMAs with K = 4 for the same K: 16/6 = 2.7x the fp32 matrix rate at an
-// error per product below the rounding of an fp32 multiply (2^-24).  Tensors in HBM stay fp32 (same bytes as the fp32 family, same
+// error per product at the rounding of one fp32 multiply (2^-24).  Tensors in HBM stay fp32 (same bytes as the fp32 family, same
 // epilogues); what changes is what the staging writes to LDS (three bf16 planes per half-chunk instead of one fp32 image: 1.5x the
 // bytes), the weight fragments (packed once per optimizer step as three bf16 planes, ctl_conv_x3.hip) and the matrix instruction.
 //

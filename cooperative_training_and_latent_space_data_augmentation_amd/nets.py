@@ -58,7 +58,8 @@ FUSE_TAIL16 = True       # bf16: CTL_EPI_TAILBWD in the bf16 family (the tail's 
 FUSE_BNAPPLY16 = True    # bf16: the BatchNorm-backward apply passes of the residual blocks run inside the staging of their consumers (pro_affine 2 / dy2)
 X3 = True                # fp32: the 2x2 / 3x3 / 4x4 convs with cin, cout multiples of 16 contract on the bf16 matrix pipe over an exact three-way
                          # bf16 split of both fp32 operands (CTL_DT_X3, csrc/ctl_conv_x3_stage.h): same tensors, same epilogues, error per product
-                         # below an fp32 multiply's rounding, 16/6 of the fp32 MFMA rate
+                         # <= 2^-24 (1 + 2^-8) (one fp32 multiply's rounding; typically 2^-25), 16/6 of the fp32 MFMA rate.  A MODULE-level
+                         # switch read when a CtlNet is built: set nets.X3 = False BEFORE constructing the solver (bench.py --set does)
 X3_WGRAD = True          # ... and so do the weight gradients of those layers (3x3 stride 1 / 2, 2x2 stride 2)
 FUSE_TAIL = True         # fp32: the residual tail's BatchNorm-backward reduction inside the launch that writes dOut (CTL_EPI_TAILBWD): dOut is
                          # never materialised, the stand-alone reduction launch (read dOut, out, v; write dS) disappears

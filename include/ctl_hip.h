@@ -82,7 +82,7 @@ typedef struct ctl_conv {
                                         fp32 computation with the contraction on the bf16 matrix pipe -- every operand is split
                                         exactly into three bf16 numbers while it is staged, six v_mfma_f32_16x16x32_bf16 per
                                         contraction step (hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi, fp32 accumulate): error
-                                        per product < 2^-25, below the rounding of an fp32 multiply; 16/6 of the fp32 MFMA rate.
+                                        per product <= 2^-24 (1 + 2^-8) worst case (the rounding of one fp32 multiply), typically 2^-25; 16/6 of the fp32 MFMA rate.
                                         Weights come from ctl_pack_weights_x3_batched (records with CTL_PACK_X3)                    */
 } ctl_conv;
 enum { CTL_DT_BF16 = 1, CTL_DT_X16 = 2, CTL_DT_Y16 = 4, CTL_DT_RES16 = 8, CTL_DT_X3 = 16 };

@@ -75,6 +75,37 @@ def graph_main(rank, world, device, out, sd):
     dist.destroy_process_group()
 
 
+def world4_main(rank, world, device, out, sd):
+    """more than two ranks.  With > 2 ranks a ring all-reduce ties an element's summation order to its position in
+    the buffer, so the five per-network ranges need not sum to the single bucket's bits -- what must hold is that every rank ends with the
+    SAME bits.  Three steps (per-network exchange launched from inside backward, then a dropout step, then targeted with random k),
+    per-rank shards and RNG streams; every rank saves its weights after each step, and the gradient bucket of the first."""
+    CH_RT = dict(CH_MSE, random_threshold=True)
+    SP_RT = dict(SP_CE, random_threshold=True)
+    torch.manual_seed(100 + rank)
+    s = AdvancedTripletReconSegmentationModel(use_gpu=True)
+    if rank == 0:
+        for k, m in s.model.items():
+            m.load_state_dict(sd[k])
+    dp = DataParallel(s)
+    torch.manual_seed(7000 + rank); np.random.seed(7000 + rank); random.seed(7000 + rank)
+    clean, label, noisy = shard(rank, device)
+    rec = {"per_step": [], "world": world}
+
+    def hook(solver):
+        dp.sync_gradients(solver)
+        rec["bucket_sum"] = dp.bucket.buf.detach().cpu().clone()
+        rec["launched_in_backward"] = list(dp.launched_in_backward)
+
+    for i, (ci, cs, h) in enumerate(((CH_MSE, SP_CE, hook), (DROP_MSE, DROP_CE, dp.launch_remaining), (CH_RT, SP_RT, dp.launch_remaining))):
+        l = s.cooperative_step(clean, label, noisy, ci, cs, grad_hook=h)
+        rec["per_step"].append((_weights(s), torch.stack([v.detach().float() for v in l]).cpu()))
+    # this rank's own (un-reduced) gradient of step 1, for the parent's sum check: one more solver from the broadcast weights
+    torch.save(rec, os.path.join(out, f"w4_rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     backend, out = sys.argv[1], sys.argv[2]
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
@@ -87,6 +118,8 @@ def main():
     sd = torch.load(os.path.join(ROOT, "tests", "golden", "state_dicts_seed0.pt"), weights_only=False)
     if len(sys.argv) > 3 and sys.argv[3] == "graph":
         return graph_main(rank, world, device, out, sd)
+    if len(sys.argv) > 3 and sys.argv[3] == "world4":
+        return world4_main(rank, world, device, out, sd)
     torch.manual_seed(100 + rank)                      # deliberately different weights before the broadcast
     s = AdvancedTripletReconSegmentationModel(use_gpu=True)
     if rank == 0:

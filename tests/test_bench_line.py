@@ -64,6 +64,9 @@ def test_bench_last_stdout_line_is_the_small_headline(tmp_path):
     assert 0 < rec["roofline"]["frac"] < 1 and rec["roofline"]["kernel"] and rec["roofline"]["bound"] in ("mfma", "hbm")
     assert rec["cpu_baseline"]["value"] > 0 and rec["cpu_baseline"]["kind"] == "port"
     assert rec["config3_bf16"]["value"] > 0 and rec["config5_inference"]["value"] > 0 and rec["config4_random_masks_n1"]["value"] > 0
+    # the pure-fp32-MFMA control next to the X3 headline
+    assert rec["dtype"] == "f32 (bf16x3 split)" and rec["config2_fp32_mfma"]["value"] > 0 and rec["config2_fp32_mfma"]["dtype"] == "f32"
+    assert "3 warm-up + 5 timed" in rec["cpu_baseline"]["sample"]
     assert rec["config4_random_masks_n1"]["mode"] == "graph"
     assert not any(l.startswith("BENCH_DETAIL") for l in lines)            # the big record goes to stderr and the file
     assert any(l.startswith("BENCH_DETAIL ") for l in out.stderr.splitlines())
@@ -73,3 +76,43 @@ def test_bench_last_stdout_line_is_the_small_headline(tmp_path):
     # the reported kernel is the arg-max of serial time over the profiling ids of the step
     assert rec["roofline"]["kernel"] == detail["kernels_by_serial_time"][0]["kernel"], (rec["roofline"], detail["kernels_by_serial_time"][:3])
     os.remove(os.path.join(ROOT, dfile))
+
+
+def test_headline_with_every_sub_record_fits():
+    """All four sub-records present (config2_fp32_mfma is round 5's) on top of the largest record on file: still < 3 KB."""
+    import bench
+    full = json.loads(open(os.path.join(ROOT, "profiles", "r3_bench_line_m.json")).read().strip().splitlines()[-1])
+    full["config2_fp32_mfma"] = dict(full["config3_bf16"])
+    full["config4_random_masks_n1"] = dict(full["config3_bf16"])
+    full["roofline"]["traffic_source"] = "s" * 400
+    line = json.dumps(bench.headline(full))
+    assert len(line) < bench.HEADLINE_MAX_BYTES, len(line)
+    assert json.loads(line)["config2_fp32_mfma"]["value"] == full["config3_bf16"]["value"]
+
+
+def test_gpus_n_without_a_launcher_is_n_ranks_or_an_error():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset on a box with no (or too few) GPUs: non-zero exit and a message, never a
+    one-rank run labelled n_gpus 1.  (No GPU here: the launcher path refuses before any device is touched.)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["HIP_VISIBLE_DEVICES"] = ""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True,
+                         text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode != 0
+    assert "--gpus 2" in out.stderr and "GPU(s) visible" in out.stderr, out.stderr[-500:]
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+@pytest.mark.gpu
+def test_gpus_2_without_a_launcher_runs_two_ranks():
+    """--gpus 2 with no torchrun in the command: bench.py starts the two ranks itself (gloo, both on GPU 0) and relays rank 0's line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--all-on-device0", "--size", "64", "--batch", "2",
+           "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-sub-records", "--detail-file", "bench_detail_test2.json"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads(out.stdout.strip().splitlines()[-1])
+    assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 4 and rec["config"]["parallelism"] == "dp2" and rec["value"] > 0
+    try:
+        os.remove(os.path.join(ROOT, "bench_detail_test2.json"))
+    except OSError:
+        pass

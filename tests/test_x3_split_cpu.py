@@ -33,6 +33,28 @@ def test_three_bf16_numbers_hold_an_fp32_number_exactly():
     assert float((lo[nz].abs() / x[nz].abs()).max()) <= 2.0 ** -16
 
 
+def test_constructed_worst_case_of_the_dropped_products():
+    """VERDICT r4 weak #9 / ADVICE r4: the three dropped products are NOT below 2^-25.  Worst case of the split: hi = 1, the remainder 2^-8 - 2^-17 a rounding tie of the
+    second step: |mid| = 2^-8 (as large as a remainder gets), |lo| = 2^-17 (half an ulp of mid) on BOTH operands; the dropped terms
+    mid*lo + lo*mid + lo*lo are then 2^-24 (1 - 2^-7.x) |x*w| -- the bound the headers state is <= 2^-24 (1 + 2^-8)."""
+    x = torch.tensor([1.0 + 2.0 ** -8 - 2.0 ** -17], dtype=torch.float32)
+    hi, mid, lo, _ = split3(x)
+    assert float(hi) == 1.0 and abs(float(mid)) == 2.0 ** -8 and abs(float(lo)) == 2.0 ** -17
+    d = lambda t: t.double()
+    six = d(hi) * d(hi) + 2 * d(hi) * d(mid) + d(mid) * d(mid) + 2 * d(hi) * d(lo)
+    assert float(hi.double() + mid.double() + lo.double()) == float(x.double())
+    rel = float(((d(x) * d(x) - six) / (d(x) * d(x))).abs())
+    assert 2.0 ** -25 < rel <= 2.0 ** -24 * (1 + 2.0 ** -8), rel
+    assert rel > 0.98 * 2.0 ** -24                       # the bound is attained to 2 %: 2^-25 was wrong by 2x
+    # and over a whole dense neighbourhood of that value (every fp32 number in [1 + 2^-8 - 2^-15, 1 + 2^-8]) nothing exceeds the bound
+    base = torch.tensor([1.0 + 2.0 ** -8 - 2.0 ** -15], dtype=torch.float32).view(torch.int32)
+    xs = (base + torch.arange(0, 300, dtype=torch.int32)).view(torch.float32)
+    h, m, l, _ = split3(xs)
+    a, b = torch.meshgrid(torch.arange(xs.numel()), torch.arange(xs.numel()), indexing="ij")
+    drop = (d(m)[a] * d(l)[b] + d(l)[a] * d(m)[b] + d(l)[a] * d(l)[b]).abs() / (d(xs)[a] * d(xs)[b])
+    assert float(drop.max()) <= 2.0 ** -24 * (1 + 2.0 ** -8)
+
+
 def test_six_products_are_an_fp32_product():
     g = torch.Generator().manual_seed(5)
     a = torch.randn(300000, generator=g) * torch.exp(torch.randn(300000, generator=g) * 3)
@@ -43,6 +65,6 @@ def test_six_products_are_an_fp32_product():
     six = d(ah) * d(bh) + d(ah) * d(bm) + d(am) * d(bh) + d(am) * d(bm) + d(ah) * d(bl) + d(al) * d(bh)      # (each product is exact in fp32: 8 x 8 bits)
     exact = d(a) * d(b)
     rel = ((six - exact).abs() / exact.abs().clamp_min(1e-300)).max()
-    assert float(rel) < 2.0 ** -24, float(rel)              # the dropped mid*lo + lo*mid + lo*lo: below half an ulp of the fp32 product
+    assert float(rel) <= 2.0 ** -24 * (1 + 2.0 ** -8), float(rel)   # the dropped mid*lo + lo*mid + lo*lo (worst case: the constructed pair above)
     fp32_rounding = ((d((a * b)) - exact).abs() / exact.abs().clamp_min(1e-300)).max()
     assert float(rel) < float(fp32_rounding)                # ... i.e. smaller than what rounding the product to fp32 costs
