@@ -109,12 +109,18 @@ struct XStage3 {
     int rel[NU];        // byte offset of the unit's first source element relative to the tile's source origin
     int rc[NU];         // r | c << 16 (tile-relative virtual coordinates); 0x7fff7fff past the tile
     int lds[NU];        // LDS byte offset inside plane (0, h); split s adds 2 s PLANE; units past the tile write the dump slot
-    f32x4 v0[NU], v1[NU];
-    f32x4 w0[X2 ? NU : 1], w1[X2 ? NU : 1];      // X2: the second tensor's units
-    unsigned vmask;
+    // What a tile's loads leave behind until its store: the units themselves and the three words that say how to treat them.  The
+    // single-set kernels use the member `pay`; the producer waves of the producer / consumer kernels (ctl_conv_igemm.h, PC) keep several
+    // sets -- several tiles of loads in flight -- and pass them explicitly.
+    struct Pay {
+        f32x4 v0[NU], v1[NU];
+        f32x4 w0[X2 ? NU : 1], w1[X2 ? NU : 1];      // X2: the second tensor's units
+        unsigned vmask;
+        int tb_last;
+        bool all_in;
+    };
+    Pay pay;
     int pad_h, pad_w;
-    int tb_last;
-    bool all_in;
 
     __device__ __forceinline__ void init(const ctl_conv& d) {
         const int tid = threadIdx.x;
@@ -131,26 +137,29 @@ struct XStage3 {
             rc[i] = in ? (r | (c << 16)) : 0x7fff7fff;
             lds[i] = in ? (PLANAR ? (h * PLANE + (r * G::IWP + G::ldscol(c)) * 16) : ((r * G::IWP + G::ldscol(c)) * 32 + h * 16)) : DUMP;
         }
-        vmask = 0;
-        all_in = false;
+        pay.vmask = 0;
+        pay.all_in = false;
         pad_h = pad_w = G::PAD;
     }
 
     __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rx, __amdgpu_buffer_rsrc_t rx2, const ctl_conv& d, int n, int ho0, int wo0, int g) {
+        load(pay, rx, rx2, d, n, ho0, wo0, g);
+    }
+    __device__ __forceinline__ void load(Pay& P, __amdgpu_buffer_rsrc_t rx, __amdgpu_buffer_rsrc_t rx2, const ctl_conv& d, int n, int ho0, int wo0, int g) {
         const int vh0 = ho0 * S - pad_h, vw0 = wo0 * S - pad_w;
         const unsigned hv = PLAIN ? d.hin : 2 * d.hin;
         const unsigned wv = PLAIN ? d.win : 2 * d.win;
         const int oh = PLAIN ? vh0 : ((ho0 >> 1) - PADH);
         const int ow = PLAIN ? vw0 : ((wo0 >> 1) - PADH);
         const int tb = (((n * d.hin + oh) * d.win + ow) * d.cin + g * 16) * 4;
-        tb_last = tb;
-        all_in = MODE != CTL_IN_ZINS2 && vh0 >= 0 && vw0 >= 0 && vh0 + G::IH <= (int)hv && vw0 + G::IW <= (int)wv;
-        if (all_in) {       // interior tile: the origin rides in the scalar offset, the per-thread offsets are loop-invariant
+        P.tb_last = tb;
+        P.all_in = MODE != CTL_IN_ZINS2 && vh0 >= 0 && vw0 >= 0 && vh0 + G::IH <= (int)hv && vw0 + G::IW <= (int)wv;
+        if (P.all_in) {       // interior tile: the origin rides in the scalar offset, the per-thread offsets are loop-invariant
 #pragma unroll
-            for (int i = 0; i < NU; ++i) { v0[i] = ctl_bload4s(rx, rel[i], tb); v1[i] = ctl_bload4s(rx, rel[i] + 16, tb); }
+            for (int i = 0; i < NU; ++i) { P.v0[i] = ctl_bload4s(rx, rel[i], tb); P.v1[i] = ctl_bload4s(rx, rel[i] + 16, tb); }
             if constexpr (X2) {
 #pragma unroll
-                for (int i = 0; i < NU; ++i) { w0[i] = ctl_bload4s(rx2, rel[i], tb); w1[i] = ctl_bload4s(rx2, rel[i] + 16, tb); }
+                for (int i = 0; i < NU; ++i) { P.w0[i] = ctl_bload4s(rx2, rel[i], tb); P.w1[i] = ctl_bload4s(rx2, rel[i] + 16, tb); }
             }
             return;
         }
@@ -164,17 +173,21 @@ struct XStage3 {
             vo[i] = ok ? (tb + rel[i]) : CTL_OOB;
             m |= ok ? (1u << i) : 0u;
         }
-        vmask = m;
+        P.vmask = m;
 #pragma unroll
-        for (int i = 0; i < NU; ++i) { v0[i] = ctl_bload4(rx, vo[i]); v1[i] = ctl_bload4(rx, vo[i] == CTL_OOB ? CTL_OOB : vo[i] + 16); }
+        for (int i = 0; i < NU; ++i) { P.v0[i] = ctl_bload4(rx, vo[i]); P.v1[i] = ctl_bload4(rx, vo[i] == CTL_OOB ? CTL_OOB : vo[i] + 16); }
         if constexpr (X2) {
 #pragma unroll
-            for (int i = 0; i < NU; ++i) { w0[i] = ctl_bload4(rx2, vo[i]); w1[i] = ctl_bload4(rx2, vo[i] == CTL_OOB ? CTL_OOB : vo[i] + 16); }
+            for (int i = 0; i < NU; ++i) { P.w0[i] = ctl_bload4(rx2, vo[i]); P.w1[i] = ctl_bload4(rx2, vo[i] == CTL_OOB ? CTL_OOB : vo[i] + 16); }
         }
     }
 
     // pro_scale / pro_shift (/ pro_c with X2) are the block's LDS copies of the coefficients, [group][cin] each; `goff` = group * cin
     __device__ __forceinline__ void store(float* __restrict__ xtf, const ctl_conv& d, int g, const float* pro_scale, const float* pro_shift,
+                                          int goff, const float* pro_c, __amdgpu_buffer_rsrc_t rxout, bool xout_on) {
+        store(pay, xtf, d, g, pro_scale, pro_shift, goff, pro_c, rxout, xout_on);
+    }
+    __device__ __forceinline__ void store(const Pay& P, float* __restrict__ xtf, const ctl_conv& d, int g, const float* pro_scale, const float* pro_shift,
                                           int goff, const float* pro_c, __amdgpu_buffer_rsrc_t rxout, bool xout_on) {
         unsigned char* xt = reinterpret_cast<unsigned char*>(xtf);
         const int cb = g * 16 + (PLANAR ? ((threadIdx.x >> 3) & 1) : (threadIdx.x & 1)) * 8;
@@ -188,16 +201,16 @@ struct XStage3 {
         const float slope = d.pro_slope;
 #pragma unroll
         for (int i = 0; i < NU; ++i) {
-            f32x4 lo = v0[i], hi = v1[i];
-            const bool in = all_in || ((vmask >> i) & 1u);
+            f32x4 lo = P.v0[i], hi = P.v1[i];
+            const bool in = P.all_in || ((P.vmask >> i) & 1u);
             if constexpr (X2) {      // the virtual tensor A * x + B * x2 + C; padding stays zero (C alone would leak into it)
-                lo = in ? (a0 * lo + b0 * w0[i] + c0) : zero;
-                hi = in ? (a1 * hi + b1 * w1[i] + c1) : zero;
+                lo = in ? (a0 * lo + b0 * P.w0[i] + c0) : zero;
+                hi = in ? (a1 * hi + b1 * P.w1[i] + c1) : zero;
                 if (xout_on) {
                     const unsigned tr = (unsigned)((rc[i] & 0xffff) - pad_h), tc = (unsigned)((rc[i] >> 16) - pad_w);
                     const bool own = in && tr < (unsigned)(G::TH * S) && tc < (unsigned)(TW * S);
-                    ctl_bstore4(rxout, own ? (tb_last + rel[i]) : CTL_OOB, lo);
-                    ctl_bstore4(rxout, own ? (tb_last + rel[i] + 16) : CTL_OOB, hi);
+                    ctl_bstore4(rxout, own ? (P.tb_last + rel[i]) : CTL_OOB, lo);
+                    ctl_bstore4(rxout, own ? (P.tb_last + rel[i] + 16) : CTL_OOB, hi);
                 }
             } else if (d.pro_affine) {      // out-of-range units hold hardware zeros and must stay zero under the affine prologue
                 lo = in ? ctl_leaky01(lo * a0 + b0, slope) : zero;
