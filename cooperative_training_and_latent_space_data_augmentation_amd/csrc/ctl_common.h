@@ -130,6 +130,7 @@ struct ctl_conv_cfg {
     int tiles_h, tiles_w;
     int g;               // cin chunks of 16
     int cot;             // cout tiles of 16 (total)
+    int pc;              // X3 forward-type launches: the producer / consumer form (ctl_conv_igemm.h, PC) was chosen
 };
 int ctl_conv_pick_cfg(const ctl_conv* d, ctl_conv_cfg* c, int for_wgrad);
 int ctl_conv_grid_x(int ntiles, int other, int occ);      // persistent grid: the resident capacity (ctl_conv.hip)

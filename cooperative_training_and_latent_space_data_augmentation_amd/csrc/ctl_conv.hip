@@ -884,6 +884,7 @@ int ctl_conv_pick_cfg(const ctl_conv* d, ctl_conv_cfg* c, int for_wgrad) {
             if (d->ks == 4 && c->nt == 2) { mt = 1; tw = 16; }
         }
     }
+    c->pc = 0;
     c->mt = mt; c->tw = tw; c->th = 4 * mt * 16 / tw;
     c->tiles_h = ctl_cdiv(d->hout, c->th);
     c->tiles_w = ctl_cdiv(d->wout, c->tw);

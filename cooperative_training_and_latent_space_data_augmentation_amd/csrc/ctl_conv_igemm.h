@@ -204,7 +204,21 @@ struct XStage {
 #endif
 // X3: the contraction runs on v_mfma_f32_16x16x32_bf16 over an exact three-way bf16 split of both fp32 operands (ctl_conv_x3_stage.h):
 // the LDS images, the weight fragments and the matrix phase change, everything around them (tile walk, prefetch pipeline, epilogues) is shared
-template <int KS, int S, int MODE, int MT, int TW, int NT, int EPI, bool X2 = false, bool X3 = false>      // X2: see XStage (pro_scale = the [group][3][cin] coefficients)
+// PC (round 5, X3 only): the PRODUCER / CONSUMER form.  One 512-thread block per CU: waves 0-3 (one per SIMD) are producers -- they keep
+// CTL_PC_SETS tiles of buffer loads in flight in registers (they hold no accumulators), apply the prologue, split and write the bf16
+// planes of step it into LDS image it & 1 (and the step's weight fragments into weight image it & 1); waves 4-7 (the SIMDs' second
+// waves) are consumers -- operand reads, MFMAs and the epilogue (whose operands they request before the step's barrier).  ONE s_barrier
+// per (tile, chunk) step: producers arrive with image it & 1 written, consumers with every read of image (it - 1) & 1 consumed, so the
+// staging of step it + 1 runs beside the matrix phase of step it on every SIMD (the matrix pipe and the vector ALU issue from
+// different waves), and a load has CTL_PC_SETS - 1 steps to come back.  Statistics rows are per consumer WAVE (no block-level sum: a
+// barrier among the consumers alone does not exist on gfx950), so ctl_conv_x3_stats_blocks reports 4 rows per block.
+#ifndef CTL_PC_SETS
+#define CTL_PC_SETS 3
+#endif
+#ifndef CTL_PC_SETS_X2
+#define CTL_PC_SETS_X2 2
+#endif
+template <int KS, int S, int MODE, int MT, int TW, int NT, int EPI, bool X2 = false, bool X3 = false, bool PC = false>      // X2: see XStage (pro_scale = the [group][3][cin] coefficients)
 // resident blocks of the X2 instantiations: two staged tensors (and with EPI an epilogue tensor) in registers -- at 3 blocks per CU the
 // 8x32-pixel form needs 92 B of scratch per lane, at 2 none: 17.15 -> 16.98 ms per step (tools/debug/fp32_x2_occ_ab.sh)
 #ifndef CTL_LB_X2EPI
@@ -223,7 +237,7 @@ template <int KS, int S, int MODE, int MT, int TW, int NT, int EPI, bool X2 = fa
 #ifndef CTL_LB_X3
 #define CTL_LB_X3(MT, NT, X2) (((NT) == 1 && (MT) >= 2 && !(X2)) ? 3 : 2)
 #endif
-__global__ __launch_bounds__(256, X3 ? CTL_LB_X3(MT, NT, X2) : (MT * NT >= 8 || KS == 4) ? 2 : ((MT * NT >= 4) ? (X2 ? (EPI ? CTL_LB_X2EPI : CTL_LB_X2) : CTL_LB_MID)
+__global__ __launch_bounds__(PC ? 512 : 256, PC ? 2 : X3 ? CTL_LB_X3(MT, NT, X2) : (MT * NT >= 8 || KS == 4) ? 2 : ((MT * NT >= 4) ? (X2 ? (EPI ? CTL_LB_X2EPI : CTL_LB_X2) : CTL_LB_MID)
                                                                                     : ((X2 && EPI) ? CTL_LB_SMALL_X2EPI : CTL_LB_SMALL))) void conv_igemm_kernel(const ctl_conv d, const float* __restrict__ x,
                                                           const float* __restrict__ wpack,
                                                           const float* __restrict__ bias,
@@ -244,6 +258,8 @@ __global__ __launch_bounds__(256, X3 ? CTL_LB_X3(MT, NT, X2) : (MT * NT >= 8 || 
     constexpr bool C4 = (MODE == CTL_IN_C4);
     static_assert(!C4 || (KS == 3 && S == 1), "K-packed taps: 3x3 stride-1 only");
     static_assert(!X3 || !C4, "X3: whole 16-channel chunks");
+    static_assert(!PC || X3, "the producer / consumer form exists for the X3 launches");
+    constexpr int NIMG = PC ? 2 : 1;                                         // LDS images of the input tile and of the weight chunk
     using XS3 = XStage3<KS, S, C4 ? CTL_IN_PLAIN : MODE, MT, TW, X2>;
     // X3: a fragment carries a PAIR of taps (K = 32 = 2 taps x 16 channels), in three split planes: [fragment][t][split][64 lanes][16 B]
     constexpr int NFRAG = X3 ? (TAPS + 1) / 2 : (C4 ? 3 : TAPS);             // weight fragments per cout tile and chunk
@@ -251,9 +267,10 @@ __global__ __launch_bounds__(256, X3 ? CTL_LB_X3(MT, NT, X2) : (MT * NT >= 8 || 
     constexpr int RED_FLOATS = 4 * NT * 16 * 2;
     constexpr int WT_FLOATS = NFRAG * NT * WSPL * 256;
     constexpr int XT_ALLOC = X3 ? XS3::XT_BYTES / 4 : G::XT_FLOATS;
-    __shared__ __attribute__((aligned(16))) float xt[XT_ALLOC + WT_FLOATS + RED_FLOATS + (X2 ? 3 : 2) * CTL_PRO_MAX];
-    float* wt = xt + XT_ALLOC;
-    float* sred = wt + WT_FLOATS;        // statistics reduction scratch (a flush can happen while xt holds the next tile)
+    static_assert((NIMG * (XT_ALLOC + WT_FLOATS) + RED_FLOATS + (X2 ? 3 : 2) * CTL_PRO_MAX) * 4 <= 160 * 1024, "LDS budget of one CU");
+    __shared__ __attribute__((aligned(16))) float xt[NIMG * (XT_ALLOC + WT_FLOATS) + RED_FLOATS + (X2 ? 3 : 2) * CTL_PRO_MAX];
+    float* wt = xt + NIMG * XT_ALLOC;
+    float* sred = wt + NIMG * WT_FLOATS; // statistics reduction scratch (a flush can happen while xt holds the next tile)
     float* cf_scale = sred + RED_FLOATS; // prologue coefficients [groups][cin]
     float* cf_shift = cf_scale + CTL_PRO_MAX;
     float* cf_c = cf_shift + (X2 ? CTL_PRO_MAX : 0);
@@ -261,7 +278,9 @@ __global__ __launch_bounds__(256, X3 ? CTL_LB_X3(MT, NT, X2) : (MT * NT >= 8 || 
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = PC ? (wave_all & 3) : wave_all;                 // PC: index among the producers (waves 0-3) / the consumers (waves 4-7)
+    const bool consumer = PC && wave_all >= 4;
     const int p = lane & 15, q = lane >> 4;
     // Tile ownership.  Blocks b, b+8, ... share an XCD (and its L2) and the dispatcher spreads blocks breadth-first: the
     // first 256 land on distinct CUs (tools/micro/dispatch_probe.hip).  So the tile list is cut into one contiguous range
@@ -377,11 +396,11 @@ __global__ __launch_bounds__(256, X3 ? CTL_LB_X3(MT, NT, X2) : (MT * NT >= 8 || 
 #pragma unroll
         for (int i = 0; i < NW; ++i) wv[i] = ctl_bload4s(rw, wrel[i], g * WSPL * 1024);
     };
-    auto wstore = [&]() {
+    auto wstore = [&](int img = 0) {
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
             const int u = tid + i * 256;
-            if (u < WU) *reinterpret_cast<f32x4*>(wt + u * 4) = wv[i];
+            if (u < WU) *reinterpret_cast<f32x4*>(wt + img * WT_FLOATS + u * 4) = wv[i];
         }
     };
 
@@ -389,29 +408,31 @@ __global__ __launch_bounds__(256, X3 ? CTL_LB_X3(MT, NT, X2) : (MT * NT >= 8 || 
     cur.init(bid0, nb, tiles_h, tiles_w);
     nxt = cur;
     TM_DECL
-    if (total_it > 0) {
+    if (!PC && total_it > 0) {
         xs.load(rx, rx2, d, cur.n, cur.th * G::TH, cur.tw * TW, 0);
         wload(0);
     }
     if constexpr (X2) {      // coefficients as the BatchNorm-backward finalize writes them: [group][A | B | C][cin]
-        for (int i = tid; i < ngroups * d.cin; i += 256) {
+        for (int i = tid; i < ngroups * d.cin; i += (PC ? 512 : 256)) {
             const int gi = i / d.cin, ch = i - gi * d.cin;
             cf_scale[i] = pro_scale[(gi * 3 + 0) * d.cin + ch]; cf_shift[i] = pro_scale[(gi * 3 + 1) * d.cin + ch]; cf_c[i] = pro_scale[(gi * 3 + 2) * d.cin + ch];
         }
         __syncthreads();
     } else if (d.pro_affine) {      // behind the first tile's loads, in front of their use
-        for (int i = tid; i < ngroups * d.cin; i += 256) { cf_scale[i] = pro_scale[i]; cf_shift[i] = pro_shift[i]; }
+        for (int i = tid; i < ngroups * d.cin; i += (PC ? 512 : 256)) { cf_scale[i] = pro_scale[i]; cf_shift[i] = pro_shift[i]; }
         __syncthreads();
     }
-    if (total_it > 0) {
-        xs.store(xt, d, 0, cf_scale, cf_shift, (cur.n / group_n) * d.cin, cf_c, rxout, xout_on);
-        wstore();
+    if constexpr (!PC) {
+        if (total_it > 0) {
+            xs.store(xt, d, 0, cf_scale, cf_shift, (cur.n / group_n) * d.cin, cf_c, rxout, xout_on);
+            wstore();
+        }
+        __syncthreads();
     }
-    __syncthreads();
 
     // X3, one 16-channel chunk (cin == 16) and the smallest tile: the block's weight fragments never change -> read them from LDS ONCE
     // into registers (5 fragments x 3 splits x 4 VGPRs for a 3x3 kernel with one cout tile) instead of once per tile
-    constexpr bool WREG3 = X3 && MT == 1 && (NFRAG * NT * 3 <= 15);      // (larger tiles: 60 registers the operand read-ahead needs more)
+    constexpr bool WREG3 = X3 && !PC && MT == 1 && (NFRAG * NT * 3 <= 15);      // (larger tiles: 60 registers the operand read-ahead needs more)
     const bool wreg_on = WREG3 && G_chunks == 1;
     x3_bf16x8 wreg[WREG3 ? NFRAG : 1][WREG3 ? 3 : 1][WREG3 ? NT : 1];
     if constexpr (WREG3) {
@@ -427,7 +448,8 @@ __global__ __launch_bounds__(256, X3 ? CTL_LB_X3(MT, NT, X2) : (MT * NT >= 8 || 
 
     // Statistics of one BatchNorm group: block-level sum through LDS -> stats_partial[group][block][2][cout].  Called when the
     // walk enters the next group (tiles are visited in increasing order) and once at the end; every wave takes part.
-    const int srows = gridDim.x * gridDim.z, srow = z * gridDim.x + blockIdx.x;       // statistics rows of one group: [sub-problem][block]
+    // (PC: one row per consumer wave, [sub-problem][block][wave]: the wave's own sums go straight to global memory)
+    const int srows = gridDim.x * gridDim.z * (PC ? 4 : 1), srow = (z * gridDim.x + blockIdx.x) * (PC ? 4 : 1) + (PC ? wave : 0);
     auto flush_stats = [&](int grp) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -438,6 +460,20 @@ __global__ __launch_bounds__(256, X3 ? CTL_LB_X3(MT, NT, X2) : (MT * NT >= 8 || 
                 v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
                 a[i] = v;
             }
+            if constexpr (PC) {
+                if (p == 0) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int co = (cot0 + t) * 16 + q * 4 + r;
+                        if (co < d.cout) {
+                            stats_partial[(((int64_t)grp * srows + srow) * 2 + 0) * d.cout + co] = a[r];
+                            stats_partial[(((int64_t)grp * srows + srow) * 2 + 1) * d.cout + co] = a[4 + r];
+                        }
+                    }
+                }
+                ssum[t] = ssq[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                continue;
+            }
             if (p == 0) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -447,6 +483,7 @@ __global__ __launch_bounds__(256, X3 ? CTL_LB_X3(MT, NT, X2) : (MT * NT >= 8 || 
             }
             ssum[t] = ssq[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
+        if constexpr (PC) return;
         __syncthreads();
         if (tid < NT * 16 * 2) {
             const int stat = tid / (NT * 16), cl = tid % (NT * 16);
@@ -459,7 +496,21 @@ __global__ __launch_bounds__(256, X3 ? CTL_LB_X3(MT, NT, X2) : (MT * NT >= 8 || 
         __syncthreads();
     };
     int cur_grp = (my_tiles > 0) ? cur.n / group_n : 0;
-    if ((flags & CTL_EPI_STATS) && ngroups > 1 && tid < NT * 16 * 2) {      // groups this block never visits contribute zeros
+    if constexpr (PC) {      // groups this wave never visits contribute zeros (written by the lanes that flush: program order per address)
+        if ((flags & CTL_EPI_STATS) && ngroups > 1 && consumer && p == 0) {
+            for (int gi = 0; gi < ngroups; ++gi)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int co = (cot0 + t) * 16 + q * 4 + r;
+                        if (co < d.cout) {
+                            stats_partial[(((int64_t)gi * srows + srow) * 2 + 0) * d.cout + co] = 0.f;
+                            stats_partial[(((int64_t)gi * srows + srow) * 2 + 1) * d.cout + co] = 0.f;
+                        }
+                    }
+        }
+    } else if ((flags & CTL_EPI_STATS) && ngroups > 1 && tid < NT * 16 * 2) {      // groups this block never visits contribute zeros
         const int stat = tid / (NT * 16), co = cot0 * 16 + tid % (NT * 16);
         if (co < d.cout)
             for (int gi = 0; gi < ngroups; ++gi) stats_partial[(((int64_t)gi * srows + srow) * 2 + stat) * d.cout + co] = 0.f;
@@ -467,6 +518,333 @@ __global__ __launch_bounds__(256, X3 ? CTL_LB_X3(MT, NT, X2) : (MT * NT >= 8 || 
 
     TM(7)
     f32x4 acc[MT][NT];
+#ifndef CTL_X3_ABLATE
+#define CTL_X3_ABLATE 0      // timing ablations of the X3 instantiations (variant builds only, WRONG results): 1 no split arithmetic, 2 no global
+#endif                       // loads in the loop, 4 no matrix phase, 8 no epilogue (profiles/r4_x3_ablation.txt)
+
+    // ---------------- X3 matrix phase of one (tile, chunk) step out of the LDS images at xb (input planes) / wb (weight fragments)
+    // Six MFMAs per (fragment, M-tile, cout tile): hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi (ctl_conv_x3_stage.h).  A step is one
+    // fragment of MS M-tiles; the three split operands of the next step are requested before this step's MFMAs (the empty asm
+    // pins that order: the scheduler otherwise sinks every read to its use -- read, wait, MFMA, see ctl_conv_bf16.hip)
+    auto mfma_phase3 = [&](auto wreg_tag, const unsigned char* xb, const unsigned char* wb) {
+        constexpr bool WR = decltype(wreg_tag)::value;
+#ifndef CTL_X3_MS
+#define CTL_X3_MS(MT, NT, X2) ((CTL_LB_X3(MT, NT, X2) == 3 || (MT) < 2) ? 1 : 2)
+#endif
+        constexpr int MS = PC ? (MT >= 2 ? 2 : 1) : CTL_X3_MS(MT, NT, X2);       // M-tiles per operand step: their MFMA chains interleave
+        constexpr int NSTEP = NFRAG * (MT / MS);
+        x3_bf16x8 xf[2][MS][3], wf[2][WR ? 1 : 3][WR ? 1 : NT];
+        auto xread = [&](int st, int b) {
+            const int f = st / (MT / MS), m0 = (st % (MT / MS)) * MS;
+#pragma unroll
+            for (int mi = 0; mi < MS; ++mi)
+#pragma unroll
+                for (int sp = 0; sp < 3; ++sp)
+                    xf[b][mi][sp] = *reinterpret_cast<const x3_bf16x8*>(xb + xoff3[f] + ((((m0 + mi) / TWT) * S) * G::IWP + ((m0 + mi) % TWT) * 16) * 16 + 2 * sp * XS3::PLANE);
+        };
+        auto wread = [&](int f, int b) {
+            if constexpr (!WR) {
+#pragma unroll
+                for (int sp = 0; sp < 3; ++sp)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) wf[b][sp][t] = *reinterpret_cast<const x3_bf16x8*>(wb + ((f * NT + t) * 3 + sp) * 1024);
+            }
+        };
+        xread(0, 0);
+        wread(0, 0);
+#pragma unroll
+        for (int st = 0; st < NSTEP; ++st) {
+            const int f = st / (MT / MS), m0 = (st % (MT / MS)) * MS, b = st & 1;
+            if (st + 1 < NSTEP) {
+                xread(st + 1, b ^ 1);
+                if ((st + 1) % (MT / MS) == 0) wread(f + 1, (f + 1) & 1);
+            }
+#pragma unroll
+            for (int mi = 0; mi < MS; ++mi) asm volatile("" : "+v"(xf[b][mi][0]), "+v"(xf[b][mi][1]), "+v"(xf[b][mi][2]) : : "memory");
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                x3_bf16x8 ah, am, al;
+                if constexpr (WR) { ah = wreg[WREG3 ? f : 0][0][WREG3 ? t : 0]; am = wreg[WREG3 ? f : 0][WREG3 ? 1 : 0][WREG3 ? t : 0]; al = wreg[WREG3 ? f : 0][WREG3 ? 2 : 0][WREG3 ? t : 0]; }
+                else { ah = wf[f & 1][0][t]; am = wf[f & 1][WR ? 0 : 1][t]; al = wf[f & 1][WR ? 0 : 2][t]; }
+                // (small terms first; the chains of the step's M-tiles alternate)
+#define CTL_X3_MFMA(A, SP) _Pragma("unroll") for (int mi = 0; mi < MS; ++mi) \
+                    acc[m0 + mi][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, xf[b][mi][SP], acc[m0 + mi][t], 0, 0, 0);
+                CTL_X3_MFMA(al, 0)
+                CTL_X3_MFMA(ah, 2)
+                CTL_X3_MFMA(am, 1)
+                CTL_X3_MFMA(am, 0)
+                CTL_X3_MFMA(ah, 1)
+                CTL_X3_MFMA(ah, 0)
+#undef CTL_X3_MFMA
+            }
+        }
+    };
+
+    // ---------------- epilogue of one tile: lane (p,q) holds channels co0..co0+3 of pixel p of each M-tile.  Buffer stores with
+    // hardware bounds checks; nothing here is waited for in the loop.  Whole tiles with whole channel tiles (FULL) put
+    // the tile origin into the scalar offset of the loads and skip every mask; ragged ones redirect dropped lanes to
+    // CTL_OOB.  Two halves: epi_load requests the epilogue's operands (residual / accumulate / tail tensors, the group's residual
+    // coefficients), epi_finish consumes them.  The single-role kernels call them back to back (requesting the operands before the
+    // barriers was measured there: the extra live registers cost more than the hidden latency gains); the consumer waves of the PC
+    // form call epi_load BEFORE the step's barrier and matrix phase -- with one block per CU nothing else would cover that round trip.
+    // EPI == 3: CTL_EPI_BNBWD alone, known at compile time (the 3x3 data gradients of the residual blocks): no accumulate
+    // operand, no per-fragment flag tests -- 16 VGPRs less than the generic EPI == 1 form, which matters next to the second
+    // staged tensor of the X2 prologue (168 VGPRs + 120 B of scratch otherwise)
+    constexpr bool BNB = (EPI == 3), HAS_OV = (EPI == 1 || EPI == 2);
+    f32x4 rv[EPI ? MT : 1][EPI ? NT : 1], ov[HAS_OV ? MT : 1][HAS_OV ? NT : 1], r2[TAIL ? MT : 1][TAIL ? NT : 1];
+    f32x4 e_rs[EPI ? NT : 1] = {}, e_rh[EPI ? NT : 1] = {};
+    auto tile_full = [&](int ho0, int wo0) {
+#ifdef CTL_NO_FULL_EPI
+        return false;
+#else
+        return ho0 + G::TH <= d.hout && wo0 + TW <= d.wout && (cot0 + NT) * 16 <= d.cout;
+#endif
+    };
+    auto tile_ybase = [&](int n, int ho0, int wo0) {
+        return (((n * d.out_h + ho0 * d.out_sy + oy0) * d.out_w + wo0 * d.out_sx + ox0) * d.cout + cot0 * 16) * 4;
+    };
+    auto epi_load = [&](auto full_tag, int n, int ho0, int wo0) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        if constexpr (EPI != 0) {
+            const int grp = n / group_n;
+            const int ybase = tile_ybase(n, ho0, wo0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const bool cok = FULL || (cot0 + t) * 16 + q * 4 < d.cout;
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const bool pvm = FULL || ((ho0 + wrow + m / TWT < d.hout) && (wo0 + (m % TWT) * 16 + p < d.wout));
+                    const int vo = FULL ? (yrel[m] + t * 64) : ((pvm && cok) ? (ybase + yrel[m] + t * 64) : CTL_OOB);
+                    const int so = FULL ? ybase : 0;
+                    rv[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if constexpr (HAS_OV) ov[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if constexpr (BNB) {            // (cout is a multiple of 16 here, checked on the host)
+                        rv[m][t] = ctl_bload4s(rres, vo, so);
+                    } else if constexpr (TAIL) {    // (likewise)
+                        rv[m][t] = ctl_bload4s(rres, vo, so);
+                        r2[m][t] = ctl_bload4s(rres2, vo, so);
+                        if (flags & CTL_EPI_ACCUM) ov[m][t] = ctl_bload4s(ry, vo, so);
+                    } else if (d.cout >= 4) {
+                        if (flags & (CTL_EPI_RES | CTL_EPI_BNBWD)) rv[m][t] = ctl_bload4s(rres, vo, so);
+                        if (flags & CTL_EPI_ACCUM) ov[m][t] = ctl_bload4s(ry, vo, so);
+                    } else {
+                        if (flags & (CTL_EPI_RES | CTL_EPI_BNBWD)) rv[m][t].x = ctl_bload1(rres, vo);
+                        if (flags & CTL_EPI_ACCUM) ov[m][t].x = ctl_bload1(ry, vo);
+                    }
+                }
+                const int co0 = (cot0 + t) * 16 + q * 4;
+                const int cc = cok ? co0 : 0;
+                f32x4 rs = {0.f, 0.f, 0.f, 0.f}, rh = {0.f, 0.f, 0.f, 0.f};
+                if (!TAIL && (BNB || (flags & (CTL_EPI_RES | CTL_EPI_BNBWD)))) {
+                    if (d.cout >= 4) {
+                        rs = *reinterpret_cast<const f32x4*>(res_scale + grp * d.cout + cc);
+                        rh = *reinterpret_cast<const f32x4*>(res_shift + grp * d.cout + cc);
+                    } else { rs.x = res_scale[grp]; rh.x = res_shift[grp]; }
+                }
+                e_rs[t] = rs; e_rh[t] = rh;
+            }
+        }
+    };
+    auto epi_finish = [&](auto full_tag, int n, int ho0, int wo0) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        const int ybase = tile_ybase(n, ho0, wo0);
+#ifndef CTL_NO_FAST_EPI
+        if constexpr (!EPI && FULL) {
+            // the common case (whole tile, no residual / accumulate operand, no activation): the stores read the accumulator
+            // registers directly and the statistics sit behind a real branch.  Written as its own path because the generic
+            // code below funnels every variant through one set of store registers (4 v_mov per fragment) and turns the
+            // statistics flag into 8 v_cndmask per tile -- VALU issue slots taken from the matrix pipe.
+            if (d.epi_act == CTL_ACT_NONE) {
+                if (flags & CTL_EPI_STATS) {
+                    asm volatile("" ::: "memory");                  // keeps the branch (not a select)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int m = 0; m < MT; ++m) { ssum[t] += acc[m][t]; ssq[t] += acc[m][t] * acc[m][t]; }
+                }
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) ctl_bstore4(ry, ybase + yrel[m] + t * 64, acc[m][t]);
+                return;
+            }
+        }
+#endif
+        bool pv[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+            pv[m] = FULL || ((ho0 + wrow + m / TWT < d.hout) && (wo0 + (m % TWT) * 16 + p < d.wout));
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int co0 = (cot0 + t) * 16 + q * 4;
+            const bool cok = FULL || co0 < d.cout;
+            const f32x4 rs = e_rs[EPI ? t : 0], rh = e_rh[EPI ? t : 0];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                f32x4 v = acc[m][t];
+                if constexpr (TAIL) {
+                    v += ov[m][t];                                   // (CTL_EPI_ACCUM: the other half of dOut, already in y)
+                    const f32x4 o = rv[m][t];
+                    const float sl = d.epi_slope;
+                    v.x *= o.x > 0.f ? 1.f : sl; v.y *= o.y > 0.f ? 1.f : sl;
+                    v.z *= o.z > 0.f ? 1.f : sl; v.w *= o.w > 0.f ? 1.f : sl;
+                    if (FULL || pv[m]) { ssum[t] += v; ssq[t] += v * r2[m][t]; }
+                    if (FULL) ctl_bstore4(ry, ybase + yrel[m] + t * 64, v);
+                    else ctl_bstore4(ry, (pv[m] && cok) ? (ybase + yrel[m] + t * 64) : CTL_OOB, v);
+                    if constexpr (CAN_POOL) {
+                        if (pool) {
+                            // column pairs sit in neighbouring lanes (p, p ^ 1), the wave's two rows in M-tiles m and m + TWT
+                            f32x4 hs;
+                            hs.x = v.x + __shfl_xor(v.x, 1); hs.y = v.y + __shfl_xor(v.y, 1);
+                            hs.z = v.z + __shfl_xor(v.z, 1); hs.w = v.w + __shfl_xor(v.w, 1);
+                            if (m < TWT) ov[m][t] = hs;              // (the accumulate operand of this fragment is consumed: its registers hold the top row's pair sums)
+                            else {
+                                const f32x4 top = ov[m - TWT][t];
+                                const f32x4 pl = {top.x + hs.x, top.y + hs.y, top.z + hs.z, top.w + hs.w};
+                                // low-resolution pixel ((ho0 + wrow) / 2, (wo0 + (m % TWT) * 16 + p) / 2); written by the even lanes
+                                const int lo = ((((n * (d.out_h >> 1) + ((ho0 + wrow) >> 1)) * (d.out_w >> 1) + ((wo0 + (m % TWT) * 16 + p) >> 1)) * d.cout) + co0) * 4;
+                                ctl_bstore4(rpool, ((p & 1) == 0 && (FULL || (pv[m] && cok))) ? lo : CTL_OOB, pl);
+                            }
+                        }
+                    }
+                    continue;
+                }
+                if (BNB || (EPI == 1 && (flags & CTL_EPI_BNBWD))) {
+                    // this conv produced dL/da of a = leaky(BN(u)): turn it into g = dL/da * leaky'(BN(u)) and take the two
+                    // sums of the BatchNorm backward (sum g, sum g*u) here instead of in a separate pass over da and u
+                    const f32x4 u = rv[m][t], sa = u * rs + rh;
+                    const float sl = d.epi_slope;
+                    v.x *= sa.x > 0.f ? 1.f : sl; v.y *= sa.y > 0.f ? 1.f : sl;
+                    v.z *= sa.z > 0.f ? 1.f : sl; v.w *= sa.w > 0.f ? 1.f : sl;
+                    if (FULL || pv[m]) { ssum[t] += v; ssq[t] += v * u; }
+                } else {
+                    if (EPI) v += rv[m][t] * rs + rh;
+                    if (flags & CTL_EPI_STATS) {
+                        if (FULL) { ssum[t] += v; ssq[t] += v * v; }
+                        else if (pv[m]) { ssum[t] += v; ssq[t] += v * v; }
+                    }
+                }
+                if (d.epi_act == CTL_ACT_LEAKY) {
+                    v = ctl_leaky01(v, d.epi_slope);
+                } else if (d.epi_act == CTL_ACT_SIGMOID) {
+                    v.x = 1.f / (1.f + expf(-v.x)); v.y = 1.f / (1.f + expf(-v.y));
+                    v.z = 1.f / (1.f + expf(-v.z)); v.w = 1.f / (1.f + expf(-v.w));
+                }
+                if constexpr (HAS_OV) v += ov[m][t];
+                if (FULL) {
+                    ctl_bstore4(ry, ybase + yrel[m] + t * 64, v);     // no SGPR soffset on stores, see ctl_bload4s
+                } else {
+                    const int vo = (pv[m] && cok) ? (ybase + yrel[m] + t * 64) : CTL_OOB;
+                    if (d.cout >= 4) ctl_bstore4(ry, vo, v);
+                    else ctl_bstore1(ry, vo, v.x);       // cout == 1: only q == 0 passes `cok`, component x is the channel
+                }
+            }
+        }
+    };
+
+    if constexpr (PC) {
+        // ================================================================ producer / consumer form (see the template's header comment)
+        const bool wdouble = G_chunks > 1;                       // one weight chunk per step -> two weight images; cin == 16: staged once
+        if (!consumer) {
+            // ---------------- producers: CTL_PC_SETS payload sets in flight; step `it` lives in set it % R and goes to image it & 1.
+            // Every load of the steady-state loop is UNCONDITIONAL (steps past the last one load from out-of-range offsets): at a
+            // control-flow join the compiler's wait-count pass keeps the SMALLER number of younger loads, so one conditional load in
+            // the loop body turns every counted wait into a near-drain (seen in the ISA: vmcnt(5) where 17 were in flight)
+            constexpr int R = X2 ? CTL_PC_SETS_X2 : CTL_PC_SETS;      // (two staged tensors: 48 registers per set of an 8x32 tile)
+            typename XS3::Pay P[R];
+            int s_n[R], s_g[R];
+            TileWalk lw = cur;
+            int lg = 0, lit = 0;
+            auto load_step = [&](typename XS3::Pay& pay, int& sn, int& sg) {
+                xs.template load<true>(pay, rx, rx2, d, lw.n, lw.th * G::TH, lw.tw * TW, lg, lit < total_it);
+                sn = lw.n; sg = lg;
+                ++lit;
+                if (++lg == G_chunks) { lg = 0; lw.next(); }
+            };
+            // (issue order of the steady state -- ..., weights of step it + 1, inputs of step it + R -- from the first load on: the wait
+            //  counts at the loop header are the join of the prologue's and the back edge's)
+#pragma unroll
+            for (int r = 0; r < R - 1; ++r) load_step(P[r], s_n[r], s_g[r]);
+            wload(0);
+            load_step(P[R - 1], s_n[R - 1], s_g[R - 1]);
+            auto run = [&](auto wd_tag) {
+                constexpr bool WD = decltype(wd_tag)::value;     // one weight chunk per step -> two weight images (cin == 16: staged once)
+                int wg = 0;                                      // chunk of the weights held in wv[]
+                auto step = [&](int it, typename XS3::Pay& pay, int& sn, int& sg, bool more) {
+                    const int img = it & 1;
+#ifdef CTL_TIMING_X3_VMCNT
+                    asm volatile("s_waitcnt vmcnt(%0)" :: "n"((R - 1) * XS3::NU * (X2 ? 4 : 2)) : "memory");
+                    TM(9)                                        // (timing variant: the wait for this step's loads alone; WD launches over-wait here)
+#endif
+                    xs.template store<true>(pay, xt + img * XT_ALLOC, d, sg, cf_scale, cf_shift, (sn / group_n) * d.cin, cf_c, rxout, xout_on);
+                    if constexpr (WD) wstore(img);
+                    else if (it == 0) wstore(0);
+                    TM(3)
+                    if (more) {      // (the next step's weights FIRST: loads return in order, so whatever is issued behind them
+                        if constexpr (WD) { wg = (wg + 1 == G_chunks) ? 0 : wg + 1; wload(wg); }      // may still be in flight at their use)
+                        load_step(pay, sn, sg);
+                    }
+                    TM(0)
+                    ctl_barrier_lds_writes_done();               // image `img` is complete (and every consumer has left step it - 1's image)
+                    TM(4)
+                };
+                const int full = (total_it / R) * R;
+                for (int it0 = 0; it0 < full; it0 += R) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) step(it0 + r, P[r], s_n[r], s_g[r], true);
+                }
+#pragma unroll
+                for (int r = 0; r < R - 1; ++r)
+                    if (full + r < total_it) {
+                        step(full + r, P[r], s_n[r], s_g[r], false);
+                        if constexpr (WD) { if (full + r + 1 < total_it) { wg = (wg + 1 == G_chunks) ? 0 : wg + 1; wload(wg); } }
+                    }
+            };
+            if (wdouble) run(std::true_type{}); else run(std::false_type{});
+            TM_FLUSH
+            return;
+        }
+        // ---------------- consumers: the critical path.  Raised priority: the vector instructions of the epilogue (and the operand
+        // addresses of the matrix phase) otherwise queue behind the producer wave of the same SIMD, the OLDER wave, whose staging is one
+        // long vector stream (phase timers before: epilogue 900 cycles per tile for 16 packed adds / fmas and four stores)
+#ifndef CTL_PC_PRIO
+#define CTL_PC_PRIO 2
+#endif
+        __builtin_amdgcn_s_setprio(CTL_PC_PRIO);
+        TileWalk cw = cur;
+        int g = 0;
+        for (int it = 0; it < total_it; ++it) {
+            const int n = cw.n, ho0 = cw.th * G::TH, wo0 = cw.tw * TW;
+            const bool last = (g == G_chunks - 1);
+            const bool full = tile_full(ho0, wo0);
+            if (last) {
+                const int grp = n / group_n;
+                if ((flags & CTL_EPI_STATS) && grp != cur_grp) { flush_stats(cur_grp); cur_grp = grp; }
+                if (full) epi_load(std::true_type{}, n, ho0, wo0); else epi_load(std::false_type{}, n, ho0, wo0);
+            }
+            TM(7)
+            ctl_barrier_lds_reads_done();                        // step `it`'s images are written; this wave's reads of step it - 1 were consumed
+            TM(2)
+            TM_COUNT(6)
+            if (g == 0) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[m][t] = bias4[t];
+            }
+            const int img = it & 1;
+            mfma_phase3(std::false_type{}, xt8 + img * (XT_ALLOC * 4), wrd8 + (wdouble ? img : 0) * (WT_FLOATS * 4));
+            TM(1)
+            if (last) {
+                if (full) epi_finish(std::true_type{}, n, ho0, wo0); else epi_finish(std::false_type{}, n, ho0, wo0);
+            }
+            TM(5)
+            if (++g == G_chunks) { g = 0; cw.next(); }
+        }
+        if (flags & CTL_EPI_STATS) flush_stats(cur_grp);
+        TM_FLUSH
+        return;
+    } else {
     for (int it = 0, g = 0; it < total_it; ++it) {
         TM_COUNT(6)
         const int n = cur.n, ho0 = cur.th * G::TH, wo0 = cur.tw * TW;
@@ -474,9 +852,6 @@ __global__ __launch_bounds__(256, X3 ? CTL_LB_X3(MT, NT, X2) : (MT * NT >= 8 || 
         const int g2 = (g + 1 == G_chunks) ? 0 : g + 1;
         const bool new_w = has_next && G_chunks > 1;
         if (g2 == 0) nxt.next();
-#ifndef CTL_X3_ABLATE
-#define CTL_X3_ABLATE 0      // timing ablations of the X3 instantiations (variant builds only, WRONG results): 1 no split arithmetic, 2 no global
-#endif                       // loads in the loop, 4 no matrix phase, 8 no epilogue (profiles/r4_x3_ablation.txt)
         if (has_next && !(X3 && (CTL_X3_ABLATE & 2))) {
             xs.load(rx, rx2, d, nxt.n, nxt.th * G::TH, nxt.tw * TW, g2);
             if (new_w) wload(g2);
@@ -490,67 +865,11 @@ __global__ __launch_bounds__(256, X3 ? CTL_LB_X3(MT, NT, X2) : (MT * NT >= 8 || 
         }
         if constexpr (X3 && (CTL_X3_ABLATE & 4)) {
         } else if constexpr (X3) {
-            // Six MFMAs per (fragment, M-tile, cout tile): hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi (ctl_conv_x3_stage.h).  A step is one
-            // fragment of MS M-tiles; the three split operands of the next step are requested before this step's MFMAs (the empty asm
-            // pins that order: the scheduler otherwise sinks every read to its use -- read, wait, MFMA, see ctl_conv_bf16.hip)
-            auto mfma_phase3 = [&](auto wreg_tag) {
-                constexpr bool WR = decltype(wreg_tag)::value;
-#ifndef CTL_X3_MS
-#define CTL_X3_MS(MT, NT, X2) ((CTL_LB_X3(MT, NT, X2) == 3 || (MT) < 2) ? 1 : 2)
-#endif
-                constexpr int MS = CTL_X3_MS(MT, NT, X2);                  // M-tiles per operand step: their MFMA chains interleave
-                constexpr int NSTEP = NFRAG * (MT / MS);
-                x3_bf16x8 xf[2][MS][3], wf[2][WR ? 1 : 3][WR ? 1 : NT];
-                auto xread = [&](int st, int b) {
-                    const int f = st / (MT / MS), m0 = (st % (MT / MS)) * MS;
-#pragma unroll
-                    for (int mi = 0; mi < MS; ++mi)
-#pragma unroll
-                        for (int sp = 0; sp < 3; ++sp)
-                            xf[b][mi][sp] = *reinterpret_cast<const x3_bf16x8*>(xt8 + xoff3[f] + ((((m0 + mi) / TWT) * S) * G::IWP + ((m0 + mi) % TWT) * 16) * 16 + 2 * sp * XS3::PLANE);
-                };
-                auto wread = [&](int f, int b) {
-                    if constexpr (!WR) {
-#pragma unroll
-                        for (int sp = 0; sp < 3; ++sp)
-#pragma unroll
-                            for (int t = 0; t < NT; ++t) wf[b][sp][t] = *reinterpret_cast<const x3_bf16x8*>(wrd8 + ((f * NT + t) * 3 + sp) * 1024);
-                    }
-                };
-                xread(0, 0);
-                wread(0, 0);
-#pragma unroll
-                for (int st = 0; st < NSTEP; ++st) {
-                    const int f = st / (MT / MS), m0 = (st % (MT / MS)) * MS, b = st & 1;
-                    if (st + 1 < NSTEP) {
-                        xread(st + 1, b ^ 1);
-                        if ((st + 1) % (MT / MS) == 0) wread(f + 1, (f + 1) & 1);
-                    }
-#pragma unroll
-                    for (int mi = 0; mi < MS; ++mi) asm volatile("" : "+v"(xf[b][mi][0]), "+v"(xf[b][mi][1]), "+v"(xf[b][mi][2]) : : "memory");
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) {
-                        x3_bf16x8 ah, am, al;
-                        if constexpr (WR) { ah = wreg[WREG3 ? f : 0][0][WREG3 ? t : 0]; am = wreg[WREG3 ? f : 0][WREG3 ? 1 : 0][WREG3 ? t : 0]; al = wreg[WREG3 ? f : 0][WREG3 ? 2 : 0][WREG3 ? t : 0]; }
-                        else { ah = wf[f & 1][0][t]; am = wf[f & 1][WR ? 0 : 1][t]; al = wf[f & 1][WR ? 0 : 2][t]; }
-                        // (small terms first; the chains of the step's M-tiles alternate)
-#define CTL_X3_MFMA(A, SP) _Pragma("unroll") for (int mi = 0; mi < MS; ++mi) \
-                            acc[m0 + mi][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, xf[b][mi][SP], acc[m0 + mi][t], 0, 0, 0);
-                        CTL_X3_MFMA(al, 0)
-                        CTL_X3_MFMA(ah, 2)
-                        CTL_X3_MFMA(am, 1)
-                        CTL_X3_MFMA(am, 0)
-                        CTL_X3_MFMA(ah, 1)
-                        CTL_X3_MFMA(ah, 0)
-#undef CTL_X3_MFMA
-                    }
-                }
-            };
             if constexpr (WREG3) {
-                if (wreg_on) mfma_phase3(std::true_type{});
-                else mfma_phase3(std::false_type{});
+                if (wreg_on) mfma_phase3(std::true_type{}, xt8, wrd8);
+                else mfma_phase3(std::false_type{}, xt8, wrd8);
             } else {
-                mfma_phase3(std::false_type{});
+                mfma_phase3(std::false_type{}, xt8, wrd8);
             }
         } else
         {   // operands of tap+1 are requested before the MFMAs of tap.  The machine scheduler sinks the reads back to their uses
@@ -608,161 +927,18 @@ __global__ __launch_bounds__(256, X3 ? CTL_LB_X3(MT, NT, X2) : (MT * NT >= 8 || 
         TM(4)
 
         if (g == G_chunks - 1 && !(X3 && (CTL_X3_ABLATE & 8))) {
-            // ---------------- epilogue: lane (p,q) holds channels co0..co0+3 of pixel p of each M-tile.  Buffer stores with
-            // hardware bounds checks; nothing here is waited for in the loop.  Whole tiles with whole channel tiles (FULL) put
-            // the tile origin into the scalar offset of the loads and skip every mask; ragged ones redirect dropped lanes to
-            // CTL_OOB.  (Requesting the residual / accumulate operands before the barriers was measured: the extra live
-            // registers cost more than the hidden latency gains.)
             const int grp = n / group_n;
             if ((flags & CTL_EPI_STATS) && grp != cur_grp) {
                 flush_stats(cur_grp);
                 cur_grp = grp;
             }
-            const int ybase = (((n * d.out_h + ho0 * d.out_sy + oy0) * d.out_w + wo0 * d.out_sx + ox0) * d.cout + cot0 * 16) * 4;
-#ifdef CTL_NO_FULL_EPI
-            const bool full = false;
-#else
-            const bool full = ho0 + G::TH <= d.hout && wo0 + TW <= d.wout && (cot0 + NT) * 16 <= d.cout;
-#endif
-            auto epilogue = [&](auto full_tag) {
-                constexpr bool FULL = decltype(full_tag)::value;
-#ifndef CTL_NO_FAST_EPI
-                if constexpr (!EPI && FULL) {
-                    // the common case (whole tile, no residual / accumulate operand, no activation): the stores read the accumulator
-                    // registers directly and the statistics sit behind a real branch.  Written as its own path because the generic
-                    // code below funnels every variant through one set of store registers (4 v_mov per fragment) and turns the
-                    // statistics flag into 8 v_cndmask per tile -- VALU issue slots taken from the matrix pipe.
-                    if (d.epi_act == CTL_ACT_NONE) {
-                        if (flags & CTL_EPI_STATS) {
-                            asm volatile("" ::: "memory");                  // keeps the branch (not a select)
-#pragma unroll
-                            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                                for (int m = 0; m < MT; ++m) { ssum[t] += acc[m][t]; ssq[t] += acc[m][t] * acc[m][t]; }
-                        }
-#pragma unroll
-                        for (int t = 0; t < NT; ++t)
-#pragma unroll
-                            for (int m = 0; m < MT; ++m) ctl_bstore4(ry, ybase + yrel[m] + t * 64, acc[m][t]);
-                        return;
-                    }
-                }
-#endif
-                bool pv[MT];
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-                    pv[m] = FULL || ((ho0 + wrow + m / TWT < d.hout) && (wo0 + (m % TWT) * 16 + p < d.wout));
-                // EPI == 3: CTL_EPI_BNBWD alone, known at compile time (the 3x3 data gradients of the residual blocks): no accumulate
-                // operand, no per-fragment flag tests -- 16 VGPRs less than the generic EPI == 1 form, which matters next to the second
-                // staged tensor of the X2 prologue (168 VGPRs + 120 B of scratch otherwise)
-                constexpr bool BNB = (EPI == 3), HAS_OV = (EPI == 1 || EPI == 2);
-                f32x4 rv[EPI ? MT : 1][EPI ? NT : 1], ov[HAS_OV ? MT : 1][HAS_OV ? NT : 1], r2[TAIL ? MT : 1][TAIL ? NT : 1];
-                if (EPI) {
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) {
-                        const bool cok = FULL || (cot0 + t) * 16 + q * 4 < d.cout;
-#pragma unroll
-                        for (int m = 0; m < MT; ++m) {
-                            const int vo = FULL ? (yrel[m] + t * 64) : ((pv[m] && cok) ? (ybase + yrel[m] + t * 64) : CTL_OOB);
-                            const int so = FULL ? ybase : 0;
-                            rv[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                            if constexpr (HAS_OV) ov[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                            if constexpr (BNB) {            // (cout is a multiple of 16 here, checked on the host)
-                                rv[m][t] = ctl_bload4s(rres, vo, so);
-                            } else if constexpr (TAIL) {    // (likewise)
-                                rv[m][t] = ctl_bload4s(rres, vo, so);
-                                r2[m][t] = ctl_bload4s(rres2, vo, so);
-                                if (flags & CTL_EPI_ACCUM) ov[m][t] = ctl_bload4s(ry, vo, so);
-                            } else if (d.cout >= 4) {
-                                if (flags & (CTL_EPI_RES | CTL_EPI_BNBWD)) rv[m][t] = ctl_bload4s(rres, vo, so);
-                                if (flags & CTL_EPI_ACCUM) ov[m][t] = ctl_bload4s(ry, vo, so);
-                            } else {
-                                if (flags & (CTL_EPI_RES | CTL_EPI_BNBWD)) rv[m][t].x = ctl_bload1(rres, vo);
-                                if (flags & CTL_EPI_ACCUM) ov[m][t].x = ctl_bload1(ry, vo);
-                            }
-                        }
-                    }
-                }
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const int co0 = (cot0 + t) * 16 + q * 4;
-                    const bool cok = FULL || co0 < d.cout;
-                    const int cc = cok ? co0 : 0;
-                    f32x4 rs = {0.f, 0.f, 0.f, 0.f}, rh = {0.f, 0.f, 0.f, 0.f};
-                    if (EPI && !TAIL && (BNB || (flags & (CTL_EPI_RES | CTL_EPI_BNBWD)))) {
-                        if (d.cout >= 4) {
-                            rs = *reinterpret_cast<const f32x4*>(res_scale + grp * d.cout + cc);
-                            rh = *reinterpret_cast<const f32x4*>(res_shift + grp * d.cout + cc);
-                        } else { rs.x = res_scale[grp]; rh.x = res_shift[grp]; }
-                    }
-#pragma unroll
-                    for (int m = 0; m < MT; ++m) {
-                        f32x4 v = acc[m][t];
-                        if constexpr (TAIL) {
-                            v += ov[m][t];                                   // (CTL_EPI_ACCUM: the other half of dOut, already in y)
-                            const f32x4 o = rv[m][t];
-                            const float sl = d.epi_slope;
-                            v.x *= o.x > 0.f ? 1.f : sl; v.y *= o.y > 0.f ? 1.f : sl;
-                            v.z *= o.z > 0.f ? 1.f : sl; v.w *= o.w > 0.f ? 1.f : sl;
-                            if (FULL || pv[m]) { ssum[t] += v; ssq[t] += v * r2[m][t]; }
-                            if (FULL) ctl_bstore4(ry, ybase + yrel[m] + t * 64, v);
-                            else ctl_bstore4(ry, (pv[m] && cok) ? (ybase + yrel[m] + t * 64) : CTL_OOB, v);
-                            if constexpr (CAN_POOL) {
-                                if (pool) {
-                                    // column pairs sit in neighbouring lanes (p, p ^ 1), the wave's two rows in M-tiles m and m + TWT
-                                    f32x4 hs;
-                                    hs.x = v.x + __shfl_xor(v.x, 1); hs.y = v.y + __shfl_xor(v.y, 1);
-                                    hs.z = v.z + __shfl_xor(v.z, 1); hs.w = v.w + __shfl_xor(v.w, 1);
-                                    if (m < TWT) ov[m][t] = hs;              // (the accumulate operand of this fragment is consumed: its registers hold the top row's pair sums)
-                                    else {
-                                        const f32x4 top = ov[m - TWT][t];
-                                        const f32x4 pl = {top.x + hs.x, top.y + hs.y, top.z + hs.z, top.w + hs.w};
-                                        // low-resolution pixel ((ho0 + wrow) / 2, (wo0 + (m % TWT) * 16 + p) / 2); written by the even lanes
-                                        const int lo = ((((n * (d.out_h >> 1) + ((ho0 + wrow) >> 1)) * (d.out_w >> 1) + ((wo0 + (m % TWT) * 16 + p) >> 1)) * d.cout) + co0) * 4;
-                                        ctl_bstore4(rpool, ((p & 1) == 0 && (FULL || (pv[m] && cok))) ? lo : CTL_OOB, pl);
-                                    }
-                                }
-                            }
-                            continue;
-                        }
-                        if (BNB || (EPI == 1 && (flags & CTL_EPI_BNBWD))) {
-                            // this conv produced dL/da of a = leaky(BN(u)): turn it into g = dL/da * leaky'(BN(u)) and take the two
-                            // sums of the BatchNorm backward (sum g, sum g*u) here instead of in a separate pass over da and u
-                            const f32x4 u = rv[m][t], sa = u * rs + rh;
-                            const float sl = d.epi_slope;
-                            v.x *= sa.x > 0.f ? 1.f : sl; v.y *= sa.y > 0.f ? 1.f : sl;
-                            v.z *= sa.z > 0.f ? 1.f : sl; v.w *= sa.w > 0.f ? 1.f : sl;
-                            if (FULL || pv[m]) { ssum[t] += v; ssq[t] += v * u; }
-                        } else {
-                            if (EPI) v += rv[m][t] * rs + rh;
-                            if (flags & CTL_EPI_STATS) {
-                                if (FULL) { ssum[t] += v; ssq[t] += v * v; }
-                                else if (pv[m]) { ssum[t] += v; ssq[t] += v * v; }
-                            }
-                        }
-                        if (d.epi_act == CTL_ACT_LEAKY) {
-                            v = ctl_leaky01(v, d.epi_slope);
-                        } else if (d.epi_act == CTL_ACT_SIGMOID) {
-                            v.x = 1.f / (1.f + expf(-v.x)); v.y = 1.f / (1.f + expf(-v.y));
-                            v.z = 1.f / (1.f + expf(-v.z)); v.w = 1.f / (1.f + expf(-v.w));
-                        }
-                        if constexpr (HAS_OV) v += ov[m][t];
-                        if (FULL) {
-                            ctl_bstore4(ry, ybase + yrel[m] + t * 64, v);     // no SGPR soffset on stores, see ctl_bload4s
-                        } else {
-                            const int vo = (pv[m] && cok) ? (ybase + yrel[m] + t * 64) : CTL_OOB;
-                            if (d.cout >= 4) ctl_bstore4(ry, vo, v);
-                            else ctl_bstore1(ry, vo, v.x);       // cout == 1: only q == 0 passes `cok`, component x is the channel
-                        }
-                    }
-                }
-            };
-            if (full) epilogue(std::true_type{});
-            else epilogue(std::false_type{});
+            if (tile_full(ho0, wo0)) { epi_load(std::true_type{}, n, ho0, wo0); epi_finish(std::true_type{}, n, ho0, wo0); }
+            else { epi_load(std::false_type{}, n, ho0, wo0); epi_finish(std::false_type{}, n, ho0, wo0); }
         }
         TM(5)
         if (g2 == 0) cur = nxt;
         g = g2;
+    }
     }
 #ifndef CTL_TIMING_WGRAD
 #ifdef CTL_TIMING_DOMINANT_ONLY

@@ -19,7 +19,7 @@ __device__ unsigned long long ctl_tm3[CTL_TM_WAVES][10];
 #else
 #define CTL_TM3_REAL tm_acc[9] = __builtin_amdgcn_s_memrealtime() - tm_r0;
 #endif
-#define TM_FLUSH { const unsigned w_ = ((blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 4 + (threadIdx.x >> 6)) % CTL_TM_WAVES; \
+#define TM_FLUSH { const unsigned w_ = ((blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8 + (threadIdx.x >> 6)) % CTL_TM_WAVES; \
                    tm_acc[8] = __builtin_amdgcn_s_memtime() - tm_t0; CTL_TM3_REAL \
                    if ((threadIdx.x & 63) == 0) { _Pragma("unroll") for (int i_ = 0; i_ < 10; ++i_) ctl_tm3[w_][i_] += tm_acc[i_]; } }
 extern "C" int ctl_debug_timing_x3(unsigned long long* out12) {
@@ -120,13 +120,51 @@ struct conv3_call {
     hipStream_t stream;
     bool query;
     int grid_x;
+    int stat_rows_per_block;      // 4 for the producer / consumer form (one statistics row per consumer wave)
 };
 
+// The producer / consumer form (ctl_conv_igemm.h, PC): one 512-thread block per CU.  Taken when a block gets at least CTL_X3_PC_MIN_STEPS
+// (tile, chunk) steps: its pipeline costs one exposed load + staging at the head of a block.
+#ifndef CTL_X3_PC_DEFAULT
+#define CTL_X3_PC_DEFAULT 1
+#endif
+#ifndef CTL_X3_PC_MIN_STEPS
+#define CTL_X3_PC_MIN_STEPS 4
+#endif
+// (which launches: the 3x3 stride-1 convs and data gradients on plain inputs -- 4.9 of the 8.6 ms this family takes per step; the other
+//  kernel shapes keep the single-role form until they are instantiated here)
+static bool conv3_pc_shape_ok(const ctl_conv* d) {
+    const int f = d->epi_flags & (CTL_EPI_RES | CTL_EPI_ACCUM | CTL_EPI_BNBWD | CTL_EPI_TAILBWD);
+    const bool epi_ok = f == 0 || (f == CTL_EPI_BNBWD && d->cout % 16 == 0 && d->epi_act == CTL_ACT_NONE);
+    return d->ks == 3 && d->stride == 1 && d->in_mode == CTL_IN_PLAIN && d->nsub == 1 && epi_ok;
+}
+template <int KS, int S, int MODE, int MT, int TW, int NT, int EPI, bool X2>
+constexpr bool conv3_pc_ok() { return S == 1 && KS == 3 && MODE == CTL_IN_PLAIN && (EPI == 0 || EPI == 3); }
+template <int KS, int S, int MODE, int MT, int TW, int NT, int EPI, bool X2>
+static bool conv3_go_pc(conv3_call& a) {
+    if constexpr (conv3_pc_ok<KS, S, MODE, MT, TW, NT, EPI, X2>()) {
+        if (!a.c.pc) return false;
+        const ctl_conv* d = a.d;
+        const int ntiles = d->n * a.c.tiles_h * a.c.tiles_w;
+        const int grid_x = ctl_conv_grid_x(ntiles, (a.c.cot / NT) * d->nsub, 1);
+        a.grid_x = grid_x;
+        a.stat_rows_per_block = 4;
+        if (a.query) return true;
+        const dim3 grid((unsigned)grid_x, (unsigned)(a.c.cot / NT), (unsigned)d->nsub);
+        conv_igemm_kernel<KS, S, MODE, MT, TW, NT, EPI, X2, true, true><<<grid, dim3(512), 0, a.stream>>>(
+            *d, a.x, a.wpack, a.bias, a.pro_scale, a.pro_shift, a.res, a.res_scale, a.res_shift, a.y, a.stats_partial, a.c.tiles_h,
+            a.c.tiles_w, a.c.g, (int64_t)ctl_conv_wpack_floats_x3(d->cin, d->cout, d->ks), ntiles, a.res2, a.x2, a.pool, a.xout);
+        return true;
+    }
+    return false;
+}
 template <int KS, int S, int MODE, int MT, int TW, int NT, int EPI, bool X2 = false>
 static void conv3_go(conv3_call& a) {
     if constexpr (!X2 && ((KS == 3 && S == 1 && MODE == CTL_IN_PLAIN) || (KS == 4 && S == 2)) && EPI != 2) {
         if (a.d->pro_affine == 2) { conv3_go<KS, S, MODE, MT, TW, NT, EPI, true>(a); return; }
     }
+    a.stat_rows_per_block = 1;
+    if (conv3_go_pc<KS, S, MODE, MT, TW, NT, EPI, X2>(a)) return;
     static int occ = 0;
     if (!occ) {
         int n = 0;
@@ -192,6 +230,29 @@ static int conv3_dispatch(conv3_call& a) {
 static int conv3_pick_cfg(const ctl_conv* d, ctl_conv_cfg* c) {
     const int rc = ctl_conv_pick_cfg(d, c, 0);
     if (rc != CTL_OK) return rc;
+    // Producer / consumer form: ONE block per CU, so the tile is the largest one that still gives every CU a block (fewer halo bytes and
+    // fewer barriers per MFMA), and a block must get CTL_X3_PC_MIN_STEPS (tile, chunk) steps to pay for its pipeline's head.
+    static const int pc_on = ctl_tune_int("CTL_X3_PC", CTL_X3_PC_DEFAULT), min_steps = ctl_tune_int("CTL_X3_PC_MIN_STEPS", CTL_X3_PC_MIN_STEPS);
+    // (measured per layer, profiles/r5_pc_conv_layers.txt: 128 -> 128 @32^2 31.3 vs 35.9 us, @16^2 14.5 vs 17.7, 64 -> 64 @64^2 n32 59.4 vs 70.0;
+    //  16 -> 16 @256^2 43.8 vs 38.7, 32 -> 16 @128^2 24.3 vs 22.7: with few channels the staging's vector instructions and the matrix
+    //  instructions of ONE wave pair per SIMD do not fill the issue port as well as three single-role waves do -> cin >= 64 only)
+    static const int pc_min_g = ctl_tune_int("CTL_X3_PC_MIN_G", 4);
+    if (pc_on && conv3_pc_shape_ok(d) && c->g >= pc_min_g && c->nt == 2) {
+        static const int tiles[3][2] = {{4, 32}, {2, 16}, {1, 16}};
+        const int other = (c->cot / c->nt) * d->nsub;
+        for (int i = 0; i < 3; ++i) {
+            const int mt = tiles[i][0], tw = tiles[i][1], th = 4 * mt * 16 / tw;
+            if (tw == 32 && d->wout < 32) continue;
+            const int64_t ntiles = (int64_t)d->n * ctl_cdiv(d->hout, th) * ctl_cdiv(d->wout, tw);
+            if (ntiles * other < 256 && i < 2) continue;                  // (a smaller tile fills more CUs)
+            const int grid_x = ctl_conv_grid_x((int)ntiles, other, 1);
+            if (ntiles * c->g >= (int64_t)min_steps * grid_x) {
+                c->pc = 1; c->mt = mt; c->tw = tw; c->th = th;
+                c->tiles_h = ctl_cdiv(d->hout, th); c->tiles_w = ctl_cdiv(d->wout, tw);
+            }
+            break;
+        }
+    }
     // (the fp32 family's tile choice is kept for stride 1: forcing the 8x32-pixel tile wherever it gives 512 blocks is 7-9 % faster per launch on the
     //  n = 32 layers alone -- tools/bench_conv.py, CTL_BENCH_X3=1 -- and worth nothing in the step: 15.69 vs 15.65 ms same-box)
     if (d->stride == 2 && d->ks >= 3) {
@@ -215,7 +276,7 @@ int ctl_conv_x3_stats_blocks(const ctl_conv* d) {
     if (!ctl_conv_x3_ok(d) || conv3_pick_cfg(d, &a.c) != CTL_OK) return -1;
     a.query = true;
     if (conv3_dispatch(a) != CTL_OK) return -1;
-    return a.grid_x * d->nsub;
+    return a.grid_x * d->nsub * a.stat_rows_per_block;
 }
 // (argument checks: ctl_conv_forward_ex, which hands over here when ctl_conv.dt has CTL_DT_X3)
 int ctl_conv_forward_x3(const ctl_conv* d, const float* x, const float* wpack, const float* bias, const float* pro_scale, const float* pro_shift,
@@ -231,7 +292,11 @@ int ctl_conv_forward_x3(const ctl_conv* d, const float* x, const float* wpack, c
     a.x = x; a.wpack = wpack; a.bias = bias; a.pro_scale = pro_scale; a.pro_shift = pro_shift; a.res = res; a.res_scale = res_scale;
     a.res_shift = res_shift; a.res2 = res2; a.x2 = x2; a.y = y; a.stats_partial = stats_partial; a.pool = pool; a.xout = xout;
     a.stream = (hipStream_t)stream;
-    const int ptok = ctl_prof_begin("conv_igemm_x3", d, &a.c, a.c.nt, a.stream);
+    a.query = true;                  // (which form will run: the producer / consumer launches carry their own profiling id)
+    rc = conv3_dispatch(a);
+    if (rc != CTL_OK) return rc;
+    a.query = false;
+    const int ptok = ctl_prof_begin(a.stat_rows_per_block == 4 ? "conv_igemm_x3pc" : "conv_igemm_x3", d, &a.c, a.c.nt, a.stream);
     rc = conv3_dispatch(a);
     if (ptok >= 0) ctl_prof_end(ptok, a.stream);
     if (rc != CTL_OK) return rc;

@@ -58,9 +58,20 @@ __device__ __forceinline__ float x3_sub_part(float x, unsigned p) {
     else asm("s_mov_b32 %0, 0xbf800000" : "=s"(sel));
     return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(x3_bf16x2, p), __builtin_bit_cast(x3_bf16x2, sel), x, false);
 }
+#ifndef CTL_X3_SPLIT_MODE
+#define CTL_X3_SPLIT_MODE 0      // 0: v_dot2c form (7 instructions per pair); 1: plain fp32 instructions only (11 per pair: shifts / masks / v_sub_f32 --
+#endif                           // no packed or dot instruction, which the matrix pipe's neighbours pay for); 2: timing ablation, WRONG results (no split)
+__device__ __forceinline__ float x3_opaque(float v) { asm volatile("" : "+v"(v)); return v; }      // (keeps the SLP vectoriser from re-packing the scalar form)
 __device__ __forceinline__ void x3_split2(x3_f32x2 e, unsigned& h, unsigned& m, unsigned& l) {
     h = x3_pack2(e.x, e.y);
-#if CTL_X3_DOT2_SPLIT
+#if CTL_X3_SPLIT_MODE == 2
+    m = h; l = h;
+#elif CTL_X3_SPLIT_MODE == 1
+    const float r0 = x3_opaque(e.x - __builtin_bit_cast(float, h << 16)), r1 = x3_opaque(e.y - __builtin_bit_cast(float, h & 0xffff0000u));      // exact
+    m = x3_pack2(r0, r1);
+    const float l0 = x3_opaque(r0 - __builtin_bit_cast(float, m << 16)), l1 = x3_opaque(r1 - __builtin_bit_cast(float, m & 0xffff0000u));        // exact, representable
+    l = x3_pack2(l0, l1);
+#elif CTL_X3_DOT2_SPLIT
     const float r0 = x3_sub_part<0>(e.x, h), r1 = x3_sub_part<1>(e.y, h);      // exact
     m = x3_pack2(r0, r1);
     l = x3_pack2(x3_sub_part<0>(r0, m), x3_sub_part<1>(r1, m));                 // exact, and exactly representable
@@ -145,7 +156,14 @@ struct XStage3 {
     __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rx, __amdgpu_buffer_rsrc_t rx2, const ctl_conv& d, int n, int ho0, int wo0, int g) {
         load(pay, rx, rx2, d, n, ho0, wo0, g);
     }
-    __device__ __forceinline__ void load(Pay& P, __amdgpu_buffer_rsrc_t rx, __amdgpu_buffer_rsrc_t rx2, const ctl_conv& d, int n, int ho0, int wo0, int g) {
+    // `live` = false: a step past the block's last one -- the same number of loads, every offset out of range (zeros come back, nothing is
+    // fetched): the producer loops issue their loads unconditionally, so that the compiler's wait counts are those of the steady state
+    // ONEPATH: no interior-tile shortcut -- one straight-line sequence of loads with per-unit offsets (a dozen vector instructions per
+    // unit, which the producer waves have to spare): the two-path form leaves a load-free edge in the structurised control flow, and at a
+    // join the wait-count pass then assumes that none of the step's loads is in flight behind the older ones
+    template <bool ONEPATH = false>
+    __device__ __forceinline__ void load(Pay& P, __amdgpu_buffer_rsrc_t rx, __amdgpu_buffer_rsrc_t rx2, const ctl_conv& d, int n, int ho0, int wo0, int g,
+                                         bool live = true) {
         const int vh0 = ho0 * S - pad_h, vw0 = wo0 * S - pad_w;
         const unsigned hv = PLAIN ? d.hin : 2 * d.hin;
         const unsigned wv = PLAIN ? d.win : 2 * d.win;
@@ -153,8 +171,8 @@ struct XStage3 {
         const int ow = PLAIN ? vw0 : ((wo0 >> 1) - PADH);
         const int tb = (((n * d.hin + oh) * d.win + ow) * d.cin + g * 16) * 4;
         P.tb_last = tb;
-        P.all_in = MODE != CTL_IN_ZINS2 && vh0 >= 0 && vw0 >= 0 && vh0 + G::IH <= (int)hv && vw0 + G::IW <= (int)wv;
-        if (P.all_in) {       // interior tile: the origin rides in the scalar offset, the per-thread offsets are loop-invariant
+        P.all_in = !ONEPATH && live && MODE != CTL_IN_ZINS2 && vh0 >= 0 && vw0 >= 0 && vh0 + G::IH <= (int)hv && vw0 + G::IW <= (int)wv;
+        if (!ONEPATH && P.all_in) {       // interior tile: the origin rides in the scalar offset, the per-thread offsets are loop-invariant
 #pragma unroll
             for (int i = 0; i < NU; ++i) { P.v0[i] = ctl_bload4s(rx, rel[i], tb); P.v1[i] = ctl_bload4s(rx, rel[i] + 16, tb); }
             if constexpr (X2) {
@@ -168,7 +186,7 @@ struct XStage3 {
 #pragma unroll
         for (int i = 0; i < NU; ++i) {
             const int vh = vh0 + (rc[i] & 0xffff), vw = vw0 + (rc[i] >> 16);
-            bool ok = (unsigned)vh < hv && (unsigned)vw < wv;
+            bool ok = live && (unsigned)vh < hv && (unsigned)vw < wv;
             if (MODE == CTL_IN_ZINS2) ok = ok && (((vh | vw) & 1) == 0);
             vo[i] = ok ? (tb + rel[i]) : CTL_OOB;
             m |= ok ? (1u << i) : 0u;
@@ -187,6 +205,9 @@ struct XStage3 {
                                           int goff, const float* pro_c, __amdgpu_buffer_rsrc_t rxout, bool xout_on) {
         store(pay, xtf, d, g, pro_scale, pro_shift, goff, pro_c, rxout, xout_on);
     }
+    // SEQ: one unit after the other (a scheduling barrier behind each unit's LDS writes): the producer waves keep several payload sets
+    // alive, and interleaving the units' prologue / split chains on top of that costs more registers than a wave has
+    template <bool SEQ = false>
     __device__ __forceinline__ void store(const Pay& P, float* __restrict__ xtf, const ctl_conv& d, int g, const float* pro_scale, const float* pro_shift,
                                           int goff, const float* pro_c, __amdgpu_buffer_rsrc_t rxout, bool xout_on) {
         unsigned char* xt = reinterpret_cast<unsigned char*>(xtf);
@@ -225,6 +246,7 @@ struct XStage3 {
             *reinterpret_cast<u32x4*>(xt + lds[i]) = ph;
             *reinterpret_cast<u32x4*>(xt + lds[i] + SPLIT) = pm;
             *reinterpret_cast<u32x4*>(xt + lds[i] + 2 * SPLIT) = pl;
+            if constexpr (SEQ) __builtin_amdgcn_sched_barrier(0);
         }
     }
 };

@@ -97,7 +97,8 @@ def test_staged_split_is_exact_identity_conv_returns_its_input_bit_for_bit():
 
 CASES = [(2, 16, 16, 32, 32), (16, 16, 16, 64, 64), (4, 16, 16, 128, 128), (2, 32, 64, 16, 16), (2, 128, 128, 8, 8), (2, 64, 32, 24, 20),
          (1, 32, 32, 6, 6), (2, 128, 64, 3, 3), (2, 32, 32, 48, 48), (1, 64, 48, 40, 72), (2, 128, 32, 36, 52), (3, 48, 16, 70, 70), (2, 16, 16, 9, 7),
-         (2, 16, 4, 40, 40), (4, 16, 4, 128, 128), (2, 32, 8, 17, 23), (2, 16, 12, 16, 16)]      # cout 4 / 8 / 12: one padded cout tile (the STN's first-layer data gradient)
+         (2, 16, 4, 40, 40), (4, 16, 4, 128, 128), (2, 32, 8, 17, 23), (2, 16, 12, 16, 16),      # cout 4 / 8 / 12: one padded cout tile (the STN's first-layer data gradient)
+         (8, 128, 128, 32, 32), (4, 64, 64, 64, 64), (8, 128, 64, 20, 28), (16, 128, 128, 16, 16)]  # round 5: sizes at which the producer / consumer form is picked
 
 
 @pytest.mark.parametrize("n,cin,cout,h,w", CASES)
@@ -240,7 +241,11 @@ WGRAD_CASES = [  # n, cin, cout, h, w, ks, stride, up
     (2, 16, 16, 32, 32, 3, 1, False), (16, 16, 16, 64, 64, 3, 1, False), (2, 32, 64, 16, 16, 3, 1, False), (2, 128, 128, 8, 8, 3, 1, False),
     (2, 64, 32, 24, 20, 3, 1, False), (3, 48, 16, 70, 70, 3, 1, False), (2, 16, 16, 9, 7, 3, 1, False), (2, 128, 64, 3, 3, 3, 1, False),
     (2, 32, 16, 16, 16, 3, 1, True), (2, 128, 64, 8, 8, 3, 1, True), (2, 16, 32, 32, 32, 3, 2, False), (2, 64, 128, 14, 18, 3, 2, False),
-    (2, 32, 32, 16, 16, 2, 2, False), (4, 16, 16, 128, 128, 3, 1, False)]
+    (2, 32, 32, 16, 16, 2, 2, False), (4, 16, 16, 128, 128, 3, 1, False),
+    # round 5: sizes at which the producer / consumer kernel is picked (32 x 32 blocks on v_mfma_f32_32x32x16_bf16: >= 4 tiles per block),
+    # plain and behind a nearest up-sampling, with ragged tiles
+    (8, 128, 128, 32, 32, 3, 1, False), (8, 64, 64, 48, 64, 3, 1, False), (4, 32, 32, 100, 120, 3, 1, False), (8, 128, 64, 16, 16, 3, 1, True),
+    (6, 64, 96, 36, 52, 3, 1, False)]
 
 
 @pytest.mark.parametrize("n,cin,cout,h,w,ks,stride,up", WGRAD_CASES)
@@ -273,7 +278,8 @@ def test_weight_gradient(n, cin, cout, h, w, ks, stride, up):
     errs(out[1][1], out[0][1], b.grad, "bias gradient")
 
 
-@pytest.mark.parametrize("n,cin,cout,h,w,groups", [(2, 16, 16, 32, 32, 1), (4, 32, 64, 24, 40, 2), (16, 16, 16, 128, 128, 1), (2, 64, 32, 9, 7, 1), (2, 128, 128, 16, 16, 1)])
+@pytest.mark.parametrize("n,cin,cout,h,w,groups", [(2, 16, 16, 32, 32, 1), (4, 32, 64, 24, 40, 2), (16, 16, 16, 128, 128, 1), (2, 64, 32, 9, 7, 1), (2, 128, 128, 16, 16, 1),
+                                                   (8, 64, 64, 48, 64, 1), (8, 128, 128, 32, 32, 2), (4, 32, 64, 100, 120, 2)])      # (round 5: producer / consumer sizes)
 def test_weight_gradient_with_virtual_output_gradient(n, cin, cout, h, w, groups):
     """ctl_conv_wgrad_ex: the output gradient is the virtual BatchNorm-backward result A*g + B*u + C (fp32 arithmetic in the staging, then the split)."""
     g = torch.Generator().manual_seed(cin + cout + h + groups)
