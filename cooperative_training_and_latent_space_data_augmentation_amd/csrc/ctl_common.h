@@ -134,6 +134,8 @@ struct ctl_conv_cfg {
 };
 int ctl_conv_pick_cfg(const ctl_conv* d, ctl_conv_cfg* c, int for_wgrad);
 int ctl_conv_grid_x(int ntiles, int other, int occ);      // persistent grid: the resident capacity (ctl_conv.hip)
+// CUs a launch may count on: 256 on MI355X.  (tuning builds: CTL_NUM_CUS, for experiments with CU-masked streams -- tools/cumask_probe.py)
+static inline int ctl_num_cus() { static const int n = ctl_tune_int("CTL_NUM_CUS", 256); return n; }
 
 // bf16 kernel family (ctl_conv_bf16.hip), reached through the public entry points when ctl_conv.dt has CTL_DT_BF16
 int ctl_conv_forward_bf16(const ctl_conv* d, const void* x, const void* x2, const void* wpack, const float* bias, const float* pro_scale,

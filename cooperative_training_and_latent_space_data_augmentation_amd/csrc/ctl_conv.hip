@@ -902,7 +902,7 @@ int ctl_conv_grid_x(int ntiles, int other, int occ) {
         if (per_cu < 1) per_cu = 1;
     }
     const int resident = occ < per_cu ? occ : per_cu;
-    int cap = (256 * resident) / other;
+    int cap = (ctl_num_cus() * resident) / other;
     if (other > 1 && cap >= 8) cap -= cap % 8;
     if (cap < 1) cap = 1;
     return ntiles < cap ? ntiles : cap;
@@ -1133,7 +1133,7 @@ static void wgrad_go(wgrad_call& a) {
     // 17.43-17.59 ms); without them two blocks give 16.80 -> 16.72 ms, four 16.79: tuning hook CTL_WGRAD_NARROW_PERSIST)
     static const int narrow_cu = ctl_tune_int("CTL_WGRAD_NARROW_PERSIST", 2);
     const int cu_blocks = (KS == 1 || MODE == CTL_IN_C4) ? narrow_cu : per_cu;
-    int splits = (slots > 0 ? slots : 256 * (occ < cu_blocks ? occ : cu_blocks)) / par;
+    int splits = (slots > 0 ? slots : ctl_num_cus() * (occ < cu_blocks ? occ : cu_blocks)) / par;
     if (splits > 512) splits = 512;
     if (splits > w.ntiles) splits = w.ntiles;
     if (splits < 1) splits = 1;

@@ -244,7 +244,7 @@ static int conv3_pick_cfg(const ctl_conv* d, ctl_conv_cfg* c) {
             const int mt = tiles[i][0], tw = tiles[i][1], th = 4 * mt * 16 / tw;
             if (tw == 32 && d->wout < 32) continue;
             const int64_t ntiles = (int64_t)d->n * ctl_cdiv(d->hout, th) * ctl_cdiv(d->wout, tw);
-            if (ntiles * other < 256 && i < 2) continue;                  // (a smaller tile fills more CUs)
+            if (ntiles * other < ctl_num_cus() && i < 2) continue;       // (a smaller tile fills more CUs)
             const int grid_x = ctl_conv_grid_x((int)ntiles, other, 1);
             if (ntiles * c->g >= (int64_t)min_steps * grid_x) {
                 c->pc = 1; c->mt = mt; c->tw = tw; c->th = th;

@@ -90,6 +90,13 @@ __device__ __forceinline__ void x3_split8(f32x4 a, f32x4 b, u32x4& ph, u32x4& pm
     x3_split2(x3_f32x2{b.z, b.w}, h[3], m[3], l[3]);
     ph = u32x4{h[0], h[1], h[2], h[3]}; pm = u32x4{m[0], m[1], m[2], m[3]}; pl = u32x4{l[0], l[1], l[2], l[3]};
 }
+// v where `on`, +0 elsewhere, branch-free and NaN-safe (a bit mask, not a multiplication by 0 / 1: a dead tile of the software-pipelined
+// kernels reads coefficient rows past its table, and 0 * garbage may be NaN)
+__device__ __forceinline__ f32x4 x3_keep4(f32x4 v, bool on) {
+    const unsigned m = on ? 0xffffffffu : 0u;
+    return f32x4{__builtin_bit_cast(float, __builtin_bit_cast(unsigned, v.x) & m), __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v.y) & m),
+                 __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v.z) & m), __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v.w) & m)};
+}
 // scalar form (weight packing): split s of v
 __device__ __forceinline__ float x3_part(float v, int s) {
     auto rne = [](float f) { return __builtin_bit_cast(float, x3_pack2(f, 0.f) << 16); };
@@ -207,14 +214,17 @@ struct XStage3 {
     }
     // SEQ: one unit after the other (a scheduling barrier behind each unit's LDS writes): the producer waves keep several payload sets
     // alive, and interleaving the units' prologue / split chains on top of that costs more registers than a wave has
-    template <bool SEQ = false>
+    // PROK: the prologue known at compile time (0 none, 1 BatchNorm + LeakyReLU; -1: ctl_conv.pro_affine decides at run time) -- the
+    // software-pipelined kernels need the staging branch-free (one basic block per tile for the instruction scheduler)
+    template <bool SEQ = false, int PROK = -1>
     __device__ __forceinline__ void store(const Pay& P, float* __restrict__ xtf, const ctl_conv& d, int g, const float* pro_scale, const float* pro_shift,
                                           int goff, const float* pro_c, __amdgpu_buffer_rsrc_t rxout, bool xout_on) {
+        const bool pro_on = PROK < 0 ? (d.pro_affine != 0) : (PROK != 0);
         unsigned char* xt = reinterpret_cast<unsigned char*>(xtf);
         const int cb = g * 16 + (PLANAR ? ((threadIdx.x >> 3) & 1) : (threadIdx.x & 1)) * 8;
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
         f32x4 a0 = {1.f, 1.f, 1.f, 1.f}, a1 = a0, b0 = zero, b1 = zero, c0 = zero, c1 = zero;
-        if (X2 || d.pro_affine) {
+        if (X2 || pro_on) {
             a0 = *reinterpret_cast<const f32x4*>(pro_scale + goff + cb); a1 = *reinterpret_cast<const f32x4*>(pro_scale + goff + cb + 4);
             b0 = *reinterpret_cast<const f32x4*>(pro_shift + goff + cb); b1 = *reinterpret_cast<const f32x4*>(pro_shift + goff + cb + 4);
         }
@@ -233,9 +243,14 @@ struct XStage3 {
                     ctl_bstore4(rxout, own ? (P.tb_last + rel[i]) : CTL_OOB, lo);
                     ctl_bstore4(rxout, own ? (P.tb_last + rel[i] + 16) : CTL_OOB, hi);
                 }
-            } else if (d.pro_affine) {      // out-of-range units hold hardware zeros and must stay zero under the affine prologue
-                lo = in ? ctl_leaky01(lo * a0 + b0, slope) : zero;
-                hi = in ? ctl_leaky01(hi * a1 + b1, slope) : zero;
+            } else if (pro_on) {      // out-of-range units hold hardware zeros and must stay zero under the affine prologue
+                if constexpr (PROK >= 0) {      // (branch-free: as a select the compiler wraps the prologue of every unit into an exec-masked block)
+                    lo = x3_keep4(ctl_leaky01(lo * a0 + b0, slope), in);
+                    hi = x3_keep4(ctl_leaky01(hi * a1 + b1, slope), in);
+                } else {
+                    lo = in ? ctl_leaky01(lo * a0 + b0, slope) : zero;
+                    hi = in ? ctl_leaky01(hi * a1 + b1, slope) : zero;
+                }
             }
             u32x4 ph, pm, pl;
 #if defined(CTL_X3_ABLATE) && (CTL_X3_ABLATE & 1)      // (timing ablation, WRONG results: no split arithmetic)
