@@ -9,7 +9,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libctl_hip.so")
-ABI_VERSION = 9                      # CTL_ABI_VERSION of include/ctl_hip.h this binding was written against
+ABI_VERSION = 10                     # CTL_ABI_VERSION of include/ctl_hip.h this binding was written against
 RED_BLOCKS = 512                     # CTL_RED_BLOCKS of ctl_hip.h; checked against the library's compiled value (ctl_red_blocks) at load
 
 # enums of ctl_hip.h
@@ -17,7 +17,9 @@ IN_PLAIN, IN_UP2, IN_ZINS2, IN_C4 = 0, 1, 2, 3
 ACT_NONE, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2
 EPI_BIAS, EPI_ACCUM, EPI_RES, EPI_STATS, EPI_BNBWD, EPI_TAILBWD = 1, 2, 4, 8, 16, 32
 (OP_CONV, OP_WGRAD, OP_WGRAD_REDUCE, OP_PACK, OP_BN_FINALIZE, OP_BN_EVAL, OP_BN_ACT, OP_BWD_REDUCE, OP_BN_BWD_FINALIZE,
- OP_BWD_APPLY, OP_CHAN_SUM_FINALIZE, OP_SUMPOOL2, OP_SIGMOID_BWD, OP_ZERO, OP_COPY, OP_PACK_BATCH, OP_WGRAD_REDUCE_BATCH, OP_DROPOUT2D, OP_BN_REPLAY) = range(1, 20)
+ OP_BWD_APPLY, OP_CHAN_SUM_FINALIZE, OP_SUMPOOL2, OP_SIGMOID_BWD, OP_ZERO, OP_COPY, OP_PACK_BATCH, OP_WGRAD_REDUCE_BATCH, OP_DROPOUT2D, OP_BN_REPLAY,
+ OP_WGRAD_GROUP) = range(1, 21)
+WGRAD_GROUP_MAX = 8                  # members of one grouped weight-gradient launch (CTL_OP_WGRAD_GROUP)
 OP_MAX_T = 14
 
 CONV_DTYPE = np.dtype([
@@ -65,6 +67,7 @@ class _Lib:
             "ctl_pack_weights": [p, p, i32, i32, i32, i64, i64, i64, i64, i32, p],
             "ctl_conv_forward": [p] * 12, "ctl_conv_forward_ex": [p] * 16, "ctl_conv_pool_ok": [p],
             "ctl_conv_wgrad": [p] * 8, "ctl_conv_wgrad_ex": [p] * 10,
+            "ctl_wgrad_group_class": [p, i32], "ctl_wgrad_group_plan": [p, i32, p], "ctl_conv_wgrad_group": [i32] + [p] * 11,
             "ctl_wgrad_reduce": [p, p, p, p, i64, i64, i64, i64, p, i32, p],
             "ctl_confusion_hist": [p, p, i64, i32, p, p],
             "ctl_rescale_intensity": [p, p, p, i32, i64, f32, f32, f32, p],
@@ -146,7 +149,8 @@ EXPORTED = ["ctl_version", "ctl_last_error", "ctl_conv_wpack_floats", "ctl_conv_
             "ctl_noise_clamp", "ctl_crop_or_pad", "ctl_step_tick", "ctl_spin", "ctl_dropout2d_ex", "ctl_dropout2d_dt", "ctl_uniform_dev", "ctl_adam_dev",
             "ctl_latent_mask_fused_ws_floats", "ctl_latent_mask_fused", "ctl_accumulate", "ctl_pack_weights_bf16_batched",
             "ctl_bn_act_dt", "ctl_bwd_reduce_dt", "ctl_bwd_apply_dt", "ctl_sumpool2_dt", "ctl_bwd_reduce_rows", "ctl_red_blocks",
-            "ctl_launch_count", "ctl_conv_wpack_floats_x3", "ctl_pack_weights_x3_batched"]
+            "ctl_launch_count", "ctl_conv_wpack_floats_x3", "ctl_pack_weights_x3_batched", "ctl_wgrad_group_class", "ctl_wgrad_group_plan",
+            "ctl_conv_wgrad_group"]
 
 
 def prof_start(kernel_filter: str = "", every: int = 1) -> None:

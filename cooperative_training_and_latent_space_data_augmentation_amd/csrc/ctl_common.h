@@ -161,3 +161,4 @@ int ctl_conv_wgrad_x3(const ctl_conv* d, const float* x, const float* pro_scale,
 // in-process profiling (ctl_plan.cpp): returns a token >= 0 if this launch is being timed
 int ctl_prof_begin(const char* kind, const ctl_conv* d, const ctl_conv_cfg* c, int nt, hipStream_t stream, bool dy2 = false);
 void ctl_prof_end(int token, hipStream_t stream);
+int ctl_prof_begin_raw(const char* id, double flops, double bytes, hipStream_t stream);

@@ -100,6 +100,22 @@ int ctl_prof_begin(const char* kind, const ctl_conv* d, const ctl_conv_cfg* c, i
     g_prof.push_back(r);
     return (int)g_prof.size() - 1;
 }
+// a launch that serves several problems (grouped weight gradients): the caller sums the members' algorithmic work
+int ctl_prof_begin_raw(const char* id, double flops, double bytes, hipStream_t stream) {
+    if (!g_prof_on) return -1;
+    if (!g_prof_filter.empty() && std::string(id).find(g_prof_filter) == std::string::npos) return -1;
+    if (g_prof_every > 1 && (g_prof_seen++ % g_prof_every) != 0) return -1;
+    ProfRec r;
+    r.id = id;
+    r.stream = (void*)stream;
+    r.a = prof_event();
+    r.b = prof_event();
+    if (!r.a || !r.b) return -1;
+    r.flops = flops; r.bytes = bytes;
+    (void)hipEventRecord(r.a, stream);
+    g_prof.push_back(r);
+    return (int)g_prof.size() - 1;
+}
 // HBM-bound plan ops (BatchNorm backward passes, bn_act, sum-pool): bracketed with their ALGORITHMIC bytes (every tensor argument once,
 // at its storage width); the other non-conv ops (finalizes, copies) only for the timeline dump of a -DCTL_TUNING build
 static int prof_begin_op(const ctl_op& op, hipStream_t stream) {
@@ -249,6 +265,32 @@ extern "C" int ctl_plan_run(const ctl_op* ops, int32_t n_ops, void* const* bases
                 memcpy(&d, op.i, sizeof(d));
                 rc = ctl_conv_wgrad_ex(&d, CF(0), CF(1), CF(2), CF(3), CF(6), CF(7), F(4), F(5), stream);
                 break;
+            case CTL_OP_WGRAD_GROUP: {      // i[0] = members: the next i[0] records are WGRAD records (not launched on their own), i[24] of each = its pixel splits
+                const int nm = op.i[0];
+                CTL_REQUIRE(nm >= 1 && nm <= 8 && k + nm < n_ops, "plan_run: op %d WGRAD_GROUP with %d members", k, nm);
+                ctl_conv ds[8];
+                int32_t sp[8];
+                const float *mx[8], *mps[8], *mpb[8], *mdy[8], *mdy2[8], *mco[8];
+                float *mw[8], *mb[8];
+                for (int j = 0; j < nm; ++j) {
+                    const ctl_op& mo = ops[k + 1 + j];
+                    CTL_REQUIRE(mo.kind == CTL_OP_WGRAD, "plan_run: op %d: member %d of a WGRAD_GROUP is not a WGRAD record", k, j);
+                    void* mt[8];
+                    for (int a = 0; a < 8; ++a) {
+                        const int s = mo.slot[a];
+                        if (s < 0) { mt[a] = nullptr; continue; }
+                        CTL_REQUIRE(s < n_bases && bases[s], "plan_run: op %d member %d arg %d uses empty slot %d", k, j, a, s);
+                        mt[a] = (char*)bases[s] + mo.off[a];
+                    }
+                    memcpy(&ds[j], mo.i, sizeof(ctl_conv));
+                    sp[j] = mo.i[24];
+                    mx[j] = (const float*)mt[0]; mps[j] = (const float*)mt[1]; mpb[j] = (const float*)mt[2]; mdy[j] = (const float*)mt[3];
+                    mw[j] = (float*)mt[4]; mb[j] = (float*)mt[5]; mdy2[j] = (const float*)mt[6]; mco[j] = (const float*)mt[7];
+                }
+                rc = ctl_conv_wgrad_group(nm, ds, sp, mx, mps, mpb, mdy, mdy2, mco, mw, mb, stream);
+                k += nm;
+                break;
+            }
             case CTL_OP_WGRAD_REDUCE:
                 memcpy(&d, op.i, sizeof(d));
                 rc = ctl_wgrad_reduce(&d, CF(0), CF(1), F(2), op.l[0], op.l[1], op.l[2], op.l[3], F(3), op.i[24], stream);

@@ -310,11 +310,6 @@ __global__ __launch_bounds__(256, CTL_X3W_LB) void conv_wgrad_x3_kernel(const ct
 #define CTL_X3W_PC_SETS_DY2 2
 #endif
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{}) in order
-template <class F, int... I>
-__device__ __forceinline__ void ctl_static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
-template <int N, class F>
-__device__ __forceinline__ void ctl_static_for(F&& f) { ctl_static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 #ifndef CTL_X3WPC_CPRIO      // wave priorities of the two roles (measured: no effect either way, profiles/r5_wgrad_pc_experiments.txt)
 #define CTL_X3WPC_CPRIO 0
 #endif
@@ -345,12 +340,35 @@ extern "C" int ctl_debug_timing_x3w(unsigned long long* out10) {
 #define TW_COUNT(i)
 #define TW_FLUSH(span)
 #endif
+// A launch serves a GROUP of problems (deferred weight gradients of one backward plan, nets.PlanBuilder.flush_wgrad_groups): the 256 CUs are
+// dealt to the members in proportion to their work, one block = one job = (member, pixel split, 32-cin block, 32-cout block).  Why groups:
+// per launch ~15 us of a 40 us n = 16 layer are fixed (launch, first loads + first staging exposed, reduction tail, partial write) while the
+// steady state is ~3.1 us per 32 x 32 x 128-pixel tile for every kernel form tried (profiles/r5_wgrad_pc_experiments.txt) -- a member of an
+// 8-member group gets an eighth of the CUs, eight times the tiles per block and an eighth of the split-K partials.
+#define CTL_WG_MAX 8
+struct wg_member {
+    ctl_conv d;
+    const float *x, *pro_scale, *pro_shift, *dy, *dy2, *dy_coef;
+    float *w_partial, *b_partial;
+    int tiles_h, tiles_w, ntiles, cin_p, cout_p, splits, job0, pad_;
+};
+struct wg_group { int n, pad_[3]; wg_member m[CTL_WG_MAX]; };
 template <int KS, int S, int MODE, bool DY2>
-__global__ __launch_bounds__(512, 2) void conv_wgrad_x3pc_kernel(const ctl_conv d, const float* __restrict__ x, const float* __restrict__ pro_scale,
-                                                                 const float* __restrict__ pro_shift, const float* __restrict__ dy,
-                                                                 const float* __restrict__ dy2, const float* __restrict__ dy_coef,
-                                                                 float* __restrict__ w_partial, float* __restrict__ b_partial, int tiles_h, int tiles_w,
-                                                                 int ntiles, int cin_p, int cout_p) {
+__global__ __launch_bounds__(512, 2) void conv_wgrad_x3pc_kernel(const wg_group grp_) {
+    int mi = 0;
+#pragma unroll
+    for (int i = 1; i < CTL_WG_MAX; ++i)
+        if (i < grp_.n && (int)blockIdx.x >= grp_.m[i].job0) mi = i;
+    const wg_member& M = grp_.m[mi];
+    const ctl_conv& d = M.d;
+    const float* __restrict__ x = M.x; const float* __restrict__ pro_scale = M.pro_scale; const float* __restrict__ pro_shift = M.pro_shift;
+    const float* __restrict__ dy = M.dy; const float* __restrict__ dy2 = M.dy2; const float* __restrict__ dy_coef = M.dy_coef;
+    float* __restrict__ w_partial = M.w_partial; float* __restrict__ b_partial = M.b_partial;
+    const int tiles_h = M.tiles_h, tiles_w = M.tiles_w, ntiles = M.ntiles, cin_p = M.cin_p, cout_p = M.cout_p;
+    // job -> (pixel split, 32-cin block, 32-cout block) of the member
+    const int job = (int)blockIdx.x - M.job0, job_ns = M.splits;
+    const int job_s = job % job_ns, job_r = job / job_ns;
+    const int gb = job_r % (cin_p / 32), cb = job_r / (cin_p / 32);
     static_assert(S == 1, "stride 1 (the transposed reads take 8 consecutive pixels of a row)");
     constexpr int MT = 2, TW = 16;
     using G = Geom<KS, S, MT, TW>;
@@ -382,10 +400,9 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_x3pc_kernel(const ctl_conv 
     const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool consumer = wave_all >= 4;
     const int wave = wave_all & 3;
-    const int gb = blockIdx.y, cb = blockIdx.z;            // 32-channel blocks of cin / cout
     const int group_n = d.n / (d.groups > 1 ? d.groups : 1);
-    // tiles of this block: blockIdx.x, + gridDim.x, ...
-    const int my_tiles = ((int)blockIdx.x < ntiles) ? (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+    // tiles of this block: job_s, + job_ns, ...
+    const int my_tiles = (job_s < ntiles) ? (ntiles - job_s + job_ns - 1) / job_ns : 0;
 
     if (tid < 256 || true) {                               // coefficient tables (every thread helps; one barrier for all)
         if (d.pro_affine)
@@ -473,7 +490,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_x3pc_kernel(const ctl_conv 
         Set P[R];
         int s_n[R];
         TileWalk lw;
-        lw.init(blockIdx.x, gridDim.x, tiles_h, tiles_w);
+        lw.init(job_s, job_ns, tiles_h, tiles_w);
         int lit = 0;
         auto load_step = [&](Set& st, int& sn) {
             const bool live = lit < my_tiles;
@@ -516,7 +533,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_x3pc_kernel(const ctl_conv 
             float v = 0.f;
             for (int sl = t * 2 + h; sl < 256; sl += 4) v += bsred[sl * 8 + j];
             const int co = cb * 32 + tid;
-            if (co < cout_p) b_partial[(int64_t)blockIdx.x * cout_p + co] = v;
+            if (co < cout_p) b_partial[(int64_t)job_s * cout_p + co] = v;
         }
 #pragma unroll
         for (int t0 = 0; t0 < TAPS; t0 += RT) {
@@ -584,7 +601,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_x3pc_kernel(const ctl_conv 
     // ---------------- the four waves' sums through LDS, RT taps per round; thread -> (register r, lane l) of a tap: ci = 8 (r >> 2) + 4 (l >> 5) + (r & 3)
     float* red = reinterpret_cast<float*>(smem);
     const int ctid = tid - 256;
-    const int64_t split_base = (int64_t)blockIdx.x * TAPS * cin_p * cout_p;
+    const int64_t split_base = (int64_t)job_s * TAPS * cin_p * cout_p;
 #pragma unroll
     for (int t0 = 0; t0 < TAPS; t0 += RT) {
 #pragma unroll
@@ -617,347 +634,6 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_x3pc_kernel(const ctl_conv 
     }
     TW(7)
     TW_FLUSH(true)
-}
-
-// ------------------------------------------------------------------------------------------------ software-pipelined form (round 5)
-// conv_wgrad_x3pipe_kernel: the same 32 cin x 32 cout blocks, images and lane maps as the producer / consumer kernel above, but ONE
-// instruction stream per SIMD (256-thread blocks, one per CU): while a wave's MFMAs of tile t read LDS image t & 1, the SAME wave's
-// staging of tile t + 1 (prologue, split, LDS writes into image (t + 1) & 1) and the loads of tile t + 1 + R are interleaved with them.
-// Why: the phase timers of the producer / consumer kernel (profiles/r5_wgrad_pc_experiments.txt) show that on a SIMD the matrix stream
-// of one wave and the vector stream of ANOTHER wave do not overlap -- their times add (staging alone 3400 cycles per tile, beside the
-// MFMA wave 5800; MFMA phase 2900; tile period 6300), whatever the wave priorities; what the hardware does overlap is an MFMA with the
-// FOLLOWING independent instructions of its own wave (MI355X_MICROARCH.md: <= 5 single-issue instructions hidden per 32-cycle MFMA).
-// The tile body is one basic block (every load unconditional and single-path, prologue choice a template argument); the interleave is
-// requested from the scheduler with sched_group_barrier (1 MFMA : 1-2 LDS : 4-5 VALU : occasional VMEM).  One barrier per tile.
-#ifndef CTL_X3W_PIPE_SETS
-#define CTL_X3W_PIPE_SETS 2
-#endif
-#ifndef CTL_X3W_PIPE_VALU
-#define CTL_X3W_PIPE_VALU 4      // VALU instructions requested behind every MFMA
-#endif
-template <int KS, int S, int MODE, bool DY2, int PROK>
-__global__ __launch_bounds__(256, 1) void conv_wgrad_x3pipe_kernel(const ctl_conv d, const float* __restrict__ x, const float* __restrict__ pro_scale,
-                                                                   const float* __restrict__ pro_shift, const float* __restrict__ dy,
-                                                                   const float* __restrict__ dy2, const float* __restrict__ dy_coef,
-                                                                   float* __restrict__ w_partial, float* __restrict__ b_partial, int tiles_h, int tiles_w,
-                                                                   int ntiles, int cin_p, int cout_p) {
-    static_assert(S == 1, "stride 1");
-    constexpr int MT = 2, TW = 16;
-    using G = Geom<KS, S, MT, TW>;
-    using XS = XStage3<KS, S, MODE, MT, TW, false, false>;
-    constexpr int TAPS = KS * KS;
-    constexpr int XCH = XS::XT_BYTES + 128, DCH = G::TP * 32 + 128;      // chunk strides: 128 B (mod 256) apart, see the producer / consumer kernel
-    constexpr int XBYTES = 2 * XCH, DYI = 2 * DCH, IMG = XBYTES + 3 * DYI;
-    constexpr int TAP_BYTES = 4 * 16 * 64 * 4;
-    constexpr int RT = (2 * IMG) / TAP_BYTES < TAPS ? (2 * IMG) / TAP_BYTES : TAPS;
-    constexpr int COEF = (DY2 ? 5 : 2) * CTL_PRO_MAX * 4;
-    static_assert(2 * IMG + COEF + 256 * 8 * 4 <= 160 * 1024, "LDS budget of one CU");
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * IMG + COEF + 256 * 8 * 4];
-    float* cf_scale = reinterpret_cast<float*>(smem + 2 * IMG);
-    float* cf_shift = cf_scale + CTL_PRO_MAX;
-    float* cd = cf_shift + CTL_PRO_MAX;
-    float* bsred = reinterpret_cast<float*>(smem + 2 * IMG + COEF);
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int gb = blockIdx.y, cb = blockIdx.z;
-    const int group_n = d.n / (d.groups > 1 ? d.groups : 1);
-    const int my_tiles = ((int)blockIdx.x < ntiles) ? (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
-    if (PROK)
-        for (int i = tid; i < (d.groups > 1 ? d.groups : 1) * d.cin; i += 256) { cf_scale[i] = pro_scale[i]; cf_shift[i] = pro_shift[i]; }
-    if constexpr (DY2) {
-        for (int i = tid; i < (d.groups > 1 ? d.groups : 1) * d.cout; i += 256) {
-            const int gi = i / d.cout, ch = i - gi * d.cout;
-            cd[i] = dy_coef[(gi * 3 + 0) * d.cout + ch]; cd[CTL_PRO_MAX + i] = dy_coef[(gi * 3 + 1) * d.cout + ch];
-            cd[2 * CTL_PRO_MAX + i] = dy_coef[(gi * 3 + 2) * d.cout + ch];
-        }
-    }
-    __syncthreads();
-
-    constexpr int R = CTL_X3W_PIPE_SETS;
-    const __amdgpu_buffer_rsrc_t rx = ctl_rsrc(x, (int64_t)d.n * d.hin * d.win * d.cin * 4);
-    const __amdgpu_buffer_rsrc_t rdy = ctl_rsrc(dy, (int64_t)d.n * d.hout * d.wout * d.cout * 4);
-    const __amdgpu_buffer_rsrc_t rdy2 = DY2 ? ctl_rsrc(dy2, (int64_t)d.n * d.hout * d.wout * d.cout * 4) : rdy;
-    const __amdgpu_buffer_rsrc_t rnone = ctl_rsrc((const void*)nullptr, 0);
-    XS xs;
-    xs.init(d);
-    constexpr int DU = G::TP * 4, ND = DU / 256;
-    static_assert(DU % 256 == 0, "dy units");
-    struct DyPay { f32x4 v0[ND], v1[ND], w0[DY2 ? ND : 1], w1[DY2 ? ND : 1]; unsigned mask; };
-    int drel[ND], drc[ND], dlds[ND];
-    const int drest = tid & 3, dt_ = drest >> 1, dh = drest & 1;
-    const int dco = cb * 32 + dt_ * 16 + dh * 8;
-#pragma unroll
-    for (int i = 0; i < ND; ++i) {
-        const int u = tid + i * 256;
-        const int pix = u >> 2;
-        const int pr = pix / TW, pc = pix % TW;
-        drc[i] = pr | (pc << 16);
-        drel[i] = ((pr * d.wout + pc) * d.cout + dco) * 4;
-        dlds[i] = dt_ * DCH + pix * 32 + dh * 16;
-    }
-    f32x4 bs0 = {0.f, 0.f, 0.f, 0.f}, bs1 = bs0;
-    auto dyload = [&](DyPay& P, int n, int ho0, int wo0, bool live) {
-        const int tb = ((n * d.hout + ho0) * d.wout + wo0) * d.cout * 4;
-        unsigned m = 0;
-#pragma unroll
-        for (int i = 0; i < ND; ++i) {
-            const bool ok = live && (unsigned)(ho0 + (drc[i] & 0xffff)) < (unsigned)d.hout && (unsigned)(wo0 + (drc[i] >> 16)) < (unsigned)d.wout;
-            const int vo = ok ? (tb + drel[i]) : CTL_OOB, vo1 = ok ? (tb + drel[i] + 16) : CTL_OOB;
-            P.v0[i] = ctl_bload4(rdy, vo); P.v1[i] = ctl_bload4(rdy, vo1);
-            if constexpr (DY2) { P.w0[i] = ctl_bload4(rdy2, vo); P.w1[i] = ctl_bload4(rdy2, vo1); }
-            m |= ok ? (1u << i) : 0u;
-        }
-        P.mask = m;
-    };
-    auto dystore = [&](const DyPay& P, unsigned char* dyt, int goff) {
-        f32x4 a0, a1, b0, b1, c0, c1;
-        if constexpr (DY2) {
-            const float* cc = cd + goff + dco;
-            a0 = *reinterpret_cast<const f32x4*>(cc); a1 = *reinterpret_cast<const f32x4*>(cc + 4);
-            b0 = *reinterpret_cast<const f32x4*>(cc + CTL_PRO_MAX); b1 = *reinterpret_cast<const f32x4*>(cc + CTL_PRO_MAX + 4);
-            c0 = *reinterpret_cast<const f32x4*>(cc + 2 * CTL_PRO_MAX); c1 = *reinterpret_cast<const f32x4*>(cc + 2 * CTL_PRO_MAX + 4);
-        }
-        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < ND; ++i) {
-            f32x4 lo = P.v0[i], hi = P.v1[i];
-            if constexpr (DY2) {      // (branch-free form of `in ? ... : 0`: the tile body is one basic block)
-                const bool in = (P.mask >> i) & 1u;
-                lo = x3_keep4(a0 * lo + b0 * P.w0[i] + c0, in);
-                hi = x3_keep4(a1 * hi + b1 * P.w1[i] + c1, in);
-            }
-            bs0 += lo; bs1 += hi;
-            u32x4 ph, pm, pl;
-            x3_split8(lo, hi, ph, pm, pl);
-            *reinterpret_cast<u32x4*>(dyt + dlds[i]) = ph;
-            *reinterpret_cast<u32x4*>(dyt + dlds[i] + DYI) = pm;
-            *reinterpret_cast<u32x4*>(dyt + dlds[i] + 2 * DYI) = pl;
-        }
-    };
-    struct Set { typename XS::Pay xa, xb; DyPay dyp; };
-    Set P[R];
-    int s_n[R];
-    TileWalk lw;
-    lw.init(blockIdx.x, gridDim.x, tiles_h, tiles_w);
-    int lit = 0;
-    auto load_step = [&](Set& st, int& sn) {
-        const bool live = lit < my_tiles;
-        xs.template load<true>(st.xa, rx, rx, d, lw.n, lw.th * G::TH, lw.tw * TW, 2 * gb, live);
-        xs.template load<true>(st.xb, rx, rx, d, lw.n, lw.th * G::TH, lw.tw * TW, 2 * gb + 1, live);
-        dyload(st.dyp, lw.n, lw.th * G::TH, lw.tw * TW, live);
-        sn = lw.n;
-        ++lit;
-        lw.next();
-    };
-    auto stage = [&](int it, Set& st, int sn) {                  // tile `it` -> image it & 1
-        unsigned char* img = smem + (it & 1) * IMG;
-        const int grp = sn / group_n;
-        xs.template store<false, PROK>(st.xa, reinterpret_cast<float*>(img), d, 2 * gb, cf_scale, cf_shift, grp * d.cin, nullptr, rnone, false);
-        xs.template store<false, PROK>(st.xb, reinterpret_cast<float*>(img + XCH), d, 2 * gb + 1, cf_scale, cf_shift, grp * d.cin, nullptr, rnone, false);
-        dystore(st.dyp, img + XBYTES, grp * d.cout);
-    };
-    f32x16 acc[TAPS];
-#pragma unroll
-    for (int a = 0; a < TAPS; ++a)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
-    const int q = lane >> 4, chunk = q & 1, phalf = q >> 1;
-    const int qp = (lane & 15) >> 2, pp = lane & 3;
-    const int a_off = chunk * XCH + (8 * phalf + qp) * 32 + pp * 8;
-    const int b_off = XBYTES + chunk * DCH + (8 * phalf + qp) * 32 + pp * 8;
-    // ---- the staging of one tile cut into PIECES (a dozen instructions each) that the tile body places behind pairs of MFMAs.  Units of
-    // the tile being staged: x chunk a (XS::NU units), x chunk b, dy (ND units); per unit: begin (prologue / virtual gradient), four
-    // pair splits, the three LDS writes, and the reload of the unit's registers with the tile R tiles on (its buffer loads).
-    constexpr int NUX = XS::NU, NUNITS = 2 * NUX + ND, PPU = 7, NPIECES = NUNITS * PPU + 1;
-    static_assert(NPIECES <= TAPS * 6, "one piece behind every pair of MFMAs");
-    f32x4 ulo, uhi;
-    unsigned uh[4], um[4], ul[4];
-    // scalars of the tile that is being LOADED (tile lit): set once per body by `next_tile`
-    int l_n = 0, l_tbx = 0, l_tbd = 0, l_vh0 = 0, l_vw0 = 0, l_ho0 = 0, l_wo0 = 0;
-    bool l_live = false;
-    constexpr bool PLAIN = (MODE == CTL_IN_PLAIN);
-    const unsigned hv = PLAIN ? d.hin : 2 * d.hin, wv = PLAIN ? d.win : 2 * d.win;
-    auto next_tile = [&]() {
-        l_live = lit < my_tiles;
-        l_n = lw.n; l_ho0 = lw.th * G::TH; l_wo0 = lw.tw * TW;
-        l_vh0 = l_ho0 * S - xs.pad_h; l_vw0 = l_wo0 * S - xs.pad_w;
-        const int oh = PLAIN ? l_vh0 : ((l_ho0 >> 1) - XS::PADH), ow = PLAIN ? l_vw0 : ((l_wo0 >> 1) - XS::PADH);
-        l_tbx = (((l_n * d.hin + oh) * d.win + ow) * d.cin + 2 * gb * 16) * 4;
-        l_tbd = ((l_n * d.hout + l_ho0) * d.wout + l_wo0) * d.cout * 4;
-        ++lit;
-        lw.next();
-    };
-    auto x_begin = [&](const typename XS::Pay& pay, int i, int chunk, int grp) {
-        f32x4 lo = pay.v0[i], hi = pay.v1[i];
-        if constexpr (PROK != 0) {
-            const float* ps = cf_scale + grp * d.cin + (2 * gb + chunk) * 16 + (tid & 1) * 8;
-            const float* pb = cf_shift + grp * d.cin + (2 * gb + chunk) * 16 + (tid & 1) * 8;
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(ps), a1 = *reinterpret_cast<const f32x4*>(ps + 4);
-            const f32x4 b0 = *reinterpret_cast<const f32x4*>(pb), b1 = *reinterpret_cast<const f32x4*>(pb + 4);
-            const bool in = (pay.vmask >> i) & 1u;      // (padding stays zero under the affine prologue; branch-free)
-            lo = x3_keep4(ctl_leaky01(lo * a0 + b0, d.pro_slope), in);
-            hi = x3_keep4(ctl_leaky01(hi * a1 + b1, d.pro_slope), in);
-        }
-        ulo = lo; uhi = hi;
-    };
-    auto d_begin = [&](const DyPay& P, int i, int grp) {
-        f32x4 lo = P.v0[i], hi = P.v1[i];
-        if constexpr (DY2) {
-            const float* cc = cd + grp * d.cout + dco;
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(cc), a1 = *reinterpret_cast<const f32x4*>(cc + 4);
-            const f32x4 b0 = *reinterpret_cast<const f32x4*>(cc + CTL_PRO_MAX), b1 = *reinterpret_cast<const f32x4*>(cc + CTL_PRO_MAX + 4);
-            const f32x4 c0 = *reinterpret_cast<const f32x4*>(cc + 2 * CTL_PRO_MAX), c1 = *reinterpret_cast<const f32x4*>(cc + 2 * CTL_PRO_MAX + 4);
-            const bool in = (P.mask >> i) & 1u;
-            lo = x3_keep4(a0 * lo + b0 * P.w0[i] + c0, in);
-            hi = x3_keep4(a1 * hi + b1 * P.w1[i] + c1, in);
-        }
-        bs0 += lo; bs1 += hi;
-        ulo = lo; uhi = hi;
-    };
-    auto u_pair = [&](int pr) {
-        const x3_f32x2 e = pr == 0 ? x3_f32x2{ulo.x, ulo.y} : pr == 1 ? x3_f32x2{ulo.z, ulo.w} : pr == 2 ? x3_f32x2{uhi.x, uhi.y} : x3_f32x2{uhi.z, uhi.w};
-        x3_split2(e, uh[pr], um[pr], ul[pr]);
-    };
-    auto u_write = [&](unsigned char* base, int split_stride) {
-        *reinterpret_cast<u32x4*>(base) = u32x4{uh[0], uh[1], uh[2], uh[3]};
-        *reinterpret_cast<u32x4*>(base + split_stride) = u32x4{um[0], um[1], um[2], um[3]};
-        *reinterpret_cast<u32x4*>(base + 2 * split_stride) = u32x4{ul[0], ul[1], ul[2], ul[3]};
-    };
-    auto x_reload = [&](typename XS::Pay& pay, int i, int chunk) {
-        const int vh = l_vh0 + (xs.rc[i] & 0xffff), vw = l_vw0 + (xs.rc[i] >> 16);
-        const bool ok = l_live && (unsigned)vh < hv && (unsigned)vw < wv;
-        const int vo = ok ? (l_tbx + chunk * 64 + xs.rel[i]) : CTL_OOB, vo1 = ok ? (l_tbx + chunk * 64 + xs.rel[i] + 16) : CTL_OOB;
-        pay.v0[i] = ctl_bload4(rx, vo); pay.v1[i] = ctl_bload4(rx, vo1);
-        pay.vmask = (pay.vmask & ~(1u << i)) | (ok ? (1u << i) : 0u);
-    };
-    auto d_reload = [&](DyPay& P, int i) {
-        const bool ok = l_live && (unsigned)(l_ho0 + (drc[i] & 0xffff)) < (unsigned)d.hout && (unsigned)(l_wo0 + (drc[i] >> 16)) < (unsigned)d.wout;
-        const int vo = ok ? (l_tbd + drel[i]) : CTL_OOB, vo1 = ok ? (l_tbd + drel[i] + 16) : CTL_OOB;
-        P.v0[i] = ctl_bload4(rdy, vo); P.v1[i] = ctl_bload4(rdy, vo1);
-        if constexpr (DY2) { P.w0[i] = ctl_bload4(rdy2, vo); P.w1[i] = ctl_bload4(rdy2, vo1); }
-        P.mask = (P.mask & ~(1u << i)) | (ok ? (1u << i) : 0u);
-    };
-    // piece K of the tile body: stages tile (it + 1) from set `st` into image `img`, reloads the set with tile lit
-    auto piece = [&](auto ktag, Set& st, int sn, unsigned char* img) {
-        constexpr int K = decltype(ktag)::value;
-        if constexpr (K == 0) {
-            next_tile();
-        } else if constexpr (K - 1 < NUNITS * PPU) {
-            constexpr int U = (K - 1) / PPU, M = (K - 1) % PPU;
-            const int grp = sn / group_n;
-            if constexpr (U < 2 * NUX) {
-                constexpr int CH = U / NUX, I = U % NUX;
-                typename XS::Pay& pay = CH ? st.xb : st.xa;
-                if constexpr (M == 0) x_begin(pay, I, CH, grp);
-                else if constexpr (M <= 4) u_pair(M - 1);
-                else if constexpr (M == 5) u_write(img + CH * XCH + xs.lds[I], XS::SPLIT);
-                else x_reload(pay, I, CH);
-            } else {
-                constexpr int I = U - 2 * NUX;
-                if constexpr (M == 0) d_begin(st.dyp, I, grp);
-                else if constexpr (M <= 4) u_pair(M - 1);
-                else if constexpr (M == 5) u_write(img + XBYTES + dlds[I], DYI);
-                else d_reload(st.dyp, I);
-            }
-        }
-    };
-    // ---- head: R tiles of loads in flight, tile 0 staged
-#pragma unroll
-    for (int r = 0; r < R; ++r) load_step(P[r], s_n[r]);
-    stage(0, P[0], s_n[0]);
-    load_step(P[0], s_n[0]);                                     // set 0 now holds tile R
-    ctl_barrier_lds_writes_done();
-    // ---- tile body: the MFMAs of tile `it` (this wave's two tile rows, all taps) with the pieces of tile it + 1 between them.  Every
-    // (two MFMAs, one piece) group is fenced (sched_barrier): left to itself the scheduler puts all 108 MFMAs first and the staging
-    // behind them (ISA checked), and sched_group_barrier requests did not move it.
-    auto body = [&](int it, Set& nxt, int& nxt_n) {
-        const unsigned char* img = smem + (it & 1) * IMG;
-        unsigned char* wimg = smem + ((it + 1) & 1) * IMG;
-        const int staged_n = nxt_n;                              // image index of the tile being staged (piece 0 moves on to the tile to load)
-        const unsigned char* arow[2];
-        const unsigned char* brow[2];
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-            arow[rr] = img + a_off + (2 * wave + rr) * (G::IWP * 32);
-            brow[rr] = img + b_off + (2 * wave + rr) * (TW * 32);
-        }
-        x3_bf16x8 bf[3], af[2][3];
-        auto a_operand = [&](int rr, int tap, x3_bf16x8* a) {
-            const int kh = tap / KS, kw = tap % KS;
-            const unsigned char* a0 = arow[rr] + (kh * G::IWP + kw) * 32;
-#pragma unroll
-            for (int sp = 0; sp < 3; ++sp) a[sp] = x3_tr_read8(a0 + sp * XS::SPLIT, a0 + sp * XS::SPLIT + 4 * 32);
-        };
-        ctl_static_for<2 * TAPS * 3>([&](auto gtag) {
-            constexpr int GI = decltype(gtag)::value, RR = GI / (TAPS * 3), TAP = (GI % (TAPS * 3)) / 3, J = GI % 3;
-            if constexpr (TAP == 0 && J == 0) {
-#pragma unroll
-                for (int sp = 0; sp < 3; ++sp) bf[sp] = x3_tr_read8(brow[RR] + sp * DYI, brow[RR] + sp * DYI + 4 * 32);
-                a_operand(RR, 0, af[0]);
-            }
-            if constexpr (J == 0 && TAP + 1 < TAPS) a_operand(RR, TAP + 1, af[(TAP + 1) & 1]);
-            x3_bf16x8* a = af[TAP & 1];
-            constexpr int SA0 = J == 0 ? 2 : J == 1 ? 1 : 0, SB0 = J == 0 ? 0 : 1;
-            constexpr int SA1 = J == 0 ? 0 : J == 1 ? 1 : 0, SB1 = J == 0 ? 2 : 0;
-            acc[TAP] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[SA0], bf[SB0], acc[TAP], 0, 0, 0);
-            acc[TAP] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[SA1], bf[SB1], acc[TAP], 0, 0, 0);
-            piece(std::integral_constant<int, GI>{}, nxt, staged_n, wimg);
-            __builtin_amdgcn_sched_barrier(0);
-        });
-        nxt_n = l_n;
-        ctl_barrier_lds_writes_done();
-    };
-    static_assert(R == 2, "the body below alternates two payload sets");
-    int it = 0;
-    for (; it + 2 <= my_tiles; it += 2) {
-        body(it, P[1], s_n[1]);                                  // tile it + 1 lives in set (it + 1) % 2 = 1 (it is even)
-        body(it + 1, P[0], s_n[0]);
-    }
-    if (it < my_tiles) body(it, P[1], s_n[1]);
-    // ---- the end of the block: bias sums, then the four waves' accumulators through LDS (every image is idle behind the last barrier)
-    *reinterpret_cast<f32x4*>(bsred + tid * 8) = bs0;
-    *reinterpret_cast<f32x4*>(bsred + tid * 8 + 4) = bs1;
-    float* red = reinterpret_cast<float*>(smem);
-    const int64_t split_base = (int64_t)blockIdx.x * TAPS * cin_p * cout_p;
-#pragma unroll
-    for (int t0 = 0; t0 < TAPS; t0 += RT) {
-#pragma unroll
-        for (int tp = 0; tp < RT; ++tp) {
-            const int tap = t0 + tp;
-            if (tap < TAPS) {
-                float* r0 = red + (tp * 4 + wave) * 16 * 64 + lane;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) r0[r * 64] = acc[tap][r];
-            }
-        }
-        ctl_barrier_lds_writes_done();
-        if (t0 == 0 && gb == 0 && b_partial != nullptr && tid < 32) {
-            const int t = tid >> 4, c = tid & 15, h = c >> 3, j = c & 7;
-            float v = 0.f;
-            for (int sl = t * 2 + h; sl < 256; sl += 4) v += bsred[sl * 8 + j];
-            const int co = cb * 32 + tid;
-            if (co < cout_p) b_partial[(int64_t)blockIdx.x * cout_p + co] = v;
-        }
-#pragma unroll
-        for (int tp = 0; tp < RT; ++tp) {
-            const int tap = t0 + tp;
-            if (tap < TAPS) {
-#pragma unroll
-                for (int e0 = 0; e0 < 16 * 64; e0 += 256) {
-                    const int e = e0 + tid, r = e >> 6, l = e & 63;
-                    float v = 0.f;
-#pragma unroll
-                    for (int w = 0; w < 4; ++w) v += red[((tp * 4 + w) * 16 + r) * 64 + l];
-                    const int co = cb * 32 + (l & 31);
-                    const int ci = gb * 32 + 8 * (r >> 2) + 4 * (l >> 5) + (r & 3);
-                    if (co < cout_p && ci < cin_p) w_partial[split_base + ((int64_t)tap * cin_p + ci) * cout_p + co] = v;
-                }
-            }
-        }
-        if (t0 + RT < TAPS) ctl_barrier_lds_reads_done();
-    }
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -1004,38 +680,43 @@ static void wgrad3_go_tile(wgrad3_call& a) {
     else { if (a.ntw == 2) wgrad3_go<KS, S, MODE, 1, 2>(a); else wgrad3_go<KS, S, MODE, 1, 1>(a); }
 }
 #ifndef CTL_X3W_PC_DEFAULT
-#define CTL_X3W_PC_DEFAULT 1
-#endif
+#define CTL_X3W_PC_DEFAULT 0      // a SINGLE problem on the producer / consumer kernel: per layer equal to the single-role kernel, in the step 0.8 % slower
+#endif                            // (one 130 KB block per CU next to the other launch chain); the kernel is what the GROUPED launches run on
 #ifndef CTL_X3W_PC_MIN_TILES
 #define CTL_X3W_PC_MIN_TILES 4
 #endif
-#ifndef CTL_X3W_PIPE_DEFAULT
-#define CTL_X3W_PIPE_DEFAULT 1
-#endif
-template <int MODE, bool DY2, int PROK>
-static void wgrad3_launch_pipe(wgrad3_call& a, dim3 grid) {
-    conv_wgrad_x3pipe_kernel<3, 1, MODE, DY2, PROK><<<grid, dim3(256), 0, a.stream>>>(*a.d, a.x, a.pro_scale, a.pro_shift, a.dy, a.dy2, a.dy_coef, a.w_partial, a.b_partial,
-                                                                                   a.c.tiles_h, a.c.tiles_w, a.ntiles, a.cin_p, a.cout_p);
+static void wgrad3_fill_member(wg_member& m, const wgrad3_call& a, int job0) {
+    m.d = *a.d;
+    m.x = a.x; m.pro_scale = a.pro_scale; m.pro_shift = a.pro_shift; m.dy = a.dy; m.dy2 = a.dy2; m.dy_coef = a.dy_coef;
+    m.w_partial = a.w_partial; m.b_partial = a.b_partial;
+    m.tiles_h = a.c.tiles_h; m.tiles_w = a.c.tiles_w; m.ntiles = a.ntiles; m.cin_p = a.cin_p; m.cout_p = a.cout_p;
+    m.splits = a.splits; m.job0 = job0; m.pad_ = 0;
+}
+static void wgrad3_launch_group(const wg_group& g, int jobs, int mode, bool dy2, hipStream_t stream) {
+    const dim3 grid((unsigned)jobs);
+    if (mode == CTL_IN_PLAIN) {
+        if (dy2) conv_wgrad_x3pc_kernel<3, 1, CTL_IN_PLAIN, true><<<grid, dim3(512), 0, stream>>>(g);
+        else conv_wgrad_x3pc_kernel<3, 1, CTL_IN_PLAIN, false><<<grid, dim3(512), 0, stream>>>(g);
+    } else {
+        if (dy2) conv_wgrad_x3pc_kernel<3, 1, CTL_IN_UP2, true><<<grid, dim3(512), 0, stream>>>(g);
+        else conv_wgrad_x3pc_kernel<3, 1, CTL_IN_UP2, false><<<grid, dim3(512), 0, stream>>>(g);
+    }
 }
 template <int MODE>
-static void wgrad3_go_pc(wgrad3_call& a) {
-    const dim3 grid((unsigned)a.splits, (unsigned)(a.cin_p / 32), (unsigned)(a.cout_p / 32));
-    static const int pipe_on = ctl_tune_int("CTL_X3W_PIPE", CTL_X3W_PIPE_DEFAULT);
-    if (pipe_on) {      // the software-pipelined single-stream form
-        const bool pro = a.d->pro_affine != 0;
-        if (a.dy2) { if (pro) wgrad3_launch_pipe<MODE, true, 1>(a, grid); else wgrad3_launch_pipe<MODE, true, 0>(a, grid); }
-        else { if (pro) wgrad3_launch_pipe<MODE, false, 1>(a, grid); else wgrad3_launch_pipe<MODE, false, 0>(a, grid); }
-        return;
-    }
-    if (a.dy2) conv_wgrad_x3pc_kernel<3, 1, MODE, true><<<grid, dim3(512), 0, a.stream>>>(*a.d, a.x, a.pro_scale, a.pro_shift, a.dy, a.dy2, a.dy_coef, a.w_partial, a.b_partial,
-                                                                                        a.c.tiles_h, a.c.tiles_w, a.ntiles, a.cin_p, a.cout_p);
-    else conv_wgrad_x3pc_kernel<3, 1, MODE, false><<<grid, dim3(512), 0, a.stream>>>(*a.d, a.x, a.pro_scale, a.pro_shift, a.dy, a.dy2, a.dy_coef, a.w_partial, a.b_partial,
-                                                                                     a.c.tiles_h, a.c.tiles_w, a.ntiles, a.cin_p, a.cout_p);
+static void wgrad3_go_pc(wgrad3_call& a) {      // a single problem = a group of one
+    wg_group g = {};
+    g.n = 1;
+    wgrad3_fill_member(g.m[0], a, 0);
+    wgrad3_launch_group(g, a.splits * (a.cin_p / 32) * (a.cout_p / 32), MODE, a.dy2 != nullptr, a.stream);
 }
 // one block per CU, (cin / 32) x (cout / 32) output blocks: the pixel tiles are split over what is left of the 256 CUs
+static bool wgrad3_pc_shape_ok(const ctl_conv* d) {
+    return ctl_wgrad_x3_ok(d) && d->ks == 3 && d->stride == 1 && (d->in_mode == CTL_IN_PLAIN || d->in_mode == CTL_IN_UP2) && d->cin % 32 == 0 && d->cout % 32 == 0 &&
+           d->hout >= 8;
+}
 static bool wgrad3_pc_pick(const ctl_conv* d, wgrad3_call* a) {
     static const int pc_on = ctl_tune_int("CTL_X3W_PC", CTL_X3W_PC_DEFAULT), min_tiles = ctl_tune_int("CTL_X3W_PC_MIN_TILES", CTL_X3W_PC_MIN_TILES);
-    if (!pc_on || d->ks != 3 || d->stride != 1 || (d->in_mode != CTL_IN_PLAIN && d->in_mode != CTL_IN_UP2) || d->cin % 32 || d->cout % 32 || a->c.mt != 2) return false;
+    if (!pc_on || !wgrad3_pc_shape_ok(d) || a->c.mt != 2) return false;
     const int par = (d->cin / 32) * (d->cout / 32);
     int splits = ctl_num_cus() / par;
     if (splits > a->ntiles) splits = a->ntiles;
@@ -1106,5 +787,78 @@ int ctl_conv_wgrad_x3(const ctl_conv* d, const float* x, const float* pro_scale,
     if (ptok >= 0) ctl_prof_end(ptok, a.stream);
     if (rc != CTL_OK) return rc;
     CTL_LAUNCH_CHECK("conv_wgrad(x3)");
+    return CTL_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ grouped launches (deferred weight gradients)
+// ctl_wgrad_group_class: >= 0 if the weight gradient of this descriptor can ride in a grouped launch (members of one launch share the class =
+// kernel instantiation: input mode | two-tensor output gradient << 1), -1 otherwise.
+extern "C" int ctl_wgrad_group_class(const ctl_conv* d, int32_t has_dy2) {
+    static const int on = ctl_tune_int("CTL_X3W_GROUP", 1);
+    if (!on || !d || !(d->dt & CTL_DT_X3) || !wgrad3_pc_shape_ok(d)) return -1;
+    return (d->in_mode == CTL_IN_UP2 ? 1 : 0) | (has_dy2 ? 2 : 0);
+}
+// ctl_wgrad_group_plan: pixel splits of the n members of one launch: the CUs are dealt in proportion to the members' work (pixel tiles x
+// 32 x 32 output blocks), every member gets at least one split, no split is empty.  The plan compiler sizes the partial buffers from this.
+extern "C" int ctl_wgrad_group_plan(const ctl_conv* descs, int32_t n, int32_t* splits) {
+    CTL_REQUIRE(descs && splits && n >= 1 && n <= CTL_WG_MAX, "wgrad_group_plan: 1..%d members", CTL_WG_MAX);
+    int64_t work[CTL_WG_MAX], total = 0;
+    int par[CTL_WG_MAX], ntiles[CTL_WG_MAX];
+    for (int i = 0; i < n; ++i) {
+        CTL_REQUIRE(wgrad3_pc_shape_ok(&descs[i]), "wgrad_group_plan: member %d is not a grouped-launch shape", i);
+        par[i] = (descs[i].cin / 32) * (descs[i].cout / 32);
+        ntiles[i] = descs[i].n * ctl_cdiv(descs[i].hout, 8) * ctl_cdiv(descs[i].wout, 16);
+        work[i] = (int64_t)ntiles[i] * par[i];
+        total += work[i];
+    }
+    const int cus = ctl_num_cus();
+    for (int i = 0; i < n; ++i) {
+        int sp = (int)((cus * work[i]) / (total * par[i]));          // floor: the sum of jobs stays <= the CU count unless a member needs its minimum
+        if (sp < 1) sp = 1;
+        if (sp > ntiles[i]) sp = ntiles[i];
+        splits[i] = sp;
+    }
+    return CTL_OK;
+}
+extern "C" int ctl_conv_wgrad_group(int32_t n, const ctl_conv* descs, const int32_t* splits, const float* const* x, const float* const* pro_scale,
+                                    const float* const* pro_shift, const float* const* dy, const float* const* dy2, const float* const* dy_coef,
+                                    float* const* w_partial, float* const* b_partial, ctl_stream stream) {
+    CTL_REQUIRE(n >= 1 && n <= CTL_WG_MAX && descs && splits && x && dy && w_partial, "conv_wgrad_group: 1..%d members and their tensors", CTL_WG_MAX);
+    wg_group g = {};
+    g.n = n;
+    int jobs = 0;
+    const int cls = ctl_wgrad_group_class(&descs[0], dy2 && dy2[0]);
+    CTL_REQUIRE(cls >= 0, "conv_wgrad_group: member 0 is not a grouped-launch shape");
+    double flops = 0.0, bytes = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const ctl_conv* d = &descs[i];
+        CTL_REQUIRE(ctl_wgrad_group_class(d, dy2 && dy2[i]) == cls, "conv_wgrad_group: member %d is of another class than member 0", i);
+        CTL_REQUIRE(x[i] && dy[i] && w_partial[i] && (!d->pro_affine || (pro_scale && pro_shift && pro_scale[i] && pro_shift[i])) && (!(cls & 2) || (dy_coef && dy_coef[i])),
+                    "conv_wgrad_group: member %d misses a tensor", i);
+        CTL_REQUIRE((d->groups > 1 ? d->groups : 1) * (d->cin > d->cout ? d->cin : d->cout) <= CTL_PRO_MAX, "conv_wgrad_group: member %d: groups * channels > %d", i, CTL_PRO_MAX);
+        CTL_REQUIRE((int64_t)d->n * d->hin * d->win * d->cin * 4 < (1ll << 31) && (int64_t)d->n * d->hout * d->wout * d->cout * 4 < (1ll << 31),
+                    "conv_wgrad_group: tensors must stay below 2 GiB (32-bit buffer offsets)");
+        wgrad3_call a = {};
+        a.d = d;
+        int rc = ctl_conv_pick_cfg(d, &a.c, 1);
+        if (rc != CTL_OK) return rc;
+        a.ntiles = d->n * a.c.tiles_h * a.c.tiles_w;
+        a.cin_p = a.c.g * 16; a.cout_p = a.c.cot * 16;
+        CTL_REQUIRE(splits[i] >= 1 && splits[i] <= a.ntiles && a.c.mt == 2, "conv_wgrad_group: member %d: splits %d of %d tiles", i, splits[i], a.ntiles);
+        a.splits = splits[i];
+        a.x = x[i]; a.pro_scale = pro_scale ? pro_scale[i] : nullptr; a.pro_shift = pro_shift ? pro_shift[i] : nullptr; a.dy = dy[i];
+        a.dy2 = dy2 ? dy2[i] : nullptr; a.dy_coef = dy_coef ? dy_coef[i] : nullptr; a.w_partial = w_partial[i]; a.b_partial = b_partial ? b_partial[i] : nullptr;
+        wgrad3_fill_member(g.m[i], a, jobs);
+        jobs += a.splits * (a.cin_p / 32) * (a.cout_p / 32);
+        const double pix = (double)d->n * d->hout * d->wout;
+        flops += 2.0 * pix * d->cout * d->cin * 9;
+        bytes += 4.0 * d->n * d->hin * d->win * d->cin + 4.0 * pix * d->cout * ((cls & 2) ? 2 : 1);
+    }
+    char kind[48];
+    snprintf(kind, sizeof(kind), "conv_wgrad_x3grp<in%d%s>", cls & 1, (cls & 2) ? ",x2" : "");
+    const int ptok = ctl_prof_begin_raw(kind, flops, bytes, (hipStream_t)stream);
+    wgrad3_launch_group(g, jobs, (cls & 1) ? CTL_IN_UP2 : CTL_IN_PLAIN, (cls & 2) != 0, (hipStream_t)stream);
+    if (ptok >= 0) ctl_prof_end(ptok, (hipStream_t)stream);
+    CTL_LAUNCH_CHECK("conv_wgrad_group");
     return CTL_OK;
 }

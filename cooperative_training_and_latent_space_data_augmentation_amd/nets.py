@@ -61,6 +61,10 @@ X3 = True                # fp32: the 2x2 / 3x3 / 4x4 convs with cin, cout multip
                          # <= 2^-24 (1 + 2^-8) (one fp32 multiply's rounding; typically 2^-25), 16/6 of the fp32 MFMA rate.  A MODULE-level
                          # switch read when a CtlNet is built: set nets.X3 = False BEFORE constructing the solver (bench.py --set does)
 X3_WGRAD = True          # ... and so do the weight gradients of those layers (3x3 stride 1 / 2, 2x2 stride 2)
+GROUP_WGRAD = True       # fp32 / X3: the weight gradients of a backward plan that can share a launch (ctl_wgrad_group_class) are DEFERRED to the end of
+                         # the plan and served in groups of up to 8 by one launch each (CTL_OP_WGRAD_GROUP): nothing in the plan reads dW, and per
+                         # launch ~15 of 40 us are fixed.  Safe to reorder: plan arenas are bump-allocated (no tensor is reused inside a plan) and
+                         # every in-place pass on a gradient tensor (apply, accumulate epilogues) is emitted BEFORE the weight gradient that reads it
 FUSE_TAIL = True         # fp32: the residual tail's BatchNorm-backward reduction inside the launch that writes dOut (CTL_EPI_TAILBWD): dOut is
                          # never materialised, the stand-alone reduction launch (read dOut, out, v; write dS) disappears
 CONV_WORDS = _ffi.CONV_DTYPE.itemsize // 4      # ctl_conv as int32 words at the head of ctl_op.i
@@ -174,6 +178,7 @@ class PlanBuilder:
         self.bscr = Arena(S_BSCR, self.b16)
         self.scr_bytes = 0
         self.reduce_recs: List[list] = []     # batched wgrad reduction records (one launch at the end of the plan)
+        self.pending_wgrads: List[dict] = []  # deferred weight gradients (GROUP_WGRAD), emitted by flush_wgrad_groups
         self.table: Optional[np.ndarray] = None
         self.bn_log: List[tuple] = []         # (BNInfo, coefficient refs) of every training-mode BatchNorm of a forward plan, in order
 
@@ -295,7 +300,25 @@ class PlanBuilder:
             dt = _ffi.DT_X3          # the weight gradient on the bf16 matrix pipe over the exact three-way split (csrc/ctl_wgrad_x3.hip)
         d = self._conv_desc(x, dy.c, ks, stride, in_mode, dy.h, dy.w, pro, 0, 0, 0.0, dt=dt)
         dp = _ffi.desc_ptr(d)
-        wb, bb = 4 * lib.ctl_wgrad_partial_floats(dp), 4 * lib.ctl_wgrad_bias_partial_floats(dp)
+        assert dw_ref[0] == S_GRAD and (dbias_ref is None or dbias_ref[0] == S_GRAD)
+        refs = [x.ref, pro[0] if pro else None, pro[1] if pro else None, dy.ref, None, None, dy2[0].ref if dy2 else None, dy2[1] if dy2 else None]
+        if GROUP_WGRAD and dt == _ffi.DT_X3:
+            cls = int(lib.ctl_wgrad_group_class(dp, 1 if dy2 else 0))
+            if cls >= 0:
+                self.pending_wgrads.append(dict(cls=cls, d=d, refs=refs, dw_ref=dw_ref, dbias_ref=dbias_ref, strides=[int(v) for v in strides],
+                                                accumulate=bool(accumulate), cin=x.c, cout=dy.c, ks=ks))
+                return
+        self._emit_wgrad(d, refs, dw_ref, dbias_ref, strides, accumulate, x.c, dy.c, ks, None)
+
+    def _emit_wgrad(self, d, refs, dw_ref, dbias_ref, strides, accumulate, cin, cout, ks, splits):
+        """One WGRAD record + its reduction record.  splits = None: a launch of its own (the library's split count); else a member of a
+        grouped launch with that many pixel splits (record word i[24])."""
+        dp = _ffi.desc_ptr(d)
+        cin_p, cout_p = _rup(cin, 16), _rup(cout, 16)
+        if splits is None:
+            wb, bb = 4 * lib.ctl_wgrad_partial_floats(dp), 4 * lib.ctl_wgrad_bias_partial_floats(dp)
+        else:
+            wb, bb = 4 * splits * ks * ks * cin_p * cout_p, 4 * splits * cout_p
         if wb == 0:
             raise _ffi.CtlError("wgrad plan: " + lib.ctl_last_error().decode())
         # every layer keeps its own partial buffers (backward arena): all reductions run as ONE table-driven launch at the end
@@ -304,17 +327,43 @@ class PlanBuilder:
         words = np.frombuffer(d.tobytes(), dtype="<i4")
         op = self.op(_ffi.OP_WGRAD)
         op["i"][:CONV_WORDS] = words
-        for idx, ref in enumerate([x.ref, pro[0] if pro else None, pro[1] if pro else None, dy.ref, wref, bref,
-                                   dy2[0].ref if dy2 else None, dy2[1] if dy2 else None]):
+        refs = list(refs)
+        refs[4], refs[5] = wref, bref
+        for idx, ref in enumerate(refs):
             self.set_t(op, idx, ref)
-        assert dw_ref[0] == S_GRAD and (dbias_ref is None or dbias_ref[0] == S_GRAD)
-        splits = lib.ctl_wgrad_splits(dp)
-        cin_p, cout_p = _rup(x.c, 16), _rup(dy.c, 16)
+        if splits is None:
+            splits = lib.ctl_wgrad_splits(dp)
+        else:
+            op["i"][CONV_WORDS] = splits
         self.reduce_recs.append([wref[1] // 4, bref[1] // 4 if bref else -1, dw_ref[1] // 4, dbias_ref[1] // 4 if dbias_ref else -1,
-                                 splits, (ks * ks) | (ks << 8), x.c, dy.c, cin_p, cout_p, *[int(v) for v in strides],
+                                 splits, (ks * ks) | (ks << 8), cin, cout, cin_p, cout_p, *[int(v) for v in strides],
                                  1 if accumulate else 0, 0])
 
+    def flush_wgrad_groups(self):
+        """Emit the deferred weight gradients: per class (kernel instantiation) in groups of up to WGRAD_GROUP_MAX members, each group
+        one CTL_OP_WGRAD_GROUP record followed by its members' WGRAD records; a class with a single member is launched on its own."""
+        pend, self.pending_wgrads = self.pending_wgrads, []
+        by_cls: Dict[int, list] = {}
+        for w in pend:
+            by_cls.setdefault(w["cls"], []).append(w)
+        for cls in sorted(by_cls):
+            members = by_cls[cls]
+            for g0 in range(0, len(members), _ffi.WGRAD_GROUP_MAX):
+                grp = members[g0:g0 + _ffi.WGRAD_GROUP_MAX]
+                if len(grp) == 1:
+                    w = grp[0]
+                    self._emit_wgrad(w["d"], w["refs"], w["dw_ref"], w["dbias_ref"], w["strides"], w["accumulate"], w["cin"], w["cout"], w["ks"], None)
+                    continue
+                descs = np.concatenate([np.atleast_1d(w["d"]) for w in grp])
+                splits = np.zeros(len(grp), dtype=np.int32)
+                _ffi.check(lib.ctl_wgrad_group_plan(descs.ctypes.data, len(grp), splits.ctypes.data), "ctl_wgrad_group_plan")
+                op = self.op(_ffi.OP_WGRAD_GROUP)
+                op["i"][0] = len(grp)
+                for w, sp in zip(grp, splits):
+                    self._emit_wgrad(w["d"], w["refs"], w["dw_ref"], w["dbias_ref"], w["strides"], w["accumulate"], w["cin"], w["cout"], w["ks"], int(sp))
+
     def flush_wgrad_reductions(self):
+        self.flush_wgrad_groups()
         if not self.reduce_recs:
             return
         assert self.table is None

@@ -31,13 +31,14 @@ enum ctl_status { CTL_OK = 0, CTL_EINVAL = -1, CTL_EUNSUPPORTED = -2, CTL_ELAUNC
  * ctl_version() with the CTL_ABI_VERSION they were written against (and ctl_sizeof_conv / ctl_sizeof_op with their struct sizes)
  * at load time and refuse to run on a mismatch.  3 = round 3: fused-finalize entry points and side lanes removed, `ds` argument of
  * ctl_bwd_reduce_dt, ctl_red_blocks().  4 = CTL_EPI_TAILBWD / ctl_conv_forward_ex (plan op CONV slot 10).
+ * 10 = grouped weight gradients: ctl_wgrad_group_class / ctl_wgrad_group_plan / ctl_conv_wgrad_group, plan op CTL_OP_WGRAD_GROUP.
  * 5 = ctl_bn_finalize_ex (save_uvar, plan op BN_FINALIZE slot 10), ctl_bn_replay_running / CTL_OP_BN_REPLAY.
  * 6 = the BatchNorm-backward prologue: ctl_conv.pro_affine == 2 + the x2 argument of ctl_conv_forward_ex (plan op CONV slot 11),
  *     ctl_conv_wgrad_ex (plan op WGRAD slots 6, 7); CTL_EPI_TAILBWD in the bf16 family.
  * 7 = the `pool` argument of ctl_conv_forward_ex (plan op CONV slot 12; CTL_OP_MAX_T 12 -> 14: sizeof(ctl_op) 304 -> 328), ctl_conv_pool_ok.
  * 8 = the `xout` argument of ctl_conv_forward_ex (plan op CONV slot 13).
  * 9 = CTL_DT_X3 / CTL_PACK_X3, ctl_conv_wpack_floats_x3, ctl_pack_weights_x3_batched; plan op PACK_BATCH i[1] is a bit mask. */
-#define CTL_ABI_VERSION 9
+#define CTL_ABI_VERSION 10
 int         ctl_version(void);
 const char* ctl_last_error(void);
 
@@ -149,6 +150,23 @@ int ctl_conv_wgrad(const ctl_conv* d, const float* x, const float* pro_scale, co
  * consumer of a block's dU / dV (see ctl_conv_forward_ex).  The bias gradient is the sum of the virtual tensor.  dy2 == NULL: ctl_conv_wgrad. */
 int ctl_conv_wgrad_ex(const ctl_conv* d, const float* x, const float* pro_scale, const float* pro_shift,
                       const float* dy, const float* dy2, const float* dy_coef, float* w_partial, float* b_partial, ctl_stream stream);
+
+/* Grouped weight gradients (ABI 10).  The reference computes every layer's dW inside autograd's backward sweep, one cuDNN/MKL call per layer
+ * (encoder_decoder.py:19-68, 285-348 under loss.backward(), train_adv_supervised_segmentation_triplet.py:225).  Nothing downstream of a backward
+ * pass reads dW before the optimizer (or the gradient all-reduce), so the plan compiler defers the X3 weight gradients of a pass and serves up to
+ * 8 of one class with ONE launch: the CUs are dealt to the members in proportion to their work.  Per launch ~15 us are fixed (launch, exposed first
+ * loads, reduction tail) against ~25 us of work for an n = 16 layer; a member of a group gets fewer CUs, more tiles per block, fewer split-K partials.
+ *   ctl_wgrad_group_class: >= 0 (the class: members of one launch must agree) if `d` (CTL_DT_X3, 3x3 stride 1, plain / nearest-up-sampled input,
+ *                          cin and cout multiples of 32, hout >= 8) can ride in a group, -1 otherwise.  has_dy2: the two-tensor output gradient.
+ *   ctl_wgrad_group_plan : the members' pixel splits; member i then needs splits[i] * 9 * cin * cout floats of w_partial (and splits[i] * cout of
+ *                          b_partial), laid out and reduced exactly like ctl_conv_wgrad's ([split][tap][cin][cout]; ctl_wgrad_reduce_batched).
+ *   ctl_conv_wgrad_group : the launch.  Arrays of n pointers; pro_scale / pro_shift / dy2 / dy_coef / b_partial entries (or the arrays) may be NULL
+ *                          where a member has none. */
+int ctl_wgrad_group_class(const ctl_conv* d, int32_t has_dy2);
+int ctl_wgrad_group_plan(const ctl_conv* descs, int32_t n, int32_t* splits);
+int ctl_conv_wgrad_group(int32_t n, const ctl_conv* descs, const int32_t* splits, const float* const* x, const float* const* pro_scale,
+                         const float* const* pro_shift, const float* const* dy, const float* const* dy2, const float* const* dy_coef,
+                         float* const* w_partial, float* const* b_partial, ctl_stream stream);
 int ctl_wgrad_reduce(const ctl_conv* d, const float* w_partial, const float* b_partial,
                      float* dw, int64_t s_co, int64_t s_ci, int64_t s_kh, int64_t s_kw,
                      float* dbias, int32_t accumulate, ctl_stream stream);
@@ -365,7 +383,9 @@ enum ctl_op_kind {
     CTL_OP_CONV = 1, CTL_OP_WGRAD = 2, CTL_OP_WGRAD_REDUCE = 3, CTL_OP_PACK = 4, CTL_OP_BN_FINALIZE = 5,
     CTL_OP_BN_EVAL = 6, CTL_OP_BN_ACT = 7, CTL_OP_BWD_REDUCE = 8, CTL_OP_BN_BWD_FINALIZE = 9, CTL_OP_BWD_APPLY = 10,
     CTL_OP_CHAN_SUM_FINALIZE = 11, CTL_OP_SUMPOOL2 = 12, CTL_OP_SIGMOID_BWD = 13, CTL_OP_ZERO = 14, CTL_OP_COPY = 15, CTL_OP_PACK_BATCH = 16,
-    CTL_OP_WGRAD_REDUCE_BATCH = 17, CTL_OP_DROPOUT2D = 18, CTL_OP_BN_REPLAY = 19
+    CTL_OP_WGRAD_REDUCE_BATCH = 17, CTL_OP_DROPOUT2D = 18, CTL_OP_BN_REPLAY = 19,
+    CTL_OP_WGRAD_GROUP = 20           /* i[0] = n members (<= 8): the next n records are WGRAD records served by ONE launch (ctl_conv_wgrad_group), i[24] of each
+                                         member = its pixel splits (ctl_wgrad_group_plan); a runner that meets the members on their own may launch them singly */
 };
 #define CTL_OP_MAX_T 14
 typedef struct ctl_op {

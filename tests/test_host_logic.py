@@ -58,6 +58,46 @@ def test_plans_compile_for_all_modes():
     assert any(int(o["kind"]) == _ffi.OP_SIGMOID_BWD for o in bi.ops)
 
 
+def test_deferred_weight_gradients_are_grouped_at_the_end_of_a_backward_plan():
+    """nets.GROUP_WGRAD (round 5): the X3 weight gradients that can share a launch are deferred to the end of the backward plan and emitted as
+    CTL_OP_WGRAD_GROUP records, each followed by its member WGRAD records; every member carries its pixel-split count (i[24]), its partial
+    buffer is sized from that count, the reduction table holds the same count, and nothing but the reduction follows the groups."""
+    model = nets.build_networks(device="cpu")
+    enc = model["image_encoder"]
+    f = enc._compile_forward(16, 256, 256, "A")
+    b = enc._compile_backward(f, "A", (True, True), False, True, True)
+    kinds = [int(o["kind"]) for o in b.ops]
+    groups = [k for k, v in enumerate(kinds) if v == _ffi.OP_WGRAD_GROUP]
+    assert groups, "a bs16 256^2 encoder backward has groupable weight gradients (32 -> 32 ... 128 -> 128 3x3 layers)"
+    first = groups[0]
+    assert _ffi.OP_CONV not in kinds[first:] and kinds[-1] == _ffi.OP_WGRAD_REDUCE_BATCH      # the groups are the tail of the plan
+    table = b.table_np
+    n_members = 0
+    for k in groups:
+        n = int(b.ops[k]["i"][0])
+        assert 2 <= n <= _ffi.WGRAD_GROUP_MAX
+        cls = set()
+        for m in b.ops[k + 1:k + 1 + n]:
+            assert int(m["kind"]) == _ffi.OP_WGRAD
+            d = np.frombuffer(np.ascontiguousarray(m["i"][:nets.CONV_WORDS]).tobytes(), dtype=_ffi.CONV_DTYPE)[0]
+            sp = int(m["i"][nets.CONV_WORDS])
+            assert sp >= 1 and d["cin"] % 32 == 0 and d["cout"] % 32 == 0 and d["ks"] == 3 and d["stride"] == 1 and d["dt"] == _ffi.DT_X3
+            cls.add((int(d["in_mode"]), int(m["slot"][6]) >= 0))
+            rec = [r for r in table if int(r[0]) * 4 == int(m["off"][4])]          # the reduction record of this member's partial buffer
+            assert len(rec) == 1 and int(rec[0][4]) == sp
+        assert len(cls) == 1                                                       # one kernel instantiation per launch
+        n_members += n
+    assert n_members >= 8
+    # the switch: without it every weight gradient is a launch of its own, in place
+    nets.GROUP_WGRAD = False
+    try:
+        b0 = enc._compile_backward(f, "A", (True, True), False, True, True)
+    finally:
+        nets.GROUP_WGRAD = True
+    k0 = [int(o["kind"]) for o in b0.ops]
+    assert _ffi.OP_WGRAD_GROUP not in k0 and sum(v == _ffi.OP_WGRAD for v in k0) == sum(v == _ffi.OP_WGRAD for v in kinds)
+
+
 def test_without_gpu_the_product_path_fails_loudly():
     model = nets.build_networks(device="cpu")
     x = torch.rand(1, 1, 32, 32)
