@@ -140,8 +140,9 @@ struct XStage3 {
     Pay pay;
     int pad_h, pad_w;
 
-    __device__ __forceinline__ void init(const ctl_conv& d) {
-        const int tid = threadIdx.x;
+    // (tid_: the thread's index among the 256 that stage this chunk; the multi-group producers of the 1024-thread kernels pass threadIdx.x & 255)
+    __device__ __forceinline__ void init(const ctl_conv& d, int tid_ = -1) {
+        const int tid = tid_ < 0 ? (int)threadIdx.x : tid_;
 #pragma unroll
         for (int i = 0; i < NU; ++i) {
             const int u = tid + i * 256;

@@ -10,6 +10,8 @@
 // The bias gradient (column sums of dy) is taken from the staged fp32 values, before the split.
 #include <utility>
 
+#include <type_traits>
+
 #include "ctl_conv_x3_stage.h"
 
 typedef short x3_s16x4 __attribute__((ext_vector_type(4)));
@@ -289,57 +291,23 @@ __global__ __launch_bounds__(256, CTL_X3W_LB) void conv_wgrad_x3_kernel(const ct
 }
 
 // ------------------------------------------------------------------------------------------------ producer / consumer form (round 5)
-// conv_wgrad_x3pc_kernel: 32 cin x 32 cout per block on v_mfma_f32_32x32x16_bf16, ONE 512-thread block per CU.
-//   * the 32x32x16 form issues HALF the matrix instructions of the 16x16x32 form for the same products (an MFMA holds the SIMD's vector
-//     issue port for 8 cycles whatever its shape: 8 of 32 instead of 8 of 16), and a 32 x 32 output block stages dy once per 32 input
-//     channels instead of once per 16 (and x once per 32 output channels): what bounds the single-role kernel above is the instruction
-//     issue of a SIMD -- matrix + split / prologue vector instructions + LDS traffic -- not the matrix pipe;
-//   * waves 0-3 (producers) keep CTL_X3W_PC_SETS tiles of loads in flight in registers, evaluate the prologue / the virtual output
-//     gradient, split and write the three bf16 images of tile `it` into LDS image it & 1; waves 4-7 (consumers) hold the 9 x 32 x 32
-//     accumulators (144 registers) and do nothing but transposed operand reads and MFMAs: one s_barrier per tile (see conv_igemm_kernel,
-//     PC, for the protocol and for why every load in the producer loop is unconditional and single-path).
-//   D[ci][co] += A[ci][k = pixel] B[pixel][co], K = 16 pixels = one tile row; consumer wave w owns tile rows 2w, 2w + 1 and all nine taps;
-//   the four waves' sums meet in LDS at the end of the block (two rounds of taps through the then free images).
+// conv_wgrad_x3pc16_kernel: 32 cin x 32 cout per block on v_mfma_f32_32x32x16_bf16, ONE 1024-thread block per CU.
+//   * the 32x32x16 form issues HALF the matrix instructions of the 16x16x32 form for the same products, and a 32 x 32 output block stages dy
+//     once per 32 input channels instead of once per 16 (and x once per 32 output channels);
+//   * producer waves keep two tiles of loads in flight in registers, evaluate the prologue / the virtual output gradient, split and write the
+//     three bf16 images of tile `it` into LDS image it & 1; consumer waves hold the tap accumulators and do nothing but transposed operand
+//     reads and MFMAs: one s_barrier per tile (see conv_igemm_kernel, PC, for the protocol and for why every load in the producer loop is
+//     unconditional and single-path).
+//   D[ci][co] += A[ci][k = pixel] B[pixel][co], K = 16 pixels = one tile row; the four row waves' sums meet in LDS at the end of the block.
 // Lane maps (v_mfma_f32_32x32x16_bf16): A[row = lane & 31][k = 8 (lane >> 5) + j], B[k = 8 (lane >> 5) + j][col = lane & 31], D[row = (r & 3)
 // + 8 (r >> 2) + 4 (lane >> 5)][col = lane & 31]: lane group q = lane >> 4 reads the 16-channel chunk q & 1 and the pixel half q >> 1 of
 // its operand with the transposed reads of the kernel above.
-#ifndef CTL_X3W_PC_SETS
-#define CTL_X3W_PC_SETS 3
-#endif
-#ifndef CTL_X3W_PC_SETS_DY2
-#define CTL_X3W_PC_SETS_DY2 2
-#endif
+// Bank phase: a transposed read is served in two halves of 32 lanes; lanes 0-15 (chunk 0) and 16-31 (chunk 1) each cover 128 contiguous bytes
+// = 32 of the 64 banks, so the second chunk of every operand sits 128 B (mod 256) behind the first (chunk strides that are multiples of 256 B:
+// SQ_LDS_BANK_CONFLICT 0.37-0.45 of the LDS-active cycles in the single-role kernel, whose two lane groups read pixels 256 B apart).
+// An eight-wave form (one producer + one consumer wave per SIMD, all nine taps on the consumer) and a single-stream software-pipelined form
+// were built, measured and removed: profiles/r5_wgrad_pc_experiments.txt has their phase timers and the micro-benchmarks behind them.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-#ifndef CTL_X3WPC_CPRIO      // wave priorities of the two roles (measured: no effect either way, profiles/r5_wgrad_pc_experiments.txt)
-#define CTL_X3WPC_CPRIO 0
-#endif
-#ifndef CTL_X3WPC_PPRIO
-#define CTL_X3WPC_PPRIO 0
-#endif
-// Phase timers (variant builds only: tools/build_variant.sh tmw "-DCTL_TIMING_X3W" ctl_wgrad_x3.hip; read and reset with ctl_debug_timing_x3w):
-// s_memtime deltas summed over waves: [0] producer staging (load wait + prologue + split + LDS writes), [1] producer load issue, [2] producer
-// barrier wait, [3] consumer barrier wait, [4] consumer matrix phase, [5] tiles (consumer waves), [6] consumer head (to the first barrier's
-// release), [7] consumer tail (reduction), [8] producer head (first loads issued), [9] block span (consumer waves)
-#ifdef CTL_TIMING_X3W
-__device__ unsigned long long ctl_tmw[16];
-#define TW_DECL unsigned long long tw_prev = __builtin_amdgcn_s_memtime(), tw_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; const unsigned long long tw_t0 = tw_prev;
-#define TW(i) { const unsigned long long tw_now = __builtin_amdgcn_s_memtime(); tw_acc[i] += tw_now - tw_prev; tw_prev = tw_now; }
-#define TW_COUNT(i) { tw_acc[i] += 1; }
-#define TW_FLUSH(span) { if (span) tw_acc[9] = __builtin_amdgcn_s_memtime() - tw_t0; \
-                         if ((threadIdx.x & 63) == 0) { _Pragma("unroll") for (int i_ = 0; i_ < 10; ++i_) if (tw_acc[i_]) atomicAdd(&ctl_tmw[i_], tw_acc[i_]); } }
-extern "C" int ctl_debug_timing_x3w(unsigned long long* out10) {
-    unsigned long long host[16] = {0};
-    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(ctl_tmw), sizeof(host)) != hipSuccess) return -1;
-    for (int i = 0; i < 10; ++i) out10[i] = host[i];
-    for (int i = 0; i < 16; ++i) host[i] = 0;
-    return hipMemcpyToSymbol(HIP_SYMBOL(ctl_tmw), host, sizeof(host)) == hipSuccess ? 0 : -1;
-}
-#else
-#define TW_DECL
-#define TW(i)
-#define TW_COUNT(i)
-#define TW_FLUSH(span)
-#endif
 // A launch serves a GROUP of problems (deferred weight gradients of one backward plan, nets.PlanBuilder.flush_wgrad_groups): the 256 CUs are
 // dealt to the members in proportion to their work, one block = one job = (member, pixel split, 32-cin block, 32-cout block).  Why groups:
 // per launch ~15 us of a 40 us n = 16 layer are fixed (launch, first loads + first staging exposed, reduction tail, partial write) while the
@@ -353,8 +321,14 @@ struct wg_member {
     int tiles_h, tiles_w, ntiles, cin_p, cout_p, splits, job0, pad_;
 };
 struct wg_group { int n, pad_[3]; wg_member m[CTL_WG_MAX]; };
+// Sixteen waves: per SIMD TWO producer waves and TWO consumer waves.  In the eight-wave form (one + one) the producer wave was the critical
+// path -- 3000 cycles of staging per tile alone, 5750 beside the MFMA wave of its SIMD (with or without that wave's operand reads) -- while the
+// MFMA wave needed 2900 and waited for the rest.  Here every producer wave stages half as much (x: one 16-channel chunk per 256-thread group;
+// dy: one unit per thread), and the nine tap accumulators are split over the SIMD's two consumer waves (taps 0-4 | 5-8: 80 accumulator
+// registers, which is what fits four waves of 128 registers on a SIMD).  Measured against the eight-wave form: grouped launch 124 -> 113 us,
+// step 14.84 -> 14.63 ms same-box.
 template <int KS, int S, int MODE, bool DY2>
-__global__ __launch_bounds__(512, 2) void conv_wgrad_x3pc_kernel(const wg_group grp_) {
+__global__ __launch_bounds__(1024, 4) void conv_wgrad_x3pc16_kernel(const wg_group grp_) {
     int mi = 0;
 #pragma unroll
     for (int i = 1; i < CTL_WG_MAX; ++i)
@@ -365,128 +339,88 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_x3pc_kernel(const wg_group 
     const float* __restrict__ dy = M.dy; const float* __restrict__ dy2 = M.dy2; const float* __restrict__ dy_coef = M.dy_coef;
     float* __restrict__ w_partial = M.w_partial; float* __restrict__ b_partial = M.b_partial;
     const int tiles_h = M.tiles_h, tiles_w = M.tiles_w, ntiles = M.ntiles, cin_p = M.cin_p, cout_p = M.cout_p;
-    // job -> (pixel split, 32-cin block, 32-cout block) of the member
     const int job = (int)blockIdx.x - M.job0, job_ns = M.splits;
     const int job_s = job % job_ns, job_r = job / job_ns;
     const int gb = job_r % (cin_p / 32), cb = job_r / (cin_p / 32);
-    static_assert(S == 1, "stride 1 (the transposed reads take 8 consecutive pixels of a row)");
+    static_assert(S == 1 && KS == 3, "3x3 stride 1");
     constexpr int MT = 2, TW = 16;
     using G = Geom<KS, S, MT, TW>;
     using XS = XStage3<KS, S, MODE, MT, TW, false, false>;
-    constexpr int TAPS = KS * KS;
-    // Bank phase: a transposed read is served in two halves of 32 lanes; lanes 0-15 (chunk 0) and 16-31 (chunk 1) each cover 128 contiguous
-    // bytes = 32 of the 64 banks, so the second chunk of every operand sits 128 B (mod 256) behind the first: the two spans take the
-    // two halves of the bank row (chunk strides that are multiples of 256 B: SQ_LDS_BANK_CONFLICT 0.37-0.45 of the LDS-active cycles in
-    // the single-role kernel, where the two lane groups read pixels 0-7 / 8-15 of one image, 256 B apart)
-    constexpr int XCH = XS::XT_BYTES + 128;                // byte distance of the two 16-channel chunks of x (XT_BYTES is a multiple of 256)
-    constexpr int DCH = G::TP * 32 + 128;                  // ... and of the two 16-channel chunks of a dy split image
-    static_assert(XS::XT_BYTES % 256 == 0 && (G::TP * 32) % 256 == 0, "bank phase of the chunks");
-    constexpr int XBYTES = 2 * XCH;                        // two 16-channel chunks of x, three split images each
-    constexpr int DYI = 2 * DCH;                           // one split image of the dy tile: [cout chunk][pixel][16 ch] bf16
-    constexpr int IMG = XBYTES + 3 * DYI;                  // everything one tile needs
-    constexpr int TAP_BYTES = 4 * 16 * 64 * 4;             // reduction scratch of one tap: [wave][register][lane] floats
-    constexpr int RT = (2 * IMG) / TAP_BYTES < TAPS ? (2 * IMG) / TAP_BYTES : TAPS;      // taps per reduction round
-    static_assert(RT >= 1, "reduction scratch");
+    constexpr int TAPS = KS * KS, TH0 = 5;                   // taps 0 .. TH0-1 on the first consumer wave of a SIMD, the rest on the second
+    constexpr int XCH = XS::XT_BYTES + 128, DCH = G::TP * 32 + 128;
+    constexpr int XBYTES = 2 * XCH, DYI = 2 * DCH, IMG = XBYTES + 3 * DYI;
+    constexpr int TAP_BYTES = 4 * 16 * 64 * 4;
+    constexpr int RT = (2 * IMG) / TAP_BYTES < TAPS ? (2 * IMG) / TAP_BYTES : TAPS;
     constexpr int COEF = (DY2 ? 5 : 2) * CTL_PRO_MAX * 4;
-    static_assert(2 * IMG + COEF + 256 * 8 * 4 <= 160 * 1024, "LDS budget of one CU");
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * IMG + COEF + 256 * 8 * 4];
+    static_assert(2 * IMG + COEF + 512 * 8 * 4 <= 160 * 1024, "LDS budget of one CU");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * IMG + COEF + 512 * 8 * 4];
     float* cf_scale = reinterpret_cast<float*>(smem + 2 * IMG);
     float* cf_shift = cf_scale + CTL_PRO_MAX;
-    float* cd = cf_shift + CTL_PRO_MAX;                    // DY2: A | B | C, [group][cout] each
+    float* cd = cf_shift + CTL_PRO_MAX;
     float* bsred = reinterpret_cast<float*>(smem + 2 * IMG + COEF);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool consumer = wave_all >= 4;
-    const int wave = wave_all & 3;
+    const bool consumer = wave_all >= 8;
     const int group_n = d.n / (d.groups > 1 ? d.groups : 1);
-    // tiles of this block: job_s, + job_ns, ...
     const int my_tiles = (job_s < ntiles) ? (ntiles - job_s + job_ns - 1) / job_ns : 0;
-
-    if (tid < 256 || true) {                               // coefficient tables (every thread helps; one barrier for all)
-        if (d.pro_affine)
-            for (int i = tid; i < (d.groups > 1 ? d.groups : 1) * d.cin; i += 512) { cf_scale[i] = pro_scale[i]; cf_shift[i] = pro_shift[i]; }
-        if constexpr (DY2) {
-            for (int i = tid; i < (d.groups > 1 ? d.groups : 1) * d.cout; i += 512) {
-                const int gi = i / d.cout, ch = i - gi * d.cout;
-                cd[i] = dy_coef[(gi * 3 + 0) * d.cout + ch]; cd[CTL_PRO_MAX + i] = dy_coef[(gi * 3 + 1) * d.cout + ch];
-                cd[2 * CTL_PRO_MAX + i] = dy_coef[(gi * 3 + 2) * d.cout + ch];
-            }
+    if (d.pro_affine)
+        for (int i = tid; i < (d.groups > 1 ? d.groups : 1) * d.cin; i += 1024) { cf_scale[i] = pro_scale[i]; cf_shift[i] = pro_shift[i]; }
+    if constexpr (DY2) {
+        for (int i = tid; i < (d.groups > 1 ? d.groups : 1) * d.cout; i += 1024) {
+            const int gi = i / d.cout, ch = i - gi * d.cout;
+            cd[i] = dy_coef[(gi * 3 + 0) * d.cout + ch]; cd[CTL_PRO_MAX + i] = dy_coef[(gi * 3 + 1) * d.cout + ch];
+            cd[2 * CTL_PRO_MAX + i] = dy_coef[(gi * 3 + 2) * d.cout + ch];
         }
     }
     __syncthreads();
-    TW_DECL
 
     if (!consumer) {
-        // ================================================================ producers
-        // (priority: the staging is a long chain of short vector instructions with one wave to hide its own latencies, the matrix wave
-        //  needs one issue slot in 32 cycles: whenever the producer can issue it should, the MFMAs fill what is left)
-        __builtin_amdgcn_s_setprio(CTL_X3WPC_PPRIO);
-        constexpr int R = DY2 ? CTL_X3W_PC_SETS_DY2 : CTL_X3W_PC_SETS;
+        // ================================================================ producers: group pg = tid >> 8 stages x chunk 2 gb + pg and dy units pg * 256 ...
+        constexpr int R = 2;
+        const int pg = tid >> 8, ltid = tid & 255;
         const __amdgpu_buffer_rsrc_t rx = ctl_rsrc(x, (int64_t)d.n * d.hin * d.win * d.cin * 4);
         const __amdgpu_buffer_rsrc_t rdy = ctl_rsrc(dy, (int64_t)d.n * d.hout * d.wout * d.cout * 4);
         const __amdgpu_buffer_rsrc_t rdy2 = DY2 ? ctl_rsrc(dy2, (int64_t)d.n * d.hout * d.wout * d.cout * 4) : rdy;
         const __amdgpu_buffer_rsrc_t rnone = ctl_rsrc((const void*)nullptr, 0);
         XS xs;
-        xs.init(d);
-        // dy tile: units of 8 channels (two 16-byte fp32 loads); a thread's units share (cout chunk, half): 256 % 4 == 0
-        constexpr int DU = G::TP * 4, ND = DU / 256;
-        static_assert(DU % 256 == 0, "dy units");
-        struct DyPay { f32x4 v0[ND], v1[ND], w0[DY2 ? ND : 1], w1[DY2 ? ND : 1]; unsigned mask; };
-        int drel[ND], drc[ND], dlds[ND];
+        xs.init(d, ltid);
+        static_assert(G::TP * 4 == 512, "one dy unit (8 channels of a pixel) per producer thread");
+        struct DyPay { f32x4 v0, v1, w0, w1; bool in; };
         const int drest = tid & 3, dt_ = drest >> 1, dh = drest & 1;
-        const int dco = cb * 32 + dt_ * 16 + dh * 8;        // first channel of this thread's units
-#pragma unroll
-        for (int i = 0; i < ND; ++i) {
-            const int u = tid + i * 256;
-            const int pix = u >> 2;
-            const int pr = pix / TW, pc = pix % TW;
-            drc[i] = pr | (pc << 16);
-            drel[i] = ((pr * d.wout + pc) * d.cout + dco) * 4;
-            dlds[i] = dt_ * DCH + pix * 32 + dh * 16;
-        }
-        f32x4 bs0 = {0.f, 0.f, 0.f, 0.f}, bs1 = bs0;        // bias gradient: this thread's 8 channels over its pixels (fp32, before the split)
+        const int dco = cb * 32 + dt_ * 16 + dh * 8;
+        const int dpix = tid >> 2, dpr = dpix / TW, dpc = dpix % TW;
+        const int drel = ((dpr * d.wout + dpc) * d.cout + dco) * 4;
+        const int dlds = dt_ * DCH + dpix * 32 + dh * 16;
+        f32x4 bs0 = {0.f, 0.f, 0.f, 0.f}, bs1 = bs0;
         auto dyload = [&](DyPay& P, int n, int ho0, int wo0, bool live) {
             const int tb = ((n * d.hout + ho0) * d.wout + wo0) * d.cout * 4;
-            unsigned m = 0;
-#pragma unroll
-            for (int i = 0; i < ND; ++i) {
-                const bool ok = live && (unsigned)(ho0 + (drc[i] & 0xffff)) < (unsigned)d.hout && (unsigned)(wo0 + (drc[i] >> 16)) < (unsigned)d.wout;
-                const int vo = ok ? (tb + drel[i]) : CTL_OOB, vo1 = ok ? (tb + drel[i] + 16) : CTL_OOB;
-                P.v0[i] = ctl_bload4(rdy, vo); P.v1[i] = ctl_bload4(rdy, vo1);
-                if constexpr (DY2) { P.w0[i] = ctl_bload4(rdy2, vo); P.w1[i] = ctl_bload4(rdy2, vo1); }
-                m |= ok ? (1u << i) : 0u;
-            }
-            P.mask = m;
+            const bool ok = live && (unsigned)(ho0 + dpr) < (unsigned)d.hout && (unsigned)(wo0 + dpc) < (unsigned)d.wout;
+            const int vo = ok ? (tb + drel) : CTL_OOB, vo1 = ok ? (tb + drel + 16) : CTL_OOB;
+            P.v0 = ctl_bload4(rdy, vo); P.v1 = ctl_bload4(rdy, vo1);
+            if constexpr (DY2) { P.w0 = ctl_bload4(rdy2, vo); P.w1 = ctl_bload4(rdy2, vo1); }
+            P.in = ok;
         };
         auto dystore = [&](const DyPay& P, unsigned char* dyt, int goff) {
-            f32x4 a0, a1, b0, b1, c0, c1;
-            if constexpr (DY2) {
+            f32x4 lo = P.v0, hi = P.v1;
+            if constexpr (DY2) {      // pixels past the image contribute nothing (C alone would)
                 const float* cc = cd + goff + dco;
-                a0 = *reinterpret_cast<const f32x4*>(cc); a1 = *reinterpret_cast<const f32x4*>(cc + 4);
-                b0 = *reinterpret_cast<const f32x4*>(cc + CTL_PRO_MAX); b1 = *reinterpret_cast<const f32x4*>(cc + CTL_PRO_MAX + 4);
-                c0 = *reinterpret_cast<const f32x4*>(cc + 2 * CTL_PRO_MAX); c1 = *reinterpret_cast<const f32x4*>(cc + 2 * CTL_PRO_MAX + 4);
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(cc), a1 = *reinterpret_cast<const f32x4*>(cc + 4);
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(cc + CTL_PRO_MAX), b1 = *reinterpret_cast<const f32x4*>(cc + CTL_PRO_MAX + 4);
+                const f32x4 c0 = *reinterpret_cast<const f32x4*>(cc + 2 * CTL_PRO_MAX), c1 = *reinterpret_cast<const f32x4*>(cc + 2 * CTL_PRO_MAX + 4);
+                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                lo = P.in ? (a0 * lo + b0 * P.w0 + c0) : zero;
+                hi = P.in ? (a1 * hi + b1 * P.w1 + c1) : zero;
             }
-            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int i = 0; i < ND; ++i) {
-                f32x4 lo = P.v0[i], hi = P.v1[i];
-                if constexpr (DY2) {      // pixels past the image contribute nothing (C alone would)
-                    const bool in = (P.mask >> i) & 1u;
-                    lo = in ? (a0 * lo + b0 * P.w0[i] + c0) : zero;
-                    hi = in ? (a1 * hi + b1 * P.w1[i] + c1) : zero;
-                }
-                bs0 += lo; bs1 += hi;
-                u32x4 ph, pm, pl;
-                x3_split8(lo, hi, ph, pm, pl);
-                *reinterpret_cast<u32x4*>(dyt + dlds[i]) = ph;
-                *reinterpret_cast<u32x4*>(dyt + dlds[i] + DYI) = pm;
-                *reinterpret_cast<u32x4*>(dyt + dlds[i] + 2 * DYI) = pl;
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            bs0 += lo; bs1 += hi;
+            u32x4 ph, pm, pl;
+            x3_split8(lo, hi, ph, pm, pl);
+            *reinterpret_cast<u32x4*>(dyt + dlds) = ph;
+            *reinterpret_cast<u32x4*>(dyt + dlds + DYI) = pm;
+            *reinterpret_cast<u32x4*>(dyt + dlds + 2 * DYI) = pl;
         };
-        struct Set { typename XS::Pay xa, xb; DyPay dyp; };
+        struct Set { typename XS::Pay xa; DyPay dyp; };
         Set P[R];
         int s_n[R];
         TileWalk lw;
@@ -494,8 +428,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_x3pc_kernel(const wg_group 
         int lit = 0;
         auto load_step = [&](Set& st, int& sn) {
             const bool live = lit < my_tiles;
-            xs.template load<true>(st.xa, rx, rx, d, lw.n, lw.th * G::TH, lw.tw * TW, 2 * gb, live);
-            xs.template load<true>(st.xb, rx, rx, d, lw.n, lw.th * G::TH, lw.tw * TW, 2 * gb + 1, live);
+            xs.template load<true>(st.xa, rx, rx, d, lw.n, lw.th * G::TH, lw.tw * TW, 2 * gb + pg, live);
             dyload(st.dyp, lw.n, lw.th * G::TH, lw.tw * TW, live);
             sn = lw.n;
             ++lit;
@@ -503,18 +436,13 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_x3pc_kernel(const wg_group 
         };
 #pragma unroll
         for (int r = 0; r < R; ++r) load_step(P[r], s_n[r]);
-        TW(8)
         auto step = [&](int it, Set& st, int& sn, bool more) {
             unsigned char* img = smem + (it & 1) * IMG;
             const int grp = sn / group_n;
-            xs.template store<true>(st.xa, reinterpret_cast<float*>(img), d, 2 * gb, cf_scale, cf_shift, grp * d.cin, nullptr, rnone, false);
-            xs.template store<true>(st.xb, reinterpret_cast<float*>(img + XCH), d, 2 * gb + 1, cf_scale, cf_shift, grp * d.cin, nullptr, rnone, false);
+            xs.template store<true>(st.xa, reinterpret_cast<float*>(img + pg * XCH), d, 2 * gb + pg, cf_scale, cf_shift, grp * d.cin, nullptr, rnone, false);
             dystore(st.dyp, img + XBYTES, grp * d.cout);
-            TW(0)
             if (more) load_step(st, sn);
-            TW(1)
             ctl_barrier_lds_writes_done();
-            TW(2)
         };
         const int full = (my_tiles / R) * R;
         for (int it0 = 0; it0 < full; it0 += R) {
@@ -524,116 +452,106 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_x3pc_kernel(const wg_group 
 #pragma unroll
         for (int r = 0; r < R - 1; ++r)
             if (full + r < my_tiles) step(full + r, P[r], s_n[r], false);
-        // ---- the end of the block: bias sums into their own LDS region, then the consumers' reduction rounds (barriers only)
         *reinterpret_cast<f32x4*>(bsred + tid * 8) = bs0;
         *reinterpret_cast<f32x4*>(bsred + tid * 8 + 4) = bs1;
         ctl_barrier_lds_writes_done();                       // E1
-        if (gb == 0 && b_partial != nullptr && tid < 32) {  // thread -> channel cb * 32 + tid: its (cout chunk, half) slots, fixed order
+        if (gb == 0 && b_partial != nullptr && tid < 32) {
             const int t = tid >> 4, c = tid & 15, h = c >> 3, j = c & 7;
             float v = 0.f;
-            for (int sl = t * 2 + h; sl < 256; sl += 4) v += bsred[sl * 8 + j];
+            for (int sl = t * 2 + h; sl < 512; sl += 4) v += bsred[sl * 8 + j];
             const int co = cb * 32 + tid;
             if (co < cout_p) b_partial[(int64_t)job_s * cout_p + co] = v;
         }
 #pragma unroll
         for (int t0 = 0; t0 < TAPS; t0 += RT) {
-            ctl_barrier_lds_reads_done();                    // the round's sums are written
-            if (t0 + RT < TAPS) ctl_barrier_lds_reads_done(); // ... and read
+            ctl_barrier_lds_reads_done();
+            if (t0 + RT < TAPS) ctl_barrier_lds_reads_done();
         }
-        TW_FLUSH(false)
         return;
     }
-    // ================================================================ consumers
-    __builtin_amdgcn_s_setprio(CTL_X3WPC_CPRIO);
-    f32x16 acc[TAPS];
-#pragma unroll
-    for (int a = 0; a < TAPS; ++a)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+    // ================================================================ consumers: wave cw = (rows 2 (cw & 3), 2 (cw & 3) + 1; tap half cw >> 2)
+    const int cw = wave_all - 8, wave = cw & 3, half = cw >> 2;
     const int q = lane >> 4, chunk = q & 1, phalf = q >> 1;
     const int qp = (lane & 15) >> 2, pp = lane & 3;
-    // per-lane byte offsets inside a step image (split 0, tile row 0, tap (0, 0)); rows, taps and splits are compile-time immediates
     const int a_off = chunk * XCH + (8 * phalf + qp) * 32 + pp * 8;
     const int b_off = XBYTES + chunk * DCH + (8 * phalf + qp) * 32 + pp * 8;
-    for (int it = 0; it < my_tiles; ++it) {
-        ctl_barrier_lds_reads_done();                        // tile `it` is staged; this wave's reads of tile it - 1 were consumed
-#ifdef CTL_TIMING_X3W
-        if (it == 0) TW(6) else TW(3)
-        TW_COUNT(5)
-#endif
-        const unsigned char* img = smem + (it & 1) * IMG;
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-            const int tr = 2 * wave + rr;                    // tile row of this k-step (runtime: one address add per row)
-            const unsigned char* arow = img + a_off + tr * (G::IWP * 32);
-            const unsigned char* brow = img + b_off + tr * (TW * 32);
-            x3_bf16x8 bf[3];
-#pragma unroll
-            for (int sp = 0; sp < 3; ++sp) bf[sp] = x3_tr_read8(brow + sp * DYI, brow + sp * DYI + 4 * 32);
-            auto a_operand = [&](int tap, x3_bf16x8* af) {
-                const int kh = tap / KS, kw = tap % KS;
-                const unsigned char* a0 = arow + (kh * G::IWP + kw) * 32;
-#pragma unroll
-                for (int sp = 0; sp < 3; ++sp) af[sp] = x3_tr_read8(a0 + sp * XS::SPLIT, a0 + sp * XS::SPLIT + 4 * 32);
-            };
-            x3_bf16x8 af[2][3];
-            a_operand(0, af[0]);
-#pragma unroll
-            for (int tap = 0; tap < TAPS; ++tap) {
-                if (tap + 1 < TAPS) a_operand(tap + 1, af[(tap + 1) & 1]);
-                x3_bf16x8* a = af[tap & 1];
-                asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]) : : "memory");
-#if defined(CTL_X3WPC_ABLATE) && (CTL_X3WPC_ABLATE & 1)      // (timing ablation, WRONG results: no matrix instructions)
-                acc[tap][0] += (float)a[0][0] * (float)bf[0][0] + (float)a[1][0] * (float)bf[1][0] + (float)a[2][0] * (float)bf[2][0];
-#else
-                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], bf[0], acc[tap], 0, 0, 0);
-                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bf[2], acc[tap], 0, 0, 0);
-                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bf[1], acc[tap], 0, 0, 0);
-                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bf[0], acc[tap], 0, 0, 0);
-                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bf[1], acc[tap], 0, 0, 0);
-                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bf[0], acc[tap], 0, 0, 0);
-#endif
-            }
-        }
-        TW(4)
-    }
-    ctl_barrier_lds_reads_done();                            // E1: every wave has left the last image
-    // ---------------- the four waves' sums through LDS, RT taps per round; thread -> (register r, lane l) of a tap: ci = 8 (r >> 2) + 4 (l >> 5) + (r & 3)
     float* red = reinterpret_cast<float*>(smem);
-    const int ctid = tid - 256;
+    const int ctid = tid - 512;
     const int64_t split_base = (int64_t)job_s * TAPS * cin_p * cout_p;
+    auto consume = [&](auto half_tag) {
+        constexpr int T0 = decltype(half_tag)::value ? TH0 : 0, NTAP = decltype(half_tag)::value ? TAPS - TH0 : TH0;
+        f32x16 acc[NTAP];
 #pragma unroll
-    for (int t0 = 0; t0 < TAPS; t0 += RT) {
+        for (int a = 0; a < NTAP; ++a)
 #pragma unroll
-        for (int tp = 0; tp < RT; ++tp) {
-            const int tap = t0 + tp;
-            if (tap < TAPS) {
-                float* r0 = red + (tp * 4 + wave) * 16 * 64 + lane;
+            for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+        for (int it = 0; it < my_tiles; ++it) {
+            ctl_barrier_lds_reads_done();
+            const unsigned char* img = smem + (it & 1) * IMG;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) r0[r * 64] = acc[tap][r];
-            }
-        }
-        ctl_barrier_lds_writes_done();
+            for (int rr = 0; rr < 2; ++rr) {
+                const int tr = 2 * wave + rr;
+                const unsigned char* arow = img + a_off + tr * (G::IWP * 32);
+                const unsigned char* brow = img + b_off + tr * (TW * 32);
+                x3_bf16x8 bf[3];
 #pragma unroll
-        for (int tp = 0; tp < RT; ++tp) {
-            const int tap = t0 + tp;
-            if (tap < TAPS) {
+                for (int sp = 0; sp < 3; ++sp) bf[sp] = x3_tr_read8(brow + sp * DYI, brow + sp * DYI + 4 * 32);
+                auto a_operand = [&](int tap, x3_bf16x8* af) {
+                    const int kh = tap / KS, kw = tap % KS;
+                    const unsigned char* a0 = arow + (kh * G::IWP + kw) * 32;
 #pragma unroll
-                for (int e0 = 0; e0 < 16 * 64; e0 += 256) {
-                    const int e = e0 + ctid, r = e >> 6, l = e & 63;
-                    float v = 0.f;
+                    for (int sp = 0; sp < 3; ++sp) af[sp] = x3_tr_read8(a0 + sp * XS::SPLIT, a0 + sp * XS::SPLIT + 4 * 32);
+                };
+                x3_bf16x8 af[2][3];
+                a_operand(T0, af[0]);
 #pragma unroll
-                    for (int w = 0; w < 4; ++w) v += red[((tp * 4 + w) * 16 + r) * 64 + l];
-                    const int co = cb * 32 + (l & 31);
-                    const int ci = gb * 32 + 8 * (r >> 2) + 4 * (l >> 5) + (r & 3);
-                    if (co < cout_p && ci < cin_p) w_partial[split_base + ((int64_t)tap * cin_p + ci) * cout_p + co] = v;
+                for (int t = 0; t < NTAP; ++t) {
+                    if (t + 1 < NTAP) a_operand(T0 + t + 1, af[(t + 1) & 1]);
+                    x3_bf16x8* a = af[t & 1];
+                    asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]) : : "memory");
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], bf[0], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bf[2], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bf[1], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bf[0], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bf[1], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bf[0], acc[t], 0, 0, 0);
                 }
             }
         }
-        if (t0 + RT < TAPS) ctl_barrier_lds_reads_done();
-    }
-    TW(7)
-    TW_FLUSH(true)
+        ctl_barrier_lds_reads_done();                        // E1
+        // ---- the sums of the four row waves of every tap through LDS, RT taps per round (each tap is owned by one tap half)
+#pragma unroll
+        for (int t0 = 0; t0 < TAPS; t0 += RT) {
+#pragma unroll
+            for (int tp = 0; tp < RT; ++tp) {
+                const int tap = t0 + tp;
+                if (tap < TAPS && tap >= T0 && tap < T0 + NTAP) {
+                    float* r0 = red + (tp * 4 + wave) * 16 * 64 + lane;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) r0[r * 64] = acc[(tap - T0) < NTAP ? (tap - T0) : 0][r];
+                }
+            }
+            ctl_barrier_lds_writes_done();
+#pragma unroll
+            for (int tp = 0; tp < RT; ++tp) {
+                const int tap = t0 + tp;
+                if (tap < TAPS) {
+#pragma unroll
+                    for (int e0 = 0; e0 < 16 * 64; e0 += 512) {
+                        const int e = e0 + ctid, r = e >> 6, l = e & 63;
+                        float v = 0.f;
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) v += red[((tp * 4 + w) * 16 + r) * 64 + l];
+                        const int co = cb * 32 + (l & 31);
+                        const int ci = gb * 32 + 8 * (r >> 2) + 4 * (l >> 5) + (r & 3);
+                        if (co < cout_p && ci < cin_p) w_partial[split_base + ((int64_t)tap * cin_p + ci) * cout_p + co] = v;
+                    }
+                }
+            }
+            if (t0 + RT < TAPS) ctl_barrier_lds_reads_done();
+        }
+    };
+    if (half) consume(std::true_type{}); else consume(std::false_type{});
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -695,11 +613,11 @@ static void wgrad3_fill_member(wg_member& m, const wgrad3_call& a, int job0) {
 static void wgrad3_launch_group(const wg_group& g, int jobs, int mode, bool dy2, hipStream_t stream) {
     const dim3 grid((unsigned)jobs);
     if (mode == CTL_IN_PLAIN) {
-        if (dy2) conv_wgrad_x3pc_kernel<3, 1, CTL_IN_PLAIN, true><<<grid, dim3(512), 0, stream>>>(g);
-        else conv_wgrad_x3pc_kernel<3, 1, CTL_IN_PLAIN, false><<<grid, dim3(512), 0, stream>>>(g);
+        if (dy2) conv_wgrad_x3pc16_kernel<3, 1, CTL_IN_PLAIN, true><<<grid, dim3(1024), 0, stream>>>(g);
+        else conv_wgrad_x3pc16_kernel<3, 1, CTL_IN_PLAIN, false><<<grid, dim3(1024), 0, stream>>>(g);
     } else {
-        if (dy2) conv_wgrad_x3pc_kernel<3, 1, CTL_IN_UP2, true><<<grid, dim3(512), 0, stream>>>(g);
-        else conv_wgrad_x3pc_kernel<3, 1, CTL_IN_UP2, false><<<grid, dim3(512), 0, stream>>>(g);
+        if (dy2) conv_wgrad_x3pc16_kernel<3, 1, CTL_IN_UP2, true><<<grid, dim3(1024), 0, stream>>>(g);
+        else conv_wgrad_x3pc16_kernel<3, 1, CTL_IN_UP2, false><<<grid, dim3(1024), 0, stream>>>(g);
     }
 }
 template <int MODE>
