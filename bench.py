@@ -660,7 +660,7 @@ def main():
             t = json.load(open(tfile)).get(args.dtype, {})
             if out["roofline"]["kernel"] in t.get("kernels", {}):
                 out["roofline"]["traffic"] = t["kernels"][out["roofline"]["kernel"]]["hbm_bytes_per_launch"]
-                out["roofline"]["traffic_source"] = t.get("source", "profiles/kernel_traffic.json")
+                out["roofline"]["traffic_source"] = t["kernels"][out["roofline"]["kernel"]].get("source") or t.get("source", "profiles/kernel_traffic.json")
         if prof_all:
             out["roofline_families"] = family_rooflines(prof_all, args.dtype, SINGLE_STREAM_STEPS)
             out["kernels_by_serial_time"] = [{"kernel": k, "ms_per_step": v["ms"] / SINGLE_STREAM_STEPS, "launches_per_step": v["launches"] / SINGLE_STREAM_STEPS,

@@ -31,13 +31,13 @@ enum ctl_status { CTL_OK = 0, CTL_EINVAL = -1, CTL_EUNSUPPORTED = -2, CTL_ELAUNC
  * ctl_version() with the CTL_ABI_VERSION they were written against (and ctl_sizeof_conv / ctl_sizeof_op with their struct sizes)
  * at load time and refuse to run on a mismatch.  3 = round 3: fused-finalize entry points and side lanes removed, `ds` argument of
  * ctl_bwd_reduce_dt, ctl_red_blocks().  4 = CTL_EPI_TAILBWD / ctl_conv_forward_ex (plan op CONV slot 10).
- * 10 = grouped weight gradients: ctl_wgrad_group_class / ctl_wgrad_group_plan / ctl_conv_wgrad_group, plan op CTL_OP_WGRAD_GROUP.
  * 5 = ctl_bn_finalize_ex (save_uvar, plan op BN_FINALIZE slot 10), ctl_bn_replay_running / CTL_OP_BN_REPLAY.
  * 6 = the BatchNorm-backward prologue: ctl_conv.pro_affine == 2 + the x2 argument of ctl_conv_forward_ex (plan op CONV slot 11),
  *     ctl_conv_wgrad_ex (plan op WGRAD slots 6, 7); CTL_EPI_TAILBWD in the bf16 family.
  * 7 = the `pool` argument of ctl_conv_forward_ex (plan op CONV slot 12; CTL_OP_MAX_T 12 -> 14: sizeof(ctl_op) 304 -> 328), ctl_conv_pool_ok.
  * 8 = the `xout` argument of ctl_conv_forward_ex (plan op CONV slot 13).
- * 9 = CTL_DT_X3 / CTL_PACK_X3, ctl_conv_wpack_floats_x3, ctl_pack_weights_x3_batched; plan op PACK_BATCH i[1] is a bit mask. */
+ * 9 = CTL_DT_X3 / CTL_PACK_X3, ctl_conv_wpack_floats_x3, ctl_pack_weights_x3_batched; plan op PACK_BATCH i[1] is a bit mask.
+ * 10 = grouped weight gradients: ctl_wgrad_group_class / ctl_wgrad_group_plan / ctl_conv_wgrad_group, plan op CTL_OP_WGRAD_GROUP. */
 #define CTL_ABI_VERSION 10
 int         ctl_version(void);
 const char* ctl_last_error(void);
