@@ -62,6 +62,26 @@ __device__ __forceinline__ double block_sum_double(double v, double* sm) {
 // (ldq / stq, the storage-type aware quad accessors, live in ctl_common.h)
 
 // ------------------------------------------------------------------------------------------------ BatchNorm forward
+// Phase timers of the forward finalize (variant build -DCTL_TIMING_FIN; tools/debug/fin_timing.py reads them with ctl_debug_timing_fin): s_memtime
+// cycles of thread 0 of block 0 summed over the launches: [0] until the rows have arrived, [1] block sum, [2] coefficient arithmetic + stores
+// acknowledged, [3] launches, [4] sum of rows, [5] sum of groups; [6] realtime (100 MHz) from the kernel's first instruction to its last
+#ifdef CTL_TIMING_FIN
+__device__ unsigned long long ctl_tmf[8];
+#define FT_DECL unsigned long long ft_prev = __builtin_amdgcn_s_memtime(), ft_acc[3] = {0, 0, 0}; const unsigned long long ft_r0 = __builtin_amdgcn_s_memrealtime();
+#define FT(i) { __builtin_amdgcn_s_waitcnt(0); const unsigned long long ft_now = __builtin_amdgcn_s_memtime(); ft_acc[i] += ft_now - ft_prev; ft_prev = ft_now; }
+#define FT_FLUSH if (blockIdx.x == 0 && threadIdx.x == 0) { for (int i_ = 0; i_ < 3; ++i_) atomicAdd(&ctl_tmf[i_], ft_acc[i_]); atomicAdd(&ctl_tmf[3], 1ull); \
+                     atomicAdd(&ctl_tmf[4], (unsigned long long)blocks); atomicAdd(&ctl_tmf[5], (unsigned long long)groups); \
+                     atomicAdd(&ctl_tmf[6], __builtin_amdgcn_s_memrealtime() - ft_r0); }
+extern "C" int ctl_debug_timing_fin(unsigned long long* out8) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(ctl_tmf), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(ctl_tmf), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+#else
+#define FT_DECL
+#define FT(i)
+#define FT_FLUSH
+#endif
 __global__ __launch_bounds__(EB) void bn_finalize_kernel(const float* __restrict__ partial, int blocks, int c,
                                                           double count, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float eps, float momentum,
@@ -72,6 +92,7 @@ __global__ __launch_bounds__(EB) void bn_finalize_kernel(const float* __restrict
                                                           float* __restrict__ save_invstd, int groups, float* __restrict__ save_uvar) {
     __shared__ double sm[16];
     const int ch = blockIdx.x;
+    FT_DECL
     ctl_bn_chan p = {};
     if (threadIdx.x == 0) p = ctl_bn_chan_load(ch, gamma, beta, update_running, running_mean, running_var);
     // groups = independent passes batched along n: one set of coefficients each; the running statistics see them in order,
@@ -79,13 +100,17 @@ __global__ __launch_bounds__(EB) void bn_finalize_kernel(const float* __restrict
     for (int g = 0; g < groups; ++g) {
         double s1 = 0.0, s2 = 0.0;
         sum_rows2(partial, (int64_t)g * blocks, blocks, c, ch, s1, s2);
+        FT(0)
         block_sum_double2(s1, s2, sm);
+        FT(1)
         if (threadIdx.x == 0) {
             ctl_bn_coefs(s1, s2, count, c, g, ch, p, eps, momentum, update_running, running_mean, running_var, scale, shift, save_mean,
                          save_invstd, save_uvar);
             if (update_running && ch == 0 && nbt) nbt[0] += 1;
         }
+        FT(2)
     }
+    FT_FLUSH
 }
 
 __global__ void bn_eval_kernel(int c, const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
@@ -669,6 +694,9 @@ extern "C" int ctl_bn_replay_running(const void* act, float* buffers, int64_t* n
     return CTL_OK;
 }
 
+#ifdef CTL_TUNING
+__global__ void fin_empty_kernel(float* p) { if (p == nullptr) p[0] = 0.f; }
+#endif
 extern "C" int ctl_bn_finalize(const float* partial, int32_t blocks, int32_t c, int64_t count, const float* gamma,
                                const float* beta, float eps, float momentum, int32_t update_running,
                                float* running_mean, float* running_var, int64_t* nbt, float* scale, float* shift,
@@ -682,6 +710,14 @@ extern "C" int ctl_bn_finalize_ex(const float* partial, int32_t blocks, int32_t 
                                   float* save_mean, float* save_invstd, float* save_uvar, int32_t groups, ctl_stream stream) {
     CTL_REQUIRE(partial && gamma && beta && scale && shift && blocks > 0 && c > 0 && count > 0 && groups >= 1, "bn_finalize: bad arguments");
     CTL_REQUIRE(!update_running || (running_mean && running_var), "bn_finalize: update_running without buffers");
+#ifdef CTL_TUNING      // ceiling probe (wrong numbers): 1 = an empty kernel of the same grid, 2 = ONE wave that does nothing (tools/debug/fin_empty_probe.sh)
+    static const int fin_empty = ctl_tune_int("CTL_FIN_EMPTY", 0);
+    if (fin_empty) {
+        fin_empty_kernel<<<dim3(fin_empty == 2 ? 1 : c), dim3(fin_empty == 2 ? 64 : CTL_FIN_THREADS), 0, S_>>>(scale);
+        CTL_LAUNCH_CHECK("bn_finalize");
+        return CTL_OK;
+    }
+#endif
     bn_finalize_kernel<<<dim3(c), dim3(CTL_FIN_THREADS), 0, S_>>>(partial, blocks, c, (double)count, gamma, beta, eps, momentum,
                                                       update_running, running_mean, running_var, nbt, scale, shift,
                                                       save_mean, save_invstd, groups, save_uvar);
