@@ -146,6 +146,13 @@ int ctl_wgrad_bf16_splits(const ctl_conv* d);
 int ctl_conv_wgrad_bf16(const ctl_conv* d, const void* x, const float* pro_scale, const float* pro_shift, const void* dy, const void* dy2,
                         const float* dy_coef, float* w_partial, float* b_partial, ctl_stream stream);
 
+// stacked grouped launches of the bf16 weight gradients (ctl_wgrad_bf16.hip), reached through ctl_wgrad_group_class / ctl_conv_wgrad_group
+int ctl_wgrad_bf16_group_class(const ctl_conv* d, int has_dy2);      // 0x100 | instantiation key, or -1
+int ctl_wgrad_bf16_group_plan(const ctl_conv* descs, int n, int32_t* splits);
+int ctl_conv_wgrad_bf16_group(int n, const ctl_conv* descs, const int32_t* splits, const void* const* x, const float* const* pro_scale,
+                              const float* const* pro_shift, const void* const* dy, const void* const* dy2, const float* const* dy_coef,
+                              float* const* w_partial, float* const* b_partial, ctl_stream stream);
+
 // X3 half of the fp32-storage family (ctl_conv_x3.hip), reached through the public entry points when ctl_conv.dt has CTL_DT_X3
 int ctl_conv_x3_ok(const ctl_conv* d);
 int ctl_conv_x3_stats_blocks(const ctl_conv* d);

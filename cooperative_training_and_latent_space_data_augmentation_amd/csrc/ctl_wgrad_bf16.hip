@@ -24,13 +24,15 @@ __device__ __forceinline__ bf16x8 tr_read8(const unsigned char* a0, const unsign
 // global load right where it is issued (seen in the ISA: buffer_load, s_waitcnt vmcnt(0), scratch_store) -- no prefetch left at all.
 // XK / DYK: the same compile-time storage kinds as XStage16's X16C for x and for dy (1 bf16 with whole chunks, 2 fp32 quads, 3 fp32 single
 // channel, 0 run time); BB = both bf16.  The network-boundary layers are (fp32 x, bf16 dy) first layers and (bf16 x, fp32 dy) output layers.
-template <int KS, int S, int MODE, int MT, int NTW, bool DY2 = false, int XK = 0, int DYK = 0>
-__global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const ctl_conv d, const void* __restrict__ x,
-                                                               const float* __restrict__ pro_scale, const float* __restrict__ pro_shift,
-                                                               const void* __restrict__ dy, const void* __restrict__ dy2,
-                                                               const float* __restrict__ dy_coef, float* __restrict__ w_partial,
-                                                               float* __restrict__ b_partial, int tiles_h, int tiles_w, int ntiles,
-                                                               int cin_p, int cout_p) {
+// The kernel body takes its place in the launch as arguments (BX of GX pixel splits, cin chunk BY, cout tile pair BZ): the single launch passes
+// blockIdx / gridDim, the grouped launch (below) the member's own coordinates.
+template <int KS, int S, int MODE, int MT, int NTW, bool DY2, int XK, int DYK>
+__device__ __forceinline__ void wgrad16_body(const ctl_conv& d, const void* __restrict__ x,
+                                             const float* __restrict__ pro_scale, const float* __restrict__ pro_shift,
+                                             const void* __restrict__ dy, const void* __restrict__ dy2,
+                                             const float* __restrict__ dy_coef, float* __restrict__ w_partial,
+                                             float* __restrict__ b_partial, int tiles_h, int tiles_w, int ntiles,
+                                             int cin_p, int cout_p, const int BX, const int BY, const int BZ, const int GX) {
     constexpr int TW = 16;
     using G = Geom<KS, S, MT, TW>;
     using XS = XStage16<KS, S, MODE, MT, TW, XK>;
@@ -51,8 +53,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const ctl_conv d, 
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int p = lane & 15, q = lane >> 4;
-    const int g = blockIdx.y;
-    const int cot0 = blockIdx.z * NTW;
+    const int g = BY;
+    const int cot0 = BZ * NTW;
     const int group_n = d.n / (d.groups > 1 ? d.groups : 1);
     const bool dy16 = DYK == 1 || (DYK == 0 && (d.dt & CTL_DT_Y16) != 0);
     const int des = dy16 ? 2 : 4;
@@ -158,8 +160,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const ctl_conv d, 
     const int qp = (lane & 15) >> 2, pp = lane & 3;
     const int krow = (q >> 1), kcol0 = 8 * (q & 1);     // tile row (within the k-block's two rows) and first column of this lane group
     TileWalk cur;
-    cur.init(blockIdx.x, gridDim.x, tiles_h, tiles_w);
-    if ((int)blockIdx.x < ntiles) {
+    cur.init(BX, GX, tiles_h, tiles_w);
+    if (BX < ntiles) {
         xs.load(rx, d, cur.n, cur.th * G::TH, cur.tw * TW, g);
         dyload(cur.n, cur.th * G::TH, cur.tw * TW);
     }
@@ -175,13 +177,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const ctl_conv d, 
         }
         __syncthreads();
     }
-    if ((int)blockIdx.x < ntiles) {
+    if (BX < ntiles) {
         xs.store(xt, d, g, cf_scale, cf_shift, (cur.n / group_n) * d.cin);
         dystore((cur.n / group_n) * d.cout);
     }
     __syncthreads();
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const bool has_next = tile + (int)gridDim.x < ntiles;
+    for (int tile = BX; tile < ntiles; tile += GX) {
+        const bool has_next = tile + GX < ntiles;
         if (has_next) {
             cur.next();
             xs.load(rx, d, cur.n, cur.th * G::TH, cur.tw * TW, g);
@@ -231,7 +233,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const ctl_conv d, 
     constexpr int TAP_FLOATS = 4 * NTW * 256;
     constexpr int TPR = (MAIN_BYTES / 4 / TAP_FLOATS) < TAPS ? (MAIN_BYTES / 4 / TAP_FLOATS) : TAPS;
     static_assert(TPR >= 1, "reduction scratch");
-    const int64_t split_base = (int64_t)blockIdx.x * TAPS * cin_p * cout_p;
+    const int64_t split_base = (int64_t)BX * TAPS * cin_p * cout_p;
 #pragma unroll
     for (int tap0 = 0; tap0 < TAPS; tap0 += TPR) {
         if (tap0 > 0) ctl_barrier_lds_reads_done();
@@ -280,16 +282,63 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const ctl_conv d, 
 #pragma unroll
             for (int w = 0; w < 4; ++w) v += red[w * NTW * 16 + tid];
             const int co = cot0 * 16 + tid;
-            if (co < cout_p) b_partial[(int64_t)blockIdx.x * cout_p + co] = v;
+            if (co < cout_p) b_partial[(int64_t)BX * cout_p + co] = v;
         }
     }
+}
+
+template <int KS, int S, int MODE, int MT, int NTW, bool DY2 = false, int XK = 0, int DYK = 0>
+__global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const ctl_conv d, const void* __restrict__ x,
+                                                               const float* __restrict__ pro_scale, const float* __restrict__ pro_shift,
+                                                               const void* __restrict__ dy, const void* __restrict__ dy2,
+                                                               const float* __restrict__ dy_coef, float* __restrict__ w_partial,
+                                                               float* __restrict__ b_partial, int tiles_h, int tiles_w, int ntiles,
+                                                               int cin_p, int cout_p) {
+    wgrad16_body<KS, S, MODE, MT, NTW, DY2, XK, DYK>(d, x, pro_scale, pro_shift, dy, dy2, dy_coef, w_partial, b_partial, tiles_h, tiles_w, ntiles, cin_p, cout_p,
+                                                    (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x);
+}
+
+// ---- grouped launch (round 5): up to CTL_WG16_MAX weight gradients of ONE kernel instantiation stacked along blockIdx.x, each with its own
+// pixel-split count (ctl_wgrad_group_plan deals the chip's resident blocks to the members in proportion to their work: a member of a group
+// walks more tiles per block, writes fewer partial sums, and its blocks start while its predecessor's drain).  With the split count of a launch
+// of its own a member's partial sums are bit for bit those of ctl_conv_wgrad_ex.  The bf16 step is launch-bound (~900 launches in 9.5 ms), its
+// weight gradients take 6-20 us each; stacked with their own full grids they measured only 10 % less serial time (the fixed cost is per BLOCK:
+// coefficient tables, pipeline ramp, cross-wave reduction, partial write), hence the proportional splits.
+#define CTL_WG16_MAX 8
+struct wg16_member {
+    ctl_conv d;
+    const void *x, *dy, *dy2;
+    const float *pro_scale, *pro_shift, *dy_coef;
+    float *w_partial, *b_partial;
+    int tiles_h, tiles_w, ntiles, cin_p, cout_p;
+    int gx, gy, gz, block0;          // the member's grid and its first block in the stacked launch
+};
+struct wg16_group { int n, pad; wg16_member m[CTL_WG16_MAX]; };
+template <int KS, int S, int MODE, int MT, int NTW, bool DY2, int XK, int DYK>
+__global__ __launch_bounds__(256) void conv_wgrad_bf16_group_kernel(const wg16_group grp) {
+    int mi = 0;
+#pragma unroll
+    for (int i = 1; i < CTL_WG16_MAX; ++i)
+        if (i < grp.n && (int)blockIdx.x >= grp.m[i].block0) mi = i;
+    const wg16_member& M = grp.m[mi];
+    const int local = (int)blockIdx.x - M.block0;
+    const int bx = local % M.gx, t = local / M.gx;
+    wgrad16_body<KS, S, MODE, MT, NTW, DY2, XK, DYK>(M.d, M.x, M.pro_scale, M.pro_shift, M.dy, M.dy2, M.dy_coef, M.w_partial, M.b_partial, M.tiles_h, M.tiles_w,
+                                                    M.ntiles, M.cin_p, M.cout_p, bx, t % M.gy, t / M.gy, M.gx);
 }
 
 struct wgrad16_call {
     const ctl_conv* d; ctl_conv_cfg c; int ntw, splits, ntiles, cin_p, cout_p;
     const void *x, *dy, *dy2; const float *pro_scale, *pro_shift, *dy_coef; float *w_partial, *b_partial;
     hipStream_t stream; bool query;
+    int key;                       // the instantiation the dispatch ends in (members of a grouped launch must agree)
+    int cap;                       // blocks of this instantiation the chip holds at once
+    const wg16_group* grp;         // launch this stacked group instead of the single problem
+    int grp_blocks;
 };
+static inline int wg16_key(int ks, int s, int mode, int mt, int ntw, int dy2, int xk, int dyk) {
+    return ks | (s << 3) | (mode << 5) | (mt << 7) | (ntw << 10) | (dy2 << 12) | (xk << 13) | (dyk << 15);
+}
 template <int KS, int S, int MODE, int MT, int NTW, bool DY2, int XK, int DYK>
 static void wgrad16_go_f(wgrad16_call& a) {
     static int occ = 0;
@@ -309,7 +358,13 @@ static void wgrad16_go_f(wgrad16_call& a) {
     if (splits > a.ntiles) splits = a.ntiles;
     if (splits < 1) splits = 1;
     a.splits = splits;
+    a.cap = 256 * (occ < 4 ? occ : 4);
+    a.key = wg16_key(KS, S, MODE, MT, NTW, DY2, XK, DYK);
     if (a.query) return;
+    if (a.grp) {
+        conv_wgrad_bf16_group_kernel<KS, S, MODE, MT, NTW, DY2, XK, DYK><<<dim3((unsigned)a.grp_blocks), dim3(256), 0, a.stream>>>(*a.grp);
+        return;
+    }
     const dim3 grid((unsigned)splits, (unsigned)a.c.g, (unsigned)(a.c.cot / NTW));
     conv_wgrad_bf16_kernel<KS, S, MODE, MT, NTW, DY2, XK, DYK><<<grid, dim3(256), 0, a.stream>>>(*a.d, a.x, a.pro_scale, a.pro_shift, a.dy, a.dy2, a.dy_coef,
                                                                                         a.w_partial, a.b_partial, a.c.tiles_h, a.c.tiles_w, a.ntiles,
@@ -403,3 +458,94 @@ int ctl_conv_wgrad_bf16(const ctl_conv* d, const void* x, const float* pro_scale
     return CTL_OK;
 }
 
+// ---- grouped launches: class = 0x100 | the instantiation key (ctl_wgrad_group_class), splits = the member's own (ctl_wgrad_group_plan)
+int ctl_wgrad_bf16_group_class(const ctl_conv* d, int has_dy2) {
+    static const int on = ctl_tune_int("CTL16_WGRAD_GROUP", 1);
+    if (!on) return -1;
+    if (has_dy2 && !(d->ks == 3 && d->stride == 1 && (d->dt & CTL_DT_Y16) && d->cout % 16 == 0)) return -1;
+    wgrad16_call a = {};
+    if (wgrad16_pick(d, &a) != CTL_OK) return -1;
+    int dummy = 0;
+    a.dy2 = has_dy2 ? &dummy : nullptr;       // (only its presence selects the instantiation)
+    a.query = true;
+    if (wgrad16_dispatch(a) != CTL_OK) return -1;
+    return 0x100 | a.key;
+}
+int ctl_conv_wgrad_bf16_group(int n, const ctl_conv* descs, const int32_t* splits, const void* const* x, const float* const* pro_scale,
+                              const float* const* pro_shift, const void* const* dy, const void* const* dy2, const float* const* dy_coef,
+                              float* const* w_partial, float* const* b_partial, ctl_stream stream) {
+    CTL_REQUIRE(n >= 1 && n <= CTL_WG16_MAX, "conv_wgrad_group(bf16): 1..%d members", CTL_WG16_MAX);
+    wg16_group g = {};
+    g.n = n;
+    wgrad16_call first = {};
+    int blocks = 0, key = -1;
+    double flops = 0.0, bytes = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const ctl_conv* d = &descs[i];
+        const bool two = dy2 && dy2[i];
+        CTL_REQUIRE(x[i] && dy[i] && w_partial[i] && (!d->pro_affine || (pro_scale && pro_shift && pro_scale[i] && pro_shift[i])) && (!two || (dy_coef && dy_coef[i])),
+                    "conv_wgrad_group(bf16): member %d misses a tensor", i);
+        CTL_REQUIRE(!two || (d->ks == 3 && d->stride == 1 && (d->dt & CTL_DT_Y16) && d->cout % 16 == 0 && (d->groups > 1 ? d->groups : 1) * d->cout <= CTL_PRO_MAX),
+                    "conv_wgrad_group(bf16): member %d: the two-tensor output gradient needs a 3x3 stride-1 conv, bf16-stored dy / dy2, groups * cout <= %d", i, CTL_PRO_MAX);
+        wgrad16_call a = {};
+        int rc = wgrad16_pick(d, &a);
+        if (rc != CTL_OK) return rc;
+        a.dy2 = two ? dy2[i] : nullptr;
+        a.query = true;
+        rc = wgrad16_dispatch(a);
+        if (rc != CTL_OK) return rc;
+        if (i == 0) key = a.key;
+        CTL_REQUIRE(a.key == key, "conv_wgrad_group(bf16): member %d is of another class than member 0", i);
+        CTL_REQUIRE(splits[i] >= 1 && splits[i] <= a.ntiles, "conv_wgrad_group(bf16): member %d: %d splits of %d tiles", i, splits[i], a.ntiles);
+        a.splits = splits[i];
+        wg16_member& m = g.m[i];
+        m.d = *d;
+        m.x = x[i]; m.dy = dy[i]; m.dy2 = a.dy2; m.pro_scale = pro_scale ? pro_scale[i] : nullptr; m.pro_shift = pro_shift ? pro_shift[i] : nullptr;
+        m.dy_coef = dy_coef ? dy_coef[i] : nullptr; m.w_partial = w_partial[i]; m.b_partial = b_partial ? b_partial[i] : nullptr;
+        m.tiles_h = a.c.tiles_h; m.tiles_w = a.c.tiles_w; m.ntiles = a.ntiles; m.cin_p = a.cin_p; m.cout_p = a.cout_p;
+        m.gx = a.splits; m.gy = a.c.g; m.gz = a.c.cot / a.ntw; m.block0 = blocks;
+        blocks += m.gx * m.gy * m.gz;
+        if (i == 0) first = a;
+        const double pix = (double)d->n * d->hout * d->wout;
+        flops += 2.0 * pix * d->cout * d->cin * d->ks * d->ks;
+        bytes += ((d->dt & CTL_DT_X16) ? 2.0 : 4.0) * d->n * d->hin * d->win * d->cin + ((d->dt & CTL_DT_Y16) ? 2.0 : 4.0) * pix * d->cout * (two ? 2 : 1);
+    }
+    char kind[64];
+    snprintf(kind, sizeof(kind), "conv_wgrad_bf16grp<ks%d,s%d,in%d,mt%d,nt%d%s>", key & 7, (key >> 3) & 3, (key >> 5) & 3, (key >> 7) & 7, (key >> 10) & 3, ((key >> 12) & 1) ? ",x2" : "");
+    const int ptok = ctl_prof_begin_raw(kind, flops, bytes, (hipStream_t)stream);
+    first.query = false;
+    first.grp = &g;
+    first.grp_blocks = blocks;
+    first.stream = (hipStream_t)stream;
+    int rc = wgrad16_dispatch(first);
+    if (ptok >= 0) ctl_prof_end(ptok, (hipStream_t)stream);
+    if (rc != CTL_OK) return rc;
+    CTL_LAUNCH_CHECK("conv_wgrad_group(bf16)");
+    return CTL_OK;
+}
+// pixel splits of the members of one stacked launch: the resident blocks of the instantiation, dealt in proportion to the members' work
+int ctl_wgrad_bf16_group_plan(const ctl_conv* descs, int n, int32_t* splits) {
+    CTL_REQUIRE(n >= 1 && n <= CTL_WG16_MAX, "wgrad_group_plan(bf16): 1..%d members", CTL_WG16_MAX);
+    int64_t work[CTL_WG16_MAX], total = 0;
+    int par[CTL_WG16_MAX], ntiles[CTL_WG16_MAX], own[CTL_WG16_MAX], cap = 0;
+    for (int i = 0; i < n; ++i) {
+        wgrad16_call a = {};
+        int rc = wgrad16_pick(&descs[i], &a);
+        if (rc != CTL_OK) return rc;
+        par[i] = a.c.g * (a.c.cot / a.ntw);
+        ntiles[i] = a.ntiles;
+        own[i] = a.splits;
+        if (a.cap > cap) cap = a.cap;
+        work[i] = (int64_t)a.ntiles * par[i];
+        total += work[i];
+    }
+    static const int mode = ctl_tune_int("CTL16_WGRAD_GROUP_SPLITS", 1);      // tuning hook: 0 = every member keeps the splits of a launch of its own
+    for (int i = 0; i < n; ++i) {
+        int sp = (int)(((int64_t)cap * work[i]) / (total * par[i]));
+        if (sp < 1) sp = 1;
+        if (sp > ntiles[i]) sp = ntiles[i];
+        if (sp > own[i] || !mode) sp = own[i];
+        splits[i] = sp;
+    }
+    return CTL_OK;
+}

@@ -713,6 +713,7 @@ int ctl_conv_wgrad_x3(const ctl_conv* d, const float* x, const float* pro_scale,
 // kernel instantiation: input mode | two-tensor output gradient << 1), -1 otherwise.
 extern "C" int ctl_wgrad_group_class(const ctl_conv* d, int32_t has_dy2) {
     static const int on = ctl_tune_int("CTL_X3W_GROUP", 1);
+    if (d && (d->dt & CTL_DT_BF16)) return ctl_wgrad_bf16_group_class(d, has_dy2);      // the bf16 family: stacked launches, class 0x100 | instantiation
     if (!on || !d || !(d->dt & CTL_DT_X3) || !wgrad3_pc_shape_ok(d)) return -1;
     return (d->in_mode == CTL_IN_UP2 ? 1 : 0) | (has_dy2 ? 2 : 0);
 }
@@ -720,6 +721,7 @@ extern "C" int ctl_wgrad_group_class(const ctl_conv* d, int32_t has_dy2) {
 // 32 x 32 output blocks), every member gets at least one split, no split is empty.  The plan compiler sizes the partial buffers from this.
 extern "C" int ctl_wgrad_group_plan(const ctl_conv* descs, int32_t n, int32_t* splits) {
     CTL_REQUIRE(descs && splits && n >= 1 && n <= CTL_WG_MAX, "wgrad_group_plan: 1..%d members", CTL_WG_MAX);
+    if (descs[0].dt & CTL_DT_BF16) return ctl_wgrad_bf16_group_plan(descs, n, splits);
     int64_t work[CTL_WG_MAX], total = 0;
     int par[CTL_WG_MAX], ntiles[CTL_WG_MAX];
     for (int i = 0; i < n; ++i) {
@@ -742,6 +744,9 @@ extern "C" int ctl_conv_wgrad_group(int32_t n, const ctl_conv* descs, const int3
                                     const float* const* pro_shift, const float* const* dy, const float* const* dy2, const float* const* dy_coef,
                                     float* const* w_partial, float* const* b_partial, ctl_stream stream) {
     CTL_REQUIRE(n >= 1 && n <= CTL_WG_MAX && descs && splits && x && dy && w_partial, "conv_wgrad_group: 1..%d members and their tensors", CTL_WG_MAX);
+    if (descs[0].dt & CTL_DT_BF16)
+        return ctl_conv_wgrad_bf16_group(n, descs, splits, (const void* const*)x, pro_scale, pro_shift, (const void* const*)dy, (const void* const*)dy2, dy_coef,
+                                         w_partial, b_partial, stream);
     wg_group g = {};
     g.n = n;
     int jobs = 0;

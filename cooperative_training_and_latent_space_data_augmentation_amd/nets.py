@@ -65,6 +65,8 @@ GROUP_WGRAD = True       # fp32 / X3: the weight gradients of a backward plan th
                          # the plan and served in groups of up to 8 by one launch each (CTL_OP_WGRAD_GROUP): nothing in the plan reads dW, and per
                          # launch ~15 of 40 us are fixed.  Safe to reorder: plan arenas are bump-allocated (no tensor is reused inside a plan) and
                          # every in-place pass on a gradient tensor (apply, accumulate epilogues) is emitted BEFORE the weight gradient that reads it
+GROUP_WGRAD_BF16 = True  # bf16 family: the weight gradients of one kernel instantiation are STACKED in one launch (up to 8; every member keeps the grid
+                         # and the split count of a launch of its own, so its partial sums are bit for bit the same): the bf16 step is launch-bound
 FUSE_TAIL = True         # fp32: the residual tail's BatchNorm-backward reduction inside the launch that writes dOut (CTL_EPI_TAILBWD): dOut is
                          # never materialised, the stand-alone reduction launch (read dOut, out, v; write dS) disappears
 CONV_WORDS = _ffi.CONV_DTYPE.itemsize // 4      # ctl_conv as int32 words at the head of ctl_op.i
@@ -302,7 +304,7 @@ class PlanBuilder:
         dp = _ffi.desc_ptr(d)
         assert dw_ref[0] == S_GRAD and (dbias_ref is None or dbias_ref[0] == S_GRAD)
         refs = [x.ref, pro[0] if pro else None, pro[1] if pro else None, dy.ref, None, None, dy2[0].ref if dy2 else None, dy2[1] if dy2 else None]
-        if GROUP_WGRAD and dt == _ffi.DT_X3:
+        if GROUP_WGRAD and (dt == _ffi.DT_X3 or (GROUP_WGRAD_BF16 and self.b16)):
             cls = int(lib.ctl_wgrad_group_class(dp, 1 if dy2 else 0))
             if cls >= 0:
                 self.pending_wgrads.append(dict(cls=cls, d=d, refs=refs, dw_ref=dw_ref, dbias_ref=dbias_ref, strides=[int(v) for v in strides],

@@ -161,7 +161,11 @@ int ctl_conv_wgrad_ex(const ctl_conv* d, const float* x, const float* pro_scale,
  *   ctl_wgrad_group_plan : the members' pixel splits; member i then needs splits[i] * 9 * cin * cout floats of w_partial (and splits[i] * cout of
  *                          b_partial), laid out and reduced exactly like ctl_conv_wgrad's ([split][tap][cin][cout]; ctl_wgrad_reduce_batched).
  *   ctl_conv_wgrad_group : the launch.  Arrays of n pointers; pro_scale / pro_shift / dy2 / dy_coef / b_partial entries (or the arrays) may be NULL
- *                          where a member has none. */
+ *                          where a member has none.
+ * The bf16 family (CTL_DT_BF16) rides the same three entry points: class = 0x100 | the kernel instantiation its dispatch ends in (any bf16 weight
+ * gradient has one), the launch stacks the members' own grids along blockIdx.x, ctl_wgrad_group_plan deals the resident blocks in proportion to
+ * the work (never more splits than a launch of its own); with splits[i] = ctl_wgrad_splits(d_i) a member's partial sums are bit for bit those of
+ * ctl_conv_wgrad_ex (tests/test_bf16_gpu.py). */
 int ctl_wgrad_group_class(const ctl_conv* d, int32_t has_dy2);
 int ctl_wgrad_group_plan(const ctl_conv* descs, int32_t n, int32_t* splits);
 int ctl_conv_wgrad_group(int32_t n, const ctl_conv* descs, const int32_t* splits, const float* const* x, const float* const* pro_scale,

@@ -98,6 +98,39 @@ def test_deferred_weight_gradients_are_grouped_at_the_end_of_a_backward_plan():
     assert _ffi.OP_WGRAD_GROUP not in k0 and sum(v == _ffi.OP_WGRAD for v in k0) == sum(v == _ffi.OP_WGRAD for v in kinds)
 
 
+def test_bf16_weight_gradients_are_stacked_by_kernel_instantiation():
+    """nets.GROUP_WGRAD_BF16 (round 5): the bf16 family's weight gradients ride in stacked launches too -- class = 0x100 | the kernel instantiation,
+    every member's split count comes from ctl_wgrad_group_plan (at most the count of a launch of its own) and sizes its partial buffer."""
+    model = nets.build_networks(device="cpu", dtype="bf16")
+    enc = model["image_encoder"]
+    f = enc._compile_forward(16, 256, 256, "A")
+    b = enc._compile_backward(f, "A", (True, True), False, True, True)
+    kinds = [int(o["kind"]) for o in b.ops]
+    groups = [k for k, v in enumerate(kinds) if v == _ffi.OP_WGRAD_GROUP]
+    assert len(groups) >= 3 and kinds[-1] == _ffi.OP_WGRAD_REDUCE_BATCH
+    for k in groups:
+        n = int(b.ops[k]["i"][0])
+        cls = set()
+        for m in b.ops[k + 1:k + 1 + n]:
+            assert int(m["kind"]) == _ffi.OP_WGRAD
+            d = np.frombuffer(np.ascontiguousarray(m["i"][:nets.CONV_WORDS]).tobytes(), dtype=_ffi.CONV_DTYPE)[0]
+            assert d["dt"] & _ffi.DT_BF16
+            c = int(_ffi.lib.ctl_wgrad_group_class(_ffi.desc_ptr(np.atleast_1d(d)), 1 if int(m["slot"][6]) >= 0 else 0))
+            assert c >= 0x100
+            cls.add(c)
+            sp = int(m["i"][nets.CONV_WORDS])
+            assert 1 <= sp <= int(_ffi.lib.ctl_wgrad_splits(_ffi.desc_ptr(np.atleast_1d(d))))
+            rec = [r for r in b.table_np if int(r[0]) * 4 == int(m["off"][4])]
+            assert len(rec) == 1 and int(rec[0][4]) == sp
+        assert len(cls) == 1
+    nets.GROUP_WGRAD_BF16 = False
+    try:
+        b0 = enc._compile_backward(f, "A", (True, True), False, True, True)
+    finally:
+        nets.GROUP_WGRAD_BF16 = True
+    assert _ffi.OP_WGRAD_GROUP not in [int(o["kind"]) for o in b0.ops]
+
+
 def test_without_gpu_the_product_path_fails_loudly():
     model = nets.build_networks(device="cpu")
     x = torch.rand(1, 1, 32, 32)
