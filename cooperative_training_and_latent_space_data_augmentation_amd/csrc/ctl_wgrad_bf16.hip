@@ -541,10 +541,14 @@ int ctl_wgrad_bf16_group_plan(const ctl_conv* descs, int n, int32_t* splits) {
     }
     static const int mode = ctl_tune_int("CTL16_WGRAD_GROUP_SPLITS", 1);      // tuning hook: 0 = every member keeps the splits of a launch of its own
     for (int i = 0; i < n; ++i) {
-        int sp = (int)(((int64_t)cap * work[i]) / (total * par[i]));
+        if (!mode) { splits[i] = own[i]; continue; }
+        // (rounded UP: a member rounded down would walk up to twice the tiles per block of the others.  Measured per class against the members'
+        //  own grids stacked: 3x3 16x16-tile classes 41 -> 37 / 67 -> 61 us, 1x1 24 -> 22, up-sampled input 33 -> 29, the batched
+        //  reduction 47 -> 34 us; the stride-2 class goes 40 -> 67 us, keeping its own grids costs the others more than it saves)
+        int sp = (int)(((int64_t)cap * work[i] + total * par[i] - 1) / (total * par[i]));
         if (sp < 1) sp = 1;
         if (sp > ntiles[i]) sp = ntiles[i];
-        if (sp > own[i] || !mode) sp = own[i];
+        if (sp > own[i]) sp = own[i];
         splits[i] = sp;
     }
     return CTL_OK;
