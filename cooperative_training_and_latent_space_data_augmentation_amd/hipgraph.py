@@ -230,7 +230,7 @@ class SegmentReplay:
         if streams_of is not None and len(streams_of._side) >= K - 1:      # (the graphs of one step object share the probed streams)
             self._pool = streams_of._pool
         else:
-            self._pool = {"side": [torch.cuda.Stream(priority=side_priority) for _ in range(K - 1)], "checked": None, "overlap": None}
+            self._pool = {"side": [torch.cuda.Stream(priority=side_priority) for _ in range(K - 1)], "checked": set(), "overlap": None}
         self.n_events = sum(1 for s in segs if s.event is not None)
 
     @property
@@ -251,9 +251,11 @@ class SegmentReplay:
         """Before the first replay on a launch stream: every other chain's stream must sit on another hardware queue than the launch
         stream (probe with idle kernels; on a collision take the next stream of torch's pool).  A chain that shares the launch stream's
         queue overlaps nothing: the fp32 step replays in 17.9 instead of 15.2 ms (tools/segments_probe.py)."""
-        if self._pool["checked"] == cur.cuda_stream or not self._side or torch.cuda.is_current_stream_capturing():
+        # (one probe per launch stream EVER: a caller alternating between launch streams must not pay the probe's device-wide synchronise on
+        #  every replay -- ADVICE r4; `prepare()` runs it ahead of a timed region)
+        if cur.cuda_stream in self._pool["checked"] or not self._side or torch.cuda.is_current_stream_capturing():
             return
-        self._pool["checked"] = cur.cuda_stream
+        self._pool["checked"].add(cur.cuda_stream)
         report = []
         for i in range(len(self._side)):
             ratio, attempts = streams_overlap_ratio(cur, self._side[i]), 1
@@ -262,6 +264,10 @@ class SegmentReplay:
                 ratio, attempts = streams_overlap_ratio(cur, self._side[i]), attempts + 1
             report.append({"probe_ratio": round(ratio, 2), "streams_tried": attempts, "overlap": ratio <= 1.5})
         self._pool["overlap"] = report
+
+    def prepare(self, stream: "torch.cuda.Stream" = None):
+        """Run the hardware-queue probe for `stream` (default: the current one) now, outside any timed region (it synchronises the device)."""
+        self._ensure_chains_overlap(stream if stream is not None else torch.cuda.current_stream())
 
     def replay(self):
         hip = self._hip

@@ -15,10 +15,19 @@ from . import ops
 from .metrics import runningMySegmentationScore
 
 
-def max_slices_per_pass(h: int, w: int, widest_channels: int = 16) -> int:
+PASS_FLOATS_PER_PIXEL = 512      # generous bound of what one slice of a `predict` pass keeps on the device, in floats per input pixel (FTN + STN
+                                 # encoder / decoder workspaces: a bs16 256^2 decoder pass holds 289 MB = 69 floats per pixel and slice)
+
+
+def max_slices_per_pass(h: int, w: int, widest_channels: int = 16, device=None) -> int:
     """The kernels address a tensor with 32-bit byte offsets (< 2 GiB, include/ctl_hip.h); the widest tensor of a pass is the
-    full-resolution 16-channel fp32 feature map: 64 bytes per pixel."""
-    return max(1, (2 ** 31 - 1) // (h * w * widest_channels * 4))
+    full-resolution 16-channel fp32 feature map: 64 bytes per pixel.  With `device` the pass is also bounded by HALF of the device memory
+    that is free right now (`maximum_batch_size` exists upstream to bound GPU memory: a coalesced pass must not defeat that -- ADVICE r4)."""
+    limit = max(1, (2 ** 31 - 1) // (h * w * widest_channels * 4))
+    if device is not None:
+        free, _ = torch.cuda.mem_get_info(device)
+        limit = max(1, min(limit, int(free // 2) // (h * w * 4 * PASS_FLOATS_PER_PIXEL)))
+    return limit
 
 
 COALESCE_CHUNKS = True      # run consecutive <= `maximum_batch_size`-slice chunks of a volume as one pass (see predict_volume)
@@ -30,10 +39,11 @@ def predict_volume(segmentation_model, image_d: torch.Tensor, n_iter=None, chunk
     `predict` puts every network in eval mode (running BatchNorm statistics), so slices are independent and batching changes nothing but
     the number of launches (bitwise equal logits and labels, tests/test_engine_gpu.py::test_whole_volume_pass_is_bitwise_the_chunked_loop).
     With `coalesce` (default: tester.COALESCE_CHUNKS = True) consecutive chunks therefore run as ONE pass, as many as the 2 GiB
-    addressing limit of a tensor allows (288 GB of HBM hold any volume); coalesce=False is the reference's literal loop.  chunk = None:
+    addressing limit of a tensor AND half of the currently free device memory allow (max_slices_per_pass); coalesce=False is the
+    reference's literal loop.  chunk = None:
     the whole volume per pass either way."""
     n, _, h, w = image_d.shape
-    limit = max_slices_per_pass(h, w)
+    limit = max_slices_per_pass(h, w, device=image_d.device)
     coalesce = COALESCE_CHUNKS if coalesce is None else bool(coalesce)
     if chunk is not None and int(chunk) < 1:
         raise ValueError("chunk must be positive")
@@ -86,7 +96,7 @@ class TestSegmentationNetwork(object):
         image = data_tensor_pack["image"]
         if image.dim() == 5:                              # DataLoader(batch_size=1) adds a leading axis upstream
             image = image[0]
-        limit = max_slices_per_pass(image.shape[-2], image.shape[-1])
+        limit = max_slices_per_pass(image.shape[-2], image.shape[-1], device=dev)
         assert maximum_batch_size is None or int(maximum_batch_size) > 0
         if maximum_batch_size is None or (COALESCE_CHUNKS if coalesce is None else coalesce):
             maximum_batch_size = min(int(image.shape[0]), limit)

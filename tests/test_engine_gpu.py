@@ -577,6 +577,10 @@ def test_whole_volume_pass_is_bitwise_the_chunked_loop(golden_sd):
         assert torch.equal(predict_volume(s, vol, n_iter=n_iter, chunk=7, coalesce=False), literal)     # ragged tail
     assert max_slices_per_pass(192, 192) == (2 ** 31 - 1) // (192 * 192 * 64) == 910
     assert max_slices_per_pass(4096, 4096) == 1
+    # ... and by half of the free device memory at 512 floats per pixel and slice (`maximum_batch_size` bounds memory upstream)
+    free, _ = torch.cuda.mem_get_info(vol.device)
+    assert max_slices_per_pass(192, 192, device=vol.device) == max(1, min(910, (free // 2) // (192 * 192 * 4 * 512)))
+    assert max_slices_per_pass(2048, 2048, device=vol.device) <= max(1, (free // 2) // (2048 * 2048 * 4 * 512))
 
 
 @pytest.mark.parametrize("two_streams", [True, False])
