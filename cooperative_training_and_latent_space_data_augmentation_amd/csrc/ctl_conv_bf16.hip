@@ -151,18 +151,6 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? CTL16_OCC_BIG : ((
         const int mt2 = 2 * j + (q & 1);
         yrel2[j] = ((wrow + mt2 / TWT) * d.out_sy * d.out_w + ((mt2 % TWT) * 16 + p) * d.out_sx) * d.cout + (q >> 1) * 8;
     }
-    f32x4 bias4[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int co0 = (cot0 + t) * 16 + q * 4;
-        f32x4 b = {0.f, 0.f, 0.f, 0.f};
-        if (flags & CTL_EPI_BIAS) {
-            if (d.cout >= 4) b = *reinterpret_cast<const f32x4*>(bias + (co0 < d.cout ? co0 : 0));
-            else b.x = bias[0];
-        }
-        bias4[t] = b;
-        asm volatile("" ::"v"(bias4[t]));
-    }
     // B-operand addresses: lane group q carries tap 2f + (q >> 1) (clamped to the last tap: its weights are zero there), channels
     // 8*(q & 1) .. +7 of it; (fragment, M-tile) offsets: one VGPR per fragment + compile-time immediates per M-tile
     int xoff[NFRAG];
@@ -213,15 +201,57 @@ __global__ __launch_bounds__(256, (MT * NT >= 8 || KS == 4) ? CTL16_OCC_BIG : ((
         xs.load(rx, rx2, d, cur.n, cur.th * G::TH, cur.tw * TW, 0);
         wload(0);
     }
-    if constexpr (X2) {          // coefficients as the BatchNorm-backward finalize writes them: [group][A | B | C][cin]
-        for (int i = tid; i < ngroups * d.cin; i += 256) {
-            const int gi = i / d.cin, ch = i - gi * d.cin;
-            cf_scale[i] = pro_scale[(gi * 3 + 0) * d.cin + ch]; cf_shift[i] = pro_scale[(gi * 3 + 1) * d.cin + ch]; cf_c[i] = pro_scale[(gi * 3 + 2) * d.cin + ch];
+    // The bias and the prologue coefficients are requested BEHIND the first tile's loads, without a branch around any load, and waited for
+    // once (see ctl_conv_igemm.h: the bias used to cost a memory round trip of its own at the start of every forward launch).
+    f32x4 bias4[NT];
+    float bv[NT][4];                 // the raw loads: first USED behind the coefficient requests below
+    {
+        const bool has_bias = (flags & CTL_EPI_BIAS) != 0;
+        const float* bp = has_bias ? bias : reinterpret_cast<const float*>(wpack);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int co0 = (cot0 + t) * 16 + q * 4;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) bv[t][k] = bp[has_bias ? (co0 + k < d.cout ? co0 + k : d.cout - 1) : k];
         }
-        __syncthreads();
-    } else if (d.pro_affine) {
-        for (int i = tid; i < ngroups * d.cin; i += 256) { cf_scale[i] = pro_scale[i]; cf_shift[i] = pro_shift[i]; }
-        __syncthreads();
+        const int ncf = ngroups * d.cin;       // groups * cin <= CTL_PRO_MAX = 256 = the block's threads: one coefficient entry per thread
+        const bool pro_on = X2 || d.pro_affine != 0;
+        const bool con = pro_on && tid < ncf;
+        const int ci = con ? tid : 0;
+        float c0, c1, c2 = 0.f;
+        if constexpr (X2) {          // coefficients as the BatchNorm-backward finalize writes them: [group][A | B | C][cin]
+            const int gi = ci / d.cin, ch = ci - gi * d.cin;
+            c0 = pro_scale[(gi * 3 + 0) * d.cin + ch]; c1 = pro_scale[(gi * 3 + 1) * d.cin + ch]; c2 = pro_scale[(gi * 3 + 2) * d.cin + ch];
+        } else {
+            const float* ps = pro_on ? pro_scale : reinterpret_cast<const float*>(wpack);
+            const float* ph = pro_on ? pro_shift : reinterpret_cast<const float*>(wpack);
+            c0 = ps[ci]; c1 = ph[ci];
+        }
+        // the bias is complete HERE (pinned): left to itself the wait-count pass puts an s_waitcnt vmcnt(0) in front of the first read of
+        // bias4 INSIDE the tile loop (the accumulator init), right behind the next tile's prefetch loads
+        // (ONE statement consumes the last-requested values and hands the bias on: the scheduler cannot put a use of the bias, and with it
+        //  a wait, in front of the coefficient requests)
+        static_assert(NT == 1 || NT == 2, "bias hand-over written for one or two cout tiles per block");
+        if constexpr (NT == 1)
+            asm volatile("" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(bv[0][0]), "+v"(bv[0][1]), "+v"(bv[0][2]), "+v"(bv[0][3]));
+        else
+            asm volatile("" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(bv[0][0]), "+v"(bv[0][1]), "+v"(bv[0][2]), "+v"(bv[0][3]),
+                              "+v"(bv[NT - 1][0]), "+v"(bv[NT - 1][1]), "+v"(bv[NT - 1][2]), "+v"(bv[NT - 1][3]));
+        const bool hb = (flags & CTL_EPI_BIAS) != 0;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int co0 = (cot0 + t) * 16 + q * 4;
+            bias4[t] = f32x4{(hb && co0 + 0 < d.cout) ? bv[t][0] : 0.f, (hb && co0 + 1 < d.cout) ? bv[t][1] : 0.f,
+                             (hb && co0 + 2 < d.cout) ? bv[t][2] : 0.f, (hb && co0 + 3 < d.cout) ? bv[t][3] : 0.f};
+            asm volatile("" ::"v"(bias4[t]));
+        }
+        if (pro_on) {
+            if (con) {
+                cf_scale[tid] = c0; cf_shift[tid] = c1;
+                if constexpr (X2) cf_c[tid] = c2;
+            }
+            __syncthreads();
+        }
     }
     if (total_it > 0) {
         xs.store(xt, d, 0, cf_scale, cf_shift, (cur.n / group_n) * d.cin, cf_c, rxout, xout_on);

@@ -331,21 +331,6 @@ __global__ __launch_bounds__(PC ? 512 : 256, PC ? 2 : X3 ? CTL_LB_X3(MT, NT, X2)
 #pragma unroll
     for (int m = 0; m < MT; ++m)
         yrel[m] = (((wrow + m / TWT) * d.out_sy * d.out_w + ((m % TWT) * 16 + p) * d.out_sx) * d.cout + q * 4) * 4;
-    // bias of this lane's 4 output channels: the accumulators start from it (no add in the epilogue)
-    f32x4 bias4[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int co0 = (cot0 + t) * 16 + q * 4;
-        f32x4 b = {0.f, 0.f, 0.f, 0.f};
-        if (flags & CTL_EPI_BIAS) {
-            if (d.cout >= 4) b = *reinterpret_cast<const f32x4*>(bias + (co0 < d.cout ? co0 : 0));
-            else b.x = bias[0];
-        }
-        bias4[t] = b;
-        // pin the load's completion here: left to itself the wait-count pass puts an s_waitcnt vmcnt(0) in front of the first
-        // read of bias4 INSIDE the tile loop (the accumulator init), right behind the next tile's prefetch loads
-        asm volatile("" ::"v"(bias4[t]));
-    }
     // LDS operand addresses: one per-thread base; (M-tile, tap) offsets are compile-time immediates of the ds_read
     const float* xrd = xt + ((wrow * S) * G::IWP + p) * 16 + q * 4;
     const float* wrd = wt + lane * 4;
@@ -412,15 +397,64 @@ __global__ __launch_bounds__(PC ? 512 : 256, PC ? 2 : X3 ? CTL_LB_X3(MT, NT, X2)
         xs.load(rx, rx2, d, cur.n, cur.th * G::TH, cur.tw * TW, 0);
         wload(0);
     }
-    if constexpr (X2) {      // coefficients as the BatchNorm-backward finalize writes them: [group][A | B | C][cin]
-        for (int i = tid; i < ngroups * d.cin; i += (PC ? 512 : 256)) {
-            const int gi = i / d.cin, ch = i - gi * d.cin;
-            cf_scale[i] = pro_scale[(gi * 3 + 0) * d.cin + ch]; cf_shift[i] = pro_scale[(gi * 3 + 1) * d.cin + ch]; cf_c[i] = pro_scale[(gi * 3 + 2) * d.cin + ch];
+    // Everything else the block needs from memory before its first tile is requested BEHIND the first tile's loads and waited for ONCE: the
+    // bias (every forward conv has one) used to be loaded and waited for ahead of ~300 instructions of set-up and the tile's loads -- one
+    // memory round trip of its own at the start of 130 launches per step (ISA; a loaded round trip is 2-4 us, profiles/r5_finalize_probe.txt)
+    // -- and the prologue coefficients another behind it.
+    // bias of this lane's 4 output channels: the accumulators start from it (no add in the epilogue)
+    // (NO load under a branch: the wait-count pass puts an s_waitcnt vmcnt(0) at the join; absent operands read a valid dummy address)
+    f32x4 bias4[NT];
+    float bv[NT][4];                 // the raw loads: first USED behind the coefficient requests below
+    {
+        const bool has_bias = (flags & CTL_EPI_BIAS) != 0;
+        const float* bp = has_bias ? bias : wpack;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int co0 = (cot0 + t) * 16 + q * 4;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) bv[t][k] = bp[has_bias ? (co0 + k < d.cout ? co0 + k : d.cout - 1) : k];
         }
-        __syncthreads();
-    } else if (d.pro_affine) {      // behind the first tile's loads, in front of their use
-        for (int i = tid; i < ngroups * d.cin; i += (PC ? 512 : 256)) { cf_scale[i] = pro_scale[i]; cf_shift[i] = pro_shift[i]; }
-        __syncthreads();
+    }
+    {   // prologue coefficients [groups][cin] (groups * cin <= CTL_PRO_MAX = 256 <= the block's threads): one entry per thread, requested
+        // unconditionally (clamped) so that no load sits under a branch, stored to LDS behind the wait
+        const int ncf = ngroups * d.cin;
+        const bool pro_on = X2 || d.pro_affine != 0;
+        const bool con = pro_on && tid < ncf;
+        const int ci = con ? tid : 0;
+        float c0, c1, c2 = 0.f;
+        if constexpr (X2) {      // coefficients as the BatchNorm-backward finalize writes them: [group][A | B | C][cin]
+            const int gi = ci / d.cin, ch = ci - gi * d.cin;
+            c0 = pro_scale[(gi * 3 + 0) * d.cin + ch]; c1 = pro_scale[(gi * 3 + 1) * d.cin + ch]; c2 = pro_scale[(gi * 3 + 2) * d.cin + ch];
+        } else {
+            const float* ps = pro_on ? pro_scale : wpack;
+            const float* ph = pro_on ? pro_shift : wpack;
+            c0 = ps[ci]; c1 = ph[ci];
+        }
+        // the bias is complete HERE (pinned): left to itself the wait-count pass puts an s_waitcnt vmcnt(0) in front of the first read of
+        // bias4 INSIDE the tile loop (the accumulator init), right behind the next tile's prefetch loads
+        // (ONE statement consumes the last-requested values and hands the bias on: the scheduler cannot put a use of the bias, and with it
+        //  a wait, in front of the coefficient requests)
+        static_assert(NT == 1 || NT == 2, "bias hand-over written for one or two cout tiles per block");
+        if constexpr (NT == 1)
+            asm volatile("" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(bv[0][0]), "+v"(bv[0][1]), "+v"(bv[0][2]), "+v"(bv[0][3]));
+        else
+            asm volatile("" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(bv[0][0]), "+v"(bv[0][1]), "+v"(bv[0][2]), "+v"(bv[0][3]),
+                              "+v"(bv[NT - 1][0]), "+v"(bv[NT - 1][1]), "+v"(bv[NT - 1][2]), "+v"(bv[NT - 1][3]));
+        const bool hb = (flags & CTL_EPI_BIAS) != 0;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int co0 = (cot0 + t) * 16 + q * 4;
+            bias4[t] = f32x4{(hb && co0 + 0 < d.cout) ? bv[t][0] : 0.f, (hb && co0 + 1 < d.cout) ? bv[t][1] : 0.f,
+                             (hb && co0 + 2 < d.cout) ? bv[t][2] : 0.f, (hb && co0 + 3 < d.cout) ? bv[t][3] : 0.f};
+            asm volatile("" ::"v"(bias4[t]));
+        }
+        if (pro_on) {
+            if (con) {
+                cf_scale[tid] = c0; cf_shift[tid] = c1;
+                if constexpr (X2) cf_c[tid] = c2;
+            }
+            __syncthreads();
+        }
     }
     if constexpr (!PC) {
         if (total_it > 0) {
