@@ -540,6 +540,8 @@ int ctl_wgrad_bf16_group_plan(const ctl_conv* descs, int n, int32_t* splits) {
         total += work[i];
     }
     static const int mode = ctl_tune_int("CTL16_WGRAD_GROUP_SPLITS", 1);      // tuning hook: 0 = every member keeps the splits of a launch of its own
+    static const int cap_pct = ctl_tune_int("CTL16_WGRAD_GROUP_CAP", 100);    // tuning hook: blocks of a stacked launch as a percentage of the resident set
+    cap = cap * cap_pct / 100;
     for (int i = 0; i < n; ++i) {
         if (!mode) { splits[i] = own[i]; continue; }
         // (rounded UP: a member rounded down would walk up to twice the tiles per block of the others.  Measured per class against the members'
