@@ -9,7 +9,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libctl_hip.so")
-ABI_VERSION = 10                     # CTL_ABI_VERSION of include/ctl_hip.h this binding was written against
+ABI_VERSION = 11                     # CTL_ABI_VERSION of include/ctl_hip.h this binding was written against
 RED_BLOCKS = 512                     # CTL_RED_BLOCKS of ctl_hip.h; checked against the library's compiled value (ctl_red_blocks) at load
 
 # enums of ctl_hip.h
@@ -81,6 +81,7 @@ class _Lib:
             "ctl_bn_act": [p, p, p, f32, p, i64, i32, i32, p],
             "ctl_bwd_reduce": [i32, p, p, p, p, p, f32, i64, i32, p, i32, p], "ctl_red_blocks": [],
             "ctl_bn_bwd_finalize": [p, i32, i64, p, p, p, p, p, p, i32, i32, i32, p],
+            "ctl_bn_bwd_finalize_ex": [p, i32, i64, p, p, p, p, p, p, i32, i32, i32, C.c_uint32, p],
             "ctl_bwd_apply": [i32, p, p, p, p, p, f32, p, i64, i32, p, p, i32, p],
             "ctl_chan_sum_finalize": [p, i32, p, i32, p],
             "ctl_sumpool2": [p, p, i32, i32, i32, i32, i32, p],
@@ -140,7 +141,7 @@ lib = _Lib()
 EXPORTED = ["ctl_version", "ctl_last_error", "ctl_conv_wpack_floats", "ctl_conv_stats_floats", "ctl_conv_stats_blocks",
             "ctl_pack_weights", "ctl_conv_forward", "ctl_conv_forward_ex", "ctl_conv_pool_ok", "ctl_wgrad_splits", "ctl_wgrad_partial_floats",
             "ctl_wgrad_bias_partial_floats", "ctl_conv_wgrad", "ctl_conv_wgrad_ex", "ctl_wgrad_reduce", "ctl_bn_finalize", "ctl_bn_finalize_ex", "ctl_bn_replay_running", "ctl_bn_eval_coeffs",
-            "ctl_bn_act", "ctl_bwd_reduce", "ctl_bn_bwd_finalize", "ctl_bwd_apply", "ctl_chan_sum_finalize", "ctl_sumpool2",
+            "ctl_bn_act", "ctl_bwd_reduce", "ctl_bn_bwd_finalize", "ctl_bn_bwd_finalize_ex", "ctl_bwd_apply", "ctl_chan_sum_finalize", "ctl_sumpool2",
             "ctl_sigmoid_bwd", "ctl_softmax_t_fwd", "ctl_softmax_t_bwd", "ctl_onehot", "ctl_ce2d_fwd", "ctl_ce2d_bwd",
             "ctl_mse_fwd", "ctl_mse_bwd", "ctl_argmax_c", "ctl_latent_score_ws_floats", "ctl_latent_score",
             "ctl_latent_mask_apply", "ctl_latent_mask_apply_ws_floats", "ctl_dropout2d", "ctl_uniform", "ctl_adam", "ctl_plan_run", "ctl_sizeof_op",

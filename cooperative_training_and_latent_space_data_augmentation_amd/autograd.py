@@ -49,11 +49,39 @@ class _NetFn(torch.autograd.Function):
         if ctx.counted and need_w:
             net = ctx.net
             net._pending_bwd -= 1
-            if net._pending_bwd == 0 and net._on_grads_complete is not None and net._defer_grads:
+            if net._pending_bwd == 0 and net._on_grads_complete is not None and net._defer_grads and \
+                    (net._stack is None or net._stack.done or not net._stack.filled):
                 # the last backward pass of this network in this step: its gradient range is complete once the parked per-pass
                 # gradients are added; dist.DataParallel does that here, on this pass' stream, and starts the exchange of the range behind it
                 net._on_grads_complete()
         return None, None, None, None, dx, gflat
+
+
+class _SlotFn(torch.autograd.Function):
+    """A network pass that is one slot of a PassStack (nets.py): the forward runs now, into the stacked arena; the backward node only
+    RECORDS the gradients arriving at the pass' outputs.  The solver issues the stacked backward of all slots once every slot has its
+    gradients (CtlNet.backward_stack) and hands the input gradients back to autograd from the pass' input tensors."""
+
+    @staticmethod
+    def forward(ctx, net, stack, mode, groups, x, flat):
+        p = stack.filled
+        outs, act, plan = net.run_forward(x, mode, groups, stack=stack)
+        net.remember_pass(x, act, outs, plan, mode, groups)
+        net._pass_seq += 1
+        stack.seqs.append(net._pass_seq)
+        stack.need_dx.append(bool(ctx.needs_input_grad[4]))
+        ctx.stack, ctx.p = stack, p
+        ctx.set_materialize_grads(False)
+        return outs
+
+    @staticmethod
+    def backward(ctx, *douts):
+        if all(d is None for d in douts):      # (a sweep that reaches this node without a gradient for it: nothing to record)
+            return None, None, None, None, None, None
+        if ctx.stack.done:
+            raise CtlError("a stacked pass received a gradient after its backward had been issued")
+        ctx.stack.receive(ctx.p, douts)
+        return None, None, None, None, None, None
 
 
 def net_apply(net, x: torch.Tensor, groups: int = 1):
@@ -64,6 +92,11 @@ def net_apply(net, x: torch.Tensor, groups: int = 1):
     mode = net.bn_mode()
     track_params = torch.is_grad_enabled() and mode != "C" and net.wants_param_grad()
     flat = net._flat if track_params else net._flat.detach()
+    stack = net._stack
+    if stack is not None and track_params and stack.accepts(x.shape[0], x.shape[2], x.shape[3], groups):
+        outs = _SlotFn.apply(net, stack, mode, groups, x, flat)
+        stack.roots.append(x)
+        return outs
     return _NetFn.apply(net, mode, mode == "A", groups, x, flat)
 
 

@@ -158,7 +158,7 @@ __device__ __forceinline__ ctl_bnb_chan bnb_chan_load(int ch, const float* __res
     return p;
 }
 __device__ __forceinline__ void bn_bwd_coefs(double s1, double s2, double count, int c, int gi, int ch, ctl_bnb_chan& p, float mean,
-                                             float invstd, float* __restrict__ coef, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                             float invstd, float* __restrict__ coef, float* __restrict__ dgamma, float* __restrict__ dbeta, bool affine = true) {
     const double mu = mean, is = invstd, g = p.gamma;
     const double sum_g = s1;
     const double sum_gxhat = is * (s2 - mu * s1);
@@ -171,8 +171,11 @@ __device__ __forceinline__ void bn_bwd_coefs(double s1, double s2, double count,
     coef[(gi * 3 + 1) * c + ch] = (float)B;
     coef[(gi * 3 + 2) * c + ch] = (float)C;
     // (first group without `accumulate`: p.dgamma = p.dbeta = 0 and 0 + x == x exactly)
-    p.dgamma += (float)sum_gxhat;
-    p.dbeta += (float)sum_g;
+    // affine = false: a group whose pass ran with frozen gamma / beta (BatchNorm mode B, model_util.py:414-451) adds nothing to their gradients
+    if (affine) {
+        p.dgamma += (float)sum_gxhat;
+        p.dbeta += (float)sum_g;
+    }
     if (dgamma) dgamma[ch] = p.dgamma;
     if (dbeta) dbeta[ch] = p.dbeta;
 }
@@ -236,7 +239,7 @@ __global__ __launch_bounds__(EB) void bn_bwd_finalize_kernel(const float* __rest
                                                               const float* __restrict__ save_mean,
                                                               const float* __restrict__ save_invstd,
                                                               float* __restrict__ coef, float* __restrict__ dgamma,
-                                                              float* __restrict__ dbeta, int accumulate, int groups) {
+                                                              float* __restrict__ dbeta, int accumulate, int groups, unsigned affine_groups) {
     __shared__ double sm[16];
     const int ch = blockIdx.x;
     ctl_bnb_chan p = {};
@@ -247,7 +250,7 @@ __global__ __launch_bounds__(EB) void bn_bwd_finalize_kernel(const float* __rest
         double s1 = 0.0, s2 = 0.0;
         sum_rows2(partial, (int64_t)gi * blocks, blocks, c, ch, s1, s2);
         block_sum_double2(s1, s2, sm);
-        if (threadIdx.x == 0) bn_bwd_coefs(s1, s2, count, c, gi, ch, p, mu, is, coef, dgamma, dbeta);
+        if (threadIdx.x == 0) bn_bwd_coefs(s1, s2, count, c, gi, ch, p, mu, is, coef, dgamma, dbeta, (affine_groups >> gi) & 1u);
     }
 }
 
@@ -791,15 +794,20 @@ extern "C" int ctl_bwd_reduce(int32_t mode, const float* dy, const float* act_sr
                               float* partial, int32_t groups, ctl_stream stream) {
     return ctl_bwd_reduce_dt(mode, dy, act_src, bn_src, scale, shift, slope, pixels, c, partial, groups, 0, nullptr, stream);
 }
+extern "C" int ctl_bn_bwd_finalize_ex(const float* partial, int32_t c, int64_t count, const float* gamma,
+                                      const float* save_mean, const float* save_invstd, float* coef, float* dgamma,
+                                      float* dbeta, int32_t accumulate, int32_t groups, int32_t blocks, uint32_t affine_groups, ctl_stream stream) {
+    CTL_REQUIRE(partial && gamma && save_mean && save_invstd && coef && c > 0 && count > 0 && groups >= 1 && groups <= 32 && blocks >= 0, "bn_bwd_finalize: bad arguments");
+    // blocks == 0: rows as written by ctl_bwd_reduce for a group of `count` pixels.  affine_groups: bit g = group g adds to dgamma / dbeta (0 = every group)
+    bn_bwd_finalize_kernel<<<dim3(c), dim3(CTL_FIN_THREADS), 0, S_>>>(partial, blocks > 0 ? blocks : red_rows_for(count * (c / 4)), c, (double)count, gamma, save_mean,
+                                                          save_invstd, coef, dgamma, dbeta, accumulate, groups, affine_groups ? affine_groups : 0xffffffffu);
+    CTL_LAUNCH_CHECK("bn_bwd_finalize");
+    return CTL_OK;
+}
 extern "C" int ctl_bn_bwd_finalize(const float* partial, int32_t c, int64_t count, const float* gamma,
                                    const float* save_mean, const float* save_invstd, float* coef, float* dgamma,
                                    float* dbeta, int32_t accumulate, int32_t groups, int32_t blocks, ctl_stream stream) {
-    CTL_REQUIRE(partial && gamma && save_mean && save_invstd && coef && c > 0 && count > 0 && groups >= 1 && blocks >= 0, "bn_bwd_finalize: bad arguments");
-    // blocks == 0: rows as written by ctl_bwd_reduce for a group of `count` pixels
-    bn_bwd_finalize_kernel<<<dim3(c), dim3(CTL_FIN_THREADS), 0, S_>>>(partial, blocks > 0 ? blocks : red_rows_for(count * (c / 4)), c, (double)count, gamma, save_mean,
-                                                          save_invstd, coef, dgamma, dbeta, accumulate, groups);
-    CTL_LAUNCH_CHECK("bn_bwd_finalize");
-    return CTL_OK;
+    return ctl_bn_bwd_finalize_ex(partial, c, count, gamma, save_mean, save_invstd, coef, dgamma, dbeta, accumulate, groups, blocks, 0u, stream);
 }
 extern "C" int ctl_bwd_apply_dt(int32_t mode, const float* dy, const float* act_src, const float* bn_src,
                                 const float* scale, const float* shift, float slope, const float* coef, int64_t pixels,

@@ -12,7 +12,7 @@
 //   BN_EVAL           0 gamma 1 beta 2 running_mean 3 running_var 4 scale 5 shift      i[0]=c f[0]=eps
 //   BN_ACT            0 x 1 scale 2 shift 3 y                            i[0]=c l[0]=pixels f[0]=slope
 //   BWD_REDUCE        0 dy 1 act_src 2 bn_src 3 scale 4 shift 5 partial 6 ds (mode 0, optional)  i[0]=mode i[1]=c l[0]=pixels f[0]=slope
-//   BN_BWD_FINALIZE   0 partial 1 gamma 2 save_mean 3 save_invstd 4 coef 5 dgamma 6 dbeta   i[0]=c i[1]=accumulate l[0]=count
+//   BN_BWD_FINALIZE   0 partial 1 gamma 2 save_mean 3 save_invstd 4 coef 5 dgamma 6 dbeta   i[0]=c i[1]=accumulate i[2]=groups i[3]=rows i[4]=affine group mask (0 = all) l[0]=count
 //   BWD_APPLY         0 dy 1 act_src 2 bn_src 3 scale 4 shift 5 coef 6 ds 7 dx   i[0]=mode i[1]=c l[0]=pixels f[0]=slope
 //   CHAN_SUM_FINALIZE 0 partial 1 out                                    i[0]=c i[1]=accumulate
 //   SUMPOOL2          0 dup 1 dx                                         i[0..4]=n,h,w,c,accumulate
@@ -262,6 +262,9 @@ extern "C" int ctl_plan_run(const ctl_op* ops, int32_t n_ops, void* const* bases
                 rc = ctl_conv_forward_ex(&d, CF(0), CF(1), CF(2), CF(3), CF(4), CF(5), CF(6), CF(7), CF(10), CF(11), F(8), F(9), F(12), F(13), stream);
                 break;
             case CTL_OP_WGRAD:
+                // a member of a grouped launch carries the group's split count in i[24] (its partial buffers are sized for it): reached here, the
+                // GROUP record in front of it is missing (a sliced or edited plan) and a launch of its own would overrun those buffers
+                CTL_REQUIRE(op.i[24] == 0, "plan_run: op %d is a member record of a WGRAD_GROUP (i[24] = %d splits) without its GROUP record", k, op.i[24]);
                 memcpy(&d, op.i, sizeof(d));
                 rc = ctl_conv_wgrad_ex(&d, CF(0), CF(1), CF(2), CF(3), CF(6), CF(7), F(4), F(5), stream);
                 break;
@@ -315,7 +318,7 @@ extern "C" int ctl_plan_run(const ctl_op* ops, int32_t n_ops, void* const* bases
                 rc = ctl_bwd_reduce_dt(op.i[0], CF(0), CF(1), CF(2), CF(3), CF(4), op.f[0], op.l[0], op.i[1], F(5), NG(op.i[2]), (uint32_t)op.i[25], F(6), stream);
                 break;
             case CTL_OP_BN_BWD_FINALIZE:
-                rc = ctl_bn_bwd_finalize(CF(0), op.i[0], op.l[0], CF(1), CF(2), CF(3), F(4), F(5), F(6), op.i[1], NG(op.i[2]), op.i[3], stream);
+                rc = ctl_bn_bwd_finalize_ex(CF(0), op.i[0], op.l[0], CF(1), CF(2), CF(3), F(4), F(5), F(6), op.i[1], NG(op.i[2]), op.i[3], (uint32_t)op.i[4], stream);
                 break;
             case CTL_OP_BWD_APPLY:
                 rc = ctl_bwd_apply_dt(op.i[0], CF(0), CF(1), CF(2), CF(3), CF(4), op.f[0], CF(5), op.l[0], op.i[1], F(6), F(7), NG(op.i[2]), (uint32_t)op.i[25], stream);

@@ -353,12 +353,12 @@ static void wgrad16_go_f(wgrad16_call& a) {
     }
     const int par = a.c.g * (a.c.cot / NTW);
     static const int cap = ctl_tune_int("CTL16_WGRAD_SPLITS", 1024);      // tuning hook (measured: 512 -> 768/1024 splits = 28.7 -> 24.5 us on the 16->16 3x3 layer at 256^2)
-    int splits = (256 * (occ < 4 ? occ : 4)) / par;
+    int splits = (ctl_num_cus() * (occ < 4 ? occ : 4)) / par;
     if (splits > cap) splits = cap;
     if (splits > a.ntiles) splits = a.ntiles;
     if (splits < 1) splits = 1;
     a.splits = splits;
-    a.cap = 256 * (occ < 4 ? occ : 4);
+    a.cap = ctl_num_cus() * (occ < 4 ? occ : 4);
     a.key = wg16_key(KS, S, MODE, MT, NTW, DY2, XK, DYK);
     if (a.query) return;
     if (a.grp) {

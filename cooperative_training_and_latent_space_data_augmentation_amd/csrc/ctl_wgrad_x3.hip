@@ -758,7 +758,12 @@ extern "C" int ctl_conv_wgrad_group(int32_t n, const ctl_conv* descs, const int3
         CTL_REQUIRE(ctl_wgrad_group_class(d, dy2 && dy2[i]) == cls, "conv_wgrad_group: member %d is of another class than member 0", i);
         CTL_REQUIRE(x[i] && dy[i] && w_partial[i] && (!d->pro_affine || (pro_scale && pro_shift && pro_scale[i] && pro_shift[i])) && (!(cls & 2) || (dy_coef && dy_coef[i])),
                     "conv_wgrad_group: member %d misses a tensor", i);
-        CTL_REQUIRE((d->groups > 1 ? d->groups : 1) * (d->cin > d->cout ? d->cin : d->cout) <= CTL_PRO_MAX, "conv_wgrad_group: member %d: groups * channels > %d", i, CTL_PRO_MAX);
+        // the coefficient tables a member actually stages (as in ctl_conv_wgrad_ex): the prologue's over groups * cin, the virtual output gradient's over groups * cout
+        {
+            const int ng = d->groups > 1 ? d->groups : 1;
+            CTL_REQUIRE((!d->pro_affine || ng * d->cin <= CTL_PRO_MAX) && (!(cls & 2) || ng * d->cout <= CTL_PRO_MAX),
+                        "conv_wgrad_group: member %d: groups * channels of a staged coefficient table > %d", i, CTL_PRO_MAX);
+        }
         CTL_REQUIRE((int64_t)d->n * d->hin * d->win * d->cin * 4 < (1ll << 31) && (int64_t)d->n * d->hout * d->wout * d->cout * 4 < (1ll << 31),
                     "conv_wgrad_group: tensors must stay below 2 GiB (32-bit buffer offsets)");
         wgrad3_call a = {};

@@ -252,17 +252,22 @@ class SegmentReplay:
         stream (probe with idle kernels; on a collision take the next stream of torch's pool).  A chain that shares the launch stream's
         queue overlaps nothing: the fp32 step replays in 17.9 instead of 15.2 ms (tools/segments_probe.py)."""
         # (one probe per launch stream EVER: a caller alternating between launch streams must not pay the probe's device-wide synchronise on
-        #  every replay -- ADVICE r4; `prepare()` runs it ahead of a timed region)
-        if cur.cuda_stream in self._pool["checked"] or not self._side or torch.cuda.is_current_stream_capturing():
+        #  every replay -- ADVICE r4; `prepare()` runs it ahead of a timed region.  The probed side streams are kept PER launch stream
+        #  -- ADVICE r5: replacing a shared side stream for launch stream B could put it on the queue of the already probed stream A)
+        key = cur.cuda_stream
+        if key in self._pool["checked"] or not self._side or torch.cuda.is_current_stream_capturing():
             return
-        self._pool["checked"].add(cur.cuda_stream)
+        self._pool["checked"].add(key)
+        side = list(self._side)
         report = []
-        for i in range(len(self._side)):
-            ratio, attempts = streams_overlap_ratio(cur, self._side[i]), 1
+        for i in range(len(side)):
+            ratio, attempts = streams_overlap_ratio(cur, side[i]), 1
             while ratio > 1.5 and attempts < 8:
-                self._side[i] = torch.cuda.Stream(priority=self._side_priority)
-                ratio, attempts = streams_overlap_ratio(cur, self._side[i]), attempts + 1
+                side[i] = torch.cuda.Stream(priority=self._side_priority)
+                ratio, attempts = streams_overlap_ratio(cur, side[i]), attempts + 1
             report.append({"probe_ratio": round(ratio, 2), "streams_tried": attempts, "overlap": ratio <= 1.5})
+        self._pool.setdefault("side_of", {})[key] = side
+        self._pool.setdefault("overlap_of", {})[key] = report
         self._pool["overlap"] = report
 
     def prepare(self, stream: "torch.cuda.Stream" = None):
@@ -274,7 +279,8 @@ class SegmentReplay:
         cur_stream = torch.cuda.current_stream()
         self._ensure_chains_overlap(cur_stream)
         cur = _VP(cur_stream.cuda_stream)
-        raw = [cur] + [_VP(s.cuda_stream) for s in self._side[:self.n_chains - 1]]
+        side = self._pool.get("side_of", {}).get(cur_stream.cuda_stream, self._side)      # the streams probed against THIS launch stream
+        raw = [cur] + [_VP(s.cuda_stream) for s in side[:self.n_chains - 1]]
         if len(raw) > 1:
             _ck(hip.hipEventRecord(self._fork, cur), "hipEventRecord")
             for st in raw[1:]:

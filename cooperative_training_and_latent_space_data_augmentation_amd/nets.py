@@ -65,8 +65,10 @@ GROUP_WGRAD = True       # fp32 / X3: the weight gradients of a backward plan th
                          # the plan and served in groups of up to 8 by one launch each (CTL_OP_WGRAD_GROUP): nothing in the plan reads dW, and per
                          # launch ~15 of 40 us are fixed.  Safe to reorder: plan arenas are bump-allocated (no tensor is reused inside a plan) and
                          # every in-place pass on a gradient tensor (apply, accumulate epilogues) is emitted BEFORE the weight gradient that reads it
-GROUP_WGRAD_BF16 = True  # bf16 family: the weight gradients of one kernel instantiation are STACKED in one launch (up to 8; every member keeps the grid
-                         # and the split count of a launch of its own, so its partial sums are bit for bit the same): the bf16 step is launch-bound
+GROUP_WGRAD_BF16 = True  # bf16 family: the weight gradients of one kernel instantiation are STACKED in one launch (up to 8 members along blockIdx.x): the bf16
+                         # step is launch-bound.  A member's pixel splits are dealt in proportion to its work (ctl_wgrad_group_plan; never more than a launch of
+                         # its own takes), so its partial sums are added in another order than the single launch's -- equal bit for bit only when the split
+                         # count equals ctl_wgrad_splits' (tests/test_bf16_gpu.py compares both: exact with own splits, 1e-5 with the proportional ones)
 FUSE_TAIL = True         # fp32: the residual tail's BatchNorm-backward reduction inside the launch that writes dOut (CTL_EPI_TAILBWD): dOut is
                          # never materialised, the stand-alone reduction launch (read dOut, out, v; write dS) disappears
 CONV_WORDS = _ffi.CONV_DTYPE.itemsize // 4      # ctl_conv as int32 words at the head of ctl_op.i
@@ -115,8 +117,12 @@ class Arena:
     """Bump allocator of one plan workspace.  `b16`: the tensors living here are network-internal and stored as bf16 (BASELINE config 3);
     network inputs / outputs (the external slots) are fp32 in every configuration."""
 
-    def __init__(self, slot, b16=False):
-        self.slot, self.size, self.b16 = slot, 0, b16
+    def __init__(self, slot, b16=False, pp=(0, 1)):
+        # pp = (p, P): this plan is pass p of P passes of one network that share the arena in the N-STACKED layout: every tensor is
+        # allocated for P * n images and pass p works on images [p * n, (p + 1) * n), every per-group coefficient table for P * groups
+        # rows with this pass' rows at p * groups -- so that ONE backward launch chain can later treat the P passes as one batch of
+        # P * n images in P * groups BatchNorm groups (round 6, CtlNet.run_backward_stacked)
+        self.slot, self.size, self.b16, self.pp = slot, 0, b16, pp
 
     def alloc(self, nbytes: int):
         off = self.size
@@ -125,7 +131,17 @@ class Arena:
 
     def tensor(self, n, h, w, c, *_, b16=None) -> T:
         b16 = self.b16 if b16 is None else b16
-        return T(self.alloc((2 if b16 else 4) * n * h * w * c), n, h, w, c, b16)
+        p, P = self.pp
+        one = (2 if b16 else 4) * n * h * w * c
+        slot, off = self.alloc(P * one)
+        return T((slot, off + p * one), n, h, w, c, b16)
+
+    def rows(self, floats: int, groups: int):
+        """A per-group table [groups][floats] of fp32 (BatchNorm coefficients / saved statistics)."""
+        p, P = self.pp
+        one = 4 * floats * groups
+        slot, off = self.alloc(P * one)
+        return (slot, off + p * one)
 
 
 class _ArenaLease:
@@ -166,7 +182,76 @@ class ArenaPool:
 
 class Plan:
     __slots__ = ("ops", "n_ops", "act_bytes", "scr_bytes", "bscr_bytes", "rec", "out_shapes", "table_np", "table_dev", "groups", "bn_log",
-                 "replay")
+                 "replay", "main_ops", "tail_ops")
+
+
+# plan ops that only PRODUCE parameter gradients (nothing in a backward plan reads them): a split plan runs them as its tail, on another
+# stream than the data-gradient chain (CtlNet._run_backward_stacked)
+_TAIL_KINDS = (_ffi.OP_WGRAD, _ffi.OP_WGRAD_GROUP, _ffi.OP_WGRAD_REDUCE, _ffi.OP_WGRAD_REDUCE_BATCH, _ffi.OP_CHAN_SUM_FINALIZE)
+
+
+def _stack_rec(obj, P: int):
+    """The forward record of pass slot 0 seen as ONE pass over the P stacked batches: every tensor descriptor grows to P * n images (its
+    reference is slot 0's = the base of the stacked tensor), the per-group coefficient tables keep their base (P * groups rows)."""
+    if isinstance(obj, T):
+        return obj._replace(n=obj.n * P)
+    if isinstance(obj, dict):
+        return {k: _stack_rec(v, P) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_stack_rec(v, P) for v in obj)
+    return obj
+
+
+class _StackedForward:
+    """What a backward compiler reads of a forward plan (`rec`, `groups`), for the stacked view of P pass slots."""
+    __slots__ = ("rec", "groups")
+
+    def __init__(self, rec, groups):
+        self.rec, self.groups = rec, groups
+
+
+class PassStack:
+    """The passes of ONE network in one training step whose backward runs as one launch chain (round 6).
+
+    The loss of a step is `standard + hard` and the hard branch's inputs are detached (train.py:216-230, model.py:502-518, 547): the
+    standard and the hard-example pass of a network are independent given their inputs, share the weights, and their backward sweeps
+    have the same shape.  Their FORWARD passes cannot be batched (the hard input is generated from the standard pass' codes), so each
+    forward pass p writes its activations into slot p of one arena laid out as if a single pass had run on the P * n stacked images
+    (Arena.pp); the backward then IS a single pass over P * n images in P * groups BatchNorm groups -- one data-gradient chain, one
+    weight-gradient contraction over both passes (no second set of split-K partials, no per-pass accumulation), half the launches.
+    A pass in BatchNorm mode B (frozen gamma / beta) is a group that adds nothing to their gradients (ctl_bn_bwd_finalize_ex)."""
+
+    def __init__(self, net: "CtlNet", P: int = 2):
+        self.net, self.P = net, P
+        self.lease = None                 # the stacked activation arena
+        self.outs = None                  # stacked outputs, [P * n, c, h, w] each; pass p returns the views [p * n, (p + 1) * n)
+        self.shape = None                 # (n, h, w, groups) of the first pass: later passes must agree or run unstacked
+        self.plans, self.modes, self.xs, self.roots, self.need_dx, self.seqs = [], [], [], [], [], []
+        self.douts = []                   # per pass: list over outputs of the gradient received so far (None = none yet)
+        self.keep = []                    # leases / tensors that must outlive the launches issued from them on other streams
+        self.events = []                  # per pass: events behind which the received gradients are complete
+        self.done = False                 # the backward has been issued
+
+    @property
+    def filled(self) -> int:
+        return len(self.plans)
+
+    def accepts(self, n, h, w, groups) -> bool:
+        return (not self.done and self.filled < self.P and self.net.drop_p is None and
+                (self.shape is None or self.shape == (n, h, w, groups)))
+
+    def receive(self, p: int, douts):
+        """Called from the autograd node of pass p: the gradients w.r.t. its outputs (a node may be visited more than once when its
+        outputs are consumed in different sweeps)."""
+        cur = self.douts[p]
+        for k, d in enumerate(douts):
+            if d is None:
+                continue
+            d = d.float().contiguous(memory_format=torch.channels_last)
+            cur[k] = d if cur[k] is None else cur[k] + d
+        ev = torch.cuda.Event()
+        ev.record()
+        self.events[p].append(ev)
 
 
 class PlanBuilder:
@@ -176,7 +261,10 @@ class PlanBuilder:
         self.groups = int(getattr(net, "_cur_groups", 1))
         self.ops: List[np.ndarray] = []
         self.b16 = bool(getattr(net, "bf16", False))
-        self.act = Arena(S_ACT, self.b16)
+        self.pp = tuple(getattr(net, "_cur_pp", (0, 1)))                 # forward plans: pass slot (p, P) of a stacked arena, see Arena
+        self.affine_mask = int(getattr(net, "_cur_affine_mask", 0))      # backward plans: the groups that add to gamma / beta gradients (0 = all)
+        self.split_tail = bool(getattr(net, "_cur_split", False))        # backward plans: also cut into data-gradient chain | weight-gradient tail
+        self.act = Arena(S_ACT, self.b16, self.pp)
         self.bscr = Arena(S_BSCR, self.b16)
         self.scr_bytes = 0
         self.reduce_recs: List[list] = []     # batched wgrad reduction records (one launch at the end of the plan)
@@ -384,7 +472,7 @@ class PlanBuilder:
         c, G = bn.c, self.groups
         assert count % G == 0
         count //= G                                   # the statistics of one group
-        co = {k: self.act.alloc(4 * c * G) for k in ("scale", "shift", "mean", "invstd", "uvar")}      # [groups][c] each
+        co = {k: self.act.rows(c, G) for k in ("scale", "shift", "mean", "invstd", "uvar")}      # [groups][c] each
         if mode == "C":
             op = self.op(_ffi.OP_BN_EVAL)
             op["i"][0], op["i"][1] = c, G
@@ -440,7 +528,7 @@ class PlanBuilder:
                                    ds.ref if ds_early else None]):
             self.set_t(op, idx, ref)
         op = self.op(_ffi.OP_BN_BWD_FINALIZE)
-        op["i"][0], op["i"][1], op["i"][2] = c, 0, G
+        op["i"][0], op["i"][1], op["i"][2], op["i"][4] = c, 0, G, self.affine_mask
         op["l"][0] = pixels // G
         for idx, ref in enumerate([part, self.P(bn.g_off), co["mean"], co["invstd"], coef,
                                    self.G(bn.g_off) if affine_grad else None, self.G(bn.b_off) if affine_grad else None]):
@@ -470,7 +558,7 @@ class PlanBuilder:
         c, pixels, G = bn_src.c, bn_src.n * bn_src.h * bn_src.w, self.groups
         coef = self.bscr.alloc(4 * 3 * c * G)
         op = self.op(_ffi.OP_BN_BWD_FINALIZE)
-        op["i"][0], op["i"][1], op["i"][2], op["i"][3] = c, 0, G, blocks
+        op["i"][0], op["i"][1], op["i"][2], op["i"][3], op["i"][4] = c, 0, G, blocks, self.affine_mask
         op["l"][0] = pixels // G
         for idx, ref in enumerate([stats_ref, self.P(bn.g_off), co["mean"], co["invstd"], coef,
                                    self.G(bn.g_off) if affine_grad else None, self.G(bn.b_off) if affine_grad else None]):
@@ -544,6 +632,23 @@ class PlanBuilder:
         p.ops = np.stack(self.ops) if self.ops else np.zeros(0, dtype=OP_DTYPE)
         p.ops = np.ascontiguousarray(p.ops)
         p.n_ops = len(self.ops)
+        p.main_ops = p.tail_ops = None
+        if self.split_tail:
+            # The weight-gradient family (and the channel sums of the transposed convs' bias gradients, reduction + finalize) in plan order
+            # behind everything else in plan order.  Safe for the reasons the grouped weight gradients are deferred (GROUP_WGRAD): nothing in
+            # the plan reads dW, arenas are bump-allocated, and every in-place pass on a gradient tensor precedes the weight gradient reading it
+            tail = []
+            for k, o in enumerate(self.ops):
+                kind = int(o["kind"])
+                if kind in _TAIL_KINDS:
+                    tail.append(k)
+                    if kind == _ffi.OP_CHAN_SUM_FINALIZE:      # its reduction (BWD_REDUCE mode 2 into the transient scratch) goes with it
+                        assert int(self.ops[k - 1]["kind"]) == _ffi.OP_BWD_REDUCE and int(self.ops[k - 1]["i"][0]) == 2
+                        tail.insert(len(tail) - 1, k - 1)
+            ts = set(tail)
+            main = [k for k in range(len(self.ops)) if k not in ts]
+            p.main_ops = np.ascontiguousarray(p.ops[main])
+            p.tail_ops = np.ascontiguousarray(p.ops[tail]) if tail else None
         p.act_bytes, p.scr_bytes, p.bscr_bytes = self.act.size, self.scr_bytes, self.bscr.size
         p.rec, p.out_shapes = rec, out_shapes
         p.groups = self.groups
@@ -580,6 +685,7 @@ class CtlNet(nn.Module):
         self._on_grads_complete = None
         self._scr: Optional[dict] = None          # stream handle -> scratch tensor
         self._arenas = ArenaPool()
+        self._stack: Optional[PassStack] = None   # set by the solver for the duration of one step: passes whose backward runs stacked
         # nn.Dropout2d behind every residual block (encoder_decoder.py:58-66; `encoder_dropout` / `decoder_dropout`, None upstream's default)
         self.drop_p: Optional[float] = None
         self._drop_state: Optional[torch.Tensor] = None      # device int64[3]: seed, pass counter (advanced by ctl_step_tick), unused
@@ -881,7 +987,8 @@ class CtlNet(nn.Module):
             self._packed_ok = True
 
     # ---------------------------------------------------------------- plan execution
-    def _run(self, plan: Plan, tensors: Dict[int, torch.Tensor]):
+    def _run(self, plan: Plan, tensors: Dict[int, torch.Tensor], ops: Optional[np.ndarray] = None):
+        """ops: run this part of the plan (Plan.main_ops / Plan.tail_ops) instead of the whole op list."""
         if not self._flat_data.is_cuda:
             raise _ffi.CtlError("the HIP engine needs the network on a GPU device; there is no CPU fallback")
         stream = torch.cuda.current_stream()
@@ -903,7 +1010,8 @@ class CtlNet(nn.Module):
         bases = (ctypes.c_void_p * N_SLOTS)()
         for s, t in tensors.items():
             bases[s] = t.data_ptr()
-        check(lib.ctl_plan_run(plan.ops.ctypes.data, plan.n_ops, bases, N_SLOTS, stream.cuda_stream),
+        run_ops = plan.ops if ops is None else ops
+        check(lib.ctl_plan_run(run_ops.ctypes.data, len(run_ops), bases, N_SLOTS, stream.cuda_stream),
               f"{type(self).__name__} plan")
 
     def set_dropout(self, p: Optional[float]):
@@ -1161,25 +1269,37 @@ class CtlNet(nn.Module):
         n, h, w, c = shape
         return torch.empty((n, c, h, w), dtype=torch.float32, device=self.device, memory_format=torch.channels_last)
 
-    def run_forward(self, x: torch.Tensor, mode: str, groups: int = 1):
+    def run_forward(self, x: torch.Tensor, mode: str, groups: int = 1, stack: Optional[PassStack] = None):
         """Returns (outputs tuple, act workspace tensor, plan).  x: logical NCHW, NHWC memory.  groups > 1: x stacks that many
-        independent batches along n; BatchNorm treats each on its own (statistics, running-stat updates in order)."""
+        independent batches along n; BatchNorm treats each on its own (statistics, running-stat updates in order).
+        stack: the pass becomes the next slot of that PassStack (shared N-stacked arena and outputs, see PassStack)."""
         n, c, h, w = x.shape
         if c != self.cin:
             raise ValueError(f"{type(self).__name__}: expected {self.cin} input channels, got {c}")
         if groups < 1 or n % groups:
             raise ValueError(f"{type(self).__name__}: batch {n} cannot be split into {groups} groups")
-        key = ("f", n, h, w, mode, groups, self.drop_p, self._drop_keep is not None)
+        pp = (0, 1) if stack is None else (stack.filled, stack.P)
+        key = ("f", n, h, w, mode, groups, self.drop_p, self._drop_keep is not None) + (() if stack is None else (pp,))
         plan = self._plans.get(key)
         if plan is None:
-            self._cur_groups = groups
+            self._cur_groups, self._cur_pp = groups, pp
             try:
                 plan = self._plans[key] = self._compile_forward(n, h, w, mode)
             finally:
-                self._cur_groups = 1
+                self._cur_groups, self._cur_pp = 1, (0, 1)
         self.ensure_packed()
-        act = self._arenas.acquire(plan.act_bytes, self.device)        # lease: lives as long as the autograd context of this pass
-        outs = [self._alloc_out(s) for s in plan.out_shapes]
+        if stack is None:
+            act = self._arenas.acquire(plan.act_bytes, self.device)        # lease: lives as long as the autograd context of this pass
+            outs = [self._alloc_out(s) for s in plan.out_shapes]
+        else:
+            if stack.lease is None:
+                if mode == "C" or self.drop_p is not None:
+                    raise _ffi.CtlError("PassStack: training-mode passes of a network without Dropout2d only")
+                stack.lease = self._arenas.acquire(plan.act_bytes, self.device)
+                stack.outs = [self._alloc_out((s[0] * stack.P,) + tuple(s[1:])) for s in plan.out_shapes]
+                stack.shape = (n, h, w, groups)
+            act = stack.lease
+            outs = [o[pp[0] * n:(pp[0] + 1) * n] for o in stack.outs]
         tensors = {S_X: x, S_P: self._flat_data, S_B: self._bflat, S_NBT: self._nbt, S_WP: self._wp, S_ACT: act.t, S_OUT0: outs[0]}
         if len(outs) > 1:
             tensors[S_OUT1] = outs[1]
@@ -1193,7 +1313,138 @@ class CtlNet(nn.Module):
                 check(lib.ctl_step_tick(self._drop_state.data_ptr(), torch.cuda.current_stream().cuda_stream), "ctl_step_tick")
                 tensors[S_STATE] = self._drop_state
         self._run(plan, tensors)
+        if stack is not None:
+            stack.plans.append(plan)
+            stack.modes.append(mode)
+            stack.xs.append(x)
+            stack.douts.append([None] * len(outs))
+            stack.events.append([])
         return tuple(outs), act, plan
+
+    # ---------------------------------------------------------------- stacked backward (PassStack)
+    @staticmethod
+    def _gather_stacked(parts, alloc):
+        """[P * n, ...] tensor whose p-th block is parts[p] (None = zeros): the parts themselves when they already are consecutive
+        blocks of one allocation (views of a stacked output / gradient), else one copy each into a fresh tensor."""
+        ref = next(t for t in parts if t is not None)
+        n = ref.shape[0]
+        nbytes = ref.numel() * ref.element_size()
+        if all(t is not None and t.shape == ref.shape and t.dtype == ref.dtype and t.is_contiguous(memory_format=torch.channels_last)
+               and t.data_ptr() == parts[0].data_ptr() + k * nbytes for k, t in enumerate(parts)):
+            base = parts[0]._base if parts[0]._base is not None else None
+            if base is not None and base.dim() == 4 and base.shape[1:] == ref.shape[1:] and base.is_contiguous(memory_format=torch.channels_last):
+                k0 = (parts[0].data_ptr() - base.data_ptr()) // nbytes
+                if base.data_ptr() + k0 * nbytes == parts[0].data_ptr() and (k0 + len(parts)) * n <= base.shape[0]:
+                    return base[k0 * n:(k0 + len(parts)) * n]
+        out = alloc((n * len(parts), ref.shape[2], ref.shape[3], ref.shape[1]))
+        for k, t in enumerate(parts):
+            if t is None:
+                out[k * n:(k + 1) * n].zero_()
+            else:
+                out[k * n:(k + 1) * n].copy_(t)
+        return out
+
+    def backward_stack(self, stack: PassStack, tail_stream: Optional["torch.cuda.Stream"] = None):
+        """Issue the backward of the passes of `stack` on the current stream (which first waits for the gradients the passes received
+        on other streams): ONE launch chain over the stacked batch when every slot is filled, else one per filled slot.  The flat
+        parameter gradient is parked like a per-pass gradient (collect_deferred_grads).  Returns [(root input tensor, its gradient)]
+        for the passes whose input wants a gradient: the caller hands them back to autograd.
+        tail_stream: the weight-gradient family of the stacked plan runs there, behind the data-gradient chain on the current stream
+        (the chain the NEXT network's backward depends on): the fat weight-gradient launches fill the second chain."""
+        assert not stack.done
+        stack.done = True
+        cur = torch.cuda.current_stream()
+        for evs in stack.events:
+            for ev in evs:
+                cur.wait_event(ev)
+        P, n = stack.P, (stack.shape[0] if stack.shape else 0)
+        cont = []
+        live = [p for p in range(stack.filled) if any(d is not None for d in stack.douts[p])]
+        if not live:
+            return cont
+        need_w = True
+        if stack.filled == P and len(live) == P:
+            n_out = len(stack.outs)
+            douts = []
+            for k in range(n_out):
+                parts = [stack.douts[p][k] for p in range(P)]
+                douts.append(None if all(t is None for t in parts) else self._gather_stacked(parts, self._alloc_out))
+            x = self._gather_stacked(list(stack.xs), self._alloc_out)
+            need_dx = any(stack.need_dx)
+            dx, gflat = self._run_backward_stacked(stack, x, tuple(douts), need_dx, need_w, tail_stream)
+            if need_dx:
+                cont = [(stack.roots[p], dx[p * n:(p + 1) * n]) for p in range(P) if stack.need_dx[p]]
+            with torch.cuda.stream(tail_stream if tail_stream is not None else cur):
+                self._park_grad(stack.seqs[0], gflat)
+        else:
+            for p in live:
+                outs = tuple(o[p * n:(p + 1) * n] for o in stack.outs)
+                dx, gflat = self.run_backward(stack.xs[p], stack.lease, outs, stack.plans[p], stack.modes[p], tuple(stack.douts[p]),
+                                              stack.need_dx[p], need_w, stack.modes[p] == "A")
+                if stack.need_dx[p]:
+                    cont.append((stack.roots[p], dx))
+                self._park_grad(stack.seqs[p], gflat)
+        if self._pending_bwd == 0 and self._on_grads_complete is not None and self._defer_grads:
+            with torch.cuda.stream(tail_stream if (tail_stream is not None and stack.filled == P and len(live) == P) else cur):
+                self._on_grads_complete()
+        return cont
+
+    def _park_grad(self, seq, gflat):
+        if gflat is None:
+            return
+        if self._defer_grads:
+            ev = torch.cuda.Event()
+            ev.record()
+            self._deferred.append((seq, gflat, ev))
+        else:
+            self._flat.grad.add_(gflat)
+            self._grad_written, self._grad_is_zero = True, False
+
+    def _run_backward_stacked(self, stack: PassStack, x, douts, need_dx: bool, need_w: bool, tail_stream=None):
+        P = stack.P
+        n, h, w, G = stack.shape
+        plan0 = stack.plans[0]
+        mask = tuple(d is not None for d in douts)
+        full = (1 << (P * G)) - 1
+        amask = sum((((1 << G) - 1) << (p * G)) for p in range(P) if stack.modes[p] == "A")
+        key = ("bs", n, h, w, tuple(stack.modes), mask, need_dx, need_w, P, G, id(plan0))
+        plan = self._plans.get(key)
+        if plan is None:
+            view = _StackedForward(_stack_rec(plan0.rec, P), P * G)
+            self._cur_groups, self._cur_affine_mask, self._cur_split = P * G, (0 if amask == full else amask), True
+            try:
+                plan = self._plans[key] = self._compile_backward(view, "A", mask, need_dx, need_w, amask != 0)
+            finally:
+                self._cur_groups, self._cur_affine_mask, self._cur_split = 1, 0, False
+        lease = self._arenas.acquire(plan.bscr_bytes, self.device)
+        stack.keep.append(lease)          # (the tail may still read the arena on another stream when this call returns: held until the step ends)
+        self._dbg_last = (plan, lease.t)
+        tensors = {S_X: x, S_P: self._flat_data, S_WP: self._wp, S_ACT: stack.lease.t, S_BSCR: lease.t, S_OUT0: stack.outs[0]}
+        if len(stack.outs) > 1:
+            tensors[S_OUT1] = stack.outs[1]
+        for slot, d in zip((S_DOUT0, S_DOUT1), douts):
+            if d is not None:
+                tensors[slot] = d
+        dx = gflat = None
+        if need_dx:
+            dx = self._alloc_out((P * n, h, w, self.cin))
+            tensors[S_DX] = dx
+        if need_w:
+            gflat = torch.empty(self._pcount, dtype=torch.float32, device=self.device)
+            tensors[S_GRAD] = gflat
+            self._grad_written, self._grad_is_zero = True, False
+        if tail_stream is None or plan.tail_ops is None or not need_w:
+            self._run(plan, tensors)
+            return dx, gflat
+        self._run(plan, tensors, ops=plan.main_ops)
+        done = torch.cuda.Event()
+        done.record()
+        with torch.cuda.stream(tail_stream):
+            tail_stream.wait_event(done)
+            for t in tensors.values():
+                t.record_stream(tail_stream)
+            self._run(plan, tensors, ops=plan.tail_ops)
+        return dx, gflat
 
     def run_backward(self, x, act, outs, fwd_plan: Plan, mode: str, douts, need_dx: bool, need_w: bool, affine: bool):
         """Returns (dx or None, flat parameter gradient or None)."""

@@ -39,6 +39,17 @@ def basic_loss_fn(pred, target, loss_type="cross entropy"):
 
 
 SPLIT_BACKWARD = True       # one backward() sweep per launch chain, the standard branch first (see _cooperative_step)
+# Networks whose standard and hard-example pass of a cooperative step run their backward STACKED (nets.PassStack, round 6; VERDICT r5 "next" #1):
+# one launch chain over both passes (n = 32 in two BatchNorm groups) instead of two n = 16 chains, one weight-gradient contraction over both.
+# Entries: (network, launch chain its stacked backward is issued on: 0 = main stream, 1 = second stream), in issue order (a network comes after
+# every network that consumes its outputs), e.g. STACK_ALL_FTN below.
+# MEASURED AND NOT ADOPTED as the default (profiles/r6_stack_experiments.txt): parity-green (tests/test_stack_gpu.py) and 142 launches fewer per
+# step, but the serial kernel time only drops 2.5 % (the grouped weight-gradient launches and the persistent-grid convs already run at n = 16
+# what they run at n = 32), while the two SYMMETRIC per-pass chains become one dependent chain STN -> D_seg -> E_i with D_img beside it: time with
+# two kernels in flight 10.5 -> 8.0 ms of the step.  fp32 14.46 -> 14.80 ms, bf16 9.20 -> 11.4 ms same-box.  () = every pass runs its own backward.
+STACK_ALL_FTN = (("image_decoder", 1), ("segmentation_decoder", 0), ("image_encoder", 0))
+STACK_PASSES = ()
+SPLIT_WGRAD_TAIL = True     # a stacked backward runs its weight-gradient family on the OTHER launch chain, behind its data-gradient chain
 
 class AdvancedTripletReconSegmentationModel(nn.Module):
     def __init__(self, network_type="FCN_16_standard", image_ch=1, learning_rate=1e-4, encoder_dropout=None,
@@ -76,6 +87,8 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
         # second HIP stream next to D_seg -> STN on the main stream
         self.two_streams = True
         self.split_backward = SPLIT_BACKWARD and self.compute_dtype != "bf16"      # (bf16: no gain eager, and the captured step replays 16 % slower)
+        self.stack_passes = tuple(STACK_PASSES)      # () = every pass runs its own backward (rounds 1-5)
+        self.split_wgrad_tail = SPLIT_WGRAD_TAIL     # the weight-gradient family of a stacked backward runs on the OTHER launch chain
         # parameter gradients of the passes of a step are parked and added with one launch per network after backward (nets.py)
         self.defer_param_grads = True
         self._side = torch.cuda.Stream(device=self.device)
@@ -706,6 +719,11 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
         self.reset_all_optimizers()
         for net in self.model.values():
             net._defer_grads, net._deferred, net._pending_bwd = self.defer_param_grads, [], 0
+        if self.defer_param_grads and latent_DA:
+            from .nets import PassStack
+            for name, _ in self.stack_passes:
+                if self.model[name].drop_p is None:
+                    self.model[name]._stack = PassStack(self.model[name], 2)
         if self._dp is not None:
             self._dp.begin_step(grad_hook is not None)
         try:
@@ -713,13 +731,45 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
                                           seg_override, do_optim, grad_hook)
         finally:
             for net in self.model.values():
-                net._defer_grads, net._deferred = False, []
+                net._defer_grads, net._deferred, net._stack = False, [], None
                 net.forget_pass()
 
+    def _has_stacks(self) -> bool:
+        return any(m._stack is not None and m._stack.filled for m in self.model.values())
+
     def _backward(self, loss):
-        loss.backward()
+        # (retain_graph with stacks: a sweep passes through the nodes upstream of a stacked pass without a gradient for them -- the stacked
+        #  pass hands its input gradient back later, in a second sweep from its inputs -- and must not release what they saved)
+        loss.backward(retain_graph=self._has_stacks())
+        self._backward_stacks(two_chains=self.two_streams)
         for net in self.model.values():             # the parked per-pass parameter gradients: one accumulation launch per network
             net.collect_deferred_grads()
+
+    def _backward_stacks(self, two_chains=False):
+        """The stacked backward sweeps (nets.PassStack) behind the autograd sweep(s) that delivered the gradients of the stacked passes'
+        outputs: per network, in STACK_PASSES order, ONE launch chain over all its passes of this step, then autograd continues from the
+        passes' inputs (which reaches the stacks of the networks upstream).  two_chains: the networks marked for the second chain are
+        issued on the second stream; a stack waits for the events of the gradients it received, whichever stream they came from."""
+        cur, side = torch.cuda.current_stream(), self._side
+        used_side = False
+        for name, chain in self.stack_passes:
+            net = self.model[name]
+            st = net._stack
+            if st is None or st.done or not st.filled:
+                continue
+            # (under stream capture every stack is issued on the capture's origin stream: with a stack on the second chain hipStreamEndCapture
+            #  crashed on this image -- tools/debug/r6_capture_bisect.py -- while the all-on-one-stream form captures and replays bit-exactly)
+            on_side = two_chains and chain == 1 and not torch.cuda.is_current_stream_capturing()
+            tail = None
+            if two_chains and self.split_wgrad_tail and not torch.cuda.is_current_stream_capturing():
+                tail = cur if on_side else side
+            with torch.cuda.stream(side if on_side else cur):
+                cont = net.backward_stack(st, tail_stream=tail)
+                if cont:
+                    torch.autograd.backward([r for r, _ in cont], [g for _, g in cont], retain_graph=True)
+            used_side = used_side or on_side or tail is not None
+        if used_side:
+            cur.wait_stream(side)
 
     def _cooperative_step(self, clean_image_l, label_l, image_l, img_cfg, seg_cfg, latent_DA, separate_training, image_override,
                           seg_override, do_optim, grad_hook):
@@ -744,9 +794,11 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
                 # fp32 17.41 -> 17.31 ms same-box.  bf16 (launch-rate bound): eager unchanged (10.61 vs 10.65), but the hipGraph replay of the
                 # two-sweep step takes 13.25 ms instead of 11.45 -- the one-sweep form stays there (profiles/r3_split_backward_ab3.txt).
                 self.reset_all_optimizers()
-                (std[0] + std[1] + std[3] + std[2]).backward()
+                keep = self._has_stacks()
+                (std[0] + std[1] + std[3] + std[2]).backward(retain_graph=keep)
                 with torch.cuda.stream(self._side):
-                    (hard[0] + hard[1] + hard[2] + hard[3]).backward()
+                    (hard[0] + hard[1] + hard[2] + hard[3]).backward(retain_graph=keep)
+                self._backward_stacks(two_chains=True)
                 torch.cuda.current_stream().wait_stream(self._side)
                 for net in self.model.values():
                     net.collect_deferred_grads()

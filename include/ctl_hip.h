@@ -37,8 +37,10 @@ enum ctl_status { CTL_OK = 0, CTL_EINVAL = -1, CTL_EUNSUPPORTED = -2, CTL_ELAUNC
  * 7 = the `pool` argument of ctl_conv_forward_ex (plan op CONV slot 12; CTL_OP_MAX_T 12 -> 14: sizeof(ctl_op) 304 -> 328), ctl_conv_pool_ok.
  * 8 = the `xout` argument of ctl_conv_forward_ex (plan op CONV slot 13).
  * 9 = CTL_DT_X3 / CTL_PACK_X3, ctl_conv_wpack_floats_x3, ctl_pack_weights_x3_batched; plan op PACK_BATCH i[1] is a bit mask.
- * 10 = grouped weight gradients: ctl_wgrad_group_class / ctl_wgrad_group_plan / ctl_conv_wgrad_group, plan op CTL_OP_WGRAD_GROUP. */
-#define CTL_ABI_VERSION 10
+ * 10 = grouped weight gradients: ctl_wgrad_group_class / ctl_wgrad_group_plan / ctl_conv_wgrad_group, plan op CTL_OP_WGRAD_GROUP.
+ * 11 = ctl_bn_bwd_finalize_ex (per-group gamma / beta gradient switch; plan op BN_BWD_FINALIZE i[4]); a WGRAD record with i[24] != 0 is refused
+ *      outside its WGRAD_GROUP. */
+#define CTL_ABI_VERSION 11
 int         ctl_version(void);
 const char* ctl_last_error(void);
 
@@ -249,6 +251,12 @@ int ctl_red_blocks(void);
 int ctl_bn_bwd_finalize(const float* partial, int32_t c, int64_t count, const float* gamma, const float* save_mean,
                         const float* save_invstd, float* coef, float* dgamma, float* dbeta, int32_t accumulate,
                         int32_t groups, int32_t blocks, ctl_stream stream);
+/* the same with a per-group switch for the gamma / beta gradients: bit g of `affine_groups` set = group g adds its sums (0 = every group).
+ * A launch that stacks passes of different BatchNorm modes along n (round 6: the standard pass, mode A, and the hard-example pass, mode B =
+ * gamma / beta frozen for that pass, model_util.py:414-451) clears the bits of the frozen passes; every group still gets its coefficients. */
+int ctl_bn_bwd_finalize_ex(const float* partial, int32_t c, int64_t count, const float* gamma, const float* save_mean,
+                           const float* save_invstd, float* coef, float* dgamma, float* dbeta, int32_t accumulate,
+                           int32_t groups, int32_t blocks, uint32_t affine_groups, ctl_stream stream);
 /* mode 0: ds = dout*leaky'(out) (written if ds != NULL), dv = A*ds + B*v + C;  mode 1: du = A*g + B*u + C with g = dy*leaky'(..);
  * mode 2: dy is already g (CTL_EPI_BNBWD): du = A*dy + B*u + C */
 int ctl_bwd_apply(int32_t mode, const float* dy, const float* act_src, const float* bn_src, const float* scale,
@@ -389,7 +397,9 @@ enum ctl_op_kind {
     CTL_OP_CHAN_SUM_FINALIZE = 11, CTL_OP_SUMPOOL2 = 12, CTL_OP_SIGMOID_BWD = 13, CTL_OP_ZERO = 14, CTL_OP_COPY = 15, CTL_OP_PACK_BATCH = 16,
     CTL_OP_WGRAD_REDUCE_BATCH = 17, CTL_OP_DROPOUT2D = 18, CTL_OP_BN_REPLAY = 19,
     CTL_OP_WGRAD_GROUP = 20           /* i[0] = n members (<= 8): the next n records are WGRAD records served by ONE launch (ctl_conv_wgrad_group), i[24] of each
-                                         member = its pixel splits (ctl_wgrad_group_plan); a runner that meets the members on their own may launch them singly */
+                                         member = its pixel splits (ctl_wgrad_group_plan).  The members' partial buffers and reduction records are sized for
+                                         THOSE split counts: a member record (i[24] != 0) must never be launched on its own -- ctl_plan_run refuses one that is
+                                         not preceded by its GROUP record */
 };
 #define CTL_OP_MAX_T 14
 typedef struct ctl_op {

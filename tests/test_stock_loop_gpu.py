@@ -100,7 +100,10 @@ def test_stock_loop_vs_golden_and_cooperative_step(golden_cases, golden_sd, case
         k, n = key.split("/")
         close(dict(s.model[k].named_buffers())[n].double(), b.double(), atol=2e-5, rel=1e-5, what=key)
     # the engine's fused form of the same sequence: bit for bit the same training state, over TWO consecutive iterations
+    # (with one backward per pass, as the stock loop's autograd sweep runs it; the fused step's default -- the standard and the hard pass
+    #  of a network stacked in one backward, solver.stack_passes -- changes summation orders only: tests/test_stack_gpu.py)
     ref = _solver(golden_sd)
+    ref.stack_passes = ()
     l_ref = ref.cooperative_step(clean, label, noisy, C["img_cfg"], C["seg_cfg"], image_override=ov_img, seg_override=ov_seg)
     assert torch.equal(torch.stack([v.detach().float() for v in l_ref]).cpu().double(), got)
     _assert_same_state(_state(ref), _state(s))
@@ -131,6 +134,7 @@ def test_stock_loop_at_bs16_256_vs_reference(golden_sd):
     s.optimize_all_params = orig
     T2._check_hip_step(rec, s, got, grads, grad_rtol=1e-2, yardstick=rec["grad_stats_64"], rec3=rec3, sd_before=golden_sd)
     ref = _solver(golden_sd)
+    ref.stack_passes = ()
     l_ref = ref.cooperative_step(clean, label, noisy, rec["img_cfg"], rec["seg_cfg"], image_override=ov[0], seg_override=ov[1])
     assert torch.equal(torch.stack([v.detach().float() for v in l_ref]).cpu().double(), got)
     _assert_same_state(_state(ref), _state(s))
