@@ -246,7 +246,15 @@ static int conv3_pick_cfg(const ctl_conv* d, ctl_conv_cfg* c) {
             const int64_t ntiles = (int64_t)d->n * ctl_cdiv(d->hout, th) * ctl_cdiv(d->wout, tw);
             if (ntiles * other < ctl_num_cus() && i < 2) continue;       // (a smaller tile fills more CUs)
             const int grid_x = ctl_conv_grid_x((int)ntiles, other, 1);
-            if (ntiles * c->g >= (int64_t)min_steps * grid_x) {
+            // Round 6 (tools/r6_pc_gate.py, profiles/r6_pc_conv_gate.txt: 14 layer shapes x n = 10 / 16 / 32 / 40, both forms): the one-block-per-CU
+            // pipeline needs EQUAL shares -- every block the same number of tiles, or at most one.  With 1.25 ... 3.75 tiles per block (the
+            // 40-slice inference volumes: 240 / 480 / 80 tiles over 64 / 128 blocks) the launch ends in a round that part of the chip sits out,
+            // and three resident single-role blocks per CU level that out better: 1.03-1.15x, 128 -> 128 @12^2 n40 1.50x (VERDICT r5 #3:
+            // config 5 18.9 -> 18.0 k slices/s).  Every layer of the bs16 256^2 training step has equal shares: its launches are unchanged.
+            // (Also rejecting equal shares of 2-3 tiles, which lose 2-5 % per launch in isolation, made the step 0.7 % SLOWER: 14.41 -> 14.52 ms.)
+            static const int gate = ctl_tune_int("CTL_X3_PC_GATE", 1);
+            const bool shares_ok = !gate || ntiles <= grid_x || ntiles % grid_x == 0;
+            if (shares_ok && ntiles * c->g >= (int64_t)min_steps * grid_x) {
                 c->pc = 1; c->mt = mt; c->tw = tw; c->th = th;
                 c->tiles_h = ctl_cdiv(d->hout, th); c->tiles_w = ctl_cdiv(d->wout, tw);
             }
