@@ -38,6 +38,10 @@ MASKS = {"dropout": (DROP_IMG, DROP_SEG, "dropout latent masks"),               
 PEAK_MFMA_F32_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
 PEAK_MFMA_BF16_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak
 PEAK_HBM_GBS = 8000.0
+# whole-step floors (SURVEY 8(d) / BASELINE.md section 4, ideal fusion: every conv reads its input once and writes its output once, fp32):
+# GB per slice of the full step by masking scheme; bf16 storage halves it.  flops: conv MACs x 2 per slice.
+STEP_GB_PER_SLICE = {"dropout": 2.110, "targeted": 2.209, "random": 2.176}      # random: dropout / channel / spatial with probability 1/3 each per code
+STEP_GFLOP_PER_SLICE = {"dropout": 77.9, "targeted": 83.6, "random": 81.7}
 X3_PRODUCTS = 6                  # an X3 launch (fp32 operands split exactly into three bf16 numbers, csrc/ctl_conv_x3_stage.h) issues six bf16 MFMA
                                  # products per fp32 product: its matrix-side ceiling for ALGORITHMIC flops is the bf16 peak / 6 = 416.7 TFLOP/s
 
@@ -137,6 +141,35 @@ def cpu_baseline(host_batch, threads, steps=5, warm=3, cfgs=(DROP_IMG, DROP_SEG)
     return {"value": n / med, "unit": "slices/s", "cores": threads, "kind": "port",
             "sample": f"oracle/ref_cpu.py, full cooperative step bs{n} {hw}x{hw} fp32, {threads} torch threads: {warm} warm-up + {steps} timed steps, median {med:.1f} s/step",
             "sample_detail": f"{what}; warm-up {[round(t, 1) for t in times[:warm]]} s, timed {[round(t, 1) for t in times[warm:]]} s; the reference's arithmetic"}
+
+
+def cpu_baselines_other_configs(host_batch, threads):
+    """BASELINE.md section 3 asks for CPU figures beside every config: configs[0] (bs4, standard_training step only: the reference's own
+    CPU-runnable case), the config-4 masking scheme (all three schemes randomly sampled) and the swapped config-3 pair (spatial masks on the
+    image code, channel masks on the shape code).  The oracle is the checker, timed here as the reported baseline; 1 warm-up + 3 timed steps
+    each (the headline's configs[1] figure does 3 + 5)."""
+    import random
+    from oracle import ref_cpu as O
+    from cooperative_training_and_latent_space_data_augmentation_amd.init import reference_init_state_dicts
+    torch.set_num_threads(threads)
+    clean, label, noisy = host_batch
+    out = {}
+    swapped = (dict(TGT_IMG, mask_type="spatial"), dict(TGT_SEG, mask_type="channel"))
+    for tag, n, cfgs, latent_da, what in (("config0_bs4_standard_only", 4, (None, None), False, "standard_training + backward + 5x Adam, no latent-space augmentation"),
+                                           ("config4_random_masks", clean.shape[0], (RND_IMG, RND_SEG), True, "full cooperative step, all three masking schemes randomly sampled"),
+                                           ("config3_swapped_spatial_channel", clean.shape[0], swapped, True, "full cooperative step, spatial masks on the image code + channel masks on the shape code")):
+        torch.manual_seed(0)
+        random.seed(0)
+        s = O.OracleSolver(state_dicts=reference_init_state_dicts())
+        times = []
+        for _ in range(4):
+            t0 = time.perf_counter()
+            s.cooperative_step(clean[:n], label[:n], noisy[:n], cfgs[0], cfgs[1], latent_DA=latent_da)
+            times.append(time.perf_counter() - t0)
+        med = sorted(times[1:])[1]
+        out[tag] = {"value": n / med, "unit": "slices/s", "cores": threads, "kind": "port",
+                    "sample": f"oracle/ref_cpu.py, {what}, bs{n} {clean.shape[-1]}x{clean.shape[-1]} fp32, {threads} torch threads: 1 warm-up + 3 timed steps, median {med:.2f} s/step"}
+    return out
 
 
 def _narrow(k):
@@ -661,6 +694,16 @@ def main():
             if out["roofline"]["kernel"] in t.get("kernels", {}):
                 out["roofline"]["traffic"] = t["kernels"][out["roofline"]["kernel"]]["hbm_bytes_per_launch"]
                 out["roofline"]["traffic_source"] = t["kernels"][out["roofline"]["kernel"]].get("source") or t.get("source", "profiles/kernel_traffic.json")
+        # the WHOLE step against its floor (VERDICT r5 "next" #7: `roofline` above describes one kernel, a few per cent of the time): ideal-fusion
+        # HBM bytes of the step at 8 TB/s, next to the matrix-side floor of its algorithmic flops on the pipe the contractions run on
+        gb = STEP_GB_PER_SLICE[args.masks] * args.batch * (0.5 if args.dtype == "bf16" else 1.0) * (args.size / 256.0) ** 2
+        tflop = STEP_GFLOP_PER_SLICE[args.masks] * args.batch * (args.size / 256.0) ** 2 / 1e3
+        pipe = PEAK_MFMA_BF16_TFLOPS if args.dtype == "bf16" else (PEAK_MFMA_BF16_TFLOPS / X3_PRODUCTS if x3_on else PEAK_MFMA_F32_TFLOPS)
+        hbm_ms, mfma_ms = gb / PEAK_HBM_GBS * 1e3, tflop / pipe * 1e3
+        floor = max(hbm_ms, mfma_ms)
+        out["roofline_step"] = {"bound": "hbm" if hbm_ms >= mfma_ms else "mfma", "floor_ms": floor, "frac": floor / out["ms_per_step"],
+                                "ideal_hbm_gb": gb, "hbm_floor_ms": hbm_ms, "algorithmic_tflop": tflop, "matrix_floor_ms": mfma_ms, "matrix_peak_tflops": pipe,
+                                "note": "per rank; ideal fusion = every conv reads its input once and writes its output once (SURVEY 8(d))"}
         if prof_all:
             out["roofline_families"] = family_rooflines(prof_all, args.dtype, SINGLE_STREAM_STEPS)
             out["kernels_by_serial_time"] = [{"kernel": k, "ms_per_step": v["ms"] / SINGLE_STREAM_STEPS, "launches_per_step": v["launches"] / SINGLE_STREAM_STEPS,
@@ -671,6 +714,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             cb_warm, cb_steps = (int(v) for v in args.cpu_baseline_steps.split("+"))
             out["cpu_baseline"] = cpu_baseline(host_batch, args.cpu_threads or min(32, os.cpu_count()), steps=cb_steps, warm=cb_warm, cfgs=(IMG_CFG, SEG_CFG), what=mask_text)
+        if world == 1 and not args.no_cpu_baseline and not args.no_sub_records and args.dtype == "fp32" and args.masks == "dropout":
+            out["cpu_baselines_other_configs"] = cpu_baselines_other_configs(host_batch, args.cpu_threads or min(32, os.cpu_count()))
         if world == 1 and not args.no_sub_records and args.dtype == "fp32" and args.masks == "dropout":
             # BASELINE configs[2] and configs[4], each measured by a child process running this script (a fresh process: its own
             # streams, pools and graphs; this process is idle meanwhile).  The headline keys above are untouched.
@@ -733,6 +778,9 @@ def headline(d):
         h["roofline"] = {k: r.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_us", "launches", "traffic") }
         if r.get("traffic_source"):
             h["roofline"]["traffic_source"] = str(r["traffic_source"])[:160]
+    rs = d.get("roofline_step")
+    if rs:
+        h["roofline_step"] = {k: rs.get(k) for k in ("bound", "floor_ms", "frac")}
     cb = d.get("cpu_baseline")
     if cb:
         h["cpu_baseline"] = {"value": cb.get("value"), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),

@@ -73,6 +73,16 @@ def test_bench_last_stdout_line_is_the_small_headline(tmp_path):
     assert "UserWarning" not in out.stderr, out.stderr[-2000:]
     detail = json.load(open(os.path.join(ROOT, dfile)))
     assert "roofline_families" in detail and detail["value"] == rec["value"]
+    # round 6 (VERDICT r5 "next" #7): the whole step against its floor in the line, the other configs' CPU baselines in the detail file
+    rs = rec["roofline_step"]
+    assert rs["bound"] in ("hbm", "mfma") and rs["floor_ms"] > 0 and abs(rs["frac"] - rs["floor_ms"] / rec["ms_per_step"]) < 1e-9 and 0 < rs["frac"] < 1
+    assert detail["roofline_step"]["ideal_hbm_gb"] > 0 and detail["roofline_step"]["matrix_floor_ms"] > 0
+    other = detail["cpu_baselines_other_configs"]
+    assert set(other) == {"config0_bs4_standard_only", "config4_random_masks", "config3_swapped_spatial_channel"}
+    assert all(v["value"] > 0 and v["kind"] == "port" and v["cores"] == 8 for v in other.values())
+    if rec["roofline"].get("traffic") is not None:                         # the file the figure was read from is named, and exists
+        src = rec["roofline"]["traffic_source"]
+        assert src.startswith("profiles/") and os.path.exists(os.path.join(ROOT, src.split(":")[0]))
     # the reported kernel is the arg-max of serial time over the profiling ids of the step
     assert rec["roofline"]["kernel"] == detail["kernels_by_serial_time"][0]["kernel"], (rec["roofline"], detail["kernels_by_serial_time"][:3])
     os.remove(os.path.join(ROOT, dfile))
@@ -85,7 +95,9 @@ def test_headline_with_every_sub_record_fits():
     full["config2_fp32_mfma"] = dict(full["config3_bf16"])
     full["config4_random_masks_n1"] = dict(full["config3_bf16"])
     full["roofline"]["traffic_source"] = "s" * 400
+    full["roofline_step"] = {"bound": "hbm", "floor_ms": 4.2250000000000005, "frac": 0.29153846153846157, "ideal_hbm_gb": 33.8, "note": "n" * 300}
     line = json.dumps(bench.headline(full))
+    assert set(json.loads(line)["roofline_step"]) == {"bound", "floor_ms", "frac"}
     assert len(line) < bench.HEADLINE_MAX_BYTES, len(line)
     assert json.loads(line)["config2_fp32_mfma"]["value"] == full["config3_bf16"]["value"]
 

@@ -28,4 +28,6 @@ head -24 $out/prof_fp32.txt
 if [ "$pmc" = "pmc" ]; then
   timeout 900 bash tools/pmc_bench.sh ${tag}_fp32 > $out/pmc_fp32.txt 2>&1; cp gpurun_out/pmc_bench_${tag}_fp32/traffic_by_kernel.json $out/pmc_traffic_by_kernel_fp32.json
   tail -16 $out/pmc_fp32.txt
+  timeout 900 bash tools/pmc_bench.sh ${tag}_bf16 --dtype bf16 > $out/pmc_bf16.txt 2>&1; cp gpurun_out/pmc_bench_${tag}_bf16/traffic_by_kernel.json $out/pmc_traffic_by_kernel_bf16.json
+  tail -8 $out/pmc_bf16.txt
 fi
