@@ -395,6 +395,7 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even for a world of 1")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo only for control-flow tests)")
     ap.add_argument("--all-on-device0", action="store_true", help="test aid: every rank uses GPU 0 (needs --backend gloo)")
+    ap.add_argument("--check-finite", action="store_true", help="debug aid: synchronise and check losses / weights / gradients / buffers after every step of every phase")
     args = ap.parse_args()
 
     if args.masks is None:
@@ -458,8 +459,29 @@ def main():
     hook = dp.launch_remaining if dp else None
     hook_graph = dp.sync_gradients if dp else None
 
+    check_state = {"calls": 0, "bad": None}
+
+    def check_finite(what, losses):
+        """--check-finite (debug aid, tools/debug/r6_dp_flake.sh): after EVERY step of every phase, name the first non-finite loss / weight /
+        gradient / BatchNorm buffer (a NaN otherwise only shows in the final losses, many steps and phases later)."""
+        check_state["calls"] += 1
+        if not args.check_finite or check_state["bad"]:
+            return losses
+        torch.cuda.synchronize()
+        bad = []
+        if not all(bool(torch.isfinite(v)) for v in losses):
+            bad.append("losses")
+        for k, m in solver.model.items():
+            for tag, t in (("weights", m._flat_data), ("gradient", m._flat.grad), ("bn_buffers", m._bflat)):
+                if not bool(torch.isfinite(t).all()):
+                    bad.append(f"{tag}:{k}")
+        if bad:
+            check_state["bad"] = f"rank {rank} call {check_state['calls']} ({what}, two_streams={solver.two_streams}): {bad}"
+            print("CHECK_FINITE " + check_state["bad"], file=sys.stderr, flush=True)
+        return losses
+
     def eager_step():
-        return solver.cooperative_step(clean, label, noisy, IMG_CFG, SEG_CFG, grad_hook=hook)
+        return check_finite("eager", solver.cooperative_step(clean, label, noisy, IMG_CFG, SEG_CFG, grad_hook=hook))
 
     step = eager_step
 
@@ -510,7 +532,7 @@ def main():
     if mode in ("auto", "graph", "segments"):
         try:
             gstep = CooperativeStepGraph(solver, IMG_CFG, SEG_CFG, grad_hook=hook_graph, replay="segments" if mode == "segments" else "runtime")
-            graph_step = lambda: gstep(clean, label, noisy)
+            graph_step = lambda: check_finite("graph:" + gstep.replay_mode, gstep(clean, label, noisy))
             graph_step()                                  # capture + first replay
             if args.masks == "random":                    # one captured graph per (image scheme, shape scheme) pair: capture all nine BEFORE the timed
                 for _ in range(200):                      # region (the scheme is drawn per step: a first-time pair inside it would time a capture)
