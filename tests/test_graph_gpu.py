@@ -255,3 +255,32 @@ def test_segment_replays_move_off_the_launch_streams_hardware_queue(golden_sd):
         assert q and q[0]["overlap"], q
         tried += q[0]["streams_tried"]
     assert tried >= 6
+
+
+def test_probed_side_streams_are_kept_per_launch_stream(golden_sd, monkeypatch):
+    """the queue probe of launch stream B must not replace the side stream that launch stream A was probed against (the probe used to
+    mutate one shared list and A was never re-probed).  With a probe that reports a collision for B's first candidate only: A keeps its stream,
+    B gets another one, and a replay on either launch stream uses its own."""
+    from cooperative_training_and_latent_space_data_augmentation_amd import hipgraph
+    clean, label, noisy = (dev(t) for t in O.synthetic_batch(2, 64, 64, seed=10))
+    s = _solver(golden_sd)
+    g = CooperativeStepGraph(s, CH_MSE, SP_CE, replay="segments")
+    g(clean, label, noisy)                                   # capture + first replay: the real probe for the current launch stream
+    seg = next(iter(g.entries.values())).segments
+    a = torch.cuda.current_stream()
+    side_a = list(seg._pool["side_of"][a.cuda_stream])
+    calls = []
+
+    def fake_ratio(cur, side, us=300):
+        calls.append((cur.cuda_stream, side.cuda_stream))
+        return 2.0 if len(calls) == 1 else 1.0               # "collision" for the first candidate, overlap for its replacement
+    monkeypatch.setattr(hipgraph, "streams_overlap_ratio", fake_ratio)
+    b = torch.cuda.Stream()
+    seg.prepare(b)
+    side_b = seg._pool["side_of"][b.cuda_stream]
+    assert len(calls) == 2 and calls[0][0] == b.cuda_stream
+    assert [x.cuda_stream for x in seg._pool["side_of"][a.cuda_stream]] == [x.cuda_stream for x in side_a], "A's probed stream was replaced"
+    assert side_b[0].cuda_stream != side_a[0].cuda_stream
+    monkeypatch.undo()
+    la = torch.stack([v.detach().float() for v in g(clean, label, noisy)]).cpu()
+    assert torch.isfinite(la).all()
